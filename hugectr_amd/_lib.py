@@ -1,0 +1,126 @@
+"""ctypes binding of the C ABI in include/hugectr_amd.h (libhugectr_amd.so, gfx950 only).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing fails loudly.
+Nothing here touches oracle/ (the CPU oracle is test infrastructure only).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhugectr_amd.so")
+
+# enums (include/hugectr_amd.h)
+OPT_FTRL, OPT_ADAM, OPT_RMSPROP, OPT_ADAGRAD, OPT_NESTEROV, OPT_MOMENTUM_SGD, OPT_SGD = range(7)
+UPDATE_LOCAL, UPDATE_GLOBAL, UPDATE_LAZY_GLOBAL = range(3)
+EMB_DISTRIBUTED, EMB_LOCALIZED = 0, 1
+KEY_U32, KEY_I64 = 0, 1
+F32, F16, BF16 = 0, 1, 2
+
+
+class EmbeddingParams(Structure):
+    """hctr_embedding_params"""
+    _fields_ = [
+        ("embedding_type", c_int), ("key_type", c_int), ("out_dtype", c_int),
+        ("train_batch_size", c_size_t), ("evaluate_batch_size", c_size_t),
+        ("max_vocabulary_size_per_gpu", c_size_t), ("embedding_vec_size", c_size_t),
+        ("max_feature_num", c_size_t), ("slot_num", c_size_t), ("combiner", c_int),
+        ("slot_size_array", POINTER(c_size_t)),
+        ("optimizer", c_int), ("update_type", c_int), ("lr", c_float),
+        ("beta1", c_float), ("beta2", c_float), ("epsilon", c_float),
+        ("initial_accu_value", c_float), ("momentum_factor", c_float), ("atomic_update", c_int),
+        ("scaler", c_float), ("rank", c_int), ("world", c_int), ("seed", c_uint64),
+    ]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "hctr_last_error": (c_char_p, []),
+    "hctr_version": (c_int, []),
+    "hctr_hash_keys": (c_int, [_P, c_int, c_size_t, _P, _P]),
+    "hctr_ht_create": (c_int, [c_size_t, c_int, POINTER(_P)]),
+    "hctr_ht_destroy": (c_int, [_P]),
+    "hctr_ht_clear": (c_int, [_P, _P]),
+    "hctr_ht_get_insert": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "hctr_ht_get_mark": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "hctr_ht_insert": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "hctr_ht_size": (c_int, [_P, _P, POINTER(c_size_t)]),
+    "hctr_ht_value_head": (c_int, [_P, _P, POINTER(c_size_t)]),
+    "hctr_ht_set_value_head": (c_int, [_P, c_size_t, _P]),
+    "hctr_ht_table_size": (c_size_t, [_P]),
+    "hctr_ht_dump": (c_int, [_P, _P, _P, POINTER(c_size_t), _P]),
+    "hctr_forward_pool": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_forward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "hctr_backward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "hctr_emb_create": (c_int, [POINTER(EmbeddingParams), POINTER(_P)]),
+    "hctr_emb_destroy": (c_int, [_P]),
+    "hctr_emb_init_params": (c_int, [_P, _P]),
+    "hctr_emb_forward": (c_int, [_P, c_int, _P, _P, c_size_t, _P, _P]),
+    "hctr_emb_backward": (c_int, [_P, _P, _P]),
+    "hctr_emb_get_wgrad": (c_int, [_P, _P, _P]),
+    "hctr_emb_update_params": (c_int, [_P, _P]),
+    "hctr_emb_set_learning_rate": (c_int, [_P, c_float]),
+    "hctr_emb_get_vocabulary_size": (c_int, [_P, _P, POINTER(c_size_t)]),
+    "hctr_emb_get_max_vocabulary_size": (c_size_t, [_P]),
+    "hctr_emb_slots_on_rank": (c_size_t, [_P]),
+    "hctr_emb_check_overflow": (c_int, [_P, _P]),
+    "hctr_emb_dump": (c_int, [_P, _P, _P, _P, POINTER(c_size_t), _P]),
+    "hctr_emb_load": (c_int, [_P, _P, _P, _P, c_size_t, _P]),
+    "hctr_emb_table_ptr": (_P, [_P]),
+    "hctr_emb_opt_state_ptr": (_P, [_P, c_int]),
+    "hctr_emb_value_index_ptr": (_P, [_P]),
+    "hctr_emb_reset": (c_int, [_P, _P]),
+    "hctr_interaction_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_interaction_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
+    "hctr_cross_v1_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "hctr_cross_v1_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hctr_cross_v1_bwd_workspace_bytes": (c_size_t, [c_size_t, c_int, c_int]),
+    "hctr_cross_v2_epilogue": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+class HugeCTRAmdError(RuntimeError):
+    """The reference surfaces C++ exceptions as Python RuntimeError; so do we."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    msg = lib.hctr_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise HugeCTRAmdError(f"hugectr_amd error {rc}: {last_error()}")
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """current torch HIP stream as hipStream_t."""
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,109 @@
+// common.h -- shared host/device helpers for libhugectr_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <string>
+
+#include "../../include/hugectr_amd.h"
+
+namespace hctr {
+
+void set_error(const std::string& msg);
+
+constexpr int kWave = 64;  // CDNA wavefront
+constexpr uint64_t kInvalidIndex = ~0ull;  // std::numeric_limits<size_t>::max()
+
+#define HCTR_HIP(call)                                                                   \
+  do {                                                                                   \
+    hipError_t e__ = (call);                                                             \
+    if (e__ != hipSuccess) {                                                             \
+      ::hctr::set_error(std::string(#call) + ": " + hipGetErrorString(e__) + " at " +    \
+                        __FILE__ + ":" + std::to_string(__LINE__));                      \
+      return HCTR_ERR_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
+#define HCTR_LAUNCH_CHECK() HCTR_HIP(hipGetLastError())
+
+#define HCTR_REQUIRE(cond, msg)                                          \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      ::hctr::set_error(std::string("invalid argument: ") + (msg));      \
+      return HCTR_ERR_INVALID_ARG;                                       \
+    }                                                                    \
+  } while (0)
+
+#define HCTR_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != HCTR_OK) return rc__; \
+  } while (0)
+
+template <typename T>
+static inline T ceil_div(T a, T b) {
+  return (a + b - 1) / b;
+}
+
+static inline hipStream_t as_stream(hctr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// grid cap for grid-stride memory-bound kernels: 256 CUs x 8 blocks
+constexpr int kMaxGrid = 2048;
+
+static inline int grid_for(size_t work_items, int block, int cap = kMaxGrid) {
+  size_t g = ceil_div<size_t>(work_items, (size_t)block);
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+// key-type traits: the reference instantiates <unsigned int> and <long long>
+template <typename K>
+struct KeyTraits;
+template <>
+struct KeyTraits<uint32_t> {
+  static constexpr int64_t empty = 0xFFFFFFFFll;
+  static constexpr int bytes = 4;
+};
+template <>
+struct KeyTraits<long long> {
+  static constexpr int64_t empty = INT64_MAX;
+  static constexpr int bytes = 8;
+};
+
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) {
+  return (x << r) | (x >> (32 - r));
+}
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+// MurmurHash3_x86_32, seed 0, over the 4 or 8 key bytes
+// (R/HugeCTR/include/hashtable/cudf/hash_functions.cuh:66-107)
+__host__ __device__ __forceinline__ uint32_t murmur3_block(uint32_t h1, uint32_t k1) {
+  k1 *= 0xcc9e2d51u;
+  k1 = rotl32(k1, 15);
+  k1 *= 0x1b873593u;
+  h1 ^= k1;
+  h1 = rotl32(h1, 13);
+  return h1 * 5u + 0xe6546b64u;
+}
+__host__ __device__ __forceinline__ uint32_t murmur3_key(uint32_t key) {
+  uint32_t h1 = murmur3_block(0u, key);
+  h1 ^= 4u;
+  return fmix32(h1);
+}
+__host__ __device__ __forceinline__ uint32_t murmur3_key(long long key) {
+  const uint64_t u = (uint64_t)key;
+  uint32_t h1 = murmur3_block(0u, (uint32_t)(u & 0xFFFFFFFFull));
+  h1 = murmur3_block(h1, (uint32_t)(u >> 32));
+  h1 ^= 8u;
+  return fmix32(h1);
+}
+
+}  // namespace hctr

@@ -1,0 +1,300 @@
+// embedding_kernels.hip -- gather + intra-slot pooling forward, and the all-to-all reorder maps.
+//
+// forward_sum / forward_mean semantics: R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:28-241
+// (fp32 accumulate in key order j = 0..n-1; SIZE_MAX row index contributes 0; mean multiplies by
+// 1.0f/n when n > 1).  The reference launches one block per SAMPLE with D threads that walk the
+// slots serially; here a "group" of D/4 lanes owns BU buckets at a time, each lane moving 16 B,
+// so a wavefront keeps 64/(D/4) * BU independent row reads in flight and every row read/write is
+// a fully coalesced D*4-byte segment.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename OutT>
+struct Store4;
+template <>
+struct Store4<float> {
+  __device__ __forceinline__ static void st(float* p, float4 v) {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+  __device__ __forceinline__ static void st1(float* p, float v) { *p = v; }
+};
+template <>
+struct Store4<__half> {
+  __device__ __forceinline__ static void st(__half* p, float4 v) {
+    __half2 a = __float22half2_rn(make_float2(v.x, v.y));
+    __half2 b = __float22half2_rn(make_float2(v.z, v.w));
+    uint2 u;
+    u.x = *reinterpret_cast<uint32_t*>(&a);
+    u.y = *reinterpret_cast<uint32_t*>(&b);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+  __device__ __forceinline__ static void st1(__half* p, float v) { *p = __float2half_rn(v); }
+};
+template <>
+struct Store4<__hip_bfloat16> {
+  __device__ __forceinline__ static void st(__hip_bfloat16* p, float4 v) {
+    __hip_bfloat16 a = __float2bfloat16(v.x), b = __float2bfloat16(v.y);
+    __hip_bfloat16 c = __float2bfloat16(v.z), d = __float2bfloat16(v.w);
+    uint2 u;
+    u.x = (uint32_t) * reinterpret_cast<uint16_t*>(&a) |
+          ((uint32_t) * reinterpret_cast<uint16_t*>(&b) << 16);
+    u.y = (uint32_t) * reinterpret_cast<uint16_t*>(&c) |
+          ((uint32_t) * reinterpret_cast<uint16_t*>(&d) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+  }
+  __device__ __forceinline__ static void st1(__hip_bfloat16* p, float v) {
+    *p = __float2bfloat16(v);
+  }
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+
+// LPR lanes per row (D = 4*LPR), BU buckets per group per iteration.
+template <int LPR, int BU, typename OffT, typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    pool_vec4_kernel(size_t buckets, int combiner, const OffT* __restrict__ row_offset,
+                     const uint64_t* __restrict__ value_index, const float* __restrict__ table,
+                     OutT* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;  // groups per block
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const size_t stride = (size_t)gridDim.x * GPB * BU;
+  for (size_t u0 = ((size_t)blockIdx.x * GPB + g) * BU; u0 < buckets; u0 += stride) {
+    long long off[BU];
+    int n[BU];
+    uint64_t idx0[BU];
+    float4 acc[BU];
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      const size_t u = u0 + k;
+      if (u < buckets) {
+        off[k] = (long long)row_offset[u];
+        n[k] = (int)((long long)row_offset[u + 1] - off[k]);
+      } else {
+        off[k] = 0;
+        n[k] = 0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BU; k++) idx0[k] = (n[k] > 0) ? value_index[off[k]] : kInvalidIndex;
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx0[k] != kInvalidIndex) r = ld4(table + idx0[k] * (uint64_t)D + l * 4);
+      // sum starts at 0.0f and adds in key order, as the reference does
+      acc[k] = make_float4(0.f + r.x, 0.f + r.y, 0.f + r.z, 0.f + r.w);
+    }
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      for (int j = 1; j < n[k]; j++) {
+        const uint64_t idx = value_index[off[k] + j];
+        if (idx != kInvalidIndex) {
+          float4 r = ld4(table + idx * (uint64_t)D + l * 4);
+          acc[k].x += r.x;
+          acc[k].y += r.y;
+          acc[k].z += r.z;
+          acc[k].w += r.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      const size_t u = u0 + k;
+      if (u < buckets) {
+        float4 v = acc[k];
+        if (combiner == 1 && n[k] > 1) {
+          const float sc = 1.0f / (float)n[k];
+          v.x *= sc;
+          v.y *= sc;
+          v.z *= sc;
+          v.w *= sc;
+        }
+        Store4<OutT>::st(out + u * (size_t)D + l * 4, v);
+      }
+    }
+  }
+}
+
+// any embedding_vec_size: one wavefront per bucket, lanes stride over the vector
+template <typename OffT, typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    pool_generic_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
+                        const uint64_t* __restrict__ value_index, const float* __restrict__ table,
+                        OutT* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = (long long)row_offset[u];
+    const int n = (int)((long long)row_offset[u + 1] - off);
+    const float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    for (int v = lane; v < D; v += 64) {
+      float sum = 0.0f;
+      for (int j = 0; j < n; j++) {
+        const uint64_t idx = value_index[off + j];
+        sum += (idx != kInvalidIndex) ? table[idx * (uint64_t)D + v] : 0.0f;
+      }
+      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? sum * sc : sum);
+    }
+  }
+}
+
+template <typename OffT, typename OutT>
+int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint64_t* vi,
+                const float* table, OutT* out, hipStream_t s) {
+#define HCTR_POOL_CASE(LPR_, BU_)                                                              \
+  {                                                                                            \
+    constexpr int GPB = kBlock / LPR_;                                                         \
+    const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)BU_), GPB, 256 * 8);          \
+    hipLaunchKernelGGL((pool_vec4_kernel<LPR_, BU_, OffT, OutT>), dim3(grid), dim3(kBlock), 0, \
+                       s, buckets, combiner, ro, vi, table, out);                              \
+  }
+  const bool aligned = (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
+                       (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  if (aligned && D % 4 == 0) {
+    switch (D / 4) {
+      case 1: HCTR_POOL_CASE(1, 4) break;
+      case 2: HCTR_POOL_CASE(2, 4) break;
+      case 4: HCTR_POOL_CASE(4, 4) break;
+      case 8: HCTR_POOL_CASE(8, 4) break;
+      case 16: HCTR_POOL_CASE(16, 4) break;
+      case 32: HCTR_POOL_CASE(32, 4) break;
+      case 64: HCTR_POOL_CASE(64, 4) break;
+      default: {
+        const int grid = grid_for(buckets * 64, kBlock);
+        hipLaunchKernelGGL((pool_generic_kernel<OffT, OutT>), dim3(grid), dim3(kBlock), 0, s,
+                           buckets, D, combiner, ro, vi, table, out);
+      }
+    }
+  } else {
+    const int grid = grid_for(buckets * 64, kBlock);
+    hipLaunchKernelGGL((pool_generic_kernel<OffT, OutT>), dim3(grid), dim3(kBlock), 0, s, buckets,
+                       D, combiner, ro, vi, table, out);
+  }
+#undef HCTR_POOL_CASE
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+// ---- reorder ---------------------------------------------------------------------------------
+// FWD: out[b][s][:] = in[(offset_pre(g) + b*spg(g) + s/N)][:], g = s % N
+// (forward_reorder_functor.cu:43-57); BWD is the inverse map.
+template <typename T, bool FWD>
+__global__ void __launch_bounds__(kBlock)
+    reorder_kernel(size_t bpg, int S, int D, int N, const T* __restrict__ in,
+                   T* __restrict__ out) {
+  const size_t total = bpg * (size_t)S * (size_t)D;
+  const int q = S / N, rem = S % N;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const int d = (int)(i % D);
+    const size_t bs = i / D;
+    const int s = (int)(bs % S);
+    const size_t b = bs / S;
+    const int g = s % N;
+    const int spg = q + (g < rem ? 1 : 0);
+    const size_t offset_pre = bpg * ((size_t)g * q + (size_t)(g < rem ? g : rem));
+    const size_t a2a = (offset_pre + b * spg + (size_t)(s / N)) * D + d;
+    if (FWD) out[i] = in[a2a];
+    else out[a2a] = in[i];
+  }
+}
+
+template <bool FWD>
+int launch_reorder(size_t bpg, int S, int D, int N, const void* in, void* out, int dtype,
+                   hipStream_t s) {
+  if (bpg == 0 || S == 0) return HCTR_OK;
+  const int esz = (dtype == HCTR_EMB_F32) ? 4 : 2;
+  const size_t row_bytes = (size_t)D * esz;
+  const bool a16 = row_bytes % 16 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (a16) {
+    const int D16 = (int)(row_bytes / 16);
+    const size_t total = bpg * (size_t)S * D16;
+    hipLaunchKernelGGL((reorder_kernel<float4, FWD>), dim3(grid_for(total, kBlock)), dim3(kBlock),
+                       0, s, bpg, S, D16, N, (const float4*)in, (float4*)out);
+  } else if (esz == 4) {
+    const size_t total = bpg * (size_t)S * D;
+    hipLaunchKernelGGL((reorder_kernel<float, FWD>), dim3(grid_for(total, kBlock)), dim3(kBlock),
+                       0, s, bpg, S, D, N, (const float*)in, (float*)out);
+  } else {
+    const size_t total = bpg * (size_t)S * D;
+    hipLaunchKernelGGL((reorder_kernel<uint16_t, FWD>), dim3(grid_for(total, kBlock)),
+                       dim3(kBlock), 0, s, bpg, S, D, N, (const uint16_t*)in, (uint16_t*)out);
+  }
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+}  // namespace
+
+int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
+                          const uint64_t* vi, const float* table, void* out, int out_dtype,
+                          hipStream_t s) {
+  if (buckets == 0) return HCTR_OK;
+#define HCTR_POOL_OUT(OffT)                                                                       \
+  switch (out_dtype) {                                                                            \
+    case HCTR_EMB_F32:                                                                            \
+      return launch_pool<OffT, float>(buckets, D, combiner, (const OffT*)ro, vi, table,           \
+                                      (float*)out, s);                                            \
+    case HCTR_EMB_F16:                                                                            \
+      return launch_pool<OffT, __half>(buckets, D, combiner, (const OffT*)ro, vi, table,          \
+                                       (__half*)out, s);                                          \
+    case HCTR_EMB_BF16:                                                                           \
+      return launch_pool<OffT, __hip_bfloat16>(buckets, D, combiner, (const OffT*)ro, vi, table,  \
+                                               (__hip_bfloat16*)out, s);                          \
+    default:                                                                                      \
+      set_error("out_dtype");                                                                     \
+      return HCTR_ERR_INVALID_ARG;                                                                \
+  }
+  if (key_type == HCTR_KEY_U32) {
+    HCTR_POOL_OUT(uint32_t)
+  } else if (key_type == HCTR_KEY_I64) {
+    HCTR_POOL_OUT(long long)
+  }
+#undef HCTR_POOL_OUT
+  set_error("key_type");
+  return HCTR_ERR_INVALID_ARG;
+}
+
+}  // namespace hctr
+
+using namespace hctr;
+
+extern "C" {
+
+int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                      int key_type, const uint64_t* value_index, const float* table, void* out,
+                      int out_dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
+  return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
+                               table, out, out_dtype, as_stream(stream));
+}
+
+int hctr_forward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,
+                         const void* in, void* out, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(gpu_num > 0 && slot_num >= 0 && vec_size > 0, "shape");
+  return launch_reorder<true>(batch_per_gpu, slot_num, vec_size, gpu_num, in, out, dtype,
+                              as_stream(stream));
+}
+
+int hctr_backward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,
+                          const void* in, void* out, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(gpu_num > 0 && slot_num >= 0 && vec_size > 0, "shape");
+  return launch_reorder<false>(batch_per_gpu, slot_num, vec_size, gpu_num, in, out, dtype,
+                               as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,51 @@
+// hashtable.h -- device open-addressing key -> row-index map (internal C++ view).
+// Replaces HashTable<Key,size_t> (R/HugeCTR/include/hashtable/nv_hashtable.hpp:31-189).
+#pragma once
+#include "common.h"
+
+namespace hctr {
+
+struct HtEntry {
+  long long key;           // u32 keys are zero-extended; empty = KeyTraits<K>::empty
+  unsigned long long val;  // row index; kInvalidIndex = unused
+};
+
+constexpr uint64_t kPendingBit = 1ull << 63;
+constexpr int kHtTile = 1024;  // positions per compaction tile
+
+struct HashTable {
+  HtEntry* entries = nullptr;
+  uint64_t size = 0;      // physical slots = (size_t)(capacity / 0.75f)
+  uint64_t capacity = 0;  // max_vocabulary_size_per_gpu
+  int key_type = HCTR_KEY_I64;
+  // device scalars
+  uint64_t* d_counter = nullptr;    // value head (next row index)
+  uint64_t* d_base = nullptr;       // counter snapshot used by the current get_insert
+  uint32_t* d_pending = nullptr;    // != 0 when the current batch holds unseen keys
+  uint32_t* d_error = nullptr;      // bit0: probe overflow (table full) bit1: counter > capacity
+  uint64_t* d_new_count = nullptr;  // number of keys inserted by the last get_insert
+  // scratch sized for max_n positions
+  size_t max_n = 0;
+  uint32_t* tile_sums = nullptr;   // [ceil(max_n / kHtTile) + 1]
+  uint64_t* new_positions = nullptr;  // [max_n] positions (into keys) of newly inserted keys
+  uint64_t* d_scratch64 = nullptr;  // 1 element
+
+  int create(size_t capacity, int key_type);
+  int destroy();
+  int clear(hipStream_t s);
+  int reserve(size_t n);  // scratch for batches up to n keys
+  int get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s);
+  int get_mark(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s);
+  int insert(const void* keys, const uint64_t* vals, size_t n, hipStream_t s);
+  int count(hipStream_t s, size_t* out);
+  int value_head(hipStream_t s, size_t* out);
+  int set_value_head(size_t v, hipStream_t s);
+  int dump(int64_t* d_keys, uint64_t* d_vals, size_t* count, hipStream_t s);
+  int error_flags(hipStream_t s, uint32_t* out);
+};
+
+}  // namespace hctr
+
+struct hctr_hashtable {
+  hctr::HashTable impl;
+};

@@ -1,0 +1,574 @@
+// hashtable.hip -- deterministic open-addressing hash map on gfx950.
+//
+// Semantics follow R/HugeCTR/src/hashtable/nv_hashtable.cu:169-303 +
+// R/HugeCTR/include/hashtable/cudf/concurrent_unordered_map.cuh:562-655:
+//   slots = (size_t)(capacity / 0.75f), slot = MurmurHash3_32(key) % slots, linear probing,
+//   empty key = max(Key), unused value = SIZE_MAX, get_mark miss -> SIZE_MAX.
+// Difference by design: the reference hands out row indices with a racing
+// atomicAdd; here a new key's index is counter + (rank of its FIRST occurrence among the new
+// keys of the batch), i.e. exactly what a sequential insert in array order produces.
+//
+// get_insert is 5 launches; in steady state (no unseen key) launches 2-5 exit on one scalar load:
+//   A probe_insert : find/claim slot (CAS on key); known key -> index; unseen -> atomicMin of
+//                    (PENDING | position) into the slot value, out = PENDING | slot
+//   B flag_count   : flag positions that are the first occurrence of an unseen key, per-tile count
+//   S scan_tiles   : single-workgroup exclusive scan of tile counts, counter bump
+//   D1 assign      : first occurrences get counter_base + rank, written to slot + out
+//   D2 resolve     : remaining occurrences read the now-final slot value
+#include "hashtable.h"
+
+#include "block_prims.h"
+
+namespace hctr {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename K>
+__device__ __forceinline__ long long widen(K k) {
+  return (long long)k;
+}
+template <>
+__device__ __forceinline__ long long widen<uint32_t>(uint32_t k) {
+  return (long long)(unsigned long long)k;
+}
+
+__device__ __forceinline__ size_t live_count(const uint64_t* d_n, size_t n) {
+  if (d_n == nullptr) return n;
+  uint64_t v = *d_n;
+  return v < n ? (size_t)v : n;
+}
+
+__global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    e[i].key = empty;
+    e[i].val = kInvalidIndex;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
+                           size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
+                           uint32_t* d_pending, uint32_t* d_error) {
+  const size_t nl = live_count(d_n, n);
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
+       i += (size_t)gridDim.x * kBlock) {
+    const K key = keys[i];
+    const long long k64 = widen<K>(key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    bool ok = false;
+    for (uint64_t probes = 0; probes < size; ++probes) {
+      long long cur = tab[slot].key;
+      if (cur == k64) {
+        ok = true;
+        break;
+      }
+      if (cur == empty) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot].key),
+                                           (unsigned long long)empty, (unsigned long long)k64);
+        if (old == (unsigned long long)empty || old == (unsigned long long)k64) {
+          ok = true;
+          break;
+        }
+      }
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+    if (!ok) {
+      atomicOr(d_error, 1u);
+      out[i] = kInvalidIndex;
+      continue;
+    }
+    unsigned long long v = tab[slot].val;
+    if (v < kPendingBit) {
+      out[i] = v;
+    } else {
+      atomicMin(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
+      out[i] = kPendingBit | slot;
+      *d_pending = 1u;  // benign race: all writers store 1
+    }
+  }
+}
+
+__device__ __forceinline__ bool is_first_occurrence(const HtEntry* tab, uint64_t o, size_t i) {
+  if (o < kPendingBit || o == kInvalidIndex) return false;
+  return tab[o & ~kPendingBit].val == (kPendingBit | (uint64_t)i);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    ht_flag_count_kernel(const HtEntry* __restrict__ tab, const uint64_t* __restrict__ out,
+                         size_t n, const uint64_t* d_n, const uint32_t* d_pending,
+                         uint32_t* __restrict__ tile_sums, size_t n_tiles) {
+  if (*d_pending == 0u) return;
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nl = live_count(d_n, n);
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kHtTile / kBlock; r++) {
+      size_t i = tile * kHtTile + r * kBlock + threadIdx.x;
+      if (i < nl) c += is_first_occurrence(tab, out[i], i) ? 1u : 0u;
+    }
+    uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
+}
+
+// single workgroup: exclusive scan of sums[0..m) in place, total -> *d_total (uint64)
+__global__ void __launch_bounds__(1024)
+    scan_tiles_kernel(uint32_t* sums, size_t m, const uint32_t* d_gate, uint64_t* d_total) {
+  if (d_gate != nullptr && *d_gate == 0u) {
+    if (threadIdx.x == 0) *d_total = 0;
+    return;
+  }
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < m; base += 1024) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = (i < m) ? sums[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<uint32_t, 1024>(v, smem, &tot);
+    uint64_t c = carry;
+    // tile counts are bounded by n <= 2^32 positions per batch in practice; keep 32-bit offsets
+    if (i < m) sums[i] = (uint32_t)(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = carry;
+}
+
+__global__ void ht_bump_counter_kernel(const uint32_t* d_pending, uint64_t* d_counter,
+                                       uint64_t* d_base, const uint64_t* d_new_count,
+                                       uint64_t capacity, uint32_t* d_error) {
+  uint64_t c = *d_counter;
+  *d_base = c;
+  if (*d_pending == 0u) return;
+  c += *d_new_count;
+  *d_counter = c;
+  if (c > capacity) atomicOr(d_error, 2u);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    ht_assign_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
+                     const uint64_t* d_n, const uint32_t* d_pending,
+                     const uint32_t* __restrict__ tile_sums, size_t n_tiles,
+                     const uint64_t* d_base, uint64_t* __restrict__ new_positions) {
+  if (*d_pending == 0u) return;
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nl = live_count(d_n, n);
+  const uint64_t base = *d_base;
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t run = tile_sums[tile];
+#pragma unroll
+    for (int r = 0; r < kHtTile / kBlock; r++) {
+      size_t i = tile * kHtTile + r * kBlock + threadIdx.x;
+      uint64_t o = (i < nl) ? out[i] : 0;
+      bool f = (i < nl) && is_first_occurrence(tab, o, i);
+      uint32_t tot;
+      uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
+      if (f) {
+        uint64_t rank = (uint64_t)run + ex;
+        uint64_t fin = base + rank;
+        tab[o & ~kPendingBit].val = fin;
+        out[i] = fin;
+        new_positions[rank] = (uint64_t)i;
+      }
+      run += tot;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    ht_resolve_kernel(const HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
+                      const uint64_t* d_n, const uint32_t* d_pending) {
+  if (*d_pending == 0u) return;
+  const size_t nl = live_count(d_n, n);
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
+       i += (size_t)gridDim.x * kBlock) {
+    uint64_t o = out[i];
+    if (o >= kPendingBit && o != kInvalidIndex) out[i] = tab[o & ~kPendingBit].val;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ht_find_kernel(const HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
+                   size_t n, const uint64_t* d_n, uint64_t* __restrict__ out) {
+  const size_t nl = live_count(d_n, n);
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
+       i += (size_t)gridDim.x * kBlock) {
+    const K key = keys[i];
+    const long long k64 = widen<K>(key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    uint64_t res = kInvalidIndex;
+    for (uint64_t probes = 0; probes <= size; ++probes) {
+      long long cur = tab[slot].key;
+      if (cur == k64) {
+        res = tab[slot].val;
+        break;
+      }
+      if (cur == empty) break;
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+    out[i] = res;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ht_insert_pairs_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
+                           const uint64_t* __restrict__ vals, size_t n, uint32_t* d_error) {
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const K key = keys[i];
+    const long long k64 = widen<K>(key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    bool ok = false;
+    for (uint64_t probes = 0; probes < size; ++probes) {
+      long long cur = tab[slot].key;
+      if (cur == k64) {
+        ok = true;
+        break;
+      }
+      if (cur == empty) {
+        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot].key),
+                                           (unsigned long long)empty, (unsigned long long)k64);
+        if (old == (unsigned long long)empty || old == (unsigned long long)k64) {
+          ok = true;
+          break;
+        }
+      }
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+    if (ok) tab[slot].val = vals[i];
+    else atomicOr(d_error, 1u);
+  }
+}
+
+// occupied-slot compaction (size_kernel / dump_kernel, nv_hashtable.cu:116-163), physical order
+__global__ void __launch_bounds__(kBlock)
+    ht_occupied_count_kernel(const HtEntry* __restrict__ tab, uint64_t size, long long empty,
+                             uint32_t* __restrict__ tile_sums, size_t n_tiles) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kHtTile / kBlock; r++) {
+      uint64_t i = tile * (uint64_t)kHtTile + r * kBlock + threadIdx.x;
+      if (i < size) c += (tab[i].key != empty) ? 1u : 0u;
+    }
+    uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    ht_dump_kernel(const HtEntry* __restrict__ tab, uint64_t size, long long empty,
+                   const uint32_t* __restrict__ tile_sums, size_t n_tiles,
+                   int64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t run = tile_sums[tile];
+#pragma unroll
+    for (int r = 0; r < kHtTile / kBlock; r++) {
+      uint64_t i = tile * (uint64_t)kHtTile + r * kBlock + threadIdx.x;
+      HtEntry e;
+      bool f = false;
+      if (i < size) {
+        e = tab[i];
+        f = e.key != empty;
+      }
+      uint32_t tot;
+      uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
+      if (f) {
+        keys[run + ex] = e.key;
+        vals[run + ex] = e.val;
+      }
+      run += tot;
+    }
+  }
+}
+
+template <typename K>
+__global__ void hash_keys_kernel(const K* keys, size_t n, uint32_t* out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    out[i] = murmur3_key(keys[i]);
+}
+
+}  // namespace
+
+int HashTable::create(size_t cap, int kt) {
+  HCTR_REQUIRE(kt == HCTR_KEY_U32 || kt == HCTR_KEY_I64, "key_type");
+  HCTR_REQUIRE(cap > 0, "capacity must be > 0");
+  capacity = cap;
+  key_type = kt;
+  // static_cast<size_t>(capacity / LOAD_FACTOR), LOAD_FACTOR = 0.75f (float division)
+  size = (uint64_t)((float)cap / 0.75f);
+  if (size == 0) size = 1;
+  HCTR_HIP(hipMalloc(&entries, size * sizeof(HtEntry)));
+  uint64_t* scal = nullptr;
+  HCTR_HIP(hipMalloc(&scal, 64));
+  d_counter = scal;
+  d_base = scal + 1;
+  d_new_count = scal + 2;
+  d_scratch64 = scal + 3;
+  d_pending = reinterpret_cast<uint32_t*>(scal + 4);
+  d_error = reinterpret_cast<uint32_t*>(scal + 4) + 1;
+  HCTR_HIP(hipMemset(scal, 0, 64));
+  return clear(nullptr);
+}
+
+int HashTable::destroy() {
+  if (entries) (void)hipFree(entries);
+  if (d_counter) (void)hipFree(d_counter);
+  if (tile_sums) (void)hipFree(tile_sums);
+  if (new_positions) (void)hipFree(new_positions);
+  entries = nullptr;
+  d_counter = nullptr;
+  tile_sums = nullptr;
+  new_positions = nullptr;
+  return HCTR_OK;
+}
+
+int HashTable::clear(hipStream_t s) {
+  const long long empty =
+      key_type == HCTR_KEY_U32 ? KeyTraits<uint32_t>::empty : KeyTraits<long long>::empty;
+  hipLaunchKernelGGL(ht_init_kernel, dim3(grid_for(size, 256, 8192)), dim3(256), 0, s, entries,
+                     size, empty);
+  HCTR_LAUNCH_CHECK();
+  HCTR_HIP(hipMemsetAsync(d_counter, 0, 64, s));
+  return HCTR_OK;
+}
+
+int HashTable::reserve(size_t n) {
+  // scratch must also cover a dump over `size` slots
+  size_t need_tiles = ceil_div<size_t>(n > size ? n : size, kHtTile) + 1;
+  if (n <= max_n && tile_sums != nullptr) return HCTR_OK;
+  if (tile_sums) (void)hipFree(tile_sums);
+  if (new_positions) (void)hipFree(new_positions);
+  HCTR_HIP(hipMalloc(&tile_sums, need_tiles * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&new_positions, (n > 0 ? n : 1) * sizeof(uint64_t)));
+  max_n = n;
+  return HCTR_OK;
+}
+
+int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out,
+                          hipStream_t s) {
+  if (n == 0) return HCTR_OK;
+  HCTR_TRY(reserve(n));
+  HCTR_HIP(hipMemsetAsync(d_pending, 0, sizeof(uint32_t), s));
+  const int grid = grid_for(n, kBlock);
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
+                       size, (const uint32_t*)keys, n, d_n, out, d_pending, d_error);
+  } else {
+    hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
+                       size, (const long long*)keys, n, d_n, out, d_pending, d_error);
+  }
+  HCTR_LAUNCH_CHECK();
+  const size_t n_tiles = ceil_div<size_t>(n, kHtTile);
+  const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+  hipLaunchKernelGGL(ht_flag_count_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
+                     d_pending, tile_sums, n_tiles);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, tile_sums, n_tiles, d_pending,
+                     d_new_count);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ht_bump_counter_kernel, dim3(1), dim3(1), 0, s, d_pending, d_counter, d_base,
+                     d_new_count, capacity, d_error);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ht_assign_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
+                     d_pending, tile_sums, n_tiles, d_base, new_positions);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ht_resolve_kernel, dim3(grid), dim3(kBlock), 0, s, entries, out, n, d_n,
+                     d_pending);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int HashTable::get_mark(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out,
+                        hipStream_t s) {
+  if (n == 0) return HCTR_OK;
+  const int grid = grid_for(n, kBlock);
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(ht_find_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries, size,
+                       (const uint32_t*)keys, n, d_n, out);
+  } else {
+    hipLaunchKernelGGL(ht_find_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries, size,
+                       (const long long*)keys, n, d_n, out);
+  }
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int HashTable::insert(const void* keys, const uint64_t* vals, size_t n, hipStream_t s) {
+  if (n == 0) return HCTR_OK;
+  const int grid = grid_for(n, kBlock);
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(ht_insert_pairs_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
+                       size, (const uint32_t*)keys, vals, n, d_error);
+  } else {
+    hipLaunchKernelGGL(ht_insert_pairs_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
+                       size, (const long long*)keys, vals, n, d_error);
+  }
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int HashTable::count(hipStream_t s, size_t* out) {
+  HCTR_TRY(reserve(max_n));
+  const long long empty =
+      key_type == HCTR_KEY_U32 ? KeyTraits<uint32_t>::empty : KeyTraits<long long>::empty;
+  const size_t n_tiles = ceil_div<size_t>(size, kHtTile);
+  const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+  hipLaunchKernelGGL(ht_occupied_count_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, size,
+                     empty, tile_sums, n_tiles);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, tile_sums, n_tiles,
+                     (const uint32_t*)nullptr, d_scratch64);
+  HCTR_LAUNCH_CHECK();
+  uint64_t h = 0;
+  HCTR_HIP(hipMemcpyAsync(&h, d_scratch64, sizeof(h), hipMemcpyDeviceToHost, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  *out = (size_t)h;
+  return HCTR_OK;
+}
+
+int HashTable::value_head(hipStream_t s, size_t* out) {
+  uint64_t h = 0;
+  HCTR_HIP(hipMemcpyAsync(&h, d_counter, sizeof(h), hipMemcpyDeviceToHost, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  *out = (size_t)h;
+  return HCTR_OK;
+}
+
+int HashTable::set_value_head(size_t v, hipStream_t s) {
+  uint64_t h = v;
+  HCTR_HIP(hipMemcpyAsync(d_counter, &h, sizeof(h), hipMemcpyHostToDevice, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  return HCTR_OK;
+}
+
+int HashTable::dump(int64_t* d_keys, uint64_t* d_vals, size_t* cnt, hipStream_t s) {
+  size_t c = 0;
+  HCTR_TRY(count(s, &c));  // leaves exclusive tile offsets in tile_sums
+  const long long empty =
+      key_type == HCTR_KEY_U32 ? KeyTraits<uint32_t>::empty : KeyTraits<long long>::empty;
+  const size_t n_tiles = ceil_div<size_t>(size, kHtTile);
+  const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+  hipLaunchKernelGGL(ht_dump_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, size, empty,
+                     tile_sums, n_tiles, d_keys, d_vals);
+  HCTR_LAUNCH_CHECK();
+  HCTR_HIP(hipStreamSynchronize(s));
+  *cnt = c;
+  return HCTR_OK;
+}
+
+int HashTable::error_flags(hipStream_t s, uint32_t* out) {
+  HCTR_HIP(hipMemcpyAsync(out, d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  return HCTR_OK;
+}
+
+}  // namespace hctr
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+using namespace hctr;
+
+extern "C" {
+
+int hctr_hash_keys(const void* keys, int key_type, size_t n, uint32_t* out, hctr_stream_t stream) {
+  if (n == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && out, "null pointer");
+  hipStream_t s = as_stream(stream);
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(hash_keys_kernel<uint32_t>, dim3(grid_for(n, 256)), dim3(256), 0, s,
+                       (const uint32_t*)keys, n, out);
+  } else if (key_type == HCTR_KEY_I64) {
+    hipLaunchKernelGGL(hash_keys_kernel<long long>, dim3(grid_for(n, 256)), dim3(256), 0, s,
+                       (const long long*)keys, n, out);
+  } else {
+    HCTR_REQUIRE(false, "key_type");
+  }
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_ht_create(size_t capacity, int key_type, hctr_hashtable** out) {
+  HCTR_REQUIRE(out, "out is null");
+  hctr_hashtable* h = new hctr_hashtable();
+  int rc = h->impl.create(capacity, key_type);
+  if (rc != HCTR_OK) {
+    h->impl.destroy();
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return HCTR_OK;
+}
+
+int hctr_ht_destroy(hctr_hashtable* ht) {
+  if (!ht) return HCTR_OK;
+  ht->impl.destroy();
+  delete ht;
+  return HCTR_OK;
+}
+
+int hctr_ht_clear(hctr_hashtable* ht, hctr_stream_t stream) {
+  HCTR_REQUIRE(ht, "null handle");
+  return ht->impl.clear(as_stream(stream));
+}
+
+int hctr_ht_get_insert(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,
+                       uint64_t* value_index, hctr_stream_t stream) {
+  HCTR_REQUIRE(ht && (n == 0 || (keys && value_index)), "null pointer");
+  return ht->impl.get_insert(keys, n, d_n, value_index, as_stream(stream));
+}
+
+int hctr_ht_get_mark(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,
+                     uint64_t* value_index, hctr_stream_t stream) {
+  HCTR_REQUIRE(ht && (n == 0 || (keys && value_index)), "null pointer");
+  return ht->impl.get_mark(keys, n, d_n, value_index, as_stream(stream));
+}
+
+int hctr_ht_insert(hctr_hashtable* ht, const void* keys, const uint64_t* vals, size_t n,
+                   hctr_stream_t stream) {
+  HCTR_REQUIRE(ht && (n == 0 || (keys && vals)), "null pointer");
+  return ht->impl.insert(keys, vals, n, as_stream(stream));
+}
+
+int hctr_ht_size(hctr_hashtable* ht, hctr_stream_t stream, size_t* out) {
+  HCTR_REQUIRE(ht && out, "null pointer");
+  return ht->impl.count(as_stream(stream), out);
+}
+
+int hctr_ht_value_head(hctr_hashtable* ht, hctr_stream_t stream, size_t* out) {
+  HCTR_REQUIRE(ht && out, "null pointer");
+  return ht->impl.value_head(as_stream(stream), out);
+}
+
+int hctr_ht_set_value_head(hctr_hashtable* ht, size_t v, hctr_stream_t stream) {
+  HCTR_REQUIRE(ht, "null handle");
+  return ht->impl.set_value_head(v, as_stream(stream));
+}
+
+size_t hctr_ht_table_size(const hctr_hashtable* ht) { return ht ? (size_t)ht->impl.size : 0; }
+
+int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* count,
+                 hctr_stream_t stream) {
+  HCTR_REQUIRE(ht && d_keys && d_vals && count, "null pointer");
+  return ht->impl.dump(d_keys, d_vals, count, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// sparse_update.h -- fused backward + sparse optimizer (internal C++ view).
+#pragma once
+#include "common.h"
+
+namespace hctr {
+
+struct OptState {
+  int optimizer = HCTR_OPT_SGD;
+  int update_type = HCTR_UPDATE_LOCAL;
+  float lr = 0.f;
+  float beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-7f;
+  float momentum_factor = 0.f;
+  float scaler = 1.f;
+  int atomic_update = 0;
+  uint64_t times = 0;  // Adam step counter (incremented before each update)
+};
+
+struct SparseUpdater {
+  size_t max_nnz = 0;
+  size_t max_vocab = 0;
+  int D = 0;
+  bool key32 = true;  // sort keys fit 32 bits
+  // sort buffers
+  void* sort_keys_in = nullptr;
+  void* sort_keys_out = nullptr;
+  uint32_t* sort_vals_in = nullptr;
+  uint32_t* sort_vals_out = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  // run detection
+  uint32_t* tile_sums = nullptr;
+  uint32_t* run_start = nullptr;  // [max_nnz + 1]
+  uint64_t* d_num_runs = nullptr;
+
+  int create(size_t max_nnz, size_t max_vocab, int D);
+  int destroy();
+  // row_offset/key_type as in the forward; top_grad [buckets][D] of grad_dtype.
+  int update(size_t buckets, size_t nnz, int combiner, const void* row_offset, int key_type,
+             const uint64_t* value_index, const void* top_grad, int grad_dtype, const OptState& opt,
+             float* table, float* state0, float* state1, uint64_t* prev_time, hipStream_t s);
+};
+
+int materialize_wgrad(size_t buckets, int D, int combiner, const void* row_offset, int key_type,
+                      const void* top_grad, void* wgrad, int dtype, hipStream_t s);
+
+}  // namespace hctr

@@ -1,0 +1,717 @@
+// sparse_update.hip -- fused embedding backward + sparse optimizer update on gfx950.
+//
+// Replaces backward_sum/backward_mean (R/HugeCTR/src/embeddings/backward_functor.cu:26-104) and
+// EmbeddingOptimizer::update (R/HugeCTR/src/optimizers/sparse_optimizer.cu:622-864).
+// Reference pipeline: wgrad copy -> sample-id expand -> radix sort (row index -> bucket id) ->
+// run flags -> scan -> BLOCKING D2H of the run count -> one block per unique row.
+// Here: no wgrad tensor (the top gradient is read in place, the mean scale 1/n is applied while
+// accumulating), the run count stays on the device (persistent grid-stride over runs), and a
+// "group" of D/4 lanes owns a row with 16-byte accesses.  Gradient accumulation per row is in
+// ascending bucket id, exactly the reference's order (stable sort), then / scaler.
+#include "sparse_update.h"
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "block_prims.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 1024;
+
+template <typename GradT>
+struct Load4;
+template <>
+struct Load4<float> {
+  __device__ __forceinline__ static float4 ld(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+  }
+  __device__ __forceinline__ static float ld1(const float* p) { return *p; }
+  __device__ __forceinline__ static float rnd(float v) { return v; }
+};
+template <>
+struct Load4<__half> {
+  __device__ __forceinline__ static float4 ld(const __half* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    __half2 a = *reinterpret_cast<__half2*>(&u.x), b = *reinterpret_cast<__half2*>(&u.y);
+    float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+  }
+  __device__ __forceinline__ static float ld1(const __half* p) { return __half2float(*p); }
+  __device__ __forceinline__ static float rnd(float v) { return __half2float(__float2half_rn(v)); }
+};
+template <>
+struct Load4<__hip_bfloat16> {
+  __device__ __forceinline__ static float4 ld(const __hip_bfloat16* p) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+  }
+  __device__ __forceinline__ static float ld1(const __hip_bfloat16* p) {
+    return __bfloat162float(*p);
+  }
+  __device__ __forceinline__ static float rnd(float v) {
+    return __bfloat162float(__float2bfloat16(v));
+  }
+};
+
+// ---- step 1: (row index, bucket id) pairs (sample_id_expand_kernel :189-200) ------------------
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    expand_pairs_kernel(size_t buckets, size_t n_sort, const OffT* __restrict__ row_offset,
+                        const uint64_t* __restrict__ value_index, SortK* __restrict__ keys,
+                        uint32_t* __restrict__ vals) {
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t u = tid; u < buckets; u += nthreads) {
+    const size_t off = (size_t)row_offset[u], end = (size_t)row_offset[u + 1];
+    for (size_t j = off; j < end && j < n_sort; j++) {
+      keys[j] = (SortK)value_index[j];
+      vals[j] = (uint32_t)u;
+    }
+  }
+  // padding (host upper bound > live nnz): sorts to the end, never forms a counted run
+  for (size_t j = nnz + tid; j < n_sort; j += nthreads) {
+    keys[j] = (SortK)~(SortK)0;
+    vals[j] = 0xFFFFFFFFu;
+  }
+}
+
+// ---- step 2: run starts ------------------------------------------------------------------------
+template <typename SortK>
+__device__ __forceinline__ bool is_run_start(const SortK* k, size_t i, size_t nnz) {
+  if (i >= nnz) return false;
+  return i == 0 || k[i] != k[i - 1];
+}
+
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    run_count_kernel(const SortK* __restrict__ keys, const OffT* __restrict__ row_offset,
+                     size_t buckets, size_t n_tiles, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nnz = (size_t)row_offset[buckets];
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kTile / kBlock; r++) {
+      size_t i = tile * kTile + r * kBlock + threadIdx.x;
+      c += is_run_start(keys, i, nnz) ? 1u : 0u;
+    }
+    uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+    scan_tiles_u32_kernel(uint32_t* sums, size_t m, uint64_t* d_total) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < m; base += 1024) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = (i < m) ? sums[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<uint32_t, 1024>(v, smem, &tot);
+    uint64_t c = carry;
+    if (i < m) sums[i] = (uint32_t)(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = carry;
+}
+
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    run_write_kernel(const SortK* __restrict__ keys, const OffT* __restrict__ row_offset,
+                     size_t buckets, size_t n_tiles, const uint32_t* __restrict__ tile_sums,
+                     const uint64_t* __restrict__ d_num_runs, uint32_t* __restrict__ run_start) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nnz = (size_t)row_offset[buckets];
+  if (blockIdx.x == 0 && threadIdx.x == 0) run_start[*d_num_runs] = (uint32_t)nnz;
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t run = tile_sums[tile];
+#pragma unroll
+    for (int r = 0; r < kTile / kBlock; r++) {
+      size_t i = tile * kTile + r * kBlock + threadIdx.x;
+      bool f = is_run_start(keys, i, nnz);
+      uint32_t tot;
+      uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
+      if (f) run_start[run + ex] = (uint32_t)i;
+      run += tot;
+    }
+  }
+}
+
+// ---- step 3: per-row ordered reduce + optimizer -------------------------------------------------
+struct OptConst {
+  int optimizer, update_type;
+  float lr, beta1, beta2, epsilon, mf, scaler;
+  float alpha_t;         // lr * adam.bias()
+  float alpha_t_common;  // lr / (1 - beta1) (lazy adam)
+  unsigned long long times;
+};
+
+// one element of one row; formulas cite sparse_optimizer.cu
+__device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w, float* s0p,
+                                          float* s1p, unsigned long long* ptp) {
+  switch (o.optimizer) {
+    case HCTR_OPT_SGD:  // opt_sgd_kernel :497-518
+      w += -o.lr * gi;
+      break;
+    case HCTR_OPT_ADAGRAD: {  // opt_adagrad_kernel :410-437 (Global == Local)
+      float accum = *s0p + gi * gi;
+      *s0p = accum;
+      w += -o.lr * gi / (sqrtf(accum) + o.epsilon);
+    } break;
+    case HCTR_OPT_ADAM:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_adam_kernel :379-408
+        float mi = o.beta1 * *s0p + (1.0f - o.beta1) * gi;
+        float vi = o.beta2 * *s1p + (1.0f - o.beta2) * gi * gi;
+        *s0p = mi;
+        *s1p = vi;
+        w += -o.alpha_t * mi / (sqrtf(vi) + o.epsilon);
+      } else if (o.update_type == HCTR_UPDATE_GLOBAL) {  // opt_adam_kernel_global :241-265
+        *s0p = *s0p + (1.0f - o.beta1) * gi / o.beta1;
+        *s1p = *s1p + (1.0f - o.beta2) * gi * gi / o.beta2;
+      } else {  // opt_adam_kernel_lazy :524-561
+        unsigned long long pt = *ptp;
+        *ptp = o.times;
+        unsigned long long skipped = o.times - pt;
+        float b1ps = powf(o.beta1, (float)skipped);
+        float a = o.alpha_t_common * sqrtf(1.0f - powf(o.beta2, (float)pt)) /
+                  (1.0f - powf(o.beta1, (float)pt)) * (1.0f - b1ps);
+        float mi = *s0p, vi = *s1p;
+        w += -a * mi / (sqrtf(vi) + o.epsilon);
+        mi = b1ps * mi + (1.0f - o.beta1) * gi;
+        vi = powf(o.beta2, (float)skipped) * vi + (1.0f - o.beta2) * gi * gi;
+        *s0p = mi;
+        *s1p = vi;
+      }
+      break;
+    case HCTR_OPT_MOMENTUM_SGD:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_momentum_sgd_kernel :440-465
+        float mo = o.mf * *s0p - o.lr * gi;
+        *s0p = mo;
+        w += mo;
+      } else {  // opt_momentum_sgd_kernel_global :292-312
+        *s0p = *s0p - o.lr * gi / o.mf;
+      }
+      break;
+    case HCTR_OPT_NESTEROV:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_nesterov_kernel :468-494
+        float accm_old = *s0p;
+        float accm_new = o.mf * accm_old - o.lr * gi;
+        *s0p = accm_new;
+        w += -o.mf * accm_old + (1.0f + o.mf) * accm_new;
+      } else {  // nesterov_local_update_kernel_global :352-375
+        float accm = *s0p;
+        accm -= o.lr * gi;
+        *s0p = accm;
+        w -= (1.0f + o.mf) * (o.lr * gi);
+      }
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ bool needs_s0(const OptConst& o) { return o.optimizer != HCTR_OPT_SGD; }
+__device__ __forceinline__ bool needs_s1(const OptConst& o) { return o.optimizer == HCTR_OPT_ADAM; }
+__device__ __forceinline__ bool needs_pt(const OptConst& o) {
+  return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
+}
+
+template <int LPR, typename OffT, typename SortK, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    update_rows_vec4_kernel(const uint64_t* __restrict__ d_num_runs,
+                            const uint32_t* __restrict__ run_start,
+                            const SortK* __restrict__ sorted_rows,
+                            const uint32_t* __restrict__ sorted_buckets,
+                            const OffT* __restrict__ row_offset, int combiner,
+                            const GradT* __restrict__ grad, OptConst o, float* __restrict__ table,
+                            float* __restrict__ state0, float* __restrict__ state1,
+                            unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int U = 4;
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const size_t num_runs = (size_t)*d_num_runs;
+  for (size_t r = (size_t)blockIdx.x * GPB + g; r < num_runs; r += (size_t)gridDim.x * GPB) {
+    const uint32_t off = run_start[r];
+    const uint32_t cnt = run_start[r + 1] - off;
+    const uint64_t row = (uint64_t)sorted_rows[off];
+    float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t k = 0;
+    for (; k + U <= cnt; k += U) {
+      uint32_t b[U];
+      float4 v[U];
+      float sc[U];
+#pragma unroll
+      for (int t = 0; t < U; t++) b[t] = sorted_buckets[off + k + t];
+#pragma unroll
+      for (int t = 0; t < U; t++) v[t] = Load4<GradT>::ld(grad + (size_t)b[t] * D + l * 4);
+      if (combiner == 1) {
+#pragma unroll
+        for (int t = 0; t < U; t++) {
+          long long n = (long long)row_offset[b[t] + 1] - (long long)row_offset[b[t]];
+          sc[t] = n > 1 ? 1.0f / (float)n : 1.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < U; t++) {
+          v[t].x = Load4<GradT>::rnd(v[t].x * sc[t]);
+          v[t].y = Load4<GradT>::rnd(v[t].y * sc[t]);
+          v[t].z = Load4<GradT>::rnd(v[t].z * sc[t]);
+          v[t].w = Load4<GradT>::rnd(v[t].w * sc[t]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; t++) {
+        gi.x += v[t].x;
+        gi.y += v[t].y;
+        gi.z += v[t].z;
+        gi.w += v[t].w;
+      }
+    }
+    for (; k < cnt; k++) {
+      const uint32_t b = sorted_buckets[off + k];
+      float4 v = Load4<GradT>::ld(grad + (size_t)b * D + l * 4);
+      if (combiner == 1) {
+        long long n = (long long)row_offset[b + 1] - (long long)row_offset[b];
+        const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
+        v.x = Load4<GradT>::rnd(v.x * sc);
+        v.y = Load4<GradT>::rnd(v.y * sc);
+        v.z = Load4<GradT>::rnd(v.z * sc);
+        v.w = Load4<GradT>::rnd(v.w * sc);
+      }
+      gi.x += v.x;
+      gi.y += v.y;
+      gi.z += v.z;
+      gi.w += v.w;
+    }
+    gi.x /= o.scaler;
+    gi.y /= o.scaler;
+    gi.z /= o.scaler;
+    gi.w /= o.scaler;
+
+    const size_t f = row * (uint64_t)D + l * 4;
+    float4 w = *reinterpret_cast<float4*>(table + f);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    unsigned long long pt[4] = {1ull, 1ull, 1ull, 1ull};
+    if (needs_s0(o)) s0 = *reinterpret_cast<float4*>(state0 + f);
+    if (needs_s1(o)) s1 = *reinterpret_cast<float4*>(state1 + f);
+    if (needs_pt(o)) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) pt[t] = prev_time[f + t];
+    }
+    apply_opt(o, gi.x, w.x, &s0.x, &s1.x, &pt[0]);
+    apply_opt(o, gi.y, w.y, &s0.y, &s1.y, &pt[1]);
+    apply_opt(o, gi.z, w.z, &s0.z, &s1.z, &pt[2]);
+    apply_opt(o, gi.w, w.w, &s0.w, &s1.w, &pt[3]);
+    const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
+                             o.update_type == HCTR_UPDATE_GLOBAL);
+    if (w_written) *reinterpret_cast<float4*>(table + f) = w;
+    if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = s0;
+    if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = s1;
+    if (needs_pt(o)) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) prev_time[f + t] = pt[t];
+    }
+  }
+}
+
+// any D: one wavefront per run, lanes stride over the vector
+template <typename OffT, typename SortK, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    update_rows_generic_kernel(const uint64_t* __restrict__ d_num_runs,
+                               const uint32_t* __restrict__ run_start,
+                               const SortK* __restrict__ sorted_rows,
+                               const uint32_t* __restrict__ sorted_buckets,
+                               const OffT* __restrict__ row_offset, int combiner, int D,
+                               const GradT* __restrict__ grad, OptConst o,
+                               float* __restrict__ table, float* __restrict__ state0,
+                               float* __restrict__ state1,
+                               unsigned long long* __restrict__ prev_time) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  const size_t num_runs = (size_t)*d_num_runs;
+  for (size_t r = wave; r < num_runs; r += nwaves) {
+    const uint32_t off = run_start[r];
+    const uint32_t cnt = run_start[r + 1] - off;
+    const uint64_t row = (uint64_t)sorted_rows[off];
+    for (int v = lane; v < D; v += 64) {
+      float gi = 0.0f;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t b = sorted_buckets[off + k];
+        float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
+        if (combiner == 1) {
+          long long n = (long long)row_offset[b + 1] - (long long)row_offset[b];
+          if (n > 1) gv = Load4<GradT>::rnd(gv * (1.0f / (float)n));
+        }
+        gi += gv;
+      }
+      gi /= o.scaler;
+      const size_t f = row * (uint64_t)D + v;
+      float w = table[f];
+      float s0 = needs_s0(o) ? state0[f] : 0.f;
+      float s1 = needs_s1(o) ? state1[f] : 0.f;
+      unsigned long long pt = needs_pt(o) ? prev_time[f] : 1ull;
+      apply_opt(o, gi, w, &s0, &s1, &pt);
+      table[f] = w;
+      if (needs_s0(o)) state0[f] = s0;
+      if (needs_s1(o)) state1[f] = s1;
+      if (needs_pt(o)) prev_time[f] = pt;
+    }
+  }
+}
+
+// SGD with atomic_update (opt_sgd_atomic_kernel :564-582): w[idx] += -(lr/scaler) * wgrad[bucket]
+template <typename OffT, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    sgd_atomic_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
+                      const uint64_t* __restrict__ value_index, const GradT* __restrict__ grad,
+                      float lr_scale, float* __restrict__ table) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = (long long)row_offset[u];
+    const int n = (int)((long long)row_offset[u + 1] - off);
+    const float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    for (int v = lane; v < D; v += 64) {
+      float gv = Load4<GradT>::ld1(grad + u * (size_t)D + v);
+      if (combiner == 1) gv = Load4<GradT>::rnd(gv * sc);
+      const float dw = -lr_scale * gv;
+      for (int j = 0; j < n; j++) {
+        const uint64_t idx = value_index[off + j];
+        if (idx != kInvalidIndex) unsafeAtomicAdd(table + idx * (uint64_t)D + v, dw);
+      }
+    }
+  }
+}
+
+// ---- global (whole-table) sweeps ----------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    adam_global_sweep_kernel(size_t n, float beta1, float beta2, float eps, float alpha_t,
+                             float* __restrict__ m, float* __restrict__ v, float* __restrict__ w) {
+  // adam_update_kernel_global :269-288
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float mi = beta1 * m[i];
+    float vi = beta2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    w[i] += -alpha_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    momentum_global_sweep_kernel(size_t n, float factor, float* __restrict__ mo,
+                                 float* __restrict__ w) {
+  // momentum_sgd_update_kernel_global :316-329
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float m = mo[i];
+    m *= factor;
+    w[i] += m;
+    mo[i] = m;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    nesterov_global_sweep_kernel(size_t n, float mu, float* __restrict__ accm,
+                                 float* __restrict__ w) {
+  // nesterov_global_update_kernel_global :333-347
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float a = accm[i];
+    a *= mu;
+    accm[i] = a;
+    w[i] += a * mu;
+  }
+}
+
+// ---- wgrad materialisation (tests / get_wgrad) --------------------------------------------------
+template <typename OffT, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    wgrad_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
+                 const GradT* __restrict__ top, GradT* __restrict__ wgrad) {
+  const size_t total = buckets * (size_t)D;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const size_t u = i / D;
+    float g = Load4<GradT>::ld1(top + i);
+    if (combiner == 1) {
+      long long n = (long long)row_offset[u + 1] - (long long)row_offset[u];
+      if (n > 1) g = g * (1.0f / (float)n);
+    }
+    if constexpr (std::is_same<GradT, float>::value) wgrad[i] = g;
+    else if constexpr (std::is_same<GradT, __half>::value) wgrad[i] = __float2half_rn(g);
+    else wgrad[i] = __float2bfloat16(g);
+  }
+}
+
+template <typename SortK>
+int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, const uint32_t* vin,
+               uint32_t* vout, size_t n, int end_bit, hipStream_t s) {
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0,
+                                           (unsigned)end_bit, s, false);
+  if (e != hipSuccess) {
+    set_error(std::string("rocprim::radix_sort_pairs: ") + hipGetErrorString(e));
+    return HCTR_ERR_HIP;
+  }
+  return HCTR_OK;
+}
+
+template <typename OffT, typename SortK, typename GradT>
+int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                 const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
+                 float* state0, float* state1, uint64_t* prev_time, hipStream_t s) {
+  const int D = u.D;
+  OptConst o;
+  o.optimizer = opt.optimizer;
+  o.update_type = opt.update_type;
+  o.lr = opt.lr;
+  o.beta1 = opt.beta1;
+  o.beta2 = opt.beta2;
+  o.epsilon = opt.epsilon;
+  o.mf = opt.momentum_factor;
+  o.scaler = opt.scaler;
+  o.times = opt.times;
+  // AdamOptHyperParams::bias() (optimizer.hpp:58-60): double pow, rounded to float, times lr
+  const float bias = (float)(std::sqrt(1.0 - std::pow((double)opt.beta2, (double)opt.times)) /
+                             (1.0 - std::pow((double)opt.beta1, (double)opt.times)));
+  o.alpha_t = opt.lr * bias;
+  o.alpha_t_common = opt.lr / (1.0f - opt.beta1);
+  const size_t table_elems = u.max_vocab * (size_t)D;
+
+  if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
+    const float lr_scale = opt.lr / opt.scaler;
+    hipLaunchKernelGGL((sgd_atomic_kernel<OffT, GradT>), dim3(grid_for(buckets * 64, kBlock)),
+                       dim3(kBlock), 0, s, buckets, D, combiner, ro, vi, grad, lr_scale, table);
+    HCTR_LAUNCH_CHECK();
+    return HCTR_OK;
+  }
+
+  if (opt.optimizer == HCTR_OPT_NESTEROV && opt.update_type == HCTR_UPDATE_GLOBAL) {
+    hipLaunchKernelGGL(nesterov_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                       dim3(kBlock), 0, s, table_elems, opt.momentum_factor, state0, table);
+    HCTR_LAUNCH_CHECK();
+  }
+
+  if (nnz > 0) {
+    SortK* kin = (SortK*)u.sort_keys_in;
+    SortK* kout = (SortK*)u.sort_keys_out;
+    hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
+                       dim3(kBlock), 0, s, buckets, nnz, ro, vi, kin, u.sort_vals_in);
+    HCTR_LAUNCH_CHECK();
+    // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
+    int end_bit = 1;
+    while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= u.max_vocab) end_bit++;
+    end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
+    size_t tb = u.sort_temp_bytes;
+    HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, nnz,
+                               end_bit, s));
+    const size_t n_tiles = ceil_div<size_t>(nnz, kTile);
+    const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+    hipLaunchKernelGGL((run_count_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout, ro,
+                       buckets, n_tiles, u.tile_sums);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_tiles_u32_kernel, dim3(1), dim3(1024), 0, s, u.tile_sums, n_tiles,
+                       u.d_num_runs);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((run_write_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout, ro,
+                       buckets, n_tiles, u.tile_sums, u.d_num_runs, u.run_start);
+    HCTR_LAUNCH_CHECK();
+
+    const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
+#define HCTR_UPD_CASE(LPR_)                                                                      \
+  {                                                                                              \
+    constexpr int GPB = kBlock / LPR_;                                                           \
+    const int grid = grid_for(nnz, GPB, 256 * 8);                                                \
+    hipLaunchKernelGGL((update_rows_vec4_kernel<LPR_, OffT, SortK, GradT>), dim3(grid),         \
+                       dim3(kBlock), 0, s, u.d_num_runs, u.run_start, kout, u.sort_vals_out, ro, \
+                       combiner, grad, o, table, state0, state1,                                 \
+                       (unsigned long long*)prev_time);                                          \
+  }
+    bool done = false;
+    if (a16 && D % 4 == 0) {
+      done = true;
+      switch (D / 4) {
+        case 1: HCTR_UPD_CASE(1) break;
+        case 2: HCTR_UPD_CASE(2) break;
+        case 4: HCTR_UPD_CASE(4) break;
+        case 8: HCTR_UPD_CASE(8) break;
+        case 16: HCTR_UPD_CASE(16) break;
+        case 32: HCTR_UPD_CASE(32) break;
+        case 64: HCTR_UPD_CASE(64) break;
+        default: done = false;
+      }
+    }
+#undef HCTR_UPD_CASE
+    if (!done) {
+      hipLaunchKernelGGL((update_rows_generic_kernel<OffT, SortK, GradT>),
+                         dim3(grid_for(nnz * 64, kBlock)), dim3(kBlock), 0, s, u.d_num_runs,
+                         u.run_start, kout, u.sort_vals_out, ro, combiner, D, grad, o, table,
+                         state0, state1, (unsigned long long*)prev_time);
+    }
+    HCTR_LAUNCH_CHECK();
+  }
+
+  if (opt.update_type == HCTR_UPDATE_GLOBAL) {
+    if (opt.optimizer == HCTR_OPT_ADAM) {
+      hipLaunchKernelGGL(adam_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                         dim3(kBlock), 0, s, table_elems, opt.beta1, opt.beta2, opt.epsilon,
+                         o.alpha_t, state0, state1, table);
+      HCTR_LAUNCH_CHECK();
+    } else if (opt.optimizer == HCTR_OPT_MOMENTUM_SGD) {
+      hipLaunchKernelGGL(momentum_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                         dim3(kBlock), 0, s, table_elems, opt.momentum_factor, state0, table);
+      HCTR_LAUNCH_CHECK();
+    }
+  }
+  return HCTR_OK;
+}
+
+template <typename OffT, typename GradT>
+int update_sortk(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                 const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
+                 float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  if (u.key32)
+    return update_typed<OffT, uint32_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
+                                               s0, s1, pt, s);
+  return update_typed<OffT, uint64_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
+                                             s0, s1, pt, s);
+}
+
+template <typename OffT>
+int update_grad(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  switch (grad_dtype) {
+    case HCTR_EMB_F32:
+      return update_sortk<OffT, float>(u, buckets, nnz, combiner, ro, vi, (const float*)grad, opt,
+                                       table, s0, s1, pt, s);
+    case HCTR_EMB_F16:
+      return update_sortk<OffT, __half>(u, buckets, nnz, combiner, ro, vi, (const __half*)grad,
+                                        opt, table, s0, s1, pt, s);
+    case HCTR_EMB_BF16:
+      return update_sortk<OffT, __hip_bfloat16>(u, buckets, nnz, combiner, ro, vi,
+                                                (const __hip_bfloat16*)grad, opt, table, s0, s1,
+                                                pt, s);
+  }
+  set_error("grad dtype");
+  return HCTR_ERR_INVALID_ARG;
+}
+
+}  // namespace
+
+int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
+  max_nnz = max_nnz_ > 0 ? max_nnz_ : 1;
+  max_vocab = max_vocab_;
+  D = D_;
+  key32 = max_vocab < 0xFFFFFFF0ull;
+  const size_t ksz = key32 ? 4 : 8;
+  HCTR_HIP(hipMalloc(&sort_keys_in, max_nnz * ksz));
+  HCTR_HIP(hipMalloc(&sort_keys_out, max_nnz * ksz));
+  HCTR_HIP(hipMalloc(&sort_vals_in, max_nnz * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&sort_vals_out, max_nnz * sizeof(uint32_t)));
+  size_t tb = 0;
+  if (key32) {
+    HCTR_TRY(sort_pairs<uint32_t>(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  nullptr, nullptr, max_nnz, 32, nullptr));
+  } else {
+    HCTR_TRY(sort_pairs<uint64_t>(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                  nullptr, nullptr, max_nnz, 64, nullptr));
+  }
+  sort_temp_bytes = tb > 0 ? tb : 16;
+  HCTR_HIP(hipMalloc(&sort_temp, sort_temp_bytes));
+  HCTR_HIP(hipMalloc(&tile_sums, (ceil_div<size_t>(max_nnz, kTile) + 1) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&run_start, (max_nnz + 2) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&d_num_runs, sizeof(uint64_t)));
+  HCTR_HIP(hipMemset(d_num_runs, 0, sizeof(uint64_t)));
+  return HCTR_OK;
+}
+
+int SparseUpdater::destroy() {
+  void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out,
+                  sort_temp,    tile_sums,     run_start,    d_num_runs};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  sort_keys_in = sort_keys_out = sort_temp = nullptr;
+  sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
+  d_num_runs = nullptr;
+  return HCTR_OK;
+}
+
+int SparseUpdater::update(size_t buckets, size_t nnz, int combiner, const void* row_offset,
+                          int key_type, const uint64_t* value_index, const void* top_grad,
+                          int grad_dtype, const OptState& opt, float* table, float* state0,
+                          float* state1, uint64_t* prev_time, hipStream_t s) {
+  if (buckets == 0) return HCTR_OK;
+  if (nnz > max_nnz) {
+    set_error("update: nnz exceeds the workspace (batch_size * max_feature_num)");
+    return HCTR_ERR_INVALID_ARG;
+  }
+  if (buckets > 0xFFFFFFF0ull) {
+    set_error("update: more than 2^32 buckets");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  switch (opt.optimizer) {
+    case HCTR_OPT_SGD:
+    case HCTR_OPT_ADAM:
+    case HCTR_OPT_ADAGRAD:
+    case HCTR_OPT_MOMENTUM_SGD:
+    case HCTR_OPT_NESTEROV: break;
+    default:
+      // Ftrl / RMSProp are not implemented by the reference's GPU update either
+      set_error("sparse optimizer not supported (reference: sparse_optimizer.cu:821-826)");
+      return HCTR_ERR_UNSUPPORTED;
+  }
+  if (opt.update_type == HCTR_UPDATE_LAZY_GLOBAL && opt.optimizer != HCTR_OPT_ADAM) {
+    set_error("lazy global update is only implemented for Adam (sparse_optimizer.cu:829-850)");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  if (key_type == HCTR_KEY_U32)
+    return update_grad<uint32_t>(*this, buckets, nnz, combiner, (const uint32_t*)row_offset,
+                                 value_index, top_grad, grad_dtype, opt, table, state0, state1,
+                                 prev_time, s);
+  if (key_type == HCTR_KEY_I64)
+    return update_grad<long long>(*this, buckets, nnz, combiner, (const long long*)row_offset,
+                                  value_index, top_grad, grad_dtype, opt, table, state0, state1,
+                                  prev_time, s);
+  set_error("key_type");
+  return HCTR_ERR_INVALID_ARG;
+}
+
+int materialize_wgrad(size_t buckets, int D, int combiner, const void* ro, int key_type,
+                      const void* top, void* wgrad, int dtype, hipStream_t s) {
+  if (buckets == 0) return HCTR_OK;
+  const int grid = grid_for(buckets * (size_t)D, kBlock);
+#define HCTR_WG(OffT, GradT)                                                                  \
+  hipLaunchKernelGGL((wgrad_kernel<OffT, GradT>), dim3(grid), dim3(kBlock), 0, s, buckets, D, \
+                     combiner, (const OffT*)ro, (const GradT*)top, (GradT*)wgrad)
+  if (key_type == HCTR_KEY_U32) {
+    if (dtype == HCTR_EMB_F32) HCTR_WG(uint32_t, float);
+    else if (dtype == HCTR_EMB_F16) HCTR_WG(uint32_t, __half);
+    else HCTR_WG(uint32_t, __hip_bfloat16);
+  } else {
+    if (dtype == HCTR_EMB_F32) HCTR_WG(long long, float);
+    else if (dtype == HCTR_EMB_F16) HCTR_WG(long long, __half);
+    else HCTR_WG(long long, __hip_bfloat16);
+  }
+#undef HCTR_WG
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+}  // namespace hctr

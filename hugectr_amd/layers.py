@@ -1,0 +1,109 @@
+"""torch.autograd wrappers of the dense ops on the path (HIP kernels through the C ABI).
+
+InteractionLayer: R/HugeCTR/include/layers/interaction_layer.hpp:26-67
+MultiCrossLayer:  R/HugeCTR/include/layers/multi_cross_layer.hpp:104-177
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+class _InteractionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mlp, emb):
+        mlp, emb = mlp.contiguous(), emb.contiguous()
+        B, W = mlp.shape
+        n_emb = emb.shape[1]
+        n_ins = n_emb + 1
+        out = torch.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=mlp.dtype, device=mlp.device)
+        check(lib.hctr_interaction_fwd(B, n_emb, W, ptr(mlp), ptr(emb), ptr(out), _DT[mlp.dtype],
+                                       stream_ptr()))
+        ctx.save_for_backward(mlp, emb)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mlp, emb = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, W = mlp.shape
+        n_emb = emb.shape[1]
+        mlp_grad = torch.empty_like(mlp)
+        emb_grad = torch.empty_like(emb)
+        check(lib.hctr_interaction_bwd(B, n_emb, W, ptr(mlp), ptr(emb), ptr(grad), ptr(mlp_grad),
+                                       ptr(emb_grad), _DT[mlp.dtype], stream_ptr()))
+        return mlp_grad, emb_grad
+
+
+def interaction(mlp: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    """mlp [B,W], emb [B,n_emb,W] -> [B, W + n_ins(n_ins-1)/2 + 1] (last column zero)."""
+    return _InteractionFn.apply(mlp, emb)
+
+
+class InteractionLayer(torch.nn.Module):
+    def forward(self, mlp, emb):
+        return interaction(mlp, emb)
+
+
+class _CrossV1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, kernels, biases):
+        x0 = x0.contiguous().float()
+        kernels, biases = kernels.contiguous(), biases.contiguous()
+        B, w = x0.shape
+        L = kernels.shape[0]
+        outputs = torch.empty((L, B, w), dtype=torch.float32, device=x0.device)
+        hiddens = torch.empty((L, B), dtype=torch.float32, device=x0.device)
+        check(lib.hctr_cross_v1_fwd(B, w, L, ptr(x0), ptr(kernels), ptr(biases), ptr(outputs),
+                                    ptr(hiddens), stream_ptr()))
+        ctx.save_for_backward(x0, kernels, outputs, hiddens)
+        return outputs[L - 1]
+
+    @staticmethod
+    def backward(ctx, grad):
+        x0, kernels, outputs, hiddens = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, w = x0.shape
+        L = kernels.shape[0]
+        in_grad = torch.empty_like(x0)
+        kg = torch.empty_like(kernels)
+        bg = torch.empty_like(kernels)
+        ws = torch.empty(lib.hctr_cross_v1_bwd_workspace_bytes(B, w, L) // 4, dtype=torch.float32,
+                         device=x0.device)
+        check(lib.hctr_cross_v1_bwd(B, w, L, ptr(x0), ptr(kernels), ptr(outputs), ptr(hiddens),
+                                    ptr(grad), ptr(in_grad), ptr(kg), ptr(bg), ptr(ws),
+                                    stream_ptr()))
+        return in_grad, kg, bg
+
+
+class MultiCrossLayer(torch.nn.Module):
+    """DCN cross layers.  projection_dim == 0: v1 (x_{l+1} = x0 * (x_l . w_l) + b_l + x_l), all
+    layers fused in one HIP launch.  projection_dim > 0: v2 (x_{l+1} = x0 * (x_l U_l V_l + b_l)
+    + x_l): the two GEMMs go to hipBLASLt through torch, the epilogue is fused in HIP."""
+
+    def __init__(self, width: int, num_layers: int, projection_dim: int = 0):
+        super().__init__()
+        self.width, self.num_layers, self.projection_dim = width, num_layers, projection_dim
+        if projection_dim == 0:
+            # XavierUniform-like default init (weights [1,w] per layer, bias zeros)
+            bound = (6.0 / (width + 1)) ** 0.5
+            self.kernels = torch.nn.Parameter(torch.empty(num_layers, width).uniform_(-bound, bound))
+            self.biases = torch.nn.Parameter(torch.zeros(num_layers, width))
+        else:
+            bu = (6.0 / (width + projection_dim)) ** 0.5
+            self.U = torch.nn.Parameter(torch.empty(num_layers, width, projection_dim).uniform_(-bu, bu))
+            self.V = torch.nn.Parameter(torch.empty(num_layers, projection_dim, width).uniform_(-bu, bu))
+            self.biases = torch.nn.Parameter(torch.zeros(num_layers, width))
+
+    def forward(self, x0):
+        if self.projection_dim == 0:
+            return _CrossV1Fn.apply(x0, self.kernels, self.biases)
+        xl = x0
+        for l in range(self.num_layers):
+            h = (xl @ self.U[l]) @ self.V[l] + self.biases[l]
+            xl = x0 * h + xl
+        return xl

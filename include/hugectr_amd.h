@@ -1,0 +1,208 @@
+/*
+ * hugectr_amd.h -- C ABI of the MI355X-native sparse-embedding hot path (libhugectr_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Every entry
+ * point names the NVIDIA-Merlin/HugeCTR interface it replaces (R = the reference checkout).
+ * All device pointers are HIP device pointers on the calling thread's current device; `stream`
+ * is a hipStream_t passed as void* (NULL = the default stream).  Nothing here synchronises the
+ * host unless the comment says so.  Every function returns 0 on success or a negative
+ * hctr_status; hctr_last_error() gives the message for the calling thread.
+ *
+ * One process drives one GPU ("rank" of "world"), which is how HugeCTR's per-GPU OpenMP threads
+ * (R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:217-283) map onto
+ * torch.distributed / RCCL.  The all-to-all between ranks is the caller's (RCCL) -- this library
+ * produces/consumes the send/receive buffers in the reference's wire layout.
+ */
+#ifndef HUGECTR_AMD_H
+#define HUGECTR_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hctr_stream_t;
+
+typedef enum {
+  HCTR_OK = 0,
+  HCTR_ERR_INVALID_ARG = -1,
+  HCTR_ERR_HIP = -2,
+  HCTR_ERR_OVERFLOW = -3, /* hash table fuller than max_vocabulary_size_per_gpu */
+  HCTR_ERR_UNSUPPORTED = -4,
+  HCTR_ERR_IO = -5
+} hctr_status;
+
+/* Values follow R/HugeCTR/include/common.hpp:82-94,145-149 */
+typedef enum { HCTR_OPT_FTRL = 0, HCTR_OPT_ADAM = 1, HCTR_OPT_RMSPROP = 2, HCTR_OPT_ADAGRAD = 3,
+               HCTR_OPT_NESTEROV = 4, HCTR_OPT_MOMENTUM_SGD = 5, HCTR_OPT_SGD = 6 } hctr_optimizer_t;
+typedef enum { HCTR_UPDATE_LOCAL = 0, HCTR_UPDATE_GLOBAL = 1, HCTR_UPDATE_LAZY_GLOBAL = 2 } hctr_update_t;
+typedef enum { HCTR_EMB_DISTRIBUTED_SLOT_HASH = 0, HCTR_EMB_LOCALIZED_SLOT_HASH = 1 } hctr_embedding_t;
+typedef enum { HCTR_KEY_U32 = 0, HCTR_KEY_I64 = 1 } hctr_key_t;
+typedef enum { HCTR_EMB_F32 = 0, HCTR_EMB_F16 = 1, HCTR_EMB_BF16 = 2 } hctr_emb_dtype_t;
+
+const char* hctr_last_error(void);
+int hctr_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Stateless kernels (usable on caller-owned buffers; the handle API below is built on them)   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* MurmurHash3_32(key bytes, seed 0): R/HugeCTR/include/hashtable/cudf/hash_functions.cuh:66-107.
+ * keys: device [n] of key_type; out: device uint32 [n]. */
+int hctr_hash_keys(const void* keys, int key_type, size_t n, uint32_t* out, hctr_stream_t stream);
+
+/* Open-addressing key -> row-index map; replaces HashTable<Key,size_t>
+ * (R/HugeCTR/include/hashtable/nv_hashtable.hpp:31-189, src/hashtable/nv_hashtable.cu:169-303).
+ * Physical slot count = (size_t)(capacity / 0.75f); slot = murmur(key) % slots; linear probing;
+ * new keys receive consecutive indices in order of FIRST OCCURRENCE in `keys` (deterministic,
+ * where the reference's atomicAdd order is racy -- see DESIGN.md q1). */
+typedef struct hctr_hashtable hctr_hashtable;
+int hctr_ht_create(size_t capacity, int key_type, hctr_hashtable** out);
+int hctr_ht_destroy(hctr_hashtable* ht);
+int hctr_ht_clear(hctr_hashtable* ht, hctr_stream_t stream);
+/* get_insert (train) / get_mark (eval: miss -> SIZE_MAX) / insert (key,val pairs).
+ * d_n: optional device uint64 holding the live count (<= n); NULL means n. */
+int hctr_ht_get_insert(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,
+                       uint64_t* value_index, hctr_stream_t stream);
+int hctr_ht_get_mark(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,
+                     uint64_t* value_index, hctr_stream_t stream);
+int hctr_ht_insert(hctr_hashtable* ht, const void* keys, const uint64_t* vals, size_t n,
+                   hctr_stream_t stream);
+/* host-synchronising queries (get_size / get_value_head / get_capacity, nv_hashtable.cu:239-301) */
+int hctr_ht_size(hctr_hashtable* ht, hctr_stream_t stream, size_t* out);
+int hctr_ht_value_head(hctr_hashtable* ht, hctr_stream_t stream, size_t* out);
+int hctr_ht_set_value_head(hctr_hashtable* ht, size_t v, hctr_stream_t stream);
+size_t hctr_ht_table_size(const hctr_hashtable* ht);
+/* dump occupied (key,val) pairs; d_keys device int64 [>=size], d_vals device uint64; host-syncs */
+int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* count,
+                 hctr_stream_t stream);
+
+/* forward_sum / forward_mean: R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:28-241.
+ * out[u,:] = sum_j table[value_index[row_offset[u]+j],:]  (SIZE_MAX index adds 0; combiner 1
+ * scales by 1/n when n > 1).  row_offset has key_type elements, [buckets+1]. */
+int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                      int key_type, const uint64_t* value_index, const float* table, void* out,
+                      int out_dtype, hctr_stream_t stream);
+
+/* forward_reorder / backward_reorder: R/HugeCTR/src/embeddings/forward_reorder_functor.cu:26-98,
+ * backward_reorder_functor.cu.  in [gpu][b][slot_in_gpu][D] <-> out [b][slot][D]. */
+int hctr_forward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,
+                         const void* in, void* out, int dtype, hctr_stream_t stream);
+int hctr_backward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,
+                          const void* in, void* out, int dtype, hctr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* IEmbedding-shaped handle: replaces LocalizedSlotSparseEmbeddingHash /                       */
+/* DistributedSlotSparseEmbeddingHash behind class IEmbedding (R/HugeCTR/include/embedding.hpp */
+/* :26-67) with SparseEmbeddingHashParams (:69-93).                                            */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int embedding_type; /* hctr_embedding_t */
+  int key_type;       /* hctr_key_t: type of keys AND row offsets, as in the reference */
+  int out_dtype;      /* hctr_emb_dtype_t of the pooled output / top gradients */
+  size_t train_batch_size;
+  size_t evaluate_batch_size;
+  size_t max_vocabulary_size_per_gpu;
+  size_t embedding_vec_size;
+  size_t max_feature_num; /* max keys per sample over all slots */
+  size_t slot_num;
+  int combiner;                  /* 0 sum, 1 mean */
+  const size_t* slot_size_array; /* [slot_num] or NULL */
+  /* OptParams, R/HugeCTR/include/optimizer.hpp:149-155 */
+  int optimizer;   /* hctr_optimizer_t */
+  int update_type; /* hctr_update_t */
+  float lr;
+  float beta1, beta2, epsilon;     /* Adam (epsilon also AdaGrad) */
+  float initial_accu_value;        /* AdaGrad */
+  float momentum_factor;           /* MomentumSGD factor / Nesterov mu */
+  int atomic_update;               /* SGD: 1 = fp32 atomicAdd path (optimizer_wrapper.hpp:40) */
+  float scaler;                    /* loss scaler the gradients are divided by */
+  /* placement: this process is GPU `rank` of `world` (global ids, resource_manager semantics) */
+  int rank;
+  int world;
+  uint64_t seed; /* table initialisation */
+} hctr_embedding_params;
+
+typedef struct hctr_embedding hctr_embedding;
+
+int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out);
+int hctr_emb_destroy(hctr_embedding* emb);
+
+/* IEmbedding::init_params: uniform(+-sqrt(1/slot_size)) per slot, or +-0.05 without slot sizes
+ * (R/HugeCTR/src/embeddings/init_embedding_functor.cu:24-55) */
+int hctr_emb_init_params(hctr_embedding* emb, hctr_stream_t stream);
+
+/* IEmbedding::forward(is_train) up to (not including) the all-to-all.
+ * row_offset [batch*slot_num+1], keys [nnz]: the FULL-batch CSR every rank receives from the
+ * reader (R/HugeCTR/src/data_readers/data_collector.cu:86-113).  Localized: filter slots with
+ * slot % world == rank, resolve + pool -> out [batch][slots_on_rank][D] (== the all-to-all send
+ * buffer [peer][batch/world][slots_on_rank][D]).  Distributed: filter keys with key % world ==
+ * rank -> partial sums out [batch][slot_num][D] (reduce-scatter input). */
+int hctr_emb_forward(hctr_embedding* emb, int is_train, const void* row_offset, const void* keys,
+                     size_t nnz, void* out, hctr_stream_t stream);
+
+/* IEmbedding::backward after the all-to-all: top_grad has the layout of forward's `out`.
+ * Zero-copy: only records the pointer; the gradient must stay valid until update_params. */
+int hctr_emb_backward(hctr_embedding* emb, const void* top_grad, hctr_stream_t stream);
+/* materialise wgrad (backward_sum/backward_mean, backward_functor.cu:26-104) for inspection */
+int hctr_emb_get_wgrad(hctr_embedding* emb, void* wgrad, hctr_stream_t stream);
+
+/* IEmbedding::update_params: EmbeddingOptimizer::update (R/HugeCTR/src/optimizers/
+ * sparse_optimizer.cu:622-864) fused with backward: sort by row, per-row ordered reduce,
+ * optimizer math on weights + state.  No host synchronisation. */
+int hctr_emb_update_params(hctr_embedding* emb, hctr_stream_t stream);
+
+int hctr_emb_set_learning_rate(hctr_embedding* emb, float lr);
+/* host-synchronising queries */
+int hctr_emb_get_vocabulary_size(hctr_embedding* emb, hctr_stream_t stream, size_t* out);
+size_t hctr_emb_get_max_vocabulary_size(const hctr_embedding* emb);
+size_t hctr_emb_slots_on_rank(const hctr_embedding* emb);
+int hctr_emb_check_overflow(hctr_embedding* emb, hctr_stream_t stream);
+
+/* dump_parameters / load_parameters (buffer form, R/.../localized_slot_sparse_embedding_hash.cu
+ * :383-440,1260-1340): keys int64, slot_id size_t (localized), emb_vector fp32, all DEVICE
+ * buffers of capacity >= vocabulary size; *count returns rows written.  Host-synchronising. */
+int hctr_emb_dump(hctr_embedding* emb, int64_t* d_keys, uint64_t* d_slot_id, float* d_vectors,
+                  size_t* count, hctr_stream_t stream);
+int hctr_emb_load(hctr_embedding* emb, const int64_t* d_keys, const uint64_t* d_slot_id,
+                  const float* d_vectors, size_t count, hctr_stream_t stream);
+/* raw device views (owned by the handle): table [max_vocab][D] fp32, optimizer state k */
+float* hctr_emb_table_ptr(hctr_embedding* emb);
+float* hctr_emb_opt_state_ptr(hctr_embedding* emb, int k);
+const uint64_t* hctr_emb_value_index_ptr(hctr_embedding* emb);
+int hctr_emb_reset(hctr_embedding* emb, hctr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dense ops on the path                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+/* InteractionLayer<T>::fprop / bprop (R/HugeCTR/src/layers/interaction_layer.cu:1046-1237).
+ * mlp [B][W], emb [B][n_emb][W] -> out [B][W + n_ins(n_ins-1)/2 + 1], n_ins = n_emb+1; pairs
+ * row-major over the strict lower triangle, last column zero. dtype: f32/f16/bf16 */
+int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
+                         void* out, int dtype, hctr_stream_t stream);
+int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
+                         const void* top_grad, void* mlp_grad, void* emb_grad, int dtype,
+                         hctr_stream_t stream);
+
+/* MultiCrossLayer<T> v1 (projection_dim = 0): x_{l+1} = x0 * (x_l . w_l) + b_l + x_l
+ * (R/HugeCTR/src/layers/multi_cross_layer.cu:582-601,1023-1060).  kernels/biases [layers][w];
+ * outputs [layers][B][w] (outputs[layers-1] is the layer output), hiddens [layers][B]. */
+int hctr_cross_v1_fwd(size_t batch, int width, int layers, const float* x0, const float* kernels,
+                      const float* biases, float* outputs, float* hiddens, hctr_stream_t stream);
+int hctr_cross_v1_bwd(size_t batch, int width, int layers, const float* x0, const float* kernels,
+                      const float* outputs, const float* hiddens, const float* out_grad,
+                      float* in_grad, float* kernel_grads, float* bias_grads, float* workspace,
+                      hctr_stream_t stream);
+size_t hctr_cross_v1_bwd_workspace_bytes(size_t batch, int width, int layers);
+
+/* DCN v2 fused epilogue: out = x0 * (h + b) + x_l  (fused_matrix_elementwise_dot_add,
+ * multi_cross_layer.cu:426-463); the two GEMMs stay in the caller's BLAS. */
+int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,
+                           const float* h, const float* bias, float* hidden_out, float* out,
+                           hctr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
