@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""bench.py -- DLRM (Criteo-1TB shape) training step on the MI355X-native embedding hot path.
+
+A "step" is one full pass of the hot path over one synthetic batch: hash/index -> per-slot gather
++ pooling -> (N > 1: all-to-all + reorder) -> bottom MLP -> dot interaction -> top MLP -> BCE
+loss -> backward -> (N > 1: reorder + all-to-all) -> sort + segmented gradient reduce + sparse
+SGD update -> dense SGD step.  Nothing is skipped inside the timed region.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N > 1 under torch.distributed.run);
+rank 0 prints ONE JSON line.  See DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# R/test/embedding_collection_test/dgx_a100_one_hot.py:24-51 -- Criteo-1TB slot_size_array
+CRITEO_1TB = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346,
+              10, 2208, 11938, 155, 4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108,
+              36]
+DENSE_DIM = 13
+BOTTOM = [512, 256, 128]          # R/samples/dlrm/train.py:415-458 bottom MLP
+TOP = [1024, 1024, 512, 256, 1]   # top MLP
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy)
+
+
+def powerlaw(rng, n, vocab, alpha):
+    """IntPowerLawDataSimulator (R/HugeCTR/include/data_generator.hpp:108-129), vectorised."""
+    if alpha <= 0:
+        return rng.integers(0, vocab, size=n).astype(np.int64)
+    u = rng.random(n, dtype=np.float32).astype(np.float64)
+    a = 1.0 - alpha
+    y = ((float(vocab) ** a - 1.0) * u + 1.0) ** (1.0 / a)
+    return np.clip(np.round(y) - 1, 0, vocab - 1).astype(np.int64)
+
+
+def make_keys(rng, batch, sizes, alpha):
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    keys = np.empty((batch, len(sizes)), dtype=np.int64)
+    for s, v in enumerate(sizes):
+        keys[:, s] = powerlaw(rng, batch, v, alpha) + offs[s]
+    return keys.reshape(-1)
+
+
+def mlp(dims, last_relu):
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(torch.nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2 or last_relu:
+            layers.append(torch.nn.ReLU())
+    return torch.nn.Sequential(*layers)
+
+
+def cpu_baseline(sizes, alpha, D, seed, budget_s=15.0):
+    """The CPU oracle (oracle/hctr_oracle.c, a line-by-line port of the reference's CPU test path
+    R/test/utest/embedding/sparse_embedding_hash_cpu.hpp) timed on this box's host cores on a
+    bounded sample of the same workload: same slot structure and key distribution, tables scaled
+    to 1/64 of the rows, B = 8192, forward + backward + SGD update (no dense tower)."""
+    from oracle import pyoracle as orc
+    scale = 64
+    ssz = [max(1, v // scale) for v in sizes]
+    V, S, B = sum(ssz), len(ssz), 8192
+    rng = np.random.default_rng(seed)
+    table = (rng.random((V, D), dtype=np.float32) - 0.5) * 0.1
+    ro = np.arange(B * S + 1, dtype=np.int64)
+    g = rng.standard_normal((B * S, D)).astype(np.float32)
+    opt = orc.OptParamsC()
+    opt.optimizer, opt.update_type, opt.lr, opt.scaler, opt.times = orc.OPT_SGD, 0, 0.01, 1.0, 1
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    res = {}
+    for label, th in (("1t", 1), ("mt", threads)):
+        ht = orc.HashTable(V, 8)
+        ht.get_insert(make_keys(rng, B, ssz, alpha))  # warm
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s / 2 and n < 50:
+            keys = make_keys(rng, B, ssz, alpha)
+            t1 = time.perf_counter()
+            vi = ht.get_insert(keys)
+            orc.forward(ro, vi, table, D, 0, threads=th)
+            wg = orc.backward(ro, g, D, 0)
+            orc.update_params(ro, vi, wg, opt, table, threads=th)
+            res.setdefault(label, []).append(time.perf_counter() - t1)
+            n += 1
+    best = {k: B / float(np.median(v)) for k, v in res.items()}
+    return {"value": best["mt"], "unit": "samples/s", "cores": threads, "kind": "port",
+            "value_1_thread": best["1t"],
+            "sample": f"embedding fwd+bwd+SGD update only (no dense tower), B={B}, 26 Criteo-1TB "
+                      f"slots one-hot power-law alpha={alpha}, D={D}, tables scaled 1/{scale} "
+                      f"({V} rows), host has {cores} logical cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=65536, help="GLOBAL batch (BASELINE config 3)")
+    ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--table-scale", type=float, default=1.0)
+    ap.add_argument("--nbatches", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--sgd-atomic", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    from hugectr_amd.parallel import LocalizedExchange
+
+    sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
+    S, D, B = len(sizes), a.dim, a.batch
+    assert B % world == 0
+    bpg = B // world
+    spr = S // world + (1 if rank < S % world else 0)
+    my_rows = sum(v for i, v in enumerate(sizes) if i % world == rank)
+    max_rows = max(sum(v for i, v in enumerate(sizes) if i % world == r) for r in range(world))
+
+    # ---- the embedding (this rank's slots), SGD as in the reference DLRM samples -----------------
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.sgd_atomic, scaler=1.0)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, max_rows, D, S, S, 0, opt,
+                                 slot_size_array=sizes, rank=rank, world=world, seed=1234)
+    emb.init_params()
+    exch = LocalizedExchange(B, S, D)
+
+    # ---- synthetic data, resident in HBM before the timed region ---------------------------------
+    rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
+    ro = torch.arange(0, B * S + 1, dtype=torch.int64, device=dev)
+    key_batches = [torch.from_numpy(make_keys(rng, B, sizes, a.alpha)).to(dev)
+                   for _ in range(a.nbatches)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99 + rank)
+    dense_batches = [torch.rand((bpg, DENSE_DIM), device=dev, generator=g) for _ in range(a.nbatches)]
+    label_batches = [(torch.rand((bpg, 1), device=dev, generator=g) < 0.5).float()
+                     for _ in range(a.nbatches)]
+
+    # ---- dense tower (PyTorch-ROCm / hipBLASLt GEMMs; interaction is our HIP kernel) ---------------
+    torch.manual_seed(7)
+    n_ins = S + 1
+    bottom = mlp([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
+    top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
+    dense_params = list(bottom.parameters()) + list(top.parameters())
+    dense_opt = torch.optim.SGD(dense_params, lr=0.01)
+    loss_fn = torch.nn.BCEWithLogitsLoss()
+    amp = a.dense_dtype == "bf16"
+    pooled = torch.empty((B, spr, D), dtype=torch.float32, device=dev)
+    flat_grads = None
+
+    def step(i):
+        keys = key_batches[i % a.nbatches]
+        dense = dense_batches[i % a.nbatches]
+        label = label_batches[i % a.nbatches]
+        emb.forward(True, ro, keys, out=pooled)
+        if world > 1:
+            recv = exch.forward(pooled)
+            E = ha.forward_reorder(recv, bpg, S, D, world)
+        else:
+            E = pooled
+        E = E.detach().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            xb = bottom(dense)
+        z = ha.interaction(xb.float(), E)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            logit = top(z)
+        loss = loss_fn(logit.float(), label)
+        loss.backward()
+        if world > 1:
+            gsend = ha.backward_reorder(E.grad, bpg, S, D, world)
+            top_grad = exch.backward(gsend)
+            grads = [p.grad for p in dense_params]
+            flat = torch.cat([x.reshape(-1) for x in grads])
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for x in grads:
+                x.copy_(flat[off:off + x.numel()].view_as(x))
+                off += x.numel()
+        else:
+            top_grad = E.grad
+        emb.backward(top_grad)
+        emb.update_params()
+        dense_opt.step()
+        dense_opt.zero_grad(set_to_none=True)
+        return loss
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    emb.profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(a.warmup, a.warmup + a.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = emb.profile()
+    emb.profiling(False)
+    emb.check_overflow()
+
+    # ---- roofline of the gather+pool kernel (algorithmic bytes, DESIGN.md / SURVEY 8d) ------------
+    nnz_g = B * spr  # one-hot: one key per (sample, slot on this rank)
+    alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * 4
+    pool_ms, pool_n = prof["gather_pool"]
+    achieved = alg_bytes / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
+    pmc = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_gather_pool.json")
+    if world == 1 and os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+        except Exception:
+            pmc = None
+    stage_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}
+
+    out = {
+        "metric": "samples/sec (whole node) + embedding-gather HBM GB/s, DLRM Criteo-1TB",
+        "value": B * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 embeddings / sparse SGD, bf16 dense GEMMs" if amp else "f32",
+        "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
+        "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
+                               "LocalizedSlotSparseEmbeddingHash, emb_dim=128, global bs=65536, SGD",
+                   "global_batch": B, "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
+                   "table_rows_this_rank": my_rows, "parallelism": f"slot-sharded x{world} + dp{world}",
+                   "final_loss": float(loss)},
+        "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
+                     "avg_launch_us": stage_us["gather_pool"]},
+        "stage_us_per_step": stage_us,
+    }
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(CRITEO_1TB, a.alpha, D, 4321)
+            except Exception as e:  # the oracle is a reported baseline, never the product path
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,8 @@ _SIGNATURES = {
     "hctr_emb_opt_state_ptr": (_P, [_P, c_int]),
     "hctr_emb_value_index_ptr": (_P, [_P]),
     "hctr_emb_reset": (c_int, [_P, _P]),
+    "hctr_emb_profiling": (c_int, [_P, c_int]),
+    "hctr_emb_profile_get": (c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]),
     "hctr_interaction_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
     "hctr_interaction_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_cross_v1_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),

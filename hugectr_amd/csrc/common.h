@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/hugectr_amd.h"
 
@@ -105,5 +106,56 @@ __host__ __device__ __forceinline__ uint32_t murmur3_key(long long key) {
   h1 ^= 8u;
   return fmix32(h1);
 }
+
+
+// Optional per-kernel timing with hipEvents recorded on the launch stream (bench.py's roofline
+// leg).  Off by default: no events are created or recorded.
+struct Profiler {
+  static constexpr int kCats = 4;  // 0 gather/pool, 1 hash/index, 2 sort, 3 segmented update
+  static constexpr size_t kMaxPairs = 16384;
+  bool enabled = false;
+  std::vector<hipEvent_t> start[kCats], stop[kCats];
+  size_t used[kCats] = {0, 0, 0, 0};
+
+  void begin(int cat, hipStream_t s) {
+    if (!enabled || used[cat] >= kMaxPairs) return;
+    if (used[cat] >= start[cat].size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      start[cat].push_back(a);
+      stop[cat].push_back(b);
+    }
+    (void)hipEventRecord(start[cat][used[cat]], s);
+  }
+  void end(int cat, hipStream_t s) {
+    if (!enabled || used[cat] >= kMaxPairs || used[cat] >= start[cat].size()) return;
+    (void)hipEventRecord(stop[cat][used[cat]], s);
+    used[cat]++;
+  }
+  void reset() {
+    for (int c = 0; c < kCats; c++) used[c] = 0;
+  }
+  int get(int cat, double* total_ms, uint64_t* launches) {
+    double tot = 0.0;
+    for (size_t i = 0; i < used[cat]; i++) {
+      if (hipEventSynchronize(stop[cat][i]) != hipSuccess) return -1;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, start[cat][i], stop[cat][i]) != hipSuccess) return -1;
+      tot += ms;
+    }
+    *total_ms = tot;
+    *launches = used[cat];
+    return 0;
+  }
+  void destroy() {
+    for (int c = 0; c < kCats; c++) {
+      for (auto e : start[c]) (void)hipEventDestroy(e);
+      for (auto e : stop[c]) (void)hipEventDestroy(e);
+      start[c].clear();
+      stop[c].clear();
+      used[c] = 0;
+    }
+  }
+};
 
 }  // namespace hctr

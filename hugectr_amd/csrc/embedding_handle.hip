@@ -251,6 +251,7 @@ struct hctr_embedding {
   int key_bytes = 8;
   HashTable ht;
   SparseUpdater upd;
+  Profiler prof;
   OptState opt;
   float* table = nullptr;
   float* state0 = nullptr;
@@ -289,6 +290,7 @@ namespace {
 int free_all(hctr_embedding* e) {
   e->ht.destroy();
   e->upd.destroy();
+  e->prof.destroy();
   void* ptrs[] = {e->table,  e->state0,  e->state1,         e->prev_time, e->slot_id,
                   e->tb.ro,  e->tb.keys, e->tb.value_index, e->eb.ro,     e->eb.keys,
                   e->eb.value_index,     e->lens,           e->tile_sums, e->d_nnz};
@@ -413,20 +415,27 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   }
   (void)d_live;
   if (nnz > 0) {
-    if (is_train) HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s));
-    else HCTR_TRY(e->ht.get_mark(keys, nnz, d_n, bb.value_index, s));
+    e->prof.begin(1, s);
+    if (is_train) {
+      SlotSink sink;
+      sink.slot_id = e->slot_id;
+      sink.row_offset = ro;
+      sink.buckets = buckets;
+      sink.buckets_per_sample = (int)e->buckets_per_sample();
+      sink.rank = e->p.rank;
+      sink.world = e->p.world;
+      sink.localized = e->p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH ? 1 : 0;
+      HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s, &sink));
+    } else {
+      HCTR_TRY(e->ht.get_mark(keys, nnz, d_n, bb.value_index, s));
+    }
+    e->prof.end(1, s);
   }
+  e->prof.begin(0, s);
   HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, e->p.combiner, ro,
                                  e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype, s));
+  e->prof.end(0, s);
   if (is_train) {
-    if (nnz > 0) {
-      const bool localized = e->p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH;
-      hipLaunchKernelGGL(store_new_slot_ids_kernel<K>, dim3(64), dim3(kBlock), 0, s,
-                         e->ht.d_new_count, e->ht.new_positions, bb.value_index, ro, buckets,
-                         (int)e->buckets_per_sample(), e->p.rank, e->p.world, localized ? 1 : 0,
-                         e->slot_id);
-      HCTR_LAUNCH_CHECK();
-    }
     e->cur_buckets = buckets;
     e->cur_nnz_bound = nnz;
     e->has_train_batch = true;
@@ -534,6 +543,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   if ((rc = e->ht.create(V, p.key_type)) != HCTR_OK) return fail(rc);
   if ((rc = e->ht.reserve(e->nnz_max)) != HCTR_OK) return fail(rc);
   if ((rc = e->upd.create(e->nnz_max, V, (int)D)) != HCTR_OK) return fail(rc);
+  e->upd.prof = &e->prof;
   e->opt.optimizer = p.optimizer;
   e->opt.update_type = p.update_type;
   e->opt.lr = p.lr;
@@ -753,6 +763,23 @@ int hctr_emb_load(hctr_embedding* e, const int64_t* d_keys, const uint64_t* d_sl
   (void)hipFree(rows);
   if (keys_typed) (void)hipFree(keys_typed);
   return rc;
+}
+
+int hctr_emb_profiling(hctr_embedding* e, int enable) {
+  HCTR_REQUIRE(e, "null handle");
+  e->prof.enabled = enable != 0;
+  e->prof.reset();
+  return HCTR_OK;
+}
+
+int hctr_emb_profile_get(hctr_embedding* e, int which, double* total_ms, uint64_t* launches) {
+  HCTR_REQUIRE(e && total_ms && launches, "null pointer");
+  HCTR_REQUIRE(which >= 0 && which < Profiler::kCats, "which");
+  if (e->prof.get(which, total_ms, launches) != 0) {
+    set_error("hipEventElapsedTime failed");
+    return HCTR_ERR_HIP;
+  }
+  return HCTR_OK;
 }
 
 float* hctr_emb_table_ptr(hctr_embedding* e) { return e ? e->table : nullptr; }

@@ -13,6 +13,14 @@ struct HtEntry {
 constexpr uint64_t kPendingBit = 1ull << 63;
 constexpr int kHtTile = 1024;  // positions per compaction tile
 
+// where get_insert records the slot id of newly inserted rows (embedding dump needs it)
+struct SlotSink {
+  uint64_t* slot_id;
+  const void* row_offset;  // key-typed CSR row offsets of the batch
+  size_t buckets;
+  int buckets_per_sample, rank, world, localized;
+};
+
 struct HashTable {
   HtEntry* entries = nullptr;
   uint64_t size = 0;      // physical slots = (size_t)(capacity / 0.75f)
@@ -22,6 +30,7 @@ struct HashTable {
   uint64_t* d_counter = nullptr;    // value head (next row index)
   uint64_t* d_base = nullptr;       // counter snapshot used by the current get_insert
   uint32_t* d_pending = nullptr;    // != 0 when the current batch holds unseen keys
+  uint32_t* d_latched = nullptr;    // d_pending as seen by the scan step of this get_insert
   uint32_t* d_error = nullptr;      // bit0: probe overflow (table full) bit1: counter > capacity
   uint64_t* d_new_count = nullptr;  // number of keys inserted by the last get_insert
   // scratch sized for max_n positions
@@ -34,7 +43,8 @@ struct HashTable {
   int destroy();
   int clear(hipStream_t s);
   int reserve(size_t n);  // scratch for batches up to n keys
-  int get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s);
+  int get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s,
+                 const SlotSink* sink = nullptr);
   int get_mark(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s);
   int insert(const void* keys, const uint64_t* vals, size_t n, hipStream_t s);
   int count(hipStream_t s, size_t* out);

@@ -143,22 +143,77 @@ __global__ void __launch_bounds__(1024)
   if (threadIdx.x == 0) *d_total = carry;
 }
 
-__global__ void ht_bump_counter_kernel(const uint32_t* d_pending, uint64_t* d_counter,
-                                       uint64_t* d_base, const uint64_t* d_new_count,
-                                       uint64_t capacity, uint32_t* d_error) {
-  uint64_t c = *d_counter;
-  *d_base = c;
-  if (*d_pending == 0u) return;
-  c += *d_new_count;
-  *d_counter = c;
-  if (c > capacity) atomicOr(d_error, 2u);
+// get_insert step S: scan the per-tile counts of new keys, hand out the index range
+// [counter, counter + new) and latch/reset the "batch has unseen keys" flag so that the next
+// get_insert needs no memset.
+__global__ void __launch_bounds__(1024)
+    ht_scan_bump_kernel(uint32_t* sums, size_t m, uint32_t* d_pending, uint32_t* d_latched,
+                        uint64_t* d_counter, uint64_t* d_base, uint64_t* d_new_count,
+                        uint64_t capacity, uint32_t* d_error) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint64_t carry;
+  const uint32_t pending = *d_pending;
+  if (pending == 0u) {
+    if (threadIdx.x == 0) {
+      *d_latched = 0u;
+      *d_new_count = 0;
+      *d_base = *d_counter;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < m; base += 1024) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = (i < m) ? sums[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<uint32_t, 1024>(v, smem, &tot);
+    uint64_t c = carry;
+    if (i < m) sums[i] = (uint32_t)(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t c0 = *d_counter;
+    *d_base = c0;
+    *d_new_count = carry;
+    *d_counter = c0 + carry;
+    if (c0 + carry > capacity) atomicOr(d_error, 2u);
+    *d_latched = 1u;
+    *d_pending = 0u;
+  }
+}
+
+// optional: record the slot id of every newly inserted row (store_slot_id_kernel semantics,
+// R/HugeCTR/src/embeddings/store_slot_id_functor.cu:26-48, restricted to rows that are new)
+struct SlotIdSink {
+  uint64_t* slot_id;       // nullptr = off
+  const void* row_offset;  // CSR of the batch being resolved (key-typed)
+  int key_is_u32;
+  size_t buckets;
+  int buckets_per_sample, rank, world, localized;
+};
+
+__device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos, uint64_t row) {
+  size_t lo = 0, hi = k.buckets;
+  while (lo < hi) {  // bucket u with ro[u] <= pos < ro[u+1]
+    const size_t mid = (lo + hi) >> 1;
+    const uint64_t e = k.key_is_u32 ? (uint64_t)((const uint32_t*)k.row_offset)[mid + 1]
+                                    : (uint64_t)((const long long*)k.row_offset)[mid + 1];
+    if (e <= pos) lo = mid + 1;
+    else hi = mid;
+  }
+  const int j = (int)(lo % (size_t)k.buckets_per_sample);
+  k.slot_id[row] = (uint64_t)(k.localized ? k.rank + j * k.world : j);
 }
 
 __global__ void __launch_bounds__(kBlock)
     ht_assign_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
                      const uint64_t* d_n, const uint32_t* d_pending,
                      const uint32_t* __restrict__ tile_sums, size_t n_tiles,
-                     const uint64_t* d_base, uint64_t* __restrict__ new_positions) {
+                     const uint64_t* d_base, uint64_t* __restrict__ new_positions,
+                     SlotIdSink sink) {
   if (*d_pending == 0u) return;
   __shared__ uint32_t smem[kBlock / 64 + 1];
   const size_t nl = live_count(d_n, n);
@@ -178,6 +233,7 @@ __global__ void __launch_bounds__(kBlock)
         tab[o & ~kPendingBit].val = fin;
         out[i] = fin;
         new_positions[rank] = (uint64_t)i;
+        if (sink.slot_id != nullptr) record_slot_id(sink, (uint64_t)i, fin);
       }
       run += tot;
     }
@@ -323,6 +379,7 @@ int HashTable::create(size_t cap, int kt) {
   d_scratch64 = scal + 3;
   d_pending = reinterpret_cast<uint32_t*>(scal + 4);
   d_error = reinterpret_cast<uint32_t*>(scal + 4) + 1;
+  d_latched = reinterpret_cast<uint32_t*>(scal + 5);
   HCTR_HIP(hipMemset(scal, 0, 64));
   return clear(nullptr);
 }
@@ -362,10 +419,27 @@ int HashTable::reserve(size_t n) {
 }
 
 int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out,
-                          hipStream_t s) {
+                          hipStream_t s, const SlotSink* sink_in) {
   if (n == 0) return HCTR_OK;
   HCTR_TRY(reserve(n));
-  HCTR_HIP(hipMemsetAsync(d_pending, 0, sizeof(uint32_t), s));
+  SlotIdSink sink;
+  sink.slot_id = nullptr;
+  sink.row_offset = nullptr;
+  sink.key_is_u32 = key_type == HCTR_KEY_U32;
+  sink.buckets = 0;
+  sink.buckets_per_sample = 1;
+  sink.rank = 0;
+  sink.world = 1;
+  sink.localized = 0;
+  if (sink_in != nullptr) {
+    sink.slot_id = sink_in->slot_id;
+    sink.row_offset = sink_in->row_offset;
+    sink.buckets = sink_in->buckets;
+    sink.buckets_per_sample = sink_in->buckets_per_sample;
+    sink.rank = sink_in->rank;
+    sink.world = sink_in->world;
+    sink.localized = sink_in->localized;
+  }
   const int grid = grid_for(n, kBlock);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
@@ -375,22 +449,21 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
                        size, (const long long*)keys, n, d_n, out, d_pending, d_error);
   }
   HCTR_LAUNCH_CHECK();
+  // steps B..D2 exit on one scalar load when the batch holds no unseen key (steady state);
+  // small grids keep those empty launches cheap, grid-stride covers the cold-start case.
   const size_t n_tiles = ceil_div<size_t>(n, kHtTile);
-  const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+  const int tgrid = (int)(n_tiles < (size_t)512 ? n_tiles : (size_t)512);
   hipLaunchKernelGGL(ht_flag_count_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
                      d_pending, tile_sums, n_tiles);
   HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(1024), 0, s, tile_sums, n_tiles, d_pending,
-                     d_new_count);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ht_bump_counter_kernel, dim3(1), dim3(1), 0, s, d_pending, d_counter, d_base,
-                     d_new_count, capacity, d_error);
+  hipLaunchKernelGGL(ht_scan_bump_kernel, dim3(1), dim3(1024), 0, s, tile_sums, n_tiles, d_pending,
+                     d_latched, d_counter, d_base, d_new_count, capacity, d_error);
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(ht_assign_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
-                     d_pending, tile_sums, n_tiles, d_base, new_positions);
+                     d_latched, tile_sums, n_tiles, d_base, new_positions, sink);
   HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ht_resolve_kernel, dim3(grid), dim3(kBlock), 0, s, entries, out, n, d_n,
-                     d_pending);
+  hipLaunchKernelGGL(ht_resolve_kernel, dim3(grid_for(n, kBlock, 512)), dim3(kBlock), 0, s,
+                     entries, out, n, d_n, d_latched);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
@@ -533,7 +606,7 @@ int hctr_ht_clear(hctr_hashtable* ht, hctr_stream_t stream) {
 int hctr_ht_get_insert(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,
                        uint64_t* value_index, hctr_stream_t stream) {
   HCTR_REQUIRE(ht && (n == 0 || (keys && value_index)), "null pointer");
-  return ht->impl.get_insert(keys, n, d_n, value_index, as_stream(stream));
+  return ht->impl.get_insert(keys, n, d_n, value_index, as_stream(stream), nullptr);
 }
 
 int hctr_ht_get_mark(hctr_hashtable* ht, const void* keys, size_t n, const uint64_t* d_n,

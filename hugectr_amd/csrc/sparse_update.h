@@ -31,6 +31,11 @@ struct SparseUpdater {
   uint32_t* tile_sums = nullptr;
   uint32_t* run_start = nullptr;  // [max_nnz + 1]
   uint64_t* d_num_runs = nullptr;
+  // tile-based segmented reduce: partial sums of runs that cross tile borders
+  float* seg_head = nullptr;    // [tiles][D]
+  float* seg_tail = nullptr;    // [tiles][D]
+  uint8_t* seg_flag = nullptr;  // [tiles] 1 = a border-crossing run starts in this tile
+  Profiler* prof = nullptr;
 
   int create(size_t max_nnz, size_t max_vocab, int D);
   int destroy();

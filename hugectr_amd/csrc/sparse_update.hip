@@ -229,102 +229,194 @@ __device__ __forceinline__ bool needs_pt(const OptConst& o) {
   return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
 }
 
+// Row update shared by the tile kernel and the spanning-run combine kernel: gi = acc / scaler,
+// then the optimizer on the 4 elements this lane owns.
+template <int LPR>
+__device__ __forceinline__ void apply_row_vec4(const OptConst& o, uint64_t row, int l, float4 gi,
+                                               float* __restrict__ table,
+                                               float* __restrict__ state0,
+                                               float* __restrict__ state1,
+                                               unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  gi.x /= o.scaler;
+  gi.y /= o.scaler;
+  gi.z /= o.scaler;
+  gi.w /= o.scaler;
+  const size_t f = row * (uint64_t)D + l * 4;
+  float4 w = *reinterpret_cast<float4*>(table + f);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  unsigned long long pt[4] = {1ull, 1ull, 1ull, 1ull};
+  if (needs_s0(o)) s0 = *reinterpret_cast<float4*>(state0 + f);
+  if (needs_s1(o)) s1 = *reinterpret_cast<float4*>(state1 + f);
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) pt[t] = prev_time[f + t];
+  }
+  apply_opt(o, gi.x, w.x, &s0.x, &s1.x, &pt[0]);
+  apply_opt(o, gi.y, w.y, &s0.y, &s1.y, &pt[1]);
+  apply_opt(o, gi.z, w.z, &s0.z, &s1.z, &pt[2]);
+  apply_opt(o, gi.w, w.w, &s0.w, &s1.w, &pt[3]);
+  const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
+                           o.update_type == HCTR_UPDATE_GLOBAL);
+  if (w_written) *reinterpret_cast<float4*>(table + f) = w;
+  if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = s0;
+  if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = s1;
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) prev_time[f + t] = pt[t];
+  }
+}
+
+// Tile-based segmented reduce + optimizer.  The sorted (row, bucket) list is cut into tiles of
+// kSegTile positions; a group of LPR lanes walks one tile in order, so every group performs the
+// same number of gradient-row reads no matter how skewed the key distribution is (the reference
+// gives one block to each unique row, sparse_optimizer.cu:223-237 -- a power-law head row with
+// 20k duplicates is then one serial 20k-iteration loop).  Runs that lie inside one tile are
+// reduced in ascending bucket order (the reference's order) and applied at once.  A run that
+// crosses tile borders leaves partial sums: `tail[t]` in the tile where it starts, `head[t']` in
+// every later tile it touches; seg_combine_kernel finishes those rows in fixed order.
+constexpr int kSegTile = 32;
+
 template <int LPR, typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
-    update_rows_vec4_kernel(const uint64_t* __restrict__ d_num_runs,
-                            const uint32_t* __restrict__ run_start,
-                            const SortK* __restrict__ sorted_rows,
-                            const uint32_t* __restrict__ sorted_buckets,
-                            const OffT* __restrict__ row_offset, int combiner,
-                            const GradT* __restrict__ grad, OptConst o, float* __restrict__ table,
-                            float* __restrict__ state0, float* __restrict__ state1,
-                            unsigned long long* __restrict__ prev_time) {
+    seg_update_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                      const SortK* __restrict__ sorted_rows,
+                      const uint32_t* __restrict__ sorted_buckets, int combiner,
+                      const GradT* __restrict__ grad, OptConst o, float* __restrict__ table,
+                      float* __restrict__ state0, float* __restrict__ state1,
+                      unsigned long long* __restrict__ prev_time, float* __restrict__ head,
+                      float* __restrict__ tail, uint8_t* __restrict__ tail_flag) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   constexpr int U = 4;
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
-  const size_t num_runs = (size_t)*d_num_runs;
-  for (size_t r = (size_t)blockIdx.x * GPB + g; r < num_runs; r += (size_t)gridDim.x * GPB) {
-    const uint32_t off = run_start[r];
-    const uint32_t cnt = run_start[r + 1] - off;
-    const uint64_t row = (uint64_t)sorted_rows[off];
-    float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t k = 0;
-    for (; k + U <= cnt; k += U) {
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
+  for (size_t tile = (size_t)blockIdx.x * GPB + g; tile < n_tiles;
+       tile += (size_t)gridDim.x * GPB) {
+    const size_t base = tile * kSegTile;
+    const size_t end = (base + kSegTile < nnz) ? base + kSegTile : nnz;
+    SortK cur_row = sorted_rows[base];
+    bool cont = base > 0 && sorted_rows[base - 1] == cur_row;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t k = base; k < end; k += U) {
+      SortK r[U];
       uint32_t b[U];
       float4 v[U];
-      float sc[U];
 #pragma unroll
-      for (int t = 0; t < U; t++) b[t] = sorted_buckets[off + k + t];
+      for (int t = 0; t < U; t++) {
+        const size_t kk = (k + t < end) ? k + t : end - 1;
+        r[t] = sorted_rows[kk];
+        b[t] = sorted_buckets[kk];
+      }
 #pragma unroll
       for (int t = 0; t < U; t++) v[t] = Load4<GradT>::ld(grad + (size_t)b[t] * D + l * 4);
       if (combiner == 1) {
 #pragma unroll
         for (int t = 0; t < U; t++) {
-          long long n = (long long)row_offset[b[t] + 1] - (long long)row_offset[b[t]];
-          sc[t] = n > 1 ? 1.0f / (float)n : 1.0f;
-        }
-#pragma unroll
-        for (int t = 0; t < U; t++) {
-          v[t].x = Load4<GradT>::rnd(v[t].x * sc[t]);
-          v[t].y = Load4<GradT>::rnd(v[t].y * sc[t]);
-          v[t].z = Load4<GradT>::rnd(v[t].z * sc[t]);
-          v[t].w = Load4<GradT>::rnd(v[t].w * sc[t]);
+          const long long n = (long long)row_offset[b[t] + 1] - (long long)row_offset[b[t]];
+          const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
+          v[t].x = Load4<GradT>::rnd(v[t].x * sc);
+          v[t].y = Load4<GradT>::rnd(v[t].y * sc);
+          v[t].z = Load4<GradT>::rnd(v[t].z * sc);
+          v[t].w = Load4<GradT>::rnd(v[t].w * sc);
         }
       }
 #pragma unroll
       for (int t = 0; t < U; t++) {
-        gi.x += v[t].x;
-        gi.y += v[t].y;
-        gi.z += v[t].z;
-        gi.w += v[t].w;
+        if (k + t < end) {
+          if (r[t] != cur_row) {
+            if (cont) *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
+            else apply_row_vec4<LPR>(o, (uint64_t)cur_row, l, acc, table, state0, state1, prev_time);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur_row = r[t];
+            cont = false;
+          }
+          acc.x += v[t].x;
+          acc.y += v[t].y;
+          acc.z += v[t].z;
+          acc.w += v[t].w;
+        }
       }
     }
-    for (; k < cnt; k++) {
-      const uint32_t b = sorted_buckets[off + k];
-      float4 v = Load4<GradT>::ld(grad + (size_t)b * D + l * 4);
-      if (combiner == 1) {
-        long long n = (long long)row_offset[b + 1] - (long long)row_offset[b];
-        const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
-        v.x = Load4<GradT>::rnd(v.x * sc);
-        v.y = Load4<GradT>::rnd(v.y * sc);
-        v.z = Load4<GradT>::rnd(v.z * sc);
-        v.w = Load4<GradT>::rnd(v.w * sc);
-      }
-      gi.x += v.x;
-      gi.y += v.y;
-      gi.z += v.z;
-      gi.w += v.w;
+    const bool continues = (end < nnz) && sorted_rows[end] == cur_row;
+    if (cont) {
+      *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
+    } else if (continues) {
+      *reinterpret_cast<float4*>(tail + tile * D + l * 4) = acc;
+    } else {
+      apply_row_vec4<LPR>(o, (uint64_t)cur_row, l, acc, table, state0, state1, prev_time);
     }
-    gi.x /= o.scaler;
-    gi.y /= o.scaler;
-    gi.z /= o.scaler;
-    gi.w /= o.scaler;
+    if (l == 0) tail_flag[tile] = (!cont && continues) ? 1 : 0;
+  }
+}
 
-    const size_t f = row * (uint64_t)D + l * 4;
-    float4 w = *reinterpret_cast<float4*>(table + f);
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    unsigned long long pt[4] = {1ull, 1ull, 1ull, 1ull};
-    if (needs_s0(o)) s0 = *reinterpret_cast<float4*>(state0 + f);
-    if (needs_s1(o)) s1 = *reinterpret_cast<float4*>(state1 + f);
-    if (needs_pt(o)) {
+// One workgroup per run that crosses tile borders (it starts in the tile whose tail_flag is set).
+// Group q adds head partials of tiles t0+1+q, t0+1+q+GPB, ...; the GPB sums are then added to
+// tail[t0] in the fixed order q = 0..GPB-1 (deterministic).
+template <int LPR, typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    seg_combine_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                       const SortK* __restrict__ sorted_rows, OptConst o,
+                       float* __restrict__ table, float* __restrict__ state0,
+                       float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                       const float* __restrict__ head, const float* __restrict__ tail,
+                       const uint8_t* __restrict__ tail_flag) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  __shared__ float4 part[kBlock];
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
+  for (size_t t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x) {
+    if (tail_flag[t0] == 0) continue;  // block-uniform
+    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // 8 head partials in flight per group (a 20k-duplicate head row spans ~680 tiles)
+    constexpr int CU = 8;
+    bool more = true;
+    for (size_t t = t0 + 1 + g; more; t += (size_t)GPB * CU) {
+      bool in[CU];
+      float4 h[CU];
 #pragma unroll
-      for (int t = 0; t < 4; t++) pt[t] = prev_time[f + t];
-    }
-    apply_opt(o, gi.x, w.x, &s0.x, &s1.x, &pt[0]);
-    apply_opt(o, gi.y, w.y, &s0.y, &s1.y, &pt[1]);
-    apply_opt(o, gi.z, w.z, &s0.z, &s1.z, &pt[2]);
-    apply_opt(o, gi.w, w.w, &s0.w, &s1.w, &pt[3]);
-    const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
-                             o.update_type == HCTR_UPDATE_GLOBAL);
-    if (w_written) *reinterpret_cast<float4*>(table + f) = w;
-    if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = s0;
-    if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = s1;
-    if (needs_pt(o)) {
+      for (int c = 0; c < CU; c++) {
+        const size_t tt = t + (size_t)c * GPB;
+        in[c] = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+      }
 #pragma unroll
-      for (int t = 0; t < 4; t++) prev_time[f + t] = pt[t];
+      for (int c = 0; c < CU; c++) {
+        const size_t tt = t + (size_t)c * GPB;
+        h[c] = in[c] ? *reinterpret_cast<const float4*>(head + tt * D + l * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        if (in[c]) {
+          acc.x += h[c].x;
+          acc.y += h[c].y;
+          acc.z += h[c].z;
+          acc.w += h[c].w;
+        }
+      }
+      more = in[CU - 1];
     }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0) {
+      float4 tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+#pragma unroll
+      for (int q = 0; q < GPB; q++) {
+        const float4 pq = part[q * LPR + l];
+        tot.x += pq.x;
+        tot.y += pq.y;
+        tot.z += pq.z;
+        tot.w += pq.w;
+      }
+      apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+    }
+    __syncthreads();
   }
 }
 
@@ -519,52 +611,61 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= u.max_vocab) end_bit++;
     end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
     size_t tb = u.sort_temp_bytes;
+    if (u.prof) u.prof->begin(2, s);
     HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, nnz,
                                end_bit, s));
-    const size_t n_tiles = ceil_div<size_t>(nnz, kTile);
-    const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
-    hipLaunchKernelGGL((run_count_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout, ro,
-                       buckets, n_tiles, u.tile_sums);
-    HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_tiles_u32_kernel, dim3(1), dim3(1024), 0, s, u.tile_sums, n_tiles,
-                       u.d_num_runs);
-    HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL((run_write_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout, ro,
-                       buckets, n_tiles, u.tile_sums, u.d_num_runs, u.run_start);
-    HCTR_LAUNCH_CHECK();
-
+    if (u.prof) u.prof->end(2, s);
+    if (u.prof) u.prof->begin(3, s);
     const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
-#define HCTR_UPD_CASE(LPR_)                                                                      \
-  {                                                                                              \
-    constexpr int GPB = kBlock / LPR_;                                                           \
-    const int grid = grid_for(nnz, GPB, 256 * 8);                                                \
-    hipLaunchKernelGGL((update_rows_vec4_kernel<LPR_, OffT, SortK, GradT>), dim3(grid),         \
-                       dim3(kBlock), 0, s, u.d_num_runs, u.run_start, kout, u.sort_vals_out, ro, \
-                       combiner, grad, o, table, state0, state1,                                 \
-                       (unsigned long long*)prev_time);                                          \
-  }
     bool done = false;
+#define HCTR_SEG_CASE(LPR_)                                                                       \
+  {                                                                                               \
+    constexpr int GPB = kBlock / LPR_;                                                            \
+    const size_t seg_tiles = ceil_div<size_t>(nnz, (size_t)kSegTile);                             \
+    hipLaunchKernelGGL((seg_update_kernel<LPR_, OffT, SortK, GradT>),                             \
+                       dim3(grid_for(seg_tiles, GPB, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,  \
+                       kout, u.sort_vals_out, combiner, grad, o, table, state0, state1,           \
+                       (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.seg_flag);       \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
+                       dim3(grid_for(seg_tiles, 1, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,    \
+                       kout, o, table, state0, state1, (unsigned long long*)prev_time,            \
+                       u.seg_head, u.seg_tail, u.seg_flag);                                       \
+  }
     if (a16 && D % 4 == 0) {
       done = true;
       switch (D / 4) {
-        case 1: HCTR_UPD_CASE(1) break;
-        case 2: HCTR_UPD_CASE(2) break;
-        case 4: HCTR_UPD_CASE(4) break;
-        case 8: HCTR_UPD_CASE(8) break;
-        case 16: HCTR_UPD_CASE(16) break;
-        case 32: HCTR_UPD_CASE(32) break;
-        case 64: HCTR_UPD_CASE(64) break;
+        case 1: HCTR_SEG_CASE(1) break;
+        case 2: HCTR_SEG_CASE(2) break;
+        case 4: HCTR_SEG_CASE(4) break;
+        case 8: HCTR_SEG_CASE(8) break;
+        case 16: HCTR_SEG_CASE(16) break;
+        case 32: HCTR_SEG_CASE(32) break;
+        case 64: HCTR_SEG_CASE(64) break;
         default: done = false;
       }
     }
-#undef HCTR_UPD_CASE
+#undef HCTR_SEG_CASE
     if (!done) {
+      // generic embedding_vec_size: run detection + one wavefront per unique row
+      const size_t n_tiles = ceil_div<size_t>(nnz, kTile);
+      const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+      hipLaunchKernelGGL((run_count_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout,
+                         ro, buckets, n_tiles, u.tile_sums);
+      HCTR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(scan_tiles_u32_kernel, dim3(1), dim3(1024), 0, s, u.tile_sums, n_tiles,
+                         u.d_num_runs);
+      HCTR_LAUNCH_CHECK();
+      hipLaunchKernelGGL((run_write_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout,
+                         ro, buckets, n_tiles, u.tile_sums, u.d_num_runs, u.run_start);
+      HCTR_LAUNCH_CHECK();
       hipLaunchKernelGGL((update_rows_generic_kernel<OffT, SortK, GradT>),
                          dim3(grid_for(nnz * 64, kBlock)), dim3(kBlock), 0, s, u.d_num_runs,
                          u.run_start, kout, u.sort_vals_out, ro, combiner, D, grad, o, table,
                          state0, state1, (unsigned long long*)prev_time);
     }
     HCTR_LAUNCH_CHECK();
+    if (u.prof) u.prof->end(3, s);
   }
 
   if (opt.update_type == HCTR_UPDATE_GLOBAL) {
@@ -586,10 +687,8 @@ template <typename OffT, typename GradT>
 int update_sortk(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
                  const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
                  float* s0, float* s1, uint64_t* pt, hipStream_t s) {
-  if (u.key32)
-    return update_typed<OffT, uint32_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
-                                               s0, s1, pt, s);
-  return update_typed<OffT, uint64_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
+  // row indices are sorted as 32-bit keys; create() rejects tables with >= 2^32 rows per GPU
+  return update_typed<OffT, uint32_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
                                              s0, s1, pt, s);
 }
 
@@ -619,37 +718,42 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   max_nnz = max_nnz_ > 0 ? max_nnz_ : 1;
   max_vocab = max_vocab_;
   D = D_;
-  key32 = max_vocab < 0xFFFFFFF0ull;
-  const size_t ksz = key32 ? 4 : 8;
+  key32 = true;
+  if (max_vocab >= 0xFFFFFFF0ull) {
+    set_error("more than 2^32 - 16 rows per GPU are not supported by the sparse update");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  const size_t ksz = 4;
   HCTR_HIP(hipMalloc(&sort_keys_in, max_nnz * ksz));
   HCTR_HIP(hipMalloc(&sort_keys_out, max_nnz * ksz));
   HCTR_HIP(hipMalloc(&sort_vals_in, max_nnz * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&sort_vals_out, max_nnz * sizeof(uint32_t)));
   size_t tb = 0;
-  if (key32) {
-    HCTR_TRY(sort_pairs<uint32_t>(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  nullptr, nullptr, max_nnz, 32, nullptr));
-  } else {
-    HCTR_TRY(sort_pairs<uint64_t>(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  nullptr, nullptr, max_nnz, 64, nullptr));
-  }
+  HCTR_TRY(sort_pairs<uint32_t>(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, nullptr,
+                                nullptr, max_nnz, 32, nullptr));
   sort_temp_bytes = tb > 0 ? tb : 16;
   HCTR_HIP(hipMalloc(&sort_temp, sort_temp_bytes));
   HCTR_HIP(hipMalloc(&tile_sums, (ceil_div<size_t>(max_nnz, kTile) + 1) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&run_start, (max_nnz + 2) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&d_num_runs, sizeof(uint64_t)));
   HCTR_HIP(hipMemset(d_num_runs, 0, sizeof(uint64_t)));
+  const size_t seg_tiles = ceil_div<size_t>(max_nnz, (size_t)kSegTile) + 1;
+  HCTR_HIP(hipMalloc(&seg_head, seg_tiles * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&seg_flag, seg_tiles));
   return HCTR_OK;
 }
 
 int SparseUpdater::destroy() {
-  void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out,
-                  sort_temp,    tile_sums,     run_start,    d_num_runs};
+  void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
+                  run_start,    d_num_runs,    seg_head,     seg_tail,      seg_flag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   sort_keys_in = sort_keys_out = sort_temp = nullptr;
   sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
   d_num_runs = nullptr;
+  seg_head = seg_tail = nullptr;
+  seg_flag = nullptr;
   return HCTR_OK;
 }
 

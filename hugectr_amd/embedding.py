@@ -178,6 +178,21 @@ class SparseEmbeddingHash:
         check(lib.hctr_emb_load(self._h, ptr(keys), ptr(slot_id), ptr(vectors), keys.numel(),
                                 stream_ptr()))
 
+    # -- measurement support ----------------------------------------------------------------------
+    PROFILE_STAGES = ("gather_pool", "hash_index", "sort", "segmented_update")
+
+    def profiling(self, enable: bool):
+        check(lib.hctr_emb_profiling(self._h, 1 if enable else 0))
+
+    def profile(self) -> dict:
+        """{stage: (total_ms, launches)} measured with hipEvents on the launch stream."""
+        res = {}
+        for i, name in enumerate(self.PROFILE_STAGES):
+            ms, n = ctypes.c_double(), ctypes.c_uint64()
+            check(lib.hctr_emb_profile_get(self._h, i, ctypes.byref(ms), ctypes.byref(n)))
+            res[name] = (ms.value, int(n.value))
+        return res
+
     # -- raw views (owned by the handle) ----------------------------------------------------------
     def _view(self, addr: int, shape, dtype):
         n = 1

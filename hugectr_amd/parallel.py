@@ -1,0 +1,97 @@
+"""Multi-GPU exchange of the localized / distributed slot embeddings: one process per GPU,
+torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+Wire layout and counts follow the reference exactly
+(R/HugeCTR/src/embeddings/all2all_forward_functor.cu:157-264, all2all_backward_functor.cu,
+reduce_scatter_functor.cu:22-65, all_gather_functor.cu:58):
+
+  localized forward : rank r sends to peer j the sample slice j of its pooled vectors,
+                      (B/N) * S_r * D elements, and receives (B/N) * S_j * D from j
+                      -> recv buffer [peer][b_local][slot_in_peer][D] -> forward_reorder
+  localized backward: the mirror all-to-all of the top gradients
+  distributed forward: reduce-scatter(sum) of [B, S, D] partial sums -> [B/N, S, D]
+  distributed backward: all-gather of the [B/N, S, D] top gradients -> [B, S, D]
+
+Nothing here computes embeddings; this module only moves buffers, so it runs unchanged on CPU
+tensors with gloo (tests/test_parallel_cpu.py).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+def slots_on_rank(slot_num: int, rank: int, world: int) -> int:
+    """R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:176-183"""
+    return slot_num // world + (1 if rank < slot_num % world else 0)
+
+
+def localized_split_sizes(batch: int, slot_num: int, vec: int, rank: int, world: int):
+    """element counts (send_to_peer[j], recv_from_peer[j]) of the embedding-vector all-to-all."""
+    bpg = batch // world
+    send = [bpg * slots_on_rank(slot_num, rank, world) * vec] * world
+    recv = [bpg * slots_on_rank(slot_num, j, world) * vec for j in range(world)]
+    return send, recv
+
+
+class LocalizedExchange:
+    """all-to-all of pooled vectors (forward) and of top gradients (backward)."""
+
+    def __init__(self, batch: int, slot_num: int, vec: int, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert batch % self.world == 0, "batch must be divisible by the number of GPUs"
+        self.batch, self.slot_num, self.vec = batch, slot_num, vec
+        self.bpg = batch // self.world
+        self.send, self.recv = localized_split_sizes(batch, slot_num, vec, self.rank, self.world)
+
+    def forward(self, pooled: torch.Tensor) -> torch.Tensor:
+        """pooled [B, S_r, D] (== [peer][B/N][S_r][D]) -> recv buffer [sum_j (B/N) S_j D]"""
+        flat = pooled.reshape(-1)
+        assert flat.numel() == sum(self.send)
+        if self.world == 1:
+            return flat
+        out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
+        dist.all_to_all_single(out, flat, output_split_sizes=self.recv, input_split_sizes=self.send,
+                               group=self.group)
+        return out
+
+    def backward(self, grad_send: torch.Tensor) -> torch.Tensor:
+        """grad_send: backward_reorder output [sum_j (B/N) S_j D] -> [B, S_r, D] top gradients"""
+        flat = grad_send.reshape(-1)
+        assert flat.numel() == sum(self.recv)
+        s_r = slots_on_rank(self.slot_num, self.rank, self.world)
+        if self.world == 1:
+            return flat.view(self.batch, s_r, self.vec)
+        out = torch.empty(sum(self.send), dtype=grad_send.dtype, device=grad_send.device)
+        dist.all_to_all_single(out, flat, output_split_sizes=self.send, input_split_sizes=self.recv,
+                               group=self.group)
+        return out.view(self.batch, s_r, self.vec)
+
+
+class DistributedExchange:
+    """reduce-scatter (forward) / all-gather (backward) of the distributed-slot embedding."""
+
+    def __init__(self, batch: int, slot_num: int, vec: int, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.batch, self.slot_num, self.vec = batch, slot_num, vec
+        self.bpg = batch // self.world
+
+    def forward(self, partial: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return partial.view(self.bpg, self.slot_num, self.vec)
+        out = torch.empty((self.bpg, self.slot_num, self.vec), dtype=partial.dtype,
+                          device=partial.device)
+        dist.reduce_scatter_tensor(out, partial.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def backward(self, grad: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return grad.view(self.batch, self.slot_num, self.vec)
+        out = torch.empty((self.batch, self.slot_num, self.vec), dtype=grad.dtype, device=grad.device)
+        dist.all_gather_into_tensor(out, grad.contiguous(), group=self.group)
+        return out

@@ -173,6 +173,12 @@ float* hctr_emb_opt_state_ptr(hctr_embedding* emb, int k);
 const uint64_t* hctr_emb_value_index_ptr(hctr_embedding* emb);
 int hctr_emb_reset(hctr_embedding* emb, hctr_stream_t stream);
 
+/* Measurement support (bench.py roofline leg; no reference counterpart): when enabled, hipEvents
+ * are recorded on the launch stream around  which = 0 the gather+pool kernel, 1 the hash/index
+ * stage, 2 the radix sort, 3 the segmented reduce + optimizer kernels.  profile_get host-syncs. */
+int hctr_emb_profiling(hctr_embedding* emb, int enable);
+int hctr_emb_profile_get(hctr_embedding* emb, int which, double* total_ms, uint64_t* launches);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Dense ops on the path                                                                       */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,146 @@
+"""GPU parity: hash / index stage, bit-exact against the sequential CPU restatement."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(torch, arr, dtype):
+    return torch.from_numpy(np.ascontiguousarray(arr)).to("cuda").to(dtype)
+
+
+class GpuHT:
+    def __init__(self, capacity, key_type):
+        from hugectr_amd import _lib
+        self._lib = _lib
+        self.h = ctypes.c_void_p()
+        _lib.check(_lib.lib.hctr_ht_create(capacity, key_type, ctypes.byref(self.h)))
+
+    def __del__(self):
+        if self.h:
+            self._lib.lib.hctr_ht_destroy(self.h)
+            self.h = None
+
+    def get_insert(self, keys_t):
+        import torch
+        out = torch.empty(keys_t.numel(), dtype=torch.int64, device="cuda")
+        self._lib.check(self._lib.lib.hctr_ht_get_insert(self.h, self._lib.ptr(keys_t), keys_t.numel(), None,
+                                                         self._lib.ptr(out), self._lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint64)
+
+    def get_mark(self, keys_t):
+        import torch
+        out = torch.empty(keys_t.numel(), dtype=torch.int64, device="cuda")
+        self._lib.check(self._lib.lib.hctr_ht_get_mark(self.h, self._lib.ptr(keys_t), keys_t.numel(), None,
+                                                       self._lib.ptr(out), self._lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint64)
+
+    def size(self):
+        n = ctypes.c_size_t()
+        self._lib.check(self._lib.lib.hctr_ht_size(self.h, self._lib.stream_ptr(), ctypes.byref(n)))
+        return n.value
+
+    def value_head(self):
+        n = ctypes.c_size_t()
+        self._lib.check(self._lib.lib.hctr_ht_value_head(self.h, self._lib.stream_ptr(), ctypes.byref(n)))
+        return n.value
+
+    def table_size(self):
+        return self._lib.lib.hctr_ht_table_size(self.h)
+
+    def dump(self):
+        import torch
+        n = self.table_size()
+        k = torch.empty(n, dtype=torch.int64, device="cuda")
+        v = torch.empty(n, dtype=torch.int64, device="cuda")
+        c = ctypes.c_size_t()
+        self._lib.check(self._lib.lib.hctr_ht_dump(self.h, self._lib.ptr(k), self._lib.ptr(v), ctypes.byref(c),
+                                                   self._lib.stream_ptr()))
+        return k[:c.value].cpu().numpy(), v[:c.value].cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("key_bytes", [4, 8])
+def test_murmur_hash_bit_exact(oracle, key_bytes):
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(0)
+    if key_bytes == 4:
+        keys = rng.integers(0, 2**32 - 1, size=5000, dtype=np.uint64).astype(np.int64)
+        kt, ktype = _mk(torch, keys.astype(np.uint32).view(np.int32), torch.int32), _lib.KEY_U32
+    else:
+        keys = rng.integers(-2**62, 2**62, size=5000, dtype=np.int64)
+        kt, ktype = _mk(torch, keys, torch.int64), _lib.KEY_I64
+    out = torch.empty(keys.size, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib.hctr_hash_keys(_lib.ptr(kt), ktype, keys.size, _lib.ptr(out), _lib.stream_ptr()))
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got == oracle.hash_keys(keys, key_bytes)).all()
+    # published vector: 4 zero bytes, seed 0
+    if key_bytes == 4:
+        z = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(_lib.lib.hctr_hash_keys(_lib.ptr(z), ktype, 1, _lib.ptr(out), _lib.stream_ptr()))
+        assert int(out[:1].cpu().numpy().view(np.uint32)[0]) == 0x2362F9DE
+
+
+@pytest.mark.parametrize("key_bytes,capacity,vocab,n", [
+    (8, 5000, 3000, 20000),    # heavy duplication, many batches
+    (4, 5000, 4000, 20000),
+    (8, 300, 290, 5000),       # nearly full table: long probe chains
+    (8, 200000, 150000, 300000),  # multi-tile compaction
+])
+def test_get_insert_matches_sequential_oracle(oracle, key_bytes, capacity, vocab, n):
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(42)
+    ht_o = oracle.HashTable(capacity, key_bytes)
+    ht_g = GpuHT(capacity, _lib.KEY_U32 if key_bytes == 4 else _lib.KEY_I64)
+    assert ht_g.table_size() == ht_o.table_size()
+    for batch in range(4):
+        # power-law-ish duplicates + a spread of big keys
+        keys = (rng.zipf(1.3, size=n) % vocab).astype(np.int64) * 7919 % (2**31)
+        kt = _mk(torch, keys.astype(np.uint32).view(np.int32) if key_bytes == 4 else keys,
+                 torch.int32 if key_bytes == 4 else torch.int64)
+        got = ht_g.get_insert(kt)
+        want = ht_o.get_insert(keys)
+        assert (got == want).all(), f"batch {batch}: first-occurrence row assignment differs"
+        assert ht_g.value_head() == ht_o.value_head()
+    assert ht_g.size() == ht_o.size()
+    # same key -> value map (physical slot order may differ under concurrent probing)
+    gk, gv = ht_g.dump()
+    ok, ov = ht_o.dump()
+    assert dict(zip(gk.tolist(), gv.tolist())) == dict(zip(ok.tolist(), ov.tolist()))
+    # get_mark: hits return the row, misses SIZE_MAX, nothing is inserted
+    probe = np.concatenate([keys[:100], np.arange(10**9, 10**9 + 50)]).astype(np.int64)
+    pt = _mk(torch, probe.astype(np.uint32).view(np.int32) if key_bytes == 4 else probe,
+             torch.int32 if key_bytes == 4 else torch.int64)
+    assert (ht_g.get_mark(pt) == ht_o.get_mark(probe)).all()
+    assert ht_g.size() == ht_o.size()
+
+
+def test_get_insert_empty_and_single(oracle):
+    import torch
+    from hugectr_amd import _lib
+    ht = GpuHT(16, _lib.KEY_I64)
+    e = torch.empty(0, dtype=torch.int64, device="cuda")
+    assert ht.get_insert(e).size == 0
+    one = torch.tensor([77], dtype=torch.int64, device="cuda")
+    assert ht.get_insert(one).tolist() == [0]
+    assert ht.get_insert(one).tolist() == [0]
+    assert ht.value_head() == 1
+
+
+def test_overflow_is_flagged():
+    """more distinct keys than max_vocabulary_size_per_gpu -> check_overflow raises
+    (R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:552-569)"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, 4, 0, 8, 4, 4, 4, 0, ha.OptParams())
+    ro = torch.arange(0, 17, dtype=torch.int64, device="cuda")
+    keys = torch.arange(0, 16, dtype=torch.int64, device="cuda")
+    emb.forward(True, ro, keys)
+    with pytest.raises(ha.HugeCTRAmdError):
+        emb.check_overflow()
