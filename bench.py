@@ -111,6 +111,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sgd-atomic", action="store_true")
+    ap.add_argument("--tunable", default="auto", choices=["auto", "tune", "off"],
+                    help="dense-tower GEMM solution selection through PyTorch TunableOp: auto = use "
+                         "the committed hugectr_amd/tuning/tunableop_gfx950.csv if present (no "
+                         "tuning at run time); tune = search during warm-up (outside the timed "
+                         "region) and write --tunable-file; off = library heuristics")
+    ap.add_argument("--tunable-file", default=os.path.join(ROOT, "hugectr_amd", "tuning",
+                                                           "tunableop_gfx950.csv"))
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,9 +211,37 @@ def main():
         dense_opt.zero_grad(set_to_none=True)
         return loss
 
+    tuned = "off"
+    if a.tunable == "tune" or (a.tunable == "auto" and os.path.exists(a.tunable_file)):
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.set_filename(a.tunable_file)
+        if a.tunable == "tune":
+            tunable.tuning_enable(True)
+            tunable.set_max_tuning_duration(30)
+            tunable.set_max_tuning_iterations(20)
+            tuned = "tuned-now"
+        else:
+            tunable.tuning_enable(False)
+            tunable.read_file(a.tunable_file)
+            tuned = "file"
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    if a.tunable == "tune":
+        tunable.tuning_enable(False)  # keep the chosen solutions, stop searching
+        if rank == 0:
+            # TunableOp writes its CSV at process exit; also write it now in the same format so
+            # the file exists even if the interpreter is torn down abnormally.
+            try:
+                os.makedirs(os.path.dirname(a.tunable_file), exist_ok=True)
+                with open(a.tunable_file + ".now", "w") as f:
+                    for k, v in tunable.get_validators():
+                        f.write(f"Validator,{k},{v}\n")
+                    for r in tunable.get_results():
+                        f.write(",".join(str(x) for x in r) + "\n")
+            except Exception as e:  # diagnostics only
+                print("tunable dump failed:", e, file=sys.stderr)
     emb.profiling(True)
     if world > 1:
         dist.barrier()
@@ -253,7 +288,7 @@ def main():
                                "LocalizedSlotSparseEmbeddingHash, emb_dim=128, global bs=65536, SGD",
                    "global_batch": B, "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
                    "table_rows_this_rank": my_rows, "parallelism": f"slot-sharded x{world} + dp{world}",
-                   "final_loss": float(loss)},
+                   "final_loss": float(loss.detach()), "dense_gemm_selection": tuned},
         "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,

@@ -18,6 +18,7 @@ namespace hctr {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
@@ -34,71 +35,107 @@ struct InterCfg {
 
 __device__ __forceinline__ int tri_index(int n, int m) { return n * (n - 1) / 2 + m; }  // n > m
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> (hi, lo) bf16 pair: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|.  Three bf16 MFMAs
+// (hi*hi + hi*lo + lo*hi) then reproduce the fp32 product to ~2^-16 relative, at 3/16 of the
+// fp32-MFMA cycle cost -- which is what lets the kernel run at the HBM roofline instead of the
+// fp32 matrix-pipe limit (MI355X_MICROARCH: f32 MFMA = 1/16 of the bf16 rate).
+__device__ __forceinline__ void split8(const float4& p, const float4& q, bf16x8& hi, bf16x8& lo) {
+  const float v[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+
+// registers <- one sample's [n_ins][W] tile (row 0 = mlp, rows 1.. = emb), 16 B per lane per load.
+// Lanes past the tile re-read element 0 so that `pre` stays in registers (no predicated array
+// writes -> no scratch).
+template <int W, int NPRE>
+__device__ __forceinline__ void load_sample_tile(f32x4 (&pre)[NPRE], const float* __restrict__ mlp,
+                                                 const float* __restrict__ emb, size_t b, int n_emb,
+                                                 int n_vec, int lane) {
+  constexpr int W4 = W / 4;
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(mlp + b * W);
+  const f32x4* e4 = reinterpret_cast<const f32x4*>(emb + b * (size_t)n_emb * W) - W4;
+#pragma unroll
+  for (int q = 0; q < NPRE; q++) {
+    int i = lane + 64 * q;
+    i = i < n_vec ? i : 0;
+    const f32x4* src = (i < W4) ? m4 : e4;
+    pre[q] = src[i];
+  }
+}
+
+// One wavefront (= one 64-thread workgroup) per sample, software-pipelined over samples:
+//   registers <- global (sample i+1, 16-byte coalesced)   ||   MFMA on the LDS tile of sample i
+// LDS per workgroup: X tile [(n_ins+1) rows][W+4] (last row = zeros for the padded MFMA rows) +
+// the staged output row.
 template <int W>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(64, 2)
     interaction_fwd_mfma_kernel(size_t batch, int n_emb, const float* __restrict__ mlp,
                                 const float* __restrict__ emb, float* __restrict__ out,
                                 int out_len) {
   using C = InterCfg<W>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
-  const int stage_len = (out_len + 3) & ~3;
-  float* xt = smem + wave * (C::XT + stage_len);
-  float* stage = xt + C::XT;
-  // zero the whole X tile once: pad rows n_ins..31 must read as 0 forever
-  for (int i = lane; i < C::XT; i += 64) xt[i] = 0.f;
-  __syncthreads();
-
-  const size_t waves_total = (size_t)gridDim.x * kWavesPerBlock;
-  const size_t iters = (batch + waves_total - 1) / waves_total;
-  const int r = lane & 31, h = lane >> 5;
+  float* xt = smem;
+  float* stage = smem + (n_ins + 1) * C::LD;
   constexpr int W4 = W / 4;
-  for (size_t it = 0; it < iters; it++) {
-    const size_t b = it * waves_total + (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const bool valid = b < batch;
-    if (valid) {
-      // coalesced 16-byte loads: row 0 = mlp[b], rows 1.. = emb[b]
-      const float4* m4 = reinterpret_cast<const float4*>(mlp + b * W);
-      const float4* e4 = reinterpret_cast<const float4*>(emb + b * (size_t)n_emb * W);
-      for (int i = lane; i < n_ins * W4; i += 64) {
+  constexpr int NPRE = (32 * W4 + 63) / 64;  // float4 per lane for up to 32 rows
+  const int n_vec = n_ins * W4;
+  for (int i = lane; i < C::LD; i += 64) xt[n_ins * C::LD + i] = 0.f;  // the zero row
+
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = r < n_ins ? r : n_ins;
+  f32x4 pre[NPRE];
+  size_t b = blockIdx.x;
+  if (b < batch) load_sample_tile<W, NPRE>(pre, mlp, emb, b, n_emb, n_vec, lane);
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
         const int row = i / W4, c4 = i % W4;
-        float4 v = (row == 0) ? m4[c4] : e4[(size_t)(row - 1) * W4 + c4];
-        *reinterpret_cast<float4*>(xt + row * C::LD + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(xt + row * C::LD + c4 * 4) = pre[q];
       }
     }
     __syncthreads();
-    if (valid) {
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      // lane (r,h) feeds X[r][h*W/2 + k]; A == B operand because the product is X.X^T.
-      const float* xr = xt + r * C::LD + h * (W / 2);
+    const size_t nb = b + gridDim.x;
+    if (nb < batch) load_sample_tile<W, NPRE>(pre, mlp, emb, nb, n_emb, n_vec, lane);
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // lane (r,h) feeds X[r][h*W/2 + 8t .. +7] at k-step t; A == B fragment (product is X.X^T)
+    const float* xr = xt + rr * C::LD + h * (W / 2);
 #pragma unroll
-      for (int t = 0; t < W / 8; t++) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + t * 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, v.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, v.w, acc, 0, 0, 0);
-      }
-      // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-      const int col = r;
-#pragma unroll
-      for (int reg = 0; reg < 16; reg++) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row > col && row < n_ins) stage[W + tri_index(row, col)] = acc[reg];
-      }
-      for (int i = lane; i < W; i += 64) stage[i] = xt[i];  // mlp passthrough
-      if (lane == 0) stage[out_len - 1] = 0.f;              // zero pad column
+    for (int t = 0; t < W / 16; t++) {
+      const float4 p = *reinterpret_cast<const float4*>(xr + t * 8);
+      const float4 q = *reinterpret_cast<const float4*>(xr + t * 8 + 4);
+      bf16x8 hi, lo;
+      split8(p, q, hi, lo);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, hi, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, lo, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, hi, acc, 0, 0, 0);
     }
+    // C layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row > r && row < n_ins) stage[W + tri_index(row, r)] = acc[reg];
+    }
+    for (int i = lane; i < W; i += 64) stage[i] = xt[i];  // mlp passthrough
+    if (lane == 0) stage[out_len - 1] = 0.f;              // zero pad column
     __syncthreads();
-    if (valid) {
-      float* o = out + b * (size_t)out_len;
-      if ((out_len & 3) == 0) {
-        for (int i = lane; i < out_len / 4; i += 64)
-          reinterpret_cast<float4*>(o)[i] = reinterpret_cast<const float4*>(stage)[i];
-      } else {
-        for (int i = lane; i < out_len; i += 64) o[i] = stage[i];
-      }
+    float* o = out + b * (size_t)out_len;
+    if ((out_len & 3) == 0) {
+      for (int i = lane; i < out_len / 4; i += 64)
+        reinterpret_cast<float4*>(o)[i] = reinterpret_cast<const float4*>(stage)[i];
+    } else {
+      for (int i = lane; i < out_len; i += 64) o[i] = stage[i];
     }
     __syncthreads();
   }
@@ -173,80 +210,140 @@ __global__ void __launch_bounds__(kBlock)
 //   mlp_grad[b] = top_grad[b][0:W] + dX[0];  emb_grad[b][i-1] = dX[i]
 // ================================================================================================
 template <int W>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(64, 2)
     interaction_bwd_mfma_kernel(size_t batch, int n_emb, const float* __restrict__ mlp,
                                 const float* __restrict__ emb, const float* __restrict__ top_grad,
                                 float* __restrict__ mlp_grad, float* __restrict__ emb_grad,
                                 int out_len) {
   using C = InterCfg<W>;
-  constexpr int GS = 33;  // G row stride (floats)
+  constexpr int GS = 36;  // G row stride (floats): 16 lanes of a ds_read_b128 group -> 16 slots
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
-  float* xt = smem + wave * (C::XT + 32 * GS);
-  float* gm = xt + C::XT;
-  for (int i = lane; i < C::XT + 32 * GS; i += 64) xt[i] = 0.f;
+  float* xt = smem;                 // [32][LD]  X, later reused for dX
+  float* gm = smem + C::XT;         // [32][GS]  G = dM + dM^T
+  unsigned short* pair_nm = reinterpret_cast<unsigned short*>(gm + 32 * GS);  // [n_pairs]
+  constexpr int W4 = W / 4;
+  constexpr int NT = W / 32;
+  constexpr int NPRE = (32 * W4 + 63) / 64;
+  constexpr int NG = 8;  // ceil(496 / 64) gradient words per lane
+  const int n_vec = n_ins * W4;
+  const int n_pairs = n_ins * (n_ins - 1) / 2;
+  for (int i = lane; i < C::XT + 32 * GS; i += 64) smem[i] = 0.f;
+  for (int p = lane; p < n_pairs; p += 64) {
+    int n = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (n * (n - 1) / 2 > p) n--;
+    while ((n + 1) * n / 2 <= p) n++;
+    pair_nm[p] = (unsigned short)((n << 8) | (p - n * (n - 1) / 2));
+  }
   __syncthreads();
 
-  const size_t waves_total = (size_t)gridDim.x * kWavesPerBlock;
-  const size_t iters = (batch + waves_total - 1) / waves_total;
   const int r = lane & 31, h = lane >> 5;
-  constexpr int W4 = W / 4;
-  constexpr int NT = W / 32;  // N tiles
-  const int n_pairs = n_ins * (n_ins - 1) / 2;
-  for (size_t it = 0; it < iters; it++) {
-    const size_t b = it * waves_total + (size_t)blockIdx.x * kWavesPerBlock + wave;
-    const bool valid = b < batch;
-    if (valid) {
-      const float4* m4 = reinterpret_cast<const float4*>(mlp + b * W);
-      const float4* e4 = reinterpret_cast<const float4*>(emb + b * (size_t)n_emb * W);
-      for (int i = lane; i < n_ins * W4; i += 64) {
+  f32x4 pre[NPRE];
+  float gpre[NG];
+  size_t b = blockIdx.x;
+#define HCTR_BWD_PREFETCH(bb)                                                   \
+  {                                                                             \
+    load_sample_tile<W, NPRE>(pre, mlp, emb, (bb), n_emb, n_vec, lane);         \
+    const float* g__ = top_grad + (bb) * (size_t)out_len + W;                   \
+    _Pragma("unroll") for (int q = 0; q < NG; q++) {                            \
+      int p__ = lane + 64 * q;                                                  \
+      p__ = p__ < n_pairs ? p__ : 0;                                            \
+      gpre[q] = g__[p__];                                                       \
+    }                                                                           \
+  }
+  if (b < batch) HCTR_BWD_PREFETCH(b)
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
         const int row = i / W4, c4 = i % W4;
-        float4 v = (row == 0) ? m4[c4] : e4[(size_t)(row - 1) * W4 + c4];
-        *reinterpret_cast<float4*>(xt + row * C::LD + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(xt + row * C::LD + c4 * 4) = pre[q];
       }
-      const float* g = top_grad + b * (size_t)out_len + W;
-      for (int p = lane; p < n_pairs; p += 64) {
-        int n = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
-        while (n * (n - 1) / 2 > p) n--;
-        while ((n + 1) * n / 2 <= p) n++;
-        const int m = p - n * (n - 1) / 2;
-        const float v = g[p];
-        gm[n * GS + m] = v;
-        gm[m * GS + n] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+      const int p = lane + 64 * q;
+      if (p < n_pairs) {
+        const int nm = pair_nm[p];
+        const int n = nm >> 8, m = nm & 0xFF;
+        gm[n * GS + m] = gpre[q];
+        gm[m * GS + n] = gpre[q];
       }
     }
     __syncthreads();
-    if (valid) {
-      f32x16 acc[NT];
+    const size_t nb = b + gridDim.x;
+    if (nb < batch) HCTR_BWD_PREFETCH(nb)
+
+    // dX = G . X : A = G [32 x 32], B = X [32 x W]; K = 32 -> two k-steps of 16.  The output is
+    // produced in column panels of HP*32 columns (32 accumulator registers instead of 64); panel
+    // p only reads columns of X that earlier panels did not overwrite, so dX replaces X in place.
+    constexpr int HP = NT >= 2 ? 2 : 1;  // N tiles per panel
 #pragma unroll
-      for (int t = 0; t < NT; t++)
+    for (int pn = 0; pn < NT / HP; pn++) {
+      f32x16 acc[HP];
+#pragma unroll
+      for (int t = 0; t < HP; t++)
         acc[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                           0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int ksteps = (n_ins + 1) / 2;  // K = n_ins rounded up to 2
-      for (int s = 0; s < ksteps; s++) {
-        const int k = 2 * s + h;
-        const float a = gm[r * GS + k];  // A[i = r][k]
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-          const float bv = xt[k * C::LD + t * 32 + r];  // B[k][j = 32 t + r]
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+      for (int s2 = 0; s2 < 2; s2++) {
+        const int k0 = 16 * s2 + 8 * h;
+        const float4 ga = *reinterpret_cast<const float4*>(gm + r * GS + k0);
+        const float4 gb = *reinterpret_cast<const float4*>(gm + r * GS + k0 + 4);
+        bf16x8 ah, al;
+        split8(ga, gb, ah, al);
+#pragma unroll
+        for (int t = 0; t < HP; t++) {
+          const int col = (pn * HP + t) * 32 + r;
+          float xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) xv[e] = xt[(k0 + e) * C::LD + col];
+          bf16x8 bh, bl;
+          split8(make_float4(xv[0], xv[1], xv[2], xv[3]), make_float4(xv[4], xv[5], xv[6], xv[7]),
+                 bh, bl);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
         }
       }
-      const float* gtop = top_grad + b * (size_t)out_len;
+      __syncthreads();  // every lane is done reading this panel's columns of X
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const int col = t * 32 + r;
+      for (int t = 0; t < HP; t++) {
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
           const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if (row == 0) mlp_grad[b * W + col] = gtop[col] + acc[t][reg];
-          else if (row < n_ins) emb_grad[(b * n_emb + (row - 1)) * (size_t)W + col] = acc[t][reg];
+          if (row < n_ins) xt[row * C::LD + (pn * HP + t) * 32 + r] = acc[t][reg];
         }
       }
     }
     __syncthreads();
+    const float4* gtop4 = reinterpret_cast<const float4*>(top_grad + b * (size_t)out_len);
+    float4* mg4 = reinterpret_cast<float4*>(mlp_grad + b * W);
+    float4* eg4 = reinterpret_cast<float4*>(emb_grad + b * (size_t)n_emb * W);
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
+        const int row = i / W4, c4 = i % W4;
+        float4 v = *reinterpret_cast<const float4*>(xt + row * C::LD + c4 * 4);
+        if (row == 0) {
+          const float4 gt = gtop4[c4];
+          v.x += gt.x;
+          v.y += gt.y;
+          v.z += gt.z;
+          v.w += gt.w;
+          mg4[c4] = v;
+        } else {
+          eg4[i - W4] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // rows >= n_ins of the tile were never written; rows < n_ins are rewritten next iteration
   }
+#undef HCTR_BWD_PREFETCH
 }
 
 template <typename T>
@@ -450,16 +547,15 @@ int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, co
                    reinterpret_cast<uintptr_t>(emb) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(out) % 16 == 0;
   const int grid = grid_for(batch, kWavesPerBlock, 256 * 2);
-  if (dtype == HCTR_EMB_F32 && n_ins <= 32 && a16 && (width == 128 || width == 64 || width == 32 || width == 16)) {
+  if (dtype == HCTR_EMB_F32 && n_ins <= 32 && a16 &&
+      (width == 128 || width == 64 || width == 32 || width == 16)) {
     const int stage_len = (out_len + 3) & ~3;
+    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
 #define HCTR_IFWD(W_)                                                                        \
   {                                                                                          \
-    const size_t lds = (size_t)kWavesPerBlock * (InterCfg<W_>::XT + stage_len) * 4;          \
-    HCTR_HIP(hipFuncSetAttribute((const void*)interaction_fwd_mfma_kernel<W_>,                \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-    hipLaunchKernelGGL(interaction_fwd_mfma_kernel<W_>, dim3(grid), dim3(kBlock), lds, s,    \
-                       batch, n_emb, (const float*)mlp, (const float*)emb, (float*)out,      \
-                       out_len);                                                             \
+    const size_t lds = (size_t)((n_ins + 1) * InterCfg<W_>::LD + stage_len) * 4;             \
+    hipLaunchKernelGGL(interaction_fwd_mfma_kernel<W_>, dim3(grid1), dim3(64), lds, s, batch, \
+                       n_emb, (const float*)mlp, (const float*)emb, (float*)out, out_len);   \
   }
     switch (width) {
       case 128: HCTR_IFWD(128) break;
@@ -502,15 +598,19 @@ int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, co
   const bool a16 = reinterpret_cast<uintptr_t>(mlp) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(emb) % 16 == 0;
   const int grid = grid_for(batch, kWavesPerBlock, 256 * 2);
-  if (dtype == HCTR_EMB_F32 && n_ins <= 32 && a16 && (width == 128 || width == 64 || width == 32)) {
-#define HCTR_IBWD(W_)                                                                         \
-  {                                                                                           \
-    const size_t lds = (size_t)kWavesPerBlock * (InterCfg<W_>::XT + 32 * 33) * 4;             \
-    HCTR_HIP(hipFuncSetAttribute((const void*)interaction_bwd_mfma_kernel<W_>,                 \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-    hipLaunchKernelGGL(interaction_bwd_mfma_kernel<W_>, dim3(grid), dim3(kBlock), lds, s,     \
-                       batch, n_emb, (const float*)mlp, (const float*)emb,                    \
-                       (const float*)top_grad, (float*)mlp_grad, (float*)emb_grad, out_len);  \
+  const bool g16 = (out_len % 4 == 0) && reinterpret_cast<uintptr_t>(top_grad) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(mlp_grad) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(emb_grad) % 16 == 0;
+  if (dtype == HCTR_EMB_F32 && n_ins <= 32 && a16 && g16 &&
+      (width == 128 || width == 64 || width == 32)) {
+    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
+    const int n_pairs = n_ins * (n_ins - 1) / 2;
+#define HCTR_IBWD(W_)                                                                          \
+  {                                                                                            \
+    const size_t lds = (size_t)(InterCfg<W_>::XT + 32 * 36) * 4 + (size_t)((n_pairs + 7) & ~7) * 2; \
+    hipLaunchKernelGGL(interaction_bwd_mfma_kernel<W_>, dim3(grid1), dim3(64), lds, s, batch,  \
+                       n_emb, (const float*)mlp, (const float*)emb, (const float*)top_grad,    \
+                       (float*)mlp_grad, (float*)emb_grad, out_len);                           \
   }
     switch (width) {
       case 128: HCTR_IBWD(128) break;

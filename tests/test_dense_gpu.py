@@ -28,13 +28,13 @@ def test_interaction_fwd_bwd(oracle, B, n_emb, W):
     out = ha.interaction(mt, et)
     want = oracle.interaction_fwd(mlp, emb)
     assert out.shape == want.shape
-    assert_close(out.detach().cpu().numpy(), want, 1e-4, 1e-4, "interaction fwd")
+    assert_close(out.detach().cpu().numpy(), want, 2e-4, 1e-3, "interaction fwd")
     assert float(out.detach()[:, -1].abs().max()) == 0.0  # zero pad column
     g = rng.standard_normal(want.shape).astype(np.float32)
     out.backward(torch.from_numpy(g).cuda())
     mg, eg = oracle.interaction_bwd(mlp, emb, g)
-    assert_close(mt.grad.cpu().numpy(), mg, 1e-4, 1e-4, "interaction mlp grad")
-    assert_close(et.grad.cpu().numpy(), eg, 1e-4, 1e-4, "interaction emb grad")
+    assert_close(mt.grad.cpu().numpy(), mg, 2e-4, 1e-3, "interaction mlp grad")
+    assert_close(et.grad.cpu().numpy(), eg, 2e-4, 1e-3, "interaction emb grad")
 
 
 def test_interaction_asymmetric_catches_transpose(oracle):
