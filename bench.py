@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--sgd-atomic", action="store_true")
+    ap.add_argument("--emb-dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="type of the pooled vectors / top gradients (tables, accumulation and the "
+                         "sparse optimizer are always fp32).  bf16 = the reference's mixed-precision "
+                         "mode (use_mixed_precision: fp16 embedding output) with bf16.")
     ap.add_argument("--tunable", default="auto", choices=["auto", "tune", "off"],
                     help="dense-tower GEMM solution selection through PyTorch TunableOp: auto = use "
                          "the committed hugectr_amd/tuning/tunableop_gfx950.csv if present (no "
@@ -146,8 +150,11 @@ def main():
 
     # ---- the embedding (this rank's slots), SGD as in the reference DLRM samples -----------------
     opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.sgd_atomic, scaler=1.0)
+    edt = torch.bfloat16 if a.emb_dtype == "bf16" else torch.float32
+    esz = 2 if a.emb_dtype == "bf16" else 4
     emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, max_rows, D, S, S, 0, opt,
-                                 slot_size_array=sizes, rank=rank, world=world, seed=1234)
+                                 slot_size_array=sizes, out_dtype=edt, rank=rank, world=world,
+                                 seed=1234)
     emb.init_params()
     exch = LocalizedExchange(B, S, D)
 
@@ -165,13 +172,18 @@ def main():
     # ---- dense tower (PyTorch-ROCm / hipBLASLt GEMMs; interaction is our HIP kernel) ---------------
     torch.manual_seed(7)
     n_ins = S + 1
-    bottom = mlp([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
-    top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
+    amp = a.dense_dtype == "bf16"
+    if amp:
+        from hugectr_amd.dense import FusedMLP
+        bottom = FusedMLP([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
+        top = FusedMLP([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
+    else:
+        bottom = mlp([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
+        top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
     dense_params = list(bottom.parameters()) + list(top.parameters())
     dense_opt = torch.optim.SGD(dense_params, lr=0.01)
     loss_fn = torch.nn.BCEWithLogitsLoss()
-    amp = a.dense_dtype == "bf16"
-    pooled = torch.empty((B, spr, D), dtype=torch.float32, device=dev)
+    pooled = torch.empty((B, spr, D), dtype=edt, device=dev)
     flat_grads = None
 
     def step(i):
@@ -185,11 +197,9 @@ def main():
         else:
             E = pooled
         E = E.detach().requires_grad_(True)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            xb = bottom(dense)
-        z = ha.interaction(xb.float(), E)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
-            logit = top(z)
+        xb = bottom(dense)
+        z = ha.interaction(xb.to(edt), E)
+        logit = top(z)
         loss = loss_fn(logit.float(), label)
         loss.backward()
         if world > 1:
@@ -209,6 +219,9 @@ def main():
         emb.update_params()
         dense_opt.step()
         dense_opt.zero_grad(set_to_none=True)
+        if amp:
+            bottom.refresh_shadow()
+            top.refresh_shadow()
         return loss
 
     tuned = "off"
@@ -265,7 +278,7 @@ def main():
 
     # ---- roofline of the gather+pool kernel (algorithmic bytes, DESIGN.md / SURVEY 8d) ------------
     nnz_g = B * spr  # one-hot: one key per (sample, slot on this rank)
-    alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * 4
+    alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz
     pool_ms, pool_n = prof["gather_pool"]
     achieved = alg_bytes / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
     pmc = None
@@ -282,7 +295,9 @@ def main():
         "value": B * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 embeddings / sparse SGD, bf16 dense GEMMs" if amp else "f32",
+        "dtype": ("f32 tables/accumulate/sparse SGD, " +
+                  ("bf16 pooled vectors+grads, " if a.emb_dtype == "bf16" else "f32 pooled vectors, ") +
+                  ("bf16 dense GEMMs" if amp else "f32 dense")),
         "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
         "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
                                "LocalizedSlotSparseEmbeddingHash, emb_dim=128, global bs=65536, SGD",

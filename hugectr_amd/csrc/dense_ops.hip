@@ -141,6 +141,268 @@ __global__ void __launch_bounds__(64, 2)
   }
 }
 
+// ================================================================================================
+// 16-bit (bf16 / fp16) interaction: same one-wavefront-per-sample pipeline, a single MFMA chain
+// (inputs are already 16-bit), fp32 accumulate, 16-bit output.  This is the reference's mixed
+// precision mode (InteractionLayer<__half>, interaction_layer.cu:47-756) with bf16 added.
+// ================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF>
+struct H16;
+template <>
+struct H16<true> {
+  typedef bf16x8 vec8;
+  __device__ __forceinline__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ __forceinline__ static unsigned short from_f32(float v) {
+    __bf16 h = (__bf16)v;
+    return *reinterpret_cast<unsigned short*>(&h);
+  }
+  __device__ __forceinline__ static float to_f32(unsigned short u) {
+    return __uint_as_float((unsigned)u << 16);
+  }
+};
+template <>
+struct H16<false> {
+  typedef f16x8 vec8;
+  __device__ __forceinline__ static f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  __device__ __forceinline__ static unsigned short from_f32(float v) {
+    _Float16 h = (_Float16)v;
+    return *reinterpret_cast<unsigned short*>(&h);
+  }
+  __device__ __forceinline__ static float to_f32(unsigned short u) {
+    _Float16 h = *reinterpret_cast<_Float16*>(&u);
+    return (float)h;
+  }
+};
+
+template <int W>
+struct InterCfg16 {
+  static constexpr int LD = W + 8;   // row stride in 16-bit elements (+16 B against conflicts)
+  static constexpr int XT = 32 * LD; // elements
+};
+
+template <int W, int NPRE>
+__device__ __forceinline__ void load_sample_tile16(u32x4 (&pre)[NPRE],
+                                                   const unsigned short* __restrict__ mlp,
+                                                   const unsigned short* __restrict__ emb, size_t b,
+                                                   int n_emb, int n_vec, int lane) {
+  constexpr int W8 = W / 8;
+  const u32x4* m4 = reinterpret_cast<const u32x4*>(mlp + b * W);
+  const u32x4* e4 = reinterpret_cast<const u32x4*>(emb + b * (size_t)n_emb * W) - W8;
+#pragma unroll
+  for (int q = 0; q < NPRE; q++) {
+    int i = lane + 64 * q;
+    i = i < n_vec ? i : 0;
+    const u32x4* src = (i < W8) ? m4 : e4;
+    pre[q] = src[i];
+  }
+}
+
+template <int W, bool BF>
+__global__ void __launch_bounds__(64, 2)
+    interaction_fwd16_kernel(size_t batch, int n_emb, const unsigned short* __restrict__ mlp,
+                             const unsigned short* __restrict__ emb,
+                             unsigned short* __restrict__ out, int out_len) {
+  using C = InterCfg16<W>;
+  using H = H16<BF>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  const int lane = threadIdx.x;
+  const int n_ins = n_emb + 1;
+  unsigned short* xt = smem16;
+  unsigned short* stage = smem16 + (n_ins + 1) * C::LD;
+  constexpr int W8 = W / 8;
+  constexpr int NPRE = (32 * W8 + 63) / 64;
+  const int n_vec = n_ins * W8;
+  for (int i = lane; i < C::LD; i += 64) xt[n_ins * C::LD + i] = 0;  // zero row
+
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = r < n_ins ? r : n_ins;
+  u32x4 pre[NPRE];
+  size_t b = blockIdx.x;
+  if (b < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, b, n_emb, n_vec, lane);
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
+        const int row = i / W8, c8 = i % W8;
+        *reinterpret_cast<u32x4*>(xt + row * C::LD + c8 * 8) = pre[q];
+      }
+    }
+    __syncthreads();
+    const size_t nb = b + gridDim.x;
+    if (nb < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, nb, n_emb, n_vec, lane);
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned short* xr = xt + rr * C::LD + h * (W / 2);
+#pragma unroll
+    for (int t = 0; t < W / 16; t++) {
+      const typename H::vec8 f = *reinterpret_cast<const typename H::vec8*>(xr + t * 8);
+      acc = H::mfma(f, f, acc);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row > r && row < n_ins) stage[W + tri_index(row, r)] = H::from_f32(acc[reg]);
+    }
+    for (int i = lane; i < W; i += 64) stage[i] = xt[i];
+    if (lane == 0) stage[out_len - 1] = 0;
+    __syncthreads();
+    unsigned short* o = out + b * (size_t)out_len;
+    if ((out_len & 7) == 0) {
+      for (int i = lane; i < out_len / 8; i += 64)
+        reinterpret_cast<u32x4*>(o)[i] = reinterpret_cast<const u32x4*>(stage)[i];
+    } else {
+      for (int i = lane; i < out_len; i += 64) o[i] = stage[i];
+    }
+    __syncthreads();
+  }
+}
+
+template <int W, bool BF>
+__global__ void __launch_bounds__(64, 2)
+    interaction_bwd16_kernel(size_t batch, int n_emb, const unsigned short* __restrict__ mlp,
+                             const unsigned short* __restrict__ emb,
+                             const unsigned short* __restrict__ top_grad,
+                             unsigned short* __restrict__ mlp_grad,
+                             unsigned short* __restrict__ emb_grad, int out_len) {
+  using C = InterCfg16<W>;
+  using H = H16<BF>;
+  constexpr int GS = 40;  // G row stride (16-bit elements): 80 B -> 16 distinct 16-B slots
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  const int lane = threadIdx.x;
+  const int n_ins = n_emb + 1;
+  unsigned short* xt = smem16;            // [32][LD] X, reused for dX
+  unsigned short* gm = smem16 + C::XT;    // [32][GS]
+  unsigned short* pair_nm = gm + 32 * GS; // [n_pairs]
+  constexpr int W8 = W / 8;
+  constexpr int NT = W / 32;
+  constexpr int NPRE = (32 * W8 + 63) / 64;
+  constexpr int NG = 8;
+  const int n_vec = n_ins * W8;
+  const int n_pairs = n_ins * (n_ins - 1) / 2;
+  for (int i = lane; i < C::XT + 32 * GS; i += 64) smem16[i] = 0;
+  for (int p = lane; p < n_pairs; p += 64) {
+    int n = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (n * (n - 1) / 2 > p) n--;
+    while ((n + 1) * n / 2 <= p) n++;
+    pair_nm[p] = (unsigned short)((n << 8) | (p - n * (n - 1) / 2));
+  }
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  u32x4 pre[NPRE];
+  unsigned short gpre[NG];
+  size_t b = blockIdx.x;
+#define HCTR_BWD16_PREFETCH(bb)                                                  \
+  {                                                                              \
+    load_sample_tile16<W, NPRE>(pre, mlp, emb, (bb), n_emb, n_vec, lane);        \
+    const unsigned short* g__ = top_grad + (bb) * (size_t)out_len + W;           \
+    _Pragma("unroll") for (int q = 0; q < NG; q++) {                             \
+      int p__ = lane + 64 * q;                                                   \
+      p__ = p__ < n_pairs ? p__ : 0;                                             \
+      gpre[q] = g__[p__];                                                        \
+    }                                                                            \
+  }
+  if (b < batch) HCTR_BWD16_PREFETCH(b)
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
+        const int row = i / W8, c8 = i % W8;
+        *reinterpret_cast<u32x4*>(xt + row * C::LD + c8 * 8) = pre[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+      const int p = lane + 64 * q;
+      if (p < n_pairs) {
+        const int nm = pair_nm[p];
+        const int n = nm >> 8, m = nm & 0xFF;
+        gm[n * GS + m] = gpre[q];
+        gm[m * GS + n] = gpre[q];
+      }
+    }
+    __syncthreads();
+    const size_t nb = b + gridDim.x;
+    if (nb < batch) HCTR_BWD16_PREFETCH(nb)
+
+    constexpr int HP = NT >= 2 ? 2 : 1;
+#pragma unroll
+    for (int pn = 0; pn < NT / HP; pn++) {
+      f32x16 acc[HP];
+#pragma unroll
+      for (int t = 0; t < HP; t++)
+        acc[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        const int k0 = 16 * s2 + 8 * h;
+        const typename H::vec8 af = *reinterpret_cast<const typename H::vec8*>(gm + r * GS + k0);
+#pragma unroll
+        for (int t = 0; t < HP; t++) {
+          const int col = (pn * HP + t) * 32 + r;
+          unsigned int w4[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const unsigned lo = xt[(k0 + 2 * e) * C::LD + col];
+            const unsigned hi = xt[(k0 + 2 * e + 1) * C::LD + col];
+            w4[e] = lo | (hi << 16);
+          }
+          const u32x4 packed = {w4[0], w4[1], w4[2], w4[3]};
+          const typename H::vec8 bfv = *reinterpret_cast<const typename H::vec8*>(&packed);
+          acc[t] = H::mfma(af, bfv, acc[t]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < HP; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+          const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          if (row < n_ins) xt[row * C::LD + (pn * HP + t) * 32 + r] = H::from_f32(acc[t][reg]);
+        }
+      }
+    }
+    __syncthreads();
+    const unsigned short* gtop = top_grad + b * (size_t)out_len;
+    u32x4* mg4 = reinterpret_cast<u32x4*>(mlp_grad + b * W);
+    u32x4* eg4 = reinterpret_cast<u32x4*>(emb_grad + b * (size_t)n_emb * W);
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
+        const int row = i / W8, c8 = i % W8;
+        u32x4 v = *reinterpret_cast<const u32x4*>(xt + row * C::LD + c8 * 8);
+        if (row == 0) {
+          const u32x4 gt = reinterpret_cast<const u32x4*>(gtop)[c8];
+          u32x4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const float a0 = H::to_f32((unsigned short)(v[e] & 0xFFFFu)) +
+                             H::to_f32((unsigned short)(gt[e] & 0xFFFFu));
+            const float a1 = H::to_f32((unsigned short)(v[e] >> 16)) +
+                             H::to_f32((unsigned short)(gt[e] >> 16));
+            o4[e] = (unsigned)H::from_f32(a0) | ((unsigned)H::from_f32(a1) << 16);
+          }
+          mg4[c8] = o4;
+        } else {
+          eg4[i - W8] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#undef HCTR_BWD16_PREFETCH
+}
+
 // any shape / dtype: one wavefront per sample, VALU dot products (fp32 accumulate)
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);
@@ -564,6 +826,30 @@ int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, co
       default: HCTR_IFWD(16) break;
     }
 #undef HCTR_IFWD
+  } else if ((dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16) && n_ins <= 32 && a16 &&
+             (width == 128 || width == 64 || width == 32 || width == 16)) {
+    const int stage_len = (out_len + 7) & ~7;
+    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
+    const bool bf = dtype == HCTR_EMB_BF16;
+#define HCTR_IFWD16(W_)                                                                         \
+  {                                                                                             \
+    const size_t lds = (size_t)((n_ins + 1) * InterCfg16<W_>::LD + stage_len) * 2;              \
+    if (bf)                                                                                     \
+      hipLaunchKernelGGL((interaction_fwd16_kernel<W_, true>), dim3(grid1), dim3(64), lds, s,   \
+                         batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,  \
+                         (unsigned short*)out, out_len);                                        \
+    else                                                                                        \
+      hipLaunchKernelGGL((interaction_fwd16_kernel<W_, false>), dim3(grid1), dim3(64), lds, s,  \
+                         batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,  \
+                         (unsigned short*)out, out_len);                                        \
+  }
+    switch (width) {
+      case 128: HCTR_IFWD16(128) break;
+      case 64: HCTR_IFWD16(64) break;
+      case 32: HCTR_IFWD16(32) break;
+      default: HCTR_IFWD16(16) break;
+    }
+#undef HCTR_IFWD16
   } else {
     const size_t lds = (size_t)kWavesPerBlock * n_ins * (width + 1) * 4;
     HCTR_REQUIRE(lds <= 160 * 1024, "interaction: tile does not fit LDS");
@@ -618,6 +904,34 @@ int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, co
       default: HCTR_IBWD(32) break;
     }
 #undef HCTR_IBWD
+  } else if ((dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16) && n_ins <= 32 && a16 &&
+             (out_len % 8 == 0) && reinterpret_cast<uintptr_t>(top_grad) % 16 == 0 &&
+             reinterpret_cast<uintptr_t>(mlp_grad) % 16 == 0 &&
+             reinterpret_cast<uintptr_t>(emb_grad) % 16 == 0 &&
+             (width == 128 || width == 64 || width == 32)) {
+    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
+    const int n_pairs = n_ins * (n_ins - 1) / 2;
+    const bool bf = dtype == HCTR_EMB_BF16;
+#define HCTR_IBWD16(W_)                                                                          \
+  {                                                                                              \
+    const size_t lds = (size_t)(InterCfg16<W_>::XT + 32 * 40 + ((n_pairs + 7) & ~7)) * 2;        \
+    if (bf)                                                                                      \
+      hipLaunchKernelGGL((interaction_bwd16_kernel<W_, true>), dim3(grid1), dim3(64), lds, s,    \
+                         batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
+                         (const unsigned short*)top_grad, (unsigned short*)mlp_grad,             \
+                         (unsigned short*)emb_grad, out_len);                                    \
+    else                                                                                         \
+      hipLaunchKernelGGL((interaction_bwd16_kernel<W_, false>), dim3(grid1), dim3(64), lds, s,   \
+                         batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
+                         (const unsigned short*)top_grad, (unsigned short*)mlp_grad,             \
+                         (unsigned short*)emb_grad, out_len);                                    \
+  }
+    switch (width) {
+      case 128: HCTR_IBWD16(128) break;
+      case 64: HCTR_IBWD16(64) break;
+      default: HCTR_IBWD16(32) break;
+    }
+#undef HCTR_IBWD16
   } else {
     const size_t lds = (size_t)kWavesPerBlock * (n_ins * (width + 1) + n_ins * n_ins) * 4;
     HCTR_REQUIRE(lds <= 160 * 1024, "interaction: tile does not fit LDS");

@@ -34,7 +34,9 @@ struct SparseUpdater {
   // tile-based segmented reduce: partial sums of runs that cross tile borders
   float* seg_head = nullptr;    // [tiles][D]
   float* seg_tail = nullptr;    // [tiles][D]
-  uint8_t* seg_flag = nullptr;  // [tiles] 1 = a border-crossing run starts in this tile
+  float* gsum = nullptr;           // [max_nnz][D] per-run gradient sums, indexed by run start
+  uint32_t* span_list = nullptr;   // [tiles] tiles in which a long (multi-tile) run starts
+  uint32_t* span_count = nullptr;  // device counter for span_list
   Profiler* prof = nullptr;
 
   int create(size_t max_nnz, size_t max_vocab, int D);

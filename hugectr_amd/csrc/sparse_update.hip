@@ -66,9 +66,10 @@ template <typename OffT, typename SortK>
 __global__ void __launch_bounds__(kBlock)
     expand_pairs_kernel(size_t buckets, size_t n_sort, const OffT* __restrict__ row_offset,
                         const uint64_t* __restrict__ value_index, SortK* __restrict__ keys,
-                        uint32_t* __restrict__ vals) {
+                        uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid == 0) *span_count = 0u;  // consumed by seg_update/seg_combine later in this stream
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   for (size_t u = tid; u < buckets; u += nthreads) {
     const size_t off = (size_t)row_offset[u], end = (size_t)row_offset[u + 1];
@@ -229,132 +230,340 @@ __device__ __forceinline__ bool needs_pt(const OptConst& o) {
   return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
 }
 
-// Row update shared by the tile kernel and the spanning-run combine kernel: gi = acc / scaler,
-// then the optimizer on the 4 elements this lane owns.
+// Row update shared by seg_apply_kernel and seg_combine_kernel, split in load / compute / store so
+// that callers can keep several rows in flight: gi = acc / scaler, then the optimizer on the 4
+// elements this lane owns.
+struct RowRegs {
+  float4 w, s0, s1;
+  unsigned long long pt[4];
+};
+
+template <int LPR>
+__device__ __forceinline__ void row_load(const OptConst& o, uint64_t row, int l, RowRegs& r,
+                                         const float* __restrict__ table,
+                                         const float* __restrict__ state0,
+                                         const float* __restrict__ state1,
+                                         const unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  const size_t f = row * (uint64_t)D + l * 4;
+  r.w = *reinterpret_cast<const float4*>(table + f);
+  r.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.s1 = r.s0;
+  r.pt[0] = r.pt[1] = r.pt[2] = r.pt[3] = 1ull;
+  if (needs_s0(o)) r.s0 = *reinterpret_cast<const float4*>(state0 + f);
+  if (needs_s1(o)) r.s1 = *reinterpret_cast<const float4*>(state1 + f);
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) r.pt[t] = prev_time[f + t];
+  }
+}
+
+__device__ __forceinline__ void row_compute(const OptConst& o, float4 gi, RowRegs& r) {
+  gi.x /= o.scaler;
+  gi.y /= o.scaler;
+  gi.z /= o.scaler;
+  gi.w /= o.scaler;
+  apply_opt(o, gi.x, r.w.x, &r.s0.x, &r.s1.x, &r.pt[0]);
+  apply_opt(o, gi.y, r.w.y, &r.s0.y, &r.s1.y, &r.pt[1]);
+  apply_opt(o, gi.z, r.w.z, &r.s0.z, &r.s1.z, &r.pt[2]);
+  apply_opt(o, gi.w, r.w.w, &r.s0.w, &r.s1.w, &r.pt[3]);
+}
+
+template <int LPR>
+__device__ __forceinline__ void row_store(const OptConst& o, uint64_t row, int l, const RowRegs& r,
+                                          float* __restrict__ table, float* __restrict__ state0,
+                                          float* __restrict__ state1,
+                                          unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  const size_t f = row * (uint64_t)D + l * 4;
+  const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
+                           o.update_type == HCTR_UPDATE_GLOBAL);
+  if (w_written) *reinterpret_cast<float4*>(table + f) = r.w;
+  if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = r.s0;
+  if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = r.s1;
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) prev_time[f + t] = r.pt[t];
+  }
+}
+
 template <int LPR>
 __device__ __forceinline__ void apply_row_vec4(const OptConst& o, uint64_t row, int l, float4 gi,
                                                float* __restrict__ table,
                                                float* __restrict__ state0,
                                                float* __restrict__ state1,
                                                unsigned long long* __restrict__ prev_time) {
-  constexpr int D = LPR * 4;
-  gi.x /= o.scaler;
-  gi.y /= o.scaler;
-  gi.z /= o.scaler;
-  gi.w /= o.scaler;
-  const size_t f = row * (uint64_t)D + l * 4;
-  float4 w = *reinterpret_cast<float4*>(table + f);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  unsigned long long pt[4] = {1ull, 1ull, 1ull, 1ull};
-  if (needs_s0(o)) s0 = *reinterpret_cast<float4*>(state0 + f);
-  if (needs_s1(o)) s1 = *reinterpret_cast<float4*>(state1 + f);
-  if (needs_pt(o)) {
-#pragma unroll
-    for (int t = 0; t < 4; t++) pt[t] = prev_time[f + t];
-  }
-  apply_opt(o, gi.x, w.x, &s0.x, &s1.x, &pt[0]);
-  apply_opt(o, gi.y, w.y, &s0.y, &s1.y, &pt[1]);
-  apply_opt(o, gi.z, w.z, &s0.z, &s1.z, &pt[2]);
-  apply_opt(o, gi.w, w.w, &s0.w, &s1.w, &pt[3]);
-  const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
-                           o.update_type == HCTR_UPDATE_GLOBAL);
-  if (w_written) *reinterpret_cast<float4*>(table + f) = w;
-  if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = s0;
-  if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = s1;
-  if (needs_pt(o)) {
-#pragma unroll
-    for (int t = 0; t < 4; t++) prev_time[f + t] = pt[t];
-  }
+  RowRegs r;
+  row_load<LPR>(o, row, l, r, table, state0, state1, prev_time);
+  row_compute(o, gi, r);
+  row_store<LPR>(o, row, l, r, table, state0, state1, prev_time);
 }
 
 // Tile-based segmented reduce + optimizer.  The sorted (row, bucket) list is cut into tiles of
-// kSegTile positions; a group of LPR lanes walks one tile in order, so every group performs the
-// same number of gradient-row reads no matter how skewed the key distribution is (the reference
-// gives one block to each unique row, sparse_optimizer.cu:223-237 -- a power-law head row with
-// 20k duplicates is then one serial 20k-iteration loop).  Runs that lie inside one tile are
-// reduced in ascending bucket order (the reference's order) and applied at once.  A run that
-// crosses tile borders leaves partial sums: `tail[t]` in the tile where it starts, `head[t']` in
-// every later tile it touches; seg_combine_kernel finishes those rows in fixed order.
+// kSegTile positions; a group of LPR lanes walks one tile in order, so every group performs about
+// the same number of gradient-row reads no matter how skewed the key distribution is (the
+// reference gives one block to each unique row, sparse_optimizer.cu:223-237 -- a power-law head
+// row with 20k duplicates is then one serial 20k-iteration loop).
+//   * A run (= all gradients of one row) that starts in tile t is OWNED by tile t's group.  The
+//     owner follows it up to one tile past its own tile end; the next tile's group skips those
+//     leading positions.  So every run that ends before the end of tile t+1 is reduced by one group
+//     in ascending bucket order (the reference's order, stable sort) and applied at once.
+//   * A run that reaches beyond tile t+1 is "long": the owner stores the sum of its own part in
+//     tail[t] and appends t to span_list; every later tile the run touches stores its part in
+//     head[t'].  seg_combine_kernel adds tail + heads in a fixed order (deterministic).
 constexpr int kSegTile = 32;
 
+template <typename GradT, int D>
+__device__ __forceinline__ float4 load_scaled_grad(const GradT* __restrict__ grad, uint32_t b,
+                                                   int l, int combiner, const void* row_offset_v,
+                                                   bool off_is_u32) {
+  float4 v = Load4<GradT>::ld(grad + (size_t)b * D + l * 4);
+  if (combiner == 1) {
+    long long n;
+    if (off_is_u32) {
+      const uint32_t* ro = (const uint32_t*)row_offset_v;
+      n = (long long)ro[b + 1] - (long long)ro[b];
+    } else {
+      const long long* ro = (const long long*)row_offset_v;
+      n = ro[b + 1] - ro[b];
+    }
+    const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
+    v.x = Load4<GradT>::rnd(v.x * sc);
+    v.y = Load4<GradT>::rnd(v.y * sc);
+    v.z = Load4<GradT>::rnd(v.z * sc);
+    v.w = Load4<GradT>::rnd(v.w * sc);
+  }
+  return v;
+}
+
+// Phase A: segmented sums.  Pure load/accumulate/store -- no read-modify-write of table rows
+// inside the walk.  The tile's 32 (row, bucket) pairs are fetched once, one per lane (coalesced),
+// run starts become a 32-bit ballot mask and bucket ids are broadcast with shuffles, so the walk
+// over the tile is straight-line code whose 32 gradient-row reads are independent of each other
+// (the only sequential part is the fp32 add chain, which is what fixes the summation order).
+// The sum of a run its owner finishes goes to gsum[start position]; seg_apply_kernel picks it up.
 template <int LPR, typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
-    seg_update_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+    seg_reduce_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                       const SortK* __restrict__ sorted_rows,
                       const uint32_t* __restrict__ sorted_buckets, int combiner,
-                      const GradT* __restrict__ grad, OptConst o, float* __restrict__ table,
-                      float* __restrict__ state0, float* __restrict__ state1,
-                      unsigned long long* __restrict__ prev_time, float* __restrict__ head,
-                      float* __restrict__ tail, uint8_t* __restrict__ tail_flag) {
+                      const GradT* __restrict__ grad, float* __restrict__ gsum,
+                      float* __restrict__ head, float* __restrict__ tail,
+                      uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
-  constexpr int U = 4;
+  constexpr int T = kSegTile;
+  constexpr int ML = LPR < T ? LPR : T;  // lanes of a group that carry tile metadata
+  constexpr int NPL = T / ML;            // metadata entries per such lane
+  constexpr bool kOff32 = sizeof(OffT) == 4;
+  static_assert(T == 32, "masks are 32-bit");
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
+  const int gshift = ((threadIdx.x & 63) / LPR) * LPR;  // first lane of my group in the wave
+  constexpr unsigned long long kGroupMask = ML >= 64 ? ~0ull : ((1ull << ML) - 1ull);
   const size_t nnz = (size_t)row_offset[buckets];
-  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
+  const size_t n_tiles = (nnz + T - 1) / T;
   for (size_t tile = (size_t)blockIdx.x * GPB + g; tile < n_tiles;
        tile += (size_t)gridDim.x * GPB) {
-    const size_t base = tile * kSegTile;
-    const size_t end = (base + kSegTile < nnz) ? base + kSegTile : nnz;
-    SortK cur_row = sorted_rows[base];
-    bool cont = base > 0 && sorted_rows[base - 1] == cur_row;
+    const size_t base = tile * T;
+    const size_t end = (base + T < nnz) ? base + T : nnz;
+    const int nvalid = (int)(end - base);
+    uint32_t mrow[NPL], mbkt[NPL];
+    uint32_t startmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const size_t pos = base + (size_t)j * ML + l;
+      const bool valid = l < ML && pos < end;
+      mrow[j] = valid ? (uint32_t)sorted_rows[pos] : 0xFFFFFFFFu;
+      mbkt[j] = valid ? sorted_buckets[pos] : 0u;
+      const bool is_start = valid && (pos == 0 || (uint32_t)sorted_rows[pos - 1] != mrow[j]);
+      const unsigned long long bal = __ballot(is_start);
+      startmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
+    }
+    const uint32_t row0 = (uint32_t)__shfl((int)mrow[0], gshift, 64);
+    int q0 = 0;
+    bool head_mode = false;
+    if (base > 0 && (startmask & 1u) == 0u) {
+      // the tile starts inside a run begun earlier: owned by the previous tile AND ending inside
+      // this tile -> its owner reduces it, skip it; otherwise it is (part of) a long run.
+      const bool owner_prev = (uint32_t)sorted_rows[base - T] != row0 || base == (size_t)T ||
+                              (uint32_t)sorted_rows[base - T - 1] != row0;
+      const bool whole_tile = startmask == 0u;
+      const bool ends_inside = !whole_tile || end == nnz || (uint32_t)sorted_rows[end] != row0;
+      if (owner_prev && ends_inside) q0 = whole_tile ? nvalid : __ffs((int)startmask) - 1;
+      else head_mode = true;
+    }
+    if (q0 >= nvalid) continue;  // the whole tile belonged to the previous tile's run
+    int run_start = q0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t k = base; k < end; k += U) {
-      SortK r[U];
-      uint32_t b[U];
-      float4 v[U];
+    // Walk the tile in batches of QB positions: all QB gradient-row reads of a batch are issued
+    // back to back (unconditionally, clamped to a valid position) BEFORE any of the branchy
+    // flush/accumulate logic, so a group keeps QB reads in flight instead of one.
+    constexpr int QB = 8;
 #pragma unroll
-      for (int t = 0; t < U; t++) {
-        const size_t kk = (k + t < end) ? k + t : end - 1;
-        r[t] = sorted_rows[kk];
-        b[t] = sorted_buckets[kk];
+    for (int qb = 0; qb < T; qb += QB) {
+      if (qb + QB <= q0 || qb >= nvalid) continue;  // group-uniform
+      float4 v[QB];
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const int q = qb + k;
+        const int qc = q < nvalid ? q : nvalid - 1;  // clamp: the read is always legal
+        const uint32_t bsel = (uint32_t)__shfl((int)mbkt[q / ML], gshift + (q % ML), 64);
+        const uint32_t blast =
+            (uint32_t)__shfl((int)mbkt[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
+        v[k] = load_scaled_grad<GradT, D>(grad, qc == q ? bsel : blast, l, combiner, row_offset,
+                                          kOff32);
       }
 #pragma unroll
-      for (int t = 0; t < U; t++) v[t] = Load4<GradT>::ld(grad + (size_t)b[t] * D + l * 4);
-      if (combiner == 1) {
-#pragma unroll
-        for (int t = 0; t < U; t++) {
-          const long long n = (long long)row_offset[b[t] + 1] - (long long)row_offset[b[t]];
-          const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
-          v[t].x = Load4<GradT>::rnd(v[t].x * sc);
-          v[t].y = Load4<GradT>::rnd(v[t].y * sc);
-          v[t].z = Load4<GradT>::rnd(v[t].z * sc);
-          v[t].w = Load4<GradT>::rnd(v[t].w * sc);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < U; t++) {
-        if (k + t < end) {
-          if (r[t] != cur_row) {
-            if (cont) *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
-            else apply_row_vec4<LPR>(o, (uint64_t)cur_row, l, acc, table, state0, state1, prev_time);
+      for (int k = 0; k < QB; k++) {
+        const int q = qb + k;
+        if (q >= q0 && q < nvalid) {
+          if (((startmask >> q) & 1u) != 0u && q != q0) {
+            float* dst = head_mode ? head + tile * D : gsum + (base + run_start) * D;
+            *reinterpret_cast<float4*>(dst + l * 4) = acc;
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            cur_row = r[t];
-            cont = false;
+            run_start = q;
+            head_mode = false;
           }
-          acc.x += v[t].x;
-          acc.y += v[t].y;
-          acc.z += v[t].z;
-          acc.w += v[t].w;
+          acc.x += v[k].x;
+          acc.y += v[k].y;
+          acc.z += v[k].z;
+          acc.w += v[k].w;
         }
       }
     }
-    const bool continues = (end < nnz) && sorted_rows[end] == cur_row;
-    if (cont) {
+    if (head_mode) {  // one run covers the whole tile
       *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
-    } else if (continues) {
-      *reinterpret_cast<float4*>(tail + tile * D + l * 4) = acc;
-    } else {
-      apply_row_vec4<LPR>(o, (uint64_t)cur_row, l, acc, table, state0, state1, prev_time);
+      continue;
     }
-    if (l == 0) tail_flag[tile] = (!cont && continues) ? 1 : 0;
+    const uint32_t cur_row =
+        (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
+    if (end == nnz || (uint32_t)sorted_rows[end] != cur_row) {
+      *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
+      continue;
+    }
+    // the last run of this tile continues: this group owns it and follows it through tile+1
+    const float4 own_part = acc;
+    const size_t limit = (end + T < nnz) ? end + T : nnz;
+    uint32_t mbkt2[NPL];
+    uint32_t matchmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const size_t pos = end + (size_t)j * ML + l;
+      const bool valid = l < ML && pos < limit;
+      const bool match = valid && (uint32_t)sorted_rows[pos] == cur_row;
+      mbkt2[j] = valid ? sorted_buckets[pos] : 0u;
+      const unsigned long long bal = __ballot(match);
+      matchmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
+    }
+    const int cnt = (~matchmask == 0u) ? T : __ffs((int)~matchmask) - 1;  // leading ones
+#pragma unroll
+    for (int qb = 0; qb < T; qb += QB) {
+      if (qb >= cnt) continue;  // group-uniform
+      float4 v[QB];
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const int q = qb + k;
+        const uint32_t bsel = (uint32_t)__shfl((int)mbkt2[q / ML], gshift + (q % ML), 64);
+        const uint32_t bfirst = (uint32_t)__shfl((int)mbkt2[0], gshift, 64);
+        v[k] = load_scaled_grad<GradT, D>(grad, q < cnt ? bsel : bfirst, l, combiner, row_offset,
+                                          kOff32);
+      }
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        if (qb + k < cnt) {
+          acc.x += v[k].x;
+          acc.y += v[k].y;
+          acc.z += v[k].z;
+          acc.w += v[k].w;
+        }
+      }
+    }
+    // long <=> the run reaches beyond the end of tile+1
+    const bool runs_on = cnt == T && limit < nnz && (uint32_t)sorted_rows[limit] == cur_row;
+    if (!runs_on) {
+      *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
+    } else {
+      *reinterpret_cast<float4*>(tail + tile * D + l * 4) = own_part;
+      if (l == 0) span_list[atomicAdd(span_count, 1u)] = (uint32_t)tile;
+    }
   }
 }
 
-// One workgroup per run that crosses tile borders (it starts in the tile whose tail_flag is set).
-// Group q adds head partials of tiles t0+1+q, t0+1+q+GPB, ...; the GPB sums are then added to
-// tail[t0] in the fixed order q = 0..GPB-1 (deterministic).
+// Phase B: one lane inspects one sorted position; run starts of runs that are not "long" are
+// compacted with a wave ballot and handed to lane groups, which read the run's gradient sum from
+// gsum[position] and apply the optimizer to the row (one coalesced D*4-byte RMW per row).
+template <int LPR, typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    seg_apply_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                     const SortK* __restrict__ sorted_rows, const float* __restrict__ gsum,
+                     OptConst o, float* __restrict__ table, float* __restrict__ state0,
+                     float* __restrict__ state1, unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  constexpr int G = 64 / LPR;  // groups per wavefront
+  constexpr int T = kSegTile;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t c0 = wave * 64; c0 < nnz; c0 += nwaves * 64) {
+    const size_t p = c0 + lane;
+    SortK row = 0;
+    bool active = false;
+    if (p < nnz) {
+      row = sorted_rows[p];
+      const bool is_start = p == 0 || sorted_rows[p - 1] != row;
+      if (is_start) {
+        const size_t e2 = (p / T + 2) * T;  // first position after the tile following p's tile
+        const bool is_long = e2 < nnz && sorted_rows[e2] == row;
+        active = !is_long;
+      }
+    }
+    unsigned long long mask = __ballot(active);
+    // R rows per group per step: all gsum / table / state reads of a step are issued before the
+    // first optimizer evaluation
+    constexpr int R = 4;
+    while (mask != 0ull) {
+      int src[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        src[k] = -1;
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+          if (mask != 0ull) {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            if (q == g) src[k] = bit;
+          }
+        }
+      }
+      uint32_t r2[R];
+      float4 gi[R];
+      RowRegs rr[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
+        if (src[k] >= 0) {
+          gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
+          row_load<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        if (src[k] >= 0) {
+          row_compute(o, gi[k], rr[k]);
+          row_store<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+        }
+      }
+    }
+  }
+}
+
+// One workgroup per long run (listed in span_list by the tile it starts in).  Group q adds head
+// partials of tiles t0+1+q, t0+1+q+GPB, ...; the GPB sums are then added to tail[t0] in the fixed
+// order q = 0..GPB-1, so the result does not depend on scheduling.
 template <int LPR, typename OffT, typename SortK>
 __global__ void __launch_bounds__(kBlock)
     seg_combine_kernel(size_t buckets, const OffT* __restrict__ row_offset,
@@ -362,7 +571,8 @@ __global__ void __launch_bounds__(kBlock)
                        float* __restrict__ table, float* __restrict__ state0,
                        float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
                        const float* __restrict__ head, const float* __restrict__ tail,
-                       const uint8_t* __restrict__ tail_flag) {
+                       const uint32_t* __restrict__ span_list,
+                       const uint32_t* __restrict__ span_count) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   __shared__ float4 part[kBlock];
@@ -370,8 +580,9 @@ __global__ void __launch_bounds__(kBlock)
   const int l = threadIdx.x % LPR;
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
-  for (size_t t0 = blockIdx.x; t0 < n_tiles; t0 += gridDim.x) {
-    if (tail_flag[t0] == 0) continue;  // block-uniform
+  const uint32_t n_span = *span_count;
+  for (uint32_t si = blockIdx.x; si < n_span; si += gridDim.x) {
+    const size_t t0 = span_list[si];
     const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     // 8 head partials in flight per group (a 20k-duplicate head row spans ~680 tiles)
@@ -604,7 +815,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     SortK* kin = (SortK*)u.sort_keys_in;
     SortK* kout = (SortK*)u.sort_keys_out;
     hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
-                       dim3(kBlock), 0, s, buckets, nnz, ro, vi, kin, u.sort_vals_in);
+                       dim3(kBlock), 0, s, buckets, nnz, ro, vi, kin, u.sort_vals_in, u.span_count);
     HCTR_LAUNCH_CHECK();
     // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
     int end_bit = 1;
@@ -622,15 +833,19 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
     const size_t seg_tiles = ceil_div<size_t>(nnz, (size_t)kSegTile);                             \
-    hipLaunchKernelGGL((seg_update_kernel<LPR_, OffT, SortK, GradT>),                             \
-                       dim3(grid_for(seg_tiles, GPB, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,  \
-                       kout, u.sort_vals_out, combiner, grad, o, table, state0, state1,           \
-                       (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.seg_flag);       \
+    hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT>),                             \
+                       dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,  \
+                       kout, u.sort_vals_out, combiner, grad, u.gsum, u.seg_head, u.seg_tail,     \
+                       u.span_list, u.span_count);                                                \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                     \
+                       dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,     \
+                       kout, u.gsum, o, table, state0, state1, (unsigned long long*)prev_time);   \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
-                       dim3(grid_for(seg_tiles, 1, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,    \
-                       kout, o, table, state0, state1, (unsigned long long*)prev_time,            \
-                       u.seg_head, u.seg_tail, u.seg_flag);                                       \
+                       dim3(grid_for(seg_tiles, 1, 1024)), dim3(kBlock), 0, s, buckets, ro, kout, \
+                       o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head,      \
+                       u.seg_tail, u.span_list, u.span_count);                                    \
   }
     if (a16 && D % 4 == 0) {
       done = true;
@@ -740,20 +955,25 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   const size_t seg_tiles = ceil_div<size_t>(max_nnz, (size_t)kSegTile) + 1;
   HCTR_HIP(hipMalloc(&seg_head, seg_tiles * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
-  HCTR_HIP(hipMalloc(&seg_flag, seg_tiles));
+  HCTR_HIP(hipMalloc(&gsum, max_nnz * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&span_list, seg_tiles * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&span_count, sizeof(uint32_t)));
+  HCTR_HIP(hipMemset(span_count, 0, sizeof(uint32_t)));
   return HCTR_OK;
 }
 
 int SparseUpdater::destroy() {
   void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
-                  run_start,    d_num_runs,    seg_head,     seg_tail,      seg_flag};
+                  run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
+                  gsum};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   sort_keys_in = sort_keys_out = sort_temp = nullptr;
   sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
   d_num_runs = nullptr;
   seg_head = seg_tail = nullptr;
-  seg_flag = nullptr;
+  span_list = span_count = nullptr;
+  gsum = nullptr;
   return HCTR_OK;
 }
 

@@ -87,3 +87,29 @@ def test_cross_v2_matches_oracle(oracle):
     out = layer(torch.from_numpy(x0).cuda())
     outs, _, _ = oracle.cross_v2_fwd(x0, U, V, b)
     assert_close(out.detach().cpu().numpy(), outs[-1], 1e-3, 1e-4, "cross v2 fwd")
+
+
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,n_emb,W", [(512, 26, 128), (70, 26, 64), (33, 13, 32)])
+def test_interaction_16bit(oracle, dtype_name, B, n_emb, W):
+    """mixed-precision mode (reference: InteractionLayer<__half>, eps 1.0 in its own test,
+    interaction_layer_test.cpp:44-47); oracle = fp32 math on the 16-bit-rounded inputs"""
+    import torch
+    import hugectr_amd as ha
+    dt = getattr(torch, dtype_name)
+    rng = np.random.default_rng(B + W)
+    mt = torch.from_numpy(rng.standard_normal((B, W)).astype(np.float32)).cuda().to(dt)
+    et = torch.from_numpy(rng.standard_normal((B, n_emb, W)).astype(np.float32)).cuda().to(dt)
+    mlp, emb = mt.float().cpu().numpy(), et.float().cpu().numpy()
+    mt.requires_grad_(True)
+    et.requires_grad_(True)
+    out = ha.interaction(mt, et)
+    assert out.dtype == dt
+    want = oracle.interaction_fwd(mlp, emb)
+    eps = 2.0 ** -7 if dtype_name == "bfloat16" else 2.0 ** -10
+    assert_close(out.detach().float().cpu().numpy(), want, 2 * eps, 2 * eps * 12, "fwd16")
+    gt = torch.from_numpy(rng.standard_normal(want.shape).astype(np.float32)).cuda().to(dt)
+    out.backward(gt)
+    mg, eg = oracle.interaction_bwd(mlp, emb, gt.float().cpu().numpy())
+    assert_close(mt.grad.float().cpu().numpy(), mg, 4 * eps, 4 * eps * 8, "mlp grad16")
+    assert_close(et.grad.float().cpu().numpy(), eg, 4 * eps, 4 * eps * 8, "emb grad16")

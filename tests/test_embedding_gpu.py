@@ -236,3 +236,44 @@ def test_dump_load_roundtrip(oracle):
     out_b = b.forward(False, _t(torch, ro), _t(torch, keys))
     assert (out_a.cpu() == out_b.cpu()).all()
     assert b.get_vocabulary_size() == a.get_vocabulary_size()
+
+
+@pytest.mark.parametrize("D,opt_kw", [(128, dict(optimizer=6, atomic_update=False)),
+                                      (16, dict(optimizer=3)),
+                                      (64, dict(optimizer=1, update_type=0))])
+def test_update_power_law_duplicates(oracle, D, opt_kw):
+    """Criteo-like skew: tiny tables (3, 4, 10 rows) next to big ones -> a row collects thousands
+    of gradients; exercises the long-run (tail/head partial + combine) path of the segmented
+    update as well as runs crossing exactly one tile border."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(11)
+    B = 2048
+    sizes = [3, 4, 10, 36, 1000, 50000, 1, 97]
+    S = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    keys = np.stack([np.minimum((rng.pareto(1.1, size=B)).astype(np.int64), v - 1) + o
+                     for v, o in zip(sizes, offs)], axis=1).reshape(-1)
+    ro = np.arange(B * S + 1, dtype=np.int64)
+    V = int(sum(sizes))
+    opt = ha.OptParams(lr=0.01, scaler=1.0, **opt_kw)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S, S, 0, opt)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    ns = {1: 2, 3: 1, 6: 0}[opt.optimizer]
+    s0 = np.zeros_like(table) if ns >= 1 else None
+    s1 = np.zeros_like(table) if ns >= 2 else None
+    ht = oracle.HashTable(V, 8)
+    for it in range(2):
+        emb.forward(True, _t(torch, ro), _t(torch, keys))
+        vi = ht.get_insert(keys)
+        g = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+        emb.backward(_t(torch, g).view(B, S, D))
+        emb.update_params()
+        torch.cuda.synchronize()
+        oracle.update_params(ro, vi, g, _oracle_opt(oracle, opt, it + 1), table, s0, s1, None)
+        # long runs are summed tile-wise (different association than the sequential oracle)
+        assert_close(emb.table().cpu().numpy(), table, 2e-4, 2e-5, f"table it{it}")
+        keys = np.roll(keys, 7)  # different run/tile alignment in the second step
