@@ -1,0 +1,340 @@
+"""Dataset formats either side of the hot path: synthetic data generator and readers.
+
+* Parquet dataset layout of the reference (`_file_list.txt`, `_metadata.json` with file_stats /
+  cats / conts / labels; R/HugeCTR/src/data_readers/metadata.cpp:60-135) read with pyarrow.
+  Keys get the cumulative `slot_size_array` offsets added, as the reference's Parquet reader does
+  (R/HugeCTR/src/pybind/add_input.cpp:315-317), so keys are globally unique.
+* Norm binary format (DataSetHeader 8 x int64, R/HugeCTR/include/common.hpp:184-191; per sample
+  label[f32 x L] dense[f32 x Dn] then per slot `nnz:int32, keys[nnz]`; optional CheckSum framing
+  `int32 length | payload | int8 sum`, R/HugeCTR/include/data_readers/check_sum.hpp:39-75) --
+  write + read helpers (the reference's Python path marks Norm deprecated; its CPU test oracle
+  still reads it, R/test/utest/embedding/sparse_embedding_hash_cpu.hpp:343-377).
+* hugectr.tools.DataGenerator(DataGeneratorParams).generate()
+  (R/HugeCTR/include/pybind/data_generator_wrapper.hpp:29-69; power law alpha: Long 0.9 /
+  Medium 1.1 / Short 1.3, R/HugeCTR/src/data_generator.cpp:94-116).
+
+Every rank reads the FULL batch of keys (the reference broadcasts the whole CSR to every GPU,
+R/HugeCTR/src/data_readers/data_collector.cu:86-113) and its own slice of dense/label.
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def powerlaw_keys(rng: np.random.Generator, n: int, vocab: int, alpha: float) -> np.ndarray:
+    """IntPowerLawDataSimulator (R/HugeCTR/include/data_generator.hpp:108-129), vectorised."""
+    u = rng.random(n, dtype=np.float32).astype(np.float64)
+    a = 1.0 - alpha
+    y = ((float(vocab) ** a - 1.0) * u + 1.0) ** (1.0 / a)
+    return np.clip(np.round(y) - 1, 0, vocab - 1).astype(np.int64)
+
+
+@dataclass
+class DataGeneratorParams:
+    format: object
+    label_dim: int
+    dense_dim: int
+    num_slot: int
+    i64_input_key: bool
+    source: str
+    eval_source: str
+    slot_size_array: Sequence[int]
+    nnz_array: Sequence[int] = field(default_factory=list)
+    check_type: object = None
+    dist_type: object = None
+    power_law_type: object = None
+    alpha: float = 1.2
+    num_files: int = 128
+    eval_num_files: int = 32
+    num_samples_per_file: int = 40960
+    num_samples: int = 5242880
+    eval_num_samples: int = 1310720
+    float_label_dense: bool = False
+    num_threads: int = 1
+
+
+class DataGenerator:
+    def __init__(self, data_generator_params: DataGeneratorParams):
+        self.p = data_generator_params
+
+    def _alpha(self) -> float:
+        p = self.p
+        dist = getattr(p.dist_type, "name", "PowerLaw")
+        if dist == "Uniform":
+            return 0.0
+        plt = getattr(p.power_law_type, "name", "Specific")
+        return {"Long": 0.9, "Medium": 1.1, "Short": 1.3}.get(plt, p.alpha)
+
+    def _samples(self, rng, n):
+        p = self.p
+        alpha = self._alpha()
+        nnz = list(p.nnz_array) if p.nnz_array else [1] * p.num_slot
+        label = (rng.random((n, p.label_dim)) < 0.5).astype(np.float32)
+        dense = rng.random((n, p.dense_dim), dtype=np.float32)
+        cats = []
+        for s in range(p.num_slot):
+            v = int(p.slot_size_array[s])
+            k = (powerlaw_keys(rng, n * nnz[s], v, alpha) if alpha > 0
+                 else rng.integers(0, v, size=n * nnz[s]).astype(np.int64))
+            cats.append(k.reshape(n, nnz[s]))
+        return label, dense, cats
+
+    def generate(self):
+        p = self.p
+        fmt = getattr(p.format, "name", str(p.format))
+        rng = np.random.default_rng(20240923)
+        for src, total, nfiles in ((p.source, p.num_samples, p.num_files),
+                                   (p.eval_source, p.eval_num_samples, p.eval_num_files)):
+            if not src:
+                continue
+            folder = os.path.dirname(src) or "."
+            os.makedirs(folder, exist_ok=True)
+            per_file = min(p.num_samples_per_file, max(1, total // max(nfiles, 1)))
+            nfiles = max(1, total // per_file)
+            names = []
+            stats = []
+            for f in range(nfiles):
+                label, dense, cats = self._samples(rng, per_file)
+                if fmt == "Parquet":
+                    name = os.path.join(folder, f"gen_{f}.parquet")
+                    write_parquet(name, label, dense, cats)
+                    stats.append({"file_name": os.path.basename(name), "num_rows": per_file})
+                else:
+                    name = os.path.join(folder, f"gen_{f}.data")
+                    write_norm(name, label, dense, cats, p.i64_input_key,
+                               check_sum=getattr(p.check_type, "name", "Sum") == "Sum")
+                names.append(name)
+            with open(src, "w") as fl:
+                fl.write(f"{len(names)}\n" + "\n".join(names) + "\n")
+            if fmt == "Parquet":
+                cols = parquet_columns(p.label_dim, p.dense_dim, p.num_slot)
+                meta = {"file_stats": stats,
+                        "labels": [{"col_name": c, "index": i} for i, c in enumerate(cols[0])],
+                        "conts": [{"col_name": c, "index": p.label_dim + i}
+                                  for i, c in enumerate(cols[1])],
+                        "cats": [{"col_name": c, "index": p.label_dim + p.dense_dim + i}
+                                 for i, c in enumerate(cols[2])]}
+                with open(os.path.join(folder, "_metadata.json"), "w") as fm:
+                    json.dump(meta, fm)
+
+
+def parquet_columns(label_dim, dense_dim, num_slot):
+    return ([f"label{i}" if label_dim > 1 else "label" for i in range(label_dim)],
+            [f"I{i + 1}" for i in range(dense_dim)], [f"C{i + 1}" for i in range(num_slot)])
+
+
+def write_parquet(path, label, dense, cats):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    lc, dc, cc = parquet_columns(label.shape[1], dense.shape[1], len(cats))
+    arrays, names = [], []
+    for i, c in enumerate(lc):
+        arrays.append(pa.array(label[:, i], type=pa.float32()))
+        names.append(c)
+    for i, c in enumerate(dc):
+        arrays.append(pa.array(dense[:, i], type=pa.float32()))
+        names.append(c)
+    for i, c in enumerate(cc):
+        k = cats[i]
+        if k.shape[1] == 1:
+            arrays.append(pa.array(k[:, 0], type=pa.int64()))
+        else:  # multi-hot: list<int64> column
+            arrays.append(pa.array(k.tolist(), type=pa.list_(pa.int64())))
+        names.append(c)
+    pq.write_table(pa.Table.from_arrays(arrays, names=names), path)
+
+
+def write_norm(path, label, dense, cats, i64_key=True, check_sum=False):
+    n = label.shape[0]
+    kfmt = "<i8" if i64_key else "<u4"
+    with open(path, "wb") as f:
+        hdr = struct.pack("<8q", 1 if check_sum else 0, n, label.shape[1], dense.shape[1], len(cats),
+                          0, 0, 0)
+        _w(f, hdr, check_sum)
+        for i in range(n):
+            rec = label[i].astype("<f4").tobytes() + dense[i].astype("<f4").tobytes()
+            for k in cats:
+                rec += struct.pack("<i", k.shape[1]) + k[i].astype(kfmt).tobytes()
+            _w(f, rec, check_sum)
+
+
+def _w(f, payload: bytes, check_sum: bool):
+    if check_sum:
+        s = np.frombuffer(payload, dtype=np.int8).sum(dtype=np.int64)
+        f.write(struct.pack("<i", len(payload)) + payload + struct.pack("<b", int(np.int8(s))))
+    else:
+        f.write(payload)
+
+
+def read_norm(path, i64_key=True):
+    """-> (label [n,L], dense [n,Dn], row_offset [n*S+1], keys [nnz]) as the reference's
+    read_a_batch builds them (sparse_embedding_hash_cpu.hpp:343-377)."""
+    raw = open(path, "rb").read()
+    pos = [0]
+    framed = struct.unpack_from("<i", raw, 0)[0] == 64  # CheckSum framing wraps the 64-byte header
+
+    def rd(nbytes):
+        b = raw[pos[0]:pos[0] + nbytes]
+        pos[0] += nbytes
+        return b
+
+    def record():
+        if framed:
+            ln = struct.unpack("<i", rd(4))[0]
+            payload = rd(ln)
+            chk = struct.unpack("<b", rd(1))[0]
+            assert int(np.int8(np.frombuffer(payload, dtype=np.int8).sum(dtype=np.int64))) == chk, \
+                "Norm file: checksum mismatch"
+            return payload
+        return None
+
+    hdr = record() if framed else rd(64)
+    err, n, L, Dn, S, _, _, _ = struct.unpack("<8q", hdr)
+    ksz = 8 if i64_key else 4
+    label = np.empty((n, L), np.float32)
+    dense = np.empty((n, Dn), np.float32)
+    ro = [0]
+    keys = []
+    for i in range(n):
+        if framed:
+            buf, o = record(), 0
+        else:
+            buf, o = raw, pos[0]
+        label[i] = np.frombuffer(buf, "<f4", L, o)
+        o += 4 * L
+        dense[i] = np.frombuffer(buf, "<f4", Dn, o)
+        o += 4 * Dn
+        for _ in range(S):
+            nnz = struct.unpack_from("<i", buf, o)[0]
+            o += 4
+            keys.append(np.frombuffer(buf, "<i8" if i64_key else "<u4", nnz, o).astype(np.int64))
+            o += ksz * nnz
+            ro.append(ro[-1] + nnz)
+        if not framed:
+            pos[0] = o
+    return label, dense, np.asarray(ro, np.int64), (np.concatenate(keys) if keys else
+                                                    np.empty(0, np.int64))
+
+
+class ParquetReader:
+    """Streams batches from a reference-layout Parquet dataset."""
+
+    def __init__(self, file_list: str, inp, slot_size_array, batch, rank, world, device, i64_key,
+                 repeat: bool):
+        import pyarrow.parquet as pq
+        self.pq = pq
+        lines = [l.strip() for l in open(file_list) if l.strip()]
+        self.files = lines[1:1 + int(lines[0])]
+        folder = os.path.dirname(file_list) or "."
+        self.files = [f if os.path.isabs(f) or os.path.exists(f) else os.path.join(folder, os.path.basename(f))
+                      for f in self.files]
+        meta_path = os.path.join(folder, "_metadata.json")
+        if not os.path.exists(meta_path):
+            raise RuntimeError(f"{meta_path} not found (Parquet datasets need _metadata.json)")
+        meta = json.load(open(meta_path))
+        self.label_cols = [c["col_name"] for c in meta["labels"]]
+        self.cont_cols = [c["col_name"] for c in meta["conts"]]
+        self.cat_cols = [c["col_name"] for c in meta["cats"]]
+        self.inp, self.batch, self.rank, self.world = inp, batch, rank, world
+        self.device, self.repeat = device, repeat
+        self.key_dtype = torch.int64 if i64_key else torch.int32
+        ssa = list(slot_size_array)
+        self.slot_offsets = np.concatenate([[0], np.cumsum(ssa)[:-1]]).astype(np.int64) if ssa \
+            else np.zeros(len(self.cat_cols), np.int64)
+        self._file_idx, self._buf, self._pos = 0, None, 0
+        self._epoch_done = False
+
+    def _load_next_file(self) -> bool:
+        if self._file_idx >= len(self.files):
+            if not self.repeat:
+                return False
+            self._file_idx = 0
+        t = self.pq.read_table(self.files[self._file_idx])
+        self._file_idx += 1
+        label = np.stack([t[c].to_numpy() for c in self.label_cols], 1).astype(np.float32)
+        dense = (np.stack([t[c].to_numpy() for c in self.cont_cols], 1).astype(np.float32)
+                 if self.cont_cols else np.zeros((t.num_rows, 0), np.float32))
+        cats = []
+        for s, c in enumerate(self.cat_cols):
+            col = t[c]
+            if str(col.type).startswith("list"):
+                lists = col.to_pylist()
+                cats.append([np.asarray(v, np.int64) + self.slot_offsets[s] for v in lists])
+            else:
+                cats.append(col.to_numpy().astype(np.int64) + self.slot_offsets[s])
+        self._buf, self._pos = (label, dense, cats), 0
+        return True
+
+    def next_batch(self):
+        B = self.batch
+        if self._buf is None or self._pos + B > self._buf[0].shape[0]:
+            # the reference drops the incomplete tail of a file (drop_incomplete_batch=True)
+            if not self._load_next_file():
+                return None
+            if self._buf[0].shape[0] < B:
+                raise RuntimeError("parquet file holds fewer rows than one batch")
+        label, dense, cats = self._buf
+        a, b = self._pos, self._pos + B
+        self._pos = b
+        bpg = B // self.world
+        sl = slice(a + self.rank * bpg, a + (self.rank + 1) * bpg)
+        out = {"label": torch.from_numpy(label[sl]).to(self.device),
+               "dense": torch.from_numpy(dense[sl]).to(self.device), "sparse": {}}
+        # one DataReaderSparseParam may cover a contiguous group of slots
+        s0 = 0
+        for p in self.inp.sparse_params:
+            group = cats[s0:s0 + p.slot_num]
+            s0 += p.slot_num
+            if all(isinstance(g, np.ndarray) for g in group):  # one-hot fast path
+                keys = np.stack([g[a:b] for g in group], 1).reshape(-1)
+                ro = np.arange(B * p.slot_num + 1, dtype=np.int64)
+            else:
+                lens = np.empty((B, p.slot_num), np.int64)
+                parts = []
+                for i in range(B):
+                    for s, g in enumerate(group):
+                        v = g[a + i] if isinstance(g, list) else g[a + i:a + i + 1]
+                        lens[i, s] = len(v)
+                        parts.append(v)
+                keys = np.concatenate(parts) if parts else np.empty(0, np.int64)
+                ro = np.concatenate([[0], np.cumsum(lens.reshape(-1))]).astype(np.int64)
+            kt = torch.from_numpy(keys)
+            rt = torch.from_numpy(ro)
+            if self.key_dtype != torch.int64:
+                kt, rt = kt.to(torch.int32), rt.to(torch.int32)
+            out["sparse"][p.top_name] = (rt.to(self.device), kt.to(self.device))
+        return out
+
+
+class _Readers:
+    def __init__(self, train, evalr):
+        self.train, self.evalr = train, evalr
+
+    def next_batch(self, train: bool):
+        r = self.train if train else self.evalr
+        return None if r is None else r.next_batch()
+
+    def has_eval(self) -> bool:
+        return self.evalr is not None
+
+
+def make_reader(rp, inp, solver, rank, world, device):
+    fmt = getattr(rp.data_reader_type, "name", str(rp.data_reader_type))
+    if fmt != "Parquet":
+        # the reference's Python path rejects Norm/Raw as deprecated (add_input.cpp:318-325)
+        raise RuntimeError(f"DataReaderType_t.{fmt} is deprecated in the reference and not supported; "
+                           "use Parquet")
+    train = ParquetReader(rp.source[0], inp, rp.slot_size_array, solver.batchsize, rank, world,
+                          device, solver.i64_input_key, solver.repeat_dataset)
+    evalr = None
+    if rp.eval_source and os.path.exists(rp.eval_source) and solver.batchsize_eval > 0:
+        evalr = ParquetReader(rp.eval_source, inp, rp.slot_size_array, solver.batchsize_eval, rank,
+                              world, device, solver.i64_input_key, True)
+    return _Readers(train, evalr)

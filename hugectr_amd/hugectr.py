@@ -1,0 +1,757 @@
+"""`hugectr`-shaped Python surface (solver + layer API) over the MI355X-native hot path.
+
+Mirrors the reference's pybind module (R/HugeCTR/src/pybind/module_main.cpp:36-48): CreateSolver
+(kwargs/defaults of R/HugeCTR/include/pybind/solver_wrapper.hpp:127-150), DataReaderParams,
+CreateOptimizer (optimizer_wrapper.hpp:35-40), Input / DataReaderSparseParam / SparseEmbedding /
+DenseLayer (model_wrapper.hpp:56-121) and Model.add/compile/summary/fit/eval/... (:123-227), so
+that scripts written as `samples/dcn/*.py`, `samples/deepfm/*.py`, `samples/wdl/*.py`, DLRM-style
+(Interaction) models run with `import hugectr_amd.hugectr as hugectr`.
+
+The sparse embeddings, Interaction and MultiCross run on the HIP kernels behind the C ABI; the
+remaining dense layers are thin PyTorch-ROCm modules (out of scope as kernels).
+One process drives one GPU: `vvgpu` must list as many GPUs as there are torch.distributed ranks
+(a plain single-process run uses vvgpu=[[0]]).
+"""
+from __future__ import annotations
+
+import enum
+import json
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .dense import FusedMLP
+from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward_reorder
+from .layers import MultiCrossLayer, interaction
+from .parallel import DistributedExchange, LocalizedExchange
+from . import data as _data
+
+
+# ---- enums (values follow R/HugeCTR/include/common.hpp:67-157) ------------------------------------
+class Check_t(enum.Enum):
+    Sum = 0
+    Non = 1
+    Unknown = 2
+
+
+class DataReaderType_t(enum.Enum):
+    Norm = 0
+    Raw = 1
+    Parquet = 2
+    RawAsync = 3
+
+
+class LrPolicy_t(enum.Enum):
+    fixed = 0
+
+
+class Optimizer_t(enum.IntEnum):
+    Ftrl = 0
+    Adam = 1
+    RMSProp = 2
+    AdaGrad = 3
+    Nesterov = 4
+    MomentumSGD = 5
+    SGD = 6
+
+
+class Update_t(enum.IntEnum):
+    Local = 0
+    Global = 1
+    LazyGlobal = 2
+
+
+class Embedding_t(enum.IntEnum):
+    DistributedSlotSparseEmbeddingHash = 0
+    LocalizedSlotSparseEmbeddingHash = 1
+
+
+class Activation_t(enum.Enum):
+    Relu = 0
+    Non = 1
+    Unspecified = 2
+
+
+class Initializer_t(enum.Enum):
+    Default = 0
+    Uniform = 1
+    XavierNorm = 2
+    XavierUniform = 3
+    Sinusoidal = 4
+    Zero = 5
+
+
+class Distribution_t(enum.Enum):
+    Uniform = 0
+    PowerLaw = 1
+
+
+class PowerLaw_t(enum.Enum):
+    Long = 0
+    Medium = 1
+    Short = 2
+    Specific = 3
+
+
+class MetricsType(enum.Enum):
+    AUC = 0
+    AverageLoss = 1
+    HitRate = 2
+    NDCG = 3
+    SMAPE = 4
+
+
+Layer_t = enum.Enum("Layer_t", [
+    "BatchNorm", "LayerNorm", "BinaryCrossEntropyLoss", "Reshape", "Select", "Concat",
+    "CrossEntropyLoss", "Dropout", "ELU", "InnerProduct", "MLP", "Interaction",
+    "MultiCrossEntropyLoss", "ReLU", "ReLUHalf", "GRU", "MatrixMultiply", "MultiHeadAttention",
+    "Scale", "FusedReshapeConcat", "FusedReshapeConcatGeneral", "Softmax", "PReLU_Dice",
+    "ReduceMean", "Sub", "Gather", "Sigmoid", "Slice", "WeightMultiply", "FmOrder2", "Add",
+    "ReduceSum", "MultiCross", "Cast", "ElementwiseMultiply", "SequenceMask", "Unknown"])
+
+
+# ---- plain parameter holders -------------------------------------------------------------------
+@dataclass
+class Solver:
+    model_name: str = ""
+    seed: int = 0
+    lr_policy: LrPolicy_t = LrPolicy_t.fixed
+    lr: float = 0.001
+    warmup_steps: int = 1
+    decay_start: int = 0
+    decay_steps: int = 1
+    decay_power: float = 2.0
+    end_lr: float = 0.0
+    max_eval_batches: int = 100
+    batchsize_eval: int = 2048
+    batchsize: int = 2048
+    vvgpu: List[List[int]] = field(default_factory=lambda: [[0]])
+    repeat_dataset: bool = True
+    use_mixed_precision: bool = False
+    enable_tf32_compute: bool = False
+    scaler: float = 1.0
+    metrics_spec: Dict = field(default_factory=lambda: {MetricsType.AUC: 1.0})
+    i64_input_key: bool = False
+    use_algorithm_search: bool = True
+    use_cuda_graph: bool = True
+    gen_loss_summary: bool = True
+    train_intra_iteration_overlap: bool = False
+    train_inter_iteration_overlap: bool = False
+    eval_intra_iteration_overlap: bool = False
+    eval_inter_iteration_overlap: bool = False
+    device_layout: str = "LOCAL_FIRST"
+    use_embedding_collection: bool = False
+    all_reduce_algo: str = "NCCL"
+    grouped_all_reduce: bool = False
+    num_iterations_statistics: int = 20
+    perf_logging: bool = False
+    drop_incomplete_batch: bool = True
+    kafka_brockers: str = ""
+    training_callbacks: list = field(default_factory=list)
+
+
+def CreateSolver(**kw) -> Solver:
+    s = Solver()
+    for k, v in kw.items():
+        if not hasattr(s, k):
+            raise RuntimeError(f"CreateSolver: unknown argument '{k}'")
+        setattr(s, k, v)
+    if s.use_mixed_precision and s.scaler not in (128.0, 256.0, 512.0, 1024.0):
+        # solver_wrapper / parser check: mixed precision requires one of these loss scalers
+        raise RuntimeError("use_mixed_precision requires scaler in {128, 256, 512, 1024}")
+    return s
+
+
+@dataclass
+class DataReaderParams:
+    data_reader_type: DataReaderType_t
+    source: Sequence[str]
+    eval_source: str = ""
+    check_type: Check_t = Check_t.Non
+    cache_eval_data: int = 0
+    num_samples: int = 0
+    eval_num_samples: int = 0
+    float_label_dense: bool = False
+    num_workers: int = 12
+    slot_size_array: Sequence[int] = field(default_factory=list)
+    async_param: object = None
+
+    def __post_init__(self):
+        if isinstance(self.source, str):
+            self.source = [self.source]
+
+
+@dataclass
+class OptParamsPy:
+    optimizer_type: Optimizer_t = Optimizer_t.Adam
+    update_type: Update_t = Update_t.Global
+    beta: float = 0.0
+    lambda1: float = 0.0
+    lambda2: float = 0.0
+    beta1: float = 0.9
+    beta2: float = 0.999
+    epsilon: float = 1e-7
+    initial_accu_value: float = 0.0
+    momentum_factor: float = 0.0
+    atomic_update: bool = True
+    initialized: bool = True
+
+
+def CreateOptimizer(optimizer_type=Optimizer_t.Adam, update_type=Update_t.Global, beta=0.0,
+                    lambda1=0.0, lambda2=0.0, beta1=0.9, beta2=0.999, epsilon=1e-7,
+                    initial_accu_value=0.0, momentum_factor=0.0, atomic_update=True) -> OptParamsPy:
+    return OptParamsPy(optimizer_type, update_type, beta, lambda1, lambda2, beta1, beta2, epsilon,
+                       initial_accu_value, momentum_factor, atomic_update)
+
+
+@dataclass
+class DataReaderSparseParam:
+    top_name: str
+    nnz_per_slot: object  # int or list of int
+    is_fixed_length: bool
+    slot_num: int
+
+    def max_nnz(self) -> int:
+        if isinstance(self.nnz_per_slot, (list, tuple)):
+            return int(max(self.nnz_per_slot))
+        return int(self.nnz_per_slot)
+
+    def max_feature_num(self) -> int:
+        if isinstance(self.nnz_per_slot, (list, tuple)):
+            return int(sum(self.nnz_per_slot))
+        return int(self.nnz_per_slot) * self.slot_num
+
+
+class Input:
+    def __init__(self, label_dim=None, label_name=None, dense_dim=0, dense_name="dense",
+                 data_reader_sparse_param_array=(), label_dims=None, label_names=None,
+                 label_weights=None):
+        if label_dims is not None:
+            self.label_dims, self.label_names = list(label_dims), list(label_names)
+        else:
+            self.label_dims, self.label_names = [int(label_dim)], [label_name]
+        self.label_dim = sum(self.label_dims)
+        self.label_name = self.label_names[0]
+        self.dense_dim, self.dense_name = int(dense_dim), dense_name
+        self.sparse_params: List[DataReaderSparseParam] = list(data_reader_sparse_param_array)
+
+
+class SparseEmbedding:
+    def __init__(self, embedding_type, embedding_vec_size, combiner, sparse_embedding_name,
+                 bottom_name, workspace_size_per_gpu_in_mb=0, slot_size_array=(), optimizer=None):
+        self.embedding_type = Embedding_t(embedding_type)
+        self.workspace_size_per_gpu_in_mb = int(workspace_size_per_gpu_in_mb)
+        self.embedding_vec_size = int(embedding_vec_size)
+        if combiner not in ("sum", "mean"):
+            raise RuntimeError("combiner must be 'sum' or 'mean'")
+        self.combiner = 0 if combiner == "sum" else 1
+        self.sparse_embedding_name = sparse_embedding_name
+        self.bottom_name = bottom_name
+        self.slot_size_array = list(slot_size_array)
+        self.optimizer = optimizer
+
+
+class DenseLayer:
+    def __init__(self, layer_type, bottom_names, top_names, **kw):
+        self.layer_type = layer_type
+        self.bottom_names, self.top_names = list(bottom_names), list(top_names)
+        d = dict(factor=1.0, eps=1e-5, dropout_rate=0.5, elu_alpha=1.0, num_output=1, num_layers=0,
+                 leading_dim=0, time_step=0, selected=False, selected_slots=[], ranges=[],
+                 indices=[], weight_dims=[], projection_dim=0, out_dim=0, axis=1,
+                 target_weight_vec=[], use_regularizer=False, act_type=Activation_t.Relu,
+                 num_outputs=[], use_bias=True, activations=[], biases=[], shape=[], dim=0,
+                 index=[], pos_type=None, compute_config=None, weight_init_type=None,
+                 bias_init_type=None, gamma_init_type=None, beta_init_type=None,
+                 regularizer_type=None, batchsize=1, SeqLength=1, vector_size=1,
+                 max_sequence_len_from=1, max_sequence_len_to=1, num_attention_heads=1,
+                 transpose_b=False)
+        d["lambda"] = 0
+        for k, v in kw.items():
+            if k not in d:
+                raise RuntimeError(f"DenseLayer: unknown argument '{k}'")
+            d[k] = v
+        self.__dict__.update(d)
+
+
+def _max_vocab_from_workspace(ws_mb: int, opt: OptParamsPy, vec: int) -> int:
+    """max_vocabulary_size_per_gpu = ws_MB * 2^20 / ((1 + #opt_states) * 4 * D)
+    (R/HugeCTR/src/pybind/model.cpp:186-196)"""
+    states = {Optimizer_t.Adam: 2, Optimizer_t.AdaGrad: 1, Optimizer_t.MomentumSGD: 1,
+              Optimizer_t.Nesterov: 1, Optimizer_t.SGD: 0, Optimizer_t.Ftrl: 2,
+              Optimizer_t.RMSProp: 1}[Optimizer_t(opt.optimizer_type)]
+    return (ws_mb * 1024 * 1024) // ((1 + states) * 4 * vec)
+
+
+class _FmOrder2(torch.nn.Module):
+    def __init__(self, out_dim):
+        super().__init__()
+        self.out_dim = out_dim
+
+    def forward(self, x):  # [B, slots*out_dim] -> 0.5 * ((sum v)^2 - sum v^2)
+        v = x.view(x.shape[0], -1, self.out_dim)
+        return 0.5 * (v.sum(1) ** 2 - (v ** 2).sum(1))
+
+
+class _WeightMultiply(torch.nn.Module):
+    def __init__(self, slots, vec):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.empty(slots, vec).uniform_(-0.05, 0.05))
+
+    def forward(self, x):  # [B, slots] -> [B, slots*vec]
+        return (x.unsqueeze(2) * self.w.unsqueeze(0)).reshape(x.shape[0], -1)
+
+
+class Model:
+    """hugectr.Model for one rank.  Supported graph: Input -> SparseEmbedding* -> DenseLayer* with
+    one BinaryCrossEntropyLoss."""
+
+    def __init__(self, solver: Solver, reader_params: DataReaderParams, opt: OptParamsPy):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hugectr_amd needs a HIP device (MI355X); there is no CPU fallback")
+        self.solver, self.reader_params, self.opt = solver, reader_params, opt
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        n_gpus = sum(len(v) for v in solver.vvgpu)
+        if n_gpus != self.world:
+            raise RuntimeError(f"vvgpu lists {n_gpus} GPUs but {self.world} rank(s) are running: "
+                               "launch one process per GPU (torch.distributed.run)")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device("cuda", local)
+        torch.cuda.set_device(self.device)
+        torch.manual_seed(solver.seed + 1)
+        self.input: Optional[Input] = None
+        self.embeddings: List[SparseEmbedding] = []
+        self.layers: List[DenseLayer] = []
+        self._compiled = False
+        self._loss = float("nan")
+        self._lr = solver.lr
+        self._iter = 0
+
+    # -- graph construction ------------------------------------------------------------------------
+    def add(self, item):
+        if isinstance(item, Input):
+            self.input = item
+        elif isinstance(item, SparseEmbedding):
+            self.embeddings.append(item)
+        elif isinstance(item, DenseLayer):
+            self.layers.append(item)
+        else:
+            raise RuntimeError(f"Model.add: unsupported item {type(item)}")
+
+    def _emb_opt(self, se: SparseEmbedding) -> OptParams:
+        o = se.optimizer if (se.optimizer is not None and se.optimizer.initialized) else self.opt
+        return OptParams(optimizer=int(o.optimizer_type), update_type=int(o.update_type),
+                         lr=self._lr, beta1=o.beta1, beta2=o.beta2, epsilon=o.epsilon,
+                         initial_accu_value=o.initial_accu_value,
+                         momentum_factor=o.momentum_factor, atomic_update=o.atomic_update,
+                         scaler=self.solver.scaler)
+
+    def compile(self):
+        assert self.input is not None, "Model.add(Input(...)) first"
+        s = self.solver
+        B, Be = s.batchsize, s.batchsize_eval
+        self.bpg, self.bpg_eval = B // self.world, Be // self.world
+        key_dtype = torch.int64 if s.i64_input_key else torch.uint32
+        self.emb_dtype = torch.float16 if s.use_mixed_precision else torch.float32
+        sp = {p.top_name: p for p in self.input.sparse_params}
+        self._emb = {}
+        self._shapes: Dict[str, tuple] = {self.input.dense_name: (self.input.dense_dim,),
+                                          self.input.label_name: (self.input.label_dim,)}
+        for se in self.embeddings:
+            p = sp[se.bottom_name]
+            opt = self._emb_opt(se)
+            ssa = se.slot_size_array or []
+            if ssa:
+                max_vocab = 0  # derived from the slot sizes by the library
+            else:
+                assert se.workspace_size_per_gpu_in_mb > 0, "workspace_size_per_gpu_in_mb or slot_size_array"
+                max_vocab = _max_vocab_from_workspace(se.workspace_size_per_gpu_in_mb,
+                                                      se.optimizer or self.opt,
+                                                      se.embedding_vec_size)
+            h = SparseEmbeddingHash(int(se.embedding_type), B, Be, max_vocab, se.embedding_vec_size,
+                                    p.max_feature_num(), p.slot_num, se.combiner, opt,
+                                    slot_size_array=ssa, key_dtype=key_dtype,
+                                    out_dtype=self.emb_dtype, rank=self.rank, world=self.world,
+                                    seed=s.seed, device=self.device)
+            h.init_params()
+            localized = se.embedding_type == Embedding_t.LocalizedSlotSparseEmbeddingHash
+            ex = {}
+            for mode, bb in (("train", B), ("eval", Be)):
+                ex[mode] = (LocalizedExchange if localized else DistributedExchange)(
+                    bb, p.slot_num, se.embedding_vec_size)
+            self._emb[se.sparse_embedding_name] = (se, p, h, ex, localized)
+            self._shapes[se.sparse_embedding_name] = (p.slot_num, se.embedding_vec_size)
+        # dense modules
+        self._mods = torch.nn.ModuleDict()
+        self._loss_layer = None
+        for i, L in enumerate(self.layers):
+            self._build_layer(i, L)
+        self._mods.to(self.device)
+        self._dense_params = [p for p in self._mods.parameters()]
+        self._dense_opt = self._make_dense_opt()
+        self.reader = _data.make_reader(self.reader_params, self.input, s, self.rank, self.world,
+                                        self.device)
+        self._compiled = True
+
+    def _in_width(self, name):
+        shp = self._shapes[name]
+        n = 1
+        for v in shp:
+            n *= v
+        return n
+
+    def _build_layer(self, i, L: DenseLayer):
+        t = L.layer_type
+        key = f"l{i}"
+        b0 = L.bottom_names[0]
+        if t == Layer_t.InnerProduct:
+            self._mods[key] = torch.nn.Linear(self._in_width(b0), L.num_output)
+            self._shapes[L.top_names[0]] = (L.num_output,)
+        elif t == Layer_t.MLP:
+            dims = [self._in_width(b0)] + list(L.num_outputs)
+            acts = L.activations or [L.act_type] * len(L.num_outputs)
+            last_relu = acts[-1] == Activation_t.Relu
+            self._mods[key] = FusedMLP(dims, last_relu,
+                                       dtype=torch.bfloat16 if self.solver.use_mixed_precision
+                                       else torch.float32)
+            self._shapes[L.top_names[0]] = (dims[-1],)
+        elif t in (Layer_t.ReLU, Layer_t.Sigmoid, Layer_t.Dropout, Layer_t.Softmax, Layer_t.ELU):
+            self._shapes[L.top_names[0]] = self._shapes[b0]
+        elif t == Layer_t.Concat:
+            self._shapes[L.top_names[0]] = (sum(self._in_width(b) for b in L.bottom_names),)
+        elif t == Layer_t.Reshape:
+            if L.selected_slots:
+                vec = self._shapes[b0][-1]
+                self._shapes[L.top_names[0]] = (len(L.selected_slots) * vec,)
+            elif L.shape:
+                self._shapes[L.top_names[0]] = tuple(int(v) for v in L.shape[1:])
+            else:
+                self._shapes[L.top_names[0]] = (L.leading_dim,)
+        elif t == Layer_t.Slice:
+            for (a, b), top in zip(L.ranges, L.top_names):
+                self._shapes[top] = (b - a,)
+        elif t in (Layer_t.Add, Layer_t.ElementwiseMultiply, Layer_t.Sub):
+            self._shapes[L.top_names[0]] = self._shapes[b0]
+        elif t == Layer_t.FmOrder2:
+            self._mods[key] = _FmOrder2(L.out_dim)
+            self._shapes[L.top_names[0]] = (L.out_dim,)
+        elif t == Layer_t.WeightMultiply:
+            self._mods[key] = _WeightMultiply(int(L.weight_dims[0]), int(L.weight_dims[1]))
+            self._shapes[L.top_names[0]] = (int(L.weight_dims[0]) * int(L.weight_dims[1]),)
+        elif t == Layer_t.ReduceSum:
+            self._shapes[L.top_names[0]] = (1,)
+        elif t == Layer_t.MultiCross:
+            w = self._in_width(b0)
+            self._mods[key] = MultiCrossLayer(w, L.num_layers, L.projection_dim)
+            self._shapes[L.top_names[0]] = (w,)
+        elif t == Layer_t.Interaction:
+            n_emb, W = self._shapes[L.bottom_names[1]]
+            n_ins = n_emb + 1
+            self._shapes[L.top_names[0]] = (W + n_ins * (n_ins - 1) // 2 + 1,)
+        elif t == Layer_t.BinaryCrossEntropyLoss:
+            self._loss_layer = L
+        else:
+            raise RuntimeError(f"Layer_t.{t.name} is outside the hot-path scope of hugectr_amd")
+
+    def _make_dense_opt(self):
+        o, lr = self.opt, self._lr
+        t = Optimizer_t(o.optimizer_type)
+        if not self._dense_params:
+            return None
+        if t == Optimizer_t.Adam:
+            return torch.optim.Adam(self._dense_params, lr=lr, betas=(o.beta1, o.beta2), eps=o.epsilon)
+        if t == Optimizer_t.AdaGrad:
+            return torch.optim.Adagrad(self._dense_params, lr=lr,
+                                       initial_accumulator_value=o.initial_accu_value, eps=o.epsilon)
+        if t == Optimizer_t.MomentumSGD:
+            return torch.optim.SGD(self._dense_params, lr=lr, momentum=o.momentum_factor)
+        if t == Optimizer_t.Nesterov:
+            return torch.optim.SGD(self._dense_params, lr=lr, momentum=max(o.momentum_factor, 1e-6),
+                                   nesterov=True)
+        return torch.optim.SGD(self._dense_params, lr=lr)
+
+    # -- execution ---------------------------------------------------------------------------------
+    def _forward_dense(self, tensors: Dict[str, torch.Tensor], train: bool):
+        logit = None
+        for i, L in enumerate(self.layers):
+            t, key = L.layer_type, f"l{i}"
+            x = [tensors[b] for b in L.bottom_names]
+            if t in (Layer_t.InnerProduct, Layer_t.MLP, Layer_t.MultiCross, Layer_t.FmOrder2):
+                y = self._mods[key](x[0].reshape(x[0].shape[0], -1).float()
+                                    if t != Layer_t.MLP else x[0].reshape(x[0].shape[0], -1))
+            elif t == Layer_t.WeightMultiply:
+                y = self._mods[key](x[0].reshape(x[0].shape[0], -1).float())
+            elif t == Layer_t.ReLU:
+                y = torch.relu(x[0])
+            elif t == Layer_t.Sigmoid:
+                y = torch.sigmoid(x[0])
+            elif t == Layer_t.Dropout:
+                y = torch.nn.functional.dropout(x[0], L.dropout_rate, training=train)
+            elif t == Layer_t.Concat:
+                y = torch.cat([v.reshape(v.shape[0], -1).float() for v in x], dim=1)
+            elif t == Layer_t.Reshape:
+                if L.selected_slots:
+                    y = x[0][:, list(L.selected_slots), :].reshape(x[0].shape[0], -1)
+                elif L.shape:
+                    y = x[0].reshape([x[0].shape[0]] + [int(v) for v in L.shape[1:]])
+                else:
+                    y = x[0].reshape(-1, L.leading_dim)
+            elif t == Layer_t.Slice:
+                for (a, b), top in zip(L.ranges, L.top_names):
+                    tensors[top] = x[0][:, a:b]
+                continue
+            elif t == Layer_t.Add:
+                y = sum(v.float() for v in x)
+            elif t == Layer_t.Sub:
+                y = x[0].float() - x[1].float()
+            elif t == Layer_t.ElementwiseMultiply:
+                y = x[0]
+                for v in x[1:]:
+                    y = y * v
+            elif t == Layer_t.ReduceSum:
+                y = x[0].sum(dim=L.axis, keepdim=True)
+            elif t == Layer_t.Interaction:
+                dt = x[1].dtype
+                y = interaction(x[0].to(dt).contiguous(), x[1].contiguous())
+            elif t == Layer_t.BinaryCrossEntropyLoss:
+                logit = x[0].float()
+                continue
+            else:
+                raise RuntimeError(t)
+            tensors[L.top_names[0]] = y
+        return logit
+
+    def _run_batch(self, batch, train: bool):
+        mode = "train" if train else "eval"
+        tensors = {self.input.dense_name: batch["dense"], self.input.label_name: batch["label"]}
+        leaves = {}
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            ro, keys = batch["sparse"][se.bottom_name]
+            pooled = h.forward(train, ro, keys)
+            bpg = self.bpg if train else self.bpg_eval
+            if localized:
+                recv = ex[mode].forward(pooled)
+                E = forward_reorder(recv, bpg, p.slot_num, se.embedding_vec_size, self.world) \
+                    if self.world > 1 else pooled.view(bpg, p.slot_num, se.embedding_vec_size)
+            else:
+                E = ex[mode].forward(pooled)
+            if train:
+                E = E.detach().requires_grad_(True)
+                leaves[name] = E
+            tensors[name] = E
+        logit = self._forward_dense(tensors, train)
+        label = batch["label"].float()
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
+        if not train:
+            return loss, torch.sigmoid(logit)
+        (loss * self.solver.scaler).backward()
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            g = leaves[name].grad
+            if localized:
+                if self.world > 1:
+                    g = backward_reorder(g.contiguous(), self.bpg, p.slot_num,
+                                         se.embedding_vec_size, self.world)
+                top = ex["train"].backward(g.contiguous())
+            else:
+                top = ex["train"].backward(g.contiguous())
+            h.backward(top.contiguous())
+            h.update_params()
+        if self._dense_opt is not None:
+            if self.world > 1:
+                for q in self._dense_params:
+                    if q.grad is not None:
+                        dist.all_reduce(q.grad)
+                        q.grad /= self.world
+            if self.solver.scaler != 1.0:
+                for q in self._dense_params:
+                    if q.grad is not None:
+                        q.grad /= self.solver.scaler
+            self._dense_opt.step()
+            self._dense_opt.zero_grad(set_to_none=True)
+            for m in self._mods.values():
+                if isinstance(m, FusedMLP):
+                    m.refresh_shadow()
+        return loss, None
+
+    def train(self) -> bool:
+        assert self._compiled
+        batch = self.reader.next_batch(train=True)
+        if batch is None:
+            return False
+        loss, _ = self._run_batch(batch, True)
+        self._loss_t = loss.detach()
+        self._iter += 1
+        return True
+
+    def eval(self) -> bool:
+        batch = self.reader.next_batch(train=False)
+        if batch is None:
+            return False
+        with torch.no_grad():
+            loss, prob = self._run_batch(batch, False)
+        self._eval_buf.append((prob.detach().float().flatten(), batch["label"].float().flatten(),
+                               loss.detach()))
+        return True
+
+    def get_current_loss(self) -> float:
+        return float(self._loss_t)
+
+    def get_eval_metrics(self):
+        if not self._eval_buf:
+            return []
+        p = torch.cat([a for a, _, _ in self._eval_buf])
+        y = torch.cat([b for _, b, _ in self._eval_buf])
+        return [("AUC", _auc(p, y)), ("AverageLoss", float(torch.stack(
+            [c for _, _, c in self._eval_buf]).mean()))]
+
+    def set_learning_rate(self, lr: float):
+        self._lr = lr
+        for (_, _, h, _, _) in self._emb.values():
+            h.set_learning_rate(lr)
+        if self._dense_opt is not None:
+            for g in self._dense_opt.param_groups:
+                g["lr"] = lr
+
+    def summary(self):
+        if self.rank != 0:
+            return
+        print("=" * 67 + "Model Summary" + "=" * 67)
+        print(f"{'Label':<40}{'Dense':<30}{'Sparse':<30}")
+        print(f"{self.input.label_name:<40}{self.input.dense_name:<30}"
+              f"{','.join(p.top_name for p in self.input.sparse_params):<30}")
+        print(f"({self.bpg},{self.input.label_dim})".ljust(40) + f"({self.bpg},{self.input.dense_dim})")
+        print("-" * 147)
+        print(f"{'Layer Type':<40}{'Input Name':<30}{'Output Name':<30}{'Output Shape':<30}")
+        for name, (se, p, h, _, _) in self._emb.items():
+            print(f"{se.embedding_type.name:<40}{se.bottom_name:<30}{name:<30}"
+                  f"({self.bpg},{p.slot_num},{se.embedding_vec_size})")
+        for L in self.layers:
+            tops = ",".join(L.top_names)
+            shp = self._shapes.get(L.top_names[0], ()) if L.top_names else ()
+            print(f"{L.layer_type.name:<40}{','.join(L.bottom_names):<30}{tops:<30}"
+                  f"({self.bpg},{','.join(str(v) for v in shp)})")
+        print("-" * 147)
+
+    def fit(self, num_epochs=0, max_iter=2000, display=200, eval_interval=1000, snapshot=10000,
+            snapshot_prefix="", data_source_params=None):
+        assert self._compiled, "call compile() first"
+        s = self.solver
+        if self.rank == 0:
+            print(f"=====================================================Model Fit====================="
+                  f"================================")
+            print(f"[HCTR][INFO] Use non-epoch mode with number of iterations: {max_iter}"
+                  if num_epochs <= 0 else f"[HCTR][INFO] Use epoch mode with number of epochs: {num_epochs}")
+            print(f"[HCTR][INFO] Training batchsize: {s.batchsize}, evaluation batchsize: {s.batchsize_eval}")
+        t0 = time.time()
+        it = 0
+        limit = max_iter if num_epochs <= 0 else 10 ** 12
+        self._eval_buf = []
+        while it < limit:
+            if not self.train():
+                break
+            it += 1
+            if display > 0 and it % display == 0:
+                torch.cuda.synchronize()
+                if self.rank == 0:
+                    print(f"[HCTR][INFO] Iter: {it} Time({display} iters): {time.time() - t0:.6f}s "
+                          f"Loss: {self.get_current_loss():.6f} lr:{self._lr:.6f}")
+                t0 = time.time()
+            if eval_interval > 0 and it % eval_interval == 0 and s.batchsize_eval > 0 \
+                    and self.reader.has_eval():
+                self._eval_buf = []
+                te = time.time()
+                for _ in range(s.max_eval_batches):
+                    if not self.eval():
+                        break
+                torch.cuda.synchronize()
+                if self.rank == 0:
+                    for name, v in self.get_eval_metrics():
+                        print(f"[HCTR][INFO] Evaluation, {name}: {v:.6f}")
+                    print(f"[HCTR][INFO] Eval Time for {s.max_eval_batches} iters: {time.time() - te:.6f}s")
+            if snapshot > 0 and it % snapshot == 0 and snapshot_prefix:
+                self.save_params_to_files(snapshot_prefix, it)
+        torch.cuda.synchronize()
+        if self.rank == 0:
+            print(f"[HCTR][INFO] Finish {it} iterations with batchsize: {s.batchsize} in "
+                  f"{time.time() - t0:.2f}s.")
+
+    # -- checkpoints: directory layout of the reference (SURVEY §5 "Checkpoint / resume") ----------
+    def save_params_to_files(self, prefix: str, iteration: int = 0):
+        for i, (name, (se, p, h, _, localized)) in enumerate(self._emb.items()):
+            keys, slot, vec = h.dump_parameters()
+            d = f"{prefix}{i}_sparse_{iteration}.model"
+            if self.world > 1:
+                d += f".rank{self.rank}"
+            os.makedirs(d, exist_ok=True)
+            keys.cpu().numpy().astype("<i8").tofile(os.path.join(d, "key"))
+            if localized:
+                slot.cpu().numpy().astype("<u8").tofile(os.path.join(d, "slot_id"))
+            vec.cpu().numpy().astype("<f4").tofile(os.path.join(d, "emb_vector"))
+        if self.rank == 0 and self._dense_params:
+            flat = torch.cat([q.detach().flatten().float() for q in self._dense_params])
+            flat.cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")
+
+    def load_sparse_weights(self, paths: Sequence[str]):
+        for path, (name, (se, p, h, _, localized)) in zip(paths, self._emb.items()):
+            keys = np.fromfile(os.path.join(path, "key"), dtype="<i8")
+            vec = np.fromfile(os.path.join(path, "emb_vector"), dtype="<f4").reshape(
+                keys.size, se.embedding_vec_size)
+            slot = None
+            sp = os.path.join(path, "slot_id")
+            if localized and os.path.exists(sp):
+                slot = np.fromfile(sp, dtype="<u8").astype(np.int64)
+                mine = slot % self.world == self.rank
+            else:
+                mine = keys % self.world == self.rank if self.world > 1 else np.ones(keys.size, bool)
+            h.load_parameters(torch.from_numpy(keys[mine]),
+                              torch.from_numpy(slot[mine]) if slot is not None else None,
+                              torch.from_numpy(vec[mine]))
+
+    def load_dense_weights(self, path: str):
+        flat = torch.from_numpy(np.fromfile(path, dtype="<f4")).to(self.device)
+        off = 0
+        with torch.no_grad():
+            for q in self._dense_params:
+                q.copy_(flat[off:off + q.numel()].view_as(q))
+                off += q.numel()
+
+    def graph_to_json(self, graph_config_file: str):
+        layers = [{"type": "Data", "label": {"top": self.input.label_name, "label_dim": self.input.label_dim},
+                   "dense": {"top": self.input.dense_name, "dense_dim": self.input.dense_dim},
+                   "sparse": [{"top": p.top_name, "slot_num": p.slot_num,
+                               "nnz_per_slot": p.nnz_per_slot, "is_fixed_length": p.is_fixed_length}
+                              for p in self.input.sparse_params]}]
+        for se in self.embeddings:
+            layers.append({"type": se.embedding_type.name, "name": se.sparse_embedding_name,
+                           "bottom": se.bottom_name, "top": se.sparse_embedding_name,
+                           "sparse_embedding_hparam": {
+                               "embedding_vec_size": se.embedding_vec_size,
+                               "combiner": "sum" if se.combiner == 0 else "mean",
+                               "workspace_size_per_gpu_in_mb": se.workspace_size_per_gpu_in_mb,
+                               "slot_size_array": se.slot_size_array}})
+        for L in self.layers:
+            layers.append({"type": L.layer_type.name, "bottom": L.bottom_names, "top": L.top_names})
+        with open(graph_config_file, "w") as f:
+            json.dump({"layers": layers}, f, indent=2)
+
+
+def _auc(p: torch.Tensor, y: torch.Tensor) -> float:
+    order = torch.argsort(p)
+    y = y[order]
+    n_pos = float(y.sum())
+    n_neg = float(y.numel() - n_pos)
+    if n_pos == 0 or n_neg == 0:
+        return 0.5
+    ranks = torch.arange(1, y.numel() + 1, device=y.device, dtype=torch.float64)
+    return float(((ranks * y).sum() - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg))
+
+
+class tools:  # hugectr.tools.* (R/HugeCTR/include/pybind/data_generator_wrapper.hpp:29-69)
+    DataGeneratorParams = _data.DataGeneratorParams
+    DataGenerator = _data.DataGenerator

@@ -1,0 +1,110 @@
+"""CPU: the hugectr-shaped Python surface (solver/optimizer defaults, enums) and the dataset
+formats either side of the hot path (Parquet layout, Norm framing)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_create_solver_defaults_match_reference():
+    # R/HugeCTR/include/pybind/solver_wrapper.hpp:127-150
+    import hugectr_amd.hugectr as hugectr
+    s = hugectr.CreateSolver()
+    assert (s.lr, s.batchsize, s.batchsize_eval, s.max_eval_batches) == (0.001, 2048, 2048, 100)
+    assert s.vvgpu == [[0]] and s.repeat_dataset and not s.use_mixed_precision
+    assert s.scaler == 1.0 and not s.i64_input_key and not s.use_embedding_collection
+    assert s.num_iterations_statistics == 20 and s.drop_incomplete_batch
+    s = hugectr.CreateSolver(batchsize=16384, vvgpu=[[0]], i64_input_key=True, lr=0.01)
+    assert s.batchsize == 16384 and s.i64_input_key
+    with pytest.raises(RuntimeError):
+        hugectr.CreateSolver(no_such_option=1)
+    with pytest.raises(RuntimeError):  # mixed precision needs a supported loss scaler
+        hugectr.CreateSolver(use_mixed_precision=True, scaler=3.0)
+
+
+def test_create_optimizer_defaults_and_enums():
+    # R/HugeCTR/include/pybind/optimizer_wrapper.hpp:35-40 ; common.hpp:82-94,145-149
+    import hugectr_amd.hugectr as hugectr
+    o = hugectr.CreateOptimizer()
+    assert o.optimizer_type == hugectr.Optimizer_t.Adam and o.update_type == hugectr.Update_t.Global
+    assert (o.beta1, o.beta2, o.epsilon, o.atomic_update) == (0.9, 0.999, 1e-7, True)
+    assert [int(x) for x in (hugectr.Optimizer_t.Ftrl, hugectr.Optimizer_t.Adam,
+                              hugectr.Optimizer_t.RMSProp, hugectr.Optimizer_t.AdaGrad,
+                              hugectr.Optimizer_t.Nesterov, hugectr.Optimizer_t.MomentumSGD,
+                              hugectr.Optimizer_t.SGD)] == list(range(7))
+    assert int(hugectr.Embedding_t.DistributedSlotSparseEmbeddingHash) == 0
+    assert int(hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash) == 1
+    # workspace -> max_vocabulary_size_per_gpu (model.cpp:186-196): 267 MB, Adam (2 states), D=16
+    from hugectr_amd.hugectr import _max_vocab_from_workspace
+    assert _max_vocab_from_workspace(267, o, 16) == 267 * 2**20 // (3 * 4 * 16)
+
+
+def test_parquet_dataset_roundtrip(tmp_path):
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd import data
+    sizes = [50, 7, 1000, 3]
+    p = hugectr.tools.DataGeneratorParams(
+        format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=5, num_slot=4,
+        i64_input_key=True, source=str(tmp_path / "train" / "_file_list.txt"),
+        eval_source=str(tmp_path / "val" / "_file_list.txt"), slot_size_array=sizes,
+        dist_type=hugectr.Distribution_t.PowerLaw, power_law_type=hugectr.PowerLaw_t.Short,
+        num_files=2, eval_num_files=1, num_samples_per_file=256, num_samples=512,
+        eval_num_samples=256)
+    hugectr.tools.DataGenerator(p).generate()
+    meta = json.load(open(tmp_path / "train" / "_metadata.json"))
+    assert [c["col_name"] for c in meta["cats"]] == ["C1", "C2", "C3", "C4"]
+    assert meta["file_stats"][0]["num_rows"] == 256 and len(meta["file_stats"]) == 2
+    inp = hugectr.Input(label_dim=1, label_name="label", dense_dim=5, dense_name="dense",
+                        data_reader_sparse_param_array=[
+                            hugectr.DataReaderSparseParam("data1", 1, True, 4)])
+    r = data.ParquetReader(p.source, inp, sizes, 128, 0, 1, torch.device("cpu"), True, False)
+    n = 0
+    while True:
+        b = r.next_batch()
+        if b is None:
+            break
+        n += 1
+        ro, keys = b["sparse"]["data1"]
+        assert ro.tolist() == list(range(128 * 4 + 1)) and keys.numel() == 128 * 4
+        k = keys.view(128, 4).numpy()
+        offs = np.array([0, 50, 57, 1057])
+        assert ((k - offs) >= 0).all() and ((k - offs) < np.array(sizes)).all()  # slot offsets added
+        assert b["dense"].shape == (128, 5) and b["label"].shape == (128, 1)
+    assert n == 4  # 2 files x 256 rows / 128
+    # two ranks see the same keys but different dense/label slices
+    r0 = data.ParquetReader(p.source, inp, sizes, 128, 0, 2, torch.device("cpu"), True, False)
+    r1 = data.ParquetReader(p.source, inp, sizes, 128, 1, 2, torch.device("cpu"), True, False)
+    b0, b1 = r0.next_batch(), r1.next_batch()
+    assert torch.equal(b0["sparse"]["data1"][1], b1["sparse"]["data1"][1])
+    assert b0["dense"].shape == (64, 5) and not torch.equal(b0["dense"], b1["dense"])
+
+
+@pytest.mark.parametrize("check_sum", [False, True])
+@pytest.mark.parametrize("i64", [True, False])
+def test_norm_format_roundtrip(tmp_path, check_sum, i64):
+    from hugectr_amd import data
+    rng = np.random.default_rng(0)
+    n, L, Dn, S = 20, 1, 3, 4
+    label = rng.random((n, L), dtype=np.float32)
+    dense = rng.random((n, Dn), dtype=np.float32)
+    cats = [rng.integers(0, 1000, size=(n, h)).astype(np.int64) for h in (1, 3, 2, 1)]
+    path = str(tmp_path / "a.data")
+    data.write_norm(path, label, dense, cats, i64_key=i64, check_sum=check_sum)
+    l2, d2, ro, keys = data.read_norm(path, i64_key=i64)
+    assert np.array_equal(l2, label) and np.array_equal(d2, dense)
+    assert ro[-1] == n * 7 and ro.size == n * S + 1
+    want = np.concatenate([np.concatenate([c[i] for c in cats]) for i in range(n)])
+    assert np.array_equal(keys, want)
+    # header layout: DataSetHeader = 8 x int64 (common.hpp:184-191)
+    raw = open(path, "rb").read()
+    off = 4 if check_sum else 0
+    hdr = np.frombuffer(raw, "<i8", 8, off)
+    assert hdr.tolist() == [1 if check_sum else 0, n, L, Dn, S, 0, 0, 0]
+    if check_sum:
+        b = bytearray(raw)
+        b[80] ^= 0xFF  # corrupt one payload byte of the first record
+        open(path, "wb").write(bytes(b))
+        with pytest.raises(AssertionError):
+            data.read_norm(path, i64_key=i64)

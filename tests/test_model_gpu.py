@@ -1,0 +1,126 @@
+"""GPU: existing-style hugectr scripts run through the hugectr_amd.hugectr surface (config 1:
+DCN on README-style synthetic parquet; DLRM-style model with Interaction)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [203, 185, 140, 70, 189, 4, 63, 12, 49, 186, 71, 67, 11, 21, 73, 61, 4, 93, 15, 204, 141,
+         199, 60, 91, 71, 34]
+
+
+def _gen(tmp_path, hugectr, n_train=8192, n_eval=2048, nnz=None):
+    p = hugectr.tools.DataGeneratorParams(
+        format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=13, num_slot=26,
+        i64_input_key=True, source=str(tmp_path / "train" / "_file_list.txt"),
+        eval_source=str(tmp_path / "val" / "_file_list.txt"), slot_size_array=SIZES,
+        nnz_array=nnz or [], dist_type=hugectr.Distribution_t.PowerLaw,
+        power_law_type=hugectr.PowerLaw_t.Short, num_files=2, eval_num_files=1,
+        num_samples_per_file=n_train // 2, num_samples=n_train, eval_num_samples=n_eval)
+    hugectr.tools.DataGenerator(p).generate()
+    # make the label learnable (the generator draws coin flips): label = parity of feature C1
+    import glob
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    for f in glob.glob(str(tmp_path / "*" / "*.parquet")):
+        t = pq.read_table(f)
+        lab = (t["C1"].to_numpy() % 2).astype(np.float32)
+        t = t.set_column(t.schema.get_field_index("label"), "label", pa.array(lab, type=pa.float32()))
+        pq.write_table(t, f)
+    return p
+
+
+def test_dcn_script_trains(tmp_path, capsys):
+    import hugectr_amd.hugectr as hugectr
+    p = _gen(tmp_path, hugectr)
+    solver = hugectr.CreateSolver(max_eval_batches=2, batchsize_eval=1024, batchsize=1024, lr=0.001,
+                                  vvgpu=[[0]], repeat_dataset=True, i64_input_key=True)
+    reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
+                                      source=[p.source], eval_source=p.eval_source,
+                                      slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
+    optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam,
+                                        update_type=hugectr.Update_t.Global)
+    model = hugectr.Model(solver, reader, optimizer)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", 1, False, 26)]))
+    model.add(hugectr.SparseEmbedding(
+        embedding_type=hugectr.Embedding_t.DistributedSlotSparseEmbeddingHash,
+        workspace_size_per_gpu_in_mb=2, embedding_vec_size=16, combiner="sum",
+        sparse_embedding_name="sparse_embedding1", bottom_name="data1", optimizer=optimizer))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.Reshape,
+                                 bottom_names=["sparse_embedding1"], top_names=["reshape1"],
+                                 leading_dim=416))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.Concat,
+                                 bottom_names=["reshape1", "dense"], top_names=["concat1"]))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.MultiCross, bottom_names=["concat1"],
+                                 top_names=["multicross1"], num_layers=6))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.InnerProduct, bottom_names=["concat1"],
+                                 top_names=["fc1"], num_output=256))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.ReLU, bottom_names=["fc1"],
+                                 top_names=["relu1"]))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.Dropout, bottom_names=["relu1"],
+                                 top_names=["dropout1"], dropout_rate=0.5))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.Concat,
+                                 bottom_names=["dropout1", "multicross1"], top_names=["concat2"]))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.InnerProduct, bottom_names=["concat2"],
+                                 top_names=["fc2"], num_output=1))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.BinaryCrossEntropyLoss,
+                                 bottom_names=["fc2", "label"], top_names=["loss"]))
+    model.compile()
+    model.summary()
+    model.train()
+    first = model.get_current_loss()
+    model.fit(max_iter=120, display=40, eval_interval=60, snapshot=120,
+              snapshot_prefix=str(tmp_path / "dcn"))
+    last = model.get_current_loss()
+    assert np.isfinite(first) and np.isfinite(last)
+    assert last < first and last < 0.5  # label = parity of C1 is learnable from the embedding
+    out = capsys.readouterr().out
+    assert "Iter: 40" in out and "Evaluation, AUC" in out
+    # checkpoint in the reference's directory layout, then reload into a fresh model
+    d = str(tmp_path / "dcn0_sparse_120.model")
+    assert os.path.exists(os.path.join(d, "key")) and os.path.exists(os.path.join(d, "emb_vector"))
+    nkeys = os.path.getsize(os.path.join(d, "key")) // 8
+    assert os.path.getsize(os.path.join(d, "emb_vector")) == nkeys * 16 * 4
+    model.graph_to_json(str(tmp_path / "dcn.json"))
+    assert "MultiCross" in open(tmp_path / "dcn.json").read()
+
+
+def test_dlrm_style_script_trains(tmp_path):
+    import hugectr_amd.hugectr as hugectr
+    p = _gen(tmp_path, hugectr, n_train=4096, n_eval=1024)
+    solver = hugectr.CreateSolver(batchsize=512, batchsize_eval=512, lr=0.01, vvgpu=[[0]],
+                                  i64_input_key=True, max_eval_batches=1)
+    reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
+                                      source=[p.source], eval_source=p.eval_source,
+                                      slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam,
+                                  update_type=hugectr.Update_t.Local)
+    model = hugectr.Model(solver, reader, opt)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", 1, True, 26)]))
+    model.add(hugectr.SparseEmbedding(
+        embedding_type=hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash,
+        slot_size_array=SIZES, embedding_vec_size=32, combiner="sum",
+        sparse_embedding_name="sparse_embedding1", bottom_name="data1", optimizer=opt))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.MLP, bottom_names=["dense"],
+                                 top_names=["mlp1"], num_outputs=[64, 32],
+                                 act_type=hugectr.Activation_t.Relu, use_bias=True))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.Interaction,
+                                 bottom_names=["mlp1", "sparse_embedding1"],
+                                 top_names=["interaction1"]))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.MLP, bottom_names=["interaction1"],
+                                 top_names=["mlp2"], num_outputs=[128, 1],
+                                 activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Non]))
+    model.add(hugectr.DenseLayer(layer_type=hugectr.Layer_t.BinaryCrossEntropyLoss,
+                                 bottom_names=["mlp2", "label"], top_names=["loss"]))
+    model.compile()
+    model.train()
+    first = model.get_current_loss()
+    model.fit(max_iter=300, display=100, eval_interval=0, snapshot=0)
+    assert model.get_current_loss() < min(first, 0.6)
