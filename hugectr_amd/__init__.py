@@ -9,3 +9,5 @@ from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward
 from .layers import InteractionLayer, MultiCrossLayer, interaction  # noqa: F401
 
 __version__ = "0.1.0"
+from .embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfig,  # noqa: F401,E402
+                                   EmbeddingTableConfig)

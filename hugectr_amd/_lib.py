@@ -74,6 +74,17 @@ _SIGNATURES = {
     "hctr_emb_reset": (c_int, [_P, _P]),
     "hctr_emb_profiling": (c_int, [_P, c_int]),
     "hctr_emb_profile_get": (c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(c_uint64)]),
+    "hctr_ebc_keys_to_indices": (c_int, [_P, c_int, c_size_t, c_int64, c_int, _P, _P]),
+    "hctr_ebc_route_workspace_bytes": (c_size_t, [c_size_t, c_int]),
+    "hctr_ebc_route_keys": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "hctr_ebc_bucket_counts": (c_int, [c_size_t, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "hctr_ebc_network_forward": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P]),
+    "hctr_ebc_network_backward": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P]),
+    "hctr_updater_create": (c_int, [c_size_t, c_size_t, c_int, POINTER(_P)]),
+    "hctr_updater_destroy": (c_int, [_P]),
+    "hctr_updater_update": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, c_int, c_int, c_int, c_float,
+                                    c_float, c_float, c_float, c_float, c_float, c_uint64, _P, _P,
+                                    _P, _P]),
     "hctr_interaction_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
     "hctr_interaction_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_cross_v1_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),

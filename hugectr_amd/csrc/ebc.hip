@@ -1,0 +1,390 @@
+// ebc.hip -- embedding_collection (EBC / SparseOperationKit) path on static tables:
+// key routing -> keys_to_indices -> pooled lookup -> (all-to-all) -> network forward/backward.
+//
+// Reference pieces restated MI355X-first:
+//   key routing      R/HugeCTR/embedding/data_distributor/key_filtering_operators.cu:37-300
+//                    (owner of a key: shard `key % num_shards`, :86-88)
+//   keys_to_indices  R/HugeCTR/embedding/operators/keys_to_indices.cu:24-43
+//                    (idx = table_start + key / num_shards)
+//   pooled lookup    R/HugeCTR/embedding/operators/generic_lookup.cuh:318-416 -> hctr_forward_pool
+//   network forward  R/HugeCTR/embedding/operators/network_forward.cu (sum row-shard partials,
+//                    Average divides by the bucket's TOTAL key count on the receiver)
+// The reference routes keys with two all-to-alls after a host-synchronised count exchange
+// (sparse_data_distribution_op_impl.cu:303-333).  SparseOperationKit instead all-gathers the keys
+// and lets every rank pick its own (sparse_operation_kit/lookup.py:490-495); that is the flow
+// implemented here: one fused filter+index pass over the gathered CSR, no host sync.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+#include "scan.h"
+#include "sparse_update.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct LookupDesc {  // one per lookup resolved on this rank
+  int global_lookup;    // index into the global feature-major bucket_range
+  int num_shards;       // row shards of the lookup's table
+  int shard_id;         // this rank's shard of that table
+  long long row_start;  // first row of the table's shard in the rank's flat table
+};
+
+__device__ __forceinline__ LookupDesc load_desc(const int* __restrict__ d3,
+                                                const long long* __restrict__ rs, int ll) {
+  LookupDesc d;
+  d.global_lookup = d3[3 * ll];
+  d.num_shards = d3[3 * ll + 1];
+  d.shard_id = d3[3 * ll + 2];
+  d.row_start = rs[ll];
+  return d;
+}
+
+// output bucket order = [peer][local lookup][b_local] so that the pooled vectors are already the
+// all-to-all send buffer
+__device__ __forceinline__ void decode_bucket(size_t ob, int n_local, size_t bpg, int& peer,
+                                              int& ll, size_t& bl) {
+  bl = ob % bpg;
+  const size_t t = ob / bpg;
+  ll = (int)(t % n_local);
+  peer = (int)(t / n_local);
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ebc_count_kernel(size_t batch, size_t bpg, int n_local, const int* __restrict__ d3,
+                     const long long* __restrict__ rs, const K* __restrict__ keys, const K* __restrict__ bucket_range,
+                     long long* __restrict__ lens) {
+  const size_t total = (size_t)n_local * batch;
+  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < total;
+       ob += (size_t)gridDim.x * kBlock) {
+    int peer, ll;
+    size_t bl;
+    decode_bucket(ob, n_local, bpg, peer, ll, bl);
+    const LookupDesc d = load_desc(d3, rs, ll);
+    const size_t sb = (size_t)d.global_lookup * batch + (size_t)peer * bpg + bl;
+    long long c = 0;
+    for (size_t q = (size_t)bucket_range[sb]; q < (size_t)bucket_range[sb + 1]; q++)
+      c += ((long long)keys[q] % d.num_shards == d.shard_id) ? 1 : 0;
+    lens[ob] = c;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ebc_index_kernel(size_t batch, size_t bpg, int n_local, const int* __restrict__ d3,
+                     const long long* __restrict__ rs, const K* __restrict__ keys, const K* __restrict__ bucket_range,
+                     const long long* __restrict__ out_range, uint64_t* __restrict__ out_idx) {
+  const size_t total = (size_t)n_local * batch;
+  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < total;
+       ob += (size_t)gridDim.x * kBlock) {
+    int peer, ll;
+    size_t bl;
+    decode_bucket(ob, n_local, bpg, peer, ll, bl);
+    const LookupDesc d = load_desc(d3, rs, ll);
+    const size_t sb = (size_t)d.global_lookup * batch + (size_t)peer * bpg + bl;
+    size_t dst = (size_t)out_range[ob];
+    for (size_t q = (size_t)bucket_range[sb]; q < (size_t)bucket_range[sb + 1]; q++) {
+      const long long k = (long long)keys[q];
+      if (k % d.num_shards == d.shard_id)
+        out_idx[dst++] = (uint64_t)(d.row_start + k / d.num_shards);  // keys_to_indices.cu:31-42
+    }
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    keys_to_indices_kernel(size_t n, const K* __restrict__ keys, long long table_start,
+                           int num_shards, uint64_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock)
+    out[i] = (uint64_t)(table_start + (long long)keys[i] / num_shards);
+}
+
+// recv / send blocks: block t holds [bpg][ev] vectors of (source rank, its local lookup).
+// src_blocks[l * max_shards + s] = block index of shard s of global lookup l, or -1.
+template <typename T>
+__device__ __forceinline__ float ld_as_f32(const T* p);
+template <>
+__device__ __forceinline__ float ld_as_f32<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_as_f32<__half>(const __half* p) { return __half2float(*p); }
+template <>
+__device__ __forceinline__ float ld_as_f32<__hip_bfloat16>(const __hip_bfloat16* p) {
+  return __bfloat162float(*p);
+}
+template <typename T>
+__device__ __forceinline__ void st_from_f32(T* p, float v);
+template <>
+__device__ __forceinline__ void st_from_f32<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void st_from_f32<__half>(__half* p, float v) { *p = __float2half_rn(v); }
+template <>
+__device__ __forceinline__ void st_from_f32<__hip_bfloat16>(__hip_bfloat16* p, float v) {
+  *p = __float2bfloat16(v);
+}
+
+template <typename T, bool FWD>
+__global__ void __launch_bounds__(kBlock)
+    ebc_network_kernel(size_t bpg, int num_lookup, int ev, int max_shards,
+                       const int* __restrict__ src_blocks, const int* __restrict__ combiner,
+                       const long long* __restrict__ bucket_counts, int batch_major,
+                       const T* __restrict__ in, T* __restrict__ out) {
+  // FWD: out[l][b][:] = (sum_s recv[block(l,s)][b][:]) / count   (count only for Average)
+  // BWD: send[block(l,s)][b][:] = grad[l][b][:] / count            for every shard s of l
+  const size_t total = (size_t)num_lookup * bpg * ev;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const int e = (int)(i % ev);
+    const size_t lb = i / ev;
+    const size_t b = lb % bpg;
+    const int l = (int)(lb / bpg);
+    float scale = 1.0f;
+    if (combiner[l] == 1) {
+      const long long c = bucket_counts[(size_t)l * bpg + b];
+      if (c > 0) scale = 1.0f / (float)c;
+    }
+    const size_t dense_idx = batch_major ? (b * (size_t)num_lookup + l) * ev + e
+                                         : ((size_t)l * bpg + b) * ev + e;
+    if (FWD) {
+      float acc = 0.f;
+      for (int s = 0; s < max_shards; s++) {
+        const int blk = src_blocks[l * max_shards + s];
+        if (blk >= 0) acc += ld_as_f32<T>(in + ((size_t)blk * bpg + b) * ev + e);
+      }
+      st_from_f32<T>(out + dense_idx, acc * scale);
+    } else {
+      const float g = ld_as_f32<T>(in + dense_idx) * scale;
+      for (int s = 0; s < max_shards; s++) {
+        const int blk = src_blocks[l * max_shards + s];
+        if (blk >= 0) st_from_f32<T>(out + ((size_t)blk * bpg + b) * ev + e, g);
+      }
+    }
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ebc_bucket_count_kernel(size_t batch, size_t bpg, int num_lookup, int rank,
+                            const K* __restrict__ bucket_range, long long* __restrict__ counts) {
+  // total key count of every (lookup, local sample) bucket of THIS rank's sample slice
+  const size_t total = (size_t)num_lookup * bpg;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const size_t l = i / bpg, b = i % bpg;
+    const size_t sb = l * batch + (size_t)rank * bpg + b;
+    counts[i] = (long long)bucket_range[sb + 1] - (long long)bucket_range[sb];
+  }
+}
+
+}  // namespace
+}  // namespace hctr
+
+using namespace hctr;
+
+struct hctr_updater {
+  SparseUpdater impl;
+};
+
+extern "C" {
+
+int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t table_start,
+                             int num_shards, uint64_t* out, hctr_stream_t stream) {
+  HCTR_REQUIRE(num_shards >= 1, "num_shards");
+  if (n == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && out, "null pointer");
+  hipStream_t s = as_stream(stream);
+  if (key_type == HCTR_KEY_U32)
+    hipLaunchKernelGGL(keys_to_indices_kernel<uint32_t>, dim3(grid_for(n, kBlock)), dim3(kBlock), 0,
+                       s, n, (const uint32_t*)keys, (long long)table_start, num_shards, out);
+  else if (key_type == HCTR_KEY_I64)
+    hipLaunchKernelGGL(keys_to_indices_kernel<long long>, dim3(grid_for(n, kBlock)), dim3(kBlock),
+                       0, s, n, (const long long*)keys, (long long)table_start, num_shards, out);
+  else
+    HCTR_REQUIRE(false, "key_type");
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_ebc_route_workspace_bytes(size_t batch, int num_local_lookups) {
+  const size_t nb = (size_t)num_local_lookups * batch;
+  return (nb + 1) * sizeof(long long) + (ceil_div<size_t>(nb + 1, 1024) + 2) * 8 + 64;
+}
+
+int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const int32_t* lookup_desc,
+                        const int64_t* row_start, const void* keys, const void* bucket_range,
+                        int key_type, int64_t* out_bucket_range, uint64_t* out_indices,
+                        uint64_t* d_nnz, void* workspace, hctr_stream_t stream) {
+  HCTR_REQUIRE(world >= 1 && batch % world == 0, "batch must be divisible by world");
+  HCTR_REQUIRE(num_local_lookups >= 0, "num_local_lookups");
+  hipStream_t s = as_stream(stream);
+  const size_t nb = (size_t)num_local_lookups * batch;
+  if (nb == 0) {
+    HCTR_HIP(hipMemsetAsync(out_bucket_range, 0, sizeof(int64_t), s));
+    if (d_nnz) HCTR_HIP(hipMemsetAsync(d_nnz, 0, sizeof(uint64_t), s));
+    return HCTR_OK;
+  }
+  HCTR_REQUIRE(lookup_desc && row_start && bucket_range && out_bucket_range && out_indices &&
+                   workspace,
+               "null pointer");
+  // workspace: [lens (nb+1) i64][tile_sums][d_total]
+  long long* lens = (long long*)workspace;
+  unsigned long long* tile_sums = (unsigned long long*)(lens + nb + 1);
+  unsigned long long* d_total = tile_sums + ceil_div<size_t>(nb + 1, 1024) + 1;
+  const int* d3 = lookup_desc;
+  const long long* rs = (const long long*)row_start;
+  const size_t bpg = batch / world;
+  const int grid = grid_for(nb, kBlock);
+  int rc = HCTR_OK;
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(ebc_count_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, batch, bpg,
+                       num_local_lookups, d3, rs, (const uint32_t*)keys,
+                       (const uint32_t*)bucket_range, lens);
+    rc = exclusive_scan_to_offsets<long long>(lens, nb, tile_sums, d_total,
+                                              (long long*)out_bucket_range, s);
+    if (rc == HCTR_OK)
+      hipLaunchKernelGGL(ebc_index_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, batch, bpg,
+                         num_local_lookups, d3, rs, (const uint32_t*)keys,
+                         (const uint32_t*)bucket_range, (const long long*)out_bucket_range,
+                         out_indices);
+  } else if (key_type == HCTR_KEY_I64) {
+    hipLaunchKernelGGL(ebc_count_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, batch, bpg,
+                       num_local_lookups, d3, rs, (const long long*)keys,
+                       (const long long*)bucket_range, lens);
+    rc = exclusive_scan_to_offsets<long long>(lens, nb, tile_sums, d_total,
+                                              (long long*)out_bucket_range, s);
+    if (rc == HCTR_OK)
+      hipLaunchKernelGGL(ebc_index_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, batch, bpg,
+                         num_local_lookups, d3, rs, (const long long*)keys,
+                         (const long long*)bucket_range, (const long long*)out_bucket_range,
+                         out_indices);
+  } else {
+    set_error("key_type");
+    rc = HCTR_ERR_INVALID_ARG;
+  }
+  if (rc == HCTR_OK && hipGetLastError() != hipSuccess) {
+    set_error("ebc route launch failed");
+    rc = HCTR_ERR_HIP;
+  }
+  if (rc == HCTR_OK && d_nnz)
+    HCTR_HIP(hipMemcpyAsync(d_nnz, d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+  return rc;
+}
+
+int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,
+                           const void* bucket_range, int key_type, int64_t* counts,
+                           hctr_stream_t stream) {
+  HCTR_REQUIRE(world >= 1 && batch % world == 0 && rank >= 0 && rank < world, "rank/world/batch");
+  const size_t bpg = batch / world;
+  const size_t total = (size_t)num_lookup * bpg;
+  if (total == 0) return HCTR_OK;
+  HCTR_REQUIRE(bucket_range && counts, "null pointer");
+  hipStream_t s = as_stream(stream);
+  if (key_type == HCTR_KEY_U32)
+    hipLaunchKernelGGL(ebc_bucket_count_kernel<uint32_t>, dim3(grid_for(total, kBlock)),
+                       dim3(kBlock), 0, s, batch, bpg, num_lookup, rank,
+                       (const uint32_t*)bucket_range, (long long*)counts);
+  else
+    hipLaunchKernelGGL(ebc_bucket_count_kernel<long long>, dim3(grid_for(total, kBlock)),
+                       dim3(kBlock), 0, s, batch, bpg, num_lookup, rank,
+                       (const long long*)bucket_range, (long long*)counts);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+static int ebc_network(bool fwd, size_t bpg, int num_lookup, int ev, int max_shards,
+                       const int32_t* src_blocks, const int32_t* combiner,
+                       const int64_t* bucket_counts, int batch_major, const void* in, void* out,
+                       int dtype, hipStream_t s) {
+  const size_t total = (size_t)num_lookup * bpg * ev;
+  if (total == 0) return HCTR_OK;
+  HCTR_REQUIRE(src_blocks && combiner && in && out, "null pointer");
+  const int grid = grid_for(total, kBlock);
+#define HCTR_NET(T)                                                                             \
+  if (fwd)                                                                                      \
+    hipLaunchKernelGGL((ebc_network_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, bpg,      \
+                       num_lookup, ev, max_shards, src_blocks, combiner,                        \
+                       (const long long*)bucket_counts, batch_major, (const T*)in, (T*)out);    \
+  else                                                                                          \
+    hipLaunchKernelGGL((ebc_network_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, bpg,     \
+                       num_lookup, ev, max_shards, src_blocks, combiner,                        \
+                       (const long long*)bucket_counts, batch_major, (const T*)in, (T*)out);
+  if (dtype == HCTR_EMB_F32) {
+    HCTR_NET(float)
+  } else if (dtype == HCTR_EMB_F16) {
+    HCTR_NET(__half)
+  } else if (dtype == HCTR_EMB_BF16) {
+    HCTR_NET(__hip_bfloat16)
+  } else {
+    HCTR_REQUIRE(false, "dtype");
+  }
+#undef HCTR_NET
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_ebc_network_forward(size_t batch_per_gpu, int num_lookup, int ev_size, int max_shards,
+                             const int32_t* d_src_blocks, const int32_t* d_combiner,
+                             const int64_t* d_bucket_counts, int batch_major, const void* recv,
+                             void* out, int dtype, hctr_stream_t stream) {
+  return ebc_network(true, batch_per_gpu, num_lookup, ev_size, max_shards, d_src_blocks,
+                     d_combiner, d_bucket_counts, batch_major, recv, out, dtype, as_stream(stream));
+}
+
+int hctr_ebc_network_backward(size_t batch_per_gpu, int num_lookup, int ev_size, int max_shards,
+                              const int32_t* d_src_blocks, const int32_t* d_combiner,
+                              const int64_t* d_bucket_counts, int batch_major, const void* grad,
+                              void* send, int dtype, hctr_stream_t stream) {
+  return ebc_network(false, batch_per_gpu, num_lookup, ev_size, max_shards, d_src_blocks,
+                     d_combiner, d_bucket_counts, batch_major, grad, send, dtype,
+                     as_stream(stream));
+}
+
+// ---- stateless sparse optimizer on a flat table (IGroupedEmbeddingTable::update) ----------------
+int hctr_updater_create(size_t max_nnz, size_t max_rows, int vec_size, hctr_updater** out) {
+  HCTR_REQUIRE(out && vec_size > 0 && max_rows > 0, "arguments");
+  hctr_updater* u = new hctr_updater();
+  int rc = u->impl.create(max_nnz, max_rows, vec_size);
+  if (rc != HCTR_OK) {
+    u->impl.destroy();
+    delete u;
+    return rc;
+  }
+  *out = u;
+  return HCTR_OK;
+}
+
+int hctr_updater_destroy(hctr_updater* u) {
+  if (!u) return HCTR_OK;
+  (void)hipDeviceSynchronize();
+  u->impl.destroy();
+  delete u;
+  return HCTR_OK;
+}
+
+int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
+                        const uint64_t* indices, const void* grad, int grad_dtype, int optimizer,
+                        int update_type, float lr, float beta1, float beta2, float epsilon,
+                        float momentum_factor, float scaler, uint64_t times, float* table,
+                        float* state0, float* state1, hctr_stream_t stream) {
+  HCTR_REQUIRE(u, "null handle");
+  if (buckets == 0) return HCTR_OK;
+  HCTR_REQUIRE(bucket_range && indices && grad && table, "null pointer");
+  OptState o;
+  o.optimizer = optimizer;
+  o.update_type = update_type;
+  o.lr = lr;
+  o.beta1 = beta1;
+  o.beta2 = beta2;
+  o.epsilon = epsilon;
+  o.momentum_factor = momentum_factor;
+  o.scaler = scaler;
+  o.atomic_update = 0;
+  o.times = times;
+  return u->impl.update(buckets, nnz, 0, bucket_range, HCTR_KEY_I64, indices, grad, grad_dtype, o,
+                        table, state0, state1, nullptr, as_stream(stream));
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@
 #include "block_prims.h"
 #include "common.h"
 #include "hashtable.h"
+#include "scan.h"
 #include "sparse_update.h"
 
 namespace hctr {
@@ -26,67 +27,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 1024;
-
-// ---- tile-based exclusive scan of per-bucket lengths -> CSR row offsets ------------------------
-template <typename OffT>
-__global__ void __launch_bounds__(kBlock)
-    tile_sum_kernel(const OffT* __restrict__ lens, size_t n, size_t n_tiles,
-                    unsigned long long* __restrict__ tile_sums) {
-  __shared__ unsigned long long smem[kBlock / 64 + 1];
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    unsigned long long c = 0;
-#pragma unroll
-    for (int r = 0; r < kTile / kBlock; r++) {
-      size_t i = tile * kTile + r * kBlock + threadIdx.x;
-      if (i < n) c += (unsigned long long)lens[i];
-    }
-    unsigned long long tot = block_reduce_sum<unsigned long long, kBlock>(c, smem);
-    if (threadIdx.x == 0) tile_sums[tile] = tot;
-  }
-}
-
-__global__ void __launch_bounds__(1024)
-    scan_tiles_u64_kernel(unsigned long long* sums, size_t m, unsigned long long* d_total) {
-  __shared__ unsigned long long smem[1024 / 64 + 1];
-  __shared__ unsigned long long carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (size_t base = 0; base < m; base += 1024) {
-    size_t i = base + threadIdx.x;
-    unsigned long long v = (i < m) ? sums[i] : 0ull;
-    unsigned long long tot;
-    unsigned long long ex = block_exclusive_scan<unsigned long long, 1024>(v, smem, &tot);
-    unsigned long long c = carry;
-    if (i < m) sums[i] = c + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *d_total = carry;
-}
-
-// offsets[i] = exclusive prefix of lens; offsets[n] = total.  lens and offsets may not alias.
-template <typename OffT>
-__global__ void __launch_bounds__(kBlock)
-    tile_downsweep_kernel(const OffT* __restrict__ lens, size_t n, size_t n_tiles,
-                          const unsigned long long* __restrict__ tile_sums,
-                          const unsigned long long* __restrict__ d_total,
-                          OffT* __restrict__ offsets) {
-  __shared__ unsigned long long smem[kBlock / 64 + 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = (OffT)*d_total;
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    unsigned long long run = tile_sums[tile];
-#pragma unroll
-    for (int r = 0; r < kTile / kBlock; r++) {
-      size_t i = tile * kTile + r * kBlock + threadIdx.x;
-      unsigned long long v = (i < n) ? (unsigned long long)lens[i] : 0ull;
-      unsigned long long tot;
-      unsigned long long ex = block_exclusive_scan<unsigned long long, kBlock>(v, smem, &tot);
-      if (i < n) offsets[i] = (OffT)(run + ex);
-      run += tot;
-    }
-  }
-}
 
 // ---- localized: keep buckets whose slot % world == rank ----------------------------------------
 // (select_value_and_rowoffset_by_slot_id_kernel, localized_slot_sparse_embedding_hash.cu:35-54)
@@ -333,18 +273,7 @@ int reset_opt_states(hctr_embedding* e, hipStream_t s) {
 
 template <typename K>
 int exclusive_scan_lens(hctr_embedding* e, void* ro_dst, size_t n, hipStream_t s) {
-  const size_t n_tiles = ceil_div<size_t>(n, kTile);
-  const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
-  hipLaunchKernelGGL(tile_sum_kernel<K>, dim3(tgrid), dim3(kBlock), 0, s, (const K*)e->lens, n,
-                     n_tiles, e->tile_sums);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(scan_tiles_u64_kernel, dim3(1), dim3(1024), 0, s, e->tile_sums, n_tiles,
-                     e->d_nnz);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tile_downsweep_kernel<K>, dim3(tgrid), dim3(kBlock), 0, s,
-                     (const K*)e->lens, n, n_tiles, e->tile_sums, e->d_nnz, (K*)ro_dst);
-  HCTR_LAUNCH_CHECK();
-  return HCTR_OK;
+  return exclusive_scan_to_offsets<K>((const K*)e->lens, n, e->tile_sums, e->d_nnz, (K*)ro_dst, s);
 }
 
 // returns (via *ro_out / *keys_out) the CSR this rank resolves

@@ -1,0 +1,277 @@
+"""embedding_collection (EBC) on static tables -- the engine SparseOperationKit plugs into.
+
+Mirrors `EmbeddingTableConfig` / `EmbeddingCollectionConfig.embedding_lookup(...).shard(...)`
+(R/HugeCTR/include/pybind/embedding_collection_wrapper.hpp:28-66) and the forward / backward /
+update of `embedding::EmbeddingCollection` (R/HugeCTR/include/embeddings/embedding_collection.hpp:
+333-406) for `RaggedStaticEmbeddingTable` storage (direct index, SGD / AdaGrad;
+R/HugeCTR/embedding_storage/ragged_static_embedding.cu).
+
+Flow per rank (one process per GPU), following SparseOperationKit's lookup_sparse
+(R/sparse_operation_kit/sparse_operation_kit/lookup.py:425-541):
+  all-gather the data-parallel keys  ->  hctr_ebc_route_keys (keep my shards' keys, key -> row)
+  ->  hctr_forward_pool into the all-to-all send layout  ->  all-to-all of embedding vectors
+  ->  hctr_ebc_network_forward (sum row-shard partials, Average scaling)  ->  [lookup][b][ev]
+Backward is the mirror; the update runs on the owner with the segmented sparse optimizer.
+
+Sharding: `shard_matrix[gpu][table]` in {0,1}; a table with one owner is table-wise sharded,
+with several owners row-wise (`key % num_shards` picks the owner in ascending GPU order, local row
+= key // num_shards).  All tables of one collection share `ev_size` here.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+@dataclass
+class EmbeddingTableConfig:
+    name: str
+    max_vocabulary_size: int
+    ev_size: int
+    opt_params: object = None
+    init_param: object = None
+
+
+class EmbeddingCollectionConfig:
+    def __init__(self, use_exclusive_keys: bool = True, comm_strategy: str = "Uniform"):
+        self.lookups = []  # (table_config, bottom_name, top_name, combiner)
+        self.shard_matrix: Optional[List[List[int]]] = None
+        self.shard_strategy = "mp"
+
+    def embedding_lookup(self, table_config, bottom_name, top_name, combiner):
+        if isinstance(table_config, (list, tuple)):
+            for t, b, tp, c in zip(table_config, bottom_name, top_name, combiner):
+                self.lookups.append((t, b, tp, c))
+        else:
+            self.lookups.append((table_config, bottom_name, top_name, combiner))
+        return self
+
+    def shard(self, shard_matrix, shard_strategy="mp", compression_strategy=None):
+        self.shard_matrix = [list(r) for r in shard_matrix]
+        self.shard_strategy = shard_strategy
+        return self
+
+
+class EmbeddingCollection:
+    """Runtime of one rank.  keys / bucket_range passed to forward are this rank's data-parallel
+    share in feature-major order: bucket = lookup * (batch/world) + b_local."""
+
+    def __init__(self, config: EmbeddingCollectionConfig, global_batch: int, lr: float = 0.01,
+                 optimizer: int = _lib.OPT_SGD, scaler: float = 1.0, epsilon: float = 1e-7,
+                 initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
+                 key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._setup(config, global_batch, lr, optimizer, scaler, epsilon, initial_accu_value,
+                    out_dtype, batch_major, key_dtype, max_hotness, seed)
+
+    @classmethod
+    def for_rank(cls, rank, world, *a, **kw):
+        """single-process construction of one rank's shard (tests / tools)"""
+        self = cls.__new__(cls)
+        self.group, self.world, self.rank = None, world, rank
+        self._setup(*a, **kw)
+        return self
+
+    def _setup(self, config, global_batch, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1.0,
+               epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
+               key_dtype=torch.int64, max_hotness=1, seed=0):
+        assert global_batch % self.world == 0
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.B, self.bpg = global_batch, global_batch // self.world
+        self.lr, self.optimizer, self.scaler, self.epsilon = lr, optimizer, scaler, epsilon
+        self.out_dtype, self.batch_major, self.key_dtype = out_dtype, batch_major, key_dtype
+        if optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD):
+            # static EBC tables: SGD / AdaGrad / Ftrl only; Ftrl not implemented here
+            raise _lib.HugeCTRAmdError("EBC static tables support SGD and AdaGrad")
+        tables: List[EmbeddingTableConfig] = []
+        for t, _, _, _ in config.lookups:
+            if t not in tables:
+                tables.append(t)
+        self.tables = tables
+        self.ev = tables[0].ev_size
+        assert all(t.ev_size == self.ev for t in tables), "one ev_size per collection"
+        self.L = len(config.lookups)
+        self.lookup_table = [tables.index(t) for t, _, _, _ in config.lookups]
+        self.combiner = [0 if str(c).lower() in ("sum", "0") else 1 for _, _, _, c in config.lookups]
+        sm = config.shard_matrix or [[1] * len(tables) for _ in range(self.world)]
+        assert len(sm) == self.world and all(len(r) == len(tables) for r in sm)
+        # owners of every table, ascending GPU order (shard id = position in that list)
+        self.owners = [[g for g in range(self.world) if sm[g][t]] for t in range(len(tables))]
+        assert all(self.owners), "every table needs at least one owner"
+        # local flat table: shards of the tables this rank owns, ceil(vocab / num_shards) rows each
+        self.local_tables = [t for t in range(len(tables)) if self.rank in self.owners[t]]
+        self.row_start_of_table = {}
+        rows = 0
+        for t in self.local_tables:
+            self.row_start_of_table[t] = rows
+            ns = len(self.owners[t])
+            rows += -(-tables[t].max_vocabulary_size // ns)
+        self.local_rows = max(rows, 1)
+        self.table = torch.empty((self.local_rows, self.ev), dtype=torch.float32, device=self.dev)
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(seed * 1000003 + self.rank)
+        for t in self.local_tables:  # U(+-sqrt(1/vocab)) per table (ragged_static_embedding.cu:499-509)
+            ns = len(self.owners[t])
+            n = -(-tables[t].max_vocabulary_size // ns)
+            b = (1.0 / tables[t].max_vocabulary_size) ** 0.5
+            s0 = self.row_start_of_table[t]
+            self.table[s0:s0 + n].uniform_(-b, b, generator=g)
+        self.accum = (torch.full_like(self.table, initial_accu_value)
+                      if optimizer == _lib.OPT_ADAGRAD else None)
+        # lookups resolved on this rank (ascending global lookup id) and their descriptors
+        self.local_lookups = [l for l in range(self.L) if self.rank in self.owners[self.lookup_table[l]]]
+        desc, rs = [], []
+        for l in self.local_lookups:
+            t = self.lookup_table[l]
+            desc += [l, len(self.owners[t]), self.owners[t].index(self.rank)]
+            rs.append(self.row_start_of_table[t])
+        self.n_local = len(self.local_lookups)
+        self.d_desc = torch.tensor(desc or [0, 1, 0], dtype=torch.int32, device=self.dev)
+        self.d_row_start = torch.tensor(rs or [0], dtype=torch.int64, device=self.dev)
+        # receive-side block table: blocks are ordered [source rank][its local lookups]
+        n_local_of = []
+        for r in range(self.world):
+            n_local_of.append([l for l in range(self.L) if r in self.owners[self.lookup_table[l]]])
+        self.n_local_of = [len(x) for x in n_local_of]
+        self.max_shards = max(len(o) for o in self.owners)
+        blk_base, acc = [], 0
+        for r in range(self.world):
+            blk_base.append(acc)
+            acc += len(n_local_of[r])
+        self.total_blocks = acc
+        src = [-1] * (self.L * self.max_shards)
+        for l in range(self.L):
+            for s, r in enumerate(self.owners[self.lookup_table[l]]):
+                src[l * self.max_shards + s] = blk_base[r] + n_local_of[r].index(l)
+        self.d_src_blocks = torch.tensor(src, dtype=torch.int32, device=self.dev)
+        self.d_combiner = torch.tensor(self.combiner, dtype=torch.int32, device=self.dev)
+        self.send_counts = [self.n_local * self.bpg * self.ev] * self.world
+        self.recv_counts = [n * self.bpg * self.ev for n in self.n_local_of]
+        # scratch
+        self.max_nnz = self.B * max(1, self.L) * max(1, max_hotness)
+        nb = self.world * max(self.n_local, 0) * self.bpg
+        self.nb = nb
+        self.ws = torch.empty(lib.hctr_ebc_route_workspace_bytes(self.B, max(self.n_local, 1)) + 64,
+                              dtype=torch.uint8, device=self.dev)
+        self.out_range = torch.zeros(nb + 1, dtype=torch.int64, device=self.dev)
+        self.indices = torch.empty(self.max_nnz, dtype=torch.int64, device=self.dev)
+        self.d_nnz = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.counts = torch.zeros(self.L * self.bpg, dtype=torch.int64, device=self.dev)
+        self._upd = ctypes.c_void_p()
+        check(lib.hctr_updater_create(self.max_nnz, self.local_rows, self.ev, ctypes.byref(self._upd)))
+        self._times = 0
+        self._nnz_host = 0
+
+    def __del__(self):
+        u = getattr(self, "_upd", None)
+        if u is not None and u.value:
+            lib.hctr_updater_destroy(u)
+            self._upd = ctypes.c_void_p()
+
+    # -- collectives (identity for world == 1; the single-process tests drive them by hand) -------
+    def _allgather_keys(self, keys, bucket_range):
+        """data-parallel CSR of every rank -> global feature-major CSR (keys, bucket_range[L*B+1]).
+        Key counts are exchanged first and read on the host (one sync), as the reference's key
+        routing does (sparse_data_distribution_op_impl.cu:303-307)."""
+        if self.world == 1 or not dist.is_initialized():
+            return keys, bucket_range
+        lens = (bucket_range[1:] - bucket_range[:-1]).to(torch.int64).contiguous()
+        all_lens = torch.empty(self.world * lens.numel(), dtype=torch.int64, device=self.dev)
+        dist.all_gather_into_tensor(all_lens, lens, group=self.group)
+        all_lens = all_lens.view(self.world, self.L, self.bpg)
+        n_all = all_lens.sum(dim=(1, 2)).tolist()  # host sync (counts)
+        parts = [torch.empty(n, dtype=keys.dtype, device=self.dev) for n in n_all]
+        dist.all_gather(parts, keys.contiguous(), group=self.group)
+        # per-rank offsets of each lookup's key segment
+        seg = all_lens.sum(dim=2)                       # [world, L] keys per (rank, lookup)
+        seg_off = torch.zeros((self.world, self.L + 1), dtype=torch.int64, device=self.dev)
+        torch.cumsum(seg, 1, out=seg_off[:, 1:])
+        seg_off = seg_off.tolist()
+        out = [parts[r][seg_off[r][l]:seg_off[r][l + 1]]
+               for l in range(self.L) for r in range(self.world)]
+        glens = all_lens.permute(1, 0, 2).reshape(-1)   # [l][rank][b_local] == [l][b]
+        gbr = torch.zeros(self.L * self.B + 1, dtype=bucket_range.dtype, device=self.dev)
+        torch.cumsum(glens, 0, out=gbr[1:])
+        return torch.cat(out), gbr
+
+    def _a2a(self, buf, send_counts, recv_counts):
+        if self.world == 1 or not dist.is_initialized():
+            return buf
+        out = torch.empty(sum(recv_counts), dtype=buf.dtype, device=self.dev)
+        dist.all_to_all_single(out, buf.reshape(-1), output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+        return out
+
+    # -- stages (public so that tests can emulate the collectives in one process) ------------------
+    def route_and_pool(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
+        """global CSR -> pooled partial vectors in the all-to-all send layout
+        [peer][local lookup][b_local][ev]"""
+        kt = _lib.KEY_I64 if gkeys.dtype == torch.int64 else _lib.KEY_U32
+        check(lib.hctr_ebc_bucket_counts(self.B, self.world, self.rank, self.L, ptr(gbucket_range),
+                                         kt, ptr(self.counts), stream_ptr()))
+        send = torch.empty((max(self.nb, 1), self.ev), dtype=self.out_dtype, device=self.dev)
+        if self.n_local == 0:
+            return send[:0]
+        check(lib.hctr_ebc_route_keys(self.B, self.world, self.n_local, ptr(self.d_desc),
+                                      ptr(self.d_row_start), ptr(gkeys), ptr(gbucket_range), kt,
+                                      ptr(self.out_range), ptr(self.indices), ptr(self.d_nnz),
+                                      ptr(self.ws), stream_ptr()))
+        self._nnz_host = int(gkeys.numel())  # upper bound; the live count stays on the device
+        check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
+                                    ptr(self.indices), ptr(self.table), ptr(send),
+                                    _DT[self.out_dtype], stream_ptr()))
+        return send
+
+    def network_forward(self, recv: torch.Tensor) -> torch.Tensor:
+        shape = (self.bpg, self.L, self.ev) if self.batch_major else (self.L, self.bpg, self.ev)
+        out = torch.empty(shape, dtype=self.out_dtype, device=self.dev)
+        check(lib.hctr_ebc_network_forward(self.bpg, self.L, self.ev, self.max_shards,
+                                           ptr(self.d_src_blocks), ptr(self.d_combiner),
+                                           ptr(self.counts), 1 if self.batch_major else 0,
+                                           ptr(recv), ptr(out), _DT[self.out_dtype], stream_ptr()))
+        return out
+
+    def network_backward(self, grad: torch.Tensor) -> torch.Tensor:
+        send = torch.zeros((max(self.total_blocks, 1) * self.bpg, self.ev), dtype=self.out_dtype,
+                           device=self.dev)
+        check(lib.hctr_ebc_network_backward(self.bpg, self.L, self.ev, self.max_shards,
+                                            ptr(self.d_src_blocks), ptr(self.d_combiner),
+                                            ptr(self.counts), 1 if self.batch_major else 0,
+                                            ptr(grad.contiguous()), ptr(send), _DT[self.out_dtype],
+                                            stream_ptr()))
+        return send
+
+    def apply_gradients(self, top_grad: torch.Tensor):
+        """top_grad: [peer][local lookup][b_local][ev] gradients of my pooled partial vectors"""
+        if self.n_local == 0:
+            return
+        self._times += 1
+        check(lib.hctr_updater_update(self._upd, self.nb, self._nnz_host, ptr(self.out_range),
+                                      ptr(self.indices), ptr(top_grad.contiguous()),
+                                      _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,
+                                      self.lr, 0.9, 0.999, self.epsilon, 0.0, self.scaler,
+                                      self._times, ptr(self.table), ptr(self.accum), None,
+                                      stream_ptr()))
+
+    # -- whole passes --------------------------------------------------------------------------------
+    def forward(self, keys: torch.Tensor, bucket_range: torch.Tensor) -> torch.Tensor:
+        gk, gbr = self._allgather_keys(keys, bucket_range)
+        send = self.route_and_pool(gk, gbr)
+        recv = self._a2a(send, self.send_counts, self.recv_counts)
+        return self.network_forward(recv)
+
+    def backward_and_update(self, grad: torch.Tensor):
+        send = self.network_backward(grad)
+        top = self._a2a(send, self.recv_counts, self.send_counts)
+        self.apply_gradients(top)

@@ -180,6 +180,58 @@ int hctr_emb_profiling(hctr_embedding* emb, int enable);
 int hctr_emb_profile_get(hctr_embedding* emb, int which, double* total_ms, uint64_t* launches);
 
 /* ------------------------------------------------------------------------------------------ */
+/* embedding_collection (EBC / SparseOperationKit) on static tables                             */
+/* ------------------------------------------------------------------------------------------ */
+/* KeysToIndicesConverter::convert (R/HugeCTR/embedding/operators/keys_to_indices.cu:24-43):
+ * idx = table_start + key / num_shards */
+int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t table_start,
+                             int num_shards, uint64_t* out, hctr_stream_t stream);
+
+/* Key routing on the gathered global CSR (DataDistributor semantics,
+ * R/HugeCTR/embedding/data_distributor/key_filtering_operators.cu:37-300, with the SOK
+ * all-gather flow): for every lookup resolved on this rank keep the keys with
+ * key % num_shards == shard_id and convert them to row indices of the rank's flat table.
+ *   keys / bucket_range: feature-major global batch, bucket = lookup * batch + b, [L*batch+1]
+ *   lookup_desc (DEVICE int32): {global_lookup, num_shards, shard_id} x num_local_lookups
+ *   row_start   (DEVICE int64): first row of each local lookup's table shard
+ * Output buckets are ordered [peer][local lookup][b_local] (= the all-to-all send layout):
+ *   out_bucket_range int64 [world * num_local_lookups * batch/world + 1], out_indices [<= nnz]. */
+size_t hctr_ebc_route_workspace_bytes(size_t batch, int num_local_lookups);
+int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const int32_t* lookup_desc,
+                        const int64_t* row_start, const void* keys, const void* bucket_range,
+                        int key_type, int64_t* out_bucket_range, uint64_t* out_indices,
+                        uint64_t* d_nnz, void* workspace, hctr_stream_t stream);
+/* total key count of each (lookup, local sample) bucket of this rank: Average divides by it on
+ * the receiving side (R/HugeCTR/embedding/operators/network_forward.cu:272-283) */
+int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,
+                           const void* bucket_range, int key_type, int64_t* counts,
+                           hctr_stream_t stream);
+/* NetworkForward / NetworkBackward: blocks of [batch_per_gpu][ev] vectors, one per (source rank,
+ * its local lookup); d_src_blocks[l * max_shards + s] = block of shard s of lookup l or -1.
+ * out / grad layout: feature-major [lookup][b][ev] or batch-major [b][lookup][ev]. */
+int hctr_ebc_network_forward(size_t batch_per_gpu, int num_lookup, int ev_size, int max_shards,
+                             const int32_t* d_src_blocks, const int32_t* d_combiner,
+                             const int64_t* d_bucket_counts, int batch_major, const void* recv,
+                             void* out, int dtype, hctr_stream_t stream);
+int hctr_ebc_network_backward(size_t batch_per_gpu, int num_lookup, int ev_size, int max_shards,
+                              const int32_t* d_src_blocks, const int32_t* d_combiner,
+                              const int64_t* d_bucket_counts, int batch_major, const void* grad,
+                              void* send, int dtype, hctr_stream_t stream);
+
+/* IGroupedEmbeddingTable::update on a caller-owned flat fp32 table
+ * (R/HugeCTR/embedding_storage/ragged_static_embedding.cu:275-353,593-700): sort + segmented
+ * reduce + optimizer, same kernels as hctr_emb_update_params.  indices[nnz] row per key,
+ * bucket_range int64 [buckets+1], grad [buckets][vec]. */
+typedef struct hctr_updater hctr_updater;
+int hctr_updater_create(size_t max_nnz, size_t max_rows, int vec_size, hctr_updater** out);
+int hctr_updater_destroy(hctr_updater* u);
+int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
+                        const uint64_t* indices, const void* grad, int grad_dtype, int optimizer,
+                        int update_type, float lr, float beta1, float beta2, float epsilon,
+                        float momentum_factor, float scaler, uint64_t times, float* table,
+                        float* state0, float* state1, hctr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Dense ops on the path                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 /* InteractionLayer<T>::fprop / bprop (R/HugeCTR/src/layers/interaction_layer.cu:1046-1237).

@@ -759,6 +759,65 @@ void hco_ebc_forward(int64_t batch, int64_t num_lookup, const int32_t* table_ids
   free(ev_off);
 }
 
+/* EmbeddingReferenceCPU::embedding_backward_cpu (reference_embedding.hpp:143-232: per (table,
+ * key) the gradients of all buckets holding the key are summed with kahanSum; Average divides
+ * the bucket gradient by its key count) + EmbeddingTableCPU::update (embedding_table_cpu.hpp:
+ * 94-124, SGD: w += -lr * g / scaler) + AdaGrad as the GPU table does it
+ * (R/HugeCTR/embedding_storage/ragged_static_embedding.cu:112-160).  All tables share `ev`.
+ * top_grad: per GPU [ev_total * bpg] in the forward's output layout, GPUs concatenated.
+ * optimizer: 0 = SGD, 1 = AdaGrad (accum [same shape as tables]). */
+void hco_ebc_backward_update(int64_t batch, int64_t num_lookup, const int32_t* table_ids,
+                             int64_t ev, const int32_t* combiners, const int64_t* keys,
+                             const int64_t* bucket_range, const int64_t* table_row_start,
+                             int64_t total_rows, int64_t num_gpus, int batch_major,
+                             const float* top_grad, int optimizer, float lr, float scaler,
+                             float epsilon, float* tables, float* accum) {
+  const int64_t bpg = batch / num_gpus;
+  const int64_t ev_total = ev * num_lookup;
+  float* sum = (float*)calloc((size_t)(total_rows * ev), sizeof(float));
+  float* comp = (float*)calloc((size_t)(total_rows * ev), sizeof(float)); /* Kahan compensation */
+  char* touched = (char*)calloc((size_t)total_rows, 1);
+  for (int64_t l = 0; l < num_lookup; l++) {
+    const int64_t rs = table_row_start[table_ids[l]];
+    for (int64_t b = 0; b < batch; b++) {
+      const int64_t bucket = l * batch + b, gpu = b / bpg, lb = b % bpg;
+      const int64_t s0 = bucket_range[bucket], e0 = bucket_range[bucket + 1];
+      const float* g = top_grad + gpu * ev_total * bpg;
+      for (int64_t r = s0; r < e0; r++) {
+        const int64_t row = rs + keys[r];
+        touched[row] = 1;
+        for (int64_t x = 0; x < ev; x++) {
+          const int64_t src = batch_major ? lb * ev_total + l * ev + x : l * ev * bpg + lb * ev + x;
+          float gi = g[src];
+          if (combiners[l] == 1) gi /= (float)(e0 - s0);
+          /* kahanSum, reference_embedding.hpp (utils): y = v - c; t = s + y; c = (t - s) - y */
+          float y = gi - comp[row * ev + x];
+          float t = sum[row * ev + x] + y;
+          comp[row * ev + x] = (t - sum[row * ev + x]) - y;
+          sum[row * ev + x] = t;
+        }
+      }
+    }
+  }
+  for (int64_t row = 0; row < total_rows; row++) {
+    if (!touched[row]) continue;
+    for (int64_t x = 0; x < ev; x++) {
+      float gi = sum[row * ev + x];
+      if (optimizer == 0) {
+        tables[row * ev + x] += -lr * gi / scaler;
+      } else {
+        gi = gi / scaler;
+        float vi = accum[row * ev + x] + gi * gi;
+        accum[row * ev + x] = vi;
+        tables[row * ev + x] += -lr * gi / (sqrtf(vi) + epsilon);
+      }
+    }
+  }
+  free(sum);
+  free(comp);
+  free(touched);
+}
+
 /* =========================================================================================== */
 /* Synthetic keys: IntPowerLawDataSimulator, R/HugeCTR/include/data_generator.hpp:108-129.      */
 /* The reference seeds mt19937 from std::random_device; we fix the seed.  u is drawn as         */

@@ -108,6 +108,12 @@ void hco_ebc_forward(int64_t batch, int64_t num_lookup, const int32_t* table_ids
                      const int64_t* bucket_range, const int64_t* table_row_start,
                      const int64_t* table_ev_start, const float* tables, int64_t num_gpus,
                      int batch_major, float* out);
+void hco_ebc_backward_update(int64_t batch, int64_t num_lookup, const int32_t* table_ids,
+                             int64_t ev, const int32_t* combiners, const int64_t* keys,
+                             const int64_t* bucket_range, const int64_t* table_row_start,
+                             int64_t total_rows, int64_t num_gpus, int batch_major,
+                             const float* top_grad, int optimizer, float lr, float scaler,
+                             float epsilon, float* tables, float* accum);
 void hco_keys_to_indices(int64_t n, const int64_t* keys, int64_t table_start, int64_t num_shards,
                          int64_t* idx);
 

@@ -88,6 +88,10 @@ def lib():
         L.hco_cross_v2_bwd.argtypes = [c_int64, c_int64, c_int64, c_int] + [c_void_p] * 11
         L.hco_ebc_forward.argtypes = [c_int64, c_int64] + [c_void_p] * 8 + [c_int64, c_int,
                                                                           c_void_p]
+        L.hco_ebc_backward_update.argtypes = [c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                              c_int, c_void_p, c_int, c_float, c_float, c_float,
+                                              c_void_p, c_void_p]
         L.hco_keys_to_indices.argtypes = [c_int64, c_void_p, c_int64, c_int64, c_void_p]
         L.hco_powerlaw_keys.argtypes = [c_uint32, c_int64, c_int64, c_float, c_void_p]
         _lib = L
@@ -304,3 +308,37 @@ def powerlaw_keys(seed, n, vocab, alpha):
     out = np.empty(n, dtype=np.int64)
     lib().hco_powerlaw_keys(seed, n, vocab, alpha, _p(out))
     return out
+
+
+def ebc_forward(batch, table_ids, ev, combiners, keys, bucket_range, table_row_start, tables,
+                num_gpus=1, batch_major=False):
+    """tables: one flat [total_rows, ev] array (all tables share ev); returns [num_gpus, ...]"""
+    L = len(table_ids)
+    t = np.ascontiguousarray(table_ids, dtype=np.int32)
+    evs = np.full(L, ev, dtype=np.int32)
+    c = np.ascontiguousarray(combiners, dtype=np.int32)
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    br = np.ascontiguousarray(bucket_range, dtype=np.int64)
+    rs = np.ascontiguousarray(table_row_start, dtype=np.int64)
+    tes = rs * ev  # element offset of each table in the flat array
+    tab = np.ascontiguousarray(tables, dtype=np.float32)
+    out = np.zeros((num_gpus, L * ev * (batch // num_gpus)), dtype=np.float32)
+    lib().hco_ebc_forward(batch, L, _p(t), _p(evs), _p(c), _p(k), _p(br), _p(rs), _p(tes), _p(tab),
+                          num_gpus, 1 if batch_major else 0, _p(out))
+    return out
+
+
+def ebc_backward_update(batch, table_ids, ev, combiners, keys, bucket_range, table_row_start,
+                        tables, top_grad, optimizer=0, lr=0.1, scaler=1.0, epsilon=1e-7, accum=None,
+                        num_gpus=1, batch_major=False):
+    """in place on `tables` (flat [total_rows, ev] float32, C-contiguous) and `accum`."""
+    t = np.ascontiguousarray(table_ids, dtype=np.int32)
+    c = np.ascontiguousarray(combiners, dtype=np.int32)
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    br = np.ascontiguousarray(bucket_range, dtype=np.int64)
+    rs = np.ascontiguousarray(table_row_start, dtype=np.int64)
+    g = np.ascontiguousarray(top_grad, dtype=np.float32)
+    assert tables.flags.c_contiguous and tables.dtype == np.float32
+    lib().hco_ebc_backward_update(batch, len(table_ids), _p(t), ev, _p(c), _p(k), _p(br), _p(rs),
+                                  tables.shape[0], num_gpus, 1 if batch_major else 0, _p(g),
+                                  optimizer, lr, scaler, epsilon, _p(tables), _p(accum))
