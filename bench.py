@@ -189,7 +189,7 @@ def main():
     n_ins = S + 1
     amp = a.dense_dtype == "bf16"
     if amp:
-        from hugectr_amd.dense import FusedMLP
+        from hugectr_amd.dense import FusedMLP, bce_with_logits
         bottom = FusedMLP([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
         top = FusedMLP([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
     else:
@@ -220,6 +220,10 @@ def main():
         xb = bottom(dense_k)
         z = ha.interaction(xb.to(edt), E)
         logit = top(z)
+        if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
+            loss, dlogit = bce_with_logits(logit, label_k, 1.0 / (Bc * C))
+            logit.backward(dlogit)
+            return loss / C
         loss = loss_fn(logit.float(), label_k) / C
         loss.backward()
         return loss.detach()

@@ -12,6 +12,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include "block_prims.h"
 #include "common.h"
 
 namespace hctr {
@@ -788,6 +789,176 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ================================================================================================
+// Fused ReLU backward + bias gradient for the MLP layers around the path:
+//   dz[b][n] = dy[b][n] * (y[b][n] > 0),   db[n] = sum_b dz[b][n]
+// PyTorch issues threshold_backward (read dy,y / write dz) and a column-sum reduction (read dz)
+// as two launches; fused, dz is consumed from registers.  Two-stage, fixed-order column sums
+// (deterministic): stage 1 writes partial[row_tile][n], stage 2 adds the tiles in order.
+// ================================================================================================
+constexpr int kRbRows = 128;  // rows per workgroup
+
+// thread t of a workgroup owns 16-byte column vector (t % cw) and walks rows (t / cw), +rg, ...;
+// cw = min(n/8, 256), rg = 256 / cw row groups; the rg partial sums meet in LDS in fixed order.
+template <bool BF>
+__global__ void __launch_bounds__(kBlock)
+    relu_bwd_bias_kernel(size_t rows, int n, int cw, int rg, const unsigned short* __restrict__ dy,
+                         const unsigned short* __restrict__ y, unsigned short* __restrict__ dz,
+                         float* __restrict__ partial) {
+  using H = H16<BF>;
+  __shared__ float red[kBlock * 8];
+  const int n8 = n / 8;
+  const int c8 = threadIdx.x % cw, g = threadIdx.x / cw;
+  const bool live = g < rg;
+  const size_t r0 = (size_t)blockIdx.x * kRbRows;
+  const size_t r1 = r0 + kRbRows < rows ? r0 + kRbRows : rows;
+  for (int cc = c8; cc - c8 < n8; cc += cw) {  // uniform trip count: every thread reaches the barriers
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live && cc < n8) {
+#pragma unroll 4
+      for (size_t r = r0 + g; r < r1; r += rg) {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + r * n + cc * 8);
+        const u32x4 av = *reinterpret_cast<const u32x4*>(y + r * n + cc * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const unsigned short g0 = (unsigned short)(gv[e] & 0xFFFFu);
+          const unsigned short g1 = (unsigned short)(gv[e] >> 16);
+          const float y0 = H::to_f32((unsigned short)(av[e] & 0xFFFFu));
+          const float y1 = H::to_f32((unsigned short)(av[e] >> 16));
+          const unsigned short z0 = y0 > 0.f ? g0 : (unsigned short)0;
+          const unsigned short z1 = y1 > 0.f ? g1 : (unsigned short)0;
+          acc[2 * e] += H::to_f32(z0);
+          acc[2 * e + 1] += H::to_f32(z1);
+          o[e] = (unsigned)z0 | ((unsigned)z1 << 16);
+        }
+        *reinterpret_cast<u32x4*>(dz + r * n + cc * 8) = o;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[e * kBlock + threadIdx.x] = acc[e];
+    __syncthreads();
+    if (g == 0 && cc < n8) {
+      float* p = partial + (size_t)blockIdx.x * n + cc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float sum = 0.f;
+        for (int k = 0; k < rg; k++) sum += red[e * kBlock + k * cw + c8];
+        p[e] = sum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// db[c..c+3] = sum over tiles of partial[tile][c..c+3]: a workgroup owns 8 float4 column groups x 32
+// tile groups; the 32 group sums are added in fixed order through LDS.
+__global__ void __launch_bounds__(kBlock)
+    colsum_partials_kernel(size_t tiles, int n, const float* __restrict__ partial,
+                           float* __restrict__ db) {
+  __shared__ f32x4 red[kBlock];
+  const int c4 = blockIdx.x * 8 + (threadIdx.x & 7), tg = threadIdx.x >> 3;
+  const bool live = c4 * 4 < n;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll 8
+    for (size_t t = tg; t < tiles; t += 32)
+      s += *reinterpret_cast<const f32x4*>(partial + t * n + c4 * 4);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tg == 0 && live) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 32; k++) sum += red[k * 8 + threadIdx.x];
+    *reinterpret_cast<f32x4*>(db + c4 * 4) = sum;
+  }
+}
+
+// out[i] = sum_g in[g][i] (fixed order), 16-bit partial products of a split-K GEMM -> fp32
+template <bool BF>
+__global__ void __launch_bounds__(kBlock)
+    sum_groups_kernel(int groups, size_t n8, const unsigned short* __restrict__ in,
+                      float* __restrict__ out) {
+  using H = H16<BF>;
+  const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n8) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int g = 0; g < groups; g++) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(in + ((size_t)g * n8 + i) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      acc[2 * e] += H::to_f32((unsigned short)(v[e] & 0xFFFFu));
+      acc[2 * e + 1] += H::to_f32((unsigned short)(v[e] >> 16));
+    }
+  }
+  f32x4* o = reinterpret_cast<f32x4*>(out + i * 8);
+  o[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  o[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+// ================================================================================================
+// BinaryCrossEntropyLoss (R/HugeCTR/src/loss.cu:231-262): per-sample stable BCE-with-logits,
+// the logit gradient scaled by grad_scale (= scaler / batch / total_gpu_count in the reference),
+// and the mean loss.  The reference accumulates the block sums with atomicAdd; here the block
+// partials are added in fixed order by the last launch (deterministic).
+// ================================================================================================
+constexpr int kBceBlocks = 256;
+
+template <typename T>
+__device__ __forceinline__ float ld_as_f32(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld_as_f32<__half>(const __half* p, size_t i) {
+  return __half2float(p[i]);
+}
+template <>
+__device__ __forceinline__ float ld_as_f32<__hip_bfloat16>(const __hip_bfloat16* p, size_t i) {
+  return __bfloat162float(p[i]);
+}
+__device__ __forceinline__ void st_from_f32(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_from_f32(__half* p, size_t i, float v) { p[i] = __float2half(v); }
+__device__ __forceinline__ void st_from_f32(__hip_bfloat16* p, size_t i, float v) {
+  p[i] = __float2bfloat16(v);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+    bce_kernel(size_t batch, const T* __restrict__ logit, const float* __restrict__ label,
+               float grad_scale, T* __restrict__ dlogit, float* __restrict__ partial) {
+  __shared__ float smem[kBlock / 64];
+  float val = 0.f;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < batch;
+       i += (size_t)gridDim.x * kBlock) {
+    const float x = ld_as_f32(logit, i);
+    const float y = label[i];
+    float g;
+    if (x >= 0.f) {
+      const float e = expf(-x);
+      g = (1.f - y) - e / (1.f + e);
+      val += x * (1.f - y) + logf(1.f + e);
+    } else {
+      const float e = expf(x);
+      g = -y + e / (1.f + e);
+      val += -x * y + logf(1.f + e);
+    }
+    if (dlogit) st_from_f32(dlogit, i, g * grad_scale);
+  }
+  const float tot = block_reduce_sum<float, kBlock>(val, smem);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    bce_finish_kernel(int blocks, size_t batch, const float* __restrict__ partial,
+                      float* __restrict__ loss) {
+  __shared__ float smem[kBlock / 64];
+  const float v = (int)threadIdx.x < blocks ? partial[threadIdx.x] : 0.f;
+  const float tot = block_reduce_sum<float, kBlock>(v, smem);
+  if (threadIdx.x == 0) *loss = tot / (float)batch;
+}
+
 constexpr int kCrossBwdWaves = 256 * 4;  // waves used by the cross backward (deterministic reduce)
 
 }  // namespace
@@ -1008,6 +1179,87 @@ int hctr_cross_v1_bwd(size_t batch, int width, int layers, const float* x0, cons
   hipLaunchKernelGGL(cross_v1_reduce_kernel, dim3(grid_for((size_t)layers * 2 * width, kBlock)),
                      dim3(kBlock), 0, s, (size_t)kCrossBwdWaves, width, layers, workspace,
                      kernel_grads, bias_grads);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_relu_bwd_bias_workspace_bytes(size_t rows, int n) {
+  return ceil_div<size_t>(rows, (size_t)kRbRows) * (size_t)n * sizeof(float);
+}
+
+int hctr_relu_bwd_bias(size_t rows, int n, const void* dy, const void* y, void* dz, float* db,
+                       float* workspace, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(n > 0 && n % 8 == 0, "n must be a multiple of 8");
+  HCTR_REQUIRE(dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16, "16-bit dtypes only");
+  if (rows == 0) return HCTR_OK;
+  HCTR_REQUIRE(dy && y && dz && db && workspace, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const size_t tiles = ceil_div<size_t>(rows, (size_t)kRbRows);
+  const int cw = n / 8 < kBlock ? n / 8 : kBlock;
+  const int rg = kBlock / cw;
+  if (dtype == HCTR_EMB_BF16)
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<true>, dim3((unsigned)tiles), dim3(kBlock), 0, s, rows,
+                       n, cw, rg, (const unsigned short*)dy, (const unsigned short*)y,
+                       (unsigned short*)dz, workspace);
+  else
+    hipLaunchKernelGGL(relu_bwd_bias_kernel<false>, dim3((unsigned)tiles), dim3(kBlock), 0, s,
+                       rows, n, cw, rg, (const unsigned short*)dy, (const unsigned short*)y,
+                       (unsigned short*)dz, workspace);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div<int>(n, 32)), dim3(kBlock), 0, s,
+                     tiles, n, workspace, db);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_sum_groups(int groups, size_t n, const void* in, int dtype, float* out,
+                    hctr_stream_t stream) {
+  HCTR_REQUIRE(groups > 0 && n % 8 == 0, "n must be a multiple of 8");
+  HCTR_REQUIRE(dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16, "16-bit dtypes only");
+  if (n == 0) return HCTR_OK;
+  HCTR_REQUIRE(in && out, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const size_t n8 = n / 8;
+  const dim3 grid((unsigned)ceil_div<size_t>(n8, (size_t)kBlock));
+  if (dtype == HCTR_EMB_BF16)
+    hipLaunchKernelGGL(sum_groups_kernel<true>, grid, dim3(kBlock), 0, s, groups, n8,
+                       (const unsigned short*)in, out);
+  else
+    hipLaunchKernelGGL(sum_groups_kernel<false>, grid, dim3(kBlock), 0, s, groups, n8,
+                       (const unsigned short*)in, out);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_bce_loss_workspace_bytes(void) { return kBceBlocks * sizeof(float); }
+
+int hctr_bce_loss(size_t batch, const void* logit, const float* label, float grad_scale,
+                  void* dlogit, float* loss, float* workspace, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(batch > 0, "empty batch");
+  HCTR_REQUIRE(logit && label && loss && workspace, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const int blocks = (int)(ceil_div<size_t>(batch, (size_t)kBlock) < (size_t)kBceBlocks
+                               ? ceil_div<size_t>(batch, (size_t)kBlock)
+                               : (size_t)kBceBlocks);
+  switch (dtype) {
+    case HCTR_EMB_F32:
+      hipLaunchKernelGGL(bce_kernel<float>, dim3(blocks), dim3(kBlock), 0, s, batch,
+                         (const float*)logit, label, grad_scale, (float*)dlogit, workspace);
+      break;
+    case HCTR_EMB_F16:
+      hipLaunchKernelGGL(bce_kernel<__half>, dim3(blocks), dim3(kBlock), 0, s, batch,
+                         (const __half*)logit, label, grad_scale, (__half*)dlogit, workspace);
+      break;
+    case HCTR_EMB_BF16:
+      hipLaunchKernelGGL(bce_kernel<__hip_bfloat16>, dim3(blocks), dim3(kBlock), 0, s, batch,
+                         (const __hip_bfloat16*)logit, label, grad_scale, (__hip_bfloat16*)dlogit,
+                         workspace);
+      break;
+    default:
+      HCTR_REQUIRE(false, "bad dtype");
+  }
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(kBlock), 0, s, blocks, batch, workspace, loss);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -18,6 +18,11 @@ from typing import List, Sequence
 
 import torch
 
+from ._lib import check, lib, ptr, stream_ptr
+
+_DT16 = {torch.float16: 1, torch.bfloat16: 2}  # hctr_emb_dtype_t
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
 
 def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16) -> torch.Tensor:
     """dW = dy^T @ x with the batch (K) dimension split into `groups` batched GEMMs."""
@@ -32,7 +37,27 @@ def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16) -> torch.
         # is 50-100 us
         return dy.t() @ x
     p = torch.bmm(dy.view(g, B // g, o).transpose(1, 2), x.view(g, B // g, i))
+    if p.is_cuda and p.dtype in _DT16 and (o * i) % 8 == 0:
+        out = torch.empty((o, i), dtype=torch.float32, device=p.device)
+        check(lib.hctr_sum_groups(g, o * i, ptr(p), _DT16[p.dtype], ptr(out), stream_ptr()))
+        return out
     return p.float().sum(0)
+
+
+def bce_with_logits(logit: torch.Tensor, label: torch.Tensor, grad_scale: float):
+    """BinaryCrossEntropyLoss forward + logit gradient in one pass (R/HugeCTR/src/loss.cu:231-262).
+
+    Returns (mean loss [1] fp32, dlogit like `logit`) with dlogit = (sigmoid(x) - y) * grad_scale;
+    feed it to `logit.backward(dlogit)`."""
+    x = logit.detach().contiguous()
+    y = label.contiguous()
+    assert x.is_cuda and y.dtype == torch.float32 and x.numel() == y.numel()
+    dlogit = torch.empty_like(x)
+    loss = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.hctr_bce_loss_workspace_bytes() // 4, dtype=torch.float32, device=x.device)
+    check(lib.hctr_bce_loss(x.numel(), ptr(x), ptr(y), float(grad_scale), ptr(dlogit), ptr(loss),
+                            ptr(ws), _DT[x.dtype], stream_ptr()))
+    return loss, dlogit
 
 
 class _LinearFn(torch.autograd.Function):
@@ -53,9 +78,20 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w16, y = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.relu:
-            dy = torch.ops.aten.threshold_backward(dy, y, 0)
-        db = dy.sum(0, dtype=torch.float32)
+        n = dy.shape[1]
+        if ctx.relu and n % 8 == 0 and dy.dtype in _DT16 and dy.is_cuda:
+            # fused ReLU backward + bias gradient (HIP): one pass instead of two
+            dz = torch.empty_like(dy)
+            db = torch.empty(n, dtype=torch.float32, device=dy.device)
+            ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(dy.shape[0], n) // 4,
+                             dtype=torch.float32, device=dy.device)
+            check(lib.hctr_relu_bwd_bias(dy.shape[0], n, ptr(dy), ptr(y), ptr(dz), ptr(db), ptr(ws),
+                                         _DT16[dy.dtype], stream_ptr()))
+            dy = dz
+        else:
+            if ctx.relu:
+                dy = torch.ops.aten.threshold_backward(dy, y, 0)
+            db = dy.sum(0, dtype=torch.float32)
         dx = dy @ w16 if ctx.needs_input_grad[0] else None
         dw = split_k_wgrad(dy, x, ctx.groups)
         return dx, dw.float(), db, None, None, None, None

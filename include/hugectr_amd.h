@@ -254,6 +254,26 @@ int hctr_cross_v1_bwd(size_t batch, int width, int layers, const float* x0, cons
                       hctr_stream_t stream);
 size_t hctr_cross_v1_bwd_workspace_bytes(size_t batch, int width, int layers);
 
+/* MLP helper around the path (MLPLayer bprop, R/HugeCTR/src/layers/mlp_layer.cu): fused
+ * dz = dy * (y > 0) and db[n] = sum_rows dz (deterministic two-stage column sum); 16-bit tensors
+ * [rows][n], n % 8 == 0; workspace >= hctr_relu_bwd_bias_workspace_bytes. */
+size_t hctr_relu_bwd_bias_workspace_bytes(size_t rows, int n);
+int hctr_relu_bwd_bias(size_t rows, int n, const void* dy, const void* y, void* dz, float* db,
+                       float* workspace, int dtype, hctr_stream_t stream);
+
+/* out[i] = sum_g in[g][i], i < n (n % 8 == 0): fixed-order reduction of the 16-bit partial products of
+ * a split-K weight-gradient GEMM into fp32. */
+int hctr_sum_groups(int groups, size_t n, const void* in, int dtype, float* out,
+                    hctr_stream_t stream);
+
+/* BinaryCrossEntropyLoss (R/HugeCTR/src/loss.cu:231-262): *loss = mean_i bce(logit_i, label_i);
+ * dlogit_i = (sigmoid(logit_i) - label_i) * grad_scale (grad_scale = scaler / batch / total_gpu_count
+ * in the reference); dlogit may be NULL (evaluation).  dtype of logit/dlogit: hctr_emb_dtype_t.
+ * Deterministic (fixed-order block sums instead of the reference's atomicAdd). */
+size_t hctr_bce_loss_workspace_bytes(void);
+int hctr_bce_loss(size_t batch, const void* logit, const float* label, float grad_scale,
+                  void* dlogit, float* loss, float* workspace, int dtype, hctr_stream_t stream);
+
 /* DCN v2 fused epilogue: out = x0 * (h + b) + x_l  (fused_matrix_elementwise_dot_add,
  * multi_cross_layer.cu:426-463); the two GEMMs stay in the caller's BLAS. */
 int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,
