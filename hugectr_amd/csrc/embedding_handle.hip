@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "block_prims.h"
+#include <cstdlib>
+
 #include "common.h"
 #include "hashtable.h"
 #include "scan.h"
@@ -215,6 +217,8 @@ struct hctr_embedding {
   uint64_t* h_nnz = nullptr;  // pinned
   hipEvent_t nnz_event = nullptr;
   bool nnz_pending = false;
+  size_t last_exact_nnz = 0;     // world > 1: exact live nnz of the previous train batch
+  bool presort_enabled = true;   // HCTR_PRESORT=0 disables the side-stream sort
   size_t cur_buckets = 0;
   size_t cur_nnz_bound = 0;
   const void* top_grad = nullptr;
@@ -364,6 +368,21 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, e->p.combiner, ro,
                                  e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype, s));
   e->prof.end(0, s);
+  if (nnz > 0 && is_train && e->presort_enabled &&
+      !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
+    // The update's (row, bucket) sort depends on the index stage only: start it on the updater's
+    // side stream, under everything the caller does between forward and update_params (after
+    // the gather: both are memory-bound and would only share HBM).  Its size must be known on
+    // the host: exact for one rank; for world > 1 the previous batch's exact count plus 1/8
+    // head room (update_params re-sorts if that was short).
+    size_t n_sort = nnz;
+    if (e->p.world > 1) {
+      n_sort = e->last_exact_nnz ? e->last_exact_nnz + e->last_exact_nnz / 8 + 1024 : 0;
+      if (n_sort > nnz) n_sort = nnz;
+    }
+    if (n_sort > 0)
+      HCTR_TRY(e->upd.presort(buckets, n_sort, ro, e->p.key_type, bb.value_index, s));
+  }
   if (is_train) {
     e->cur_buckets = buckets;
     e->cur_nnz_bound = nnz;
@@ -472,6 +491,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   if ((rc = e->ht.create(V, p.key_type)) != HCTR_OK) return fail(rc);
   if ((rc = e->ht.reserve(e->nnz_max)) != HCTR_OK) return fail(rc);
   if ((rc = e->upd.create(e->nnz_max, V, (int)D)) != HCTR_OK) return fail(rc);
+  if (const char* ps = getenv("HCTR_PRESORT")) e->presort_enabled = ps[0] != '0';
   e->upd.prof = &e->prof;
   e->opt.optimizer = p.optimizer;
   e->opt.update_type = p.update_type;
@@ -577,6 +597,7 @@ int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
   if (e->nnz_pending) {
     HCTR_HIP(hipEventSynchronize(e->nnz_event));
     nnz = (size_t)*e->h_nnz;
+    e->last_exact_nnz = nnz;
     e->nnz_pending = false;
   }
   e->opt.times++;  // update_params(): adam.times++ before the update (…hash.hpp:346-347)

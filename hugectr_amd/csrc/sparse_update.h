@@ -38,9 +38,19 @@ struct SparseUpdater {
   uint32_t* span_list = nullptr;   // [tiles] tiles in which a long (multi-tile) run starts
   uint32_t* span_count = nullptr;  // device counter for span_list
   Profiler* prof = nullptr;
+  // the (row, bucket) sort needs only the index stage's output, not the gradients: presort() runs
+  // it on a side stream while the caller's stream does the gather and the dense tower
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_sorted = nullptr;
+  size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
+  const uint64_t* early_vi = nullptr;
+  size_t early_buckets = 0;
 
   int create(size_t max_nnz, size_t max_vocab, int D);
   int destroy();
+  // optional: start sorting n >= live nnz (row, bucket) pairs now, concurrently with stream s
+  int presort(size_t buckets, size_t n, const void* row_offset, int key_type,
+              const uint64_t* value_index, hipStream_t s);
   // row_offset/key_type as in the forward; top_grad [buckets][D] of grad_dtype.
   int update(size_t buckets, size_t nnz, int combiner, const void* row_offset, int key_type,
              const uint64_t* value_index, const void* top_grad, int grad_dtype, const OptState& opt,

@@ -29,6 +29,11 @@ template <typename GradT>
 struct Load4;
 template <>
 struct Load4<float> {
+  typedef float4 raw;  // 4 elements as they sit in memory
+  __device__ __forceinline__ static raw ld_raw(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw r) { return r; }
   __device__ __forceinline__ static float4 ld(const float* p) {
     return *reinterpret_cast<const float4*>(p);
   }
@@ -37,22 +42,30 @@ struct Load4<float> {
 };
 template <>
 struct Load4<__half> {
-  __device__ __forceinline__ static float4 ld(const __half* p) {
-    uint2 u = *reinterpret_cast<const uint2*>(p);
+  typedef uint2 raw;
+  __device__ __forceinline__ static raw ld_raw(const __half* p) {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw u) {
     __half2 a = *reinterpret_cast<__half2*>(&u.x), b = *reinterpret_cast<__half2*>(&u.y);
     float2 fa = __half22float2(a), fb = __half22float2(b);
     return make_float4(fa.x, fa.y, fb.x, fb.y);
   }
+  __device__ __forceinline__ static float4 ld(const __half* p) { return cvt(ld_raw(p)); }
   __device__ __forceinline__ static float ld1(const __half* p) { return __half2float(*p); }
   __device__ __forceinline__ static float rnd(float v) { return __half2float(__float2half_rn(v)); }
 };
 template <>
 struct Load4<__hip_bfloat16> {
-  __device__ __forceinline__ static float4 ld(const __hip_bfloat16* p) {
-    uint2 u = *reinterpret_cast<const uint2*>(p);
+  typedef uint2 raw;
+  __device__ __forceinline__ static raw ld_raw(const __hip_bfloat16* p) {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
   }
+  __device__ __forceinline__ static float4 ld(const __hip_bfloat16* p) { return cvt(ld_raw(p)); }
   __device__ __forceinline__ static float ld1(const __hip_bfloat16* p) {
     return __bfloat162float(*p);
   }
@@ -336,12 +349,42 @@ __device__ __forceinline__ float4 load_scaled_grad(const GradT* __restrict__ gra
   return v;
 }
 
+// number of keys in bucket b (the mean combiner's divisor)
+__device__ __forceinline__ int bucket_len(const void* row_offset_v, bool off_is_u32, uint32_t b) {
+  if (off_is_u32) {
+    const uint32_t* ro = (const uint32_t*)row_offset_v;
+    return (int)(ro[b + 1] - ro[b]);
+  }
+  const long long* ro = (const long long*)row_offset_v;
+  return (int)(ro[b + 1] - ro[b]);
+}
+
+template <typename GradT>
+__device__ __forceinline__ float4 scaled_grad(typename Load4<GradT>::raw r, int combiner, int n) {
+  float4 v = Load4<GradT>::cvt(r);
+  if (combiner == 1) {
+    const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
+    v.x = Load4<GradT>::rnd(v.x * sc);
+    v.y = Load4<GradT>::rnd(v.y * sc);
+    v.z = Load4<GradT>::rnd(v.z * sc);
+    v.w = Load4<GradT>::rnd(v.w * sc);
+  }
+  return v;
+}
+
 // Phase A: segmented sums.  Pure load/accumulate/store -- no read-modify-write of table rows
-// inside the walk.  The tile's 32 (row, bucket) pairs are fetched once, one per lane (coalesced),
-// run starts become a 32-bit ballot mask and bucket ids are broadcast with shuffles, so the walk
-// over the tile is straight-line code whose 32 gradient-row reads are independent of each other
-// (the only sequential part is the fp32 add chain, which is what fixes the summation order).
+// inside the walk.  The kernel is bound by DEPENDENT memory round trips per tile, not by bytes, so
+// everything a tile may need is fetched in as few trips as possible:
+//   trip 1: the tile's 32 (row, bucket) pairs, one per lane (coalesced), the NEXT tile's pairs
+//           (for the run that overhangs the tile end) and the four neighbour rows that decide
+//           ownership -- run starts / overhang length become 32-bit ballot masks;
+//   trips 2..: the 32 gradient rows of the tile plus the first kSegAhead rows of the overhang,
+//           issued back to back in batches of QB raw (unconverted) fragments, clamped to a row the
+//           batch reads anyway where a position is not needed.
+// The only sequential part is the fp32 add chain, which is what fixes the summation order.
 // The sum of a run its owner finishes goes to gsum[start position]; seg_apply_kernel picks it up.
+constexpr int kSegAhead = 8;
+
 template <int LPR, typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
     seg_reduce_kernel(size_t buckets, const OffT* __restrict__ row_offset,
@@ -350,13 +393,16 @@ __global__ void __launch_bounds__(kBlock)
                       const GradT* __restrict__ grad, float* __restrict__ gsum,
                       float* __restrict__ head, float* __restrict__ tail,
                       uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count) {
+  typedef typename Load4<GradT>::raw Raw;
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   constexpr int T = kSegTile;
+  constexpr int LA = kSegAhead;
   constexpr int ML = LPR < T ? LPR : T;  // lanes of a group that carry tile metadata
   constexpr int NPL = T / ML;            // metadata entries per such lane
+  constexpr int QB = sizeof(Raw) == 8 ? 20 : 10;  // fragments in flight per lane: 40 VGPRs
   constexpr bool kOff32 = sizeof(OffT) == 4;
-  static_assert(T == 32, "masks are 32-bit");
+  static_assert(T == 32 && (T + LA) % QB == 0, "masks are 32-bit; batches tile T + LA");
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
   const int gshift = ((threadIdx.x & 63) / LPR) * LPR;  // first lane of my group in the wave
@@ -367,68 +413,115 @@ __global__ void __launch_bounds__(kBlock)
        tile += (size_t)gridDim.x * GPB) {
     const size_t base = tile * T;
     const size_t end = (base + T < nnz) ? base + T : nnz;
+    const size_t limit = (end + T < nnz) ? end + T : nnz;
     const int nvalid = (int)(end - base);
-    uint32_t mrow[NPL], mbkt[NPL];
-    uint32_t startmask = 0u;
+    // ---- trip 1: all metadata --------------------------------------------------------------
+    uint32_t mrow[NPL], mbkt[NPL], prow[NPL], nrow[NPL], nbkt[NPL];
 #pragma unroll
     for (int j = 0; j < NPL; j++) {
       const size_t pos = base + (size_t)j * ML + l;
       const bool valid = l < ML && pos < end;
       mrow[j] = valid ? (uint32_t)sorted_rows[pos] : 0xFFFFFFFFu;
       mbkt[j] = valid ? sorted_buckets[pos] : 0u;
-      const bool is_start = valid && (pos == 0 || (uint32_t)sorted_rows[pos - 1] != mrow[j]);
+      prow[j] = (valid && pos > 0) ? (uint32_t)sorted_rows[pos - 1] : 0xFFFFFFFFu;
+      const size_t np = end + (size_t)j * ML + l;
+      const bool nval = l < ML && np < limit;
+      nrow[j] = nval ? (uint32_t)sorted_rows[np] : 0xFFFFFFFFu;
+      nbkt[j] = nval ? sorted_buckets[np] : 0u;
+    }
+    // rows at base-T, base-T-1 (who owns a run that enters this tile) and at limit (does the
+    // overhanging run reach beyond tile+1); 0xFFFFFFFF never equals a live row
+    const uint32_t row_pt = base >= (size_t)T ? (uint32_t)sorted_rows[base - T] : 0xFFFFFFFFu;
+    const uint32_t row_pt1 = base > (size_t)T ? (uint32_t)sorted_rows[base - T - 1] : 0xFFFFFFFFu;
+    const uint32_t row_lim = limit < nnz ? (uint32_t)sorted_rows[limit] : 0xFFFFFFFFu;
+
+    uint32_t startmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const size_t pos = base + (size_t)j * ML + l;
+      const bool valid = l < ML && pos < end;
+      const bool is_start = valid && (pos == 0 || prow[j] != mrow[j]);
       const unsigned long long bal = __ballot(is_start);
       startmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
     }
     const uint32_t row0 = (uint32_t)__shfl((int)mrow[0], gshift, 64);
+    const uint32_t cur_row =
+        (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
+    const uint32_t next_row0 = (uint32_t)__shfl((int)nrow[0], gshift, 64);
+    const bool ends_at_tile_end = end == nnz || next_row0 != cur_row;
     int q0 = 0;
     bool head_mode = false;
     if (base > 0 && (startmask & 1u) == 0u) {
       // the tile starts inside a run begun earlier: owned by the previous tile AND ending inside
       // this tile -> its owner reduces it, skip it; otherwise it is (part of) a long run.
-      const bool owner_prev = (uint32_t)sorted_rows[base - T] != row0 || base == (size_t)T ||
-                              (uint32_t)sorted_rows[base - T - 1] != row0;
+      const bool owner_prev = row_pt != row0 || base == (size_t)T || row_pt1 != row0;
       const bool whole_tile = startmask == 0u;
-      const bool ends_inside = !whole_tile || end == nnz || (uint32_t)sorted_rows[end] != row0;
+      const bool ends_inside = !whole_tile || ends_at_tile_end;
       if (owner_prev && ends_inside) q0 = whole_tile ? nvalid : __ffs((int)startmask) - 1;
       else head_mode = true;
     }
     if (q0 >= nvalid) continue;  // the whole tile belonged to the previous tile's run
+    // overhang: leading positions of the next tile that continue this tile's last run
+    uint32_t matchmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const unsigned long long bal = __ballot(nrow[j] == cur_row);
+      matchmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
+    }
+    const bool whole_head = head_mode && startmask == 0u;  // one earlier run covers the tile
+    int cnt = (~matchmask == 0u) ? T : __ffs((int)~matchmask) - 1;  // leading ones
+    if (ends_at_tile_end || whole_head) cnt = 0;
+    const int cnt_la = cnt < LA ? cnt : LA;
+
+    // ---- trips 2..: gradient rows, QB fragments in flight ---------------------------------
     int run_start = q0;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Walk the tile in batches of QB positions: all QB gradient-row reads of a batch are issued
-    // back to back (unconditionally, clamped to a valid position) BEFORE any of the branchy
-    // flush/accumulate logic, so a group keeps QB reads in flight instead of one.
-    constexpr int QB = 8;
+    float4 own_part = acc;
+    const uint32_t b_q0 = (uint32_t)__shfl((int)mbkt[q0 / ML], gshift + (q0 % ML), 64);
 #pragma unroll
-    for (int qb = 0; qb < T; qb += QB) {
-      if (qb + QB <= q0 || qb >= nvalid) continue;  // group-uniform
-      float4 v[QB];
+    for (int qb = 0; qb < T + LA; qb += QB) {
+      Raw v[QB];
+      int nb[QB];
 #pragma unroll
       for (int k = 0; k < QB; k++) {
         const int q = qb + k;
-        const int qc = q < nvalid ? q : nvalid - 1;  // clamp: the read is always legal
-        const uint32_t bsel = (uint32_t)__shfl((int)mbkt[q / ML], gshift + (q % ML), 64);
-        const uint32_t blast =
-            (uint32_t)__shfl((int)mbkt[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
-        v[k] = load_scaled_grad<GradT, D>(grad, qc == q ? bsel : blast, l, combiner, row_offset,
-                                          kOff32);
+        uint32_t bsel;
+        if (q < T) {
+          const uint32_t bq = (uint32_t)__shfl((int)mbkt[q / ML], gshift + (q % ML), 64);
+          bsel = (q >= q0 && q < nvalid) ? bq : b_q0;
+        } else {
+          const uint32_t bq =
+              (uint32_t)__shfl((int)nbkt[(q - T) / ML], gshift + ((q - T) % ML), 64);
+          bsel = (q - T) < cnt_la ? bq : b_q0;
+        }
+        v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
+        nb[k] = combiner == 1 ? bucket_len(row_offset, kOff32, bsel) : 1;
       }
 #pragma unroll
       for (int k = 0; k < QB; k++) {
         const int q = qb + k;
-        if (q >= q0 && q < nvalid) {
-          if (((startmask >> q) & 1u) != 0u && q != q0) {
-            float* dst = head_mode ? head + tile * D : gsum + (base + run_start) * D;
-            *reinterpret_cast<float4*>(dst + l * 4) = acc;
-            acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            run_start = q;
-            head_mode = false;
+        if (q == T) own_part = acc;
+        if (q < T) {
+          if (q >= q0 && q < nvalid) {
+            if (((startmask >> q) & 1u) != 0u && q != q0) {
+              float* dst = head_mode ? head + tile * D : gsum + (base + run_start) * D;
+              *reinterpret_cast<float4*>(dst + l * 4) = acc;
+              acc = make_float4(0.f, 0.f, 0.f, 0.f);
+              run_start = q;
+              head_mode = false;
+            }
+            const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+            acc.x += f.x;
+            acc.y += f.y;
+            acc.z += f.z;
+            acc.w += f.w;
           }
-          acc.x += v[k].x;
-          acc.y += v[k].y;
-          acc.z += v[k].z;
-          acc.w += v[k].w;
+        } else if ((q - T) < cnt_la) {
+          const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+          acc.x += f.x;
+          acc.y += f.y;
+          acc.z += f.z;
+          acc.w += f.w;
         }
       }
     }
@@ -436,51 +529,42 @@ __global__ void __launch_bounds__(kBlock)
       *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
       continue;
     }
-    const uint32_t cur_row =
-        (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
-    if (end == nnz || (uint32_t)sorted_rows[end] != cur_row) {
+    if (cnt == 0) {  // the last run ends with the tile
       *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
       continue;
     }
     // the last run of this tile continues: this group owns it and follows it through tile+1
-    const float4 own_part = acc;
-    const size_t limit = (end + T < nnz) ? end + T : nnz;
-    uint32_t mbkt2[NPL];
-    uint32_t matchmask = 0u;
+    if (cnt > LA) {
+      constexpr int QC = 8;
+#pragma unroll 1
+      for (int qb = LA; qb < cnt; qb += QC) {
+        Raw v[QC];
+        int nb[QC];
 #pragma unroll
-    for (int j = 0; j < NPL; j++) {
-      const size_t pos = end + (size_t)j * ML + l;
-      const bool valid = l < ML && pos < limit;
-      const bool match = valid && (uint32_t)sorted_rows[pos] == cur_row;
-      mbkt2[j] = valid ? sorted_buckets[pos] : 0u;
-      const unsigned long long bal = __ballot(match);
-      matchmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
-    }
-    const int cnt = (~matchmask == 0u) ? T : __ffs((int)~matchmask) - 1;  // leading ones
+        for (int k = 0; k < QC; k++) {
+          const int q = (qb + k) < cnt ? qb + k : cnt - 1;
+          // NPL > 1: the register index is dynamic here -> select with a small unrolled scan
+          uint32_t src = nbkt[0];
 #pragma unroll
-    for (int qb = 0; qb < T; qb += QB) {
-      if (qb >= cnt) continue;  // group-uniform
-      float4 v[QB];
+          for (int j = 1; j < NPL; j++) src = (q / ML == j) ? nbkt[j] : src;
+          const uint32_t bsel = (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
+          v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
+          nb[k] = combiner == 1 ? bucket_len(row_offset, kOff32, bsel) : 1;
+        }
 #pragma unroll
-      for (int k = 0; k < QB; k++) {
-        const int q = qb + k;
-        const uint32_t bsel = (uint32_t)__shfl((int)mbkt2[q / ML], gshift + (q % ML), 64);
-        const uint32_t bfirst = (uint32_t)__shfl((int)mbkt2[0], gshift, 64);
-        v[k] = load_scaled_grad<GradT, D>(grad, q < cnt ? bsel : bfirst, l, combiner, row_offset,
-                                          kOff32);
-      }
-#pragma unroll
-      for (int k = 0; k < QB; k++) {
-        if (qb + k < cnt) {
-          acc.x += v[k].x;
-          acc.y += v[k].y;
-          acc.z += v[k].z;
-          acc.w += v[k].w;
+        for (int k = 0; k < QC; k++) {
+          if (qb + k < cnt) {
+            const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+            acc.x += f.x;
+            acc.y += f.y;
+            acc.z += f.z;
+            acc.w += f.w;
+          }
         }
       }
     }
     // long <=> the run reaches beyond the end of tile+1
-    const bool runs_on = cnt == T && limit < nnz && (uint32_t)sorted_rows[limit] == cur_row;
+    const bool runs_on = cnt == T && limit < nnz && row_lim == cur_row;
     if (!runs_on) {
       *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
     } else {
@@ -561,11 +645,15 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// One workgroup per long run (listed in span_list by the tile it starts in).  Group q adds head
-// partials of tiles t0+1+q, t0+1+q+GPB, ...; the GPB sums are then added to tail[t0] in the fixed
-// order q = 0..GPB-1, so the result does not depend on scheduling.
+// One workgroup per long run (listed in span_list by the tile it starts in).  The workgroup first
+// measures the run (how many following tiles begin with the same row: one round of loads per
+// kCombBlock tiles), then group q adds the head partials of tiles t0+1+q, t0+1+q+GPB, ... with 8
+// independent reads in flight; the GPB sums are added to tail[t0] in the fixed order q = 0..GPB-1,
+// so the result does not depend on scheduling.
+constexpr int kCombBlock = 1024;
+
 template <int LPR, typename OffT, typename SortK>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kCombBlock)
     seg_combine_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                        const SortK* __restrict__ sorted_rows, OptConst o,
                        float* __restrict__ table, float* __restrict__ state0,
@@ -574,50 +662,62 @@ __global__ void __launch_bounds__(kBlock)
                        const uint32_t* __restrict__ span_list,
                        const uint32_t* __restrict__ span_count) {
   constexpr int D = LPR * 4;
-  constexpr int GPB = kBlock / LPR;
-  __shared__ float4 part[kBlock];
+  constexpr int GPB = kCombBlock / LPR;
+  constexpr int NW = kCombBlock / 64;
+  __shared__ float4 part[kCombBlock];
+  __shared__ int lead[NW];
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
   const uint32_t n_span = *span_count;
   for (uint32_t si = blockIdx.x; si < n_span; si += gridDim.x) {
     const size_t t0 = span_list[si];
     const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    // ---- length of the run in tiles after t0 -------------------------------------------------
+    size_t n_heads = 0;
+    for (;;) {
+      const size_t tt = t0 + 1 + n_heads + threadIdx.x;
+      const bool match = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+      const unsigned long long bal = __ballot(match);
+      if (lane == 0) lead[wave] = (~bal == 0ull) ? 64 : __ffsll((long long)~bal) - 1;
+      __syncthreads();
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        if (tot == w * 64) tot += lead[w];
+      }
+      __syncthreads();
+      n_heads += (size_t)tot;
+      if (tot < kCombBlock) break;
+    }
+    // ---- strided sums of the head partials ---------------------------------------------------
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // 8 head partials in flight per group (a 20k-duplicate head row spans ~680 tiles)
     constexpr int CU = 8;
-    bool more = true;
-    for (size_t t = t0 + 1 + g; more; t += (size_t)GPB * CU) {
-      bool in[CU];
+    for (size_t i = (size_t)g; i < n_heads; i += (size_t)GPB * CU) {
       float4 h[CU];
 #pragma unroll
       for (int c = 0; c < CU; c++) {
-        const size_t tt = t + (size_t)c * GPB;
-        in[c] = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+        const size_t ii = i + (size_t)c * GPB;
+        const size_t tt = t0 + 1 + (ii < n_heads ? ii : i);  // clamp: always a legal read
+        h[c] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
       }
 #pragma unroll
       for (int c = 0; c < CU; c++) {
-        const size_t tt = t + (size_t)c * GPB;
-        h[c] = in[c] ? *reinterpret_cast<const float4*>(head + tt * D + l * 4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int c = 0; c < CU; c++) {
-        if (in[c]) {
+        if (i + (size_t)c * GPB < n_heads) {
           acc.x += h[c].x;
           acc.y += h[c].y;
           acc.z += h[c].z;
           acc.w += h[c].w;
         }
       }
-      more = in[CU - 1];
     }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0) {
       float4 tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
-#pragma unroll
+#pragma unroll 8
       for (int q = 0; q < GPB; q++) {
         const float4 pq = part[q * LPR + l];
         tot.x += pq.x;
@@ -775,6 +875,27 @@ int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, co
   return HCTR_OK;
 }
 
+// (row, bucket) pairs -> stable radix sort by row (sparse_optimizer.cu:657-676)
+template <typename OffT, typename SortK>
+int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const uint64_t* vi,
+               hipStream_t s) {
+  SortK* kin = (SortK*)u.sort_keys_in;
+  SortK* kout = (SortK*)u.sort_keys_out;
+  hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
+                     dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count);
+  HCTR_LAUNCH_CHECK();
+  // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
+  int end_bit = 1;
+  while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= u.max_vocab) end_bit++;
+  end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
+  size_t tb = u.sort_temp_bytes;
+  if (u.prof) u.prof->begin(2, s);
+  HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, n,
+                             end_bit, s));
+  if (u.prof) u.prof->end(2, s);
+  return HCTR_OK;
+}
+
 template <typename OffT, typename SortK, typename GradT>
 int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
                  const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
@@ -812,20 +933,16 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   }
 
   if (nnz > 0) {
-    SortK* kin = (SortK*)u.sort_keys_in;
     SortK* kout = (SortK*)u.sort_keys_out;
-    hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
-                       dim3(kBlock), 0, s, buckets, nnz, ro, vi, kin, u.sort_vals_in, u.span_count);
-    HCTR_LAUNCH_CHECK();
-    // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
-    int end_bit = 1;
-    while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= u.max_vocab) end_bit++;
-    end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
-    size_t tb = u.sort_temp_bytes;
-    if (u.prof) u.prof->begin(2, s);
-    HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, nnz,
-                               end_bit, s));
-    if (u.prof) u.prof->end(2, s);
+    if (u.early_n >= nnz && u.early_vi == vi && u.early_buckets == buckets) {
+      // (row, bucket) pairs of this batch were sorted on the side stream right after the index
+      // stage (SparseUpdater::presort); padding keys sit behind the live ones
+      HCTR_HIP(hipStreamWaitEvent(s, u.ev_sorted, 0));
+      nnz = u.early_n;
+    } else {
+      HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, s)));
+    }
+    u.early_n = 0;
     if (u.prof) u.prof->begin(3, s);
     const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
     bool done = false;
@@ -843,8 +960,8 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                        kout, u.gsum, o, table, state0, state1, (unsigned long long*)prev_time);   \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
-                       dim3(grid_for(seg_tiles, 1, 1024)), dim3(kBlock), 0, s, buckets, ro, kout, \
-                       o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head,      \
+                       dim3(grid_for(seg_tiles, 1, 512)), dim3(kCombBlock), 0, s, buckets, ro,    \
+                       kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
                        u.seg_tail, u.span_list, u.span_count);                                    \
   }
     if (a16 && D % 4 == 0) {
@@ -952,6 +1069,13 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   HCTR_HIP(hipMalloc(&run_start, (max_nnz + 2) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&d_num_runs, sizeof(uint64_t)));
   HCTR_HIP(hipMemset(d_num_runs, 0, sizeof(uint64_t)));
+  {
+    int lo = 0, hi = 0;  // hi = numerically lowest = most urgent
+    HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HCTR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
+    HCTR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HCTR_HIP(hipEventCreateWithFlags(&ev_sorted, hipEventDisableTiming));
+  }
   const size_t seg_tiles = ceil_div<size_t>(max_nnz, (size_t)kSegTile) + 1;
   HCTR_HIP(hipMalloc(&seg_head, seg_tiles * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
@@ -968,12 +1092,41 @@ int SparseUpdater::destroy() {
                   gsum};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (side) {
+    (void)hipStreamSynchronize(side);
+    (void)hipStreamDestroy(side);
+    (void)hipEventDestroy(ev_fork);
+    (void)hipEventDestroy(ev_sorted);
+    side = nullptr;
+  }
+  early_n = 0;
   sort_keys_in = sort_keys_out = sort_temp = nullptr;
   sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
   d_num_runs = nullptr;
   seg_head = seg_tail = nullptr;
   span_list = span_count = nullptr;
   gsum = nullptr;
+  return HCTR_OK;
+}
+
+int SparseUpdater::presort(size_t buckets, size_t n, const void* row_offset, int key_type,
+                           const uint64_t* value_index, hipStream_t s) {
+  early_n = 0;
+  if (buckets == 0 || n == 0 || n > max_nnz || buckets > 0xFFFFFFF0ull || !side) return HCTR_OK;
+  HCTR_HIP(hipEventRecord(ev_fork, s));
+  HCTR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+  int rc;
+  if (key_type == HCTR_KEY_U32)
+    rc = sort_stage<uint32_t, uint32_t>(*this, buckets, n, (const uint32_t*)row_offset,
+                                        value_index, side);
+  else
+    rc = sort_stage<long long, uint32_t>(*this, buckets, n, (const long long*)row_offset,
+                                         value_index, side);
+  if (rc != HCTR_OK) return rc;
+  HCTR_HIP(hipEventRecord(ev_sorted, side));
+  early_n = n;
+  early_vi = value_index;
+  early_buckets = buckets;
   return HCTR_OK;
 }
 
