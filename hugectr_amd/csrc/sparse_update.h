@@ -36,7 +36,8 @@ struct SparseUpdater {
   float* seg_tail = nullptr;    // [tiles][D]
   float* gsum = nullptr;           // [max_nnz][D] per-run gradient sums, indexed by run start
   uint32_t* span_list = nullptr;   // [tiles] tiles in which a long (multi-tile) run starts
-  uint32_t* span_count = nullptr;  // device counter for span_list
+  uint32_t* span_count = nullptr;  // device counters: [0] span_list, [1] big_list
+  uint32_t* big_list = nullptr;    // [tiles] start tiles of runs longer than kCombBigTiles tiles
   Profiler* prof = nullptr;
   // the (row, bucket) sort needs only the index stage's output, not the gradients: presort() runs
   // it on a side stream while the caller's stream does the gather and the dense tower

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(kBlock)
                         uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (tid == 0) *span_count = 0u;  // consumed by seg_update/seg_combine later in this stream
+  if (tid == 0) span_count[0] = span_count[1] = 0u;  // long-run lists of seg_reduce / seg_combine
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   for (size_t u = tid; u < buckets; u += nthreads) {
     const size_t off = (size_t)row_offset[u], end = (size_t)row_offset[u + 1];
@@ -645,25 +645,90 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// One workgroup per long run (listed in span_list by the tile it starts in).  The workgroup first
-// measures the run (how many following tiles begin with the same row: one round of loads per
-// kCombBlock tiles), then group q adds the head partials of tiles t0+1+q, t0+1+q+GPB, ... with 8
-// independent reads in flight; the GPB sums are added to tail[t0] in the fixed order q = 0..GPB-1,
-// so the result does not depend on scheduling.
+// Long runs (listed in span_list by the tile they start in): tail[t0] + head[t0+1] + head[t0+2] ...
+// With power-law keys most long runs are a few tiles long while a handful (the rows of 3- or
+// 10-row tables) span hundreds of tiles.  seg_combine_kernel gives one lane group to each run: it
+// measures the run (how many following tiles begin with the same row) and adds the head partials
+// in order, 8 reads in flight; runs of more than kCombBigTiles tiles are parked in big_list and
+// taken by seg_combine_big_kernel, one 1024-thread workgroup per run: group q adds heads q,
+// q+GPB, ...; the GPB sums are added in the fixed order q = 0..GPB-1.  Both orders are fixed, so
+// the result does not depend on scheduling.
+constexpr int kCombBigTiles = 64;
 constexpr int kCombBlock = 1024;
 
 template <int LPR, typename OffT, typename SortK>
-__global__ void __launch_bounds__(kCombBlock)
+__global__ void __launch_bounds__(kBlock)
     seg_combine_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                        const SortK* __restrict__ sorted_rows, OptConst o,
                        float* __restrict__ table, float* __restrict__ state0,
                        float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
                        const float* __restrict__ head, const float* __restrict__ tail,
-                       const uint32_t* __restrict__ span_list,
-                       const uint32_t* __restrict__ span_count) {
+                       const uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
+                       uint32_t* __restrict__ big_list) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int CU = 8;
+  constexpr unsigned long long kGroupMask = LPR >= 64 ? ~0ull : ((1ull << LPR) - 1ull);
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
+  const uint32_t n_span = span_count[0];
+  for (size_t si = (size_t)blockIdx.x * GPB + g; si < n_span; si += (size_t)gridDim.x * GPB) {
+    const size_t t0 = span_list[si];
+    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    float4 acc = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+    size_t n_heads = 0;
+    bool parked = false;
+    for (;;) {
+      const size_t tt = t0 + 1 + n_heads + l;
+      const bool match = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+      const unsigned long long gm = (__ballot(match) >> gshift) & kGroupMask;
+      const int ld = gm == kGroupMask ? LPR : __ffsll((long long)~gm) - 1;
+      n_heads += (size_t)ld;
+      if (ld < LPR) break;
+      if (n_heads > (size_t)kCombBigTiles) {
+        if (l == 0) big_list[atomicAdd(span_count + 1, 1u)] = (uint32_t)t0;
+        parked = true;
+        break;
+      }
+    }
+    if (parked) continue;
+    for (size_t i = 0; i < n_heads; i += CU) {
+      float4 h[CU];
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        const size_t tt = t0 + 1 + (i + c < n_heads ? i + c : i);  // clamp: always a legal read
+        h[c] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
+      }
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        if (i + c < n_heads) {
+          acc.x += h[c].x;
+          acc.y += h[c].y;
+          acc.z += h[c].z;
+          acc.w += h[c].w;
+        }
+      }
+    }
+    apply_row_vec4<LPR>(o, (uint64_t)row, l, acc, table, state0, state1, prev_time);
+  }
+}
+
+template <int LPR, typename OffT, typename SortK>
+__global__ void __launch_bounds__(kCombBlock)
+    seg_combine_big_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                           const SortK* __restrict__ sorted_rows, OptConst o,
+                           float* __restrict__ table, float* __restrict__ state0,
+                           float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                           const float* __restrict__ head, const float* __restrict__ tail,
+                           const uint32_t* __restrict__ big_list,
+                           const uint32_t* __restrict__ span_count) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kCombBlock / LPR;
   constexpr int NW = kCombBlock / 64;
+  constexpr int CU = 8;
   __shared__ float4 part[kCombBlock];
   __shared__ int lead[NW];
   const int g = threadIdx.x / LPR;
@@ -671,11 +736,11 @@ __global__ void __launch_bounds__(kCombBlock)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
-  const uint32_t n_span = *span_count;
-  for (uint32_t si = blockIdx.x; si < n_span; si += gridDim.x) {
-    const size_t t0 = span_list[si];
+  const uint32_t n_big = span_count[1];
+  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+    const size_t t0 = big_list[bi];
     const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
-    // ---- length of the run in tiles after t0 -------------------------------------------------
+    const float4 own = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
     size_t n_heads = 0;
     for (;;) {
       const size_t tt = t0 + 1 + n_heads + threadIdx.x;
@@ -692,15 +757,13 @@ __global__ void __launch_bounds__(kCombBlock)
       n_heads += (size_t)tot;
       if (tot < kCombBlock) break;
     }
-    // ---- strided sums of the head partials ---------------------------------------------------
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    constexpr int CU = 8;
     for (size_t i = (size_t)g; i < n_heads; i += (size_t)GPB * CU) {
       float4 h[CU];
 #pragma unroll
       for (int c = 0; c < CU; c++) {
         const size_t ii = i + (size_t)c * GPB;
-        const size_t tt = t0 + 1 + (ii < n_heads ? ii : i);  // clamp: always a legal read
+        const size_t tt = t0 + 1 + (ii < n_heads ? ii : i);
         h[c] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
       }
 #pragma unroll
@@ -716,7 +779,7 @@ __global__ void __launch_bounds__(kCombBlock)
     part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0) {
-      float4 tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+      float4 tot = own;
 #pragma unroll 8
       for (int q = 0; q < GPB; q++) {
         const float4 pq = part[q * LPR + l];
@@ -960,9 +1023,14 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                        kout, u.gsum, o, table, state0, state1, (unsigned long long*)prev_time);   \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
-                       dim3(grid_for(seg_tiles, 1, 512)), dim3(kCombBlock), 0, s, buckets, ro,    \
+                       dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, s, buckets, ro, \
                        kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
-                       u.seg_tail, u.span_list, u.span_count);                                    \
+                       u.seg_tail, u.span_list, u.span_count, u.big_list);                        \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((seg_combine_big_kernel<LPR_, OffT, SortK>), dim3(256), dim3(kCombBlock),  \
+                       0, s, buckets, ro, kout, o, table, state0, state1,                         \
+                       (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.big_list,        \
+                       u.span_count);                                                             \
   }
     if (a16 && D % 4 == 0) {
       done = true;
@@ -1081,15 +1149,16 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&gsum, max_nnz * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&span_list, seg_tiles * sizeof(uint32_t)));
-  HCTR_HIP(hipMalloc(&span_count, sizeof(uint32_t)));
-  HCTR_HIP(hipMemset(span_count, 0, sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&span_count, 2 * sizeof(uint32_t)));  // [0] long runs, [1] parked big runs
+  HCTR_HIP(hipMemset(span_count, 0, 2 * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&big_list, seg_tiles * sizeof(uint32_t)));
   return HCTR_OK;
 }
 
 int SparseUpdater::destroy() {
   void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
                   run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
-                  gsum};
+                  gsum,         big_list};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (side) {
@@ -1104,7 +1173,7 @@ int SparseUpdater::destroy() {
   sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
   d_num_runs = nullptr;
   seg_head = seg_tail = nullptr;
-  span_list = span_count = nullptr;
+  span_list = span_count = big_list = nullptr;
   gsum = nullptr;
   return HCTR_OK;
 }
