@@ -215,9 +215,17 @@ def main():
             tunable.tuning_enable(False)
             tunable.read_file(a.tunable_file)
             tuned = "file"
-    def dense_chunk(dense_k, label_k, E):
-        """bottom MLP -> interaction -> top MLP -> BCE (scaled 1/C) -> backward.  E is a leaf."""
+    def dense_chunk(dense_k, label_k, E, get_E=None, on_E_grad=None):
+        """bottom MLP -> interaction -> top MLP -> BCE (scaled 1/C) -> backward.  E is a leaf; when
+        get_E is given the bottom MLP is launched first (it does not need the embeddings, so it runs
+        under the all-to-all) and get_E() waits for / reorders the received vectors.  on_E_grad(g)
+        fires as soon as dL/dE exists -- before the bottom MLP's backward -- so the gradient
+        all-to-all starts under the rest of the backward pass."""
         xb = bottom(dense_k)
+        if get_E is not None:
+            E = get_E()
+        if on_E_grad is not None:
+            E.register_hook(on_E_grad)
         z = ha.interaction(xb.to(edt), E)
         logit = top(z)
         if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
@@ -272,9 +280,9 @@ def main():
         for k in range(C):
             if k + 1 < C:  # next sub-batch's vectors travel while this one's dense tower runs
                 recvs[k + 1], works[k + 1] = exch.forward_async(pooled[(k + 1) * Bsub:(k + 2) * Bsub])
-            if works[k] is not None:
-                works[k].wait()
             if graph is not None:
+                if works[k] is not None:
+                    works[k].wait()
                 if world > 1:
                     ha.forward_reorder(recvs[k], Bc, S, D, world, out=st_E.detach())
                 else:
@@ -284,11 +292,34 @@ def main():
                 graph.replay()
                 Eg, loss = st_E.grad, st_loss
             else:
-                E = (ha.forward_reorder(recvs[k], Bc, S, D, world) if world > 1
-                     else recvs[k].view(Bc, S, D))
-                E = E.detach().requires_grad_(True)
-                loss = dense_chunk(dense[k * Bc:(k + 1) * Bc], label[k * Bc:(k + 1) * Bc], E)
-                Eg = E.grad
+                sent = {}
+
+                def get_E(k=k):
+                    if works[k] is not None:
+                        works[k].wait()
+                    E = (ha.forward_reorder(recvs[k], Bc, S, D, world) if world > 1
+                         else recvs[k].view(Bc, S, D))
+                    return E.detach().requires_grad_(True)
+
+                def on_E_grad(g, k=k):
+                    # runs inside backward, right after the interaction's backward kernel
+                    if top_grad is not None:
+                        gsend = (ha.backward_reorder(g.contiguous(), Bc, S, D, world) if world > 1
+                                 else g.reshape(-1))
+                        sent["w"] = exch.backward_async(
+                            gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
+                        sent["buf"] = gsend
+                    else:
+                        sent["g"] = g
+
+                loss = dense_chunk(dense[k * Bc:(k + 1) * Bc], label[k * Bc:(k + 1) * Bc], None,
+                                   get_E=get_E, on_E_grad=on_E_grad)
+                if top_grad is None:
+                    tg = sent["g"]
+                else:
+                    back.append((sent["w"], sent["buf"]))
+                total = loss.clone() if total is None else total + loss
+                continue
             total = loss.clone() if total is None else total + loss
             if top_grad is None:
                 tg = Eg
