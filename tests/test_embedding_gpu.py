@@ -277,3 +277,42 @@ def test_update_power_law_duplicates(oracle, D, opt_kw):
         # long runs are summed tile-wise (different association than the sequential oracle)
         assert_close(emb.table().cpu().numpy(), table, 2e-4, 2e-5, f"table it{it}")
         keys = np.roll(keys, 7)  # different run/tile alignment in the second step
+
+
+@pytest.mark.parametrize("presort", ["1", "0"])
+def test_rank_shard_updates_with_presort_guess(oracle, presort, monkeypatch):
+    """world = 2, rank 1 of a localized embedding over several train steps whose per-rank nnz
+    jumps (so the side-stream sort's size guess -- previous exact nnz + 1/8 -- is once too short
+    and update_params must re-sort in line): table after every step == oracle on the filtered CSR.
+    HCTR_PRESORT=0 runs the same steps with the sort on the caller's stream."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    monkeypatch.setenv("HCTR_PRESORT", presort)
+    rng = np.random.default_rng(11)
+    B, S, D, vps, world, rank = 256, 6, 16, 300, 2, 1
+    V = S * vps
+    opt = ha.OptParams(optimizer=_lib.OPT_ADAGRAD, lr=0.05, epsilon=1e-6, scaler=1.0)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S * 12, S, 1, opt, rank=rank,
+                                 world=world)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    acc = np.zeros_like(table)
+    ht = oracle.HashTable(V, 8)
+    s_r = oracle.slots_on_gpu(S, rank, world)
+    for it, hot in enumerate([2, 2, 12, 3, 12]):  # nnz: ~1.2k, 1.2k, 7.4k (guess short), 1.8k, 7.4k
+        ro, keys = make_csr(rng, B, S, hot, vps, empty_frac=0.1)
+        fro, fkeys = oracle.localized_filter(ro, keys, B, S, rank, world)
+        out = emb.forward(True, _t(torch, ro), _t(torch, keys))
+        vi = ht.get_insert(fkeys)
+        want = oracle.forward(fro, vi, table, D, 1)
+        assert_close(out.cpu().numpy().reshape(-1, D), want, 1e-5, 1e-6, f"fwd it{it}")
+        g = rng.standard_normal((B * s_r, D)).astype(np.float32)
+        emb.backward(_t(torch, g).view(B, s_r, D).contiguous())
+        emb.update_params()
+        torch.cuda.synchronize()
+        wg = oracle.backward(fro, g, D, 1)
+        oracle.update_params(fro, vi, wg, _oracle_opt(oracle, opt, it + 1), table, acc)
+        assert_close(emb.table().cpu().numpy(), table, 1e-5, 1e-6, f"table it{it}")
+        assert_close(emb.opt_state(0).cpu().numpy(), acc, 1e-5, 1e-6, f"accum it{it}")
