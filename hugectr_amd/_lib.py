@@ -52,6 +52,7 @@ _SIGNATURES = {
     "hctr_ht_table_size": (c_size_t, [_P]),
     "hctr_ht_dump": (c_int, [_P, _P, _P, POINTER(c_size_t), _P]),
     "hctr_forward_pool": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_forward_pool_multihot": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
     "hctr_forward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_backward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_emb_create": (c_int, [POINTER(EmbeddingParams), POINTER(_P)]),

@@ -23,7 +23,7 @@ namespace hctr {
 
 int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
                           const uint64_t* vi, const float* table, void* out, int out_dtype,
-                          hipStream_t s);
+                          bool multi_hot, hipStream_t s);
 
 namespace {
 
@@ -365,8 +365,12 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     e->prof.end(1, s);
   }
   e->prof.begin(0, s);
+  // more keys than buckets in the full-batch CSR (host numbers) -> the flat multi-hot walk
+  const size_t full_buckets = batch * (size_t)e->p.slot_num;
+  const bool multi_hot = nnz > full_buckets + full_buckets / 2;
   HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, e->p.combiner, ro,
-                                 e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype, s));
+                                 e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype,
+                                 multi_hot, s));
   e->prof.end(0, s);
   if (nnz > 0 && is_train && e->presort_enabled &&
       !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {

@@ -9,6 +9,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace hctr {
@@ -125,6 +127,105 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// Multi-hot variant.  A lane group owns NB consecutive buckets = one contiguous range of keys and
+// walks that flat range JU keys at a time: the JU row reads of a chunk are independent of bucket
+// boundaries and are issued back to back (the next chunk's indices are already in registers), so
+// a group keeps JU rows in flight whether its buckets hold 1 key or 1000.  Sums still start at
+// 0.0f and add in key order inside each bucket -- same bits as the one-hot kernel and the oracle.
+template <int LPR, int NB, int JU, typename OffT, typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    pool_flat_kernel(size_t buckets, int combiner, const OffT* __restrict__ row_offset,
+                     const uint64_t* __restrict__ value_index, const float* __restrict__ table,
+                     OutT* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const size_t stride = (size_t)gridDim.x * GPB * NB;
+  for (size_t u0 = ((size_t)blockIdx.x * GPB + g) * NB; u0 < buckets; u0 += stride) {
+    const int nb = (int)((buckets - u0) < (size_t)NB ? (buckets - u0) : (size_t)NB);
+    const long long kbeg = (long long)row_offset[u0];
+    int e[NB];  // bucket ends relative to kbeg (group-uniform)
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+      e[i] = (int)((long long)row_offset[u0 + (size_t)(i < nb ? i + 1 : nb)] - kbeg);
+    const int total = e[NB - 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int cur = -1, cnt = 0;  // bucket being summed, keys seen in it
+    uint64_t idx[JU], nxt[JU];
+#pragma unroll
+    for (int k = 0; k < JU; k++)
+      nxt[k] = total > 0 ? value_index[kbeg + (k < total ? k : total - 1)] : kInvalidIndex;
+    for (int j0 = 0; j0 < total; j0 += JU) {
+      float4 r[JU];
+#pragma unroll
+      for (int k = 0; k < JU; k++) {
+        idx[k] = nxt[k];
+        const uint64_t row = idx[k] != kInvalidIndex ? idx[k] : 0ull;  // always a legal read
+        r[k] = ld4(table + row * (uint64_t)D + l * 4);
+      }
+      if (j0 + JU < total) {
+#pragma unroll
+        for (int k = 0; k < JU; k++) {
+          const int p = j0 + JU + k;
+          nxt[k] = value_index[kbeg + (p < total ? p : total - 1)];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < JU; k++) {
+        const int p = j0 + k;
+        if (p < total) {
+          int b = 0;  // bucket of position p = number of bucket ends <= p
+#pragma unroll
+          for (int i = 0; i < NB - 1; i++) b += (p >= e[i]) ? 1 : 0;
+          if (b != cur) {
+            if (cur >= 0) {
+              float4 v = acc;
+              if (combiner == 1 && cnt > 1) {
+                const float sc = 1.0f / (float)cnt;
+                v.x *= sc;
+                v.y *= sc;
+                v.z *= sc;
+                v.w *= sc;
+              }
+              Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
+            }
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur = b;
+            cnt = 0;
+          }
+          cnt++;
+          if (idx[k] != kInvalidIndex) {
+            acc.x += r[k].x;
+            acc.y += r[k].y;
+            acc.z += r[k].z;
+            acc.w += r[k].w;
+          }
+        }
+      }
+    }
+    if (cur >= 0) {
+      float4 v = acc;
+      if (combiner == 1 && cnt > 1) {
+        const float sc = 1.0f / (float)cnt;
+        v.x *= sc;
+        v.y *= sc;
+        v.z *= sc;
+        v.w *= sc;
+      }
+      Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
+    }
+    // empty buckets pool to zeros
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int len = e[i] - (i > 0 ? e[i - 1] : 0);
+      if (i < nb && len == 0)
+        Store4<OutT>::st(out + (u0 + (size_t)i) * (size_t)D + l * 4,
+                         make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  }
+}
+
 // any embedding_vec_size: one wavefront per bucket, lanes stride over the vector
 template <typename OffT, typename OutT>
 __global__ void __launch_bounds__(kBlock)
@@ -151,13 +252,19 @@ __global__ void __launch_bounds__(kBlock)
 
 template <typename OffT, typename OutT>
 int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint64_t* vi,
-                const float* table, OutT* out, hipStream_t s) {
+                const float* table, OutT* out, bool multi_hot, hipStream_t s) {
 #define HCTR_POOL_CASE(LPR_, BU_)                                                              \
   {                                                                                            \
     constexpr int GPB = kBlock / LPR_;                                                         \
-    const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)BU_), GPB, 256 * 8);          \
-    hipLaunchKernelGGL((pool_vec4_kernel<LPR_, BU_, OffT, OutT>), dim3(grid), dim3(kBlock), 0, \
-                       s, buckets, combiner, ro, vi, table, out);                              \
+    if (multi_hot) {                                                                           \
+      const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)8), GPB, 256 * 8);          \
+      hipLaunchKernelGGL((pool_flat_kernel<LPR_, 8, 8, OffT, OutT>), dim3(grid), dim3(kBlock), \
+                         0, s, buckets, combiner, ro, vi, table, out);                         \
+    } else {                                                                                   \
+      const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)BU_), GPB, 256 * 8);        \
+      hipLaunchKernelGGL((pool_vec4_kernel<LPR_, BU_, OffT, OutT>), dim3(grid), dim3(kBlock), \
+                         0, s, buckets, combiner, ro, vi, table, out);                         \
+    }                                                                                          \
   }
   const bool aligned = (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
@@ -240,19 +347,26 @@ int launch_reorder(size_t bpg, int S, int D, int N, const void* in, void* out, i
 
 int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
                           const uint64_t* vi, const float* table, void* out, int out_dtype,
-                          hipStream_t s) {
+                          bool multi_hot, hipStream_t s) {
   if (buckets == 0) return HCTR_OK;
+  // HCTR_POOL_KERNEL=bucket|flat pins the kernel (measurements); default: the caller's hint
+  static const int forced = [] {
+    const char* v = getenv("HCTR_POOL_KERNEL");
+    if (!v) return -1;
+    return v[0] == 'f' ? 1 : (v[0] == 'b' ? 0 : -1);
+  }();
+  if (forced >= 0) multi_hot = forced == 1;
 #define HCTR_POOL_OUT(OffT)                                                                       \
   switch (out_dtype) {                                                                            \
     case HCTR_EMB_F32:                                                                            \
       return launch_pool<OffT, float>(buckets, D, combiner, (const OffT*)ro, vi, table,           \
-                                      (float*)out, s);                                            \
+                                      (float*)out, multi_hot, s);                                            \
     case HCTR_EMB_F16:                                                                            \
       return launch_pool<OffT, __half>(buckets, D, combiner, (const OffT*)ro, vi, table,          \
-                                       (__half*)out, s);                                          \
+                                       (__half*)out, multi_hot, s);                                          \
     case HCTR_EMB_BF16:                                                                           \
       return launch_pool<OffT, __hip_bfloat16>(buckets, D, combiner, (const OffT*)ro, vi, table,  \
-                                               (__hip_bfloat16*)out, s);                          \
+                                               (__hip_bfloat16*)out, multi_hot, s);                          \
     default:                                                                                      \
       set_error("out_dtype");                                                                     \
       return HCTR_ERR_INVALID_ARG;                                                                \
@@ -280,7 +394,17 @@ int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* ro
   HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
   HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
   return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
-                               table, out, out_dtype, as_stream(stream));
+                               table, out, out_dtype, false, as_stream(stream));
+}
+
+int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                               int key_type, const uint64_t* value_index, const float* table,
+                               void* out, int out_dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
+  return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
+                               table, out, out_dtype, true, as_stream(stream));
 }
 
 int hctr_forward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,

@@ -84,6 +84,11 @@ int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* 
 int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* row_offset,
                       int key_type, const uint64_t* value_index, const float* table, void* out,
                       int out_dtype, hctr_stream_t stream);
+/* same contract; walks each lane group's keys as one flat range (8 row reads in flight whatever the
+ * bucket lengths): the kernel of choice for multi-hot buckets. */
+int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                      int key_type, const uint64_t* value_index, const float* table, void* out,
+                      int out_dtype, hctr_stream_t stream);
 
 /* forward_reorder / backward_reorder: R/HugeCTR/src/embeddings/forward_reorder_functor.cu:26-98,
  * backward_reorder_functor.cu.  in [gpu][b][slot_in_gpu][D] <-> out [b][slot][D]. */

@@ -316,3 +316,33 @@ def test_rank_shard_updates_with_presort_guess(oracle, presort, monkeypatch):
         oracle.update_params(fro, vi, wg, _oracle_opt(oracle, opt, it + 1), table, acc)
         assert_close(emb.table().cpu().numpy(), table, 1e-5, 1e-6, f"table it{it}")
         assert_close(emb.opt_state(0).cpu().numpy(), acc, 1e-5, 1e-6, f"accum it{it}")
+
+
+@pytest.mark.parametrize("D", [4, 16, 64, 128, 256])
+@pytest.mark.parametrize("combiner", [0, 1])
+def test_stateless_pool_kernels_agree_bit_exact(oracle, D, combiner):
+    """hctr_forward_pool (bucket-major) and hctr_forward_pool_multihot (flat key walk) on ragged
+    buckets with empty ones, very long ones and missing rows: identical bits, equal to the oracle."""
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(D + combiner)
+    nb, V = 1003, 500
+    lens = rng.integers(0, 7, size=nb)
+    lens[rng.random(nb) < 0.3] = 0
+    lens[[5, 400, 1002]] = [300, 77, 19]        # long buckets, one of them the very last
+    lens[:3] = 0                                  # leading empties
+    ro = np.zeros(nb + 1, dtype=np.int64)
+    np.cumsum(lens, out=ro[1:])
+    vi = rng.integers(0, V, size=int(ro[-1])).astype(np.uint64)
+    vi[rng.random(vi.size) < 0.05] = oracle.INVALID   # eval misses contribute 0 but count (q3)
+    table = rng.standard_normal((V, D)).astype(np.float32)
+    want = oracle.forward(ro, vi, table, D, combiner)
+    rot, vit, tt = _t(torch, ro), _t(torch, vi.view(np.int64)), _t(torch, table)
+    outs = []
+    for fn in (_lib.lib.hctr_forward_pool, _lib.lib.hctr_forward_pool_multihot):
+        out = torch.full((nb, D), 7.0, device="cuda")
+        _lib.check(fn(nb, D, combiner, _lib.ptr(rot), _lib.KEY_I64, _lib.ptr(vit), _lib.ptr(tt),
+                      _lib.ptr(out), _lib.F32, _lib.stream_ptr()))
+        outs.append(out.cpu().numpy())
+        assert (outs[-1].view(np.uint32) == want.view(np.uint32)).all()
+    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()
