@@ -34,7 +34,18 @@ class EmbeddingParams(Structure):
     ]
 
 
+class DetOptParams(Structure):
+    """hctr_det_opt_params"""
+    _fields_ = [
+        ("optimizer", c_int), ("lr", c_float), ("beta1", c_float), ("beta2", c_float),
+        ("epsilon", c_float), ("momentum_factor", c_float), ("rmsprop_beta", c_float),
+        ("ftrl_lambda1", c_float), ("ftrl_lambda2", c_float), ("ftrl_beta", c_float),
+        ("scaler", c_float),
+    ]
+
+
 _P = c_void_p
+_SZP = POINTER(c_size_t)
 _SIGNATURES = {
     # name: (restype, argtypes)
     "hctr_last_error": (c_char_p, []),
@@ -91,6 +102,20 @@ _SIGNATURES = {
     "hctr_cross_v1_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "hctr_cross_v1_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hctr_cross_v1_bwd_workspace_bytes": (c_size_t, [c_size_t, c_int, c_int]),
+    "hctr_det_create": (c_int, [c_size_t, _SZP, c_char_p, c_size_t, c_int, c_uint64, POINTER(_P)]),
+    "hctr_det_destroy": (c_int, [_P]),
+    "hctr_det_num_classes": (c_size_t, [_P]),
+    "hctr_det_lookup": (c_int, [_P, _P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
+    "hctr_det_lookup_unsafe": (c_int, [_P, _P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
+    "hctr_det_scatter_add": (c_int, [_P, _P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
+    "hctr_det_scatter_update": (c_int, [_P, _P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
+    "hctr_det_remove": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
+    "hctr_det_export": (c_int, [_P, c_size_t, _P, _P, c_size_t, _SZP, _P]),
+    "hctr_det_clear": (c_int, [_P, _P]),
+    "hctr_det_size_per_class": (c_int, [_P, _SZP, _P]),
+    "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),
+    "hctr_det_update": (c_int, [_P, _P, POINTER(DetOptParams), _P, c_size_t, _SZP, _SZP, c_size_t,
+                                _P, _P, _P]),
     "hctr_relu_bwd_bias_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_relu_bwd_bias": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_sum_groups": (c_int, [c_int, c_size_t, _P, c_int, _P, _P]),

@@ -1,0 +1,652 @@
+// det.hip -- dynamic embedding table: key -> embedding vector maps that grow on demand.
+//
+// Replaces det::DynamicEmbeddingTable<Key, float>
+// (R/third_party/dynamic_embedding_table/dynamic_embedding_table.hpp:25-66, .cu) and the fused
+// optimizer step of embedding::DynamicEmbeddingTable::update
+// (R/HugeCTR/embedding_storage/dynamic_embedding.cu:176-330, optimizers.cuh:29-233).
+//
+// MI355X-first layout instead of cuco's chain of sub-maps with inline vectors: per class (= one
+// embedding dimension) an open-addressing index (the path's HashTable: 16-B {key,row} entries,
+// deterministic first-occurrence row numbers) in front of ONE dense row store [capacity][dim]
+// fp32.  Lookups are then the same coalesced row gathers as the static path, new rows are dense at
+// the tail (initialised by a counter-based RNG, so results do not depend on thread scheduling or
+// on std::random_device as in the reference), and growth is a doubling re-allocation + re-index.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "hashtable.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// cuco::initializer (initializer.cuh:36-55): a constant, or curand_uniform -> (0, 1]
+__device__ __forceinline__ float det_init_value(int mode, float val, uint64_t seed, uint64_t row,
+                                                uint32_t e) {
+  if (mode == 0) return val;
+  const uint64_t h = splitmix64(seed ^ splitmix64(row * 0x100000001B3ull + e));
+  return ((float)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);  // 24 random bits -> (0, 1]
+}
+
+// rows created by the get_insert that just ran: positions (into the key batch) of the first
+// occurrence of every unseen key are in new_positions[0 .. *d_new_count)
+__global__ void __launch_bounds__(kBlock)
+    det_init_rows_kernel(const uint64_t* __restrict__ new_positions,
+                         const uint64_t* __restrict__ d_new_count,
+                         const uint64_t* __restrict__ idx, float* __restrict__ rows, int dim,
+                         int mode, float val, uint64_t seed) {
+  const uint64_t n_new = *d_new_count;
+  const uint64_t total = n_new * (uint64_t)dim;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t row = idx[new_positions[i / dim]];
+    const uint32_t e = (uint32_t)(i % dim);
+    rows[row * dim + e] = det_init_value(mode, val, seed, row, e);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    det_gather_kernel(const uint64_t* __restrict__ idx, size_t n, const float* __restrict__ rows,
+                      int dim, float* __restrict__ out) {
+  const uint64_t total = (uint64_t)n * dim;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t r = idx[i / dim];
+    out[i] = r != kInvalidIndex ? rows[r * dim + (i % dim)] : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    det_ptr_kernel(const uint64_t* __restrict__ idx, size_t n, float* rows, int dim,
+                   float** __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock)
+    out[i] = idx[i] != kInvalidIndex ? rows + idx[i] * (uint64_t)dim : nullptr;
+}
+
+// dynamic_map_kernels.cuh:143-183: keys that are not in the map are skipped
+template <bool ADD>
+__global__ void __launch_bounds__(kBlock)
+    det_scatter_kernel(const uint64_t* __restrict__ idx, size_t n, float* __restrict__ rows,
+                       int dim, const float* __restrict__ upd) {
+  const uint64_t total = (uint64_t)n * dim;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t r = idx[i / dim];
+    if (r == kInvalidIndex) continue;
+    float* dst = rows + r * dim + (i % dim);
+    if (ADD) unsafeAtomicAdd(dst, upd[i]);
+    else *dst = upd[i];
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    det_erase_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
+                     size_t n, long long tomb, unsigned long long* __restrict__ d_erased) {
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const K key = keys[i];
+    const long long k64 = (long long)(sizeof(K) == 4 ? (unsigned long long)(uint32_t)key
+                                                     : (unsigned long long)key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    for (uint64_t probes = 0; probes <= size; ++probes) {
+      const long long cur = tab[slot].key;
+      if (cur == k64) {
+        // duplicates of one key in the batch race for the slot; one of them wins the CAS
+        const unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot].key),
+                      (unsigned long long)k64, (unsigned long long)tomb);
+        if (old == (unsigned long long)k64) {
+          tab[slot].val = kInvalidIndex;
+          atomicAdd(d_erased, 1ull);
+        }
+        break;
+      }
+      if (cur == empty) break;
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+  }
+}
+
+struct DetOpt {
+  int optimizer;
+  float lr, beta1, beta2, epsilon, momentum, scaler;
+  float lr_scaled_bias;               // adam
+  float rms_beta;                     // rmsprop
+  float lambda1, lambda2_plus_beta_div_lr;  // ftrl
+};
+
+// One thread per element of one unique key's vector.  Formulas: optimizers.cuh:29-233 -- the
+// reference turns wgrad into the weight delta in place and then scatter_adds it; here the delta is
+// applied to the row directly (same arithmetic, one pass).
+__global__ void __launch_bounds__(kBlock)
+    det_update_kernel(DetOpt o, size_t n, int dim, const uint64_t* __restrict__ idx_w,
+                      const uint64_t* __restrict__ idx_s, float* __restrict__ rows_w,
+                      float* __restrict__ rows_s, const uint32_t* __restrict__ ev_start,
+                      const float* __restrict__ wgrad) {
+  const uint64_t total = (uint64_t)n * dim;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const size_t k = (size_t)(i / dim);
+    const int e = (int)(i % dim);
+    const uint64_t rw = idx_w[k];
+    if (rw == kInvalidIndex) continue;  // scatter_add skips keys that are not in the table
+    const float gi = wgrad[ev_start[k] + e] / o.scaler;
+    float* w = rows_w + rw * dim + e;
+    const int sdim = dim * (o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_FTRL ? 2 : 1);
+    float* st = (rows_s != nullptr && idx_s != nullptr) ? rows_s + idx_s[k] * (uint64_t)sdim
+                                                         : nullptr;
+    float delta;
+    switch (o.optimizer) {
+      case HCTR_OPT_SGD:
+        delta = -o.lr * gi;
+        break;
+      case HCTR_OPT_MOMENTUM_SGD: {
+        const float mi = o.momentum * st[e] - o.lr * gi;
+        st[e] = mi;
+        delta = mi;
+      } break;
+      case HCTR_OPT_NESTEROV: {
+        const float prev = st[e];
+        const float mi = o.momentum * prev - o.lr * gi;
+        st[e] = mi;
+        delta = mi + o.momentum * mi - o.momentum * prev;
+      } break;
+      case HCTR_OPT_ADAGRAD: {
+        const float vi = st[e] + gi * gi;
+        st[e] = vi;
+        delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
+      } break;
+      case HCTR_OPT_RMSPROP: {
+        const float vi = o.rms_beta * st[e] + (1.f - o.rms_beta) * gi * gi;
+        st[e] = vi;
+        delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
+      } break;
+      case HCTR_OPT_ADAM: {
+        const float mi = o.beta1 * st[e] + (1.f - o.beta1) * gi;
+        const float vi = o.beta2 * st[dim + e] + (1.f - o.beta2) * gi * gi;
+        st[e] = mi;
+        st[dim + e] = vi;
+        delta = -o.lr_scaled_bias * mi / (sqrtf(vi) + o.epsilon);
+      } break;
+      default: {  // HCTR_OPT_FTRL
+        float ni = st[e];
+        const float ni_prev_sqrt = sqrtf(ni + 1.1920929e-07f);  // FLT_EPSILON
+        ni = ni + gi * gi;
+        st[e] = ni;
+        const float ni_sqrt = sqrtf(ni + 1.1920929e-07f);
+        const float sigma = (ni_sqrt - ni_prev_sqrt) / o.lr;
+        const float wi = *w;
+        const float zi = st[dim + e] + gi - sigma * wi;
+        st[dim + e] = zi;
+        const float p = (1.f - 2.f * (float)signbit(zi)) * o.lambda1 - zi;
+        const float q = ni_sqrt / o.lr + o.lambda2_plus_beta_div_lr;
+        delta = (p / q) * (float)signbit(o.lambda1 - fabsf(zi)) - wi;
+      } break;
+    }
+    *w += delta;
+  }
+}
+
+struct DetClass {
+  HashTable ht;
+  float* rows = nullptr;
+  size_t cap = 0;         // rows allocated == ht.capacity
+  int dim = 0;
+  size_t head_bound = 0;  // host upper bound of the row counter (value head)
+  unsigned long long* d_erased = nullptr;
+};
+
+}  // namespace
+}  // namespace hctr
+
+using namespace hctr;
+
+struct hctr_det {
+  std::vector<DetClass> cls;
+  int key_type = HCTR_KEY_I64;
+  int init_mode = 1;  // 0 constant, 1 uniform (0, 1]
+  float init_val = 0.f;
+  uint64_t seed = 0;
+  uint64_t adam_times = 0;
+  uint64_t* idx = nullptr;  // scratch row indices
+  uint64_t* idx2 = nullptr;
+  size_t idx_cap = 0;
+};
+
+namespace {
+
+int det_scratch(hctr_det* h, size_t n) {
+  if (n <= h->idx_cap) return HCTR_OK;
+  if (h->idx) (void)hipFree(h->idx);
+  if (h->idx2) (void)hipFree(h->idx2);
+  h->idx = h->idx2 = nullptr;
+  size_t c = h->idx_cap ? h->idx_cap : 1024;
+  while (c < n) c *= 2;
+  HCTR_HIP(hipMalloc(&h->idx, c * sizeof(uint64_t)));
+  HCTR_HIP(hipMalloc(&h->idx2, c * sizeof(uint64_t)));
+  h->idx_cap = c;
+  return HCTR_OK;
+}
+
+int class_create(DetClass& c, size_t cap, int dim, int key_type) {
+  c.dim = dim;
+  c.cap = cap;
+  HCTR_TRY(c.ht.create(cap, key_type));
+  HCTR_HIP(hipMalloc(&c.rows, cap * (size_t)dim * sizeof(float)));
+  HCTR_HIP(hipMalloc(&c.d_erased, sizeof(unsigned long long)));
+  HCTR_HIP(hipMemset(c.d_erased, 0, sizeof(unsigned long long)));
+  c.head_bound = 0;
+  return HCTR_OK;
+}
+
+void class_destroy(DetClass& c) {
+  c.ht.destroy();
+  if (c.rows) (void)hipFree(c.rows);
+  if (c.d_erased) (void)hipFree(c.d_erased);
+  c.rows = nullptr;
+  c.d_erased = nullptr;
+}
+
+// make room for n more rows (cuco::dynamic_map::reserve): doubling re-allocation of the row store
+// and a re-index of the live keys into a table of the new capacity (tombstones are dropped)
+int class_reserve(DetClass& c, size_t n, int key_type, hipStream_t s) {
+  if (c.head_bound + n <= c.cap) return HCTR_OK;
+  size_t head = 0;
+  HCTR_TRY(c.ht.value_head(s, &head));  // synchronises: the exact row counter
+  c.head_bound = head;
+  if (head + n <= c.cap) return HCTR_OK;
+  size_t ncap = c.cap * 2;
+  while (ncap < head + n) ncap *= 2;
+  // live (key, row) pairs of the old index
+  int64_t* d_keys = nullptr;
+  uint64_t* d_vals = nullptr;
+  const size_t slots = (size_t)c.ht.size;
+  HCTR_HIP(hipMalloc(&d_keys, slots * sizeof(int64_t)));
+  HCTR_HIP(hipMalloc(&d_vals, slots * sizeof(uint64_t)));
+  size_t live = 0;
+  HCTR_TRY(c.ht.dump(d_keys, d_vals, &live, s));
+  HashTable nht;
+  HCTR_TRY(nht.create(ncap, key_type));
+  if (live > 0) {
+    if (key_type == HCTR_KEY_U32) {
+      // dump widens keys to int64; the u32 insert path wants 32-bit keys
+      std::vector<int64_t> hk(live);
+      HCTR_HIP(hipMemcpy(hk.data(), d_keys, live * sizeof(int64_t), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> hk32(live);
+      for (size_t i = 0; i < live; i++) hk32[i] = (uint32_t)hk[i];
+      HCTR_HIP(hipMemcpy(d_keys, hk32.data(), live * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    HCTR_TRY(nht.insert(d_keys, d_vals, live, s));
+  }
+  HCTR_TRY(nht.set_value_head(head, s));
+  float* nrows = nullptr;
+  HCTR_HIP(hipMalloc(&nrows, ncap * (size_t)c.dim * sizeof(float)));
+  HCTR_HIP(hipMemcpyAsync(nrows, c.rows, head * (size_t)c.dim * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d_keys);
+  (void)hipFree(d_vals);
+  (void)hipFree(c.rows);
+  c.ht.destroy();
+  c.ht = nht;
+  c.rows = nrows;
+  c.cap = ncap;
+  // rows of erased keys stay allocated (indices are never reused); only the index forgets them
+  return HCTR_OK;
+}
+
+struct Range {
+  size_t cls, off, n;
+};
+
+int ranges_of(const hctr_det* h, size_t num_keys, const size_t* id_spaces,
+              const size_t* id_space_offsets, size_t num_id_spaces, std::vector<Range>* out) {
+  HCTR_REQUIRE(num_id_spaces == 0 || (id_spaces && id_space_offsets), "null id_space arrays");
+  for (size_t i = 0; i < num_id_spaces; i++) {
+    HCTR_REQUIRE(id_spaces[i] < h->cls.size(), "id_space out of range");
+    HCTR_REQUIRE(id_space_offsets[i] <= id_space_offsets[i + 1] &&
+                     id_space_offsets[i + 1] <= num_keys,
+                 "id_space_offsets must be ascending and end at num_keys");
+    out->push_back({id_spaces[i], id_space_offsets[i], id_space_offsets[i + 1] - id_space_offsets[i]});
+  }
+  return HCTR_OK;
+}
+
+inline const void* key_at(const hctr_det* h, const void* keys, size_t off) {
+  return (const char*)keys + off * (h->key_type == HCTR_KEY_U32 ? 4 : 8);
+}
+
+// lookup with insertion of unseen keys; leaves row indices in h->idx[0..n)
+int class_lookup_insert(hctr_det* h, DetClass& c, size_t cls_index, const void* keys, size_t n,
+                        uint64_t* idx, hipStream_t s) {
+  HCTR_TRY(class_reserve(c, n, h->key_type, s));
+  HCTR_TRY(c.ht.get_insert(keys, n, nullptr, idx, s));
+  c.head_bound += n;
+  hipLaunchKernelGGL(det_init_rows_kernel, dim3(grid_for(n * (size_t)c.dim, kBlock, 2048)),
+                     dim3(kBlock), 0, s, c.ht.new_positions, c.ht.d_new_count, idx, c.rows, c.dim,
+                     h->init_mode, h->init_val, h->seed + 0x9E3779B97F4A7C15ull * (cls_index + 1));
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const char* initializer,
+                    size_t initial_capacity_per_class, int key_type, uint64_t seed,
+                    hctr_det** out) {
+  HCTR_REQUIRE(out && dimension_per_class && num_classes > 0, "null pointer / no classes");
+  HCTR_REQUIRE(key_type == HCTR_KEY_U32 || key_type == HCTR_KEY_I64, "key_type");
+  hctr_det* h = new hctr_det();
+  h->key_type = key_type;
+  h->seed = seed;
+  // dynamic_embedding_table.cu:66-84: "ones", "zeros", a float literal, anything else = random
+  const std::string ini = initializer ? initializer : "";
+  h->init_mode = 1;
+  if (ini == "ones") {
+    h->init_mode = 0;
+    h->init_val = 1.0f;
+  } else if (ini == "zeros") {
+    h->init_mode = 0;
+    h->init_val = 0.0f;
+  } else if (!ini.empty()) {
+    char* end = nullptr;
+    const float v = strtof(ini.c_str(), &end);
+    if (end != ini.c_str()) {
+      h->init_mode = 0;
+      h->init_val = v;
+    }
+  }
+  const size_t cap = initial_capacity_per_class ? initial_capacity_per_class : 1048576;
+  h->cls.resize(num_classes);
+  for (size_t i = 0; i < num_classes; i++) {
+    if (dimension_per_class[i] == 0 || dimension_per_class[i] > (1u << 20)) {
+      set_error("dimension_per_class out of range");
+      for (size_t j = 0; j < i; j++) class_destroy(h->cls[j]);
+      delete h;
+      return HCTR_ERR_INVALID_ARG;
+    }
+    const int rc = class_create(h->cls[i], cap, (int)dimension_per_class[i], key_type);
+    if (rc != HCTR_OK) {
+      for (size_t j = 0; j <= i; j++) class_destroy(h->cls[j]);
+      delete h;
+      return rc;
+    }
+  }
+  (void)hipDeviceSynchronize();
+  *out = h;
+  return HCTR_OK;
+}
+
+int hctr_det_destroy(hctr_det* h) {
+  if (!h) return HCTR_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& c : h->cls) class_destroy(c);
+  if (h->idx) (void)hipFree(h->idx);
+  if (h->idx2) (void)hipFree(h->idx2);
+  delete h;
+  return HCTR_OK;
+}
+
+int hctr_det_lookup(hctr_det* h, const void* keys, float* elements, size_t num_keys,
+                    const size_t* id_spaces, const size_t* id_space_offsets, size_t num_id_spaces,
+                    hctr_stream_t stream) {
+  HCTR_REQUIRE(h, "null handle");
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && elements, "null pointer");
+  hipStream_t s = as_stream(stream);
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  HCTR_TRY(det_scratch(h, num_keys));
+  size_t out_off = 0;
+  for (const Range& r : rs) {
+    DetClass& c = h->cls[r.cls];
+    if (r.n == 0) continue;
+    HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
+    hipLaunchKernelGGL(det_gather_kernel, dim3(grid_for(r.n * (size_t)c.dim, kBlock, 4096)),
+                       dim3(kBlock), 0, s, h->idx, r.n, c.rows, c.dim, elements + out_off);
+    HCTR_LAUNCH_CHECK();
+    out_off += r.n * (size_t)c.dim;
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size_t num_keys,
+                           const size_t* id_spaces, const size_t* id_space_offsets,
+                           size_t num_id_spaces, hctr_stream_t stream) {
+  HCTR_REQUIRE(h, "null handle");
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && elements, "null pointer");
+  hipStream_t s = as_stream(stream);
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  HCTR_TRY(det_scratch(h, num_keys));
+  // two passes: every insertion (and so every re-allocation) happens before a pointer is taken
+  for (const Range& r : rs)
+    if (r.n) HCTR_TRY(class_reserve(h->cls[r.cls], r.n, h->key_type, s));
+  for (const Range& r : rs) {
+    DetClass& c = h->cls[r.cls];
+    if (r.n == 0) continue;
+    HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
+    hipLaunchKernelGGL(det_ptr_kernel, dim3(grid_for(r.n, kBlock, 1024)), dim3(kBlock), 0, s,
+                       h->idx, r.n, c.rows, c.dim, elements + r.off);
+    HCTR_LAUNCH_CHECK();
+  }
+  return HCTR_OK;
+}
+
+static int det_scatter(hctr_det* h, const void* keys, const float* elements, size_t num_keys,
+                       const size_t* id_spaces, const size_t* id_space_offsets,
+                       size_t num_id_spaces, bool add, hipStream_t s) {
+  HCTR_REQUIRE(h, "null handle");
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && elements, "null pointer");
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  HCTR_TRY(det_scratch(h, num_keys));
+  size_t off = 0;
+  for (const Range& r : rs) {
+    DetClass& c = h->cls[r.cls];
+    if (r.n == 0) continue;
+    HCTR_TRY(c.ht.get_mark(key_at(h, keys, r.off), r.n, nullptr, h->idx, s));
+    const dim3 grid(grid_for(r.n * (size_t)c.dim, kBlock, 4096));
+    if (add)
+      hipLaunchKernelGGL(det_scatter_kernel<true>, grid, dim3(kBlock), 0, s, h->idx, r.n, c.rows,
+                         c.dim, elements + off);
+    else
+      hipLaunchKernelGGL(det_scatter_kernel<false>, grid, dim3(kBlock), 0, s, h->idx, r.n, c.rows,
+                         c.dim, elements + off);
+    HCTR_LAUNCH_CHECK();
+    off += r.n * (size_t)c.dim;
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_scatter_add(hctr_det* h, const void* keys, const float* elements, size_t num_keys,
+                         const size_t* id_spaces, const size_t* id_space_offsets,
+                         size_t num_id_spaces, hctr_stream_t stream) {
+  return det_scatter(h, keys, elements, num_keys, id_spaces, id_space_offsets, num_id_spaces, true,
+                     as_stream(stream));
+}
+
+int hctr_det_scatter_update(hctr_det* h, const void* keys, const float* elements, size_t num_keys,
+                            const size_t* id_spaces, const size_t* id_space_offsets,
+                            size_t num_id_spaces, hctr_stream_t stream) {
+  return det_scatter(h, keys, elements, num_keys, id_spaces, id_space_offsets, num_id_spaces,
+                     false, as_stream(stream));
+}
+
+int hctr_det_remove(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
+                    const size_t* id_space_offsets, size_t num_id_spaces, hctr_stream_t stream) {
+  HCTR_REQUIRE(h, "null handle");
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys, "null pointer");
+  hipStream_t s = as_stream(stream);
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  for (const Range& r : rs) {
+    DetClass& c = h->cls[r.cls];
+    if (r.n == 0) continue;
+    const dim3 grid(grid_for(r.n, kBlock, 2048));
+    if (h->key_type == HCTR_KEY_U32)
+      hipLaunchKernelGGL(det_erase_kernel<uint32_t>, grid, dim3(kBlock), 0, s, c.ht.entries,
+                         c.ht.size, (const uint32_t*)key_at(h, keys, r.off), r.n,
+                         KeyTraits<uint32_t>::empty - 1, c.d_erased);
+    else
+      hipLaunchKernelGGL(det_erase_kernel<long long>, grid, dim3(kBlock), 0, s, c.ht.entries,
+                         c.ht.size, (const long long*)key_at(h, keys, r.off), r.n,
+                         KeyTraits<long long>::empty - 1, c.d_erased);
+    HCTR_LAUNCH_CHECK();
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, size_t num_keys,
+                    size_t* exported, hctr_stream_t stream) {
+  HCTR_REQUIRE(h && class_index < h->cls.size(), "class_index");
+  hipStream_t s = as_stream(stream);
+  DetClass& c = h->cls[class_index];
+  int64_t* d_keys = nullptr;
+  uint64_t* d_vals = nullptr;
+  const size_t slots = (size_t)c.ht.size;
+  HCTR_HIP(hipMalloc(&d_keys, slots * sizeof(int64_t)));
+  HCTR_HIP(hipMalloc(&d_vals, slots * sizeof(uint64_t)));
+  size_t live = 0;
+  int rc = c.ht.dump(d_keys, d_vals, &live, s);
+  if (rc == HCTR_OK) {
+    const size_t n = live < num_keys ? live : num_keys;
+    if (exported) *exported = n;
+    if (n > 0) {
+      HCTR_REQUIRE(keys && values, "null pointer");
+      if (h->key_type == HCTR_KEY_U32) {
+        std::vector<int64_t> hk(n);
+        std::vector<uint32_t> hk32(n);
+        (void)hipMemcpy(hk.data(), d_keys, n * sizeof(int64_t), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n; i++) hk32[i] = (uint32_t)hk[i];
+        (void)hipMemcpy(keys, hk32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+      } else {
+        (void)hipMemcpyAsync(keys, d_keys, n * sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+      }
+      hipLaunchKernelGGL(det_gather_kernel, dim3(grid_for(n * (size_t)c.dim, kBlock, 4096)),
+                         dim3(kBlock), 0, s, d_vals, n, c.rows, c.dim, values);
+      (void)hipStreamSynchronize(s);
+    }
+  }
+  (void)hipFree(d_keys);
+  (void)hipFree(d_vals);
+  return rc;
+}
+
+int hctr_det_clear(hctr_det* h, hctr_stream_t stream) {
+  HCTR_REQUIRE(h, "null handle");
+  hipStream_t s = as_stream(stream);
+  for (auto& c : h->cls) {
+    HCTR_TRY(c.ht.clear(s));
+    HCTR_HIP(hipMemsetAsync(c.d_erased, 0, sizeof(unsigned long long), s));
+    c.head_bound = 0;
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream) {
+  HCTR_REQUIRE(h && sizes, "null pointer");
+  hipStream_t s = as_stream(stream);
+  for (size_t i = 0; i < h->cls.size(); i++) {
+    size_t head = 0;
+    HCTR_TRY(h->cls[i].ht.value_head(s, &head));
+    unsigned long long er = 0;
+    HCTR_HIP(hipMemcpy(&er, h->cls[i].d_erased, sizeof(er), hipMemcpyDeviceToHost));
+    h->cls[i].head_bound = head;
+    sizes[i] = head - (size_t)er;
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_capacity_per_class(const hctr_det* h, size_t* caps) {
+  HCTR_REQUIRE(h && caps, "null pointer");
+  for (size_t i = 0; i < h->cls.size(); i++) caps[i] = h->cls[i].cap;
+  return HCTR_OK;
+}
+
+size_t hctr_det_num_classes(const hctr_det* h) { return h ? h->cls.size() : 0; }
+
+int hctr_det_update(hctr_det* weights, hctr_det* states, const hctr_det_opt_params* p,
+                    const void* unique_keys, size_t num_unique_keys, const size_t* id_spaces,
+                    const size_t* id_space_offsets, size_t num_id_spaces,
+                    const uint32_t* ev_start_indices, const float* wgrad, hctr_stream_t stream) {
+  HCTR_REQUIRE(weights && p, "null pointer");
+  if (num_unique_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(unique_keys && ev_start_indices && wgrad, "null pointer");
+  const int opt = p->optimizer;
+  HCTR_REQUIRE(opt == HCTR_OPT_SGD || opt == HCTR_OPT_ADAM || opt == HCTR_OPT_ADAGRAD ||
+                   opt == HCTR_OPT_MOMENTUM_SGD || opt == HCTR_OPT_NESTEROV ||
+                   opt == HCTR_OPT_RMSPROP || opt == HCTR_OPT_FTRL,
+               "optimizer");
+  const bool needs_state = opt != HCTR_OPT_SGD;
+  HCTR_REQUIRE(!needs_state || states, "this optimizer needs a state table");
+  hipStream_t s = as_stream(stream);
+  hctr_det* h = weights;
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_unique_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  HCTR_TRY(det_scratch(h, num_unique_keys));
+  DetOpt o{};
+  o.optimizer = opt;
+  o.lr = p->lr;
+  o.beta1 = p->beta1;
+  o.beta2 = p->beta2;
+  o.epsilon = p->epsilon;
+  o.momentum = p->momentum_factor;
+  o.scaler = p->scaler;
+  o.rms_beta = p->rmsprop_beta;
+  o.lambda1 = p->ftrl_lambda1;
+  o.lambda2_plus_beta_div_lr = p->ftrl_lambda2 + p->ftrl_beta / p->lr;
+  if (opt == HCTR_OPT_ADAM) {
+    // ++adam.times; lr * adam.bias()  (dynamic_embedding.cu:239-240, optimizer.hpp:58-60)
+    const uint64_t t = ++weights->adam_times;
+    o.lr_scaled_bias = p->lr * (float)(std::sqrt(1.0 - std::pow((double)p->beta2, (double)t)) /
+                                       (1.0 - std::pow((double)p->beta1, (double)t)));
+  }
+  const int smul = (opt == HCTR_OPT_ADAM || opt == HCTR_OPT_FTRL) ? 2 : 1;
+  for (const Range& r : rs) {
+    if (r.n == 0) continue;
+    DetClass& cw = h->cls[r.cls];
+    const void* kp = key_at(h, unique_keys, r.off);
+    float* rows_s = nullptr;
+    if (needs_state) {
+      HCTR_REQUIRE(r.cls < states->cls.size() && states->cls[r.cls].dim == cw.dim * smul,
+                   "state table: dimension must be ev_size * num_parameters_per_weight");
+      DetClass& cs = states->cls[r.cls];
+      HCTR_TRY(class_lookup_insert(states, cs, r.cls, kp, r.n, h->idx2, s));
+      rows_s = cs.rows;
+    }
+    if (opt == HCTR_OPT_FTRL)  // the reference looks the weights up (inserting) for Ftrl
+      HCTR_TRY(class_lookup_insert(h, cw, r.cls, kp, r.n, h->idx, s));
+    else
+      HCTR_TRY(cw.ht.get_mark(kp, r.n, nullptr, h->idx, s));
+    hipLaunchKernelGGL(det_update_kernel, dim3(grid_for(r.n * (size_t)cw.dim, kBlock, 4096)),
+                       dim3(kBlock), 0, s, o, r.n, cw.dim, h->idx, needs_state ? h->idx2 : nullptr,
+                       cw.rows, rows_s, ev_start_indices + r.off, wgrad);
+    HCTR_LAUNCH_CHECK();
+  }
+  return HCTR_OK;
+}
+
+}  // extern "C"

@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int r = 0; r < kHtTile / kBlock; r++) {
       uint64_t i = tile * (uint64_t)kHtTile + r * kBlock + threadIdx.x;
-      if (i < size) c += (tab[i].key != empty) ? 1u : 0u;
+      // erased entries (dynamic tables) keep a tombstone key with an invalid value
+      if (i < size) c += (tab[i].key != empty && tab[i].val != kInvalidIndex) ? 1u : 0u;
     }
     uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
     if (threadIdx.x == 0) tile_sums[tile] = tot;
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(kBlock)
       bool f = false;
       if (i < size) {
         e = tab[i];
-        f = e.key != empty;
+        f = e.key != empty && e.val != kInvalidIndex;
       }
       uint32_t tot;
       uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);

@@ -259,6 +259,66 @@ int hctr_cross_v1_bwd(size_t batch, int width, int layers, const float* x0, cons
                       hctr_stream_t stream);
 size_t hctr_cross_v1_bwd_workspace_bytes(size_t batch, int width, int layers);
 
+/* ---- dynamic embedding table (EBC "dynamic" tables / SOK DynamicVariable backend) -------------
+ * det::DynamicEmbeddingTable<Key, float>
+ * (R/third_party/dynamic_embedding_table/dynamic_embedding_table.hpp:25-66): num_classes maps key ->
+ * fp32 vector of dimension_per_class[c]; maps grow on demand.  Keys of one call are grouped by id
+ * space: id_spaces[i] (class index) owns keys[id_space_offsets[i] .. id_space_offsets[i+1]) -- both
+ * arrays live on the HOST, as in the reference; keys / elements are device pointers.  elements of
+ * consecutive keys are packed back to back with each key's own dimension.
+ * initializer: "ones" | "zeros" | a float literal | anything else (also "") = uniform (0, 1]
+ * (dynamic_embedding_table.cu:66-84; the reference seeds curand from std::random_device, here the
+ * value is a pure function of (seed, class, row, element)). */
+typedef struct hctr_det hctr_det;
+int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const char* initializer,
+                    size_t initial_capacity_per_class, int key_type, uint64_t seed,
+                    hctr_det** out);
+int hctr_det_destroy(hctr_det* h);
+size_t hctr_det_num_classes(const hctr_det* h);
+/* lookup: unseen keys are inserted and initialised, then all vectors are copied out */
+int hctr_det_lookup(hctr_det* h, const void* keys, float* elements, size_t num_keys,
+                    const size_t* id_spaces, const size_t* id_space_offsets, size_t num_id_spaces,
+                    hctr_stream_t stream);
+/* lookup_unsafe: device pointers to the stored vectors (valid until the next inserting call) */
+int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size_t num_keys,
+                           const size_t* id_spaces, const size_t* id_space_offsets,
+                           size_t num_id_spaces, hctr_stream_t stream);
+/* scatter_add / scatter_update: keys that are not in the table are skipped
+ * (cuco/detail/dynamic_map_kernels.cuh:143-183) */
+int hctr_det_scatter_add(hctr_det* h, const void* keys, const float* elements, size_t num_keys,
+                         const size_t* id_spaces, const size_t* id_space_offsets,
+                         size_t num_id_spaces, hctr_stream_t stream);
+int hctr_det_scatter_update(hctr_det* h, const void* keys, const float* elements, size_t num_keys,
+                            const size_t* id_spaces, const size_t* id_space_offsets,
+                            size_t num_id_spaces, hctr_stream_t stream);
+int hctr_det_remove(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
+                    const size_t* id_space_offsets, size_t num_id_spaces, hctr_stream_t stream);
+/* eXport: up to num_keys (key, vector) pairs of one class; *exported = how many (host sync) */
+int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, size_t num_keys,
+                    size_t* exported, hctr_stream_t stream);
+int hctr_det_clear(hctr_det* h, hctr_stream_t stream);
+int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream); /* host sync */
+int hctr_det_capacity_per_class(const hctr_det* h, size_t* capacities);
+
+/* embedding::DynamicEmbeddingTable::update (R/HugeCTR/embedding_storage/dynamic_embedding.cu:176-330,
+ * optimizers.cuh:29-233): optimizer step on the unique keys of a batch.  wgrad holds the summed
+ * gradient of key k at [ev_start_indices[k], +dim) (device, uint32 offsets).  `states` is a second
+ * table whose class dimensions are dim * {1: momentum/nesterov/adagrad/rmsprop, 2: adam (m|v),
+ * ftrl (n|z)} created with initializer "zeros"; NULL for SGD.  The Adam step counter lives in
+ * `weights` and is incremented by every Adam call, as the reference does. */
+typedef struct {
+  int optimizer; /* hctr_optimizer_t */
+  float lr, beta1, beta2, epsilon; /* adam; adagrad / rmsprop use epsilon */
+  float momentum_factor;           /* momentum: factor, nesterov: mu */
+  float rmsprop_beta;
+  float ftrl_lambda1, ftrl_lambda2, ftrl_beta;
+  float scaler;
+} hctr_det_opt_params;
+int hctr_det_update(hctr_det* weights, hctr_det* states, const hctr_det_opt_params* p,
+                    const void* unique_keys, size_t num_unique_keys, const size_t* id_spaces,
+                    const size_t* id_space_offsets, size_t num_id_spaces,
+                    const uint32_t* ev_start_indices, const float* wgrad, hctr_stream_t stream);
+
 /* MLP helper around the path (MLPLayer bprop, R/HugeCTR/src/layers/mlp_layer.cu): fused
  * dz = dy * (y > 0) and db[n] = sum_rows dz (deterministic two-stage column sum); 16-bit tensors
  * [rows][n], n % 8 == 0; workspace >= hctr_relu_bwd_bias_workspace_bytes. */
