@@ -63,6 +63,8 @@ _SIGNATURES = {
     "hctr_ht_table_size": (c_size_t, [_P]),
     "hctr_ht_dump": (c_int, [_P, _P, _P, POINTER(c_size_t), _P]),
     "hctr_forward_pool": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_forward_pool_weighted": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "hctr_expand_key_grads": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P]),
     "hctr_forward_pool_multihot": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
     "hctr_forward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_backward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
@@ -111,6 +113,8 @@ _SIGNATURES = {
     "hctr_det_scatter_update": (c_int, [_P, _P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
     "hctr_det_remove": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, _P]),
     "hctr_det_export": (c_int, [_P, c_size_t, _P, _P, c_size_t, _SZP, _P]),
+    "hctr_det_lookup_index": (c_int, [_P, c_size_t, _P, c_size_t, c_int, _P, _P]),
+    "hctr_det_rows": (c_int, [_P, c_size_t, POINTER(_P), _SZP]),
     "hctr_det_clear": (c_int, [_P, _P]),
     "hctr_det_size_per_class": (c_int, [_P, _SZP, _P]),
     "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),

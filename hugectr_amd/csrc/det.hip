@@ -555,6 +555,23 @@ int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, 
   return rc;
 }
 
+int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, size_t num_keys,
+                          int insert, uint64_t* row_index, hctr_stream_t stream) {
+  HCTR_REQUIRE(h && class_index < h->cls.size(), "class_index");
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && row_index, "null pointer");
+  DetClass& c = h->cls[class_index];
+  if (insert) return class_lookup_insert(h, c, class_index, keys, num_keys, row_index, as_stream(stream));
+  return c.ht.get_mark(keys, num_keys, nullptr, row_index, as_stream(stream));
+}
+
+int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacity) {
+  HCTR_REQUIRE(h && class_index < h->cls.size() && rows, "class_index");
+  *rows = h->cls[class_index].rows;
+  if (capacity) *capacity = h->cls[class_index].cap;
+  return HCTR_OK;
+}
+
 int hctr_det_clear(hctr_det* h, hctr_stream_t stream) {
   HCTR_REQUIRE(h, "null handle");
   hipStream_t s = as_stream(stream);

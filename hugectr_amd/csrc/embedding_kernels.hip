@@ -250,6 +250,58 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- weighted pooling (SOK lookup_sparse with sp_weights, R/sparse_operation_kit/.../lookup.py
+//      :425-541): out[b] = sum_j w_j * row_j, mean divides by sum_j w_j; without weights w = 1 and
+//      mean divides by the key count.  One wavefront per bucket, lanes stride over the vector.
+__global__ void __launch_bounds__(kBlock)
+    pool_weighted_kernel(size_t buckets, int D, int combiner, const long long* __restrict__ ro,
+                         const uint64_t* __restrict__ value_index,
+                         const float* __restrict__ weights, const float* __restrict__ table,
+                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = ro[u];
+    const int n = (int)(ro[u + 1] - off);
+    float denom = 0.f;
+    for (int j = 0; j < n; j++) denom += weights ? weights[off + j] : 1.0f;
+    for (int v = lane; v < D; v += 64) {
+      float sum = 0.0f;
+      for (int j = 0; j < n; j++) {
+        const uint64_t idx = value_index[off + j];
+        const float w = weights ? weights[off + j] : 1.0f;
+        if (idx != kInvalidIndex) sum += w * table[idx * (uint64_t)D + v];
+      }
+      out[u * (size_t)D + v] = (combiner == 1 && n > 0) ? sum / denom : sum;
+    }
+  }
+}
+
+// gradient of the pooled vector w.r.t. every looked-up row: g_j = top[b] * w_j (/ denom for mean)
+__global__ void __launch_bounds__(kBlock)
+    expand_key_grads_kernel(size_t buckets, int D, int combiner, const long long* __restrict__ ro,
+                            const float* __restrict__ weights, const float* __restrict__ top,
+                            float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = ro[u];
+    const int n = (int)(ro[u + 1] - off);
+    float denom = 1.0f;
+    if (combiner == 1) {
+      denom = 0.f;
+      for (int j = 0; j < n; j++) denom += weights ? weights[off + j] : 1.0f;
+    }
+    for (int j = 0; j < n; j++) {
+      const float sc = (weights ? weights[off + j] : 1.0f) / denom;
+      for (int v = lane; v < D; v += 64)
+        out[(size_t)(off + j) * D + v] = top[u * (size_t)D + v] * sc;
+    }
+  }
+}
+
 template <typename OffT, typename OutT>
 int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint64_t* vi,
                 const float* table, OutT* out, bool multi_hot, hipStream_t s) {
@@ -395,6 +447,34 @@ int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* ro
   HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
   return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
                                table, out, out_dtype, false, as_stream(stream));
+}
+
+int hctr_forward_pool_weighted(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                               const uint64_t* value_index, const float* weights,
+                               const float* table, float* out, hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  if (buckets == 0) return HCTR_OK;
+  HCTR_REQUIRE(row_offset && value_index && table && out, "null pointer");
+  hipLaunchKernelGGL(pool_weighted_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
+                     dim3(kBlock), 0, as_stream(stream), buckets, vec_size, combiner,
+                     (const long long*)row_offset, value_index, weights, table, out);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_expand_key_grads(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                          const float* weights, const float* top_grad, float* key_grads,
+                          hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  if (buckets == 0) return HCTR_OK;
+  HCTR_REQUIRE(row_offset && top_grad && key_grads, "null pointer");
+  hipLaunchKernelGGL(expand_key_grads_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
+                     dim3(kBlock), 0, as_stream(stream), buckets, vec_size, combiner,
+                     (const long long*)row_offset, weights, top_grad, key_grads);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
 }
 
 int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,

@@ -84,6 +84,16 @@ int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* 
 int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* row_offset,
                       int key_type, const uint64_t* value_index, const float* table, void* out,
                       int out_dtype, hctr_stream_t stream);
+/* SOK lookup_sparse with sp_weights (R/sparse_operation_kit/sparse_operation_kit/lookup.py:425-541):
+ * out[b] = sum_j w_j * table[value_index[j]] (weights NULL: w = 1); combiner 1 divides by sum_j w_j.
+ * int64 row_offset, fp32 out.  hctr_expand_key_grads is its backward: key_grads[j] =
+ * top_grad[bucket(j)] * w_j (/ sum w for mean), one row per key. */
+int hctr_forward_pool_weighted(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                               const uint64_t* value_index, const float* weights,
+                               const float* table, float* out, hctr_stream_t stream);
+int hctr_expand_key_grads(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                          const float* weights, const float* top_grad, float* key_grads,
+                          hctr_stream_t stream);
 /* same contract; walks each lane group's keys as one flat range (8 row reads in flight whatever the
  * bucket lengths): the kernel of choice for multi-hot buckets. */
 int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,
@@ -296,6 +306,12 @@ int hctr_det_remove(hctr_det* h, const void* keys, size_t num_keys, const size_t
 /* eXport: up to num_keys (key, vector) pairs of one class; *exported = how many (host sync) */
 int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, size_t num_keys,
                     size_t* exported, hctr_stream_t stream);
+/* row indices of keys in one class's row store (insert != 0: unseen keys are inserted and
+ * initialised; else unseen -> SIZE_MAX) and the store itself ([capacity][dim] fp32; the pointer
+ * changes when the table grows): lets the path's gather / update kernels run on dynamic tables */
+int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, size_t num_keys,
+                          int insert, uint64_t* row_index, hctr_stream_t stream);
+int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacity);
 int hctr_det_clear(hctr_det* h, hctr_stream_t stream);
 int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream); /* host sync */
 int hctr_det_capacity_per_class(const hctr_det* h, size_t* capacities);
