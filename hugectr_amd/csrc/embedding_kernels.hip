@@ -56,6 +56,24 @@ struct Store4<__hip_bfloat16> {
   }
 };
 
+// Mean of a 16-bit output, even embedding_vec_size (forward_mean_align2_kernel,
+// forward_per_gpu_functor.cu:136-176): the fp32 sum and the scaler are BOTH rounded to the output
+// type and multiplied there (__hmul2).  The product of two 11-bit (8-bit) significands is exact in
+// fp32, so rounding it once on the store reproduces the half multiply.  fp32 output and the generic
+// (odd size) kernel multiply in fp32 (forward_mean_kernel :98-131).  bf16 follows the fp16 rule.
+template <typename OutT>
+__device__ __forceinline__ float mean_product(float sum, float sc) {
+  return sum * sc;
+}
+template <>
+__device__ __forceinline__ float mean_product<__half>(float sum, float sc) {
+  return __half2float(__float2half_rn(sum)) * __half2float(__float2half_rn(sc));
+}
+template <>
+__device__ __forceinline__ float mean_product<__hip_bfloat16>(float sum, float sc) {
+  return __bfloat162float(__float2bfloat16(sum)) * __bfloat162float(__float2bfloat16(sc));
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }
@@ -116,10 +134,10 @@ __global__ void __launch_bounds__(kBlock)
         float4 v = acc[k];
         if (combiner == 1 && n[k] > 1) {
           const float sc = 1.0f / (float)n[k];
-          v.x *= sc;
-          v.y *= sc;
-          v.z *= sc;
-          v.w *= sc;
+          v.x = mean_product<OutT>(v.x, sc);
+          v.y = mean_product<OutT>(v.y, sc);
+          v.z = mean_product<OutT>(v.z, sc);
+          v.w = mean_product<OutT>(v.w, sc);
         }
         Store4<OutT>::st(out + u * (size_t)D + l * 4, v);
       }
@@ -183,10 +201,10 @@ __global__ void __launch_bounds__(kBlock)
               float4 v = acc;
               if (combiner == 1 && cnt > 1) {
                 const float sc = 1.0f / (float)cnt;
-                v.x *= sc;
-                v.y *= sc;
-                v.z *= sc;
-                v.w *= sc;
+                v.x = mean_product<OutT>(v.x, sc);
+                v.y = mean_product<OutT>(v.y, sc);
+                v.z = mean_product<OutT>(v.z, sc);
+                v.w = mean_product<OutT>(v.w, sc);
               }
               Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
             }
@@ -208,10 +226,10 @@ __global__ void __launch_bounds__(kBlock)
       float4 v = acc;
       if (combiner == 1 && cnt > 1) {
         const float sc = 1.0f / (float)cnt;
-        v.x *= sc;
-        v.y *= sc;
-        v.z *= sc;
-        v.w *= sc;
+        v.x = mean_product<OutT>(v.x, sc);
+        v.y = mean_product<OutT>(v.y, sc);
+        v.z = mean_product<OutT>(v.z, sc);
+        v.w = mean_product<OutT>(v.w, sc);
       }
       Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
     }
@@ -245,7 +263,9 @@ __global__ void __launch_bounds__(kBlock)
         const uint64_t idx = value_index[off + j];
         sum += (idx != kInvalidIndex) ? table[idx * (uint64_t)D + v] : 0.0f;
       }
-      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? sum * sc : sum);
+      // even sizes take the reference's align2 rule also here (e.g. D = 6, 10)
+      const float m = (D % 2 == 0) ? mean_product<OutT>(sum, sc) : sum * sc;
+      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? m : sum);
     }
   }
 }

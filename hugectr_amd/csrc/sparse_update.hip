@@ -363,7 +363,9 @@ template <typename GradT>
 __device__ __forceinline__ float4 scaled_grad(typename Load4<GradT>::raw r, int combiner, int n) {
   float4 v = Load4<GradT>::cvt(r);
   if (combiner == 1) {
-    const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
+    // backward_mean_align2_kernel (backward_functor.cu:83-104): the scaler is rounded to the
+    // gradient type before the multiply; fp32 gradients: rnd() is the identity
+    const float sc = Load4<GradT>::rnd(n > 1 ? 1.0f / (float)n : 1.0f);
     v.x = Load4<GradT>::rnd(v.x * sc);
     v.y = Load4<GradT>::rnd(v.y * sc);
     v.z = Load4<GradT>::rnd(v.z * sc);
@@ -821,7 +823,10 @@ __global__ void __launch_bounds__(kBlock)
         float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
         if (combiner == 1) {
           long long n = (long long)row_offset[b + 1] - (long long)row_offset[b];
-          if (n > 1) gv = Load4<GradT>::rnd(gv * (1.0f / (float)n));
+          if (n > 1) {
+            const float sc = 1.0f / (float)n;  // even sizes: align2 rule (16-bit scaler)
+            gv = Load4<GradT>::rnd(gv * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc));
+          }
         }
         gi += gv;
       }
@@ -852,7 +857,8 @@ __global__ void __launch_bounds__(kBlock)
   for (size_t u = wave; u < buckets; u += nwaves) {
     const long long off = (long long)row_offset[u];
     const int n = (int)((long long)row_offset[u + 1] - off);
-    const float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    if (D % 2 == 0) sc = Load4<GradT>::rnd(sc);  // align2 rule (backward_functor.cu:83-104)
     for (int v = lane; v < D; v += 64) {
       float gv = Load4<GradT>::ld1(grad + u * (size_t)D + v);
       if (combiner == 1) gv = Load4<GradT>::rnd(gv * sc);
@@ -918,7 +924,10 @@ __global__ void __launch_bounds__(kBlock)
     float g = Load4<GradT>::ld1(top + i);
     if (combiner == 1) {
       long long n = (long long)row_offset[u + 1] - (long long)row_offset[u];
-      if (n > 1) g = g * (1.0f / (float)n);
+      if (n > 1) {
+        const float sc = 1.0f / (float)n;
+        g = g * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc);
+      }
     }
     if constexpr (std::is_same<GradT, float>::value) wgrad[i] = g;
     else if constexpr (std::is_same<GradT, __half>::value) wgrad[i] = __float2half_rn(g);

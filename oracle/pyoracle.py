@@ -342,3 +342,47 @@ def ebc_backward_update(batch, table_ids, ev, combiners, keys, bucket_range, tab
     lib().hco_ebc_backward_update(batch, len(table_ids), _p(t), ev, _p(c), _p(k), _p(br), _p(rs),
                                   tables.shape[0], num_gpus, 1 if batch_major else 0, _p(g),
                                   optimizer, lr, scaler, epsilon, _p(tables), _p(accum))
+
+
+# ---- mixed precision: the 16-bit embedding output / gradient modes -------------------
+def round_to(x, dtype: str):
+    """fp32 array rounded (nearest even) to "f16" / "bf16", returned as fp32; "f32" is the identity"""
+    x = np.asarray(x, dtype=np.float32)
+    if dtype == "f32":
+        return x.copy()
+    if dtype == "f16":
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16  # round-to-nearest-even on the top 16 bits
+    return r.astype(np.uint32).view(np.float32)
+
+
+def forward_mixed(row_offset, value_index, table, D, combiner, dtype: str):
+    """forward with a 16-bit output.  sum: convert(fp32 sum) (forward_sum_kernel).  mean, even D:
+    forward_mean_align2_kernel (forward_per_gpu_functor.cu:136-176) = hmul2(half(sum), half(1/n));
+    mean, odd D: forward_mean_kernel :98-131 = convert(sum * (1/n)) in fp32."""
+    ro = np.asarray(row_offset, dtype=np.int64)
+    s = forward(ro, value_index, table, D, 0)  # fp32 sums in key order
+    if combiner == 0 or dtype == "f32":
+        if combiner == 1:
+            return forward(ro, value_index, table, D, 1)
+        return round_to(s, dtype)
+    n = (ro[1:] - ro[:-1]).astype(np.float32)
+    sc = np.where(n > 1, np.float32(1.0) / np.maximum(n, 1), np.float32(1.0)).astype(np.float32)
+    if D % 2 == 0:
+        return round_to(round_to(s, dtype) * round_to(sc, dtype)[:, None], dtype)
+    return round_to(s * sc[:, None], dtype)
+
+
+def backward_mixed(row_offset, top_grad, D, combiner, dtype: str):
+    """wgrad in the gradient's own 16-bit type: backward_mean_align2_kernel (backward_functor.cu:83-104)
+    multiplies by half(1/n) in half precision for even D, backward_mean_kernel :57-80 in fp32 else."""
+    ro = np.asarray(row_offset, dtype=np.int64)
+    g = round_to(top_grad, dtype).reshape(-1, D)
+    if combiner == 0:
+        return g
+    n = (ro[1:] - ro[:-1]).astype(np.float32)
+    sc = np.where(n > 1, np.float32(1.0) / np.maximum(n, 1), np.float32(1.0)).astype(np.float32)
+    if dtype != "f32" and D % 2 == 0:
+        sc = round_to(sc, dtype)
+    return round_to(g * sc[:, None], dtype)

@@ -346,3 +346,45 @@ def test_stateless_pool_kernels_agree_bit_exact(oracle, D, combiner):
         outs.append(out.cpu().numpy())
         assert (outs[-1].view(np.uint32) == want.view(np.uint32)).all()
     assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("D,combiner,one_hot", [(16, 1, False), (128, 0, True), (128, 1, False),
+                                                (11, 1, False), (6, 1, False)])
+def test_mixed_precision_forward_wgrad_update(oracle, dtype, D, combiner, one_hot):
+    """16-bit pooled vectors and top gradients (the reference's use_mixed_precision mode, fp16;
+    bf16 is the same rule with bf16): forward and wgrad BIT-exact against the restated align2 /
+    generic kernels (half-precision multiply by half(1/n) for even sizes), table after
+    the update at rel 1e-5 (fp32 accumulation of the 16-bit wgrads in ascending bucket order)."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    rng = np.random.default_rng(D * 3 + combiner + (dtype == "f16"))
+    B, S, hot, vps = 64, 5, 6, 30
+    V = S * vps
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.1, scaler=2.0, atomic_update=False)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S * hot, S, combiner, opt,
+                                 out_dtype=tdt)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    ht = oracle.HashTable(V, 8)
+    for it in range(2):
+        ro, keys = make_csr(rng, B, S, hot, vps, one_hot=one_hot)
+        out = emb.forward(True, _t(torch, ro), _t(torch, keys))
+        assert out.dtype == tdt
+        vi = ht.get_insert(keys)
+        want = oracle.forward_mixed(ro, vi, table, D, combiner, dtype)
+        got = out.float().cpu().numpy().reshape(-1, D)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"forward {dtype} it{it}"
+        g = (rng.standard_normal((B * S, D)) * 3).astype(np.float32)
+        gt = _t(torch, g).to(tdt).view(B, S, D).contiguous()
+        emb.backward(gt)
+        wg = emb.get_wgrad().float().cpu().numpy().reshape(-1, D)
+        want_wg = oracle.backward_mixed(ro, g, D, combiner, dtype)
+        assert (wg.view(np.uint32) == want_wg.view(np.uint32)).all(), f"wgrad {dtype} it{it}"
+        emb.update_params()
+        torch.cuda.synchronize()
+        oracle.update_params(ro, vi, want_wg, _oracle_opt(oracle, opt, it + 1), table)
+        assert_close(emb.table().cpu().numpy(), table, 1e-5, 1e-6, f"table {dtype} it{it}")
