@@ -299,23 +299,24 @@ def main():
                         works[k].wait()
                     E = (ha.forward_reorder(recvs[k], Bc, S, D, world) if world > 1
                          else recvs[k].view(Bc, S, D))
-                    return E.detach().requires_grad_(True)
+                    sent["E"] = E.detach().requires_grad_(True)
+                    return sent["E"]
 
                 def on_E_grad(g, k=k):
-                    # runs inside backward, right after the interaction's backward kernel
-                    if top_grad is not None:
-                        gsend = (ha.backward_reorder(g.contiguous(), Bc, S, D, world) if world > 1
-                                 else g.reshape(-1))
-                        sent["w"] = exch.backward_async(
-                            gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
-                        sent["buf"] = gsend
-                    else:
-                        sent["g"] = g
+                    # runs inside backward, right after the interaction's backward kernel.  The
+                    # hook must not keep `g` alive: autograd then steals it for E.grad instead of
+                    # cloning 436 MB
+                    gsend = (ha.backward_reorder(g.contiguous(), Bc, S, D, world) if world > 1
+                             else g.reshape(-1))
+                    sent["w"] = exch.backward_async(
+                        gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
+                    sent["buf"] = gsend if world > 1 else None
 
                 loss = dense_chunk(dense[k * Bc:(k + 1) * Bc], label[k * Bc:(k + 1) * Bc], None,
-                                   get_E=get_E, on_E_grad=on_E_grad)
+                                   get_E=get_E,
+                                   on_E_grad=on_E_grad if top_grad is not None else None)
                 if top_grad is None:
-                    tg = sent["g"]
+                    tg = sent["E"].grad
                 else:
                     back.append((sent["w"], sent["buf"]))
                 total = loss.clone() if total is None else total + loss
