@@ -120,6 +120,16 @@ _SIGNATURES = {
     "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),
     "hctr_det_update": (c_int, [_P, _P, POINTER(DetOptParams), _P, c_size_t, _SZP, _SZP, c_size_t,
                                 _P, _P, _P]),
+    "hctr_uniq_create": (c_int, [c_size_t, POINTER(_P)]),
+    "hctr_uniq_destroy": (c_int, [_P]),
+    "hctr_uniq_plan": (c_int, [_P, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, _P,
+                               c_uint64, _P, _P, _P, _P]),
+    "hctr_uniq_gather_rows": (c_int, [c_size_t, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_uniq_expand": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,
+                                              c_size_t, _P, _P]),
+    "hctr_emb_index": (c_int, [_P, c_int, _P, _P, c_size_t, _P]),
+    "hctr_emb_update_rows": (c_int, [_P, c_size_t, _P, _P, _P, c_int, _P]),
     "hctr_relu_bwd_bias_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_relu_bwd_bias": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_sum_groups": (c_int, [c_int, c_size_t, _P, c_int, _P, _P]),

@@ -387,4 +387,34 @@ int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64
                         table, state0, state1, nullptr, as_stream(stream));
 }
 
+int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buckets,
+                                  const int64_t* row_offset, const uint32_t* sorted_rows,
+                                  const uint32_t* sorted_buckets, const void* grad, int grad_dtype,
+                                  size_t n_rows, float* out_sum, hctr_stream_t stream) {
+  HCTR_REQUIRE(u, "null handle");
+  if (n_rows == 0) return HCTR_OK;
+  HCTR_REQUIRE(out_sum, "null pointer");
+  hipStream_t s = as_stream(stream);
+  HCTR_HIP(hipMemsetAsync(out_sum, 0, n_rows * (size_t)u->impl.D * sizeof(float), s));
+  if (positions == 0) return HCTR_OK;
+  HCTR_REQUIRE(row_offset && sorted_rows && sorted_buckets && grad, "null pointer");
+  HCTR_REQUIRE(positions <= u->impl.max_nnz, "positions exceed the updater's capacity");
+  // out_sum[row] += sum of grad[bucket] over the row's run: the segmented reduce of the sparse
+  // update with "SGD, lr = -1" on a zeroed table
+  OptState o;
+  o.optimizer = HCTR_OPT_SGD;
+  o.update_type = HCTR_UPDATE_LOCAL;
+  o.lr = -1.0f;
+  o.scaler = 1.0f;
+  o.atomic_update = 0;
+  o.times = 1;
+  u->impl.ext_rows = sorted_rows;
+  u->impl.ext_buckets = sorted_buckets;
+  const int rc = u->impl.update(buckets, positions, 0, row_offset, HCTR_KEY_I64, nullptr, grad,
+                                grad_dtype, o, out_sum, nullptr, nullptr, nullptr, s);
+  u->impl.ext_rows = nullptr;
+  u->impl.ext_buckets = nullptr;
+  return rc;
+}
+
 }  // extern "C"

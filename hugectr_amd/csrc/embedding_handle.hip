@@ -364,6 +364,15 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     }
     e->prof.end(1, s);
   }
+  if (out == nullptr) {  // hctr_emb_index: resolve rows only (unique-row exchange)
+    if (is_train) {
+      e->cur_buckets = buckets;
+      e->cur_nnz_bound = nnz;
+      e->has_train_batch = true;
+      e->nnz_pending = false;
+    }
+    return HCTR_OK;
+  }
   e->prof.begin(0, s);
   // more keys than buckets in the full-batch CSR (host numbers) -> the flat multi-hot walk
   const size_t full_buckets = batch * (size_t)e->p.slot_num;
@@ -576,6 +585,36 @@ int hctr_emb_forward(hctr_embedding* e, int is_train, const void* row_offset, co
                                    (const uint32_t*)keys, nnz, out, s);
   return forward_typed<long long>(e, is_train, (const long long*)row_offset,
                                   (const long long*)keys, nnz, out, s);
+}
+
+int hctr_emb_index(hctr_embedding* e, int is_train, const void* row_offset, const void* keys,
+                   size_t nnz, hctr_stream_t stream) {
+  HCTR_REQUIRE(e, "null handle");
+  HCTR_REQUIRE(row_offset, "null pointer");
+  HCTR_REQUIRE(nnz == 0 || keys, "keys is null");
+  HCTR_REQUIRE(nnz <= (is_train ? e->p.train_batch_size : e->p.evaluate_batch_size) *
+                          (e->p.max_feature_num ? e->p.max_feature_num : 1),
+               "nnz exceeds batch_size * max_feature_num");
+  hipStream_t s = as_stream(stream);
+  if (e->p.key_type == HCTR_KEY_U32)
+    return forward_typed<uint32_t>(e, is_train, (const uint32_t*)row_offset,
+                                   (const uint32_t*)keys, nnz, nullptr, s);
+  return forward_typed<long long>(e, is_train, (const long long*)row_offset,
+                                  (const long long*)keys, nnz, nullptr, s);
+}
+
+int hctr_emb_update_rows(hctr_embedding* e, size_t n, const int64_t* row_offset,
+                         const uint64_t* rows, const void* grad, int grad_dtype,
+                         hctr_stream_t stream) {
+  HCTR_REQUIRE(e, "null handle");
+  if (n == 0) {
+    e->opt.times++;
+    return HCTR_OK;
+  }
+  HCTR_REQUIRE(row_offset && rows && grad, "null pointer");
+  e->opt.times++;
+  return e->upd.update(n, n, 0, row_offset, HCTR_KEY_I64, rows, grad, grad_dtype, e->opt, e->table,
+                       e->state0, e->state1, e->prev_time, as_stream(stream));
 }
 
 int hctr_emb_backward(hctr_embedding* e, const void* top_grad, hctr_stream_t stream) {

@@ -43,6 +43,9 @@ struct SparseUpdater {
   // it on a side stream while the caller's stream does the gather and the dense tower
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_sorted = nullptr;
+  // presorted mode: the caller supplies the sorted (row, bucket) list (unique-row exchange)
+  const uint32_t* ext_rows = nullptr;
+  const uint32_t* ext_buckets = nullptr;
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;

@@ -1006,7 +1006,14 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
 
   if (nnz > 0) {
     SortK* kout = (SortK*)u.sort_keys_out;
-    if (u.early_n >= nnz && u.early_vi == vi && u.early_buckets == buckets) {
+    const uint32_t* vout = u.sort_vals_out;
+    if (u.ext_rows != nullptr) {
+      // presorted by the caller: only the long-run counters need a reset
+      static_assert(sizeof(SortK) == 4, "presorted lists carry 32-bit rows");
+      kout = (SortK*)const_cast<uint32_t*>(u.ext_rows);
+      vout = u.ext_buckets;
+      HCTR_HIP(hipMemsetAsync(u.span_count, 0, 2 * sizeof(uint32_t), s));
+    } else if (u.early_n >= nnz && u.early_vi == vi && u.early_buckets == buckets) {
       // (row, bucket) pairs of this batch were sorted on the side stream right after the index
       // stage (SparseUpdater::presort); padding keys sit behind the live ones
       HCTR_HIP(hipStreamWaitEvent(s, u.ev_sorted, 0));
@@ -1024,7 +1031,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     const size_t seg_tiles = ceil_div<size_t>(nnz, (size_t)kSegTile);                             \
     hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT>),                             \
                        dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,  \
-                       kout, u.sort_vals_out, combiner, grad, u.gsum, u.seg_head, u.seg_tail,     \
+                       kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail,                \
                        u.span_list, u.span_count);                                                \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                     \
@@ -1070,7 +1077,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       HCTR_LAUNCH_CHECK();
       hipLaunchKernelGGL((update_rows_generic_kernel<OffT, SortK, GradT>),
                          dim3(grid_for(nnz * 64, kBlock)), dim3(kBlock), 0, s, u.d_num_runs,
-                         u.run_start, kout, u.sort_vals_out, ro, combiner, D, grad, o, table,
+                         u.run_start, kout, vout, ro, combiner, D, grad, o, table,
                          state0, state1, (unsigned long long*)prev_time);
     }
     HCTR_LAUNCH_CHECK();

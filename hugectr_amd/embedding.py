@@ -121,6 +121,22 @@ class SparseEmbeddingHash:
                                    ptr(out), stream_ptr()))
         return out
 
+    def index(self, is_train: bool, row_offset: torch.Tensor, keys: torch.Tensor,
+              nnz: Optional[int] = None):
+        """index stage only (filter + hash): rows in value_index(); no gather"""
+        if nnz is None:
+            nnz = int(keys.numel())
+        check(lib.hctr_emb_index(self._h, 1 if is_train else 0, ptr(row_offset), ptr(keys), nnz,
+                                 stream_ptr()))
+
+    def update_rows(self, rows: torch.Tensor, grads: torch.Tensor, row_offset: torch.Tensor):
+        """sparse optimizer on (row, gradient) entries: entry i updates rows[i] with grads[i]
+        (entries naming the same row are summed in entry order); row_offset = arange(n + 1)"""
+        n = rows.numel()
+        assert grads.is_contiguous() and row_offset.dtype == torch.int64
+        check(lib.hctr_emb_update_rows(self._h, n, ptr(row_offset), ptr(rows), ptr(grads),
+                                       _TORCH_TO_EMB[grads.dtype], stream_ptr()))
+
     def backward(self, top_grad: torch.Tensor):
         assert top_grad.is_cuda and top_grad.is_contiguous() and top_grad.dtype == self.out_dtype
         self._top_grad = top_grad

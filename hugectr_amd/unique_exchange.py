@@ -1,0 +1,149 @@
+"""Unique-row form of the localized embedding exchange (multi-GPU, one key per bucket).
+
+`LocalizedExchange` moves one pooled vector per (sample, slot) each way, as the reference does
+(R/HugeCTR/src/embeddings/all2all_forward_functor.cu:157-264).  With one-hot buckets the pooled
+vector is the table row itself, and power-law keys repeat rows heavily, so this exchange ships every
+distinct row ONCE per destination GPU plus an 8-byte (index, bucket) pair per position, and returns
+per-row gradient SUMS (fp32) instead of per-sample gradients: the payload that crosses xGMI drops
+by the duplication factor of the batch (~7x on the Criteo-1TB shape at alpha = 1.1), and the owner's
+sparse update sees one entry per distinct row and peer instead of one per sample.
+
+    owner r:  index stage -> hctr_uniq_plan (sort by (peer, row), runs, distinct rows) ->
+              counts all-gather + one host sync (the variable all-to-all needs host-side sizes) ->
+              gather distinct rows -> all-to-all(meta, fixed size), all-to-all(rows, variable)
+    receiver: hctr_uniq_expand -> E [B/N, S, D]   ... dense tower ...
+              dE -> hctr_updater_reduce_presorted (per-row sums over the sorted list) ->
+              all-to-all(sums, variable)
+    owner r:  hctr_emb_update_rows on (row, sum) entries
+
+Summation order differs from the per-sample exchange (gradients of one row are first added per
+destination GPU, then across GPUs), so results agree to fp32 rounding, not bit for bit.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .parallel import slots_on_rank
+
+_EMB_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _staged() -> bool:
+    """gloo cannot move device tensors through all_to_all: stage through the host (tests only)"""
+    return dist.get_backend() == "gloo"
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int], group):
+    if _staged():
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def _all_gather(out: torch.Tensor, inp: torch.Tensor, group):
+    if _staged():
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
+class UniqueExchange:
+    def __init__(self, emb, batch_per_gpu: int, slot_num: int, vec: int, group=None):
+        self.emb, self.group = emb, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bl, self.S, self.D = batch_per_gpu, slot_num, vec
+        self.dtype = emb.out_dtype
+        self.s_r = slots_on_rank(slot_num, self.rank, self.world)
+        self.P = self.world * batch_per_gpu * self.s_r      # positions this rank owns
+        self.ppp = batch_per_gpu * self.s_r                  # ... per destination GPU
+        self.Q = batch_per_gpu * slot_num                    # positions this rank receives
+        dev = emb.device
+        assert (vec * torch.empty(0, dtype=self.dtype).element_size()) % 16 == 0
+        self._h = ctypes.c_void_p()
+        check(lib.hctr_uniq_create(max(self.P, 1), ctypes.byref(self._h)))
+        self._upd = ctypes.c_void_p()
+        check(lib.hctr_updater_create(self.Q, self.Q, vec, ctypes.byref(self._upd)))
+        i32, i64 = torch.int32, torch.int64
+        self.meta = torch.empty((max(self.P, 1), 2), dtype=i32, device=dev)
+        self.urow = torch.empty(max(self.P, 1), dtype=i64, device=dev)
+        self.peer_off = torch.zeros(self.world + 1, dtype=i64, device=dev)
+        self.rows_send = torch.empty((max(self.P, 1), vec), dtype=self.dtype, device=dev)
+        self.meta_recv = torch.empty((self.Q, 2), dtype=i32, device=dev)
+        self.rows_recv = torch.empty((self.Q, vec), dtype=self.dtype, device=dev)
+        self.sorted_rows = torch.empty(self.Q, dtype=i32, device=dev)
+        self.sorted_buckets = torch.empty(self.Q, dtype=i32, device=dev)
+        self.sums = torch.empty((self.Q, vec), dtype=torch.float32, device=dev)
+        self.grads_back = torch.empty((max(self.P, 1), vec), dtype=torch.float32, device=dev)
+        self.arange = torch.arange(max(self.P, self.Q) + 1, dtype=i64, device=dev)
+        self.counts = torch.empty((self.world, self.world), dtype=i64, device=dev)
+        s_of = [slots_on_rank(slot_num, j, self.world) for j in range(self.world)]
+        self.meta_send_splits = [self.ppp * 2] * self.world
+        self.meta_recv_splits = [batch_per_gpu * s * 2 for s in s_of]
+        q = [0]
+        for s in s_of:
+            q.append(q[-1] + batch_per_gpu * s)
+        self.q_off = torch.tensor(q, dtype=i64, device=dev)
+        self.u_send: Optional[List[int]] = None
+        self.u_recv: Optional[List[int]] = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.hctr_uniq_destroy(self._h)
+            lib.hctr_updater_destroy(self._upd)
+            self._h = None
+
+    def forward(self, row_offset: torch.Tensor, keys: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """full-batch one-hot CSR -> E [batch_per_gpu, slot_num, D] of this rank's samples"""
+        emb, W, D = self.emb, self.world, self.D
+        emb.index(True, row_offset, keys)
+        if self.P > 0:
+            vi = emb.value_index(self.P)
+            check(lib.hctr_uniq_plan(self._h, self.P, self.ppp, self.bl, self.s_r, self.S,
+                                     self.rank, W, ptr(vi), emb.get_max_vocabulary_size(),
+                                     ptr(self.meta), ptr(self.urow), ptr(self.peer_off),
+                                     stream_ptr()))
+        mine = (self.peer_off[1:] - self.peer_off[:-1]).contiguous()
+        _all_gather(self.counts.view(-1), mine, self.group)
+        c = self.counts.cpu()                       # the step's one host sync
+        self.u_send = [int(x) for x in c[self.rank]]
+        self.u_recv = [int(x) for x in c[:, self.rank]]
+        n_send, n_recv = sum(self.u_send), sum(self.u_recv)
+        check(lib.hctr_uniq_gather_rows(n_send, D, ptr(self.urow), lib.hctr_emb_table_ptr(emb._h),
+                                        ptr(self.rows_send), _EMB_DT[self.dtype], stream_ptr()))
+        _a2a(self.meta_recv.view(-1), self.meta.view(-1)[:self.P * 2], self.meta_recv_splits,
+             self.meta_send_splits, self.group)
+        _a2a(self.rows_recv.view(-1)[:n_recv * D], self.rows_send.view(-1)[:n_send * D],
+             [u * D for u in self.u_recv], [u * D for u in self.u_send], self.group)
+        r_off = torch.zeros(W + 1, dtype=torch.int64, device=emb.device)
+        torch.cumsum(self.counts[:, self.rank], 0, out=r_off[1:])
+        if out is None:
+            out = torch.empty((self.bl, self.S, D), dtype=self.dtype, device=emb.device)
+        check(lib.hctr_uniq_expand(self.Q, W, ptr(self.q_off), ptr(r_off), ptr(self.meta_recv),
+                                   ptr(self.rows_recv), D, _EMB_DT[self.dtype], ptr(out),
+                                   ptr(self.sorted_rows), ptr(self.sorted_buckets), stream_ptr()))
+        return out
+
+    def backward_and_update(self, grad: torch.Tensor):
+        """dE [batch_per_gpu, slot_num, D] -> per-row sums -> owners -> sparse optimizer"""
+        D = self.D
+        n_send, n_recv = sum(self.u_send), sum(self.u_recv)
+        grad = grad.contiguous()
+        check(lib.hctr_updater_reduce_presorted(
+            self._upd, self.Q, self.Q, ptr(self.arange), ptr(self.sorted_rows),
+            ptr(self.sorted_buckets), ptr(grad), _EMB_DT[grad.dtype], n_recv, ptr(self.sums),
+            stream_ptr()))
+        _a2a(self.grads_back.view(-1)[:n_send * D], self.sums.view(-1)[:n_recv * D],
+             [u * D for u in self.u_send], [u * D for u in self.u_recv], self.group)
+        self.emb.update_rows(self.urow[:n_send], self.grads_back[:n_send], self.arange[:n_send + 1])

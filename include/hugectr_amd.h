@@ -246,6 +246,44 @@ int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64
                         float momentum_factor, float scaler, uint64_t times, float* table,
                         float* state0, float* state1, hctr_stream_t stream);
 
+/* ---- unique-row exchange (multi-GPU, one key per bucket): ship every distinct row once per
+ * destination GPU + an (index, bucket) pair per position, return per-row gradient sums instead of
+ * per-sample gradients.  Replaces the payload of all2all_forward / all2all_backward
+ * (R/HugeCTR/src/embeddings/all2all_forward_functor.cu:157-264) when keys repeat; the collective
+ * itself stays the caller's.  See hugectr_amd/parallel.py:UniqueExchange for the call order. */
+typedef struct hctr_uniq hctr_uniq;
+int hctr_uniq_create(size_t max_positions, hctr_uniq** out);
+int hctr_uniq_destroy(hctr_uniq* u);
+/* owner: value_index[positions] rows of the pooled layout [world][batch_per_gpu][slots_local] ->
+ * meta[positions][2] = (unique index inside the peer segment, bucket b_local * slots_total +
+ * s_global on the receiver), sorted by row inside each peer segment; urow = distinct rows,
+ * peer-major; peer_off[world + 1] (device) = offsets of the peers' segments in urow */
+int hctr_uniq_plan(hctr_uniq* u, size_t positions, size_t positions_per_peer, int batch_per_gpu,
+                   int slots_local, int slots_total, int rank, int world,
+                   const uint64_t* value_index, uint64_t max_rows, uint32_t* meta, uint64_t* urow,
+                   int64_t* peer_off, hctr_stream_t stream);
+int hctr_uniq_gather_rows(size_t n_rows, int vec_size, const uint64_t* urow, const float* table,
+                          void* out, int out_dtype, hctr_stream_t stream);
+/* receiver: out[bucket] = rows[r_off[owner] + index]; owner j holds positions [q_off[j], q_off[j+1])
+ * (device int64 arrays); also emits the globally numbered sorted (row, bucket) list for
+ * hctr_updater_reduce_presorted */
+int hctr_uniq_expand(size_t positions, int n_owners, const int64_t* q_off, const int64_t* r_off,
+                     const uint32_t* meta, const void* rows, int vec_size, int dtype, void* out,
+                     uint32_t* sorted_rows, uint32_t* sorted_buckets, hctr_stream_t stream);
+/* receiver backward: out_sum[row] = sum over the row's run of grad[bucket] (ascending position,
+ * fp32), row_offset = int64 [buckets + 1] with row_offset[buckets] == positions */
+int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buckets,
+                                  const int64_t* row_offset, const uint32_t* sorted_rows,
+                                  const uint32_t* sorted_buckets, const void* grad, int grad_dtype,
+                                  size_t n_rows, float* out_sum, hctr_stream_t stream);
+/* owner: index stage only (hctr_emb_forward without the gather), and the sparse update driven by
+ * (row, gradient) entries: entry i updates rows[i] with grad[i][:] (row_offset = arange(n + 1)) */
+int hctr_emb_index(hctr_embedding* emb, int is_train, const void* row_offset, const void* keys,
+                   size_t nnz, hctr_stream_t stream);
+int hctr_emb_update_rows(hctr_embedding* emb, size_t n, const int64_t* row_offset,
+                         const uint64_t* rows, const void* grad, int grad_dtype,
+                         hctr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* Dense ops on the path                                                                       */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,91 @@
+"""Unique-row exchange (hugectr_amd/unique_exchange.py) against the per-sample exchange of the
+reference layout, 2 ranks (gloo, both on this one GPU): identical E bit for bit, tables after the
+sparse update equal to fp32 rounding, over several power-law batches with new keys arriving."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, dtype_name, opt_name, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import hugectr_amd as ha
+        from hugectr_amd import _lib
+        from hugectr_amd.parallel import LocalizedExchange, slots_on_rank
+        from hugectr_amd.unique_exchange import UniqueExchange
+        dt = getattr(torch, dtype_name)
+        Bl, S, D = 96, 5, 64
+        B = Bl * world
+        sizes = [7, 300, 3, 5000, 41]
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        kw = dict(optimizer=_lib.OPT_SGD, lr=0.05, atomic_update=False) if opt_name == "sgd" else \
+            dict(optimizer=_lib.OPT_ADAGRAD, lr=0.05, epsilon=1e-6)
+        mk = lambda: ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, sum(sizes), D, S, S, 0,
+                                            ha.OptParams(**kw), slot_size_array=sizes,
+                                            out_dtype=dt, rank=rank, world=world, seed=5)
+        emb_u, emb_d = mk(), mk()
+        emb_u.init_params()
+        emb_d.init_params()
+        assert torch.equal(emb_u.table(), emb_d.table())
+        ux = UniqueExchange(emb_u, Bl, S, D)
+        dx = LocalizedExchange(B, S, D)
+        s_r = slots_on_rank(S, rank, world)
+        ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
+        rng = np.random.default_rng(17)   # same keys on every rank (full-batch CSR)
+        for step in range(4):
+            keys = np.stack([(rng.zipf(1.3, size=B) - 1) % v + o for v, o in zip(sizes, offs)],
+                            axis=1).reshape(-1).astype(np.int64)
+            kt = torch.from_numpy(keys).cuda()
+            E = ux.forward(ro, kt)
+            pooled = emb_d.forward(True, ro, kt)
+            recv = dx.forward(pooled.cpu()).cuda()
+            E_ref = ha.forward_reorder(recv, Bl, S, D, world)
+            if step == 0:   # same tables: the expanded rows are the same bits
+                assert torch.equal(E, E_ref), "E differs at step 0"
+            else:           # tables have diverged by fp32 rounding (different summation order)
+                assert torch.allclose(E.float(), E_ref.float(), rtol=1e-2 if dt != torch.float32
+                                      else 1e-4, atol=1e-5), f"E differs at step {step}"
+            g = torch.from_numpy(rng.standard_normal((world, Bl, S, D)).astype(np.float32))[rank]
+            g = g.cuda().to(dt)
+            ux.backward_and_update(g)
+            gsend = ha.backward_reorder(g, Bl, S, D, world)
+            top = dx.backward(gsend.cpu()).cuda().view(B, s_r, D)
+            emb_d.backward(top.contiguous())
+            emb_d.update_params()
+            tu, td = emb_u.table(), emb_d.table()
+            err = (tu - td).abs().max().item()
+            assert err <= 2e-5 * td.abs().max().item() + 1e-6, (step, err)
+            assert emb_u.get_vocabulary_size() == emb_d.get_vocabulary_size()
+        # the exchange really shipped fewer rows than positions
+        assert sum(ux.u_send) < ux.P / 2
+        ret[rank] = "ok"
+    except Exception as e:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype_name,opt_name", [("bfloat16", "sgd"), ("float32", "adagrad")])
+def test_unique_exchange_matches_per_sample_exchange(dtype_name, opt_name):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 23000 + os.getpid() % 4000 + (7 if opt_name == "sgd" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, opt_name, ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for r in range(2):
+        if ret.get(r) != "ok":
+            print(f"--- rank {r} ---\n{ret.get(r)}")
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
