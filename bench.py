@@ -113,6 +113,12 @@ def main():
                          "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
                          "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
                          "is what the overlap could save at N = 8, so no split is the default")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique"],
+                    help="multi-GPU payload of the embedding exchange: rows = one pooled vector / "
+                         "gradient per (sample, slot) as the reference; unique = every distinct row "
+                         "once per destination + per-row gradient sums "
+                         "(hugectr_amd/unique_exchange.py); auto = time both during warm-up and "
+                         "keep the faster one")
     ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--table-scale", type=float, default=1.0)
@@ -139,15 +145,23 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
+            # functional check of the N > 1 orchestration with all ranks on ONE GPU (collectives
+            # staged through the host); never used for measurements
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import hugectr_amd as ha
     from hugectr_amd import _lib
     from hugectr_amd.parallel import LocalizedExchange
+    from hugectr_amd.parallel import all_reduce as par_all_reduce
 
     sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
     S, D = len(sizes), a.dim
@@ -172,6 +186,11 @@ def main():
                                  seed=1234)
     emb.init_params()
     exch = LocalizedExchange(Bsub, S, D)
+    ux = None
+    if world > 1 and C == 1 and a.exchange != "rows":
+        from hugectr_amd.unique_exchange import UniqueExchange
+        ux = UniqueExchange(emb, Bl, S, D)
+    mode = {"name": "unique" if (ux is not None and a.exchange == "unique") else "rows"}
 
     # ---- synthetic data, resident in HBM before the timed region ---------------------------------
     rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
@@ -267,7 +286,42 @@ def main():
             graph = None
             dense_opt.zero_grad(set_to_none=True)
 
+    def finish_step():
+        if world > 1:
+            grads = [p.grad for p in dense_params]
+            flat = torch.cat([x.reshape(-1) for x in grads])
+            par_all_reduce(flat)
+            flat /= world
+            off = 0
+            for x in grads:
+                x.copy_(flat[off:off + x.numel()].view_as(x))
+                off += x.numel()
+
+    def step_unique(i):
+        """same step with the unique-row exchange: the counts' host sync sits behind the bottom
+        MLP's launches, the gradient sums leave from inside backward"""
+        keys = key_batches[i % a.nbatches]
+        ux.forward_begin(ro, keys)
+        sent = {}
+
+        def get_E():
+            sent["E"] = ux.forward_finish().detach().requires_grad_(True)
+            return sent["E"]
+
+        loss = dense_chunk(dense_batches[i % a.nbatches], label_batches[i % a.nbatches], None,
+                           get_E=get_E, on_E_grad=ux.backward_begin)
+        finish_step()
+        ux.backward_finish()
+        dense_opt.step()
+        dense_opt.zero_grad(set_to_none=True)
+        if amp:
+            bottom.refresh_shadow()
+            top.refresh_shadow()
+        return loss
+
     def step(i):
+        if mode["name"] == "unique":
+            return step_unique(i)
         keys = key_batches[i % a.nbatches]
         dense = dense_batches[i % a.nbatches]
         label = label_batches[i % a.nbatches]
@@ -331,15 +385,7 @@ def main():
         for w, _ in back:
             if w is not None:
                 w.wait()
-        if world > 1:
-            grads = [p.grad for p in dense_params]
-            flat = torch.cat([x.reshape(-1) for x in grads])
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for x in grads:
-                x.copy_(flat[off:off + x.numel()].view_as(x))
-                off += x.numel()
+        finish_step()
         emb.backward(tg)
         emb.update_params()
         dense_opt.step()
@@ -352,6 +398,35 @@ def main():
             top.refresh_shadow()
         return total
 
+    emb.profiling(True)
+    if ux is not None and a.exchange == "auto":
+        # measure, don't guess: a few steps of each payload during warm-up, keep the faster one
+        # (the decision is taken on the max over ranks, so every rank takes the same one)
+        timing = {}
+        for name in ("rows", "unique"):
+            mode["name"] = name
+            try:
+                for i in range(2):
+                    step(i)
+            except Exception as e:  # e.g. keys x peers beyond the 32-bit sort key: same on every rank
+                if rank == 0:
+                    print(f"[bench] exchange '{name}' unavailable: {e!r}", file=sys.stderr)
+                timing[name] = float("inf")
+                continue
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(2, 5):
+                step(i)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            if dist.get_backend() != "gloo":
+                t = t.to(dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            timing[name] = float(t.item()) / 3
+        mode["name"] = min(timing, key=timing.get)
+        mode["timing_ms"] = {k: v * 1e3 for k, v in timing.items()}
+    pool_prof = emb.profile().get("gather_pool", (0.0, 0))
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -383,7 +458,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            t = t.to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = emb.profile()
@@ -394,6 +471,8 @@ def main():
     nnz_g = B * spr  # one-hot: one key per (sample, slot on this rank)
     alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz
     pool_ms, pool_n = prof["gather_pool"]
+    if pool_n == 0:  # unique-row exchange: the pool kernel only ran in the warm-up comparison
+        pool_ms, pool_n = pool_prof
     achieved = alg_bytes / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
     pmc = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_gather_pool.json")
@@ -415,14 +494,16 @@ def main():
         "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
         "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
                                "LocalizedSlotSparseEmbeddingHash, emb_dim=128, bs=65536 per GPU, SGD",
-                   "batch_per_gpu": Bl, "global_batch": B, "sub_batches_per_step": C, "dense_tower_hip_graph": graph is not None, "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
+                   "batch_per_gpu": Bl, "global_batch": B, "sub_batches_per_step": C, "dense_tower_hip_graph": graph is not None,
+                   "exchange": mode["name"] if world > 1 else "none (1 GPU)",
+                   "exchange_warmup_ms_per_step": mode.get("timing_ms"), "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
                    "table_rows_this_rank": my_rows, "parallelism": f"slot-sharded x{world} + dp{world}",
                    "final_loss": float(loss.detach()), "dense_gemm_selection": tuned},
         "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
-                     "avg_launch_us": stage_us["gather_pool"]},
+                     "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3},
         "stage_us_per_step": stage_us,
     }
     if rank == 0:

@@ -23,6 +23,30 @@ import torch
 import torch.distributed as dist
 
 
+def _staged(t: torch.Tensor) -> bool:
+    """gloo cannot run these collectives on device tensors: stage through the host.  Only the
+    2-ranks-on-one-GPU tests and `HCTR_BENCH_BACKEND=gloo` take this path; RCCL never does."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_to_all_single(out, inp, out_splits, in_splits, group=None, async_op=False):
+    if _staged(inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(o)
+        return None
+    return dist.all_to_all_single(out, inp, out_splits, in_splits, group=group, async_op=async_op)
+
+
+def all_reduce(t: torch.Tensor, group=None):
+    if _staged(t):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+
+
 def slots_on_rank(slot_num: int, rank: int, world: int) -> int:
     """R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:176-183"""
     return slot_num // world + (1 if rank < slot_num % world else 0)
@@ -55,8 +79,7 @@ class LocalizedExchange:
         if self.world == 1:
             return flat
         out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
-        dist.all_to_all_single(out, flat, output_split_sizes=self.recv, input_split_sizes=self.send,
-                               group=self.group)
+        all_to_all_single(out, flat, self.recv, self.send, group=self.group)
         return out
 
     # -- non-blocking forms: the collective runs on the communicator's stream while the caller
@@ -67,8 +90,7 @@ class LocalizedExchange:
         if self.world == 1:
             return flat, None
         out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
-        work = dist.all_to_all_single(out, flat, output_split_sizes=self.recv,
-                                      input_split_sizes=self.send, group=self.group, async_op=True)
+        work = all_to_all_single(out, flat, self.recv, self.send, group=self.group, async_op=True)
         return out, work
 
     def backward_async(self, grad_send: torch.Tensor, out: torch.Tensor):
@@ -78,8 +100,7 @@ class LocalizedExchange:
         if self.world == 1:
             out.copy_(flat)
             return None
-        return dist.all_to_all_single(out, flat, output_split_sizes=self.send,
-                                      input_split_sizes=self.recv, group=self.group, async_op=True)
+        return all_to_all_single(out, flat, self.send, self.recv, group=self.group, async_op=True)
 
     def backward(self, grad_send: torch.Tensor) -> torch.Tensor:
         """grad_send: backward_reorder output [sum_j (B/N) S_j D] -> [B, S_r, D] top gradients"""
@@ -89,8 +110,7 @@ class LocalizedExchange:
         if self.world == 1:
             return flat.view(self.batch, s_r, self.vec)
         out = torch.empty(sum(self.send), dtype=grad_send.dtype, device=grad_send.device)
-        dist.all_to_all_single(out, flat, output_split_sizes=self.send, input_split_sizes=self.recv,
-                               group=self.group)
+        all_to_all_single(out, flat, self.send, self.recv, group=self.group)
         return out.view(self.batch, s_r, self.vec)
 
 

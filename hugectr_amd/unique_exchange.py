@@ -96,6 +96,7 @@ class UniqueExchange:
         self.q_off = torch.tensor(q, dtype=i64, device=dev)
         self.u_send: Optional[List[int]] = None
         self.u_recv: Optional[List[int]] = None
+        self._work = None
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -103,10 +104,11 @@ class UniqueExchange:
             lib.hctr_updater_destroy(self._upd)
             self._h = None
 
-    def forward(self, row_offset: torch.Tensor, keys: torch.Tensor,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """full-batch one-hot CSR -> E [batch_per_gpu, slot_num, D] of this rank's samples"""
-        emb, W, D = self.emb, self.world, self.D
+    # -- forward: begin() enqueues everything up to the counts all-gather; finish() does the one
+    #    host sync and the rest.  Work the caller enqueues in between (the bottom MLP) keeps the
+    #    GPU busy while the host waits for the counts. -------------------------------------------
+    def forward_begin(self, row_offset: torch.Tensor, keys: torch.Tensor):
+        emb, W = self.emb, self.world
         emb.index(True, row_offset, keys)
         if self.P > 0:
             vi = emb.value_index(self.P)
@@ -116,14 +118,18 @@ class UniqueExchange:
                                      stream_ptr()))
         mine = (self.peer_off[1:] - self.peer_off[:-1]).contiguous()
         _all_gather(self.counts.view(-1), mine, self.group)
+        # fixed-size part of the payload: (index, bucket) pairs
+        _a2a(self.meta_recv.view(-1), self.meta.view(-1)[:self.P * 2], self.meta_recv_splits,
+             self.meta_send_splits, self.group)
+
+    def forward_finish(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        emb, W, D = self.emb, self.world, self.D
         c = self.counts.cpu()                       # the step's one host sync
         self.u_send = [int(x) for x in c[self.rank]]
         self.u_recv = [int(x) for x in c[:, self.rank]]
         n_send, n_recv = sum(self.u_send), sum(self.u_recv)
         check(lib.hctr_uniq_gather_rows(n_send, D, ptr(self.urow), lib.hctr_emb_table_ptr(emb._h),
                                         ptr(self.rows_send), _EMB_DT[self.dtype], stream_ptr()))
-        _a2a(self.meta_recv.view(-1), self.meta.view(-1)[:self.P * 2], self.meta_recv_splits,
-             self.meta_send_splits, self.group)
         _a2a(self.rows_recv.view(-1)[:n_recv * D], self.rows_send.view(-1)[:n_send * D],
              [u * D for u in self.u_recv], [u * D for u in self.u_send], self.group)
         r_off = torch.zeros(W + 1, dtype=torch.int64, device=emb.device)
@@ -135,8 +141,15 @@ class UniqueExchange:
                                    ptr(self.sorted_rows), ptr(self.sorted_buckets), stream_ptr()))
         return out
 
-    def backward_and_update(self, grad: torch.Tensor):
-        """dE [batch_per_gpu, slot_num, D] -> per-row sums -> owners -> sparse optimizer"""
+    def forward(self, row_offset: torch.Tensor, keys: torch.Tensor,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """full-batch one-hot CSR -> E [batch_per_gpu, slot_num, D] of this rank's samples"""
+        self.forward_begin(row_offset, keys)
+        return self.forward_finish(out)
+
+    # -- backward: begin() may run inside autograd (as soon as dE exists); finish() applies the
+    #    sparse optimizer once the sums have arrived ------------------------------------------------
+    def backward_begin(self, grad: torch.Tensor):
         D = self.D
         n_send, n_recv = sum(self.u_send), sum(self.u_recv)
         grad = grad.contiguous()
@@ -144,6 +157,23 @@ class UniqueExchange:
             self._upd, self.Q, self.Q, ptr(self.arange), ptr(self.sorted_rows),
             ptr(self.sorted_buckets), ptr(grad), _EMB_DT[grad.dtype], n_recv, ptr(self.sums),
             stream_ptr()))
-        _a2a(self.grads_back.view(-1)[:n_send * D], self.sums.view(-1)[:n_recv * D],
-             [u * D for u in self.u_send], [u * D for u in self.u_recv], self.group)
+        out, inp = self.grads_back.view(-1)[:n_send * D], self.sums.view(-1)[:n_recv * D]
+        osz, isz = [u * D for u in self.u_send], [u * D for u in self.u_recv]
+        if _staged():
+            _a2a(out, inp, osz, isz, self.group)
+            self._work = None
+        else:
+            self._work = dist.all_to_all_single(out, inp, osz, isz, group=self.group,
+                                                async_op=True)
+
+    def backward_finish(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        n_send = sum(self.u_send)
         self.emb.update_rows(self.urow[:n_send], self.grads_back[:n_send], self.arange[:n_send + 1])
+
+    def backward_and_update(self, grad: torch.Tensor):
+        """dE [batch_per_gpu, slot_num, D] -> per-row sums -> owners -> sparse optimizer"""
+        self.backward_begin(grad)
+        self.backward_finish()
