@@ -72,25 +72,48 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// receiver: one 16-byte lane per 16 B of a row; also emits the globally numbered sorted list
+// receiver: a group of `row16` lanes (16 B each) copies one row; the owner of position q is found
+// against the (at most 64) segment starts held in registers; also emits the globally numbered
+// sorted (row, bucket) list for the backward reduce
+template <int ROW16>
 __global__ void __launch_bounds__(kBlock)
     uniq_expand_kernel(size_t Q, int n_owners, const long long* __restrict__ q_off,
                        const long long* __restrict__ r_off, const uint32_t* __restrict__ meta,
-                       const uint4* __restrict__ rows, int row16, uint4* __restrict__ out,
+                       const uint4* __restrict__ rows, uint4* __restrict__ out,
                        uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ sorted_buckets) {
-  const size_t total = Q * (size_t)row16;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * kBlock) {
-    const size_t q = i / row16;
-    const int c = (int)(i % row16);
-    int j = 0;
-    while (j + 1 < n_owners && (long long)q >= q_off[j + 1]) j++;
-    const uint32_t u = meta[2 * q] + (uint32_t)r_off[j];
-    const uint32_t bucket = meta[2 * q + 1];
-    out[(size_t)bucket * row16 + c] = rows[(size_t)u * row16 + c];
-    if (c == 0) {
-      sorted_rows[q] = u;
-      sorted_buckets[q] = bucket;
+  constexpr int GPB = kBlock / ROW16;
+  __shared__ long long s_q[65], s_r[65];
+  for (int i = threadIdx.x; i <= n_owners; i += kBlock) {
+    s_q[i] = q_off[i];
+    s_r[i] = r_off[i];
+  }
+  __syncthreads();
+  const int g = threadIdx.x / ROW16, c = threadIdx.x % ROW16;
+  constexpr int U = 4;  // positions in flight per group
+  for (size_t q0 = ((size_t)blockIdx.x * GPB + g) * U; q0 < Q;
+       q0 += (size_t)gridDim.x * GPB * U) {
+    uint32_t u[U], bkt[U];
+    uint4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      const size_t q = q0 + k < Q ? q0 + k : Q - 1;
+      const uint2 m = *reinterpret_cast<const uint2*>(meta + 2 * q);
+      int j = 0;
+      while (j + 1 < n_owners && (long long)q >= s_q[j + 1]) j++;
+      u[k] = m.x + (uint32_t)s_r[j];
+      bkt[k] = m.y;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) v[k] = rows[(size_t)u[k] * ROW16 + c];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      if (q0 + k < Q) {
+        out[(size_t)bkt[k] * ROW16 + c] = v[k];
+        if (c == 0) {
+          sorted_rows[q0 + k] = u[k];
+          sorted_buckets[q0 + k] = bkt[k];
+        }
+      }
     }
   }
 }
@@ -256,10 +279,28 @@ int hctr_uniq_expand(size_t positions, int n_owners, const int64_t* q_off, const
                    reinterpret_cast<uintptr_t>(out) % 16 == 0,
                "rows / out must be 16-byte aligned");
   const int row16 = (int)(row_bytes / 16);
-  hipLaunchKernelGGL(uniq_expand_kernel, dim3(grid_for(positions * (size_t)row16, kBlock, 8192)),
-                     dim3(kBlock), 0, as_stream(stream), positions, n_owners,
-                     (const long long*)q_off, (const long long*)r_off, meta, (const uint4*)rows,
-                     row16, (uint4*)out, sorted_rows, sorted_buckets);
+  HCTR_REQUIRE(n_owners >= 1 && n_owners <= 64, "1..64 owners");
+  hipStream_t s = as_stream(stream);
+#define HCTR_EXPAND_CASE(R16)                                                                     \
+  case R16:                                                                                       \
+    hipLaunchKernelGGL(uniq_expand_kernel<R16>,                                                   \
+                       dim3(grid_for(ceil_div<size_t>(positions, 4), kBlock / R16, 8192)),        \
+                       dim3(kBlock), 0, s, positions, n_owners, (const long long*)q_off,          \
+                       (const long long*)r_off, meta, (const uint4*)rows, (uint4*)out,            \
+                       sorted_rows, sorted_buckets);                                              \
+    break;
+  switch (row16) {
+    HCTR_EXPAND_CASE(1)
+    HCTR_EXPAND_CASE(2)
+    HCTR_EXPAND_CASE(4)
+    HCTR_EXPAND_CASE(8)
+    HCTR_EXPAND_CASE(16)
+    HCTR_EXPAND_CASE(32)
+    HCTR_EXPAND_CASE(64)
+    default:
+      HCTR_REQUIRE(false, "row size: 16 B x a power of two up to 1 KiB");
+  }
+#undef HCTR_EXPAND_CASE
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
