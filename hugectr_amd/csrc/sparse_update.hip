@@ -326,29 +326,6 @@ __device__ __forceinline__ void apply_row_vec4(const OptConst& o, uint64_t row, 
 //     head[t'].  seg_combine_kernel adds tail + heads in a fixed order (deterministic).
 constexpr int kSegTile = 32;
 
-template <typename GradT, int D>
-__device__ __forceinline__ float4 load_scaled_grad(const GradT* __restrict__ grad, uint32_t b,
-                                                   int l, int combiner, const void* row_offset_v,
-                                                   bool off_is_u32) {
-  float4 v = Load4<GradT>::ld(grad + (size_t)b * D + l * 4);
-  if (combiner == 1) {
-    long long n;
-    if (off_is_u32) {
-      const uint32_t* ro = (const uint32_t*)row_offset_v;
-      n = (long long)ro[b + 1] - (long long)ro[b];
-    } else {
-      const long long* ro = (const long long*)row_offset_v;
-      n = ro[b + 1] - ro[b];
-    }
-    const float sc = n > 1 ? 1.0f / (float)n : 1.0f;
-    v.x = Load4<GradT>::rnd(v.x * sc);
-    v.y = Load4<GradT>::rnd(v.y * sc);
-    v.z = Load4<GradT>::rnd(v.z * sc);
-    v.w = Load4<GradT>::rnd(v.w * sc);
-  }
-  return v;
-}
-
 // number of keys in bucket b (the mean combiner's divisor)
 __device__ __forceinline__ int bucket_len(const void* row_offset_v, bool off_is_u32, uint32_t b) {
   if (off_is_u32) {
