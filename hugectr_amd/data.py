@@ -313,6 +313,80 @@ class ParquetReader:
         return out
 
 
+# ---- Raw format (docs/source/api/python_interface.md "Raw"; R/HugeCTR/src/data_readers/multi_hot/) ---
+# one binary file, fixed-size samples: label[label_dim] dense[dense_dim] keys[sum of hotness], every
+# field 4 bytes: label/dense float32 (float_label_dense / is_dense_float) or int32/uint32 (dense is
+# then fed through log(x + 1)), keys uint32 with STATIC hotness per slot taken from the Input layer.
+def write_raw(path, label, dense, cats, float_label_dense=True):
+    """cats: [num_samples, sum_hotness] keys in slot-major order"""
+    n = label.shape[0]
+    ld = (np.asarray(label, np.float32) if float_label_dense else np.asarray(label, np.int32))
+    dd = (np.asarray(dense, np.float32) if float_label_dense else np.asarray(dense, np.uint32))
+    rec = np.concatenate([ld.view(np.uint32).reshape(n, -1), dd.view(np.uint32).reshape(n, -1),
+                          np.asarray(cats, np.uint32).reshape(n, -1)], axis=1)
+    rec.astype("<u4").tofile(path)
+
+
+class RawReader:
+    """DataReaderType_t.RawAsync: streams batches of a Raw file (np.memmap; the reference uses
+    Linux AIO worker threads -- I/O engines are outside the scope contract, the FORMAT is not)."""
+
+    def __init__(self, path: str, inp, slot_size_array, batch, rank, world, device, num_samples,
+                 float_label_dense: bool, repeat: bool):
+        self.inp, self.batch, self.rank, self.world, self.device = inp, batch, rank, world, device
+        self.float_ld, self.repeat = float_label_dense, repeat
+        self.hot = []  # static hotness per slot, over all sparse params
+        for p in inp.sparse_params:
+            h = p.nnz_per_slot
+            self.hot += list(h) if isinstance(h, (list, tuple)) else [int(h)] * p.slot_num
+        self.width = inp.label_dim + inp.dense_dim + sum(self.hot)
+        words = os.path.getsize(path) // 4
+        n = words // self.width
+        if num_samples:
+            n = min(n, int(num_samples))
+        if n < batch:
+            raise RuntimeError("raw file holds fewer samples than one batch")
+        self.data = np.memmap(path, dtype="<u4", mode="r", shape=(n, self.width))
+        self.n, self._pos = n, 0
+        ssa = list(slot_size_array)
+        self.slot_offsets = (np.concatenate([[0], np.cumsum(ssa)[:-1]]).astype(np.int64) if ssa
+                             else np.zeros(len(self.hot), np.int64))
+
+    def next_batch(self):
+        B = self.batch
+        if self._pos + B > self.n:  # incomplete tail dropped, as the reference does
+            if not self.repeat:
+                return None
+            self._pos = 0
+        blk = np.asarray(self.data[self._pos:self._pos + B])
+        self._pos += B
+        L, Dn = self.inp.label_dim, self.inp.dense_dim
+        bpg = B // self.world
+        sl = slice(self.rank * bpg, (self.rank + 1) * bpg)
+        if self.float_ld:
+            label = blk[:, :L].view(np.float32)
+            dense = blk[:, L:L + Dn].view(np.float32)
+        else:
+            label = blk[:, :L].view(np.int32).astype(np.float32)
+            dense = np.log(blk[:, L:L + Dn].astype(np.float32) + 1.0)
+        out = {"label": torch.from_numpy(np.ascontiguousarray(label[sl])).to(self.device),
+               "dense": torch.from_numpy(np.ascontiguousarray(dense[sl])).to(self.device),
+               "sparse": {}}
+        col, s0 = L + Dn, 0
+        for p in self.inp.sparse_params:
+            hot = self.hot[s0:s0 + p.slot_num]
+            w = sum(hot)
+            keys = blk[:, col:col + w].astype(np.int64)
+            offs = np.repeat(self.slot_offsets[s0:s0 + p.slot_num], hot)
+            keys = (keys + offs[None, :]).reshape(-1)
+            ro = np.concatenate([[0], np.cumsum(np.tile(hot, B))]).astype(np.int64)
+            col += w
+            s0 += p.slot_num
+            out["sparse"][p.top_name] = (torch.from_numpy(ro).to(self.device),
+                                         torch.from_numpy(keys).to(self.device))
+        return out
+
+
 class _Readers:
     def __init__(self, train, evalr):
         self.train, self.evalr = train, evalr
@@ -327,6 +401,14 @@ class _Readers:
 
 def make_reader(rp, inp, solver, rank, world, device):
     fmt = getattr(rp.data_reader_type, "name", str(rp.data_reader_type))
+    if fmt == "RawAsync":
+        train = RawReader(rp.source[0], inp, rp.slot_size_array, solver.batchsize, rank, world,
+                          device, rp.num_samples, rp.float_label_dense, solver.repeat_dataset)
+        evalr = None
+        if rp.eval_source and os.path.exists(rp.eval_source) and solver.batchsize_eval > 0:
+            evalr = RawReader(rp.eval_source, inp, rp.slot_size_array, solver.batchsize_eval, rank,
+                              world, device, rp.eval_num_samples, rp.float_label_dense, True)
+        return _Readers(train, evalr)
     if fmt != "Parquet":
         # the reference's Python path rejects Norm/Raw as deprecated (add_input.cpp:318-325)
         raise RuntimeError(f"DataReaderType_t.{fmt} is deprecated in the reference and not supported; "

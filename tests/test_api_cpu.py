@@ -108,3 +108,43 @@ def test_norm_format_roundtrip(tmp_path, check_sum, i64):
         open(path, "wb").write(bytes(b))
         with pytest.raises(AssertionError):
             data.read_norm(path, i64_key=i64)
+
+
+@pytest.mark.parametrize("float_ld", [True, False])
+def test_raw_format_reader(tmp_path, float_ld):
+    """Raw (RawAsync) dataset: fixed-size 4-byte records, static multi-hot, uint32 keys + slot
+    offsets, integer dense -> log(x + 1) (docs/source/api/python_interface.md "Raw")"""
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd import data
+    rng = np.random.default_rng(1)
+    n, L, Dn = 300, 1, 3
+    hot = [2, 1, 3]
+    sizes = [40, 9, 100]
+    label = rng.integers(0, 2, size=(n, L))
+    dense = rng.integers(0, 50, size=(n, Dn)) if not float_ld else rng.random((n, Dn))
+    cats = np.concatenate([rng.integers(0, v, size=(n, h)) for v, h in zip(sizes, hot)], axis=1)
+    path = str(tmp_path / "train.bin")
+    data.write_raw(path, label, dense, cats, float_label_dense=float_ld)
+    assert os.path.getsize(path) == n * (L + Dn + sum(hot)) * 4
+    inp = hugectr.Input(label_dim=L, label_name="label", dense_dim=Dn, dense_name="dense",
+                        data_reader_sparse_param_array=[
+                            hugectr.DataReaderSparseParam("wide", [2, 1], True, 2),
+                            hugectr.DataReaderSparseParam("deep", 3, True, 1)])
+    r = data.RawReader(path, inp, sizes, 64, 1, 2, torch.device("cpu"), 0, float_ld, False)
+    nb = 0
+    while True:
+        b = r.next_batch()
+        if b is None:
+            break
+        a = nb * 64
+        ro, keys = b["sparse"]["wide"]
+        assert ro.tolist() == np.concatenate([[0], np.cumsum(np.tile([2, 1], 64))]).tolist()
+        want = cats[a:a + 64, :3] + np.array([0, 0, 40])
+        assert (keys.view(64, 3).numpy() == want).all()
+        ro2, keys2 = b["sparse"]["deep"]
+        assert (keys2.view(64, 3).numpy() == cats[a:a + 64, 3:] + 49).all()
+        want_d = dense[a + 32:a + 64] if float_ld else np.log(dense[a + 32:a + 64] + 1.0)
+        assert np.allclose(b["dense"].numpy(), want_d.astype(np.float32), rtol=1e-6)
+        assert (b["label"].numpy() == label[a + 32:a + 64]).all()     # rank 1 of 2
+        nb += 1
+    assert nb == 4  # 300 // 64, tail dropped
