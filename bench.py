@@ -302,6 +302,8 @@ def main():
         MLP's launches, the gradient sums leave from inside backward"""
         keys = key_batches[i % a.nbatches]
         ux.forward_begin(ro, keys)
+        # next batch's index stage + plan run on a side stream under this step's dense tower
+        ux.prefetch(ro, key_batches[(i + 1) % a.nbatches])
         sent = {}
 
         def get_E():
@@ -418,7 +420,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(2, 5):
                 step(i)
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()  # (also drains the unique exchange's prefetch stream)
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             if dist.get_backend() != "gloo":
                 t = t.to(dev)

@@ -1133,7 +1133,9 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   {
     int lo = 0, hi = 0;  // hi = numerically lowest = most urgent
     HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HCTR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
+    const char* pr = getenv("HCTR_PRESORT_PRIO");  // "low": fill gaps only (measurements)
+    HCTR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking,
+                                         (pr && pr[0] == 'l') ? lo : hi));
     HCTR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HCTR_HIP(hipEventCreateWithFlags(&ev_sorted, hipEventDisableTiming));
   }

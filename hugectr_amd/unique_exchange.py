@@ -75,9 +75,16 @@ class UniqueExchange:
         self._upd = ctypes.c_void_p()
         check(lib.hctr_updater_create(self.Q, self.Q, vec, ctypes.byref(self._upd)))
         i32, i64 = torch.int32, torch.int64
-        self.meta = torch.empty((max(self.P, 1), 2), dtype=i32, device=dev)
-        self.urow = torch.empty(max(self.P, 1), dtype=i64, device=dev)
-        self.peer_off = torch.zeros(self.world + 1, dtype=i64, device=dev)
+        # plan outputs are double-buffered: prefetch() fills the other set for the next batch on
+        # a side stream while this batch's set is still in use by expand / update_rows
+        self._plans = [{"meta": torch.empty((max(self.P, 1), 2), dtype=i32, device=dev),
+                        "urow": torch.empty(max(self.P, 1), dtype=i64, device=dev),
+                        "peer_off": torch.zeros(self.world + 1, dtype=i64, device=dev),
+                        "keys": None, "event": None} for _ in range(2)]
+        self._cur = 0
+        self.meta, self.urow, self.peer_off = (self._plans[0][k] for k in ("meta", "urow", "peer_off"))
+        self._side = torch.cuda.Stream(device=dev)
+        self._main_done = None  # event on the caller's stream after which the side stream may plan
         self.rows_send = torch.empty((max(self.P, 1), vec), dtype=self.dtype, device=dev)
         self.meta_recv = torch.empty((self.Q, 2), dtype=i32, device=dev)
         self.rows_recv = torch.empty((self.Q, vec), dtype=self.dtype, device=dev)
@@ -107,15 +114,48 @@ class UniqueExchange:
     # -- forward: begin() enqueues everything up to the counts all-gather; finish() does the one
     #    host sync and the rest.  Work the caller enqueues in between (the bottom MLP) keeps the
     #    GPU busy while the host waits for the counts. -------------------------------------------
-    def forward_begin(self, row_offset: torch.Tensor, keys: torch.Tensor):
-        emb, W = self.emb, self.world
+    def _plan(self, slot: int, row_offset: torch.Tensor, keys: torch.Tensor):
+        """index stage + plan of one batch into plan set `slot`, on the current stream"""
+        emb, pl = self.emb, self._plans[slot]
         emb.index(True, row_offset, keys)
         if self.P > 0:
             vi = emb.value_index(self.P)
             check(lib.hctr_uniq_plan(self._h, self.P, self.ppp, self.bl, self.s_r, self.S,
-                                     self.rank, W, ptr(vi), emb.get_max_vocabulary_size(),
-                                     ptr(self.meta), ptr(self.urow), ptr(self.peer_off),
-                                     stream_ptr()))
+                                     self.rank, self.world, ptr(vi),
+                                     emb.get_max_vocabulary_size(), ptr(pl["meta"]),
+                                     ptr(pl["urow"]), ptr(pl["peer_off"]), stream_ptr()))
+        pl["keys"] = keys
+
+    def prefetch(self, row_offset: torch.Tensor, keys: torch.Tensor):
+        """Index stage + plan of the NEXT batch on a side stream, to be called once this batch's
+        forward_begin() has been issued.  Only the key -> row map is touched (new keys are
+        inserted a step early, which changes nothing they map to); table values are not read, so
+        running ahead of this batch's update is exact -- the reference's inter-iteration overlap
+        of the index calculation does the same."""
+        nxt = 1 - self._cur
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._plan(nxt, row_offset, keys)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._plans[nxt]["event"] = ev
+
+    def drain(self):
+        """wait for an outstanding prefetch (call before using the embedding outside this class)"""
+        self._side.synchronize()
+
+    def forward_begin(self, row_offset: torch.Tensor, keys: torch.Tensor):
+        nxt = 1 - self._cur
+        pl = self._plans[nxt]
+        if pl["event"] is not None and pl["keys"] is keys:
+            torch.cuda.current_stream().wait_event(pl["event"])  # planned ahead by prefetch()
+            self._cur = nxt
+        else:
+            self._side.synchronize()  # a stale prefetch must not race the inline plan
+            self._plan(self._cur, row_offset, keys)
+            pl = self._plans[self._cur]
+        pl["event"] = None
+        self.meta, self.urow, self.peer_off = pl["meta"], pl["urow"], pl["peer_off"]
         mine = (self.peer_off[1:] - self.peer_off[:-1]).contiguous()
         _all_gather(self.counts.view(-1), mine, self.group)
         # fixed-size part of the payload: (index, bucket) pairs

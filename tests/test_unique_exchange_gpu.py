@@ -39,11 +39,15 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
         s_r = slots_on_rank(S, rank, world)
         ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
         rng = np.random.default_rng(17)   # same keys on every rank (full-batch CSR)
-        for step in range(4):
-            keys = np.stack([(rng.zipf(1.3, size=B) - 1) % v + o for v, o in zip(sizes, offs)],
-                            axis=1).reshape(-1).astype(np.int64)
-            kt = torch.from_numpy(keys).cuda()
-            E = ux.forward(ro, kt)
+        batches = [torch.from_numpy(np.stack(
+            [(rng.zipf(1.3, size=B) - 1) % v + o for v, o in zip(sizes, offs)],
+            axis=1).reshape(-1).astype(np.int64)).cuda() for _ in range(5)]
+        for step in range(5):
+            kt = batches[step]
+            ux.forward_begin(ro, kt)
+            if step + 1 < 5 and step != 2:   # planned ahead, except once (inline path again)
+                ux.prefetch(ro, batches[step + 1])
+            E = ux.forward_finish()
             pooled = emb_d.forward(True, ro, kt)
             recv = dx.forward(pooled.cpu()).cuda()
             E_ref = ha.forward_reorder(recv, Bl, S, D, world)
@@ -62,7 +66,8 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
             tu, td = emb_u.table(), emb_d.table()
             err = (tu - td).abs().max().item()
             assert err <= 2e-5 * td.abs().max().item() + 1e-6, (step, err)
-            assert emb_u.get_vocabulary_size() == emb_d.get_vocabulary_size()
+            if step == 4:  # earlier, the prefetch has already inserted the next batch's new keys
+                assert emb_u.get_vocabulary_size() == emb_d.get_vocabulary_size()
         # the exchange really shipped fewer rows than positions
         assert sum(ux.u_send) < ux.P / 2
         ret[rank] = "ok"
