@@ -70,6 +70,32 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// dim % 4 == 0 and 16-byte aligned buffers: one float4 per thread (the common case)
+__global__ void __launch_bounds__(kBlock)
+    det_gather4_kernel(const uint64_t* __restrict__ idx, size_t n, const float4* __restrict__ rows,
+                       int d4, float4* __restrict__ out) {
+  const uint64_t total = (uint64_t)n * d4;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t k = i / (uint32_t)d4;
+    const uint32_t c = (uint32_t)(i - k * (uint32_t)d4);
+    const uint64_t r = idx[k];
+    out[i] = r != kInvalidIndex ? rows[r * (uint32_t)d4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+static void launch_det_gather(const uint64_t* idx, size_t n, const float* rows, int dim, float* out,
+                              hipStream_t s) {
+  const bool v4 = dim % 4 == 0 && reinterpret_cast<uintptr_t>(rows) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  if (v4)
+    hipLaunchKernelGGL(det_gather4_kernel, dim3(grid_for(n * (size_t)(dim / 4), kBlock, 8192)),
+                       dim3(kBlock), 0, s, idx, n, (const float4*)rows, dim / 4, (float4*)out);
+  else
+    hipLaunchKernelGGL(det_gather_kernel, dim3(grid_for(n * (size_t)dim, kBlock, 8192)),
+                       dim3(kBlock), 0, s, idx, n, rows, dim, out);
+}
+
 __global__ void __launch_bounds__(kBlock)
     det_ptr_kernel(const uint64_t* __restrict__ idx, size_t n, float* rows, int dim,
                    float** __restrict__ out) {
@@ -421,8 +447,7 @@ int hctr_det_lookup(hctr_det* h, const void* keys, float* elements, size_t num_k
     DetClass& c = h->cls[r.cls];
     if (r.n == 0) continue;
     HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
-    hipLaunchKernelGGL(det_gather_kernel, dim3(grid_for(r.n * (size_t)c.dim, kBlock, 4096)),
-                       dim3(kBlock), 0, s, h->idx, r.n, c.rows, c.dim, elements + out_off);
+    launch_det_gather(h->idx, r.n, c.rows, c.dim, elements + out_off, s);
     HCTR_LAUNCH_CHECK();
     out_off += r.n * (size_t)c.dim;
   }
@@ -545,8 +570,7 @@ int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, 
       } else {
         (void)hipMemcpyAsync(keys, d_keys, n * sizeof(int64_t), hipMemcpyDeviceToDevice, s);
       }
-      hipLaunchKernelGGL(det_gather_kernel, dim3(grid_for(n * (size_t)c.dim, kBlock, 4096)),
-                         dim3(kBlock), 0, s, d_vals, n, c.rows, c.dim, values);
+      launch_det_gather(d_vals, n, c.rows, c.dim, values, s);
       (void)hipStreamSynchronize(s);
     }
   }
