@@ -124,3 +124,76 @@ def test_dlrm_style_script_trains(tmp_path):
     first = model.get_current_loss()
     model.fit(max_iter=300, display=100, eval_interval=0, snapshot=0)
     assert model.get_current_loss() < min(first, 0.6)
+
+
+def test_deepfm_script_trains(tmp_path):
+    """BASELINE config 2: the layer graph of R/samples/deepfm/deepfm_parquet.py (embedding_vec_size
+    11 -> Slice 10 + 1, WeightMultiply, FmOrder2, ReduceSum, Add) on a Criteo-Kaggle-shaped
+    synthetic Parquet set, Adam with the Global update, as the sample configures it."""
+    import hugectr_amd.hugectr as hugectr
+    _gen(tmp_path, hugectr)
+    solver = hugectr.CreateSolver(max_eval_batches=4, batchsize_eval=512, batchsize=512, lr=0.002,
+                                  vvgpu=[[0]], repeat_dataset=True, i64_input_key=True)
+    reader = hugectr.DataReaderParams(
+        data_reader_type=hugectr.DataReaderType_t.Parquet,
+        source=[str(tmp_path / "train" / "_file_list.txt")],
+        eval_source=str(tmp_path / "val" / "_file_list.txt"), slot_size_array=SIZES,
+        check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam,
+                                  update_type=hugectr.Update_t.Global, beta1=0.9, beta2=0.999,
+                                  epsilon=1e-7)
+    model = hugectr.Model(solver, reader, opt)
+    L, D = hugectr.Layer_t, hugectr.DenseLayer
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", 1, False, 26)]))
+    model.add(hugectr.SparseEmbedding(
+        embedding_type=hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash,
+        workspace_size_per_gpu_in_mb=8, embedding_vec_size=11, combiner="sum",
+        sparse_embedding_name="sparse_embedding1", bottom_name="data1", slot_size_array=SIZES,
+        optimizer=opt))
+    model.add(D(layer_type=L.Reshape, bottom_names=["sparse_embedding1"], top_names=["reshape1"],
+                leading_dim=11))
+    model.add(D(layer_type=L.Slice, bottom_names=["reshape1"], top_names=["slice11", "slice12"],
+                ranges=[(0, 10), (10, 11)]))
+    model.add(D(layer_type=L.Reshape, bottom_names=["slice11"], top_names=["reshape2"],
+                leading_dim=260))
+    model.add(D(layer_type=L.Reshape, bottom_names=["slice12"], top_names=["reshape3"],
+                leading_dim=26))
+    model.add(D(layer_type=L.WeightMultiply, bottom_names=["dense"],
+                top_names=["weight_multiply1"], weight_dims=[13, 10]))
+    model.add(D(layer_type=L.WeightMultiply, bottom_names=["dense"],
+                top_names=["weight_multiply2"], weight_dims=[13, 1]))
+    model.add(D(layer_type=L.Concat, bottom_names=["reshape2", "weight_multiply1"],
+                top_names=["concat1"]))
+    prev = "concat1"
+    for i in (1, 2, 3):
+        model.add(D(layer_type=L.InnerProduct, bottom_names=[prev], top_names=[f"fc{i}"],
+                    num_output=64))
+        model.add(D(layer_type=L.ReLU, bottom_names=[f"fc{i}"], top_names=[f"relu{i}"]))
+        model.add(D(layer_type=L.Dropout, bottom_names=[f"relu{i}"], top_names=[f"dropout{i}"],
+                    dropout_rate=0.1))
+        prev = f"dropout{i}"
+    model.add(D(layer_type=L.InnerProduct, bottom_names=[prev], top_names=["fc4"], num_output=1))
+    model.add(D(layer_type=L.FmOrder2, bottom_names=["concat1"], top_names=["fmorder2"],
+                out_dim=10))
+    model.add(D(layer_type=L.ReduceSum, bottom_names=["fmorder2"], top_names=["reducesum1"],
+                axis=1))
+    model.add(D(layer_type=L.Concat, bottom_names=["reshape3", "weight_multiply2"],
+                top_names=["concat2"]))
+    model.add(D(layer_type=L.ReduceSum, bottom_names=["concat2"], top_names=["reducesum2"],
+                axis=1))
+    model.add(D(layer_type=L.Add, bottom_names=["fc4", "reducesum1", "reducesum2"],
+                top_names=["add"]))
+    model.add(D(layer_type=L.BinaryCrossEntropyLoss, bottom_names=["add", "label"],
+                top_names=["loss"]))
+    model.compile()
+    model.summary()
+    model.train()
+    first = model.get_current_loss()
+    model.fit(max_iter=150, display=50, eval_interval=75, snapshot=1000000,
+              snapshot_prefix=str(tmp_path / "deepfm"))
+    last = model.get_current_loss()
+    assert np.isfinite(first) and np.isfinite(last) and last < first and last < 0.55
+    auc = dict(model.get_eval_metrics()).get("AUC")
+    assert auc is not None and auc > 0.7
