@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the HIP library is a build artefact (git-ignored): build it when a fresh checkout has none
+    lib = os.path.join(ROOT, "hugectr_amd", "libhugectr_amd.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
