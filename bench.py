@@ -115,12 +115,14 @@ def main():
                          "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
                          "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
                          "is what the overlap could save at N = 8, so no split is the default")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique", "unique16"],
                     help="multi-GPU payload of the embedding exchange: rows = one pooled vector / "
                          "gradient per (sample, slot) as the reference; unique = every distinct row "
                          "once per destination + per-row gradient sums "
-                         "(hugectr_amd/unique_exchange.py); auto = time both during warm-up and "
-                         "keep the faster one")
+                         "(hugectr_amd/unique_exchange.py), sums on the wire in fp32; unique16 = "
+                         "the same with the sums in the pooled vectors' 16-bit type (the precision "
+                         "class of the per-sample gradients the rows payload ships); auto = time "
+                         "all three during warm-up and keep the fastest")
     ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--table-scale", type=float, default=1.0)
@@ -192,7 +194,14 @@ def main():
     if world > 1 and C == 1 and a.exchange != "rows":
         from hugectr_amd.unique_exchange import UniqueExchange
         ux = UniqueExchange(emb, Bl, S, D)
-    mode = {"name": "unique" if (ux is not None and a.exchange == "unique") else "rows"}
+    mode = {"name": a.exchange if (ux is not None and a.exchange != "auto") else "rows"}
+
+    def set_mode(name):
+        mode["name"] = name
+        if ux is not None and name != "rows":
+            ux.set_sum_dtype(edt if name == "unique16" else torch.float32)
+
+    set_mode(mode["name"])
 
     # ---- synthetic data, resident in HBM before the timed region ---------------------------------
     rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
@@ -324,7 +333,7 @@ def main():
         return loss
 
     def step(i):
-        if mode["name"] == "unique":
+        if mode["name"] != "rows":
             return step_unique(i)
         keys = key_batches[i % a.nbatches]
         dense = dense_batches[i % a.nbatches]
@@ -407,8 +416,8 @@ def main():
         # measure, don't guess: a few steps of each payload during warm-up, keep the faster one
         # (the decision is taken on the max over ranks, so every rank takes the same one)
         timing = {}
-        for name in ("rows", "unique"):
-            mode["name"] = name
+        for name in ("rows", "unique", "unique16"):
+            set_mode(name)
             try:
                 for i in range(2):
                     step(i)
@@ -428,7 +437,7 @@ def main():
                 t = t.to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             timing[name] = float(t.item()) / 3
-        mode["name"] = min(timing, key=timing.get)
+        set_mode(min(timing, key=timing.get))
         mode["timing_ms"] = {k: v * 1e3 for k, v in timing.items()}
     pool_prof = emb.profile().get("gather_pool", (0.0, 0))
     for i in range(a.warmup):

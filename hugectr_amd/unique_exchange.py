@@ -58,8 +58,13 @@ def _all_gather(out: torch.Tensor, inp: torch.Tensor, group):
 
 
 class UniqueExchange:
-    def __init__(self, emb, batch_per_gpu: int, slot_num: int, vec: int, group=None):
+    def __init__(self, emb, batch_per_gpu: int, slot_num: int, vec: int, group=None,
+                 sum_dtype=torch.float32):
+        """sum_dtype: wire type of the per-row gradient sums (accumulated in fp32 either way).
+        fp32 keeps the sums exact; a 16-bit type halves the return payload at the precision class
+        of the 16-bit per-sample gradients the rows exchange ships (use set_sum_dtype to switch)."""
         self.emb, self.group = emb, group
+        self.sum_dtype = sum_dtype
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bl, self.S, self.D = batch_per_gpu, slot_num, vec
@@ -92,6 +97,8 @@ class UniqueExchange:
         self.sorted_buckets = torch.empty(self.Q, dtype=i32, device=dev)
         self.sums = torch.empty((self.Q, vec), dtype=torch.float32, device=dev)
         self.grads_back = torch.empty((max(self.P, 1), vec), dtype=torch.float32, device=dev)
+        self._sums16 = None   # 16-bit staging of the sums / received sums, allocated on demand
+        self._back16 = None
         self.arange = torch.arange(max(self.P, self.Q) + 1, dtype=i64, device=dev)
         self.counts = torch.empty((self.world, self.world), dtype=i64, device=dev)
         s_of = [slots_on_rank(slot_num, j, self.world) for j in range(self.world)]
@@ -197,7 +204,14 @@ class UniqueExchange:
             self._upd, self.Q, self.Q, ptr(self.arange), ptr(self.sorted_rows),
             ptr(self.sorted_buckets), ptr(grad), _EMB_DT[grad.dtype], n_recv, ptr(self.sums),
             stream_ptr()))
-        out, inp = self.grads_back.view(-1)[:n_send * D], self.sums.view(-1)[:n_recv * D]
+        if self.sum_dtype == torch.float32:
+            out, inp = self.grads_back.view(-1)[:n_send * D], self.sums.view(-1)[:n_recv * D]
+        else:
+            if self._sums16 is None or self._sums16.dtype != self.sum_dtype:
+                self._sums16 = torch.empty_like(self.sums, dtype=self.sum_dtype)
+                self._back16 = torch.empty_like(self.grads_back, dtype=self.sum_dtype)
+            self._sums16[:n_recv].copy_(self.sums[:n_recv])
+            out, inp = self._back16.view(-1)[:n_send * D], self._sums16.view(-1)[:n_recv * D]
         osz, isz = [u * D for u in self.u_send], [u * D for u in self.u_recv]
         if _staged():
             _a2a(out, inp, osz, isz, self.group)
@@ -206,12 +220,16 @@ class UniqueExchange:
             self._work = dist.all_to_all_single(out, inp, osz, isz, group=self.group,
                                                 async_op=True)
 
+    def set_sum_dtype(self, dtype):
+        self.sum_dtype = dtype
+
     def backward_finish(self):
         if self._work is not None:
             self._work.wait()
             self._work = None
         n_send = sum(self.u_send)
-        self.emb.update_rows(self.urow[:n_send], self.grads_back[:n_send], self.arange[:n_send + 1])
+        back = self.grads_back if self.sum_dtype == torch.float32 else self._back16
+        self.emb.update_rows(self.urow[:n_send], back[:n_send], self.arange[:n_send + 1])
 
     def backward_and_update(self, grad: torch.Tensor):
         """dE [batch_per_gpu, slot_num, D] -> per-row sums -> owners -> sparse optimizer"""

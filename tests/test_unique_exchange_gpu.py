@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dtype_name, opt_name, ret):
+def _worker(rank, world, port, dtype_name, opt_name, sum16, ret):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -34,7 +34,8 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
         emb_u.init_params()
         emb_d.init_params()
         assert torch.equal(emb_u.table(), emb_d.table())
-        ux = UniqueExchange(emb_u, Bl, S, D)
+        ux = UniqueExchange(emb_u, Bl, S, D,
+                            sum_dtype=dt if sum16 else torch.float32)
         dx = LocalizedExchange(B, S, D)
         s_r = slots_on_rank(S, rank, world)
         ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
@@ -54,8 +55,13 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
             if step == 0:   # same tables: the expanded rows are the same bits
                 assert torch.equal(E, E_ref), "E differs at step 0"
             else:           # tables have diverged by fp32 rounding (different summation order)
-                assert torch.allclose(E.float(), E_ref.float(), rtol=1e-2 if dt != torch.float32
-                                      else 1e-4, atol=1e-5), f"E differs at step {step}"
+                if sum16:   # partial sums rounded to bf16: 2^-9 of the (large, hot-row) updates
+                    err = (E.float() - E_ref.float()).abs().max().item()
+                    assert err <= 1e-2 * E_ref.float().abs().max().item() + 4e-3, (step, err)
+                else:
+                    rt, at = (1e-2, 1e-5) if dt != torch.float32 else (1e-4, 1e-5)
+                    assert torch.allclose(E.float(), E_ref.float(), rtol=rt, atol=at), \
+                        f"E differs at step {step}"
             g = torch.from_numpy(rng.standard_normal((world, Bl, S, D)).astype(np.float32))[rank]
             g = g.cuda().to(dt)
             ux.backward_and_update(g)
@@ -65,7 +71,10 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
             emb_d.update_params()
             tu, td = emb_u.table(), emb_d.table()
             err = (tu - td).abs().max().item()
-            assert err <= 2e-5 * td.abs().max().item() + 1e-6, (step, err)
+            # 16-bit sums on the wire: each partial sum carries 2^-9 relative rounding
+            tol = ((1e-2, 4e-3) if sum16 else (2e-5, 1e-6))
+            tol = tol[0] * td.abs().max().item() + tol[1]
+            assert err <= tol, (step, err)
             if step == 4:  # earlier, the prefetch has already inserted the next batch's new keys
                 assert emb_u.get_vocabulary_size() == emb_d.get_vocabulary_size()
         # the exchange really shipped fewer rows than positions
@@ -78,13 +87,15 @@ def _worker(rank, world, port, dtype_name, opt_name, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype_name,opt_name", [("bfloat16", "sgd"), ("float32", "adagrad")])
-def test_unique_exchange_matches_per_sample_exchange(dtype_name, opt_name):
+@pytest.mark.parametrize("dtype_name,opt_name,sum16", [("bfloat16", "sgd", False),
+                                                        ("float32", "adagrad", False),
+                                                        ("bfloat16", "sgd", True)])
+def test_unique_exchange_matches_per_sample_exchange(dtype_name, opt_name, sum16):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 23000 + os.getpid() % 4000 + (7 if opt_name == "sgd" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, opt_name, ret))
+    port = 23000 + os.getpid() % 4000 + (7 if opt_name == "sgd" else 0) + (13 if sum16 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dtype_name, opt_name, sum16, ret))
              for r in range(2)]
     for p in procs:
         p.start()

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 export HCTR_BENCH_BACKEND=gloo
-for ex in rows unique auto; do
+for ex in rows unique unique16 auto; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
     --master-port $((29610 + RANDOM % 200)) bench.py --gpus 2 --steps 4 --warmup 2 --batch 8192 \
     --table-scale 0.02 --exchange $ex --tunable off 2>&1 | grep '^{' | python -c "
