@@ -121,8 +121,8 @@ def main():
                          "once per destination + per-row gradient sums "
                          "(hugectr_amd/unique_exchange.py), sums on the wire in fp32; unique16 = "
                          "the same with the sums in the pooled vectors' 16-bit type (the precision "
-                         "class of the per-sample gradients the rows payload ships); auto = time "
-                         "all three during warm-up and keep the fastest")
+                         "class of the per-sample gradients the rows payload ships; opt-in); auto = "
+                         "time rows and unique during warm-up and keep the faster")
     ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--table-scale", type=float, default=1.0)
@@ -416,7 +416,7 @@ def main():
         # measure, don't guess: a few steps of each payload during warm-up, keep the faster one
         # (the decision is taken on the max over ranks, so every rank takes the same one)
         timing = {}
-        for name in ("rows", "unique", "unique16"):
+        for name in ("rows", "unique"):  # unique16 changes the wire precision: opt-in only
             set_mode(name)
             try:
                 for i in range(2):
