@@ -313,12 +313,14 @@ def main():
         MLP's launches, the gradient sums leave from inside backward"""
         keys = key_batches[i % a.nbatches]
         ux.forward_begin(ro, keys)
-        # next batch's index stage + plan run on a side stream under this step's dense tower
-        ux.prefetch(ro, key_batches[(i + 1) % a.nbatches])
         sent = {}
 
         def get_E():
             sent["E"] = ux.forward_finish().detach().requires_grad_(True)
+            # next batch's index stage, plan, counts and (index, bucket) exchange: side stream,
+            # under this step's dense tower; issued after this step's row all-to-all so that the
+            # communicator serves the critical-path transfer first
+            ux.prefetch(ro, key_batches[(i + 1) % a.nbatches])
             return sent["E"]
 
         loss = dense_chunk(dense_batches[i % a.nbatches], label_batches[i % a.nbatches], None,

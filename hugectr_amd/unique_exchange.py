@@ -85,13 +85,16 @@ class UniqueExchange:
         self._plans = [{"meta": torch.empty((max(self.P, 1), 2), dtype=i32, device=dev),
                         "urow": torch.empty(max(self.P, 1), dtype=i64, device=dev),
                         "peer_off": torch.zeros(self.world + 1, dtype=i64, device=dev),
-                        "keys": None, "event": None} for _ in range(2)]
+                        "counts": torch.zeros((self.world, self.world), dtype=i64, device=dev),
+                        "counts_host": torch.zeros((self.world, self.world), dtype=i64).pin_memory(),
+                        "meta_recv": torch.empty((max(batch_per_gpu * slot_num, 1), 2), dtype=i32,
+                                                 device=dev),
+                        "keys": None, "event": None, "host_event": None} for _ in range(2)]
         self._cur = 0
         self.meta, self.urow, self.peer_off = (self._plans[0][k] for k in ("meta", "urow", "peer_off"))
         self._side = torch.cuda.Stream(device=dev)
         self._main_done = None  # event on the caller's stream after which the side stream may plan
         self.rows_send = torch.empty((max(self.P, 1), vec), dtype=self.dtype, device=dev)
-        self.meta_recv = torch.empty((self.Q, 2), dtype=i32, device=dev)
         self.rows_recv = torch.empty((self.Q, vec), dtype=self.dtype, device=dev)
         self.sorted_rows = torch.empty(self.Q, dtype=i32, device=dev)
         self.sorted_buckets = torch.empty(self.Q, dtype=i32, device=dev)
@@ -100,7 +103,6 @@ class UniqueExchange:
         self._sums16 = None   # 16-bit staging of the sums / received sums, allocated on demand
         self._back16 = None
         self.arange = torch.arange(max(self.P, self.Q) + 1, dtype=i64, device=dev)
-        self.counts = torch.empty((self.world, self.world), dtype=i64, device=dev)
         s_of = [slots_on_rank(slot_num, j, self.world) for j in range(self.world)]
         self.meta_send_splits = [self.ppp * 2] * self.world
         self.meta_recv_splits = [batch_per_gpu * s * 2 for s in s_of]
@@ -118,9 +120,8 @@ class UniqueExchange:
             lib.hctr_updater_destroy(self._upd)
             self._h = None
 
-    # -- forward: begin() enqueues everything up to the counts all-gather; finish() does the one
-    #    host sync and the rest.  Work the caller enqueues in between (the bottom MLP) keeps the
-    #    GPU busy while the host waits for the counts. -------------------------------------------
+    # -- forward: begin() makes a plan current (prefetched or computed in line); finish() reads the
+    #    counts on the host and runs the variable part of the exchange --------------------------------
     def _plan(self, slot: int, row_offset: torch.Tensor, keys: torch.Tensor):
         """index stage + plan of one batch into plan set `slot`, on the current stream"""
         emb, pl = self.emb, self._plans[slot]
@@ -131,11 +132,23 @@ class UniqueExchange:
                                      self.rank, self.world, ptr(vi),
                                      emb.get_max_vocabulary_size(), ptr(pl["meta"]),
                                      ptr(pl["urow"]), ptr(pl["peer_off"]), stream_ptr()))
+        # counts of distinct rows per (owner, destination): every rank needs its row and its column
+        mine = (pl["peer_off"][1:] - pl["peer_off"][:-1]).contiguous()
+        _all_gather(pl["counts"].view(-1), mine, self.group)
+        pl["counts_host"].copy_(pl["counts"], non_blocking=True)
+        he = torch.cuda.Event()
+        he.record(torch.cuda.current_stream())
+        pl["host_event"] = he
+        # fixed-size part of the payload: (index, bucket) pairs
+        _a2a(pl["meta_recv"].view(-1), pl["meta"].view(-1)[:self.P * 2], self.meta_recv_splits,
+             self.meta_send_splits, self.group)
         pl["keys"] = keys
 
     def prefetch(self, row_offset: torch.Tensor, keys: torch.Tensor):
-        """Index stage + plan of the NEXT batch on a side stream, to be called once this batch's
-        forward_begin() has been issued.  Only the key -> row map is touched (new keys are
+        """Index stage + plan of the NEXT batch -- and the exchange of its counts and (index,
+        bucket) pairs, with the counts copied to pinned host memory -- on a side stream, to be
+        called once this batch's forward_begin() has been issued.  The next step then needs no
+        host-device synchronisation at all: the host only waits for a copy that finished long ago.  Only the key -> row map is touched (new keys are
         inserted a step early, which changes nothing they map to); table values are not read, so
         running ahead of this batch's update is exact -- the reference's inter-iteration overlap
         of the index calculation does the same."""
@@ -162,16 +175,16 @@ class UniqueExchange:
             self._plan(self._cur, row_offset, keys)
             pl = self._plans[self._cur]
         pl["event"] = None
+        self._pl = pl
         self.meta, self.urow, self.peer_off = pl["meta"], pl["urow"], pl["peer_off"]
-        mine = (self.peer_off[1:] - self.peer_off[:-1]).contiguous()
-        _all_gather(self.counts.view(-1), mine, self.group)
-        # fixed-size part of the payload: (index, bucket) pairs
-        _a2a(self.meta_recv.view(-1), self.meta.view(-1)[:self.P * 2], self.meta_recv_splits,
-             self.meta_send_splits, self.group)
+        self.meta_recv, self.counts = pl["meta_recv"], pl["counts"]
 
     def forward_finish(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         emb, W, D = self.emb, self.world, self.D
-        c = self.counts.cpu()                       # the step's one host sync
+        # the variable all-to-all needs the counts on the host: wait for their (pinned) copy only --
+        # with a prefetched plan that copy finished during the previous step
+        self._pl["host_event"].synchronize()
+        c = self._pl["counts_host"]
         self.u_send = [int(x) for x in c[self.rank]]
         self.u_recv = [int(x) for x in c[:, self.rank]]
         n_send, n_recv = sum(self.u_send), sum(self.u_recv)

@@ -46,9 +46,9 @@ def _worker(rank, world, port, dtype_name, opt_name, sum16, ret):
         for step in range(5):
             kt = batches[step]
             ux.forward_begin(ro, kt)
+            E = ux.forward_finish()
             if step + 1 < 5 and step != 2:   # planned ahead, except once (inline path again)
                 ux.prefetch(ro, batches[step + 1])
-            E = ux.forward_finish()
             pooled = emb_d.forward(True, ro, kt)
             recv = dx.forward(pooled.cpu()).cuda()
             E_ref = ha.forward_reorder(recv, Bl, S, D, world)
