@@ -165,6 +165,74 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// 16-byte vector form (ev * sizeof(T) % 16 == 0, 16-byte aligned buffers): one thread moves
+// 16 B of one (lookup, sample) vector; arithmetic only where a scale or a shard sum is needed
+template <typename T>
+struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+};
+
+template <typename T, bool FWD>
+__global__ void __launch_bounds__(kBlock)
+    ebc_network_vec_kernel(size_t bpg, int num_lookup, int row16, int max_shards,
+                           const int* __restrict__ src_blocks, const int* __restrict__ combiner,
+                           const long long* __restrict__ bucket_counts, int batch_major,
+                           const uint4* __restrict__ in, uint4* __restrict__ out) {
+  constexpr int N = Vec16<T>::N;
+  const size_t total = (size_t)num_lookup * bpg * row16;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const size_t lb = i / (uint32_t)row16;
+    const uint32_t c = (uint32_t)(i - lb * (uint32_t)row16);
+    const uint32_t l = (uint32_t)(lb / bpg);
+    const size_t b = lb - (size_t)l * bpg;
+    float scale = 1.0f;
+    if (combiner[l] == 1) {
+      const long long cnt = bucket_counts[(size_t)l * bpg + b];
+      if (cnt > 0) scale = 1.0f / (float)cnt;
+    }
+    const size_t dense_idx =
+        (batch_major ? (b * (size_t)num_lookup + l) : ((size_t)l * bpg + b)) * row16 + c;
+    const int* blocks = src_blocks + (size_t)l * max_shards;
+    if (FWD) {
+      int first = -1, n = 0;
+      for (int s = 0; s < max_shards; s++)
+        if (blocks[s] >= 0) {
+          if (first < 0) first = blocks[s];
+          n++;
+        }
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (n == 1 && scale == 1.0f) {
+        v = in[((size_t)first * bpg + b) * row16 + c];  // plain move
+      } else if (n >= 1) {
+        float acc[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) acc[k] = 0.f;
+        for (int s = 0; s < max_shards; s++) {
+          if (blocks[s] < 0) continue;
+          const uint4 r = in[((size_t)blocks[s] * bpg + b) * row16 + c];
+          const T* rt = reinterpret_cast<const T*>(&r);
+#pragma unroll
+          for (int k = 0; k < N; k++) acc[k] += ld_as_f32<T>(rt + k);
+        }
+        T* vt = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, acc[k] * scale);
+      }
+      out[dense_idx] = v;
+    } else {
+      uint4 v = in[dense_idx];
+      if (scale != 1.0f) {
+        T* vt = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, ld_as_f32<T>(vt + k) * scale);
+      }
+      for (int s = 0; s < max_shards; s++)
+        if (blocks[s] >= 0) out[((size_t)blocks[s] * bpg + b) * row16 + c] = v;
+    }
+  }
+}
+
 template <typename K>
 __global__ void __launch_bounds__(kBlock)
     ebc_bucket_count_kernel(size_t batch, size_t bpg, int num_lookup, int rank,
@@ -302,8 +370,24 @@ static int ebc_network(bool fwd, size_t bpg, int num_lookup, int ev, int max_sha
   if (total == 0) return HCTR_OK;
   HCTR_REQUIRE(src_blocks && combiner && in && out, "null pointer");
   const int grid = grid_for(total, kBlock);
+  const size_t esz = dtype == HCTR_EMB_F32 ? 4 : 2;
+  const bool vec = ((size_t)ev * esz) % 16 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(out) % 16 == 0;
 #define HCTR_NET(T)                                                                             \
-  if (fwd)                                                                                      \
+  if (vec) {                                                                                    \
+    const int row16 = (int)((size_t)ev * sizeof(T) / 16);                                       \
+    const int vgrid = grid_for((size_t)num_lookup * bpg * row16, kBlock, 8192);                 \
+    if (fwd)                                                                                    \
+      hipLaunchKernelGGL((ebc_network_vec_kernel<T, true>), dim3(vgrid), dim3(kBlock), 0, s,    \
+                         bpg, num_lookup, row16, max_shards, src_blocks, combiner,              \
+                         (const long long*)bucket_counts, batch_major, (const uint4*)in,        \
+                         (uint4*)out);                                                          \
+    else                                                                                        \
+      hipLaunchKernelGGL((ebc_network_vec_kernel<T, false>), dim3(vgrid), dim3(kBlock), 0, s,   \
+                         bpg, num_lookup, row16, max_shards, src_blocks, combiner,              \
+                         (const long long*)bucket_counts, batch_major, (const uint4*)in,        \
+                         (uint4*)out);                                                          \
+  } else if (fwd)                                                                               \
     hipLaunchKernelGGL((ebc_network_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, bpg,      \
                        num_lookup, ev, max_shards, src_blocks, combiner,                        \
                        (const long long*)bucket_counts, batch_major, (const T*)in, (T*)out);    \

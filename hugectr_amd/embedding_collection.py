@@ -243,7 +243,8 @@ class EmbeddingCollection:
         return out
 
     def network_backward(self, grad: torch.Tensor) -> torch.Tensor:
-        send = torch.zeros((max(self.total_blocks, 1) * self.bpg, self.ev), dtype=self.out_dtype,
+        # every (lookup, shard) block is written exactly once by the kernel: no zero fill needed
+        send = torch.empty((max(self.total_blocks, 1) * self.bpg, self.ev), dtype=self.out_dtype,
                            device=self.dev)
         check(lib.hctr_ebc_network_backward(self.bpg, self.L, self.ev, self.max_shards,
                                             ptr(self.d_src_blocks), ptr(self.d_combiner),
