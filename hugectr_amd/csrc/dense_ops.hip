@@ -711,16 +711,21 @@ __global__ void __launch_bounds__(kBlock)
 
 // backward: per row local math; dW/db column sums go to per-wave partial rows in `partials`
 // [num_waves][layers][2][w], reduced in fixed order by cross_v1_reduce_kernel (deterministic).
-template <int NPL>
+// LDS = true: one wavefront per workgroup keeps its dW/db partial rows in LDS (2*layers*w floats)
+// instead of read-modify-writing them in global memory for every row -- the per-row RMW chain
+// through L2 made the backward 12x slower than the forward at the DCN shape.
+template <int NPL, bool LDS>
 __global__ void __launch_bounds__(kBlock)
     cross_v1_bwd_kernel(size_t batch, int w, int layers, const float* __restrict__ x0,
                         const float* __restrict__ kernels, const float* __restrict__ outputs,
                         const float* __restrict__ hiddens, const float* __restrict__ out_grad,
                         float* __restrict__ in_grad, float* __restrict__ partials) {
+  extern __shared__ float cross_lds[];
   const int lane = threadIdx.x & 63;
-  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
-  float* my = partials + wave * (size_t)layers * 2 * w;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  float* gmy = partials + wave * (size_t)layers * 2 * w;
+  float* my = LDS ? cross_lds : gmy;
   for (int i = lane; i < layers * 2 * w; i += 64) my[i] = 0.f;
   for (size_t row = wave; row < batch; row += nwaves) {
     float a0[NPL], dy[NPL], dx0[NPL];
@@ -760,19 +765,33 @@ __global__ void __launch_bounds__(kBlock)
       if (i < w) in_grad[row * w + i] = dx0[t] + dy[t];
     }
   }
+  if (LDS)
+    for (int i = lane; i < layers * 2 * w; i += 64) gmy[i] = my[i];
 }
 
+// column sums of the per-wave partial rows: a workgroup owns 32 columns x 8 row groups; the 8
+// group sums are added in fixed order (deterministic)
 __global__ void __launch_bounds__(kBlock)
     cross_v1_reduce_kernel(size_t nwaves, int w, int layers, const float* __restrict__ partials,
                            float* __restrict__ kernel_grads, float* __restrict__ bias_grads) {
+  __shared__ float red[kBlock];
   const size_t total = (size_t)layers * 2 * w;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * kBlock) {
-    float s = 0.f;
-    for (size_t q = 0; q < nwaves; q++) s += partials[q * total + i];
+  const size_t i = (size_t)blockIdx.x * 32 + (threadIdx.x & 31);
+  const int tg = threadIdx.x >> 5;
+  float s = 0.f;
+  if (i < total) {
+#pragma unroll 8
+    for (size_t q = tg; q < nwaves; q += 8) s += partials[q * total + i];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tg == 0 && i < total) {
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += red[k * 32 + threadIdx.x];
     const int l = (int)(i / (2 * w)), rem = (int)(i % (2 * w));
-    if (rem < w) kernel_grads[(size_t)l * w + rem] = s;
-    else bias_grads[(size_t)l * w + (rem - w)] = s;
+    if (rem < w) kernel_grads[(size_t)l * w + rem] = sum;
+    else bias_grads[(size_t)l * w + (rem - w)] = sum;
   }
 }
 
@@ -1170,13 +1189,24 @@ int hctr_cross_v1_bwd(size_t batch, int width, int layers, const float* x0, cons
   hipStream_t s = as_stream(stream);
   const int npl = (width + 63) / 64;
   const int grid = kCrossBwdWaves / kWavesPerBlock;
+  const size_t lds_bytes = (size_t)layers * 2 * width * sizeof(float);
+  if (lds_bytes <= 60 * 1024) {
 #define HCTR_CB(N_)                                                                           \
-  hipLaunchKernelGGL(cross_v1_bwd_kernel<N_>, dim3(grid), dim3(kBlock), 0, s, batch, width,   \
-                     layers, x0, kernels, outputs, hiddens, out_grad, in_grad, workspace);
-  HCTR_CROSS_DISPATCH(HCTR_CB)
+  hipLaunchKernelGGL((cross_v1_bwd_kernel<N_, true>), dim3(kCrossBwdWaves), dim3(64), lds_bytes, \
+                     s, batch, width, layers, x0, kernels, outputs, hiddens, out_grad, in_grad,  \
+                     workspace);
+    HCTR_CROSS_DISPATCH(HCTR_CB)
 #undef HCTR_CB
+  } else {
+#define HCTR_CB(N_)                                                                           \
+  hipLaunchKernelGGL((cross_v1_bwd_kernel<N_, false>), dim3(grid), dim3(kBlock), 0, s, batch, \
+                     width, layers, x0, kernels, outputs, hiddens, out_grad, in_grad, workspace);
+    HCTR_CROSS_DISPATCH(HCTR_CB)
+#undef HCTR_CB
+  }
   HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cross_v1_reduce_kernel, dim3(grid_for((size_t)layers * 2 * width, kBlock)),
+  hipLaunchKernelGGL(cross_v1_reduce_kernel,
+                     dim3((unsigned)ceil_div<size_t>((size_t)layers * 2 * width, 32)),
                      dim3(kBlock), 0, s, (size_t)kCrossBwdWaves, width, layers, workspace,
                      kernel_grads, bias_grads);
   HCTR_LAUNCH_CHECK();

@@ -298,6 +298,80 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// vec4 form of the two SOK kernels: LPR = D/4 lanes per bucket, float4 per lane, 4 keys in flight
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    pool_weighted_vec4_kernel(size_t buckets, int combiner, const long long* __restrict__ ro,
+                              const uint64_t* __restrict__ value_index,
+                              const float* __restrict__ weights, const float* __restrict__ table,
+                              float* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  for (size_t u = (size_t)blockIdx.x * GPB + g; u < buckets; u += (size_t)gridDim.x * GPB) {
+    const long long off = ro[u];
+    const int n = (int)(ro[u + 1] - off);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float denom = 0.f;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+      float4 r[4];
+      float w[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = j0 + k < n ? j0 + k : n - 1;
+        const uint64_t idx = value_index[off + j];
+        w[k] = (j0 + k < n) ? (weights ? weights[off + j] : 1.0f) : 0.0f;
+        const bool ok = idx != kInvalidIndex;
+        r[k] = ld4(table + (ok ? idx : 0ull) * (uint64_t)D + l * 4);
+        if (!ok) r[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (j0 + k < n) {
+          denom += w[k];
+          acc.x += w[k] * r[k].x;
+          acc.y += w[k] * r[k].y;
+          acc.z += w[k] * r[k].z;
+          acc.w += w[k] * r[k].w;
+        }
+      }
+    }
+    if (combiner == 1 && n > 0) {
+      acc.x /= denom;
+      acc.y /= denom;
+      acc.z /= denom;
+      acc.w /= denom;
+    }
+    *reinterpret_cast<float4*>(out + u * (size_t)D + l * 4) = acc;
+  }
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    expand_key_grads_vec4_kernel(size_t buckets, int combiner, const long long* __restrict__ ro,
+                                 const float* __restrict__ weights, const float* __restrict__ top,
+                                 float* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  for (size_t u = (size_t)blockIdx.x * GPB + g; u < buckets; u += (size_t)gridDim.x * GPB) {
+    const long long off = ro[u];
+    const int n = (int)(ro[u + 1] - off);
+    if (n == 0) continue;
+    float denom = 1.0f;
+    if (combiner == 1) {
+      denom = 0.f;
+      for (int j = 0; j < n; j++) denom += weights ? weights[off + j] : 1.0f;
+    }
+    const float4 t = ld4(top + u * (size_t)D + l * 4);
+    for (int j = 0; j < n; j++) {
+      const float sc = (weights ? weights[off + j] : 1.0f) / denom;
+      *reinterpret_cast<float4*>(out + (size_t)(off + j) * D + l * 4) =
+          make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc);
+    }
+  }
+}
+
 // gradient of the pooled vector w.r.t. every looked-up row: g_j = top[b] * w_j (/ denom for mean)
 __global__ void __launch_bounds__(kBlock)
     expand_key_grads_kernel(size_t buckets, int D, int combiner, const long long* __restrict__ ro,
@@ -476,9 +550,28 @@ int hctr_forward_pool_weighted(size_t buckets, int vec_size, int combiner, const
   HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
   if (buckets == 0) return HCTR_OK;
   HCTR_REQUIRE(row_offset && value_index && table && out, "null pointer");
-  hipLaunchKernelGGL(pool_weighted_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
-                     dim3(kBlock), 0, as_stream(stream), buckets, vec_size, combiner,
-                     (const long long*)row_offset, value_index, weights, table, out);
+  hipStream_t s = as_stream(stream);
+  const bool v4 = vec_size % 4 == 0 && reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(out) % 16 == 0;
+  bool done = false;
+#define HCTR_PW(LPR_)                                                                            \
+  case LPR_:                                                                                      \
+    hipLaunchKernelGGL(pool_weighted_vec4_kernel<LPR_>,                                           \
+                       dim3(grid_for(buckets, kBlock / LPR_, 8192)), dim3(kBlock), 0, s, buckets, \
+                       combiner, (const long long*)row_offset, value_index, weights, table, out); \
+    done = true;                                                                                  \
+    break;
+  if (v4) {
+    switch (vec_size / 4) {
+      HCTR_PW(1) HCTR_PW(2) HCTR_PW(4) HCTR_PW(8) HCTR_PW(16) HCTR_PW(32) HCTR_PW(64)
+      default: break;
+    }
+  }
+#undef HCTR_PW
+  if (!done)
+    hipLaunchKernelGGL(pool_weighted_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
+                       dim3(kBlock), 0, s, buckets, vec_size, combiner,
+                       (const long long*)row_offset, value_index, weights, table, out);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
@@ -490,9 +583,28 @@ int hctr_expand_key_grads(size_t buckets, int vec_size, int combiner, const int6
   HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
   if (buckets == 0) return HCTR_OK;
   HCTR_REQUIRE(row_offset && top_grad && key_grads, "null pointer");
-  hipLaunchKernelGGL(expand_key_grads_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
-                     dim3(kBlock), 0, as_stream(stream), buckets, vec_size, combiner,
-                     (const long long*)row_offset, weights, top_grad, key_grads);
+  hipStream_t s = as_stream(stream);
+  const bool v4 = vec_size % 4 == 0 && reinterpret_cast<uintptr_t>(top_grad) % 16 == 0 &&
+                  reinterpret_cast<uintptr_t>(key_grads) % 16 == 0;
+  bool done = false;
+#define HCTR_EG(LPR_)                                                                            \
+  case LPR_:                                                                                      \
+    hipLaunchKernelGGL(expand_key_grads_vec4_kernel<LPR_>,                                        \
+                       dim3(grid_for(buckets, kBlock / LPR_, 8192)), dim3(kBlock), 0, s, buckets, \
+                       combiner, (const long long*)row_offset, weights, top_grad, key_grads);     \
+    done = true;                                                                                  \
+    break;
+  if (v4) {
+    switch (vec_size / 4) {
+      HCTR_EG(1) HCTR_EG(2) HCTR_EG(4) HCTR_EG(8) HCTR_EG(16) HCTR_EG(32) HCTR_EG(64)
+      default: break;
+    }
+  }
+#undef HCTR_EG
+  if (!done)
+    hipLaunchKernelGGL(expand_key_grads_kernel, dim3(grid_for(buckets * 64, kBlock, 8192)),
+                       dim3(kBlock), 0, s, buckets, vec_size, combiner,
+                       (const long long*)row_offset, weights, top_grad, key_grads);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
