@@ -125,6 +125,10 @@ class UniqueExchange:
     def _plan(self, slot: int, row_offset: torch.Tensor, keys: torch.Tensor):
         """index stage + plan of one batch into plan set `slot`, on the current stream"""
         emb, pl = self.emb, self._plans[slot]
+        if keys.numel() != self.world * self.bl * self.S:
+            raise _lib.HugeCTRAmdError(
+                "the unique-row exchange needs exactly one key per (sample, slot) bucket; use the "
+                "per-sample exchange (LocalizedExchange) for multi-hot input")
         emb.index(True, row_offset, keys)
         if self.P > 0:
             vi = emb.value_index(self.P)
