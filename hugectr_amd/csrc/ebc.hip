@@ -483,12 +483,12 @@ int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buck
   if (positions == 0) return HCTR_OK;
   HCTR_REQUIRE(row_offset && sorted_rows && sorted_buckets && grad, "null pointer");
   HCTR_REQUIRE(positions <= u->impl.max_nnz, "positions exceed the updater's capacity");
-  // out_sum[row] += sum of grad[bucket] over the row's run: the segmented reduce of the sparse
-  // update with "SGD, lr = -1" on a zeroed table
+  // out_sum[row] = sum of grad[bucket] over the row's run: the segmented reduce of the sparse
+  // update with a store-only "optimizer" (rows that own no position keep the zero of the memset)
   OptState o;
-  o.optimizer = HCTR_OPT_SGD;
+  o.optimizer = kOptStoreSumId;
   o.update_type = HCTR_UPDATE_LOCAL;
-  o.lr = -1.0f;
+  o.lr = 0.0f;
   o.scaler = 1.0f;
   o.atomic_update = 0;
   o.times = 1;

@@ -15,6 +15,8 @@ struct OptState {
   uint64_t times = 0;  // Adam step counter (incremented before each update)
 };
 
+constexpr int kOptStoreSumId = 1000;  // internal: table[row] = per-row gradient sum
+
 struct SparseUpdater {
   size_t max_nnz = 0;
   size_t max_vocab = 0;

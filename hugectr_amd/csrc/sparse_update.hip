@@ -174,12 +174,18 @@ struct OptConst {
   unsigned long long times;
 };
 
+// internal pseudo-optimizer of hctr_updater_reduce_presorted: table[row] = gradient sum (no read)
+constexpr int kOptStoreSum = 1000;
+
 // one element of one row; formulas cite sparse_optimizer.cu
 __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w, float* s0p,
                                           float* s1p, unsigned long long* ptp) {
   switch (o.optimizer) {
     case HCTR_OPT_SGD:  // opt_sgd_kernel :497-518
       w += -o.lr * gi;
+      break;
+    case kOptStoreSum:
+      w = gi;
       break;
     case HCTR_OPT_ADAGRAD: {  // opt_adagrad_kernel :410-437 (Global == Local)
       float accum = *s0p + gi * gi;
@@ -237,7 +243,9 @@ __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w,
   }
 }
 
-__device__ __forceinline__ bool needs_s0(const OptConst& o) { return o.optimizer != HCTR_OPT_SGD; }
+__device__ __forceinline__ bool needs_s0(const OptConst& o) {
+  return o.optimizer != HCTR_OPT_SGD && o.optimizer != kOptStoreSum;
+}
 __device__ __forceinline__ bool needs_s1(const OptConst& o) { return o.optimizer == HCTR_OPT_ADAM; }
 __device__ __forceinline__ bool needs_pt(const OptConst& o) {
   return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
@@ -259,8 +267,9 @@ __device__ __forceinline__ void row_load(const OptConst& o, uint64_t row, int l,
                                          const unsigned long long* __restrict__ prev_time) {
   constexpr int D = LPR * 4;
   const size_t f = row * (uint64_t)D + l * 4;
-  r.w = *reinterpret_cast<const float4*>(table + f);
   r.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.w = r.s0;
+  if (o.optimizer != kOptStoreSum) r.w = *reinterpret_cast<const float4*>(table + f);
   r.s1 = r.s0;
   r.pt[0] = r.pt[1] = r.pt[2] = r.pt[3] = 1ull;
   if (needs_s0(o)) r.s0 = *reinterpret_cast<const float4*>(state0 + f);
@@ -364,6 +373,15 @@ __device__ __forceinline__ float4 scaled_grad(typename Load4<GradT>::raw r, int 
 // The sum of a run its owner finishes goes to gsum[start position]; seg_apply_kernel picks it up.
 constexpr int kSegAhead = 8;
 
+// row id of tile position q (0..31): the metadata lane that holds it broadcasts it to the group
+template <int NPL, int ML>
+__device__ __forceinline__ uint32_t seg_row_at(const uint32_t (&mrow)[NPL], int q, int gshift) {
+  uint32_t src = mrow[0];
+#pragma unroll
+  for (int j = 1; j < NPL; j++) src = (q / ML == j) ? mrow[j] : src;
+  return (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
+}
+
 template <int LPR, typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
     seg_reduce_kernel(size_t buckets, const OffT* __restrict__ row_offset,
@@ -371,7 +389,10 @@ __global__ void __launch_bounds__(kBlock)
                       const uint32_t* __restrict__ sorted_buckets, int combiner,
                       const GradT* __restrict__ grad, float* __restrict__ gsum,
                       float* __restrict__ head, float* __restrict__ tail,
-                      uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count) {
+                      uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
+                      float* __restrict__ direct_out) {
+  // direct_out != nullptr (hctr_updater_reduce_presorted): the sum of a finished run goes to
+  // direct_out[row] instead of gsum[run start] -- no apply pass is needed afterwards
   typedef typename Load4<GradT>::raw Raw;
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
@@ -427,6 +448,10 @@ __global__ void __launch_bounds__(kBlock)
     const uint32_t cur_row =
         (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
     const uint32_t next_row0 = (uint32_t)__shfl((int)nrow[0], gshift, 64);
+#define HCTR_RUN_DST(q_)                                                                        \
+  (direct_out != nullptr                                                                        \
+       ? direct_out + (size_t)seg_row_at<NPL, ML>(mrow, (q_), gshift) * D                       \
+       : gsum + (base + (size_t)(q_)) * D)
     const bool ends_at_tile_end = end == nnz || next_row0 != cur_row;
     int q0 = 0;
     bool head_mode = false;
@@ -483,7 +508,7 @@ __global__ void __launch_bounds__(kBlock)
         if (q < T) {
           if (q >= q0 && q < nvalid) {
             if (((startmask >> q) & 1u) != 0u && q != q0) {
-              float* dst = head_mode ? head + tile * D : gsum + (base + run_start) * D;
+              float* dst = head_mode ? head + tile * D : HCTR_RUN_DST(run_start);
               *reinterpret_cast<float4*>(dst + l * 4) = acc;
               acc = make_float4(0.f, 0.f, 0.f, 0.f);
               run_start = q;
@@ -509,7 +534,7 @@ __global__ void __launch_bounds__(kBlock)
       continue;
     }
     if (cnt == 0) {  // the last run ends with the tile
-      *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
+      *reinterpret_cast<float4*>(HCTR_RUN_DST(run_start) + l * 4) = acc;
       continue;
     }
     // the last run of this tile continues: this group owns it and follows it through tile+1
@@ -545,13 +570,14 @@ __global__ void __launch_bounds__(kBlock)
     // long <=> the run reaches beyond the end of tile+1
     const bool runs_on = cnt == T && limit < nnz && row_lim == cur_row;
     if (!runs_on) {
-      *reinterpret_cast<float4*>(gsum + (base + run_start) * D + l * 4) = acc;
+      *reinterpret_cast<float4*>(HCTR_RUN_DST(run_start) + l * 4) = acc;
     } else {
       *reinterpret_cast<float4*>(tail + tile * D + l * 4) = own_part;
       if (l == 0) span_list[atomicAdd(span_count, 1u)] = (uint32_t)tile;
     }
   }
 }
+#undef HCTR_RUN_DST
 
 // Phase B: one lane inspects one sorted position; run starts of runs that are not "long" are
 // compacted with a wave ballot and handed to lane groups, which read the run's gradient sum from
@@ -1002,6 +1028,8 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     if (u.prof) u.prof->begin(3, s);
     const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
     bool done = false;
+    // store-only mode: finished runs are written straight to their output row
+    float* direct = (opt.optimizer == kOptStoreSum && opt.scaler == 1.0f) ? table : nullptr;
 #define HCTR_SEG_CASE(LPR_)                                                                       \
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
@@ -1009,12 +1037,15 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT>),                             \
                        dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,  \
                        kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail,                \
-                       u.span_list, u.span_count);                                                \
+                       u.span_list, u.span_count, direct);                                        \
     HCTR_LAUNCH_CHECK();                                                                          \
-    hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                     \
-                       dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,     \
-                       kout, u.gsum, o, table, state0, state1, (unsigned long long*)prev_time);   \
-    HCTR_LAUNCH_CHECK();                                                                          \
+    if (direct == nullptr) {                                                                      \
+      hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                   \
+                         dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,   \
+                         kout, u.gsum, o, table, state0, state1,                                  \
+                         (unsigned long long*)prev_time);                                         \
+      HCTR_LAUNCH_CHECK();                                                                        \
+    }                                                                                             \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
                        dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, s, buckets, ro, \
                        kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
@@ -1212,7 +1243,8 @@ int SparseUpdater::update(size_t buckets, size_t nnz, int combiner, const void* 
     case HCTR_OPT_ADAM:
     case HCTR_OPT_ADAGRAD:
     case HCTR_OPT_MOMENTUM_SGD:
-    case HCTR_OPT_NESTEROV: break;
+    case HCTR_OPT_NESTEROV:
+    case kOptStoreSum: break;
     default:
       // Ftrl / RMSProp are not implemented by the reference's GPU update either
       set_error("sparse optimizer not supported (reference: sparse_optimizer.cu:821-826)");
