@@ -51,3 +51,25 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "hctr_oracle" not in txt, f
+
+
+def test_new_entry_points_validate_before_touching_the_device():
+    """dynamic table / unique exchange / loss glue: bad arguments come back as error codes with a
+    message, without a GPU"""
+    from hugectr_amd import _lib
+    L = _lib.lib
+    assert L.hctr_det_create(0, None, b"", 0, 1, 0, None) == -1 and _lib.last_error()
+    assert L.hctr_det_lookup(None, None, None, 4, None, None, 0, None) == -1
+    assert "null handle" in _lib.last_error()
+    assert L.hctr_det_update(None, None, None, None, 0, None, None, 0, None, None, None) == -1
+    assert L.hctr_uniq_create(0, None) == -1
+    assert L.hctr_uniq_plan(None, 8, 4, 2, 2, 4, 0, 2, None, 100, None, None, None, None) == -1
+    assert L.hctr_uniq_expand(8, 2, None, None, None, None, 128, 2, None, None, None, None) == -1
+    assert L.hctr_updater_reduce_presorted(None, 1, 1, None, None, None, None, 0, 1, None,
+                                           None) == -1
+    assert L.hctr_relu_bwd_bias(4, 12, None, None, None, None, None, 2, None) == -1
+    assert "multiple of 8" in _lib.last_error()
+    assert L.hctr_bce_loss(0, None, None, 1.0, None, None, None, 0, None) == -1
+    assert L.hctr_forward_pool_weighted(4, 0, 0, None, None, None, None, None, None) == -1
+    assert L.hctr_emb_index(None, 1, None, None, 0, None) == -1
+    assert L.hctr_emb_update_rows(None, 1, None, None, None, 0, None) == -1
