@@ -309,22 +309,33 @@ def main():
                 off += x.numel()
 
     def step_unique(i):
-        """same step with the unique-row exchange: the counts' host sync sits behind the bottom
-        MLP's launches, the gradient sums leave from inside backward"""
+        """same step with the unique-row exchange.  With 16-bit vectors the received distinct rows
+        are never expanded: the interaction kernels read them through the (sample, slot) -> row
+        table; the gradient sums leave from inside backward."""
         keys = key_batches[i % a.nbatches]
         ux.forward_begin(ro, keys)
-        sent = {}
-
-        def get_E():
-            sent["E"] = ux.forward_finish().detach().requires_grad_(True)
+        nxt = key_batches[(i + 1) % a.nbatches]
+        dense_k, label_k = dense_batches[i % a.nbatches], label_batches[i % a.nbatches]
+        if amp and edt != torch.float32:
+            xb = bottom(dense_k)                       # runs under the row all-to-all
+            rows, row_of = ux.forward_finish(indexed=True)
             # next batch's index stage, plan, counts and (index, bucket) exchange: side stream,
             # under this step's dense tower; issued after this step's row all-to-all so that the
             # communicator serves the critical-path transfer first
-            ux.prefetch(ro, key_batches[(i + 1) % a.nbatches])
-            return sent["E"]
+            ux.prefetch(ro, nxt)
+            z = ha.interaction_indexed(xb.to(edt), rows, row_of, on_emb_grad=ux.backward_begin)
+            logit = top(z)
+            loss, dlogit = bce_with_logits(logit, label_k, 1.0 / Bl)
+            logit.backward(dlogit)
+        else:
+            sent = {}
 
-        loss = dense_chunk(dense_batches[i % a.nbatches], label_batches[i % a.nbatches], None,
-                           get_E=get_E, on_E_grad=ux.backward_begin)
+            def get_E():
+                sent["E"] = ux.forward_finish().detach().requires_grad_(True)
+                ux.prefetch(ro, nxt)
+                return sent["E"]
+
+            loss = dense_chunk(dense_k, label_k, None, get_E=get_E, on_E_grad=ux.backward_begin)
         finish_step()
         ux.backward_finish()
         dense_opt.step()

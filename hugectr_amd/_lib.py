@@ -125,7 +125,10 @@ _SIGNATURES = {
     "hctr_uniq_plan": (c_int, [_P, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, _P,
                                c_uint64, _P, _P, _P, _P]),
     "hctr_uniq_gather_rows": (c_int, [c_size_t, c_int, _P, _P, _P, c_int, _P]),
-    "hctr_uniq_expand": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "hctr_uniq_expand": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "hctr_interaction_fwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "hctr_interaction_bwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int,
+                                             _P]),
     "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,
                                               c_size_t, _P, _P]),
     "hctr_emb_index": (c_int, [_P, c_int, _P, _P, c_size_t, _P]),

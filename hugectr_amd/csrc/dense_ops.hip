@@ -188,20 +188,44 @@ struct InterCfg16 {
   static constexpr int XT = 32 * LD; // elements
 };
 
+// row_of == nullptr: emb is the dense [batch][n_emb][W] tensor.  row_of != nullptr (unique-row
+// exchange): emb is a table of distinct rows [R][W] and embedding row s of sample b is
+// emb[row_of[b * n_emb + s]] -- the receiver never materialises the expanded tensor.
 template <int W, int NPRE>
 __device__ __forceinline__ void load_sample_tile16(u32x4 (&pre)[NPRE],
                                                    const unsigned short* __restrict__ mlp,
-                                                   const unsigned short* __restrict__ emb, size_t b,
+                                                   const unsigned short* __restrict__ emb,
+                                                   const uint32_t* __restrict__ row_of, size_t b,
                                                    int n_emb, int n_vec, int lane) {
   constexpr int W8 = W / 8;
   const u32x4* m4 = reinterpret_cast<const u32x4*>(mlp + b * W);
-  const u32x4* e4 = reinterpret_cast<const u32x4*>(emb + b * (size_t)n_emb * W) - W8;
+  if (row_of == nullptr) {
+    const u32x4* e4 = reinterpret_cast<const u32x4*>(emb + b * (size_t)n_emb * W) - W8;
 #pragma unroll
-  for (int q = 0; q < NPRE; q++) {
-    int i = lane + 64 * q;
-    i = i < n_vec ? i : 0;
-    const u32x4* src = (i < W8) ? m4 : e4;
-    pre[q] = src[i];
+    for (int q = 0; q < NPRE; q++) {
+      int i = lane + 64 * q;
+      i = i < n_vec ? i : 0;
+      const u32x4* src = (i < W8) ? m4 : e4;
+      pre[q] = src[i];
+    }
+  } else {
+    const u32x4* r4 = reinterpret_cast<const u32x4*>(emb);
+    const uint32_t* ro = row_of + b * (size_t)n_emb;
+    uint32_t idx[NPRE];
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      int i = lane + 64 * q;
+      i = i < n_vec ? i : 0;
+      const int row = i / W8;
+      idx[q] = ro[row > 0 ? row - 1 : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      int i = lane + 64 * q;
+      i = i < n_vec ? i : 0;
+      const int row = i / W8, c8 = i % W8;
+      pre[q] = (row == 0) ? m4[c8] : r4[(size_t)idx[q] * W8 + c8];
+    }
   }
 }
 
@@ -209,6 +233,7 @@ template <int W, bool BF>
 __global__ void __launch_bounds__(64, 2)
     interaction_fwd16_kernel(size_t batch, int n_emb, const unsigned short* __restrict__ mlp,
                              const unsigned short* __restrict__ emb,
+                             const uint32_t* __restrict__ row_of,
                              unsigned short* __restrict__ out, int out_len) {
   using C = InterCfg16<W>;
   using H = H16<BF>;
@@ -226,7 +251,7 @@ __global__ void __launch_bounds__(64, 2)
   const int rr = r < n_ins ? r : n_ins;
   u32x4 pre[NPRE];
   size_t b = blockIdx.x;
-  if (b < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, b, n_emb, n_vec, lane);
+  if (b < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, row_of, b, n_emb, n_vec, lane);
   for (; b < batch; b += gridDim.x) {
 #pragma unroll
     for (int q = 0; q < NPRE; q++) {
@@ -238,7 +263,7 @@ __global__ void __launch_bounds__(64, 2)
     }
     __syncthreads();
     const size_t nb = b + gridDim.x;
-    if (nb < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, nb, n_emb, n_vec, lane);
+    if (nb < batch) load_sample_tile16<W, NPRE>(pre, mlp, emb, row_of, nb, n_emb, n_vec, lane);
 
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const unsigned short* xr = xt + rr * C::LD + h * (W / 2);
@@ -270,6 +295,7 @@ template <int W, bool BF>
 __global__ void __launch_bounds__(64, 2)
     interaction_bwd16_kernel(size_t batch, int n_emb, const unsigned short* __restrict__ mlp,
                              const unsigned short* __restrict__ emb,
+                             const uint32_t* __restrict__ row_of,
                              const unsigned short* __restrict__ top_grad,
                              unsigned short* __restrict__ mlp_grad,
                              unsigned short* __restrict__ emb_grad, int out_len) {
@@ -303,7 +329,7 @@ __global__ void __launch_bounds__(64, 2)
   size_t b = blockIdx.x;
 #define HCTR_BWD16_PREFETCH(bb)                                                  \
   {                                                                              \
-    load_sample_tile16<W, NPRE>(pre, mlp, emb, (bb), n_emb, n_vec, lane);        \
+    load_sample_tile16<W, NPRE>(pre, mlp, emb, row_of, (bb), n_emb, n_vec, lane); \
     const unsigned short* g__ = top_grad + (bb) * (size_t)out_len + W;           \
     _Pragma("unroll") for (int q = 0; q < NG; q++) {                             \
       int p__ = lane + 64 * q;                                                   \
@@ -987,9 +1013,18 @@ using namespace hctr;
 
 extern "C" {
 
-int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
-                         void* out, int dtype, hctr_stream_t stream) {
+static int interaction_fwd_impl(size_t batch, int n_emb, int width, const void* mlp,
+                                const void* emb, const uint32_t* row_of, void* out, int dtype,
+                                hctr_stream_t stream) {
   HCTR_REQUIRE(n_emb >= 1 && width >= 1, "shape");
+  HCTR_REQUIRE(row_of == nullptr ||
+                   ((dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16) && n_emb + 1 <= 32 &&
+                    (width == 128 || width == 64 || width == 32) &&
+                    reinterpret_cast<uintptr_t>(mlp) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(emb) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(out) % 16 == 0),
+               "indexed interaction: 16-bit rows, width 32/64/128, <= 31 embeddings, 16-byte "
+               "aligned buffers");
   if (batch == 0) return HCTR_OK;
   HCTR_REQUIRE(mlp && emb && out, "null pointer");
   hipStream_t s = as_stream(stream);
@@ -1027,11 +1062,11 @@ int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, co
     if (bf)                                                                                     \
       hipLaunchKernelGGL((interaction_fwd16_kernel<W_, true>), dim3(grid1), dim3(64), lds, s,   \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,  \
-                         (unsigned short*)out, out_len);                                        \
+                         row_of, (unsigned short*)out, out_len);                                \
     else                                                                                        \
       hipLaunchKernelGGL((interaction_fwd16_kernel<W_, false>), dim3(grid1), dim3(64), lds, s,  \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,  \
-                         (unsigned short*)out, out_len);                                        \
+                         row_of, (unsigned short*)out, out_len);                                \
   }
     switch (width) {
       case 128: HCTR_IFWD16(128) break;
@@ -1062,10 +1097,36 @@ int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, co
   return HCTR_OK;
 }
 
-int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
-                         const void* top_grad, void* mlp_grad, void* emb_grad, int dtype,
-                         hctr_stream_t stream) {
+int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
+                         void* out, int dtype, hctr_stream_t stream) {
+  return interaction_fwd_impl(batch, n_emb, width, mlp, emb, nullptr, out, dtype, stream);
+}
+
+int hctr_interaction_fwd_indexed(size_t batch, int n_emb, int width, const void* mlp,
+                                 const void* rows, const uint32_t* row_of, void* out, int dtype,
+                                 hctr_stream_t stream) {
+  HCTR_REQUIRE(row_of, "null pointer");
+  return interaction_fwd_impl(batch, n_emb, width, mlp, rows, row_of, out, dtype, stream);
+}
+
+static int interaction_bwd_impl(size_t batch, int n_emb, int width, const void* mlp,
+                                const void* emb, const uint32_t* row_of, const void* top_grad,
+                                void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream) {
   HCTR_REQUIRE(n_emb >= 1 && width >= 1, "shape");
+  {
+    const int n_ins_ = n_emb + 1;
+    const int out_len_ = width + n_ins_ * (n_ins_ - 1) / 2 + 1;
+    HCTR_REQUIRE(row_of == nullptr ||
+                     ((dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16) && n_ins_ <= 32 &&
+                      (width == 128 || width == 64 || width == 32) && out_len_ % 8 == 0 &&
+                      reinterpret_cast<uintptr_t>(mlp) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(emb) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(top_grad) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(mlp_grad) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(emb_grad) % 16 == 0),
+                 "indexed interaction: 16-bit rows, width 32/64/128, <= 31 embeddings, output "
+                 "length % 8 == 0, 16-byte aligned buffers");
+  }
   if (batch == 0) return HCTR_OK;
   HCTR_REQUIRE(mlp && emb && top_grad && mlp_grad && emb_grad, "null pointer");
   hipStream_t s = as_stream(stream);
@@ -1108,12 +1169,12 @@ int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, co
     if (bf)                                                                                      \
       hipLaunchKernelGGL((interaction_bwd16_kernel<W_, true>), dim3(grid1), dim3(64), lds, s,    \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
-                         (const unsigned short*)top_grad, (unsigned short*)mlp_grad,             \
+                         row_of, (const unsigned short*)top_grad, (unsigned short*)mlp_grad,     \
                          (unsigned short*)emb_grad, out_len);                                    \
     else                                                                                         \
       hipLaunchKernelGGL((interaction_bwd16_kernel<W_, false>), dim3(grid1), dim3(64), lds, s,   \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
-                         (const unsigned short*)top_grad, (unsigned short*)mlp_grad,             \
+                         row_of, (const unsigned short*)top_grad, (unsigned short*)mlp_grad,     \
                          (unsigned short*)emb_grad, out_len);                                    \
   }
     switch (width) {
@@ -1143,6 +1204,21 @@ int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, co
   }
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
+}
+
+int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
+                         const void* top_grad, void* mlp_grad, void* emb_grad, int dtype,
+                         hctr_stream_t stream) {
+  return interaction_bwd_impl(batch, n_emb, width, mlp, emb, nullptr, top_grad, mlp_grad, emb_grad,
+                              dtype, stream);
+}
+
+int hctr_interaction_bwd_indexed(size_t batch, int n_emb, int width, const void* mlp,
+                                 const void* rows, const uint32_t* row_of, const void* top_grad,
+                                 void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(row_of, "null pointer");
+  return interaction_bwd_impl(batch, n_emb, width, mlp, rows, row_of, top_grad, mlp_grad, emb_grad,
+                              dtype, stream);
 }
 
 #define HCTR_CROSS_DISPATCH(MACRO)       \

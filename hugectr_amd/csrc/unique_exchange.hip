@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(kBlock)
     uniq_expand_kernel(size_t Q, int n_owners, const long long* __restrict__ q_off,
                        const long long* __restrict__ r_off, const uint32_t* __restrict__ meta,
                        const uint4* __restrict__ rows, uint4* __restrict__ out,
-                       uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ sorted_buckets) {
+                       uint32_t* __restrict__ sorted_rows, uint32_t* __restrict__ sorted_buckets,
+                       uint32_t* __restrict__ row_of) {
   constexpr int GPB = kBlock / ROW16;
   __shared__ long long s_q[65], s_r[65];
   for (int i = threadIdx.x; i <= n_owners; i += kBlock) {
@@ -103,15 +104,18 @@ __global__ void __launch_bounds__(kBlock)
       u[k] = m.x + (uint32_t)s_r[j];
       bkt[k] = m.y;
     }
+    if (out != nullptr) {
 #pragma unroll
-    for (int k = 0; k < U; k++) v[k] = rows[(size_t)u[k] * ROW16 + c];
+      for (int k = 0; k < U; k++) v[k] = rows[(size_t)u[k] * ROW16 + c];
+    }
 #pragma unroll
     for (int k = 0; k < U; k++) {
       if (q0 + k < Q) {
-        out[(size_t)bkt[k] * ROW16 + c] = v[k];
+        if (out != nullptr) out[(size_t)bkt[k] * ROW16 + c] = v[k];
         if (c == 0) {
           sorted_rows[q0 + k] = u[k];
           sorted_buckets[q0 + k] = bkt[k];
+          if (row_of != nullptr) row_of[bkt[k]] = u[k];  // bucket -> row of the received table
         }
       }
     }
@@ -269,10 +273,11 @@ int hctr_uniq_gather_rows(size_t n_rows, int vec_size, const uint64_t* urow, con
 
 int hctr_uniq_expand(size_t positions, int n_owners, const int64_t* q_off, const int64_t* r_off,
                      const uint32_t* meta, const void* rows, int vec_size, int dtype, void* out,
-                     uint32_t* sorted_rows, uint32_t* sorted_buckets, hctr_stream_t stream) {
+                     uint32_t* sorted_rows, uint32_t* sorted_buckets, uint32_t* row_of,
+                     hctr_stream_t stream) {
   if (positions == 0) return HCTR_OK;
-  HCTR_REQUIRE(q_off && r_off && meta && rows && out && sorted_rows && sorted_buckets,
-               "null pointer");
+  HCTR_REQUIRE(q_off && r_off && meta && rows && sorted_rows && sorted_buckets, "null pointer");
+  HCTR_REQUIRE(out || row_of, "expand needs an output: the expanded tensor and / or row_of");
   const size_t row_bytes = (size_t)vec_size * (dtype == HCTR_EMB_F32 ? 4 : 2);
   HCTR_REQUIRE(row_bytes % 16 == 0, "row bytes must be a multiple of 16");
   HCTR_REQUIRE(reinterpret_cast<uintptr_t>(rows) % 16 == 0 &&
@@ -287,7 +292,7 @@ int hctr_uniq_expand(size_t positions, int n_owners, const int64_t* q_off, const
                        dim3(grid_for(ceil_div<size_t>(positions, 4), kBlock / R16, 8192)),        \
                        dim3(kBlock), 0, s, positions, n_owners, (const long long*)q_off,          \
                        (const long long*)r_off, meta, (const uint4*)rows, (uint4*)out,            \
-                       sorted_rows, sorted_buckets);                                              \
+                       sorted_rows, sorted_buckets, row_of);                                      \
     break;
   switch (row16) {
     HCTR_EXPAND_CASE(1)

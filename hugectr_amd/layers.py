@@ -39,6 +39,47 @@ class _InteractionFn(torch.autograd.Function):
         return mlp_grad, emb_grad
 
 
+class _InteractionIndexedFn(torch.autograd.Function):
+    """interaction over a table of distinct rows (unique-row exchange): embedding s of sample b is
+    rows[row_of[b, s]].  `on_emb_grad(dE)` receives the dense [B, n_emb, W] embedding gradient as
+    soon as it exists (the exchange reduces it per row); rows itself gets no gradient here."""
+
+    @staticmethod
+    def forward(ctx, mlp, rows, row_of, on_emb_grad):
+        mlp = mlp.contiguous()
+        B, W = mlp.shape
+        n_emb = row_of.shape[1]
+        n_ins = n_emb + 1
+        out = torch.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=mlp.dtype, device=mlp.device)
+        check(lib.hctr_interaction_fwd_indexed(B, n_emb, W, ptr(mlp), ptr(rows), ptr(row_of),
+                                               ptr(out), _DT[mlp.dtype], stream_ptr()))
+        ctx.save_for_backward(mlp, rows, row_of)
+        ctx.on_emb_grad = on_emb_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mlp, rows, row_of = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, W = mlp.shape
+        n_emb = row_of.shape[1]
+        mlp_grad = torch.empty_like(mlp)
+        emb_grad = torch.empty((B, n_emb, W), dtype=mlp.dtype, device=mlp.device)
+        check(lib.hctr_interaction_bwd_indexed(B, n_emb, W, ptr(mlp), ptr(rows), ptr(row_of),
+                                               ptr(grad), ptr(mlp_grad), ptr(emb_grad),
+                                               _DT[mlp.dtype], stream_ptr()))
+        if ctx.on_emb_grad is not None:
+            ctx.on_emb_grad(emb_grad)
+        return mlp_grad, None, None, None
+
+
+def interaction_indexed(mlp: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor,
+                        on_emb_grad=None) -> torch.Tensor:
+    """mlp [B,W], rows [R,W] (same 16-bit dtype), row_of int32 [B,n_emb] -> interaction output"""
+    assert rows.dtype == mlp.dtype and row_of.dtype == torch.int32 and rows.is_contiguous()
+    return _InteractionIndexedFn.apply(mlp, rows, row_of.contiguous(), on_emb_grad)
+
+
 def interaction(mlp: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
     """mlp [B,W], emb [B,n_emb,W] -> [B, W + n_ins(n_ins-1)/2 + 1] (last column zero)."""
     return _InteractionFn.apply(mlp, emb)

@@ -183,7 +183,10 @@ class UniqueExchange:
         self.meta, self.urow, self.peer_off = pl["meta"], pl["urow"], pl["peer_off"]
         self.meta_recv, self.counts = pl["meta_recv"], pl["counts"]
 
-    def forward_finish(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_finish(self, out: Optional[torch.Tensor] = None, indexed: bool = False):
+        """indexed = False: returns E [batch_per_gpu, slot_num, D].  indexed = True: returns
+        (rows [R, D], row_of int32 [batch_per_gpu, slot_num]) for `interaction_indexed` -- the
+        expanded tensor is never written."""
         emb, W, D = self.emb, self.world, self.D
         # the variable all-to-all needs the counts on the host: wait for their (pinned) copy only --
         # with a prefetched plan that copy finished during the previous step
@@ -198,11 +201,17 @@ class UniqueExchange:
              [u * D for u in self.u_recv], [u * D for u in self.u_send], self.group)
         r_off = torch.zeros(W + 1, dtype=torch.int64, device=emb.device)
         torch.cumsum(self.counts[:, self.rank], 0, out=r_off[1:])
-        if out is None:
+        row_of = None
+        if indexed:
+            row_of = torch.empty((self.bl, self.S), dtype=torch.int32, device=emb.device)
+        elif out is None:
             out = torch.empty((self.bl, self.S, D), dtype=self.dtype, device=emb.device)
         check(lib.hctr_uniq_expand(self.Q, W, ptr(self.q_off), ptr(r_off), ptr(self.meta_recv),
-                                   ptr(self.rows_recv), D, _EMB_DT[self.dtype], ptr(out),
-                                   ptr(self.sorted_rows), ptr(self.sorted_buckets), stream_ptr()))
+                                   ptr(self.rows_recv), D, _EMB_DT[self.dtype],
+                                   None if indexed else ptr(out), ptr(self.sorted_rows),
+                                   ptr(self.sorted_buckets), ptr(row_of), stream_ptr()))
+        if indexed:
+            return self.rows_recv[:max(n_recv, 1)], row_of
         return out
 
     def forward(self, row_offset: torch.Tensor, keys: torch.Tensor,

@@ -266,10 +266,13 @@ int hctr_uniq_gather_rows(size_t n_rows, int vec_size, const uint64_t* urow, con
                           void* out, int out_dtype, hctr_stream_t stream);
 /* receiver: out[bucket] = rows[r_off[owner] + index]; owner j holds positions [q_off[j], q_off[j+1])
  * (device int64 arrays); also emits the globally numbered sorted (row, bucket) list for
- * hctr_updater_reduce_presorted */
+ * hctr_updater_reduce_presorted.  out may be NULL when row_of (uint32 [buckets], bucket -> row of
+ * the received table) is requested instead: hctr_interaction_*_indexed read the rows through it and
+ * the expanded tensor is never materialised. */
 int hctr_uniq_expand(size_t positions, int n_owners, const int64_t* q_off, const int64_t* r_off,
                      const uint32_t* meta, const void* rows, int vec_size, int dtype, void* out,
-                     uint32_t* sorted_rows, uint32_t* sorted_buckets, hctr_stream_t stream);
+                     uint32_t* sorted_rows, uint32_t* sorted_buckets, uint32_t* row_of,
+                     hctr_stream_t stream);
 /* receiver backward: out_sum[row] = sum over the row's run of grad[bucket] (ascending position,
  * fp32), row_offset = int64 [buckets + 1] with row_offset[buckets] == positions */
 int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buckets,
@@ -295,6 +298,16 @@ int hctr_interaction_fwd(size_t batch, int n_emb, int width, const void* mlp, co
 int hctr_interaction_bwd(size_t batch, int n_emb, int width, const void* mlp, const void* emb,
                          const void* top_grad, void* mlp_grad, void* emb_grad, int dtype,
                          hctr_stream_t stream);
+
+/* Interaction on a table of distinct rows: embedding s of sample b is rows[row_of[b * n_emb + s]]
+ * (unique-row exchange).  16-bit dtypes, width 32/64/128, n_emb <= 31; emb_grad is the dense
+ * [batch][n_emb][width] gradient. */
+int hctr_interaction_fwd_indexed(size_t batch, int n_emb, int width, const void* mlp,
+                                 const void* rows, const uint32_t* row_of, void* out, int dtype,
+                                 hctr_stream_t stream);
+int hctr_interaction_bwd_indexed(size_t batch, int n_emb, int width, const void* mlp,
+                                 const void* rows, const uint32_t* row_of, const void* top_grad,
+                                 void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream);
 
 /* MultiCrossLayer<T> v1 (projection_dim = 0): x_{l+1} = x0 * (x_l . w_l) + b_l + x_l
  * (R/HugeCTR/src/layers/multi_cross_layer.cu:582-601,1023-1060).  kernels/biases [layers][w];

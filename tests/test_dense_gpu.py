@@ -195,3 +195,30 @@ def test_sum_groups_fixed_order():
     assert dw.dtype == torch.float32
     assert (dw.double() - ref).norm() / ref.norm() < 1e-2
     assert torch.equal(dw, split_k_wgrad(dy, x, 16))
+
+
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,n_emb,W", [(300, 26, 128), (65, 5, 64), (33, 10, 32), (70, 21, 128)])
+def test_interaction_indexed_equals_dense(dtype_name, B, n_emb, W):
+    """interaction over (rows, row_of) == interaction over the expanded tensor, bit for bit,
+    forward and both gradients"""
+    import torch
+    import hugectr_amd as ha
+    dt = getattr(torch, dtype_name)
+    g = torch.Generator(device="cuda").manual_seed(B + n_emb)
+    R = 97
+    rows = torch.randn(R, W, device="cuda", generator=g).to(dt)
+    row_of = torch.randint(0, R, (B, n_emb), device="cuda", generator=g, dtype=torch.int32)
+    mlp = torch.randn(B, W, device="cuda", generator=g).to(dt)
+    emb = rows[row_of.long()].contiguous()
+    m1, m2 = mlp.clone().requires_grad_(), mlp.clone().requires_grad_()
+    e1 = emb.clone().requires_grad_()
+    got = {}
+    out_i = ha.interaction_indexed(m2, rows, row_of, on_emb_grad=lambda d: got.setdefault("dE", d))
+    out_d = ha.interaction(m1, e1)
+    assert torch.equal(out_i, out_d)
+    top = torch.randn(out_d.shape, device="cuda", generator=g).to(dt)
+    out_d.backward(top)
+    out_i.backward(top)
+    assert torch.equal(m1.grad, m2.grad)
+    assert torch.equal(e1.grad, got["dE"])

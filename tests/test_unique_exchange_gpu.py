@@ -46,7 +46,11 @@ def _worker(rank, world, port, dtype_name, opt_name, sum16, ret):
         for step in range(5):
             kt = batches[step]
             ux.forward_begin(ro, kt)
-            E = ux.forward_finish()
+            if step == 3:   # the indexed form: distinct rows + (sample, slot) -> row table
+                rows_u, row_of = ux.forward_finish(indexed=True)
+                E = rows_u[row_of.long()].contiguous()
+            else:
+                E = ux.forward_finish()
             if step + 1 < 5 and step != 2:   # planned ahead, except once (inline path again)
                 ux.prefetch(ro, batches[step + 1])
             pooled = emb_d.forward(True, ro, kt)
