@@ -64,7 +64,7 @@ def test_new_entry_points_validate_before_touching_the_device():
     assert L.hctr_det_update(None, None, None, None, 0, None, None, 0, None, None, None) == -1
     assert L.hctr_uniq_create(0, None) == -1
     assert L.hctr_uniq_plan(None, 8, 4, 2, 2, 4, 0, 2, None, 100, None, None, None, None) == -1
-    assert L.hctr_uniq_expand(8, 2, None, None, None, None, 128, 2, None, None, None, None) == -1
+    assert L.hctr_uniq_expand(8, 2, None, None, None, None, 128, 2, None, None, None, None, None) == -1
     assert L.hctr_updater_reduce_presorted(None, 1, 1, None, None, None, None, 0, 1, None,
                                            None) == -1
     assert L.hctr_relu_bwd_bias(4, 12, None, None, None, None, None, 2, None) == -1
