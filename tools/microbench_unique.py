@@ -95,7 +95,7 @@ def main():
     sbkt = torch.empty(Qe, dtype=torch.int32, device="cuda")
     res["expand_us"] = timed(lambda: check(lib.hctr_uniq_expand(
         Qe, W, ptr(q_off), ptr(r_off), ptr(meta_r), ptr(rows_r_buf), D, _lib.BF16, ptr(E), ptr(srow),
-        ptr(sbkt), stream_ptr())))
+        ptr(sbkt), None, stream_ptr())))
     upd = ctypes.c_void_p()
     check(lib.hctr_updater_create(Qe, Qe, D, ctypes.byref(upd)))
     ar = torch.arange(max(Qe, U) + 1, dtype=torch.int64, device="cuda")
