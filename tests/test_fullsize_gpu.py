@@ -101,6 +101,39 @@ def test_fullsize_zero_gradient_update_is_identity_and_sgd_matches_fp64(criteo):
     assert err <= 1e-5 * scale, (err, scale)  # the hottest rows add ~20 k gradients in fp32
 
 
+def test_fullsize_multihot_pooling_is_linear_in_the_rows(criteo):
+    """ragged multi-hot CSR at full batch on the real table (flat key-walk kernel): every pooled
+    vector equals the fp64 sum of its rows (sum) / their mean, checked through an independent
+    torch segment reduction; empty buckets pool to exactly zero"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    emb, _, keys, (B, S, D, _) = criteo
+    table = emb.table()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nb = B * S
+    lens = torch.randint(0, 6, (nb,), device="cuda", generator=g)
+    lens[torch.rand(nb, device="cuda", generator=g) < 0.2] = 0
+    ro = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=ro[1:])
+    nnz = int(ro[-1])
+    rows = torch.randint(0, emb.get_vocabulary_size(), (nnz,), device="cuda", generator=g)
+    seg = torch.repeat_interleave(torch.arange(nb, device="cuda"), lens)
+    for comb in (0, 1):
+        out = torch.empty((nb, D), device="cuda")
+        _lib.check(_lib.lib.hctr_forward_pool_multihot(nb, D, comb, _lib.ptr(ro), _lib.KEY_I64,
+                                                       _lib.ptr(rows), _lib.ptr(table),
+                                                       _lib.ptr(out), _lib.F32, _lib.stream_ptr()))
+        # reference on a sample of buckets (an fp64 index_add over all 4 M rows x 128 is 4 GB: fine)
+        want = torch.zeros((nb, D), dtype=torch.float64, device="cuda")
+        want.index_add_(0, seg, table[rows].double())
+        if comb == 1:
+            want = want / lens.clamp_min(1).unsqueeze(1)
+        err = (out.double() - want).abs().max().item()
+        assert err <= 1e-6 * max(1.0, want.abs().max().item()), (comb, err)
+        assert float(out[lens == 0].abs().max()) == 0.0
+
+
 def test_fullsize_interaction_matches_fp32_bmm():
     import torch
     import hugectr_amd as ha
