@@ -254,6 +254,7 @@ using namespace hctr;
 
 struct hctr_updater {
   SparseUpdater impl;
+  float ftrl_lambda1 = 0.f, ftrl_lambda2 = 0.f, ftrl_beta = 0.f;
 };
 
 extern "C" {
@@ -440,6 +441,15 @@ int hctr_updater_create(size_t max_nnz, size_t max_rows, int vec_size, hctr_upda
   return HCTR_OK;
 }
 
+int hctr_updater_set_ftrl(hctr_updater* u, float lambda1, float lambda2, float beta) {
+  HCTR_REQUIRE(u, "null handle");
+  u->ftrl_lambda1 = lambda1;
+  u->ftrl_lambda2 = lambda2;
+  u->ftrl_beta = beta;
+  u->impl.allow_ftrl = true;
+  return HCTR_OK;
+}
+
 int hctr_updater_destroy(hctr_updater* u) {
   if (!u) return HCTR_OK;
   (void)hipDeviceSynchronize();
@@ -467,6 +477,10 @@ int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64
   o.scaler = scaler;
   o.atomic_update = 0;
   o.times = times;
+  o.ftrl_lambda1 = u->ftrl_lambda1;
+  o.ftrl_lambda2 = u->ftrl_lambda2;
+  o.ftrl_beta = u->ftrl_beta;
+  HCTR_REQUIRE(optimizer != HCTR_OPT_FTRL || (state0 && state1), "Ftrl needs state0 (n), state1 (z)");
   return u->impl.update(buckets, nnz, 0, bucket_range, HCTR_KEY_I64, indices, grad, grad_dtype, o,
                         table, state0, state1, nullptr, as_stream(stream));
 }

@@ -12,6 +12,7 @@ struct OptState {
   float momentum_factor = 0.f;
   float scaler = 1.f;
   int atomic_update = 0;
+  float ftrl_lambda1 = 0.f, ftrl_lambda2 = 0.f, ftrl_beta = 0.f;  // EBC static tables only
   uint64_t times = 0;  // Adam step counter (incremented before each update)
 };
 
@@ -41,6 +42,7 @@ struct SparseUpdater {
   uint32_t* span_count = nullptr;  // device counters: [0] span_list, [1] big_list
   uint32_t* big_list = nullptr;    // [tiles] start tiles of runs longer than kCombBigTiles tiles
   Profiler* prof = nullptr;
+  bool allow_ftrl = false;  // the legacy embedding rejects Ftrl as the reference does (q9)
   // the (row, bucket) sort needs only the index stage's output, not the gradients: presort() runs
   // it on a side stream while the caller's stream does the gather and the dense tower
   hipStream_t side = nullptr;

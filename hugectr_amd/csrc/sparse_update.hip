@@ -171,6 +171,7 @@ struct OptConst {
   float lr, beta1, beta2, epsilon, mf, scaler;
   float alpha_t;         // lr * adam.bias()
   float alpha_t_common;  // lr / (1 - beta1) (lazy adam)
+  float ftrl_l1, ftrl_l2b;  // lambda1, lambda2 + beta / lr
   unsigned long long times;
 };
 
@@ -187,6 +188,19 @@ __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w,
     case kOptStoreSum:
       w = gi;
       break;
+    case HCTR_OPT_FTRL: {  // FtrlOptimizer::update, ragged_static_embedding.cu:159-290 (s0 = n, s1 = z)
+      float ni = *s0p;
+      const float sq = sqrtf(ni + 1.1920929e-07f);
+      ni = ni + gi * gi;
+      const float sqn = sqrtf(ni + 1.1920929e-07f);
+      const float sigma = (sqn - sq) / o.lr;
+      const float zi = *s1p + gi - sigma * w;
+      const float p = (1.f - 2.f * (float)signbit(zi)) * o.ftrl_l1 - zi;
+      const float q = sqn / o.lr + o.ftrl_l2b;
+      w = p / q * (float)signbit(o.ftrl_l1 - fabsf(zi));
+      *s0p = ni;
+      *s1p = zi;
+    } break;
     case HCTR_OPT_ADAGRAD: {  // opt_adagrad_kernel :410-437 (Global == Local)
       float accum = *s0p + gi * gi;
       *s0p = accum;
@@ -246,7 +260,9 @@ __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w,
 __device__ __forceinline__ bool needs_s0(const OptConst& o) {
   return o.optimizer != HCTR_OPT_SGD && o.optimizer != kOptStoreSum;
 }
-__device__ __forceinline__ bool needs_s1(const OptConst& o) { return o.optimizer == HCTR_OPT_ADAM; }
+__device__ __forceinline__ bool needs_s1(const OptConst& o) {
+  return o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_FTRL;
+}
 __device__ __forceinline__ bool needs_pt(const OptConst& o) {
   return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
 }
@@ -991,6 +1007,8 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                              (1.0 - std::pow((double)opt.beta1, (double)opt.times)));
   o.alpha_t = opt.lr * bias;
   o.alpha_t_common = opt.lr / (1.0f - opt.beta1);
+  o.ftrl_l1 = opt.ftrl_lambda1;
+  o.ftrl_l2b = opt.ftrl_lambda2 + opt.ftrl_beta / opt.lr;
   const size_t table_elems = u.max_vocab * (size_t)D;
 
   if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
@@ -1245,6 +1263,9 @@ int SparseUpdater::update(size_t buckets, size_t nnz, int combiner, const void* 
     case HCTR_OPT_MOMENTUM_SGD:
     case HCTR_OPT_NESTEROV:
     case kOptStoreSum: break;
+    case HCTR_OPT_FTRL:
+      if (allow_ftrl) break;
+      [[fallthrough]];
     default:
       // Ftrl / RMSProp are not implemented by the reference's GPU update either
       set_error("sparse optimizer not supported (reference: sparse_optimizer.cu:821-826)");

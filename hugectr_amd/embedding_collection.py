@@ -68,12 +68,13 @@ class EmbeddingCollection:
     def __init__(self, config: EmbeddingCollectionConfig, global_batch: int, lr: float = 0.01,
                  optimizer: int = _lib.OPT_SGD, scaler: float = 1.0, epsilon: float = 1e-7,
                  initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
-                 key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None):
+                 key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None,
+                 ftrl=(0.0, 0.0, 0.0)):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._setup(config, global_batch, lr, optimizer, scaler, epsilon, initial_accu_value,
-                    out_dtype, batch_major, key_dtype, max_hotness, seed)
+                    out_dtype, batch_major, key_dtype, max_hotness, seed, ftrl)
 
     @classmethod
     def for_rank(cls, rank, world, *a, **kw):
@@ -85,15 +86,16 @@ class EmbeddingCollection:
 
     def _setup(self, config, global_batch, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1.0,
                epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
-               key_dtype=torch.int64, max_hotness=1, seed=0):
+               key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0)):
         assert global_batch % self.world == 0
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.B, self.bpg = global_batch, global_batch // self.world
         self.lr, self.optimizer, self.scaler, self.epsilon = lr, optimizer, scaler, epsilon
         self.out_dtype, self.batch_major, self.key_dtype = out_dtype, batch_major, key_dtype
-        if optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD):
-            # static EBC tables: SGD / AdaGrad / Ftrl only; Ftrl not implemented here
-            raise _lib.HugeCTRAmdError("EBC static tables support SGD and AdaGrad")
+        if optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_FTRL):
+            # static EBC tables: SGD / AdaGrad / Ftrl only
+            raise _lib.HugeCTRAmdError("EBC static tables support SGD, AdaGrad and Ftrl")
+        self.ftrl = tuple(float(x) for x in ftrl)  # (lambda1, lambda2, beta)
         tables: List[EmbeddingTableConfig] = []
         for t, _, _, _ in config.lookups:
             if t not in tables:
@@ -129,6 +131,10 @@ class EmbeddingCollection:
             self.table[s0:s0 + n].uniform_(-b, b, generator=g)
         self.accum = (torch.full_like(self.table, initial_accu_value)
                       if optimizer == _lib.OPT_ADAGRAD else None)
+        self.ftrl_z = None
+        if optimizer == _lib.OPT_FTRL:  # n and z start at zero (ragged_static_embedding.cu:484-496)
+            self.accum = torch.zeros_like(self.table)
+            self.ftrl_z = torch.zeros_like(self.table)
         # lookups resolved on this rank (ascending global lookup id) and their descriptors
         self.local_lookups = [l for l in range(self.L) if self.rank in self.owners[self.lookup_table[l]]]
         desc, rs = [], []
@@ -170,6 +176,8 @@ class EmbeddingCollection:
         self.counts = torch.zeros(self.L * self.bpg, dtype=torch.int64, device=self.dev)
         self._upd = ctypes.c_void_p()
         check(lib.hctr_updater_create(self.max_nnz, self.local_rows, self.ev, ctypes.byref(self._upd)))
+        if optimizer == _lib.OPT_FTRL:
+            check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
         self._nnz_host = 0
 
@@ -262,8 +270,8 @@ class EmbeddingCollection:
                                       ptr(self.indices), ptr(top_grad.contiguous()),
                                       _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,
                                       self.lr, 0.9, 0.999, self.epsilon, 0.0, self.scaler,
-                                      self._times, ptr(self.table), ptr(self.accum), None,
-                                      stream_ptr()))
+                                      self._times, ptr(self.table), ptr(self.accum),
+                                      ptr(self.ftrl_z), stream_ptr()))
 
     # -- whole passes --------------------------------------------------------------------------------
     def forward(self, keys: torch.Tensor, bucket_range: torch.Tensor) -> torch.Tensor:

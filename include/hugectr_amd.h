@@ -240,6 +240,9 @@ int hctr_ebc_network_backward(size_t batch_per_gpu, int num_lookup, int ev_size,
 typedef struct hctr_updater hctr_updater;
 int hctr_updater_create(size_t max_nnz, size_t max_rows, int vec_size, hctr_updater** out);
 int hctr_updater_destroy(hctr_updater* u);
+/* Ftrl hyper-parameters for optimizer = HCTR_OPT_FTRL (FtrlOptimizer,
+ * R/HugeCTR/embedding_storage/ragged_static_embedding.cu:159-290): state0 = n, state1 = z */
+int hctr_updater_set_ftrl(hctr_updater* u, float lambda1, float lambda2, float beta);
 int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
                         const uint64_t* indices, const void* grad, int grad_dtype, int optimizer,
                         int update_type, float lr, float beta1, float beta2, float epsilon,

@@ -771,7 +771,8 @@ void hco_ebc_backward_update(int64_t batch, int64_t num_lookup, const int32_t* t
                              const int64_t* bucket_range, const int64_t* table_row_start,
                              int64_t total_rows, int64_t num_gpus, int batch_major,
                              const float* top_grad, int optimizer, float lr, float scaler,
-                             float epsilon, float* tables, float* accum) {
+                             float epsilon, float* tables, float* accum, float ftrl_lambda1,
+                             float ftrl_lambda2, float ftrl_beta, float* ftrl_z) {
   const int64_t bpg = batch / num_gpus;
   const int64_t ev_total = ev * num_lookup;
   float* sum = (float*)calloc((size_t)(total_rows * ev), sizeof(float));
@@ -805,11 +806,27 @@ void hco_ebc_backward_update(int64_t batch, int64_t num_lookup, const int32_t* t
       float gi = sum[row * ev + x];
       if (optimizer == 0) {
         tables[row * ev + x] += -lr * gi / scaler;
-      } else {
+      } else if (optimizer == 1) {
         gi = gi / scaler;
         float vi = accum[row * ev + x] + gi * gi;
         accum[row * ev + x] = vi;
         tables[row * ev + x] += -lr * gi / (sqrtf(vi) + epsilon);
+      } else {
+        /* FtrlOptimizer::update, ragged_static_embedding.cu:159-290 (accum = n, ftrl_z = z) */
+        const float l2b = ftrl_lambda2 + ftrl_beta / lr;
+        gi = gi / scaler;
+        float ni = accum[row * ev + x];
+        const float sq = sqrtf(ni + 1.1920929e-07f);
+        ni = ni + gi * gi;
+        const float sqn = sqrtf(ni + 1.1920929e-07f);
+        const float sigma = (sqn - sq) / lr;
+        const float w = tables[row * ev + x];
+        const float zi = ftrl_z[row * ev + x] + gi - sigma * w;
+        const float pq = ((1.f - 2.f * (float)(signbit(zi) != 0)) * ftrl_lambda1 - zi) /
+                         (sqn / lr + l2b);
+        tables[row * ev + x] = pq * (float)(signbit(ftrl_lambda1 - fabsf(zi)) != 0);
+        accum[row * ev + x] = ni;
+        ftrl_z[row * ev + x] = zi;
       }
     }
   }

@@ -112,8 +112,10 @@ void hco_ebc_backward_update(int64_t batch, int64_t num_lookup, const int32_t* t
                              int64_t ev, const int32_t* combiners, const int64_t* keys,
                              const int64_t* bucket_range, const int64_t* table_row_start,
                              int64_t total_rows, int64_t num_gpus, int batch_major,
-                             const float* top_grad, int optimizer, float lr, float scaler,
-                             float epsilon, float* tables, float* accum);
+                             const float* top_grad, int optimizer /* 0 SGD, 1 AdaGrad, 2 Ftrl */,
+                             float lr, float scaler, float epsilon, float* tables, float* accum,
+                             float ftrl_lambda1, float ftrl_lambda2, float ftrl_beta,
+                             float* ftrl_z);
 void hco_keys_to_indices(int64_t n, const int64_t* keys, int64_t table_start, int64_t num_shards,
                          int64_t* idx);
 

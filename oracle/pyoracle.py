@@ -91,7 +91,8 @@ def lib():
         L.hco_ebc_backward_update.argtypes = [c_int64, c_int64, c_void_p, c_int64, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                               c_int, c_void_p, c_int, c_float, c_float, c_float,
-                                              c_void_p, c_void_p]
+                                              c_void_p, c_void_p, c_float, c_float, c_float,
+                                              c_void_p]
         L.hco_keys_to_indices.argtypes = [c_int64, c_void_p, c_int64, c_int64, c_void_p]
         L.hco_powerlaw_keys.argtypes = [c_uint32, c_int64, c_int64, c_float, c_void_p]
         _lib = L
@@ -330,7 +331,7 @@ def ebc_forward(batch, table_ids, ev, combiners, keys, bucket_range, table_row_s
 
 def ebc_backward_update(batch, table_ids, ev, combiners, keys, bucket_range, table_row_start,
                         tables, top_grad, optimizer=0, lr=0.1, scaler=1.0, epsilon=1e-7, accum=None,
-                        num_gpus=1, batch_major=False):
+                        num_gpus=1, batch_major=False, ftrl=(0.0, 0.0, 0.0), ftrl_z=None):
     """in place on `tables` (flat [total_rows, ev] float32, C-contiguous) and `accum`."""
     t = np.ascontiguousarray(table_ids, dtype=np.int32)
     c = np.ascontiguousarray(combiners, dtype=np.int32)
@@ -341,7 +342,8 @@ def ebc_backward_update(batch, table_ids, ev, combiners, keys, bucket_range, tab
     assert tables.flags.c_contiguous and tables.dtype == np.float32
     lib().hco_ebc_backward_update(batch, len(table_ids), _p(t), ev, _p(c), _p(k), _p(br), _p(rs),
                                   tables.shape[0], num_gpus, 1 if batch_major else 0, _p(g),
-                                  optimizer, lr, scaler, epsilon, _p(tables), _p(accum))
+                                  optimizer, lr, scaler, epsilon, _p(tables), _p(accum),
+                                  float(ftrl[0]), float(ftrl[1]), float(ftrl[2]), _p(ftrl_z))
 
 
 # ---- mixed precision: the 16-bit embedding output / gradient modes -------------------

@@ -38,7 +38,7 @@ def test_keys_to_indices_bit_exact(oracle):
 
 @pytest.mark.parametrize("world,shard", [(1, "table"), (2, "table"), (4, "row"), (2, "mixed")])
 @pytest.mark.parametrize("batch_major", [False, True])
-@pytest.mark.parametrize("opt_name", ["sgd", "adagrad"])
+@pytest.mark.parametrize("opt_name", ["sgd", "adagrad", "ftrl"])
 def test_ebc_forward_backward_update(oracle, world, shard, batch_major, opt_name):
     import torch
     import hugectr_amd as ha
@@ -60,9 +60,11 @@ def test_ebc_forward_backward_update(oracle, world, shard, batch_major, opt_name
     else:  # table 0 and 3 table-wise, 1 and 2 row-wise over all ranks
         sm = [[1 if g == 0 else 0, 1, 1, 1 if g == world - 1 else 0] for g in range(world)]
     cfg.shard(sm)
-    opt = _lib.OPT_SGD if opt_name == "sgd" else _lib.OPT_ADAGRAD
+    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "ftrl": _lib.OPT_FTRL}[opt_name]
+    ftrl = (0.02, 0.05, 0.3)  # lambda1, lambda2, beta
     ranks = [ha.EmbeddingCollection.for_rank(r, world, cfg, B, lr=0.1, optimizer=opt, scaler=2.0,
-                                             epsilon=1e-6, batch_major=batch_major, max_hotness=4)
+                                             epsilon=1e-6, batch_major=batch_major, max_hotness=4,
+                                             ftrl=ftrl)
              for r in range(world)]
     # dense "logical" tables for the oracle, assembled from the shards (row = key)
     row_start = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).astype(np.int64)
@@ -75,6 +77,7 @@ def test_ebc_forward_backward_update(oracle, world, shard, batch_major, opt_name
             keys_of_shard = np.arange(sid, vocabs[t], len(owners))
             dense[row_start[t] + keys_of_shard] = e.table[s0:s0 + keys_of_shard.size].cpu().numpy()
     accum = np.zeros_like(dense)
+    ftrl_z = np.zeros_like(dense)
     bpg = B // world
     for it in range(2):
         keys, br = _make_inputs(rng, B, vocabs, lookup_table, 4)
@@ -107,8 +110,9 @@ def test_ebc_forward_backward_update(oracle, world, shard, batch_major, opt_name
         torch.cuda.synchronize()
         oracle.ebc_backward_update(B, lookup_table, ev, [0 if c == "sum" else 1 for c in combiners],
                                    keys, br, row_start, dense, np.stack([g.reshape(-1) for g in grads]),
-                                   optimizer=0 if opt_name == "sgd" else 1, lr=0.1, scaler=2.0,
-                                   epsilon=1e-6, accum=accum, num_gpus=world, batch_major=batch_major)
+                                   optimizer={"sgd": 0, "adagrad": 1, "ftrl": 2}[opt_name], lr=0.1,
+                                   scaler=2.0, epsilon=1e-6, accum=accum, num_gpus=world,
+                                   batch_major=batch_major, ftrl=ftrl, ftrl_z=ftrl_z)
         for t in range(T):
             owners = ranks[0].owners[t]
             for sid, g in enumerate(owners):
