@@ -227,6 +227,12 @@ def main():
         top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
     dense_params = list(bottom.parameters()) + list(top.parameters())
     dense_opt = torch.optim.SGD(dense_params, lr=0.01)
+    # flat master / gradient / 16-bit buffers: backward writes gradients in place, the SGD step and
+    # the shadow refresh are one kernel per MLP, the data-parallel all-reduce needs no packing
+    flat_mode = amp and C == 1 and a.graph != "on"
+    if flat_mode:
+        bottom.flatten()
+        top.flatten()
     loss_fn = torch.nn.BCEWithLogitsLoss()
     pooled = torch.empty((B, spr, D), dtype=edt, device=dev)
     top_grad = torch.empty((B, spr, D), dtype=edt, device=dev) if world > 1 or C > 1 else None
@@ -297,7 +303,23 @@ def main():
             graph = None
             dense_opt.zero_grad(set_to_none=True)
 
+    def dense_update():
+        if flat_mode:
+            bottom.sgd_step(0.01)
+            top.sgd_step(0.01)
+            return
+        dense_opt.step()
+        dense_opt.zero_grad(set_to_none=(graph is None))
+        if amp:
+            bottom.refresh_shadow()
+            top.refresh_shadow()
+
     def finish_step():
+        if world > 1 and flat_mode:
+            for m in (bottom, top):
+                par_all_reduce(m.flat_g)
+                m.flat_g /= world
+            return
         if world > 1:
             grads = [p.grad for p in dense_params]
             flat = torch.cat([x.reshape(-1) for x in grads])
@@ -338,11 +360,7 @@ def main():
             loss = dense_chunk(dense_k, label_k, None, get_E=get_E, on_E_grad=ux.backward_begin)
         finish_step()
         ux.backward_finish()
-        dense_opt.step()
-        dense_opt.zero_grad(set_to_none=True)
-        if amp:
-            bottom.refresh_shadow()
-            top.refresh_shadow()
+        dense_update()
         return loss
 
     def step(i):
@@ -414,14 +432,7 @@ def main():
         finish_step()
         emb.backward(tg)
         emb.update_params()
-        dense_opt.step()
-        if graph is not None:
-            dense_opt.zero_grad(set_to_none=False)  # gradients are static graph buffers
-        else:
-            dense_opt.zero_grad(set_to_none=True)
-        if amp:
-            bottom.refresh_shadow()
-            top.refresh_shadow()
+        dense_update()  # (static graph gradient buffers are zeroed in place, not released)
         return total
 
     emb.profiling(True)

@@ -137,6 +137,7 @@ _SIGNATURES = {
     "hctr_relu_bwd_bias_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_relu_bwd_bias": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_sum_groups": (c_int, [c_int, c_size_t, _P, c_int, _P, _P]),
+    "hctr_sgd_shadow": (c_int, [c_size_t, c_float, c_float, _P, _P, _P, c_int, _P]),
     "hctr_bce_loss_workspace_bytes": (c_size_t, []),
     "hctr_bce_loss": (c_int, [c_size_t, _P, _P, c_float, _P, _P, _P, c_int, _P]),
     "hctr_cross_v2_epilogue": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -943,6 +943,24 @@ __global__ void __launch_bounds__(kBlock)
   o[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
 
+// dense SGD step fused with the refresh of the 16-bit compute copy: w -= lr * g; w16 = (T16)w
+template <bool BF>
+__global__ void __launch_bounds__(kBlock)
+    sgd_shadow_kernel(size_t n4, float lr, float grad_scale, float* __restrict__ w,
+                      const float* __restrict__ g, unsigned short* __restrict__ w16) {
+  using H = H16<BF>;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4;
+       i += (size_t)gridDim.x * kBlock) {
+    f32x4 wv = reinterpret_cast<f32x4*>(w)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    wv -= lr * grad_scale * gv;
+    reinterpret_cast<f32x4*>(w)[i] = wv;
+    const unsigned lo = (unsigned)H::from_f32(wv[0]) | ((unsigned)H::from_f32(wv[1]) << 16);
+    const unsigned hi = (unsigned)H::from_f32(wv[2]) | ((unsigned)H::from_f32(wv[3]) << 16);
+    reinterpret_cast<uint2*>(w16)[i] = make_uint2(lo, hi);
+  }
+}
+
 // ================================================================================================
 // BinaryCrossEntropyLoss (R/HugeCTR/src/loss.cu:231-262): per-sample stable BCE-with-logits,
 // the logit gradient scaled by grad_scale (= scaler / batch / total_gpu_count in the reference),
@@ -1333,6 +1351,24 @@ int hctr_sum_groups(int groups, size_t n, const void* in, int dtype, float* out,
   else
     hipLaunchKernelGGL(sum_groups_kernel<false>, grid, dim3(kBlock), 0, s, groups, n8,
                        (const unsigned short*)in, out);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_sgd_shadow(size_t n, float lr, float grad_scale, float* w, const float* g, void* w16,
+                    int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(n % 4 == 0, "n must be a multiple of 4");
+  HCTR_REQUIRE(dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16, "16-bit shadow dtypes only");
+  if (n == 0) return HCTR_OK;
+  HCTR_REQUIRE(w && g && w16, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(grid_for(n / 4, kBlock, 4096));
+  if (dtype == HCTR_EMB_BF16)
+    hipLaunchKernelGGL(sgd_shadow_kernel<true>, grid, dim3(kBlock), 0, s, n / 4, lr, grad_scale, w,
+                       g, (unsigned short*)w16);
+  else
+    hipLaunchKernelGGL(sgd_shadow_kernel<false>, grid, dim3(kBlock), 0, s, n / 4, lr, grad_scale,
+                       w, g, (unsigned short*)w16);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

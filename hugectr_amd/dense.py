@@ -24,8 +24,10 @@ _DT16 = {torch.float16: 1, torch.bfloat16: 2}  # hctr_emb_dtype_t
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16) -> torch.Tensor:
-    """dW = dy^T @ x with the batch (K) dimension split into `groups` batched GEMMs."""
+def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16,
+                  out: torch.Tensor = None) -> torch.Tensor:
+    """dW = dy^T @ x with the batch (K) dimension split into `groups` batched GEMMs (fp32 result,
+    written to `out` when given)."""
     B, o = dy.shape
     i = x.shape[1]
     g = groups
@@ -35,13 +37,22 @@ def split_k_wgrad(dy: torch.Tensor, x: torch.Tensor, groups: int = 16) -> torch.
         # degenerate outputs (the logit layer, out = 1): the batched-GEMM path of the library
         # spends ~11 ms per call on the HOST for M = 1 (tools/gemm_probe2.py); one GEMV-like call
         # is 50-100 us
-        return dy.t() @ x
+        r = dy.t() @ x
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
     p = torch.bmm(dy.view(g, B // g, o).transpose(1, 2), x.view(g, B // g, i))
     if p.is_cuda and p.dtype in _DT16 and (o * i) % 8 == 0:
-        out = torch.empty((o, i), dtype=torch.float32, device=p.device)
+        if out is None:
+            out = torch.empty((o, i), dtype=torch.float32, device=p.device)
         check(lib.hctr_sum_groups(g, o * i, ptr(p), _DT16[p.dtype], ptr(out), stream_ptr()))
         return out
-    return p.float().sum(0)
+    r = p.float().sum(0)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 def bce_with_logits(logit: torch.Tensor, label: torch.Tensor, grad_scale: float):
@@ -64,8 +75,11 @@ class _LinearFn(torch.autograd.Function):
     """y = act(x @ W^T + b) on 16-bit shadow weights; gradients returned for the fp32 masters."""
 
     @staticmethod
-    def forward(ctx, x, w_master, b_master, w16, b16, relu: bool, groups: int):
+    def forward(ctx, x, w_master, b_master, w16, b16, relu: bool, groups: int, gw=None, gb=None):
+        """gw / gb: views of the module's flat gradient buffer; when given, backward writes the
+        weight / bias gradients there and returns no gradient for the masters"""
         x = x.contiguous()
+        ctx.gw, ctx.gb = gw, gb
         if relu:
             y = torch._addmm_activation(b16, x, w16.t(), use_gelu=False)
         else:
@@ -82,7 +96,8 @@ class _LinearFn(torch.autograd.Function):
         if ctx.relu and n % 8 == 0 and dy.dtype in _DT16 and dy.is_cuda:
             # fused ReLU backward + bias gradient (HIP): one pass instead of two
             dz = torch.empty_like(dy)
-            db = torch.empty(n, dtype=torch.float32, device=dy.device)
+            db = ctx.gb if ctx.gb is not None else torch.empty(n, dtype=torch.float32,
+                                                             device=dy.device)
             ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(dy.shape[0], n) // 4,
                              dtype=torch.float32, device=dy.device)
             check(lib.hctr_relu_bwd_bias(dy.shape[0], n, ptr(dy), ptr(y), ptr(dz), ptr(db), ptr(ws),
@@ -92,9 +107,13 @@ class _LinearFn(torch.autograd.Function):
             if ctx.relu:
                 dy = torch.ops.aten.threshold_backward(dy, y, 0)
             db = dy.sum(0, dtype=torch.float32)
+            if ctx.gb is not None:
+                ctx.gb.copy_(db)
         dx = dy @ w16 if ctx.needs_input_grad[0] else None
-        dw = split_k_wgrad(dy, x, ctx.groups)
-        return dx, dw.float(), db, None, None, None, None
+        dw = split_k_wgrad(dy, x, ctx.groups, out=ctx.gw)
+        if ctx.gw is not None:  # gradients live in the flat buffer; nothing for autograd to keep
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dw.float(), db, None, None, None, None, None, None
 
 
 class FusedMLP(torch.nn.Module):
@@ -118,9 +137,49 @@ class FusedMLP(torch.nn.Module):
             self.biases.append(torch.nn.Parameter(lin.bias.detach().clone()))
         self._w16: List[torch.Tensor] = []
         self._b16: List[torch.Tensor] = []
+        self.flat_w = self.flat_g = self.flat_w16 = None
+        self._gw: List[torch.Tensor] = []
+        self._gb: List[torch.Tensor] = []
+
+    def flatten(self):
+        """Move masters, gradients and 16-bit copies into three flat buffers (parameters become
+        views).  Afterwards backward writes gradients straight into `flat_g`, `sgd_step` is one
+        kernel (update + shadow refresh), and a data-parallel all-reduce runs on `flat_g` as is."""
+        dev = self.weights[0].device
+        sizes = [p.numel() for p in list(self.weights) + list(self.biases)]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4  # every view starts 16-byte aligned
+        self.flat_w = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.flat_w16 = torch.zeros(tot, dtype=self.dtype, device=dev)
+        params = list(self.weights) + list(self.biases)
+        views16 = []
+        self._gw, self._gb = [], []
+        for p, o, n in zip(params, offs, sizes):
+            v = self.flat_w[o:o + n].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            views16.append(self.flat_w16[o:o + n].view_as(p))
+        nl = len(self.weights)
+        self._w16, self._b16 = views16[:nl], views16[nl:]
+        gviews = [self.flat_g[o:o + n].view_as(p) for p, o, n in zip(params, offs, sizes)]
+        self._gw, self._gb = gviews[:nl], gviews[nl:]
+        self.flat_w16.copy_(self.flat_w)
+        return self
+
+    def sgd_step(self, lr: float, grad_scale: float = 1.0):
+        """w -= lr * grad_scale * g and refresh of the 16-bit copy, one launch (after flatten())"""
+        check(lib.hctr_sgd_shadow(self.flat_w.numel(), float(lr), float(grad_scale),
+                                  ptr(self.flat_w), ptr(self.flat_g), ptr(self.flat_w16),
+                                  _DT16[self.dtype], stream_ptr()))
 
     def refresh_shadow(self):
         """call after every optimizer step (and once after .to(device))"""
+        if self.flat_w is not None:
+            self.flat_w16.copy_(self.flat_w)
+            return
         if not self._w16:
             self._w16 = [w.detach().to(self.dtype) for w in self.weights]
             self._b16 = [b.detach().to(self.dtype) for b in self.biases]
@@ -135,5 +194,7 @@ class FusedMLP(torch.nn.Module):
         x = x.to(self.dtype)
         for i in range(len(self.weights)):
             x = _LinearFn.apply(x, self.weights[i], self.biases[i], self._w16[i], self._b16[i],
-                                self.relu[i], self.wgrad_groups)
+                                self.relu[i], self.wgrad_groups,
+                                self._gw[i] if self._gw else None,
+                                self._gb[i] if self._gb else None)
         return x

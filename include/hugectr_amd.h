@@ -401,6 +401,12 @@ int hctr_relu_bwd_bias(size_t rows, int n, const void* dy, const void* y, void* 
 int hctr_sum_groups(int groups, size_t n, const void* in, int dtype, float* out,
                     hctr_stream_t stream);
 
+/* dense SGD on a flat fp32 parameter buffer fused with the refresh of its 16-bit compute copy
+ * (SGDOptimizer + the mixed-precision weight conversion of the reference's dense layers):
+ * w -= lr * grad_scale * g; w16 = (16-bit)w.  n % 4 == 0, 16-byte aligned buffers. */
+int hctr_sgd_shadow(size_t n, float lr, float grad_scale, float* w, const float* g, void* w16,
+                    int dtype, hctr_stream_t stream);
+
 /* BinaryCrossEntropyLoss (R/HugeCTR/src/loss.cu:231-262): *loss = mean_i bce(logit_i, label_i);
  * dlogit_i = (sigmoid(logit_i) - label_i) * grad_scale (grad_scale = scaler / batch / total_gpu_count
  * in the reference); dlogit may be NULL (evaluation).  dtype of logit/dlogit: hctr_emb_dtype_t.

@@ -222,3 +222,38 @@ def test_interaction_indexed_equals_dense(dtype_name, B, n_emb, W):
     out_i.backward(top)
     assert torch.equal(m1.grad, m2.grad)
     assert torch.equal(e1.grad, got["dE"])
+
+
+def test_fused_mlp_flat_mode_equals_parameter_mode():
+    """flatten(): gradients written straight into the flat buffer and the fused SGD + shadow-refresh
+    kernel give the same weights as torch.optim.SGD on the unflattened module"""
+    import copy
+    import torch
+    from hugectr_amd.dense import FusedMLP
+    torch.manual_seed(11)
+    a = FusedMLP([40, 128, 64, 1], last_relu=False).cuda()
+    b = copy.deepcopy(a)
+    a.refresh_shadow()
+    b.flatten()
+    opt = torch.optim.SGD(a.parameters(), lr=0.05)
+    for step in range(3):
+        x = torch.randn(4096, 40, device="cuda")
+        ya, yb = a(x), b(x)
+        # same math; the library may pick another GEMM kernel for the flat views, and after a step
+        # the masters agree to an fp32 ulp, so single bf16 weights may round differently
+        assert torch.allclose(ya.float(), yb.float(), rtol=2e-2, atol=2e-2)
+        gy = torch.randn_like(ya)
+        ya.backward(gy)
+        yb.backward(gy)
+        for p, gw in zip(list(a.weights) + list(a.biases), b._gw + b._gb):
+            assert (p.grad - gw).norm() <= 2e-2 * p.grad.norm() + 1e-6, "flat gradient differs"
+        assert all(p.grad is None for p in b.parameters())
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        a.refresh_shadow()
+        b.sgd_step(0.05)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert (pa - pb).norm() <= 1e-3 * pa.norm() + 1e-6
+        for wa, wb in zip(a._w16 + a._b16, b._w16 + b._b16):
+            # the masters agree to one fp32 ulp (fma vs mul+sub), so a bf16 rounding may flip
+            assert (wa.float() - wb.float()).norm() <= 1e-2 * wa.float().norm() + 1e-6
