@@ -115,6 +115,11 @@ _SIGNATURES = {
     "hctr_det_export": (c_int, [_P, c_size_t, _P, _P, c_size_t, _SZP, _P]),
     "hctr_det_lookup_index": (c_int, [_P, c_size_t, _P, c_size_t, c_int, _P, _P]),
     "hctr_det_rows": (c_int, [_P, c_size_t, POINTER(_P), _SZP]),
+    "hctr_det_lookup_rows": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, c_int, _P, _P,
+                                     POINTER(c_uint64), _P]),
+    "hctr_forward_pool_ptrs": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_ebc_local_reduce": (c_int, [_P, c_size_t, c_size_t, _P, _P, c_uint64, _P, _P, c_int, _SZP,
+                                      _P, _P, _P, _P]),
     "hctr_det_clear": (c_int, [_P, _P]),
     "hctr_det_size_per_class": (c_int, [_P, _SZP, _P]),
     "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),

@@ -104,6 +104,19 @@ __global__ void __launch_bounds__(kBlock)
     out[i] = idx[i] != kInvalidIndex ? rows + idx[i] * (uint64_t)dim : nullptr;
 }
 
+// pointer and / or globally numbered row (row_base + row inside the class) of every key
+__global__ void __launch_bounds__(kBlock)
+    det_rows_kernel(const uint64_t* __restrict__ idx, size_t n, float* rows, int dim,
+                    uint64_t row_base, float** __restrict__ out_ptr,
+                    uint64_t* __restrict__ out_row) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const uint64_t r = idx[i];
+    if (out_ptr) out_ptr[i] = r != kInvalidIndex ? rows + r * (uint64_t)dim : nullptr;
+    if (out_row) out_row[i] = r != kInvalidIndex ? row_base + r : kInvalidIndex;
+  }
+}
+
 // dynamic_map_kernels.cuh:143-183: keys that are not in the map are skipped
 template <bool ADD>
 __global__ void __launch_bounds__(kBlock)
@@ -465,14 +478,57 @@ int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size
   HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
   HCTR_TRY(det_scratch(h, num_keys));
   // two passes: every insertion (and so every re-allocation) happens before a pointer is taken
-  for (const Range& r : rs)
-    if (r.n) HCTR_TRY(class_reserve(h->cls[r.cls], r.n, h->key_type, s));
+  // (a class may own several ranges: reserve their sum, or a later range could move the store)
+  std::vector<size_t> need(h->cls.size(), 0);
+  for (const Range& r : rs) need[r.cls] += r.n;
+  for (size_t ci = 0; ci < need.size(); ci++)
+    if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
   for (const Range& r : rs) {
     DetClass& c = h->cls[r.cls];
     if (r.n == 0) continue;
     HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
     hipLaunchKernelGGL(det_ptr_kernel, dim3(grid_for(r.n, kBlock, 1024)), dim3(kBlock), 0, s,
                        h->idx, r.n, c.rows, c.dim, elements + r.off);
+    HCTR_LAUNCH_CHECK();
+  }
+  return HCTR_OK;
+}
+
+int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
+                         const size_t* id_space_offsets, size_t num_id_spaces, int insert,
+                         float** elements, uint64_t* row_index, uint64_t* class_row_base,
+                         hctr_stream_t stream) {
+  HCTR_REQUIRE(h, "null handle");
+  hipStream_t s = as_stream(stream);
+  std::vector<Range> rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  if (num_keys) {
+    HCTR_REQUIRE(keys && (elements || row_index), "null pointer");
+    HCTR_TRY(det_scratch(h, num_keys));
+  }
+  // every insertion (and so every re-allocation) happens before a pointer or a row base is taken
+  if (insert) {
+    std::vector<size_t> need(h->cls.size(), 0);
+    for (const Range& r : rs) need[r.cls] += r.n;
+    for (size_t ci = 0; ci < need.size(); ci++)
+      if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
+  }
+  std::vector<uint64_t> base(h->cls.size() + 1, 0);
+  for (size_t ci = 0; ci < h->cls.size(); ci++) base[ci + 1] = base[ci] + h->cls[ci].cap;
+  if (class_row_base)
+    for (size_t ci = 0; ci <= h->cls.size(); ci++) class_row_base[ci] = base[ci];
+  for (const Range& r : rs) {
+    DetClass& c = h->cls[r.cls];
+    if (r.n == 0) continue;
+    const void* kp = key_at(h, keys, r.off);
+    if (insert)
+      HCTR_TRY(class_lookup_insert(h, c, r.cls, kp, r.n, h->idx, s));
+    else
+      HCTR_TRY(c.ht.get_mark(kp, r.n, nullptr, h->idx, s));
+    hipLaunchKernelGGL(det_rows_kernel, dim3(grid_for(r.n, kBlock, 1024)), dim3(kBlock), 0, s,
+                       h->idx, r.n, c.rows, c.dim, base[r.cls],
+                       elements ? elements + r.off : nullptr,
+                       row_index ? row_index + r.off : nullptr);
     HCTR_LAUNCH_CHECK();
   }
   return HCTR_OK;

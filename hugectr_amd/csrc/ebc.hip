@@ -16,6 +16,8 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "common.h"
 #include "scan.h"
 #include "sparse_update.h"
@@ -89,8 +91,54 @@ __global__ void __launch_bounds__(kBlock)
     for (size_t q = (size_t)bucket_range[sb]; q < (size_t)bucket_range[sb + 1]; q++) {
       const long long k = (long long)keys[q];
       if (k % d.num_shards == d.shard_id)
-        out_idx[dst++] = (uint64_t)(d.row_start + k / d.num_shards);  // keys_to_indices.cu:31-42
+        // keys_to_indices.cu:31-42; row_start < 0: dynamic table, the key itself is kept
+        out_idx[dst++] = d.row_start < 0 ? (uint64_t)k : (uint64_t)(d.row_start + k / d.num_shards);
     }
+  }
+}
+
+// ---- LocalReduceIndexCalculation + LocalReduce (R/HugeCTR/embedding/operators/
+//      index_calculation.cu, model_backward.cu:113-...): sort the keys of the local lookups by
+//      row id, find the unique ones, sum the gradients of every unique row (ascending position).
+__global__ void __launch_bounds__(kBlock)
+    lr_expand_kernel(size_t buckets, const long long* __restrict__ bucket_range,
+                     uint32_t* __restrict__ pos_bucket, uint32_t* __restrict__ pos_iota) {
+  for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < buckets;
+       b += (size_t)gridDim.x * kBlock)
+    for (long long q = bucket_range[b]; q < bucket_range[b + 1]; q++) {
+      pos_bucket[q] = (uint32_t)b;
+      pos_iota[q] = (uint32_t)q;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    lr_flags_kernel(size_t n, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ flags) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock)
+    flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
+}
+
+// heads_before[i] = number of run heads in [0, i): compact id of position i = heads_before[i] +
+// flag[i] - 1
+__global__ void __launch_bounds__(kBlock)
+    lr_emit_kernel(size_t n, const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ pos,
+                   const uint32_t* __restrict__ flags, const uint32_t* __restrict__ heads_before,
+                   const uint32_t* __restrict__ pos_bucket, const uint64_t* __restrict__ src_keys,
+                   uint32_t* __restrict__ sorted_cid, uint32_t* __restrict__ sorted_bucket,
+                   uint64_t* __restrict__ unique_rows, uint64_t* __restrict__ unique_keys,
+                   uint64_t* __restrict__ d_num_unique) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const uint32_t f = flags[i];
+    const uint32_t cid = heads_before[i] + f - 1u;
+    const uint32_t p = pos[i];
+    sorted_cid[i] = cid;
+    sorted_bucket[i] = pos_bucket[p];
+    if (f) {
+      unique_rows[cid] = sorted[i];
+      if (unique_keys) unique_keys[cid] = src_keys[p];
+    }
+    if (i == n - 1) *d_num_unique = (uint64_t)cid + 1;
   }
 }
 
@@ -255,6 +303,47 @@ using namespace hctr;
 struct hctr_updater {
   SparseUpdater impl;
   float ftrl_lambda1 = 0.f, ftrl_lambda2 = 0.f, ftrl_beta = 0.f;
+  // hctr_ebc_local_reduce scratch (allocated on first use, sized by impl.max_nnz)
+  uint64_t* lr_sorted = nullptr;
+  uint32_t *lr_pos_in = nullptr, *lr_pos_out = nullptr, *lr_pos_bucket = nullptr;
+  uint32_t *lr_flags = nullptr, *lr_heads = nullptr, *lr_cid = nullptr, *lr_sbucket = nullptr;
+  void* lr_temp = nullptr;
+  size_t lr_temp_bytes = 0;
+  unsigned long long *lr_tile_sums = nullptr, *lr_total = nullptr;
+  uint64_t* lr_num_unique = nullptr;
+
+  int lr_alloc() {
+    if (lr_sorted) return HCTR_OK;
+    const size_t n = impl.max_nnz ? impl.max_nnz : 1;
+    HCTR_HIP(hipMalloc(&lr_sorted, n * 8));
+    HCTR_HIP(hipMalloc(&lr_pos_in, n * 4));
+    HCTR_HIP(hipMalloc(&lr_pos_out, n * 4));
+    HCTR_HIP(hipMalloc(&lr_pos_bucket, n * 4));
+    HCTR_HIP(hipMalloc(&lr_flags, n * 4));
+    HCTR_HIP(hipMalloc(&lr_heads, (n + 1) * 4));
+    HCTR_HIP(hipMalloc(&lr_cid, n * 4));
+    HCTR_HIP(hipMalloc(&lr_sbucket, n * 4));
+    HCTR_HIP(hipMalloc(&lr_tile_sums, (n / 1024 + 2) * 8));
+    HCTR_HIP(hipMalloc(&lr_total, 8));
+    HCTR_HIP(hipMalloc(&lr_num_unique, 8));
+    size_t tb = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 64, nullptr,
+                                  false) != hipSuccess) {
+      set_error("rocprim::radix_sort_pairs (size query) failed");
+      return HCTR_ERR_HIP;
+    }
+    lr_temp_bytes = tb ? tb : 16;
+    HCTR_HIP(hipMalloc(&lr_temp, lr_temp_bytes));
+    return HCTR_OK;
+  }
+  void lr_free() {
+    void* ptrs[] = {lr_sorted, lr_pos_in, lr_pos_out, lr_pos_bucket, lr_flags, lr_heads, lr_cid,
+                    lr_sbucket, lr_temp, lr_tile_sums, lr_total, lr_num_unique};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    lr_sorted = nullptr;
+  }
 };
 
 extern "C" {
@@ -454,6 +543,7 @@ int hctr_updater_destroy(hctr_updater* u) {
   if (!u) return HCTR_OK;
   (void)hipDeviceSynchronize();
   u->impl.destroy();
+  u->lr_free();
   delete u;
   return HCTR_OK;
 }
@@ -513,6 +603,53 @@ int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buck
   u->impl.ext_rows = nullptr;
   u->impl.ext_buckets = nullptr;
   return rc;
+}
+
+int hctr_ebc_local_reduce(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
+                          const uint64_t* row_ids, uint64_t max_row_id, const uint64_t* keys,
+                          const void* grad, int grad_dtype, size_t* num_unique,
+                          uint64_t* unique_row_ids, uint64_t* unique_keys, float* wgrad,
+                          hctr_stream_t stream) {
+  HCTR_REQUIRE(u && num_unique, "null pointer");
+  *num_unique = 0;
+  if (buckets == 0 || nnz == 0) return HCTR_OK;
+  HCTR_REQUIRE(bucket_range && row_ids && grad && unique_row_ids && wgrad, "null pointer");
+  HCTR_REQUIRE(!unique_keys || keys, "unique_keys requested without keys");
+  HCTR_REQUIRE(nnz <= u->impl.max_nnz && nnz < 0xFFFFFFF0ull, "nnz exceeds the updater's capacity");
+  HCTR_REQUIRE(buckets < 0xFFFFFFF0ull, "buckets");
+  HCTR_TRY(u->lr_alloc());
+  hipStream_t s = as_stream(stream);
+  unsigned bits = 1;
+  while (bits < 64 && (max_row_id >> bits) != 0) bits++;
+  hipLaunchKernelGGL(lr_expand_kernel, dim3(grid_for(buckets, kBlock, 4096)), dim3(kBlock), 0, s,
+                     buckets, (const long long*)bucket_range, u->lr_pos_bucket, u->lr_pos_in);
+  HCTR_LAUNCH_CHECK();
+  size_t tb = u->lr_temp_bytes;
+  // stable: equal rows keep ascending positions, so a row's gradients are summed in ascending
+  // bucket order
+  if (rocprim::radix_sort_pairs(u->lr_temp, tb, row_ids, u->lr_sorted, u->lr_pos_in, u->lr_pos_out,
+                                nnz, 0, bits, s, false) != hipSuccess) {
+    set_error("rocprim::radix_sort_pairs failed");
+    return HCTR_ERR_HIP;
+  }
+  const int grid = grid_for(nnz, kBlock, 4096);
+  hipLaunchKernelGGL(lr_flags_kernel, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
+                     u->lr_flags);
+  HCTR_LAUNCH_CHECK();
+  HCTR_TRY(exclusive_scan_to_offsets<uint32_t>(u->lr_flags, nnz, u->lr_tile_sums, u->lr_total,
+                                               u->lr_heads, s));
+  hipLaunchKernelGGL(lr_emit_kernel, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
+                     u->lr_pos_out, u->lr_flags, u->lr_heads, u->lr_pos_bucket, keys, u->lr_cid,
+                     u->lr_sbucket, unique_row_ids, unique_keys, u->lr_num_unique);
+  HCTR_LAUNCH_CHECK();
+  // the caller sizes the optimizer step from the count (the reference reads num_unique_keys on the
+  // host at the same point, dynamic_embedding.cu:186-190)
+  uint64_t nu = 0;
+  HCTR_HIP(hipMemcpyAsync(&nu, u->lr_num_unique, sizeof(nu), hipMemcpyDeviceToHost, s));
+  HCTR_HIP(hipStreamSynchronize(s));
+  *num_unique = (size_t)nu;
+  return hctr_updater_reduce_presorted(u, nnz, buckets, bucket_range, u->lr_cid, u->lr_sbucket,
+                                       grad, grad_dtype, (size_t)nu, wgrad, stream);
 }
 
 }  // extern "C"

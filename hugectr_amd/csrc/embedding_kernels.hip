@@ -270,6 +270,111 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- pooling through per-key row pointers (the ILookup::lookup(..., float** embedding_vec) seam,
+//      R/HugeCTR/embedding/embedding_table.hpp:22-33, consumed by generic_lookup.cuh:318-416): the
+//      rows of a dynamic table live in per-class stores, so a key carries its row's address.
+//      nullptr = key not in the table (contributes 0, still counts for the mean).
+template <int LPR, int BU, typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    pool_ptrs_vec4_kernel(size_t buckets, int combiner, const long long* __restrict__ row_offset,
+                          const float* const* __restrict__ rows, OutT* __restrict__ out) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const size_t stride = (size_t)gridDim.x * GPB * BU;
+  for (size_t u0 = ((size_t)blockIdx.x * GPB + g) * BU; u0 < buckets; u0 += stride) {
+    long long off[BU];
+    int n[BU];
+    float4 acc[BU];
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      const size_t u = u0 + k;
+      off[k] = (u < buckets) ? row_offset[u] : 0;
+      n[k] = (u < buckets) ? (int)(row_offset[u + 1] - off[k]) : 0;
+      acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      for (int j = 0; j < n[k]; j++) {
+        const float* r = rows[off[k] + j];
+        if (r != nullptr) {
+          const float4 v = ld4(r + l * 4);
+          acc[k].x += v.x;
+          acc[k].y += v.y;
+          acc[k].z += v.z;
+          acc[k].w += v.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < BU; k++) {
+      const size_t u = u0 + k;
+      if (u < buckets) {
+        float4 v = acc[k];
+        if (combiner == 1 && n[k] > 1) {
+          const float sc = 1.0f / (float)n[k];
+          v.x = mean_product<OutT>(v.x, sc);
+          v.y = mean_product<OutT>(v.y, sc);
+          v.z = mean_product<OutT>(v.z, sc);
+          v.w = mean_product<OutT>(v.w, sc);
+        }
+        Store4<OutT>::st(out + u * (size_t)D + l * 4, v);
+      }
+    }
+  }
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(kBlock)
+    pool_ptrs_generic_kernel(size_t buckets, int D, int combiner,
+                             const long long* __restrict__ row_offset,
+                             const float* const* __restrict__ rows, OutT* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = row_offset[u];
+    const int n = (int)(row_offset[u + 1] - off);
+    const float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    for (int v = lane; v < D; v += 64) {
+      float sum = 0.0f;
+      for (int j = 0; j < n; j++) {
+        const float* r = rows[off + j];
+        sum += (r != nullptr) ? r[v] : 0.0f;
+      }
+      const float m = (D % 2 == 0) ? mean_product<OutT>(sum, sc) : sum * sc;
+      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? m : sum);
+    }
+  }
+}
+
+template <typename OutT>
+int launch_pool_ptrs(size_t buckets, int D, int combiner, const long long* ro,
+                     const float* const* rows, OutT* out, hipStream_t s) {
+  // row stores are hipMalloc'ed ([capacity][D] fp32): rows are 16-byte aligned iff D % 4 == 0
+  const bool aligned = reinterpret_cast<uintptr_t>(out) % 16 == 0;
+#define HCTR_PP(LPR_)                                                                          \
+  case LPR_:                                                                                    \
+    hipLaunchKernelGGL((pool_ptrs_vec4_kernel<LPR_, 4, OutT>),                                  \
+                       dim3(grid_for(ceil_div<size_t>(buckets, 4), kBlock / LPR_, 256 * 8)),    \
+                       dim3(kBlock), 0, s, buckets, combiner, ro, rows, out);                   \
+    break;
+  bool done = aligned && D % 4 == 0;
+  if (done) {
+    switch (D / 4) {
+      HCTR_PP(1) HCTR_PP(2) HCTR_PP(4) HCTR_PP(8) HCTR_PP(16) HCTR_PP(32) HCTR_PP(64)
+      default: done = false;
+    }
+  }
+#undef HCTR_PP
+  if (!done)
+    hipLaunchKernelGGL((pool_ptrs_generic_kernel<OutT>), dim3(grid_for(buckets * 64, kBlock)),
+                       dim3(kBlock), 0, s, buckets, D, combiner, ro, rows, out);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
 // ---- weighted pooling (SOK lookup_sparse with sp_weights, R/sparse_operation_kit/.../lookup.py
 //      :425-541): out[b] = sum_j w_j * row_j, mean divides by sum_j w_j; without weights w = 1 and
 //      mean divides by the key count.  One wavefront per bucket, lanes stride over the vector.
@@ -541,6 +646,29 @@ int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* ro
   HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
   return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
                                table, out, out_dtype, false, as_stream(stream));
+}
+
+int hctr_forward_pool_ptrs(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                           const float* const* rows, void* out, int out_dtype,
+                           hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  if (buckets == 0) return HCTR_OK;
+  HCTR_REQUIRE(row_offset && rows && out, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const long long* ro = (const long long*)row_offset;
+  switch (out_dtype) {
+    case HCTR_EMB_F32:
+      return launch_pool_ptrs<float>(buckets, vec_size, combiner, ro, rows, (float*)out, s);
+    case HCTR_EMB_F16:
+      return launch_pool_ptrs<__half>(buckets, vec_size, combiner, ro, rows, (__half*)out, s);
+    case HCTR_EMB_BF16:
+      return launch_pool_ptrs<__hip_bfloat16>(buckets, vec_size, combiner, ro, rows,
+                                              (__hip_bfloat16*)out, s);
+    default:
+      HCTR_REQUIRE(false, "out_dtype");
+  }
+  return HCTR_OK;
 }
 
 int hctr_forward_pool_weighted(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,

@@ -74,6 +74,19 @@ class DynamicEmbeddingTable:
                                          stream_ptr()))
         return out
 
+    def lookup_rows(self, keys: torch.Tensor, id_spaces=None, id_space_offsets=None,
+                    insert: bool = True, want_ptrs: bool = True, want_rows: bool = True):
+        """(row addresses int64[n] | None, row numbers int64[n] | None, class_row_base list):
+        row number = class_row_base[class] + row inside the class, unique over the classes"""
+        n = keys.numel()
+        sp, so, ns = self._ranges(n, id_spaces, id_space_offsets)
+        ptrs = torch.empty(n, dtype=torch.int64, device=keys.device) if want_ptrs else None
+        rows = torch.empty(n, dtype=torch.int64, device=keys.device) if want_rows else None
+        base = (ctypes.c_uint64 * (len(self.dims) + 1))()
+        check(lib.hctr_det_lookup_rows(self._h, ptr(keys), n, sp, so, ns, 1 if insert else 0,
+                                       ptr(ptrs), ptr(rows), base, stream_ptr()))
+        return ptrs, rows, list(base)
+
     def scatter_add(self, keys, elements, id_spaces=None, id_space_offsets=None):
         sp, so, ns = self._ranges(keys.numel(), id_spaces, id_space_offsets)
         elements = elements.contiguous().float()

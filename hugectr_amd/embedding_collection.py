@@ -1,4 +1,4 @@
-"""embedding_collection (EBC) on static tables -- the engine SparseOperationKit plugs into.
+"""embedding_collection (EBC) on static or dynamic tables -- the engine SparseOperationKit plugs into.
 
 Mirrors `EmbeddingTableConfig` / `EmbeddingCollectionConfig.embedding_lookup(...).shard(...)`
 (R/HugeCTR/include/pybind/embedding_collection_wrapper.hpp:28-66) and the forward / backward /
@@ -12,6 +12,13 @@ Flow per rank (one process per GPU), following SparseOperationKit's lookup_spars
   ->  hctr_forward_pool into the all-to-all send layout  ->  all-to-all of embedding vectors
   ->  hctr_ebc_network_forward (sum row-shard partials, Average scaling)  ->  [lookup][b][ev]
 Backward is the mirror; the update runs on the owner with the segmented sparse optimizer.
+
+storage="dynamic" (embedding::DynamicEmbeddingTable, R/HugeCTR/embedding_storage/
+dynamic_embedding.cu:21-330; BASELINE config 5): the local shards are classes of one hctr_det table
+that grows on demand; routing keeps the raw keys, `lookup` returns per-key row addresses
+(hctr_det_lookup_rows = ILookup::lookup), pooling reads through them (hctr_forward_pool_ptrs), and
+the backward builds Wgrad{unique_keys, ev_start_indices, data} (hctr_ebc_local_reduce) for the
+table's fused optimizer step (hctr_det_update, all seven optimizers of optimizers.cuh).
 
 Sharding: `shard_matrix[gpu][table]` in {0,1}; a table with one owner is table-wise sharded,
 with several owners row-wise (`key % num_shards` picks the owner in ascending GPU order, local row
@@ -69,12 +76,14 @@ class EmbeddingCollection:
                  optimizer: int = _lib.OPT_SGD, scaler: float = 1.0, epsilon: float = 1e-7,
                  initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
                  key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None,
-                 ftrl=(0.0, 0.0, 0.0)):
+                 ftrl=(0.0, 0.0, 0.0), storage: str = "static", initializer: str = "",
+                 init_capacity: int = 1 << 20, **opt_kw):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self._setup(config, global_batch, lr, optimizer, scaler, epsilon, initial_accu_value,
-                    out_dtype, batch_major, key_dtype, max_hotness, seed, ftrl)
+                    out_dtype, batch_major, key_dtype, max_hotness, seed, ftrl, storage,
+                    initializer, init_capacity, **opt_kw)
 
     @classmethod
     def for_rank(cls, rank, world, *a, **kw):
@@ -86,13 +95,18 @@ class EmbeddingCollection:
 
     def _setup(self, config, global_batch, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1.0,
                epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
-               key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0)):
+               key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0),
+               storage="static", initializer="", init_capacity=1 << 20, beta1=0.9, beta2=0.999,
+               momentum_factor=0.9, rmsprop_beta=0.9):
         assert global_batch % self.world == 0
+        assert storage in ("static", "dynamic")
+        self.dynamic = storage == "dynamic"
+        self.training = True
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.B, self.bpg = global_batch, global_batch // self.world
         self.lr, self.optimizer, self.scaler, self.epsilon = lr, optimizer, scaler, epsilon
         self.out_dtype, self.batch_major, self.key_dtype = out_dtype, batch_major, key_dtype
-        if optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_FTRL):
+        if not self.dynamic and optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_FTRL):
             # static EBC tables: SGD / AdaGrad / Ftrl only
             raise _lib.HugeCTRAmdError("EBC static tables support SGD, AdaGrad and Ftrl")
         self.ftrl = tuple(float(x) for x in ftrl)  # (lambda1, lambda2, beta)
@@ -120,29 +134,46 @@ class EmbeddingCollection:
             ns = len(self.owners[t])
             rows += -(-tables[t].max_vocabulary_size // ns)
         self.local_rows = max(rows, 1)
-        self.table = torch.empty((self.local_rows, self.ev), dtype=torch.float32, device=self.dev)
-        g = torch.Generator(device=self.dev)
-        g.manual_seed(seed * 1000003 + self.rank)
-        for t in self.local_tables:  # U(+-sqrt(1/vocab)) per table (ragged_static_embedding.cu:499-509)
-            ns = len(self.owners[t])
-            n = -(-tables[t].max_vocabulary_size // ns)
-            b = (1.0 / tables[t].max_vocabulary_size) ** 0.5
-            s0 = self.row_start_of_table[t]
-            self.table[s0:s0 + n].uniform_(-b, b, generator=g)
-        self.accum = (torch.full_like(self.table, initial_accu_value)
-                      if optimizer == _lib.OPT_ADAGRAD else None)
-        self.ftrl_z = None
-        if optimizer == _lib.OPT_FTRL:  # n and z start at zero (ragged_static_embedding.cu:484-496)
-            self.accum = torch.zeros_like(self.table)
-            self.ftrl_z = torch.zeros_like(self.table)
+        self.accum = self.ftrl_z = self.table = None
+        if self.dynamic:
+            # one class of the dynamic table per local table shard; max_vocabulary_size is only a
+            # hint here, the maps grow on demand (dynamic_embedding.cu:41-75)
+            from .dynamic_table import DynamicEmbeddingTable, DynamicTableOptimizer
+            self.class_of_table = {t: c for c, t in enumerate(self.local_tables)}
+            ncls = max(len(self.local_tables), 1)
+            self.det = DynamicEmbeddingTable([self.ev] * ncls, initializer, init_capacity,
+                                             torch.int64, seed=seed * 1000003 + self.rank)
+            self.det_opt = DynamicTableOptimizer(
+                self.det, optimizer, lr, beta1, beta2, epsilon, momentum_factor, rmsprop_beta,
+                self.ftrl[0], self.ftrl[1], self.ftrl[2], scaler, init_capacity)
+            self.local_rows = 1
+        else:
+            self.table = torch.empty((self.local_rows, self.ev), dtype=torch.float32,
+                                     device=self.dev)
+            g = torch.Generator(device=self.dev)
+            g.manual_seed(seed * 1000003 + self.rank)
+            for t in self.local_tables:  # U(+-sqrt(1/vocab)) per table (ragged_static_embedding.cu:499-509)
+                ns = len(self.owners[t])
+                n = -(-tables[t].max_vocabulary_size // ns)
+                b = (1.0 / tables[t].max_vocabulary_size) ** 0.5
+                s0 = self.row_start_of_table[t]
+                self.table[s0:s0 + n].uniform_(-b, b, generator=g)
+            if optimizer == _lib.OPT_ADAGRAD:
+                self.accum = torch.full_like(self.table, initial_accu_value)
+            if optimizer == _lib.OPT_FTRL:  # n and z start at zero (ragged_static_embedding.cu:484-496)
+                self.accum = torch.zeros_like(self.table)
+                self.ftrl_z = torch.zeros_like(self.table)
         # lookups resolved on this rank (ascending global lookup id) and their descriptors
         self.local_lookups = [l for l in range(self.L) if self.rank in self.owners[self.lookup_table[l]]]
         desc, rs = [], []
         for l in self.local_lookups:
             t = self.lookup_table[l]
             desc += [l, len(self.owners[t]), self.owners[t].index(self.rank)]
-            rs.append(self.row_start_of_table[t])
+            rs.append(-1 if self.dynamic else self.row_start_of_table[t])  # < 0: keep the key
         self.n_local = len(self.local_lookups)
+        if self.dynamic:  # class of every (peer, local lookup) segment of the routed keys
+            self.seg_class = [self.class_of_table[self.lookup_table[l]]
+                              for _ in range(self.world) for l in self.local_lookups]
         self.d_desc = torch.tensor(desc or [0, 1, 0], dtype=torch.int32, device=self.dev)
         self.d_row_start = torch.tensor(rs or [0], dtype=torch.int64, device=self.dev)
         # receive-side block table: blocks are ordered [source rank][its local lookups]
@@ -175,8 +206,10 @@ class EmbeddingCollection:
         self.d_nnz = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.counts = torch.zeros(self.L * self.bpg, dtype=torch.int64, device=self.dev)
         self._upd = ctypes.c_void_p()
-        check(lib.hctr_updater_create(self.max_nnz, self.local_rows, self.ev, ctypes.byref(self._upd)))
-        if optimizer == _lib.OPT_FTRL:
+        # (dynamic: the updater only sums gradients per unique row, rows are numbered < max_nnz)
+        check(lib.hctr_updater_create(self.max_nnz, self.max_nnz if self.dynamic else self.local_rows,
+                                      self.ev, ctypes.byref(self._upd)))
+        if optimizer == _lib.OPT_FTRL and not self.dynamic:
             check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
         self._nnz_host = 0
@@ -235,11 +268,51 @@ class EmbeddingCollection:
                                       ptr(self.d_row_start), ptr(gkeys), ptr(gbucket_range), kt,
                                       ptr(self.out_range), ptr(self.indices), ptr(self.d_nnz),
                                       ptr(self.ws), stream_ptr()))
+        if self.dynamic:
+            return self._dynamic_pool(send)
         self._nnz_host = int(gkeys.numel())  # upper bound; the live count stays on the device
         check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
                                     ptr(self.indices), ptr(self.table), ptr(send),
                                     _DT[self.out_dtype], stream_ptr()))
         return send
+
+    def _dynamic_pool(self, send: torch.Tensor) -> torch.Tensor:
+        """self.indices holds the routed raw keys in [peer][local lookup][b_local] bucket order:
+        one (peer, lookup) segment = one id space of the dynamic table.  The segment offsets are
+        read on the host, like the id_space_offset of the reference's lookup
+        (dynamic_embedding.cu:139-150)."""
+        seg = self.out_range[0:self.nb + 1:self.bpg].tolist()  # host sync (offsets)
+        nnz = seg[-1]
+        self._nnz_host = nnz
+        if nnz == 0:
+            return send.zero_()
+        keys = self.indices[:nnz]
+        ptrs, rows, base = self.det.lookup_rows(keys, self.seg_class, seg, insert=self.training)
+        self._dyn_rows, self._dyn_base = rows, base
+        check(lib.hctr_forward_pool_ptrs(self.nb, self.ev, 0, ptr(self.out_range), ptr(ptrs),
+                                         ptr(send), _DT[self.out_dtype], stream_ptr()))
+        return send
+
+    def _dynamic_apply(self, top_grad: torch.Tensor):
+        nnz = self._nnz_host
+        if nnz == 0:
+            return
+        urow = torch.empty(nnz, dtype=torch.int64, device=self.dev)
+        ukey = torch.empty(nnz, dtype=torch.int64, device=self.dev)
+        wgrad = torch.empty((nnz, self.ev), dtype=torch.float32, device=self.dev)
+        nu = ctypes.c_size_t()
+        check(lib.hctr_ebc_local_reduce(self._upd, self.nb, nnz, ptr(self.out_range),
+                                        ptr(self._dyn_rows), self._dyn_base[-1], ptr(self.indices),
+                                        ptr(top_grad), _DT[self.out_dtype], ctypes.byref(nu),
+                                        ptr(urow), ptr(ukey), ptr(wgrad), stream_ptr()))
+        n = nu.value
+        # unique rows ascend, so the classes are contiguous: their borders in the unique list
+        ncls = len(self.det.dims)
+        base = torch.tensor(self._dyn_base, dtype=torch.int64, device=self.dev)
+        off = torch.searchsorted(urow[:n], base).tolist()  # host sync (table ranges)
+        ev_start = torch.arange(0, n * self.ev, self.ev, dtype=torch.int32, device=self.dev)
+        self.det_opt.set_learning_rate(self.lr)
+        self.det_opt.update(ukey[:n], ev_start, wgrad[:n].view(-1), list(range(ncls)), off)
 
     def network_forward(self, recv: torch.Tensor) -> torch.Tensor:
         shape = (self.bpg, self.L, self.ev) if self.batch_major else (self.L, self.bpg, self.ev)
@@ -266,6 +339,8 @@ class EmbeddingCollection:
         if self.n_local == 0:
             return
         self._times += 1
+        if self.dynamic:
+            return self._dynamic_apply(top_grad.contiguous())
         check(lib.hctr_updater_update(self._upd, self.nb, self._nnz_host, ptr(self.out_range),
                                       ptr(self.indices), ptr(top_grad.contiguous()),
                                       _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,

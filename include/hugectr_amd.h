@@ -99,6 +99,13 @@ int hctr_expand_key_grads(size_t buckets, int vec_size, int combiner, const int6
 int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,
                       int key_type, const uint64_t* value_index, const float* table, void* out,
                       int out_dtype, hctr_stream_t stream);
+/* pooling through per-key row pointers -- what embedding::ILookup::lookup(keys, ..., float**
+ * embedding_vec) hands to the pooling kernel (R/HugeCTR/embedding/embedding_table.hpp:22-33,
+ * generic_lookup.cuh:318-416): rows[j] = device address of key j's fp32 vector, NULL = key not in
+ * the table (adds 0, still counts for the mean).  int64 row_offset. */
+int hctr_forward_pool_ptrs(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                           const float* const* rows, void* out, int out_dtype,
+                           hctr_stream_t stream);
 
 /* forward_reorder / backward_reorder: R/HugeCTR/src/embeddings/forward_reorder_functor.cu:26-98,
  * backward_reorder_functor.cu.  in [gpu][b][slot_in_gpu][D] <-> out [b][slot][D]. */
@@ -208,7 +215,8 @@ int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t t
  * key % num_shards == shard_id and convert them to row indices of the rank's flat table.
  *   keys / bucket_range: feature-major global batch, bucket = lookup * batch + b, [L*batch+1]
  *   lookup_desc (DEVICE int32): {global_lookup, num_shards, shard_id} x num_local_lookups
- *   row_start   (DEVICE int64): first row of each local lookup's table shard
+ *   row_start   (DEVICE int64): first row of each local lookup's table shard; a negative value
+ *                 marks a dynamic table: the key itself is written to out_indices
  * Output buckets are ordered [peer][local lookup][b_local] (= the all-to-all send layout):
  *   out_bucket_range int64 [world * num_local_lookups * batch/world + 1], out_indices [<= nnz]. */
 size_t hctr_ebc_route_workspace_bytes(size_t batch, int num_local_lookups);
@@ -248,6 +256,21 @@ int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64
                         int update_type, float lr, float beta1, float beta2, float epsilon,
                         float momentum_factor, float scaler, uint64_t times, float* table,
                         float* state0, float* state1, hctr_stream_t stream);
+
+/* LocalReduceIndexCalculation + LocalReduce (R/HugeCTR/embedding/operators/index_calculation.cu,
+ * model_backward.cu:113-...): the Wgrad{unique_keys, ev_start_indices, data} a grouped table's
+ * update() consumes (R/HugeCTR/embedding/common.hpp:352-373).  row_ids[nnz] < = max_row_id identify
+ * the row of every key (any numbering that is unique per (table, key), e.g. hctr_det_lookup_rows);
+ * grad [buckets][vec] of grad_dtype.  Outputs, ordered by ascending row id: unique_row_ids
+ * [<= nnz], unique_keys [<= nnz] (= keys[first position of the row]; both NULL to skip), wgrad
+ * [*num_unique][vec] fp32 sums in ascending bucket order (ev_start_indices = i * vec).
+ * *num_unique is returned on the HOST (one stream synchronisation, where the reference reads
+ * num_unique_keys).  The updater must have been created with max_nnz >= nnz. */
+int hctr_ebc_local_reduce(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
+                          const uint64_t* row_ids, uint64_t max_row_id, const uint64_t* keys,
+                          const void* grad, int grad_dtype, size_t* num_unique,
+                          uint64_t* unique_row_ids, uint64_t* unique_keys, float* wgrad,
+                          hctr_stream_t stream);
 
 /* ---- unique-row exchange (multi-GPU, one key per bucket): ship every distinct row once per
  * destination GPU + an (index, bucket) pair per position, return per-row gradient sums instead of
@@ -366,6 +389,18 @@ int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, 
 int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, size_t num_keys,
                           int insert, uint64_t* row_index, hctr_stream_t stream);
 int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacity);
+/* embedding::DynamicEmbeddingTable::lookup (R/HugeCTR/embedding_storage/dynamic_embedding.cu:
+ * 130-160): keys grouped by id space (HOST id_spaces / id_space_offsets as in hctr_det_lookup) ->
+ * per key the address of its vector (elements, may be NULL) and / or a row number that is unique
+ * over all classes: class_row_base[class] + row inside the class (row_index, may be NULL; the
+ * sort key of hctr_ebc_local_reduce).  class_row_base (HOST, num_classes + 1 entries, may be NULL)
+ * receives the bases used by this call = running sum of the class capacities after any growth.
+ * insert != 0: unseen keys are inserted and initialised first (the training lookup); else unseen
+ * keys give NULL / SIZE_MAX.  Pointers and row numbers stay valid until the next inserting call. */
+int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
+                         const size_t* id_space_offsets, size_t num_id_spaces, int insert,
+                         float** elements, uint64_t* row_index, uint64_t* class_row_base,
+                         hctr_stream_t stream);
 int hctr_det_clear(hctr_det* h, hctr_stream_t stream);
 int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream); /* host sync */
 int hctr_det_capacity_per_class(const hctr_det* h, size_t* capacities);

@@ -71,5 +71,12 @@ def test_new_entry_points_validate_before_touching_the_device():
     assert "multiple of 8" in _lib.last_error()
     assert L.hctr_bce_loss(0, None, None, 1.0, None, None, None, 0, None) == -1
     assert L.hctr_forward_pool_weighted(4, 0, 0, None, None, None, None, None, None) == -1
+    assert L.hctr_forward_pool_ptrs(4, 16, 2, None, None, None, 0, None) == -1
+    assert "combiner" in _lib.last_error()
+    assert L.hctr_det_lookup_rows(None, None, 0, None, None, 0, 1, None, None, None, None) == -1
+    import ctypes
+    n = ctypes.c_size_t(7)
+    assert L.hctr_ebc_local_reduce(None, 1, 1, None, None, 10, None, None, 0, ctypes.byref(n), None,
+                                   None, None, None) == -1
     assert L.hctr_emb_index(None, 1, None, None, 0, None) == -1
     assert L.hctr_emb_update_rows(None, 1, None, None, None, 0, None) == -1
