@@ -125,6 +125,19 @@ _SIGNATURES = {
     "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),
     "hctr_det_update": (c_int, [_P, _P, POINTER(DetOptParams), _P, c_size_t, _SZP, _SZP, c_size_t,
                                 _P, _P, _P]),
+    "hctr_cache_create": (c_int, [c_size_t, c_int, c_int, POINTER(_P)]),
+    "hctr_cache_destroy": (c_int, [_P]),
+    "hctr_cache_capacity_in_set": (c_size_t, [_P]),
+    "hctr_cache_query": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P, _P]),
+    "hctr_cache_replace": (c_int, [_P, _P, c_size_t, _P, _P]),
+    "hctr_cache_update": (c_int, [_P, _P, c_size_t, _P, _P]),
+    "hctr_cache_dump": (c_int, [_P, _P, _P, c_size_t, c_size_t, _P]),
+    "hctr_tiered_create": (c_int, [c_size_t, c_int, c_size_t, POINTER(_P)]),
+    "hctr_tiered_destroy": (c_int, [_P]),
+    "hctr_tiered_host_rows": (_P, [_P]),
+    "hctr_tiered_cache": (_P, [_P]),
+    "hctr_tiered_lookup": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
+    "hctr_tiered_scatter": (c_int, [_P, _P, c_size_t, _P, c_int, _P]),
     "hctr_uniq_create": (c_int, [c_size_t, POINTER(_P)]),
     "hctr_uniq_destroy": (c_int, [_P]),
     "hctr_uniq_plan": (c_int, [_P, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, _P,

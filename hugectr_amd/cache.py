@@ -1,0 +1,97 @@
+"""Embedding cache in HBM and the host<->HBM tiered table (BASELINE config 4): host mirror of
+gpu_cache::gpu_cache (R/gpu_cache/include/nv_gpu_cache.hpp:46-124 -- Query / Replace / Update /
+Dump) and of the role of gpu_cache::UvmTable (R/gpu_cache/include/uvm_table.hpp:133-174).
+Thin ctypes calls into hctr_cache_* / hctr_tiered_* -- no compute here."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+
+class GpuCache:
+    """capacity_in_set sets of 64 slots; vectors are fp32[embedding_vec_size]"""
+
+    def __init__(self, capacity_in_set: int, embedding_vec_size: int, key_dtype=torch.int64,
+                 _handle=None):
+        self.capacity_in_set, self.D, self.key_dtype = capacity_in_set, embedding_vec_size, key_dtype
+        self._own = _handle is None
+        self._h = ctypes.c_void_p(_handle) if _handle is not None else ctypes.c_void_p()
+        if self._own:
+            kt = _lib.KEY_I64 if key_dtype == torch.int64 else _lib.KEY_U32
+            check(lib.hctr_cache_create(capacity_in_set, embedding_vec_size, kt, ctypes.byref(self._h)))
+        self._len = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def __del__(self):
+        if getattr(self, "_own", False) and getattr(self, "_h", None):
+            lib.hctr_cache_destroy(self._h)
+            self._h = None
+
+    def Query(self, keys: torch.Tensor, values: torch.Tensor = None):
+        """hits are written to values[i]; returns (missing_index, missing_keys) (host sync on the
+        count, for the caller's convenience -- the ABI keeps it on the device)"""
+        n = keys.numel()
+        mi = torch.empty(n, dtype=torch.int64, device=keys.device)
+        mk = torch.empty(n, dtype=keys.dtype, device=keys.device)
+        check(lib.hctr_cache_query(self._h, ptr(keys), n, ptr(values), ptr(mi), ptr(mk),
+                                   ptr(self._len), stream_ptr()))
+        m = int(self._len.item())
+        return mi[:m], mk[:m]
+
+    def Replace(self, keys: torch.Tensor, values: torch.Tensor):
+        check(lib.hctr_cache_replace(self._h, ptr(keys), keys.numel(), ptr(values.contiguous()),
+                                     stream_ptr()))
+
+    def Update(self, keys: torch.Tensor, values: torch.Tensor):
+        check(lib.hctr_cache_update(self._h, ptr(keys), keys.numel(), ptr(values.contiguous()),
+                                    stream_ptr()))
+
+    def Dump(self, start_set_index: int = 0, end_set_index: int = None) -> torch.Tensor:
+        end = self.capacity_in_set if end_set_index is None else end_set_index
+        out = torch.empty(max(end - start_set_index, 0) * 64, dtype=self.key_dtype, device="cuda")
+        check(lib.hctr_cache_dump(self._h, ptr(out), ptr(self._len), start_set_index, end,
+                                  stream_ptr()))
+        return out[:int(self._len.item())]
+
+
+class TieredTable:
+    """[host_rows, vec] fp32 table in pinned host memory behind a GpuCache; key = row"""
+
+    def __init__(self, host_rows: int, embedding_vec_size: int, cache_capacity_in_set: int):
+        self.rows, self.D = host_rows, embedding_vec_size
+        self._h = ctypes.c_void_p()
+        check(lib.hctr_tiered_create(host_rows, embedding_vec_size, cache_capacity_in_set,
+                                     ctypes.byref(self._h)))
+        addr = lib.hctr_tiered_host_rows(self._h)
+        buf = (ctypes.c_float * (host_rows * embedding_vec_size)).from_address(addr)
+        self.host = np.ctypeslib.as_array(buf).reshape(host_rows, embedding_vec_size)
+        self.cache = GpuCache(cache_capacity_in_set, embedding_vec_size,
+                              _handle=lib.hctr_tiered_cache(self._h))
+        self._miss = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.host = None
+            lib.hctr_tiered_destroy(self._h)
+            self._h = None
+
+    def lookup(self, keys: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((keys.numel(), self.D), dtype=torch.float32, device=keys.device)
+        check(lib.hctr_tiered_lookup(self._h, ptr(keys), keys.numel(), ptr(out), ptr(self._miss),
+                                     stream_ptr()))
+        return out
+
+    def last_missing(self) -> int:
+        return int(self._miss.item())
+
+    def scatter_add(self, unique_keys: torch.Tensor, values: torch.Tensor):
+        check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
+                                      ptr(values.contiguous()), 1, stream_ptr()))
+
+    def scatter_update(self, unique_keys: torch.Tensor, values: torch.Tensor):
+        check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
+                                      ptr(values.contiguous()), 0, stream_ptr()))

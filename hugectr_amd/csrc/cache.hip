@@ -1,0 +1,667 @@
+// cache.hip -- set-associative LRU embedding cache in HBM and the host<->HBM tiered table on top.
+//
+// Replaces gpu_cache::gpu_cache (R/gpu_cache/include/nv_gpu_cache.hpp:46-124,
+// R/gpu_cache/src/nv_gpu_cache.cu:247-1155: Query / Replace / Update / Dump) and the role of
+// gpu_cache::UvmTable (R/gpu_cache/include/uvm_table.hpp:133-174: device table in front of a host
+// table) -- BASELINE config 4, SURVEY 8(f)2.  The reference has neither tests nor callers for these
+// in tree: parity is against our own sequential restatement (oracle/cache_oracle.py), "unpinned".
+//
+// MI355X-first layout: a slab set of the reference is SET_ASSOCIATIVITY (2) slabs x 32 keys; here
+// the whole set is ONE wavefront-wide row of 64 slots, searched with a single 64-lane ballot
+// (keys of a set = one 512-byte line).  The reference serialises concurrent sub-warps on a per-set
+// mutex, so which key wins a slot depends on scheduling; here the keys of a Replace / Update call
+// are sorted by set and every set is walked by exactly one wavefront in position order: results
+// are a pure function of the call sequence (= the reference's behaviour under one legal
+// interleaving).  The slot rules are the reference's: a key lives in set MurmurHash3_32(key) %
+// capacity_in_set, probing starts in slab key % 2; insertion takes the first empty slot in probing
+// order, else evicts the least recently used slot (smallest counter; ties: earlier slab in probing
+// order, then lower slot); Query / Replace refresh the slot's counter with the global counter,
+// which Query advances once per call.
+// Calls on one cache are ordered by their streams; calls from unordered streams need external
+// ordering (the reference's per-set mutexes are not reproduced).
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <cstring>
+
+#include "common.h"
+#include "scan.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kSetSlots = 64;  // SET_ASSOCIATIVITY (2) x SLAB_SIZE (32), nv_gpu_cache.hpp:30-31
+constexpr uint32_t kPadSet = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __ballot(p); }
+
+template <typename K>
+__device__ __forceinline__ long long widen(K k) {
+  return (long long)(sizeof(K) == 4 ? (unsigned long long)(uint32_t)k : (unsigned long long)k);
+}
+
+// copy one vector with the 64 lanes of a wavefront (float4 when the caller proved alignment)
+template <bool V4>
+__device__ __forceinline__ void wave_copy(int lane, int D, float* __restrict__ dst,
+                                          const float* __restrict__ src) {
+  if (V4) {
+    for (int c = lane; c < D / 4; c += 64)
+      reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+  } else {
+    for (int c = lane; c < D; c += 64) dst[c] = src[c];
+  }
+}
+
+// update_kernel_overflow_ignore (nv_gpu_cache.cu:225-240): advance the global counter, reset the
+// missing length
+__global__ void cache_tick_kernel(unsigned long long* global_counter, size_t* d_missing_len) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *global_counter += 1;
+    if (d_missing_len) *d_missing_len = 0;
+  }
+}
+
+// get_kernel (nv_gpu_cache.cu:247-388): one wavefront per key
+template <typename K, bool V4>
+__global__ void __launch_bounds__(kBlock)
+    cache_query_kernel(const K* __restrict__ keys, size_t len, float* __restrict__ values, int D,
+                       size_t num_sets, const long long* __restrict__ set_keys,
+                       unsigned long long* __restrict__ counters, const float* __restrict__ vals,
+                       const unsigned long long* __restrict__ global_counter,
+                       uint32_t* __restrict__ miss_flag) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  const unsigned long long gc = *global_counter;
+  for (size_t i = wave; i < len; i += nwaves) {
+    const K key = keys[i];
+    const size_t set = (size_t)murmur3_key(key) % num_sets;
+    const long long mine = set_keys[set * kSetSlots + lane];
+    const unsigned long long hit = ballot64(mine == widen(key));
+    if (hit) {
+      const int h = __ffsll((long long)hit) - 1;
+      const size_t slot = set * kSetSlots + h;
+      if (lane == 0) counters[slot] = gc;
+      if (values) wave_copy<V4>(lane, D, values + i * (size_t)D, vals + slot * (size_t)D);
+    }
+    if (lane == 0) miss_flag[i] = hit ? 0u : 1u;
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    cache_emit_missing_kernel(const K* __restrict__ keys, size_t len,
+                              const uint32_t* __restrict__ miss_flag,
+                              const uint32_t* __restrict__ before, uint64_t* __restrict__ missing_index,
+                              K* __restrict__ missing_keys, size_t* __restrict__ d_missing_len) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len;
+       i += (size_t)gridDim.x * kBlock) {
+    if (miss_flag[i]) {
+      const uint32_t j = before[i];
+      if (missing_index) missing_index[j] = i;
+      if (missing_keys) missing_keys[j] = keys[i];
+    }
+    if (i == len - 1) *d_missing_len = (size_t)before[i] + miss_flag[i];
+  }
+}
+
+// set id of every key (padding behind *d_len sorts last), position iota
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    cache_setid_kernel(const K* __restrict__ keys, size_t len, const size_t* __restrict__ d_len,
+                       size_t num_sets, uint32_t* __restrict__ set_id, uint32_t* __restrict__ pos) {
+  const size_t live = d_len ? *d_len : len;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len;
+       i += (size_t)gridDim.x * kBlock) {
+    set_id[i] = i < live ? (uint32_t)((size_t)murmur3_key(keys[i]) % num_sets) : kPadSet;
+    pos[i] = (uint32_t)i;
+  }
+}
+
+// insert_replace_kernel (nv_gpu_cache.cu:541-697) / update_kernel (:860-967).  One wavefront per
+// run of equal set ids in the sorted list: it keeps the set's 64 keys and counters in registers
+// and applies the run's keys one after the other in position order.
+//   REPLACE: found -> refresh counter; else first empty slot in probing order; else evict LRU
+//   UPDATE : found -> overwrite the vector; else nothing
+// value of key at position p: values[(value_index ? value_index[p] : p) * D]
+template <typename K, bool REPLACE, bool V4>
+__global__ void __launch_bounds__(kBlock)
+    cache_modify_kernel(const K* __restrict__ keys, size_t len,
+                        const uint32_t* __restrict__ sorted_set, const uint32_t* __restrict__ sorted_pos,
+                        const float* __restrict__ values, const uint64_t* __restrict__ value_index,
+                        int D, long long* __restrict__ set_keys,
+                        unsigned long long* __restrict__ counters, float* __restrict__ vals,
+                        const unsigned long long* __restrict__ global_counter, long long empty_key) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  const unsigned long long gc = *global_counter;
+  for (size_t i = wave; i < len; i += nwaves) {
+    const uint32_t set = sorted_set[i];
+    if (set == kPadSet) continue;
+    if (i > 0 && sorted_set[i - 1] == set) continue;  // not the head of its run
+    long long my_key = set_keys[(size_t)set * kSetSlots + lane];
+    unsigned long long my_cnt = counters[(size_t)set * kSetSlots + lane];
+    for (size_t j = i; j < len && sorted_set[j] == set; j++) {
+      const uint32_t p = sorted_pos[j];
+      const K key = keys[p];
+      const long long k64 = widen(key);
+      const float* src = values + (value_index ? (size_t)value_index[p] : (size_t)p) * (size_t)D;
+      const unsigned long long hit = ballot64(my_key == k64);
+      int target = -1;
+      if (hit) {
+        const int h = __ffsll((long long)hit) - 1;
+        if (REPLACE) {
+          if (lane == h) {
+            my_cnt = gc;
+            counters[(size_t)set * kSetSlots + h] = gc;
+          }
+        } else {
+          target = h;
+        }
+      } else if (REPLACE) {
+        // probing order: slab (key % 2) first (Mod_Hash, nv_gpu_cache.hpp:49), then the other
+        const int first_slab = (int)((unsigned long long)k64 & 1ull);
+        const unsigned long long empties = ballot64(my_key == empty_key);
+        unsigned long long cand = empties;
+        if (!cand) {  // LRU: smallest counter, ties by probing order
+          unsigned long long mn = my_cnt;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(mn, o);
+            mn = other < mn ? other : mn;
+          }
+          cand = ballot64(my_cnt == mn);
+        }
+        const unsigned long long lo = cand & 0xFFFFFFFFull, hi = cand >> 32;
+        const unsigned long long a = first_slab == 0 ? lo : hi;  // first slab in probing order
+        const unsigned long long b = first_slab == 0 ? hi : lo;
+        if (a)
+          target = (__ffsll((long long)a) - 1) + 32 * first_slab;
+        else
+          target = (__ffsll((long long)b) - 1) + 32 * (1 - first_slab);
+        if (lane == target) {
+          my_key = k64;
+          my_cnt = gc;
+          set_keys[(size_t)set * kSetSlots + target] = k64;
+          counters[(size_t)set * kSetSlots + target] = gc;
+        }
+      }
+      if (target >= 0)
+        wave_copy<V4>(lane, D, vals + ((size_t)set * kSetSlots + target) * (size_t)D, src);
+    }
+  }
+}
+
+// dump_kernel (nv_gpu_cache.cu:1080-1153): keys of the sets [start, end) in (set, slot) order
+__global__ void __launch_bounds__(kBlock)
+    cache_dump_count_kernel(const long long* __restrict__ set_keys, size_t start, size_t n_sets,
+                            long long empty_key, uint32_t* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t s = wave; s < n_sets; s += nwaves) {
+    const unsigned long long live = ballot64(set_keys[(start + s) * kSetSlots + lane] != empty_key);
+    if (lane == 0) counts[s] = (uint32_t)__popcll(live);
+  }
+}
+
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    cache_dump_emit_kernel(const long long* __restrict__ set_keys, size_t start, size_t n_sets,
+                           long long empty_key, const uint32_t* __restrict__ offsets,
+                           K* __restrict__ out, size_t* __restrict__ d_counter) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t s = wave; s < n_sets; s += nwaves) {
+    const long long k = set_keys[(start + s) * kSetSlots + lane];
+    const unsigned long long live = ballot64(k != empty_key);
+    if (k != empty_key) {
+      const int rank = __popcll(live & ((1ull << lane) - 1ull));
+      out[offsets[s] + rank] = (K)k;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_counter = (size_t)offsets[n_sets];
+}
+
+__global__ void __launch_bounds__(kBlock)
+    cache_init_kernel(size_t slots, long long empty_key, long long* __restrict__ set_keys,
+                      unsigned long long* __restrict__ counters) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < slots;
+       i += (size_t)gridDim.x * kBlock) {
+    set_keys[i] = empty_key;
+    counters[i] = 0ull;
+  }
+}
+
+// ---- tiered table: rows missing in the cache come straight out of pinned host memory -----------
+template <bool V4>
+__global__ void __launch_bounds__(kBlock)
+    tier_fill_kernel(const long long* __restrict__ miss_keys, const uint64_t* __restrict__ miss_index,
+                     const size_t* __restrict__ d_missing_len, size_t host_rows, int D,
+                     const float* __restrict__ host, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  const size_t n = *d_missing_len;
+  for (size_t j = wave; j < n; j += nwaves) {
+    const long long key = miss_keys[j];
+    float* dst = out + (size_t)miss_index[j] * (size_t)D;
+    if (key >= 0 && (size_t)key < host_rows) {
+      wave_copy<V4>(lane, D, dst, host + (size_t)key * (size_t)D);
+    } else {  // unknown row: zeros (UvmTable's default_value, uvm_table.hpp:137)
+      for (int c = lane; c < D; c += 64) dst[c] = 0.0f;
+    }
+  }
+}
+
+// write-through update of unique rows: new = (add ? old : 0) + value, stored in the host table
+// and, when the row is cached, in the cache (whose copy is the newer one to read)
+template <bool V4>
+__global__ void __launch_bounds__(kBlock)
+    tier_scatter_kernel(const long long* __restrict__ keys, size_t len,
+                        const float* __restrict__ values, int add, size_t host_rows, int D,
+                        size_t num_sets, const long long* __restrict__ set_keys,
+                        float* __restrict__ vals, float* __restrict__ host) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t i = wave; i < len; i += nwaves) {
+    const long long key = keys[i];
+    if (key < 0 || (size_t)key >= host_rows) continue;
+    const size_t set = (size_t)murmur3_key(key) % num_sets;
+    const unsigned long long hit = ballot64(set_keys[set * kSetSlots + lane] == key);
+    float* hrow = host + (size_t)key * (size_t)D;
+    float* crow = hit ? vals + (set * kSetSlots + (__ffsll((long long)hit) - 1)) * (size_t)D : nullptr;
+    const float* old = crow ? crow : hrow;
+    const float* v = values + i * (size_t)D;
+    if (V4) {
+      for (int c = lane; c < D / 4; c += 64) {
+        float4 x = reinterpret_cast<const float4*>(v)[c];
+        if (add) {
+          const float4 o = reinterpret_cast<const float4*>(old)[c];
+          x = make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
+        }
+        reinterpret_cast<float4*>(hrow)[c] = x;
+        if (crow) reinterpret_cast<float4*>(crow)[c] = x;
+      }
+    } else {
+      for (int c = lane; c < D; c += 64) {
+        const float x = add ? old[c] + v[c] : v[c];
+        hrow[c] = x;
+        if (crow) crow[c] = x;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace hctr
+
+using namespace hctr;
+
+struct hctr_cache {
+  size_t num_sets = 0;
+  int D = 0;
+  int key_type = HCTR_KEY_I64;
+  long long empty_key = 0;
+  long long* set_keys = nullptr;
+  unsigned long long* counters = nullptr;
+  float* vals = nullptr;
+  unsigned long long* global_counter = nullptr;
+  // scratch, sized for `cap` keys per call (grows on demand)
+  size_t cap = 0;
+  uint32_t *flags = nullptr, *before = nullptr;
+  uint32_t *set_in = nullptr, *set_out = nullptr, *pos_in = nullptr, *pos_out = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  unsigned long long *tile_sums = nullptr, *d_total = nullptr;
+
+  void free_scratch() {
+    void* ptrs[] = {flags, before, set_in, set_out, pos_in, pos_out, sort_temp, tile_sums, d_total};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    flags = before = set_in = set_out = pos_in = pos_out = nullptr;
+    sort_temp = nullptr;
+    tile_sums = d_total = nullptr;
+    cap = 0;
+  }
+  int reserve(size_t n, hipStream_t s) {
+    if (n <= cap) return HCTR_OK;
+    if (cap) HCTR_HIP(hipStreamSynchronize(s));  // earlier calls may still read the old scratch
+    free_scratch();
+    size_t c = 1024;
+    while (c < n) c *= 2;
+    HCTR_HIP(hipMalloc(&flags, c * 4));
+    HCTR_HIP(hipMalloc(&before, (c + 1) * 4));
+    HCTR_HIP(hipMalloc(&set_in, c * 4));
+    HCTR_HIP(hipMalloc(&set_out, c * 4));
+    HCTR_HIP(hipMalloc(&pos_in, c * 4));
+    HCTR_HIP(hipMalloc(&pos_out, c * 4));
+    HCTR_HIP(hipMalloc(&tile_sums, (c / 1024 + 2) * 8));
+    HCTR_HIP(hipMalloc(&d_total, 8));
+    size_t tb = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, c, 0, 32, nullptr,
+                                  false) != hipSuccess) {
+      set_error("rocprim::radix_sort_pairs (size query) failed");
+      return HCTR_ERR_HIP;
+    }
+    sort_temp_bytes = tb ? tb : 16;
+    HCTR_HIP(hipMalloc(&sort_temp, sort_temp_bytes));
+    cap = c;
+    return HCTR_OK;
+  }
+};
+
+namespace {
+
+bool vec4_ok(int D, const void* a, const void* b) {
+  return D % 4 == 0 && reinterpret_cast<uintptr_t>(a) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(b) % 16 == 0;
+}
+
+template <typename K>
+int cache_query_typed(hctr_cache* c, const K* keys, size_t len, float* values,
+                      uint64_t* missing_index, K* missing_keys, size_t* d_missing_len,
+                      hipStream_t s) {
+  const int grid = grid_for(len * 64, kBlock, 1 << 16);
+  if (vec4_ok(c->D, values, c->vals))
+    hipLaunchKernelGGL((cache_query_kernel<K, true>), dim3(grid), dim3(kBlock), 0, s, keys, len,
+                       values, c->D, c->num_sets, c->set_keys, c->counters, c->vals,
+                       c->global_counter, c->flags);
+  else
+    hipLaunchKernelGGL((cache_query_kernel<K, false>), dim3(grid), dim3(kBlock), 0, s, keys, len,
+                       values, c->D, c->num_sets, c->set_keys, c->counters, c->vals,
+                       c->global_counter, c->flags);
+  HCTR_LAUNCH_CHECK();
+  HCTR_TRY(exclusive_scan_to_offsets<uint32_t>(c->flags, len, c->tile_sums, c->d_total, c->before,
+                                               s));
+  hipLaunchKernelGGL(cache_emit_missing_kernel<K>, dim3(grid_for(len, kBlock, 4096)), dim3(kBlock),
+                     0, s, keys, len, c->flags, c->before, missing_index, missing_keys,
+                     d_missing_len);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+// Replace / Update on up to `len` keys (live count optionally on the device)
+template <typename K>
+int cache_modify_typed(hctr_cache* c, bool replace, const K* keys, size_t len, const size_t* d_len,
+                       const float* values, const uint64_t* value_index, hipStream_t s) {
+  HCTR_TRY(c->reserve(len, s));
+  hipLaunchKernelGGL(cache_setid_kernel<K>, dim3(grid_for(len, kBlock, 4096)), dim3(kBlock), 0, s,
+                     keys, len, d_len, c->num_sets, c->set_in, c->pos_in);
+  HCTR_LAUNCH_CHECK();
+  size_t tb = c->sort_temp_bytes;
+  // stable sort by set id: inside a set the keys keep their position order
+  if (rocprim::radix_sort_pairs(c->sort_temp, tb, c->set_in, c->set_out, c->pos_in, c->pos_out, len,
+                                0, 32, s, false) != hipSuccess) {
+    set_error("rocprim::radix_sort_pairs failed");
+    return HCTR_ERR_HIP;
+  }
+  const int grid = grid_for(len * 64, kBlock, 1 << 16);
+  const bool v4 = vec4_ok(c->D, values, c->vals);
+#define HCTR_CM(R_, V_)                                                                          \
+  hipLaunchKernelGGL((cache_modify_kernel<K, R_, V_>), dim3(grid), dim3(kBlock), 0, s, keys, len, \
+                     c->set_out, c->pos_out, values, value_index, c->D, c->set_keys, c->counters, \
+                     c->vals, c->global_counter, c->empty_key)
+  if (replace) {
+    if (v4) HCTR_CM(true, true);
+    else HCTR_CM(true, false);
+  } else {
+    if (v4) HCTR_CM(false, true);
+    else HCTR_CM(false, false);
+  }
+#undef HCTR_CM
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hctr_cache_create(size_t capacity_in_set, int vec_size, int key_type, hctr_cache** out) {
+  HCTR_REQUIRE(out && capacity_in_set > 0 && capacity_in_set < 0xFFFFFFF0ull, "capacity_in_set");
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(key_type == HCTR_KEY_U32 || key_type == HCTR_KEY_I64, "key_type");
+  hctr_cache* c = new hctr_cache();
+  c->num_sets = capacity_in_set;
+  c->D = vec_size;
+  c->key_type = key_type;
+  c->empty_key = key_type == HCTR_KEY_U32 ? KeyTraits<uint32_t>::empty : KeyTraits<long long>::empty;
+  const size_t slots = capacity_in_set * kSetSlots;
+  bool ok = hipMalloc(&c->set_keys, slots * 8) == hipSuccess &&
+            hipMalloc(&c->counters, slots * 8) == hipSuccess &&
+            hipMalloc(&c->vals, slots * (size_t)vec_size * sizeof(float)) == hipSuccess &&
+            hipMalloc(&c->global_counter, 8) == hipSuccess;
+  if (ok) ok = hipMemset(c->global_counter, 0, 8) == hipSuccess;
+  if (!ok) {
+    set_error("hctr_cache_create: allocation failed");
+    if (c->set_keys) (void)hipFree(c->set_keys);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->vals) (void)hipFree(c->vals);
+    if (c->global_counter) (void)hipFree(c->global_counter);
+    delete c;
+    return HCTR_ERR_HIP;
+  }
+  hipLaunchKernelGGL(cache_init_kernel, dim3(grid_for(slots, kBlock, 4096)), dim3(kBlock), 0, 0,
+                     slots, c->empty_key, c->set_keys, c->counters);
+  (void)hipDeviceSynchronize();
+  *out = c;
+  return HCTR_OK;
+}
+
+int hctr_cache_destroy(hctr_cache* c) {
+  if (!c) return HCTR_OK;
+  (void)hipDeviceSynchronize();
+  c->free_scratch();
+  (void)hipFree(c->set_keys);
+  (void)hipFree(c->counters);
+  (void)hipFree(c->vals);
+  (void)hipFree(c->global_counter);
+  delete c;
+  return HCTR_OK;
+}
+
+int hctr_cache_query(hctr_cache* c, const void* keys, size_t len, float* values,
+                     uint64_t* missing_index, void* missing_keys, size_t* d_missing_len,
+                     hctr_stream_t stream) {
+  HCTR_REQUIRE(c && d_missing_len, "null pointer");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(cache_tick_kernel, dim3(1), dim3(64), 0, s, c->global_counter, d_missing_len);
+  HCTR_LAUNCH_CHECK();
+  if (len == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys, "null pointer");
+  HCTR_REQUIRE(len < 0xFFFFFFF0ull, "len");
+  HCTR_TRY(c->reserve(len, s));
+  if (c->key_type == HCTR_KEY_U32)
+    return cache_query_typed<uint32_t>(c, (const uint32_t*)keys, len, values, missing_index,
+                                       (uint32_t*)missing_keys, d_missing_len, s);
+  return cache_query_typed<long long>(c, (const long long*)keys, len, values, missing_index,
+                                      (long long*)missing_keys, d_missing_len, s);
+}
+
+int hctr_cache_replace(hctr_cache* c, const void* keys, size_t len, const float* values,
+                       hctr_stream_t stream) {
+  HCTR_REQUIRE(c, "null handle");
+  if (len == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && values, "null pointer");
+  HCTR_REQUIRE(len < 0xFFFFFFF0ull, "len");
+  hipStream_t s = as_stream(stream);
+  if (c->key_type == HCTR_KEY_U32)
+    return cache_modify_typed<uint32_t>(c, true, (const uint32_t*)keys, len, nullptr, values,
+                                        nullptr, s);
+  return cache_modify_typed<long long>(c, true, (const long long*)keys, len, nullptr, values,
+                                       nullptr, s);
+}
+
+int hctr_cache_update(hctr_cache* c, const void* keys, size_t len, const float* values,
+                      hctr_stream_t stream) {
+  HCTR_REQUIRE(c, "null handle");
+  if (len == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && values, "null pointer");
+  HCTR_REQUIRE(len < 0xFFFFFFF0ull, "len");
+  hipStream_t s = as_stream(stream);
+  if (c->key_type == HCTR_KEY_U32)
+    return cache_modify_typed<uint32_t>(c, false, (const uint32_t*)keys, len, nullptr, values,
+                                        nullptr, s);
+  return cache_modify_typed<long long>(c, false, (const long long*)keys, len, nullptr, values,
+                                       nullptr, s);
+}
+
+int hctr_cache_dump(hctr_cache* c, void* keys, size_t* d_dump_counter, size_t start_set_index,
+                    size_t end_set_index, hctr_stream_t stream) {
+  HCTR_REQUIRE(c && d_dump_counter, "null pointer");
+  HCTR_REQUIRE(start_set_index <= end_set_index && end_set_index <= c->num_sets,
+               "set range out of bounds");
+  hipStream_t s = as_stream(stream);
+  const size_t n = end_set_index - start_set_index;
+  if (n == 0) {
+    HCTR_HIP(hipMemsetAsync(d_dump_counter, 0, sizeof(size_t), s));
+    return HCTR_OK;
+  }
+  HCTR_REQUIRE(keys, "null pointer");
+  HCTR_TRY(c->reserve(n, s));
+  const int grid = grid_for(n * 64, kBlock, 1 << 16);
+  hipLaunchKernelGGL(cache_dump_count_kernel, dim3(grid), dim3(kBlock), 0, s, c->set_keys,
+                     start_set_index, n, c->empty_key, c->flags);
+  HCTR_LAUNCH_CHECK();
+  HCTR_TRY(exclusive_scan_to_offsets<uint32_t>(c->flags, n, c->tile_sums, c->d_total, c->before, s));
+  if (c->key_type == HCTR_KEY_U32)
+    hipLaunchKernelGGL(cache_dump_emit_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s,
+                       c->set_keys, start_set_index, n, c->empty_key, c->before, (uint32_t*)keys,
+                       d_dump_counter);
+  else
+    hipLaunchKernelGGL(cache_dump_emit_kernel<long long>, dim3(grid), dim3(kBlock), 0, s,
+                       c->set_keys, start_set_index, n, c->empty_key, c->before, (long long*)keys,
+                       d_dump_counter);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_cache_capacity_in_set(const hctr_cache* c) { return c ? c->num_sets : 0; }
+
+}  // extern "C"
+
+// ---- host <-> HBM tiered table -------------------------------------------------------------------
+struct hctr_tiered {
+  hctr_cache* cache = nullptr;
+  size_t rows = 0;
+  int D = 0;
+  float* host = nullptr;      // pinned, device-mapped
+  float* host_dev = nullptr;  // the same memory as the GPU addresses it
+  size_t cap = 0;
+  long long* miss_keys = nullptr;
+  uint64_t* miss_index = nullptr;
+  size_t* d_missing_len = nullptr;
+
+  int reserve(size_t n, hipStream_t s) {
+    if (n <= cap) return HCTR_OK;
+    if (cap) HCTR_HIP(hipStreamSynchronize(s));
+    if (miss_keys) (void)hipFree(miss_keys);
+    if (miss_index) (void)hipFree(miss_index);
+    miss_keys = nullptr;
+    miss_index = nullptr;
+    size_t c = 1024;
+    while (c < n) c *= 2;
+    HCTR_HIP(hipMalloc(&miss_keys, c * 8));
+    HCTR_HIP(hipMalloc(&miss_index, c * 8));
+    cap = c;
+    return HCTR_OK;
+  }
+};
+
+extern "C" {
+
+int hctr_tiered_create(size_t host_rows, int vec_size, size_t cache_capacity_in_set,
+                       hctr_tiered** out) {
+  HCTR_REQUIRE(out && host_rows > 0 && vec_size > 0 && cache_capacity_in_set > 0, "arguments");
+  hctr_tiered* t = new hctr_tiered();
+  t->rows = host_rows;
+  t->D = vec_size;
+  int rc = hctr_cache_create(cache_capacity_in_set, vec_size, HCTR_KEY_I64, &t->cache);
+  if (rc != HCTR_OK) {
+    delete t;
+    return rc;
+  }
+  const size_t bytes = host_rows * (size_t)vec_size * sizeof(float);
+  bool ok = hipHostMalloc((void**)&t->host, bytes, hipHostMallocMapped | hipHostMallocPortable) ==
+            hipSuccess;
+  if (ok) ok = hipHostGetDevicePointer((void**)&t->host_dev, t->host, 0) == hipSuccess;
+  if (ok) ok = hipMalloc(&t->d_missing_len, sizeof(size_t)) == hipSuccess;
+  if (!ok) {
+    set_error("hctr_tiered_create: host / device allocation failed");
+    if (t->host) (void)hipHostFree(t->host);
+    hctr_cache_destroy(t->cache);
+    delete t;
+    return HCTR_ERR_HIP;
+  }
+  memset(t->host, 0, bytes);
+  *out = t;
+  return HCTR_OK;
+}
+
+int hctr_tiered_destroy(hctr_tiered* t) {
+  if (!t) return HCTR_OK;
+  (void)hipDeviceSynchronize();
+  hctr_cache_destroy(t->cache);
+  if (t->miss_keys) (void)hipFree(t->miss_keys);
+  if (t->miss_index) (void)hipFree(t->miss_index);
+  if (t->d_missing_len) (void)hipFree(t->d_missing_len);
+  if (t->host) (void)hipHostFree(t->host);
+  delete t;
+  return HCTR_OK;
+}
+
+float* hctr_tiered_host_rows(hctr_tiered* t) { return t ? t->host : nullptr; }
+hctr_cache* hctr_tiered_cache(hctr_tiered* t) { return t ? t->cache : nullptr; }
+
+int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* out,
+                       size_t* d_missing_len, hctr_stream_t stream) {
+  HCTR_REQUIRE(t, "null handle");
+  if (len == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && out, "null pointer");
+  hipStream_t s = as_stream(stream);
+  HCTR_TRY(t->reserve(len, s));
+  size_t* dml = d_missing_len ? d_missing_len : t->d_missing_len;
+  // 1. hits are copied out of the cache, misses are listed (no host round trip)
+  HCTR_TRY(hctr_cache_query(t->cache, keys, len, out, t->miss_index, t->miss_keys, dml, stream));
+  // 2. missing rows: host table -> output, over the host link, by the GPU itself
+  const int grid = grid_for(len * 64, kBlock, 1 << 14);
+  if (vec4_ok(t->D, out, t->host_dev))
+    hipLaunchKernelGGL(tier_fill_kernel<true>, dim3(grid), dim3(kBlock), 0, s, t->miss_keys,
+                       t->miss_index, dml, t->rows, t->D, t->host_dev, out);
+  else
+    hipLaunchKernelGGL(tier_fill_kernel<false>, dim3(grid), dim3(kBlock), 0, s, t->miss_keys,
+                       t->miss_index, dml, t->rows, t->D, t->host_dev, out);
+  HCTR_LAUNCH_CHECK();
+  // 3. ... and into the cache (values are read back from the output rows just written)
+  return cache_modify_typed<long long>(t->cache, true, t->miss_keys, len, dml, out, t->miss_index,
+                                       s);
+}
+
+int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,
+                        int add, hctr_stream_t stream) {
+  HCTR_REQUIRE(t, "null handle");
+  if (len == 0) return HCTR_OK;
+  HCTR_REQUIRE(unique_keys && values, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const int grid = grid_for(len * 64, kBlock, 1 << 14);
+  const hctr_cache* c = t->cache;
+  if (vec4_ok(t->D, values, c->vals))
+    hipLaunchKernelGGL(tier_scatter_kernel<true>, dim3(grid), dim3(kBlock), 0, s,
+                       (const long long*)unique_keys, len, values, add, t->rows, t->D, c->num_sets,
+                       c->set_keys, c->vals, t->host_dev);
+  else
+    hipLaunchKernelGGL(tier_scatter_kernel<false>, dim3(grid), dim3(kBlock), 0, s,
+                       (const long long*)unique_keys, len, values, add, t->rows, t->D, c->num_sets,
+                       c->set_keys, c->vals, t->host_dev);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+}  // extern "C"

@@ -176,6 +176,7 @@ class DynamicVariable(_VariableBase):
         self._det = DynamicEmbeddingTable([self.dimension], self.initializer_str, init_capacity,
                                           key_type, seed=seed + 1000003 * _RANK)
         self._opt: Optional[DynamicTableOptimizer] = None
+        self._updater = None  # (hctr_updater handle, capacity) of the gradient reduce
 
     @property
     def size(self) -> int:
@@ -483,9 +484,29 @@ class OptimizerWrapper:
     # does this with tf.unique / unsorted_segment_sum, optimizer.py:170-230) -> fused HIP step
     def _step_dynamic(self, var: DynamicVariable, keys, kg):
         D = var.dimension
-        uniq, inv = torch.unique(keys, return_inverse=True)
-        sums = torch.zeros((uniq.numel(), D), dtype=torch.float32, device=kg.device)
-        sums.index_add_(0, inv, kg)
+        n = keys.numel()
+        keys = keys.contiguous()
+        # unique keys + per-key gradient sums in ascending position order (deterministic): the
+        # path's local reduce, sorted by the keys' row numbers in the table
+        _, rows, base = var._det.lookup_rows(keys, insert=False, want_ptrs=False)
+        if var._updater is None or var._updater[1] < n:
+            if var._updater is not None:
+                lib.hctr_updater_destroy(var._updater[0])
+            h = ctypes.c_void_p()
+            cap = max(2 * n, 1024)
+            check(lib.hctr_updater_create(cap, cap, D, ctypes.byref(h)))
+            var._updater = (h, cap)
+        ro = torch.arange(n + 1, dtype=torch.int64, device=kg.device)
+        urow = torch.empty(n, dtype=torch.int64, device=kg.device)
+        ukey = torch.empty(n, dtype=torch.int64, device=kg.device)
+        wg = torch.empty((n, D), dtype=torch.float32, device=kg.device)
+        nu = ctypes.c_size_t()
+        k64 = keys if keys.dtype == torch.int64 else keys.to(torch.int64)
+        check(lib.hctr_ebc_local_reduce(var._updater[0], n, n, ptr(ro), ptr(rows), base[-1],
+                                        ptr(k64), ptr(kg.contiguous()), _lib.F32, ctypes.byref(nu),
+                                        ptr(urow), ptr(ukey), ptr(wg), stream_ptr()))
+        uniq = ukey[:nu.value].to(keys.dtype)
+        sums = wg[:nu.value]
         if var._opt is None or var._opt.p.optimizer != self.code:
             hp = self.hp
             var._opt = DynamicTableOptimizer(

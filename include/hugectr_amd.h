@@ -456,6 +456,52 @@ int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float
                            const float* h, const float* bias, float* hidden_out, float* out,
                            hctr_stream_t stream);
 
+/* ---- embedding cache in HBM + host<->HBM tiered table (BASELINE config 4) ----------------------
+ * gpu_cache::gpu_cache<key, ref_counter, empty_key, SET_ASSOCIATIVITY 2, SLAB_SIZE 32>
+ * (R/gpu_cache/include/nv_gpu_cache.hpp:46-124, R/gpu_cache/src/nv_gpu_cache.cu): a key lives in set
+ * MurmurHash3_32(key) % capacity_in_set, 64 slots per set, least-recently-used replacement driven
+ * by a global counter that every Query advances.  All pointers are device pointers; the calls of
+ * one cache must be stream-ordered.  Results are deterministic: inside one call, keys that share a
+ * set are applied in position order. */
+typedef struct hctr_cache hctr_cache;
+int hctr_cache_create(size_t capacity_in_set, int vec_size, int key_type, hctr_cache** out);
+int hctr_cache_destroy(hctr_cache* c);
+size_t hctr_cache_capacity_in_set(const hctr_cache* c);
+/* Query (:53-56): hits copy their vector to values[i] and become most recent; misses leave
+ * values[i] untouched and are listed in ascending position: missing_index / missing_keys
+ * [*d_missing_len].  values / missing_index / missing_keys may be NULL. */
+int hctr_cache_query(hctr_cache* c, const void* keys, size_t len, float* values,
+                     uint64_t* missing_index, void* missing_keys, size_t* d_missing_len,
+                     hctr_stream_t stream);
+/* Replace (:58-60): a cached key is refreshed (its vector stays); a new key takes an empty slot
+ * of its set, else evicts the set's least recently used key. */
+int hctr_cache_replace(hctr_cache* c, const void* keys, size_t len, const float* values,
+                       hctr_stream_t stream);
+/* Update (:62-64): overwrite the vectors of the keys that are cached, ignore the others */
+int hctr_cache_update(hctr_cache* c, const void* keys, size_t len, const float* values,
+                      hctr_stream_t stream);
+/* Dump (:66-68): the cached keys of sets [start_set_index, end_set_index), (set, slot) order */
+int hctr_cache_dump(hctr_cache* c, void* keys, size_t* d_dump_counter, size_t start_set_index,
+                    size_t end_set_index, hctr_stream_t stream);
+
+/* The role of gpu_cache::UvmTable (R/gpu_cache/include/uvm_table.hpp:133-174) for the training
+ * path: the full table [host_rows][vec] fp32 lives in pinned host memory (key = row), the cache
+ * above holds the hot rows.  lookup = Query + the GPU reading the missing rows straight out of
+ * host memory into `out` + Replace -- three launches, no host synchronisation (rows outside
+ * [0, host_rows) read as zeros).  d_missing_len (device, may be NULL) receives the miss count.
+ * scatter: write-through update of UNIQUE rows, new = (add ? old : 0) + values[i], stored in the
+ * host table and in the cached copy when there is one. */
+typedef struct hctr_tiered hctr_tiered;
+int hctr_tiered_create(size_t host_rows, int vec_size, size_t cache_capacity_in_set,
+                       hctr_tiered** out);
+int hctr_tiered_destroy(hctr_tiered* t);
+float* hctr_tiered_host_rows(hctr_tiered* t); /* HOST pointer: initialise / checkpoint the table */
+hctr_cache* hctr_tiered_cache(hctr_tiered* t);
+int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* out,
+                       size_t* d_missing_len, hctr_stream_t stream);
+int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,
+                        int add, hctr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+"""GPU parity: embedding cache (hctr_cache_*: Query / Replace / Update / Dump of gpu_cache::gpu_cache,
+R/gpu_cache/src/nv_gpu_cache.cu) and the host<->HBM tiered table (hctr_tiered_*) against the
+sequential restatement in oracle/cache_oracle.py.  Everything is compared exactly: which keys hit,
+the order of the missing list, which key every eviction removes, the slot order of Dump."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("key_dtype", ["i64", "u32"])
+@pytest.mark.parametrize("D,num_sets", [(16, 3), (10, 5), (128, 2)])
+def test_cache_matches_oracle(key_dtype, D, num_sets):
+    import torch
+    from hugectr_amd.cache import GpuCache
+    from oracle.cache_oracle import CacheOracle
+    rng = np.random.default_rng(D * 10 + num_sets)
+    tdt = torch.int64 if key_dtype == "i64" else torch.int32
+    ndt = np.int64 if key_dtype == "i64" else np.int32
+    c = GpuCache(num_sets, D, tdt)
+    o = CacheOracle(num_sets, D, 8 if key_dtype == "i64" else 4)
+    universe = num_sets * 64 * 3                    # 3x the capacity: evictions every round
+    table = rng.standard_normal((universe, D)).astype(np.float32)
+    for it in range(12):
+        n = int(rng.integers(1, 400))
+        keys = np.minimum(rng.pareto(0.8, size=n) * 20, universe - 1).astype(ndt)  # skewed, duplicates
+        tk = torch.from_numpy(keys).cuda()
+        vals = torch.full((n, D), -7.0, device="cuda")
+        mi, mk = c.Query(tk, vals)
+        want = np.full((n, D), -7.0, np.float32)
+        wmi, wmk = o.query(keys, want)
+        assert (mi.cpu().numpy() == wmi).all() and mi.numel() == wmi.size, f"missing index it{it}"
+        assert (mk.cpu().numpy().astype(np.int64) == wmk).all(), f"missing keys it{it}"
+        assert (vals.cpu().numpy() == want).all(), f"hit values it{it}"
+        # fetch the missing rows "from the backing store" and insert them
+        mkeys = keys[wmi]
+        c.Replace(torch.from_numpy(mkeys).cuda(), torch.from_numpy(table[mkeys]).cuda())
+        o.replace(mkeys, table[mkeys])
+        if it % 3 == 1:                             # refresh some vectors in place
+            uk = rng.integers(0, universe, size=150).astype(ndt)
+            uv = rng.standard_normal((150, D)).astype(np.float32)
+            c.Update(torch.from_numpy(uk).cuda(), torch.from_numpy(uv).cuda())
+            o.update(uk, uv)
+            last = {}
+            for i, k in enumerate(uk):
+                last[int(k)] = i
+            for k, i in last.items():
+                table[k] = uv[i]                    # the backing store sees the update too
+        got = c.Dump().cpu().numpy().astype(np.int64)
+        assert (got == o.dump(0, num_sets)).all(), f"dump it{it}"
+        a, b = sorted(rng.integers(0, num_sets + 1, size=2))
+        assert (c.Dump(int(a), int(b)).cpu().numpy().astype(np.int64) == o.dump(int(a), int(b))).all()
+    # every cached key returns the oracle's vector
+    ks = o.dump(0, num_sets).astype(ndt)
+    vals = torch.zeros((ks.size, D), device="cuda")
+    mi, _ = c.Query(torch.from_numpy(ks).cuda(), vals)
+    want = np.zeros((ks.size, D), np.float32)
+    o.query(ks, want)
+    assert mi.numel() == 0
+    assert (vals.cpu().numpy() == want).all()
+
+
+def test_cache_large_batch_and_duplicates():
+    """one Replace with far more keys than slots and heavy duplication: the survivors of every set
+    are the ones the position-ordered walk leaves"""
+    import torch
+    from hugectr_amd.cache import GpuCache
+    from oracle.cache_oracle import CacheOracle
+    rng = np.random.default_rng(1)
+    D, num_sets = 8, 16
+    c, o = GpuCache(num_sets, D), CacheOracle(num_sets, D)
+    keys = rng.integers(0, 6000, size=20000).astype(np.int64)
+    vals = rng.standard_normal((keys.size, D)).astype(np.float32)
+    for _ in range(2):
+        c.Query(torch.from_numpy(keys[:10]).cuda())
+        o.query(keys[:10], None)
+        c.Replace(torch.from_numpy(keys).cuda(), torch.from_numpy(vals).cuda())
+        o.replace(keys, vals)
+        assert (c.Dump().cpu().numpy() == o.dump(0, num_sets)).all()
+    ks = o.dump(0, num_sets)
+    got = torch.zeros((ks.size, D), device="cuda")
+    c.Query(torch.from_numpy(ks).cuda(), got)
+    want = np.zeros((ks.size, D), np.float32)
+    o.query(ks, want)
+    assert (got.cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("D", [32, 6])
+def test_tiered_table_matches_oracle(D):
+    import torch
+    from hugectr_amd.cache import TieredTable
+    from oracle.cache_oracle import TieredOracle
+    rng = np.random.default_rng(D)
+    rows, num_sets = 5000, 8                         # cache holds 512 of 5000 rows
+    t = TieredTable(rows, D, num_sets)
+    o = TieredOracle(rows, D, num_sets)
+    init = rng.standard_normal((rows, D)).astype(np.float32)
+    t.host[:] = init
+    o.host[:] = init
+    misses = []
+    for it in range(10):
+        n = int(rng.integers(50, 900))
+        keys = np.minimum(rng.pareto(1.05, size=n) * 30, rows + 5).astype(np.int64)  # some out of range
+        out = t.lookup(torch.from_numpy(keys).cuda())
+        want, nmiss = o.lookup(keys)
+        assert (out.cpu().numpy() == want).all(), f"lookup it{it}"
+        assert t.last_missing() == nmiss
+        misses.append(nmiss / n)
+        uk = np.unique(keys)
+        g = rng.standard_normal((uk.size, D)).astype(np.float32)
+        if it % 4 == 3:
+            t.scatter_update(torch.from_numpy(uk).cuda(), torch.from_numpy(g).cuda())
+            o.scatter(uk, g, add=False)
+        else:
+            t.scatter_add(torch.from_numpy(uk).cuda(), torch.from_numpy(g).cuda())
+            o.scatter(uk, g, add=True)
+        torch.cuda.synchronize()
+        assert (t.host == o.host).all(), f"host table it{it}"
+        assert (t.cache.Dump().cpu().numpy() == o.cache.dump(0, num_sets)).all(), f"cache keys it{it}"
+    assert misses[-1] < misses[0]                   # the hot rows stay cached
+    ks = o.cache.dump(0, num_sets)
+    got = torch.zeros((ks.size, D), device="cuda")
+    t.cache.Query(torch.from_numpy(ks).cuda(), got)
+    want = np.zeros((ks.size, D), np.float32)
+    o.cache.query(ks, want)
+    assert (got.cpu().numpy() == want).all()
