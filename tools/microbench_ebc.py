@@ -1,4 +1,5 @@
-"""embedding_collection (static tables) forward / backward+update at the DLRM Criteo-1TB shape, 1 GPU."""
+"""embedding_collection forward / backward+update at the DLRM Criteo-1TB shape, 1 GPU
+(argv[1] = static | dynamic; dynamic tables start empty and grow, the timed steps run on warm tables)."""
 import os
 import sys
 
@@ -31,15 +32,17 @@ def main():
     tabs = [EmbeddingTableConfig(f"t{i}", v, D) for i, v in enumerate(CRITEO_1TB)]
     cfg.embedding_lookup(tabs, [f"b{i}" for i in range(26)], [f"e{i}" for i in range(26)],
                          ["sum"] * 26)
+    storage = sys.argv[1] if len(sys.argv) > 1 else "static"
     ebc = EmbeddingCollection.for_rank(0, 1, cfg, B, lr=0.01, optimizer=_lib.OPT_SGD,
-                                       out_dtype=torch.bfloat16, max_hotness=1)
+                                       out_dtype=torch.bfloat16, max_hotness=1, storage=storage,
+                                       init_capacity=1 << 21)
     rng = np.random.default_rng(0)
     keys = np.concatenate([powerlaw(rng, B, v, 1.1) for v in CRITEO_1TB]).astype(np.int64)  # feature-major
     kt = torch.from_numpy(keys).cuda()
     br = torch.arange(0, 26 * B + 1, dtype=torch.int64, device="cuda")
     out = ebc.forward(kt, br)
     g = torch.randn(out.shape, device="cuda").to(out.dtype)
-    print({"forward_us": round(timed(lambda: ebc.forward(kt, br)), 1),
+    print({"storage": storage, "forward_us": round(timed(lambda: ebc.forward(kt, br)), 1),
            "backward+update_us": round(timed(lambda: ebc.backward_and_update(g)), 1),
            "out_shape": list(out.shape)})
 
