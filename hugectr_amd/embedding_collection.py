@@ -51,11 +51,15 @@ class EmbeddingTableConfig:
 class EmbeddingCollectionConfig:
     def __init__(self, use_exclusive_keys: bool = True, comm_strategy: str = "Uniform"):
         self.lookups = []  # (table_config, bottom_name, top_name, combiner)
-        self.shard_matrix: Optional[List[List[int]]] = None
+        self.shard_matrix = None
         self.shard_strategy = "mp"
+        self.top_name: Optional[str] = None  # one name for the concatenated output (train.py:398)
 
     def embedding_lookup(self, table_config, bottom_name, top_name, combiner):
         if isinstance(table_config, (list, tuple)):
+            if isinstance(top_name, str):  # all lookups feed one [batch, sum(ev)] tensor
+                self.top_name = top_name
+                top_name = [top_name] * len(table_config)
             for t, b, tp, c in zip(table_config, bottom_name, top_name, combiner):
                 self.lookups.append((t, b, tp, c))
         else:
@@ -63,9 +67,32 @@ class EmbeddingCollectionConfig:
         return self
 
     def shard(self, shard_matrix, shard_strategy="mp", compression_strategy=None):
+        """shard_matrix: either [gpu][table] in {0, 1}, or the reference's form
+        (embedding_collection_wrapper.hpp / samples/dlrm/train.py:404): per GPU the list of table
+        NAMES it holds, with shard_strategy = [("mp", names), ("dp", names)]."""
         self.shard_matrix = [list(r) for r in shard_matrix]
         self.shard_strategy = shard_strategy
         return self
+
+    def ownership(self, tables, world) -> List[List[int]]:
+        """-> [gpu][table] in {0, 1}.  A table listed on several GPUs is row-sharded over them; a
+        "dp" table (replicated in the reference) is held row-sharded over its GPUs as well -- same
+        results, no replica to keep in sync."""
+        T = len(tables)
+        sm = self.shard_matrix
+        if sm is None:
+            return [[1] * T for _ in range(world)]
+        assert len(sm) == world, f"shard_matrix has {len(sm)} rows for {world} GPUs"
+        binary = all(len(r) == T and all(isinstance(v, int) and not isinstance(v, bool) and
+                                         v in (0, 1) for v in r) for r in sm)
+        if binary:
+            return [list(r) for r in sm]
+        index = {t.name: i for i, t in enumerate(tables)}
+        own = [[0] * T for _ in range(world)]
+        for g, row in enumerate(sm):
+            for name in row:
+                own[g][index[str(name)]] = 1
+        return own
 
 
 class EmbeddingCollection:
@@ -120,8 +147,7 @@ class EmbeddingCollection:
         self.L = len(config.lookups)
         self.lookup_table = [tables.index(t) for t, _, _, _ in config.lookups]
         self.combiner = [0 if str(c).lower() in ("sum", "0") else 1 for _, _, _, c in config.lookups]
-        sm = config.shard_matrix or [[1] * len(tables) for _ in range(self.world)]
-        assert len(sm) == self.world and all(len(r) == len(tables) for r in sm)
+        sm = config.ownership(tables, self.world)
         # owners of every table, ascending GPU order (shard id = position in that list)
         self.owners = [[g for g in range(self.world) if sm[g][t]] for t in range(len(tables))]
         assert all(self.owners), "every table needs at least one owner"

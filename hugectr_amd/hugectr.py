@@ -28,6 +28,8 @@ import torch.distributed as dist
 from . import _lib
 from .dense import FusedMLP
 from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward_reorder
+from .embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfig,  # noqa: F401
+                                   EmbeddingTableConfig)
 from .layers import MultiCrossLayer, interaction
 from .parallel import DistributedExchange, LocalizedExchange
 from . import data as _data
@@ -242,6 +244,17 @@ class Input:
         self.sparse_params: List[DataReaderSparseParam] = list(data_reader_sparse_param_array)
 
 
+class CommunicationStrategy(enum.Enum):  # R/HugeCTR/include/embedding/common.hpp
+    Uniform = 0
+    Hierarchical = 1
+
+
+@dataclass
+class DenseLayerComputeConfig:  # scheduling hints of the reference's MLP layer; accepted, unused
+    async_wgrad: bool = False
+    fuse_wb: bool = False
+
+
 class SparseEmbedding:
     def __init__(self, embedding_type, embedding_vec_size, combiner, sparse_embedding_name,
                  bottom_name, workspace_size_per_gpu_in_mb=0, slot_size_array=(), optimizer=None):
@@ -327,6 +340,7 @@ class Model:
         torch.manual_seed(solver.seed + 1)
         self.input: Optional[Input] = None
         self.embeddings: List[SparseEmbedding] = []
+        self.ebc_configs: List[EmbeddingCollectionConfig] = []
         self.layers: List[DenseLayer] = []
         self._compiled = False
         self._loss = float("nan")
@@ -339,6 +353,8 @@ class Model:
             self.input = item
         elif isinstance(item, SparseEmbedding):
             self.embeddings.append(item)
+        elif isinstance(item, EmbeddingCollectionConfig):
+            self.ebc_configs.append(item)  # use_embedding_collection path (model.cpp add(ebc))
         elif isinstance(item, DenseLayer):
             self.layers.append(item)
         else:
@@ -387,6 +403,9 @@ class Model:
                     bb, p.slot_num, se.embedding_vec_size)
             self._emb[se.sparse_embedding_name] = (se, p, h, ex, localized)
             self._shapes[se.sparse_embedding_name] = (p.slot_num, se.embedding_vec_size)
+        self._ebc = []
+        for cfg in self.ebc_configs:
+            self._ebc.append(self._compile_ebc(cfg, sp, B, Be))
         # dense modules
         self._mods = torch.nn.ModuleDict()
         self._loss_layer = None
@@ -398,6 +417,68 @@ class Model:
         self.reader = _data.make_reader(self.reader_params, self.input, s, self.rank, self.world,
                                         self.device)
         self._compiled = True
+
+    def _compile_ebc(self, cfg: EmbeddingCollectionConfig, sp, B, Be):
+        """embedding_collection of the model (R/HugeCTR/src/pybind/add_embedding_collection.cpp):
+        one runtime for the training batch, one for the evaluation batch, sharing the tables"""
+        o = self.opt
+        t = Optimizer_t(o.optimizer_type)
+        code = {Optimizer_t.SGD: _lib.OPT_SGD, Optimizer_t.AdaGrad: _lib.OPT_ADAGRAD,
+                Optimizer_t.Ftrl: _lib.OPT_FTRL}.get(t)
+        if code is None:
+            raise RuntimeError("embedding_collection tables support SGD, AdaGrad and Ftrl "
+                               "(R/HugeCTR/embedding_storage/ragged_static_embedding.cu:593-700)")
+        params, offsets = [], []
+        slot0, slot_of_param = 0, {}
+        for p in self.input.sparse_params:
+            slot_of_param[p.top_name] = slot0
+            slot0 += p.slot_num
+        ssa = list(self.reader_params.slot_size_array or [])
+        cum = np.concatenate([[0], np.cumsum(ssa)]).astype(np.int64) if ssa else None
+        for _, bottom, _, _ in cfg.lookups:
+            p = sp[bottom]
+            if p.slot_num != 1:
+                raise RuntimeError("embedding_collection inputs carry one slot per lookup "
+                                   "(DataReaderSparseParam(name, hotness, fixed, 1))")
+            params.append(p)
+            # the readers add cumulative slot offsets for the legacy embeddings; tables of a
+            # collection are indexed by the raw key
+            offsets.append(int(cum[slot_of_param[bottom]]) if cum is not None else 0)
+        hot = max(p.max_nnz() for p in params)
+        kw = dict(lr=self._lr, optimizer=code, scaler=self.solver.scaler, epsilon=o.epsilon,
+                  initial_accu_value=o.initial_accu_value, out_dtype=self.emb_dtype,
+                  batch_major=True, max_hotness=hot, seed=self.solver.seed,
+                  ftrl=(o.lambda1, o.lambda2, o.beta))
+        train = EmbeddingCollection(cfg, B, **kw)
+        ev = None
+        if Be > 0:
+            ev = train if Be == B else EmbeddingCollection(cfg, Be, **kw)
+            if ev is not train:  # same tables, own per-batch scratch
+                ev.table, ev.accum, ev.ftrl_z = train.table, train.accum, train.ftrl_z
+        L, evs = train.L, train.ev
+        if cfg.top_name:
+            self._shapes[cfg.top_name] = (L, evs)
+        else:
+            for _, _, top, _ in cfg.lookups:
+                self._shapes[top] = (evs,)
+        return dict(cfg=cfg, train=train, eval=ev, params=params,
+                    offsets=torch.tensor(offsets, dtype=torch.int64, device=self.device))
+
+    def _ebc_forward(self, rt, batch, train: bool) -> torch.Tensor:
+        """global feature-major CSR of the collection's lookups -> [batch/world, lookups, ev]"""
+        e = rt["train"] if train else rt["eval"]
+        ros, keys = [], []
+        for p in rt["params"]:
+            ro, k = batch["sparse"][p.top_name]
+            ros.append(ro.to(torch.int64))
+            keys.append(k.to(torch.int64))
+        ends = torch.stack([r[-1] for r in ros])
+        base = torch.cumsum(ends, 0) - ends                      # first key of every lookup
+        gbr = torch.cat([r[:-1] + base[l] for l, r in enumerate(ros)] + [ends.sum().view(1)])
+        gk = torch.cat([k - rt["offsets"][l] for l, k in enumerate(keys)])
+        send = e.route_and_pool(gk, gbr)
+        recv = e._a2a(send, e.send_counts, e.recv_counts)
+        return e.network_forward(recv)
 
     def _in_width(self, name):
         shp = self._shapes[name]
@@ -545,6 +626,17 @@ class Model:
                 E = E.detach().requires_grad_(True)
                 leaves[name] = E
             tensors[name] = E
+        for i, rt in enumerate(self._ebc):
+            E = self._ebc_forward(rt, batch, train)
+            if train:
+                E = E.detach().requires_grad_(True)
+                leaves[("ebc", i)] = E
+            cfg = rt["cfg"]
+            if cfg.top_name:
+                tensors[cfg.top_name] = E
+            else:
+                for l, (_, _, top, _) in enumerate(cfg.lookups):
+                    tensors[top] = E[:, l, :]
         logit = self._forward_dense(tensors, train)
         label = batch["label"].float()
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
@@ -562,6 +654,9 @@ class Model:
                 top = ex["train"].backward(g.contiguous())
             h.backward(top.contiguous())
             h.update_params()
+        for i, rt in enumerate(self._ebc):
+            rt["train"].lr = self._lr
+            rt["train"].backward_and_update(leaves[("ebc", i)].grad.contiguous())
         if self._dense_opt is not None:
             if self.world > 1:
                 for q in self._dense_params:
@@ -631,6 +726,11 @@ class Model:
         for name, (se, p, h, _, _) in self._emb.items():
             print(f"{se.embedding_type.name:<40}{se.bottom_name:<30}{name:<30}"
                   f"({self.bpg},{p.slot_num},{se.embedding_vec_size})")
+        for rt in self._ebc:
+            cfg, e = rt["cfg"], rt["train"]
+            print(f"{'EmbeddingCollection':<40}{','.join(b for _, b, _, _ in cfg.lookups)[:28]:<30}"
+                  f"{(cfg.top_name or ','.join(t for _, _, t, _ in cfg.lookups))[:28]:<30}"
+                  f"({self.bpg},{e.L},{e.ev})")
         for L in self.layers:
             tops = ",".join(L.top_names)
             shp = self._shapes.get(L.top_names[0], ()) if L.top_names else ()
@@ -693,6 +793,11 @@ class Model:
             if localized:
                 slot.cpu().numpy().astype("<u8").tofile(os.path.join(d, "slot_id"))
             vec.cpu().numpy().astype("<f4").tofile(os.path.join(d, "emb_vector"))
+        for i, rt in enumerate(self._ebc):  # one file per rank: its flat [rows][ev] shard table
+            d = f"{prefix}_ebc{i}_sparse_{iteration}.model"
+            os.makedirs(d, exist_ok=True)
+            rt["train"].table.cpu().numpy().astype("<f4").tofile(
+                os.path.join(d, f"emb_vector.rank{self.rank}"))
         if self.rank == 0 and self._dense_params:
             flat = torch.cat([q.detach().flatten().float() for q in self._dense_params])
             flat.cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")
@@ -735,6 +840,12 @@ class Model:
                                "combiner": "sum" if se.combiner == 0 else "mean",
                                "workspace_size_per_gpu_in_mb": se.workspace_size_per_gpu_in_mb,
                                "slot_size_array": se.slot_size_array}})
+        for cfg in self.ebc_configs:
+            layers.append({"type": "EmbeddingCollection",
+                           "lookups": [{"table": t.name, "max_vocabulary_size": t.max_vocabulary_size,
+                                        "ev_size": t.ev_size, "bottom": b, "top": tp, "combiner": str(c)}
+                                       for t, b, tp, c in cfg.lookups],
+                           "shard_matrix": cfg.shard_matrix})
         for L in self.layers:
             layers.append({"type": L.layer_type.name, "bottom": L.bottom_names, "top": L.top_names})
         with open(graph_config_file, "w") as f:
