@@ -799,8 +799,41 @@ class Model:
             rt["train"].table.cpu().numpy().astype("<f4").tofile(
                 os.path.join(d, f"emb_vector.rank{self.rank}"))
         if self.rank == 0 and self._dense_params:
-            flat = torch.cat([q.detach().flatten().float() for q in self._dense_params])
-            flat.cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")
+            blobs = [b.detach().float().contiguous().flatten() for b, _ in self._dense_blobs()]
+            torch.cat(blobs).cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")
+
+    def _dense_blobs(self):
+        """the trainable dense tensors in the order and orientation of the reference's dense model
+        file (what R/onnx_converter/hugectr2onnx/hugectr_loader.py:336-520 reads back): per layer
+        in graph order -- InnerProduct / each MLP sub-layer: weight [in, out] then bias [out];
+        MultiCross: per cross layer w[width], b[width] (v1) or U[width, p], V[p, width], b (v2,
+        multi_cross_layer.cu:864-874); WeightMultiply: [slots, vec].  Yields (tensor in file
+        orientation, setter taking a tensor of that shape)."""
+        out = []
+
+        def direct(q):
+            return q, (lambda v, q=q: q.copy_(v.view_as(q)))
+
+        def transposed(q):  # torch keeps [out, in]
+            return q.t(), (lambda v, q=q: q.copy_(v.view(q.shape[1], q.shape[0]).t()))
+
+        for i, L in enumerate(self.layers):
+            m = self._mods[f"l{i}"] if f"l{i}" in self._mods else None
+            t = L.layer_type
+            if t == Layer_t.InnerProduct:
+                out += [transposed(m.weight), direct(m.bias)]
+            elif t == Layer_t.MLP:
+                for w, b in zip(m.weights, m.biases):
+                    out += [transposed(w), direct(b)]
+            elif t == Layer_t.MultiCross:
+                for l in range(m.num_layers):
+                    if m.projection_dim == 0:
+                        out += [direct(m.kernels[l]), direct(m.biases[l])]
+                    else:
+                        out += [direct(m.U[l]), direct(m.V[l]), direct(m.biases[l])]
+            elif t == Layer_t.WeightMultiply:
+                out += [direct(m.w)]
+        return out
 
     def load_sparse_weights(self, paths: Sequence[str]):
         for path, (name, (se, p, h, _, localized)) in zip(paths, self._emb.items()):
@@ -822,24 +855,60 @@ class Model:
         flat = torch.from_numpy(np.fromfile(path, dtype="<f4")).to(self.device)
         off = 0
         with torch.no_grad():
-            for q in self._dense_params:
-                q.copy_(flat[off:off + q.numel()].view_as(q))
-                off += q.numel()
+            for blob, put in self._dense_blobs():
+                n = blob.numel()
+                put(flat[off:off + n])
+                off += n
+        if off != flat.numel():
+            raise RuntimeError(f"{path}: {flat.numel()} values, the model's dense layers hold {off}")
+        for m in self._mods.values():
+            if isinstance(m, FusedMLP):
+                m.refresh_shadow()
 
     def graph_to_json(self, graph_config_file: str):
-        layers = [{"type": "Data", "label": {"top": self.input.label_name, "label_dim": self.input.label_dim},
-                   "dense": {"top": self.input.dense_name, "dense_dim": self.input.dense_dim},
+        """the reference's graph schema (save_graph_to_json,
+        R/HugeCTR/src/pybind/add_dense_layer.cpp:65-460): single bottom / top names are strings,
+        layer hyper-parameters sit under the reference's keys (fc_param, mlp_param, mc_param, ...)"""
+        def one_or_list(names):
+            return names[0] if len(names) == 1 else list(names)
+
+        inp = self.input
+        label = ({"top": inp.label_names[0], "label_dim": inp.label_dims[0]} if len(inp.label_names) == 1
+                 else {"top": list(inp.label_names), "label_dim": list(inp.label_dims)})
+        layers = [{"type": "Data", "label": label,
+                   "dense": {"top": inp.dense_name, "dense_dim": inp.dense_dim},
                    "sparse": [{"top": p.top_name, "slot_num": p.slot_num,
-                               "nnz_per_slot": p.nnz_per_slot, "is_fixed_length": p.is_fixed_length}
-                              for p in self.input.sparse_params]}]
+                               "nnz_per_slot": (list(p.nnz_per_slot)
+                                                if isinstance(p.nnz_per_slot, (list, tuple))
+                                                else [int(p.nnz_per_slot)] * p.slot_num),
+                               "is_fixed_length": p.is_fixed_length}
+                              for p in inp.sparse_params]}]
         for se in self.embeddings:
-            layers.append({"type": se.embedding_type.name, "name": se.sparse_embedding_name,
-                           "bottom": se.bottom_name, "top": se.sparse_embedding_name,
-                           "sparse_embedding_hparam": {
-                               "embedding_vec_size": se.embedding_vec_size,
-                               "combiner": "sum" if se.combiner == 0 else "mean",
-                               "workspace_size_per_gpu_in_mb": se.workspace_size_per_gpu_in_mb,
-                               "slot_size_array": se.slot_size_array}})
+            o = se.optimizer if (se.optimizer is not None and se.optimizer.initialized) else self.opt
+            t = Optimizer_t(o.optimizer_type)
+            hp = {Optimizer_t.Ftrl: ("ftrl_hparam", {"beta": o.beta, "lambda1": o.lambda1,
+                                                      "lambda2": o.lambda2}),
+                  Optimizer_t.Adam: ("adam_hparam", {"beta1": o.beta1, "beta2": o.beta2,
+                                                      "epsilon": o.epsilon}),
+                  Optimizer_t.AdaGrad: ("adagrad_hparam", {"initial_accu_value": o.initial_accu_value,
+                                                            "epsilon": o.epsilon}),
+                  Optimizer_t.MomentumSGD: ("momentum_sgd_hparam", {"momentum_factor": o.momentum_factor}),
+                  Optimizer_t.Nesterov: ("nesterov_hparam", {"momentum_factor": o.momentum_factor}),
+                  Optimizer_t.SGD: ("sgd_hparam", {"atomic_update": o.atomic_update})}.get(t)
+            opt = {"update_type": Update_t(o.update_type).name, "type": t.name}
+            if hp:
+                opt[hp[0]] = hp[1]
+            hparam = {"workspace_size_per_gpu_in_mb": se.workspace_size_per_gpu_in_mb,
+                      "embedding_vec_size": se.embedding_vec_size,
+                      "combiner": "sum" if se.combiner == 0 else "mean"}
+            if self._compiled:  # max_vocabulary_size_per_gpu x GPUs (model_compile.cpp:200-201)
+                h = self._emb[se.sparse_embedding_name][2]
+                hparam["max_vocabulary_size_global"] = h.get_max_vocabulary_size() * self.world
+            if se.slot_size_array:
+                hparam["slot_size_array"] = list(se.slot_size_array)
+            layers.append({"type": se.embedding_type.name, "bottom": se.bottom_name,
+                           "top": se.sparse_embedding_name, "sparse_embedding_hparam": hparam,
+                           "optimizer": opt})
         for cfg in self.ebc_configs:
             layers.append({"type": "EmbeddingCollection",
                            "lookups": [{"table": t.name, "max_vocabulary_size": t.max_vocabulary_size,
@@ -847,9 +916,53 @@ class Model:
                                        for t, b, tp, c in cfg.lookups],
                            "shard_matrix": cfg.shard_matrix})
         for L in self.layers:
-            layers.append({"type": L.layer_type.name, "bottom": L.bottom_names, "top": L.top_names})
+            t = L.layer_type
+            d = {"type": t.name, "bottom": one_or_list(L.bottom_names), "top": one_or_list(L.top_names)}
+            if t == Layer_t.Dropout:
+                d["rate"] = L.dropout_rate
+            elif t == Layer_t.ELU:
+                d["elu_param"] = {"alpha": L.elu_alpha}
+            elif t == Layer_t.MLP:
+                mp = {"num_output": L.num_output, "num_outputs": list(L.num_outputs)}
+                if L.biases:
+                    mp["biases"] = list(L.biases)
+                else:
+                    mp["use_bias"] = L.use_bias
+                if L.activations:
+                    mp["activations"] = [_ACT_NAME[a] for a in L.activations]
+                else:
+                    mp["activation"] = _ACT_NAME[L.act_type]
+                d["mlp_param"] = mp
+            elif t == Layer_t.InnerProduct:
+                d["fc_param"] = {"num_output": L.num_output}
+            elif t == Layer_t.MultiCross:
+                d["mc_param"] = {"num_layers": L.num_layers}
+                if L.projection_dim:
+                    d["mc_param"]["projection_dim"] = L.projection_dim
+            elif t == Layer_t.Reshape:
+                if L.selected_slots:
+                    d["selected"] = list(L.selected_slots)
+                else:
+                    d["leading_dim"], d["time_step"] = L.leading_dim, L.time_step
+            elif t == Layer_t.Concat:
+                d["axis"] = L.axis
+            elif t == Layer_t.Slice:
+                d["ranges"] = [list(r) for r in L.ranges]
+            elif t == Layer_t.WeightMultiply:
+                d["weight_dims"] = [int(v) for v in L.weight_dims]
+            elif t == Layer_t.FmOrder2:
+                d["out_dim"] = L.out_dim
+            elif t == Layer_t.ReduceSum:
+                d["axis"] = L.axis
+            elif t == Layer_t.Softmax:
+                d["factor"] = L.factor
+            layers.append(d)
         with open(graph_config_file, "w") as f:
             json.dump({"layers": layers}, f, indent=2)
+
+
+# FC_ACTIVATION_TO_STRING (R/HugeCTR/include/pybind/model.hpp:132-133)
+_ACT_NAME = {Activation_t.Relu: "Relu", Activation_t.Non: "None", Activation_t.Unspecified: "None"}
 
 
 def _auc(p: torch.Tensor, y: torch.Tensor) -> float:

@@ -257,3 +257,37 @@ def test_dcnv2_embedding_collection_script_trains(tmp_path, plan):
     assert (model._ebc[0]["train"].table != before).any()
     assert os.path.exists(tmp_path / "dcnv2_ebc0_sparse_200.model" / "emb_vector.rank0")
     model.graph_to_json(str(tmp_path / "graph.json"))
+
+
+@pytest.mark.parametrize("name", ["dcn", "dlrm"])
+def test_load_reference_format_checkpoint(tmp_path, name):
+    """the fixture under tests/golden/ckpt is in the reference's formats (verified with the
+    reference's own loader, tests/test_ckpt_format_cpu.py): load_dense_weights /
+    load_sparse_weights must bring a fresh model to exactly those weights, and saving again must
+    reproduce the files byte for byte"""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ckpt_fixture as fx
+    ck = os.path.join(here, "golden", "ckpt")
+    p = fx.gen(str(tmp_path / "data"))
+    m = getattr(fx, name)(p)
+    m.compile()
+    m.load_dense_weights(os.path.join(ck, f"{name}_dense_5.model"))
+    m.load_sparse_weights([os.path.join(ck, f"{name}0_sparse_5.model")])
+    want = np.load(os.path.join(ck, f"{name}_truth.npz"))
+    got = fx.truth(m)
+    for k in want.files:
+        if k.startswith("emb_"):
+            continue
+        assert (got[k] == want[k]).all(), k
+    o, w = np.argsort(got["emb_keys"]), np.argsort(want["emb_keys"])
+    assert (got["emb_keys"][o] == want["emb_keys"][w]).all()
+    assert (got["emb_vectors"][o] == want["emb_vectors"][w]).all()
+    m.save_params_to_files(str(tmp_path / name), 5)
+    a = np.fromfile(tmp_path / f"{name}_dense_5.model", dtype="<f4")
+    b = np.fromfile(os.path.join(ck, f"{name}_dense_5.model"), dtype="<f4")
+    assert (a == b).all()
+    m.graph_to_json(str(tmp_path / "g.json"))
+    import json
+    assert json.load(open(tmp_path / "g.json")) == json.load(open(os.path.join(ck, f"{name}.json")))
