@@ -332,9 +332,19 @@ class RawReader:
     Linux AIO worker threads -- I/O engines are outside the scope contract, the FORMAT is not)."""
 
     def __init__(self, path: str, inp, slot_size_array, batch, rank, world, device, num_samples,
-                 float_label_dense: bool, repeat: bool):
+                 float_label_dense: bool, repeat: bool, async_param=None):
         self.inp, self.batch, self.rank, self.world, self.device = inp, batch, rank, world, device
-        self.float_ld, self.repeat = float_label_dense, repeat
+        self.repeat = repeat
+        # two conventions exist in the reference:
+        # * the multi-hot async reader (AsyncParam, split_batch.cu:28-66): the label word is ALWAYS
+        #   an int32 (cast to float), dense words are floats when is_dense_float else ints fed
+        #   through log(x + 1) -- the MLPerf raw files (samples/dlrm/preprocessing/convert_to_raw.py);
+        # * files of the data generator (data_generator.hpp:977-1040): float_label_dense decides
+        #   for label AND dense together.
+        if async_param is not None and getattr(async_param, "multi_hot_reader", True):
+            self.float_label, self.float_dense = False, bool(async_param.is_dense_float)
+        else:
+            self.float_label = self.float_dense = bool(float_label_dense)
         self.hot = []  # static hotness per slot, over all sparse params
         for p in inp.sparse_params:
             h = p.nnz_per_slot
@@ -363,12 +373,10 @@ class RawReader:
         L, Dn = self.inp.label_dim, self.inp.dense_dim
         bpg = B // self.world
         sl = slice(self.rank * bpg, (self.rank + 1) * bpg)
-        if self.float_ld:
-            label = blk[:, :L].view(np.float32)
-            dense = blk[:, L:L + Dn].view(np.float32)
-        else:
-            label = blk[:, :L].view(np.int32).astype(np.float32)
-            dense = np.log(blk[:, L:L + Dn].astype(np.float32) + 1.0)
+        label = (blk[:, :L].view(np.float32) if self.float_label
+                 else blk[:, :L].view(np.int32).astype(np.float32))
+        dense = (blk[:, L:L + Dn].view(np.float32) if self.float_dense
+                 else np.log(blk[:, L:L + Dn].view(np.int32).astype(np.float32) + np.float32(1.0)))
         out = {"label": torch.from_numpy(np.ascontiguousarray(label[sl])).to(self.device),
                "dense": torch.from_numpy(np.ascontiguousarray(dense[sl])).to(self.device),
                "sparse": {}}
@@ -403,11 +411,13 @@ def make_reader(rp, inp, solver, rank, world, device):
     fmt = getattr(rp.data_reader_type, "name", str(rp.data_reader_type))
     if fmt == "RawAsync":
         train = RawReader(rp.source[0], inp, rp.slot_size_array, solver.batchsize, rank, world,
-                          device, rp.num_samples, rp.float_label_dense, solver.repeat_dataset)
+                          device, rp.num_samples, rp.float_label_dense, solver.repeat_dataset,
+                          rp.async_param)
         evalr = None
         if rp.eval_source and os.path.exists(rp.eval_source) and solver.batchsize_eval > 0:
             evalr = RawReader(rp.eval_source, inp, rp.slot_size_array, solver.batchsize_eval, rank,
-                              world, device, rp.eval_num_samples, rp.float_label_dense, True)
+                              world, device, rp.eval_num_samples, rp.float_label_dense, True,
+                              rp.async_param)
         return _Readers(train, evalr)
     if fmt != "Parquet":
         # the reference's Python path rejects Norm/Raw as deprecated (add_input.cpp:318-325)

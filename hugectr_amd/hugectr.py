@@ -170,6 +170,24 @@ def CreateSolver(**kw) -> Solver:
     return s
 
 
+class Alignment_t(enum.Enum):
+    Auto = 0
+    Non = 1
+
+
+@dataclass
+class AsyncParam:  # R/HugeCTR/include/pybind/common_wrapper.hpp:144-151 (same names and defaults)
+    num_threads: int
+    num_batches_per_thread: int
+    max_num_requests_per_thread: int = 0
+    io_depth: int = 0
+    io_alignment: int = 0
+    shuffle: bool = False
+    aligned_type: Alignment_t = Alignment_t.Non
+    multi_hot_reader: bool = True
+    is_dense_float: bool = True
+
+
 @dataclass
 class DataReaderParams:
     data_reader_type: DataReaderType_t

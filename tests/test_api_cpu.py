@@ -148,3 +148,39 @@ def test_raw_format_reader(tmp_path, float_ld):
         assert (b["label"].numpy() == label[a + 32:a + 64]).all()     # rank 1 of 2
         nb += 1
     assert nb == 4  # 300 // 64, tail dropped
+
+
+def test_raw_reader_reads_the_reference_converters_file():
+    """tests/golden/raw_mlperf_val.bin was written by the reference's own converter
+    (R/samples/dlrm/preprocessing/convert_to_raw.py, see tests/golden/make_raw_golden.py) in the
+    layout the MLPerf DLRM-DCNv2 sample trains from: the reader configured like the sample
+    (train.py:350-378: RawAsync, AsyncParam(multi_hot_reader, is_dense_float), one multi-hot
+    DataReaderSparseParam per table) must return the converter's inputs"""
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd import data
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = np.load(os.path.join(here, "golden", "raw_mlperf_inputs.npz"))
+    hot = [src[str(i)].shape[1] for i in range(26)]
+    n = src["labels"].size
+    inp = hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                        data_reader_sparse_param_array=[
+                            hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                            for i in range(26)])
+    ap = hugectr.AsyncParam(num_threads=1, num_batches_per_thread=16, shuffle=False,
+                            multi_hot_reader=True, is_dense_float=True)
+    path = os.path.join(here, "golden", "raw_mlperf_val.bin")
+    assert os.path.getsize(path) == n * (1 + 13 + sum(hot)) * 4
+    B, world = 32, 2
+    for rank in range(world):
+        r = data.RawReader(path, inp, [], B, rank, world, torch.device("cpu"), 0, False, False, ap)
+        for nb in range(n // B):
+            b = r.next_batch()
+            a = nb * B
+            mine = slice(a + rank * (B // world), a + (rank + 1) * (B // world))
+            assert (b["label"].numpy().reshape(-1) == src["labels"][mine].astype(np.float32)).all()
+            assert (b["dense"].numpy() == src["dense"][mine]).all()      # float words, bit for bit
+            for i in range(26):
+                ro, keys = b["sparse"][f"data{i}"]                        # the full batch
+                assert ro.tolist() == list(range(0, B * hot[i] + 1, hot[i]))
+                assert (keys.view(B, hot[i]).numpy() == src[str(i)][a:a + B]).all()
+        assert r.next_batch() is None
