@@ -137,7 +137,7 @@ _SIGNATURES = {
     "hctr_tiered_host_rows": (_P, [_P]),
     "hctr_tiered_cache": (_P, [_P]),
     "hctr_tiered_lookup": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
-    "hctr_tiered_scatter": (c_int, [_P, _P, c_size_t, _P, c_int, _P]),
+    "hctr_tiered_scatter": (c_int, [_P, _P, c_size_t, _P, c_int, c_float, _P]),
     "hctr_uniq_create": (c_int, [c_size_t, POINTER(_P)]),
     "hctr_uniq_destroy": (c_int, [_P]),
     "hctr_uniq_plan": (c_int, [_P, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, _P,

@@ -88,10 +88,52 @@ class TieredTable:
     def last_missing(self) -> int:
         return int(self._miss.item())
 
-    def scatter_add(self, unique_keys: torch.Tensor, values: torch.Tensor):
+    def scatter_add(self, unique_keys: torch.Tensor, values: torch.Tensor, alpha: float = 1.0):
         check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
-                                      ptr(values.contiguous()), 1, stream_ptr()))
+                                      ptr(values.contiguous()), 1, alpha, stream_ptr()))
 
     def scatter_update(self, unique_keys: torch.Tensor, values: torch.Tensor):
         check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
-                                      ptr(values.contiguous()), 0, stream_ptr()))
+                                      ptr(values.contiguous()), 0, 1.0, stream_ptr()))
+
+
+class TieredEmbedding:
+    """One-hot embedding over a table that does not fit HBM (BASELINE config 3): key = row of a
+    flat [rows, vec] table in host memory, hot rows cached in HBM.  forward = tiered lookup;
+    backward_update = per-row gradient sums (hctr_ebc_local_reduce, ascending position order) and a
+    write-through SGD step on the unique rows.  `keys` of one call: int64 [n]."""
+
+    def __init__(self, host_rows: int, embedding_vec_size: int, cache_capacity_in_set: int,
+                 max_keys_per_batch: int, lr: float = 0.01):
+        self.table = TieredTable(host_rows, embedding_vec_size, cache_capacity_in_set)
+        self.D, self.lr, self.max_keys = embedding_vec_size, lr, max_keys_per_batch
+        self._upd = ctypes.c_void_p()
+        check(lib.hctr_updater_create(max_keys_per_batch, max_keys_per_batch, embedding_vec_size,
+                                      ctypes.byref(self._upd)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self._ro = torch.arange(max_keys_per_batch + 1, dtype=torch.int64, device=dev)
+        self._urow = torch.empty(max_keys_per_batch, dtype=torch.int64, device=dev)
+        self._wgrad = torch.empty((max_keys_per_batch, embedding_vec_size), dtype=torch.float32,
+                                  device=dev)
+        self._keys = None
+
+    def __del__(self):
+        if getattr(self, "_upd", None):
+            lib.hctr_updater_destroy(self._upd)
+            self._upd = None
+
+    def forward(self, keys: torch.Tensor) -> torch.Tensor:
+        assert keys.numel() <= self.max_keys and keys.dtype == torch.int64
+        self._keys = keys.contiguous()
+        return self.table.lookup(self._keys)
+
+    def backward_update(self, grad: torch.Tensor):
+        """grad [n, vec] of the vectors the last forward returned"""
+        n = self._keys.numel()
+        nu = ctypes.c_size_t()
+        dt = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[grad.dtype]
+        check(lib.hctr_ebc_local_reduce(self._upd, n, n, ptr(self._ro), ptr(self._keys),
+                                        self.table.rows, None, ptr(grad.contiguous()), dt,
+                                        ctypes.byref(nu), ptr(self._urow), None, ptr(self._wgrad),
+                                        stream_ptr()))
+        self.table.scatter_add(self._urow[:nu.value], self._wgrad[:nu.value], alpha=-self.lr)

@@ -258,12 +258,13 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// write-through update of unique rows: new = (add ? old : 0) + value, stored in the host table
-// and, when the row is cached, in the cache (whose copy is the newer one to read)
+// write-through update of unique rows: new = (add ? old : 0) + alpha * value, stored in the host
+// table and, when the row is cached, in the cache (whose copy is the newer one to read)
 template <bool V4>
 __global__ void __launch_bounds__(kBlock)
     tier_scatter_kernel(const long long* __restrict__ keys, size_t len,
-                        const float* __restrict__ values, int add, size_t host_rows, int D,
+                        const float* __restrict__ values, int add, float alpha, size_t host_rows,
+                        int D,
                         size_t num_sets, const long long* __restrict__ set_keys,
                         float* __restrict__ vals, float* __restrict__ host) {
   const int lane = threadIdx.x & 63;
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(kBlock)
     if (V4) {
       for (int c = lane; c < D / 4; c += 64) {
         float4 x = reinterpret_cast<const float4*>(v)[c];
+        x = make_float4(alpha * x.x, alpha * x.y, alpha * x.z, alpha * x.w);
         if (add) {
           const float4 o = reinterpret_cast<const float4*>(old)[c];
           x = make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     } else {
       for (int c = lane; c < D; c += 64) {
-        const float x = add ? old[c] + v[c] : v[c];
+        const float x = add ? old[c] + alpha * v[c] : alpha * v[c];
         hrow[c] = x;
         if (crow) crow[c] = x;
       }
@@ -645,7 +647,7 @@ int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* o
 }
 
 int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,
-                        int add, hctr_stream_t stream) {
+                        int add, float alpha, hctr_stream_t stream) {
   HCTR_REQUIRE(t, "null handle");
   if (len == 0) return HCTR_OK;
   HCTR_REQUIRE(unique_keys && values, "null pointer");
@@ -654,11 +656,11 @@ int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, 
   const hctr_cache* c = t->cache;
   if (vec4_ok(t->D, values, c->vals))
     hipLaunchKernelGGL(tier_scatter_kernel<true>, dim3(grid), dim3(kBlock), 0, s,
-                       (const long long*)unique_keys, len, values, add, t->rows, t->D, c->num_sets,
+                       (const long long*)unique_keys, len, values, add, alpha, t->rows, t->D, c->num_sets,
                        c->set_keys, c->vals, t->host_dev);
   else
     hipLaunchKernelGGL(tier_scatter_kernel<false>, dim3(grid), dim3(kBlock), 0, s,
-                       (const long long*)unique_keys, len, values, add, t->rows, t->D, c->num_sets,
+                       (const long long*)unique_keys, len, values, add, alpha, t->rows, t->D, c->num_sets,
                        c->set_keys, c->vals, t->host_dev);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;

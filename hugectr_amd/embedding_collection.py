@@ -103,7 +103,7 @@ class EmbeddingCollection:
                  optimizer: int = _lib.OPT_SGD, scaler: float = 1.0, epsilon: float = 1e-7,
                  initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
                  key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None,
-                 ftrl=(0.0, 0.0, 0.0), storage: str = "static", initializer: str = "",
+                 ftrl=(0.0, 0.0, 0.0), storage: Optional[str] = None, initializer: str = "",
                  init_capacity: int = 1 << 20, **opt_kw):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -123,9 +123,13 @@ class EmbeddingCollection:
     def _setup(self, config, global_batch, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1.0,
                epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
                key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0),
-               storage="static", initializer="", init_capacity=1 << 20, beta1=0.9, beta2=0.999,
+               storage=None, initializer="", init_capacity=1 << 20, beta1=0.9, beta2=0.999,
                momentum_factor=0.9, rmsprop_beta=0.9):
         assert global_batch % self.world == 0
+        if storage is None:  # max_vocabulary_size < 0 means dynamic (embedding_storage/common.hpp:78,
+            # embedding_table.cpp:27-34: one dynamic table makes the whole group dynamic)
+            storage = "dynamic" if any(t.max_vocabulary_size < 0 for t, _, _, _ in config.lookups) \
+                else "static"
         assert storage in ("static", "dynamic")
         self.dynamic = storage == "dynamic"
         self.training = True
@@ -158,7 +162,7 @@ class EmbeddingCollection:
         for t in self.local_tables:
             self.row_start_of_table[t] = rows
             ns = len(self.owners[t])
-            rows += -(-tables[t].max_vocabulary_size // ns)
+            rows += -(-max(tables[t].max_vocabulary_size, 0) // ns)
         self.local_rows = max(rows, 1)
         self.accum = self.ftrl_z = self.table = None
         if self.dynamic:

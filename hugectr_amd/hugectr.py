@@ -441,10 +441,16 @@ class Model:
         one runtime for the training batch, one for the evaluation batch, sharing the tables"""
         o = self.opt
         t = Optimizer_t(o.optimizer_type)
-        code = {Optimizer_t.SGD: _lib.OPT_SGD, Optimizer_t.AdaGrad: _lib.OPT_ADAGRAD,
-                Optimizer_t.Ftrl: _lib.OPT_FTRL}.get(t)
+        dynamic = any(tc.max_vocabulary_size < 0 for tc, _, _, _ in cfg.lookups)
+        codes = {Optimizer_t.SGD: _lib.OPT_SGD, Optimizer_t.AdaGrad: _lib.OPT_ADAGRAD,
+                 Optimizer_t.Ftrl: _lib.OPT_FTRL}
+        if dynamic:  # the dynamic table has all seven (embedding_storage/optimizers.cuh:29-233)
+            codes.update({Optimizer_t.Adam: _lib.OPT_ADAM, Optimizer_t.RMSProp: _lib.OPT_RMSPROP,
+                          Optimizer_t.MomentumSGD: _lib.OPT_MOMENTUM_SGD,
+                          Optimizer_t.Nesterov: _lib.OPT_NESTEROV})
+        code = codes.get(t)
         if code is None:
-            raise RuntimeError("embedding_collection tables support SGD, AdaGrad and Ftrl "
+            raise RuntimeError("static embedding_collection tables support SGD, AdaGrad and Ftrl "
                                "(R/HugeCTR/embedding_storage/ragged_static_embedding.cu:593-700)")
         params, offsets = [], []
         slot0, slot_of_param = 0, {}
@@ -467,12 +473,18 @@ class Model:
                   initial_accu_value=o.initial_accu_value, out_dtype=self.emb_dtype,
                   batch_major=True, max_hotness=hot, seed=self.solver.seed,
                   ftrl=(o.lambda1, o.lambda2, o.beta))
+        if dynamic:
+            kw.update(beta1=o.beta1, beta2=o.beta2, momentum_factor=o.momentum_factor,
+                      init_capacity=1 << 16)
         train = EmbeddingCollection(cfg, B, **kw)
         ev = None
         if Be > 0:
-            ev = train if Be == B else EmbeddingCollection(cfg, Be, **kw)
+            ev = train if (Be == B and not dynamic) else EmbeddingCollection(cfg, Be, **kw)
             if ev is not train:  # same tables, own per-batch scratch
                 ev.table, ev.accum, ev.ftrl_z = train.table, train.accum, train.ftrl_z
+                if dynamic:
+                    ev.det, ev.det_opt = train.det, train.det_opt
+                    ev.training = False  # evaluation never inserts: unseen keys read as zeros
         L, evs = train.L, train.ev
         if cfg.top_name:
             self._shapes[cfg.top_name] = (L, evs)
@@ -811,11 +823,19 @@ class Model:
             if localized:
                 slot.cpu().numpy().astype("<u8").tofile(os.path.join(d, "slot_id"))
             vec.cpu().numpy().astype("<f4").tofile(os.path.join(d, "emb_vector"))
-        for i, rt in enumerate(self._ebc):  # one file per rank: its flat [rows][ev] shard table
+        for i, rt in enumerate(self._ebc):
             d = f"{prefix}_ebc{i}_sparse_{iteration}.model"
             os.makedirs(d, exist_ok=True)
-            rt["train"].table.cpu().numpy().astype("<f4").tofile(
-                os.path.join(d, f"emb_vector.rank{self.rank}"))
+            e = rt["train"]
+            if e.dynamic:  # per local table: the keys it holds and their vectors
+                for t, c in e.class_of_table.items():
+                    k, v = e.det.export(c)
+                    k.cpu().numpy().astype("<i8").tofile(os.path.join(d, f"key.table{t}.rank{self.rank}"))
+                    v.cpu().numpy().astype("<f4").tofile(
+                        os.path.join(d, f"emb_vector.table{t}.rank{self.rank}"))
+            else:  # one file per rank: its flat [rows][ev] shard table
+                e.table.cpu().numpy().astype("<f4").tofile(
+                    os.path.join(d, f"emb_vector.rank{self.rank}"))
         if self.rank == 0 and self._dense_params:
             blobs = [b.detach().float().contiguous().flatten() for b, _ in self._dense_blobs()]
             torch.cat(blobs).cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")

@@ -489,8 +489,9 @@ int hctr_cache_dump(hctr_cache* c, void* keys, size_t* d_dump_counter, size_t st
  * above holds the hot rows.  lookup = Query + the GPU reading the missing rows straight out of
  * host memory into `out` + Replace -- three launches, no host synchronisation (rows outside
  * [0, host_rows) read as zeros).  d_missing_len (device, may be NULL) receives the miss count.
- * scatter: write-through update of UNIQUE rows, new = (add ? old : 0) + values[i], stored in the
- * host table and in the cached copy when there is one. */
+ * scatter: write-through update of UNIQUE rows, new = (add ? old : 0) + alpha * values[i], stored
+ * in the host table and in the cached copy when there is one (alpha = -lr and the per-row gradient
+ * sums of hctr_ebc_local_reduce make it the SGD step of a tiered embedding). */
 typedef struct hctr_tiered hctr_tiered;
 int hctr_tiered_create(size_t host_rows, int vec_size, size_t cache_capacity_in_set,
                        hctr_tiered** out);
@@ -500,7 +501,7 @@ hctr_cache* hctr_tiered_cache(hctr_tiered* t);
 int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* out,
                        size_t* d_missing_len, hctr_stream_t stream);
 int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,
-                        int add, hctr_stream_t stream);
+                        int add, float alpha, hctr_stream_t stream);
 
 #ifdef __cplusplus
 }

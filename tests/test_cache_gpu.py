@@ -124,3 +124,31 @@ def test_tiered_table_matches_oracle(D):
     want = np.zeros((ks.size, D), np.float32)
     o.cache.query(ks, want)
     assert (got.cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("D", [16, 128])
+def test_tiered_embedding_trains_like_a_dense_table(D):
+    """BASELINE config 3 in miniature: a one-hot embedding whose table lives in host memory behind
+    the cache; forward rows and the SGD-updated table must follow a plain in-memory table"""
+    import torch
+    from hugectr_amd.cache import TieredEmbedding
+    rng = np.random.default_rng(D)
+    rows, n, lr = 30000, 4096, 0.05
+    emb = TieredEmbedding(rows, D, 4, n, lr=lr)           # 256 cached rows of 30000
+    ref = rng.standard_normal((rows, D)).astype(np.float32)
+    emb.table.host[:] = ref
+    ref = ref.astype(np.float64)
+    for it in range(6):
+        keys = np.minimum(rng.pareto(1.05, size=n) * 3, rows - 1).astype(np.int64)
+        out = emb.forward(torch.from_numpy(keys).cuda())
+        assert np.allclose(out.cpu().numpy(), ref[keys], rtol=1e-6, atol=1e-6), f"forward it{it}"
+        g = rng.standard_normal((n, D)).astype(np.float32)
+        emb.backward_update(torch.from_numpy(g).cuda())
+        np.subtract.at(ref, keys, lr * g.astype(np.float64))
+    torch.cuda.synchronize()
+    assert np.allclose(emb.table.host, ref, rtol=2e-5, atol=2e-5)
+    # the cached copies agree with the host table (write-through)
+    ks = emb.table.cache.Dump()
+    got = torch.zeros((ks.numel(), D), device="cuda")
+    emb.table.cache.Query(ks, got)
+    assert (got.cpu().numpy() == emb.table.host[ks.cpu().numpy()]).all()

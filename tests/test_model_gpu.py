@@ -199,8 +199,8 @@ def test_deepfm_script_trains(tmp_path):
     assert auc is not None and auc > 0.7
 
 
-@pytest.mark.parametrize("plan", ["round_robin", "auto"])
-def test_dcnv2_embedding_collection_script_trains(tmp_path, plan):
+@pytest.mark.parametrize("plan,dynamic", [("round_robin", False), ("auto", False), ("auto", True)])
+def test_dcnv2_embedding_collection_script_trains(tmp_path, plan, dynamic):
     """the graph of R/samples/dlrm/train.py (MLPerf DLRM-DCNv2): one multi-hot input per table, an
     embedding_collection sharded by the sample's planner, bottom MLP, concat, MultiCross with a
     projection, top MLP -- at a small synthetic shape"""
@@ -208,20 +208,23 @@ def test_dcnv2_embedding_collection_script_trains(tmp_path, plan):
     from hugectr_amd import sharding
     hot = [1, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 10, 7, 4, 3, 1, 1]  # (C1 one-hot: _gen derives the label from it)
     p = _gen(tmp_path, hugectr, n_train=4096, n_eval=1024, nnz=hot)
-    solver = hugectr.CreateSolver(batchsize=512, batchsize_eval=256, lr=0.05, vvgpu=[[0]],
-                                  i64_input_key=True, max_eval_batches=2,
+    solver = hugectr.CreateSolver(batchsize=512, batchsize_eval=256, lr=0.003 if dynamic else 0.05,
+                                  vvgpu=[[0]], i64_input_key=True, max_eval_batches=2,
                                   use_embedding_collection=True)
     reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
                                       source=[p.source], eval_source=p.eval_source,
                                       slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
-    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.AdaGrad,
+    # dynamic hash tables (max_vocabulary_size = -1, BASELINE config 4) take any optimizer
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam if dynamic
+                                  else hugectr.Optimizer_t.AdaGrad,
                                   update_type=hugectr.Update_t.Global, initial_accu_value=0.0)
     model = hugectr.Model(solver, reader, opt)
     model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
                             data_reader_sparse_param_array=[
                                 hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
                                 for i in range(26)]))
-    tables = [hugectr.EmbeddingTableConfig(name=str(i), max_vocabulary_size=SIZES[i], ev_size=16)
+    tables = [hugectr.EmbeddingTableConfig(name=str(i), ev_size=16,
+                                           max_vocabulary_size=-1 if dynamic else SIZES[i])
               for i in range(26)]
     args = sharding.mi355x_args(sharding_plan=plan, ev_size=16, optimizer="adagrad",
                                 num_gpus_per_node=1)
@@ -247,15 +250,20 @@ def test_dcnv2_embedding_collection_script_trains(tmp_path, plan):
                                  bottom_names=["mlp2", "label"], top_names=["loss"]))
     model.compile()
     model.summary()
-    before = model._ebc[0]["train"].table.clone()
+    before = None if dynamic else model._ebc[0]["train"].table.clone()
     model.train()
     first = model.get_current_loss()
     model.fit(max_iter=200, display=100, eval_interval=100, snapshot=200,
               snapshot_prefix=str(tmp_path / "dcnv2"))
     assert model.get_current_loss() < min(first, 0.62)
     assert dict(model.get_eval_metrics())["AUC"] > 0.6
-    assert (model._ebc[0]["train"].table != before).any()
-    assert os.path.exists(tmp_path / "dcnv2_ebc0_sparse_200.model" / "emb_vector.rank0")
+    if dynamic:
+        e = model._ebc[0]["train"]
+        assert e.det.size() > 500 and os.path.exists(
+            tmp_path / "dcnv2_ebc0_sparse_200.model" / "emb_vector.table0.rank0")
+    else:
+        assert (model._ebc[0]["train"].table != before).any()
+        assert os.path.exists(tmp_path / "dcnv2_ebc0_sparse_200.model" / "emb_vector.rank0")
     model.graph_to_json(str(tmp_path / "graph.json"))
 
 
