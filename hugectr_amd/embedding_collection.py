@@ -258,12 +258,15 @@ class EmbeddingCollection:
         if self.world == 1 or not dist.is_initialized():
             return keys, bucket_range
         lens = (bucket_range[1:] - bucket_range[:-1]).to(torch.int64).contiguous()
-        all_lens = torch.empty(self.world * lens.numel(), dtype=torch.int64, device=self.dev)
-        dist.all_gather_into_tensor(all_lens, lens, group=self.group)
-        all_lens = all_lens.view(self.world, self.L, self.bpg)
+        staged = dist.get_backend(self.group) == "gloo"  # host staging: tests only
+        cdev = torch.device("cpu") if staged else self.dev
+        all_lens = torch.empty(self.world * lens.numel(), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_lens, lens.to(cdev), group=self.group)
+        all_lens = all_lens.to(self.dev).view(self.world, self.L, self.bpg)
         n_all = all_lens.sum(dim=(1, 2)).tolist()  # host sync (counts)
-        parts = [torch.empty(n, dtype=keys.dtype, device=self.dev) for n in n_all]
-        dist.all_gather(parts, keys.contiguous(), group=self.group)
+        parts = [torch.empty(n, dtype=keys.dtype, device=cdev) for n in n_all]
+        dist.all_gather(parts, keys.contiguous().to(cdev), group=self.group)
+        parts = [q.to(self.dev) for q in parts]
         # per-rank offsets of each lookup's key segment
         seg = all_lens.sum(dim=2)                       # [world, L] keys per (rank, lookup)
         seg_off = torch.zeros((self.world, self.L + 1), dtype=torch.int64, device=self.dev)
@@ -280,8 +283,9 @@ class EmbeddingCollection:
         if self.world == 1 or not dist.is_initialized():
             return buf
         out = torch.empty(sum(recv_counts), dtype=buf.dtype, device=self.dev)
-        dist.all_to_all_single(out, buf.reshape(-1), output_split_sizes=recv_counts,
-                               input_split_sizes=send_counts, group=self.group)
+        # (parallel.all_to_all_single stages through the host under gloo: the 2-rank tests)
+        from .parallel import all_to_all_single
+        all_to_all_single(out, buf.reshape(-1), recv_counts, send_counts, group=self.group)
         return out
 
     # -- stages (public so that tests can emulate the collectives in one process) ------------------

@@ -32,6 +32,7 @@ from .embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfi
                                    EmbeddingTableConfig)
 from .layers import MultiCrossLayer, interaction
 from .parallel import DistributedExchange, LocalizedExchange
+from .parallel import all_reduce as _all_reduce
 from . import data as _data
 
 
@@ -691,7 +692,7 @@ class Model:
             if self.world > 1:
                 for q in self._dense_params:
                     if q.grad is not None:
-                        dist.all_reduce(q.grad)
+                        _all_reduce(q.grad)
                         q.grad /= self.world
             if self.solver.scaler != 1.0:
                 for q in self._dense_params:

@@ -299,3 +299,92 @@ def test_load_reference_format_checkpoint(tmp_path, name):
     m.graph_to_json(str(tmp_path / "g.json"))
     import json
     assert json.load(open(tmp_path / "g.json")) == json.load(open(os.path.join(ck, f"{name}.json")))
+
+
+def _ebc_model_worker(rank, world, port, folder, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hugectr_amd.hugectr as hugectr
+        from hugectr_amd import sharding
+        hot = [1, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 10, 7, 4, 3, 1, 1]
+        solver = hugectr.CreateSolver(batchsize=256, batchsize_eval=256, lr=0.05, vvgpu=[[0, 1]],
+                                      i64_input_key=True, max_eval_batches=1,
+                                      use_embedding_collection=True)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.Parquet,
+            source=[os.path.join(folder, "train", "_file_list.txt")],
+            eval_source=os.path.join(folder, "val", "_file_list.txt"), slot_size_array=SIZES,
+            check_type=hugectr.Check_t.Non)
+        opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.AdaGrad,
+                                      update_type=hugectr.Update_t.Global, initial_accu_value=0.0)
+        model = hugectr.Model(solver, reader, opt)
+        model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                                data_reader_sparse_param_array=[
+                                    hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                                    for i in range(26)]))
+        tables = [hugectr.EmbeddingTableConfig(name=str(i), max_vocabulary_size=SIZES[i], ev_size=16)
+                  for i in range(26)]
+        args = sharding.mi355x_args(sharding_plan="auto", ev_size=16, num_gpus_per_node=2)
+        sm, ss = sharding.generate_plan(SIZES, hot, 1, 2, args, False)
+        ebc = hugectr.EmbeddingCollectionConfig()
+        ebc.embedding_lookup(table_config=tables, bottom_name=[f"data{i}" for i in range(26)],
+                             top_name="sparse_embedding", combiner=["sum"] * 26)
+        ebc.shard(shard_matrix=sm, shard_strategy=ss)
+        model.add(ebc)
+        D, T = hugectr.DenseLayer, hugectr.Layer_t
+        model.add(D(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"], num_outputs=[32, 16],
+                    act_type=hugectr.Activation_t.Relu))
+        model.add(D(layer_type=T.Interaction, bottom_names=["mlp1", "sparse_embedding"],
+                    top_names=["interaction1"]))
+        model.add(D(layer_type=T.MLP, bottom_names=["interaction1"], top_names=["mlp2"],
+                    num_outputs=[64, 1],
+                    activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Non]))
+        model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+                    top_names=["loss"]))
+        model.compile()
+        e = model._ebc[0]["train"]
+        owned = [t for t in range(26) if rank in e.owners[t]]
+        assert owned and len(owned) < 26          # the planner split the tables over the 2 ranks
+        before = e.table.clone()
+        model.train()
+        first = model.get_current_loss()
+        model.fit(max_iter=200, display=0, eval_interval=0, snapshot=0)
+        last = model.get_current_loss()
+        assert last < min(first, 0.64), (first, last)
+        assert (e.table != before).any()
+        # data-parallel dense weights stay identical on both ranks
+        flat = torch.cat([q.detach().flatten().float() for q in model._dense_params]).cpu()
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        ret[rank] = "ok"
+    except Exception as ex:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_embedding_collection_model_two_ranks_on_one_gpu(tmp_path):
+    """the N > 1 path of the embedding_collection model (tables placed by the planner, key routing
+    on the replicated batch, all-to-all of the pooled vectors, data-parallel dense tower): 2
+    processes over gloo on this one GPU"""
+    import hugectr_amd.hugectr as hugectr
+    import torch.multiprocessing as mp
+    hot = [1, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 10, 7, 4, 3, 1, 1]
+    _gen(tmp_path, hugectr, n_train=4096, n_eval=512, nnz=hot)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ebc_model_worker, args=(r, 2, port, str(tmp_path), ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r in range(2):
+        if ret.get(r) != "ok":
+            print(f"--- rank {r} ---\n{ret.get(r)}")
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
