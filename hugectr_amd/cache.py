@@ -98,7 +98,7 @@ class TieredTable:
 
 
 class TieredEmbedding:
-    """One-hot embedding over a table that does not fit HBM (BASELINE config 3): key = row of a
+    """One-hot embedding over a table that does not fit HBM (BASELINE config 4): key = row of a
     flat [rows, vec] table in host memory, hot rows cached in HBM.  forward = tiered lookup;
     backward_update = per-row gradient sums (hctr_ebc_local_reduce, ascending position order) and a
     write-through SGD step on the unique rows.  `keys` of one call: int64 [n]."""

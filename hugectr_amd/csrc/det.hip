@@ -117,6 +117,74 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- one launch over all id spaces of a call (instead of one hash pass per id space) -------------
+struct DetClassDesc {
+  const HtEntry* tab;
+  uint64_t size;
+  float* rows;
+  uint64_t row_base;
+  int dim;
+};
+
+// segment (id space) of position i: the last s with seg_off[s] <= i
+__device__ __forceinline__ int det_segment_of(const uint64_t* __restrict__ seg_off, int n_seg,
+                                              uint64_t i) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg_off[mid] <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+// find-only probe of every key in its own class; classes that miss a key are flagged so that only
+// they go through the inserting path
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    det_find_multi_kernel(const DetClassDesc* __restrict__ cls, const uint32_t* __restrict__ seg_class,
+                          const uint64_t* __restrict__ seg_off, int n_seg,
+                          const K* __restrict__ keys, size_t n, uint64_t* __restrict__ idx,
+                          uint32_t* __restrict__ miss) {
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const uint32_t c = seg_class[det_segment_of(seg_off, n_seg, i)];
+    const HtEntry* __restrict__ tab = cls[c].tab;
+    const uint64_t size = cls[c].size;
+    const K key = keys[i];
+    const long long k64 = (long long)(sizeof(K) == 4 ? (unsigned long long)(uint32_t)key
+                                                     : (unsigned long long)key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    uint64_t res = kInvalidIndex;
+    for (uint64_t probes = 0; probes <= size; ++probes) {
+      const long long cur = tab[slot].key;
+      if (cur == k64) {
+        res = tab[slot].val;
+        break;
+      }
+      if (cur == empty) break;
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+    idx[i] = res;
+    if (res == kInvalidIndex) miss[c] = 1u;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    det_rows_multi_kernel(const DetClassDesc* __restrict__ cls, const uint32_t* __restrict__ seg_class,
+                          const uint64_t* __restrict__ seg_off, int n_seg,
+                          const uint64_t* __restrict__ idx, size_t n, float** __restrict__ out_ptr,
+                          uint64_t* __restrict__ out_row) {
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const DetClassDesc d = cls[seg_class[det_segment_of(seg_off, n_seg, i)]];
+    const uint64_t r = idx[i];
+    if (out_ptr) out_ptr[i] = r != kInvalidIndex ? d.rows + r * (uint64_t)d.dim : nullptr;
+    if (out_row) out_row[i] = r != kInvalidIndex ? d.row_base + r : kInvalidIndex;
+  }
+}
+
 // dynamic_map_kernels.cuh:143-183: keys that are not in the map are skipped
 template <bool ADD>
 __global__ void __launch_bounds__(kBlock)
@@ -174,6 +242,60 @@ struct DetOpt {
 // One thread per element of one unique key's vector.  Formulas: optimizers.cuh:29-233 -- the
 // reference turns wgrad into the weight delta in place and then scatter_adds it; here the delta is
 // applied to the row directly (same arithmetic, one pass).
+// one element of one row: state update + weight delta (optimizers.cuh:29-233)
+__device__ __forceinline__ void det_apply(const DetOpt& o, int dim, int e, float gi, float* w,
+                                          float* st) {
+  float delta;
+  switch (o.optimizer) {
+    case HCTR_OPT_SGD:
+      delta = -o.lr * gi;
+      break;
+    case HCTR_OPT_MOMENTUM_SGD: {
+      const float mi = o.momentum * st[e] - o.lr * gi;
+      st[e] = mi;
+      delta = mi;
+    } break;
+    case HCTR_OPT_NESTEROV: {
+      const float prev = st[e];
+      const float mi = o.momentum * prev - o.lr * gi;
+      st[e] = mi;
+      delta = mi + o.momentum * mi - o.momentum * prev;
+    } break;
+    case HCTR_OPT_ADAGRAD: {
+      const float vi = st[e] + gi * gi;
+      st[e] = vi;
+      delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
+    } break;
+    case HCTR_OPT_RMSPROP: {
+      const float vi = o.rms_beta * st[e] + (1.f - o.rms_beta) * gi * gi;
+      st[e] = vi;
+      delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
+    } break;
+    case HCTR_OPT_ADAM: {
+      const float mi = o.beta1 * st[e] + (1.f - o.beta1) * gi;
+      const float vi = o.beta2 * st[dim + e] + (1.f - o.beta2) * gi * gi;
+      st[e] = mi;
+      st[dim + e] = vi;
+      delta = -o.lr_scaled_bias * mi / (sqrtf(vi) + o.epsilon);
+    } break;
+    default: {  // HCTR_OPT_FTRL
+      float ni = st[e];
+      const float ni_prev_sqrt = sqrtf(ni + 1.1920929e-07f);  // FLT_EPSILON
+      ni = ni + gi * gi;
+      st[e] = ni;
+      const float ni_sqrt = sqrtf(ni + 1.1920929e-07f);
+      const float sigma = (ni_sqrt - ni_prev_sqrt) / o.lr;
+      const float wi = *w;
+      const float zi = st[dim + e] + gi - sigma * wi;
+      st[dim + e] = zi;
+      const float p = (1.f - 2.f * (float)signbit(zi)) * o.lambda1 - zi;
+      const float q = ni_sqrt / o.lr + o.lambda2_plus_beta_div_lr;
+      delta = (p / q) * (float)signbit(o.lambda1 - fabsf(zi)) - wi;
+    } break;
+  }
+  *w += delta;
+}
+
 __global__ void __launch_bounds__(kBlock)
     det_update_kernel(DetOpt o, size_t n, int dim, const uint64_t* __restrict__ idx_w,
                       const uint64_t* __restrict__ idx_s, float* __restrict__ rows_w,
@@ -187,59 +309,29 @@ __global__ void __launch_bounds__(kBlock)
     const uint64_t rw = idx_w[k];
     if (rw == kInvalidIndex) continue;  // scatter_add skips keys that are not in the table
     const float gi = wgrad[ev_start[k] + e] / o.scaler;
-    float* w = rows_w + rw * dim + e;
     const int sdim = dim * (o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_FTRL ? 2 : 1);
     float* st = (rows_s != nullptr && idx_s != nullptr) ? rows_s + idx_s[k] * (uint64_t)sdim
                                                          : nullptr;
-    float delta;
-    switch (o.optimizer) {
-      case HCTR_OPT_SGD:
-        delta = -o.lr * gi;
-        break;
-      case HCTR_OPT_MOMENTUM_SGD: {
-        const float mi = o.momentum * st[e] - o.lr * gi;
-        st[e] = mi;
-        delta = mi;
-      } break;
-      case HCTR_OPT_NESTEROV: {
-        const float prev = st[e];
-        const float mi = o.momentum * prev - o.lr * gi;
-        st[e] = mi;
-        delta = mi + o.momentum * mi - o.momentum * prev;
-      } break;
-      case HCTR_OPT_ADAGRAD: {
-        const float vi = st[e] + gi * gi;
-        st[e] = vi;
-        delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
-      } break;
-      case HCTR_OPT_RMSPROP: {
-        const float vi = o.rms_beta * st[e] + (1.f - o.rms_beta) * gi * gi;
-        st[e] = vi;
-        delta = -o.lr * gi / (sqrtf(vi) + o.epsilon);
-      } break;
-      case HCTR_OPT_ADAM: {
-        const float mi = o.beta1 * st[e] + (1.f - o.beta1) * gi;
-        const float vi = o.beta2 * st[dim + e] + (1.f - o.beta2) * gi * gi;
-        st[e] = mi;
-        st[dim + e] = vi;
-        delta = -o.lr_scaled_bias * mi / (sqrtf(vi) + o.epsilon);
-      } break;
-      default: {  // HCTR_OPT_FTRL
-        float ni = st[e];
-        const float ni_prev_sqrt = sqrtf(ni + 1.1920929e-07f);  // FLT_EPSILON
-        ni = ni + gi * gi;
-        st[e] = ni;
-        const float ni_sqrt = sqrtf(ni + 1.1920929e-07f);
-        const float sigma = (ni_sqrt - ni_prev_sqrt) / o.lr;
-        const float wi = *w;
-        const float zi = st[dim + e] + gi - sigma * wi;
-        st[dim + e] = zi;
-        const float p = (1.f - 2.f * (float)signbit(zi)) * o.lambda1 - zi;
-        const float q = ni_sqrt / o.lr + o.lambda2_plus_beta_div_lr;
-        delta = (p / q) * (float)signbit(o.lambda1 - fabsf(zi)) - wi;
-      } break;
-    }
-    *w += delta;
+    det_apply(o, dim, e, gi, rows_w + rw * dim + e, st);
+  }
+}
+
+// the same step through per-key row addresses: one launch for keys of any number of classes
+// (dynamic_embedding.cu:227-317: *_update_grad_kernel(ev_start_indices, ..., float** state,
+// float** weight))
+__global__ void __launch_bounds__(kBlock)
+    det_update_ptr_kernel(DetOpt o, size_t n, int dim, float* const* __restrict__ wptr,
+                          float* const* __restrict__ sptr, const uint32_t* __restrict__ ev_start,
+                          const float* __restrict__ wgrad) {
+  const uint64_t total = (uint64_t)n * dim;
+  for (uint64_t i = blockIdx.x * (uint64_t)kBlock + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const size_t k = (size_t)(i / dim);
+    const int e = (int)(i % dim);
+    float* w = wptr[k];
+    if (w == nullptr) continue;  // scatter_add skips keys that are not in the table
+    const float gi = wgrad[ev_start[k] + e] / o.scaler;
+    det_apply(o, dim, e, gi, w + e, sptr ? sptr[k] : nullptr);
   }
 }
 
@@ -267,6 +359,15 @@ struct hctr_det {
   uint64_t* idx = nullptr;  // scratch row indices
   uint64_t* idx2 = nullptr;
   size_t idx_cap = 0;
+  // device copies of the per-call id-space table and the class descriptors (multi-space lookups)
+  float** ptr_w = nullptr;  // per-key row addresses of a multi-class update
+  float** ptr_s = nullptr;
+  size_t ptr_cap = 0;
+  DetClassDesc* d_desc = nullptr;
+  uint32_t* d_seg_class = nullptr;
+  uint64_t* d_seg_off = nullptr;
+  uint32_t* d_miss = nullptr;
+  size_t seg_cap = 0;
 };
 
 namespace {
@@ -441,6 +542,12 @@ int hctr_det_destroy(hctr_det* h) {
   for (auto& c : h->cls) class_destroy(c);
   if (h->idx) (void)hipFree(h->idx);
   if (h->idx2) (void)hipFree(h->idx2);
+  if (h->ptr_w) (void)hipFree(h->ptr_w);
+  if (h->ptr_s) (void)hipFree(h->ptr_s);
+  if (h->d_desc) (void)hipFree(h->d_desc);
+  if (h->d_seg_class) (void)hipFree(h->d_seg_class);
+  if (h->d_seg_off) (void)hipFree(h->d_seg_off);
+  if (h->d_miss) (void)hipFree(h->d_miss);
   delete h;
   return HCTR_OK;
 }
@@ -494,43 +601,118 @@ int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size
   return HCTR_OK;
 }
 
+// upload the id-space table of a call and the current class descriptors
+static int det_upload_spaces(hctr_det* h, const std::vector<Range>& rs,
+                             const std::vector<uint64_t>& base, hipStream_t s) {
+  const size_t ncls = h->cls.size();
+  if (!h->d_desc) {
+    HCTR_HIP(hipMalloc(&h->d_desc, ncls * sizeof(DetClassDesc)));
+    HCTR_HIP(hipMalloc(&h->d_miss, ncls * sizeof(uint32_t)));
+  }
+  if (rs.size() > h->seg_cap) {
+    if (h->d_seg_class) (void)hipFree(h->d_seg_class);
+    if (h->d_seg_off) (void)hipFree(h->d_seg_off);
+    h->d_seg_class = nullptr;
+    h->d_seg_off = nullptr;
+    size_t c = 64;
+    while (c < rs.size()) c *= 2;
+    HCTR_HIP(hipMalloc(&h->d_seg_class, c * sizeof(uint32_t)));
+    HCTR_HIP(hipMalloc(&h->d_seg_off, c * sizeof(uint64_t)));
+    h->seg_cap = c;
+  }
+  std::vector<DetClassDesc> desc(ncls);
+  for (size_t ci = 0; ci < ncls; ci++) {
+    const DetClass& c = h->cls[ci];
+    desc[ci] = {c.ht.entries, c.ht.size, c.rows, base[ci], c.dim};
+  }
+  std::vector<uint32_t> sc(rs.size());
+  std::vector<uint64_t> so(rs.size());
+  for (size_t i = 0; i < rs.size(); i++) {
+    sc[i] = (uint32_t)rs[i].cls;
+    so[i] = rs[i].off;
+  }
+  // (pageable sources: the runtime has consumed them when these calls return)
+  HCTR_HIP(hipMemcpyAsync(h->d_desc, desc.data(), ncls * sizeof(DetClassDesc),
+                          hipMemcpyHostToDevice, s));
+  HCTR_HIP(hipMemcpyAsync(h->d_seg_class, sc.data(), sc.size() * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, s));
+  HCTR_HIP(hipMemcpyAsync(h->d_seg_off, so.data(), so.size() * sizeof(uint64_t),
+                          hipMemcpyHostToDevice, s));
+  return HCTR_OK;
+}
+
 int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
                          const size_t* id_space_offsets, size_t num_id_spaces, int insert,
                          float** elements, uint64_t* row_index, uint64_t* class_row_base,
                          hctr_stream_t stream) {
   HCTR_REQUIRE(h, "null handle");
   hipStream_t s = as_stream(stream);
-  std::vector<Range> rs;
-  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
+  std::vector<Range> all, rs;
+  HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &all));
+  for (const Range& r : all)
+    if (r.n) rs.push_back(r);
   if (num_keys) {
     HCTR_REQUIRE(keys && (elements || row_index), "null pointer");
+    HCTR_REQUIRE(!rs.empty() && rs.front().off == 0 &&
+                     rs.back().off + rs.back().n == num_keys,
+                 "id spaces must cover keys[0, num_keys)");
+    for (size_t i = 1; i < rs.size(); i++)
+      HCTR_REQUIRE(rs[i].off == rs[i - 1].off + rs[i - 1].n, "id spaces must be contiguous");
     HCTR_TRY(det_scratch(h, num_keys));
   }
-  // every insertion (and so every re-allocation) happens before a pointer or a row base is taken
-  if (insert) {
-    std::vector<size_t> need(h->cls.size(), 0);
-    for (const Range& r : rs) need[r.cls] += r.n;
-    for (size_t ci = 0; ci < need.size(); ci++)
-      if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
-  }
-  std::vector<uint64_t> base(h->cls.size() + 1, 0);
-  for (size_t ci = 0; ci < h->cls.size(); ci++) base[ci + 1] = base[ci] + h->cls[ci].cap;
-  if (class_row_base)
-    for (size_t ci = 0; ci <= h->cls.size(); ci++) class_row_base[ci] = base[ci];
-  for (const Range& r : rs) {
-    DetClass& c = h->cls[r.cls];
-    if (r.n == 0) continue;
-    const void* kp = key_at(h, keys, r.off);
-    if (insert)
-      HCTR_TRY(class_lookup_insert(h, c, r.cls, kp, r.n, h->idx, s));
+  const size_t ncls = h->cls.size();
+  std::vector<uint64_t> base(ncls + 1, 0);
+  auto rebase = [&] {
+    for (size_t ci = 0; ci < ncls; ci++) base[ci + 1] = base[ci] + h->cls[ci].cap;
+  };
+  rebase();
+  if (num_keys) {
+    // 1. one find-only pass over all id spaces; classes that met an unseen key are flagged
+    HCTR_TRY(det_upload_spaces(h, rs, base, s));
+    HCTR_HIP(hipMemsetAsync(h->d_miss, 0, ncls * sizeof(uint32_t), s));
+    const int grid = grid_for(num_keys, kBlock, 8192);
+    if (h->key_type == HCTR_KEY_U32)
+      hipLaunchKernelGGL(det_find_multi_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, h->d_desc,
+                         h->d_seg_class, h->d_seg_off, (int)rs.size(), (const uint32_t*)keys,
+                         num_keys, h->idx, h->d_miss);
     else
-      HCTR_TRY(c.ht.get_mark(kp, r.n, nullptr, h->idx, s));
-    hipLaunchKernelGGL(det_rows_kernel, dim3(grid_for(r.n, kBlock, 1024)), dim3(kBlock), 0, s,
-                       h->idx, r.n, c.rows, c.dim, base[r.cls],
-                       elements ? elements + r.off : nullptr,
-                       row_index ? row_index + r.off : nullptr);
+      hipLaunchKernelGGL(det_find_multi_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, h->d_desc,
+                         h->d_seg_class, h->d_seg_off, (int)rs.size(), (const long long*)keys,
+                         num_keys, h->idx, h->d_miss);
+    HCTR_LAUNCH_CHECK();
+    if (insert) {
+      // 2. only those classes take the inserting path (and may grow: every insertion happens
+      //    before a pointer or a row base is taken)
+      std::vector<uint32_t> miss(ncls, 0);
+      HCTR_HIP(hipMemcpyAsync(miss.data(), h->d_miss, ncls * sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, s));
+      HCTR_HIP(hipStreamSynchronize(s));
+      std::vector<size_t> need(ncls, 0);
+      bool any = false;
+      for (const Range& r : rs)
+        if (miss[r.cls]) {
+          need[r.cls] += r.n;
+          any = true;
+        }
+      if (any) {
+        for (size_t ci = 0; ci < ncls; ci++)
+          if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
+        for (const Range& r : rs)
+          if (miss[r.cls])
+            HCTR_TRY(class_lookup_insert(h, h->cls[r.cls], r.cls, key_at(h, keys, r.off), r.n,
+                                         h->idx + r.off, s));
+        rebase();
+        HCTR_TRY(det_upload_spaces(h, rs, base, s));
+      }
+    }
+    // 3. addresses / table-wide row numbers of all keys
+    hipLaunchKernelGGL(det_rows_multi_kernel, dim3(grid_for(num_keys, kBlock, 8192)), dim3(kBlock),
+                       0, s, h->d_desc, h->d_seg_class, h->d_seg_off, (int)rs.size(), h->idx,
+                       num_keys, elements, row_index);
     HCTR_LAUNCH_CHECK();
   }
+  if (class_row_base)
+    for (size_t ci = 0; ci <= ncls; ci++) class_row_base[ci] = base[ci];
   return HCTR_OK;
 }
 
@@ -722,6 +904,44 @@ int hctr_det_update(hctr_det* weights, hctr_det* states, const hctr_det_opt_para
                                        (1.0 - std::pow((double)p->beta1, (double)t)));
   }
   const int smul = (opt == HCTR_OPT_ADAM || opt == HCTR_OPT_FTRL) ? 2 : 1;
+  // several id spaces of one vector size that tile the key list (the embedding_collection case):
+  // row addresses of all keys by the multi-class lookup, then one optimizer launch
+  bool tiled = rs.size() > 1 && rs.front().off == 0;
+  size_t covered = 0;
+  for (const Range& r : rs) {
+    tiled = tiled && r.off == covered && h->cls[r.cls].dim == h->cls[rs[0].cls].dim;
+    if (needs_state)
+      tiled = tiled && r.cls < states->cls.size() &&
+              states->cls[r.cls].dim == h->cls[r.cls].dim * smul;
+    covered += r.n;
+  }
+  if (tiled && covered == num_unique_keys) {
+    if (num_unique_keys > h->ptr_cap) {
+      if (h->ptr_w) (void)hipFree(h->ptr_w);
+      if (h->ptr_s) (void)hipFree(h->ptr_s);
+      h->ptr_w = h->ptr_s = nullptr;
+      size_t c = h->ptr_cap ? h->ptr_cap : 1024;
+      while (c < num_unique_keys) c *= 2;
+      HCTR_HIP(hipMalloc(&h->ptr_w, c * sizeof(float*)));
+      HCTR_HIP(hipMalloc(&h->ptr_s, c * sizeof(float*)));
+      h->ptr_cap = c;
+    }
+    // (the reference looks the weights up with insertion only for Ftrl)
+    HCTR_TRY(hctr_det_lookup_rows(h, unique_keys, num_unique_keys, id_spaces, id_space_offsets,
+                                  num_id_spaces, opt == HCTR_OPT_FTRL ? 1 : 0, h->ptr_w, nullptr,
+                                  nullptr, stream));
+    if (needs_state)
+      HCTR_TRY(hctr_det_lookup_rows(states, unique_keys, num_unique_keys, id_spaces,
+                                    id_space_offsets, num_id_spaces, 1, h->ptr_s, nullptr, nullptr,
+                                    stream));
+    const int dim = h->cls[rs[0].cls].dim;
+    hipLaunchKernelGGL(det_update_ptr_kernel,
+                       dim3(grid_for(num_unique_keys * (size_t)dim, kBlock, 8192)), dim3(kBlock), 0,
+                       s, o, num_unique_keys, dim, h->ptr_w, needs_state ? h->ptr_s : nullptr,
+                       ev_start_indices, wgrad);
+    HCTR_LAUNCH_CHECK();
+    return HCTR_OK;
+  }
   for (const Range& r : rs) {
     if (r.n == 0) continue;
     DetClass& cw = h->cls[r.cls];

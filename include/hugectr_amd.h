@@ -396,7 +396,10 @@ int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacit
  * sort key of hctr_ebc_local_reduce).  class_row_base (HOST, num_classes + 1 entries, may be NULL)
  * receives the bases used by this call = running sum of the class capacities after any growth.
  * insert != 0: unseen keys are inserted and initialised first (the training lookup); else unseen
- * keys give NULL / SIZE_MAX.  Pointers and row numbers stay valid until the next inserting call. */
+ * keys give NULL / SIZE_MAX.  Pointers and row numbers stay valid until the next inserting call.
+ * The id spaces must tile keys[0, num_keys) without gaps.  All of them are probed by ONE launch;
+ * only classes that met an unseen key take the inserting path (one stream synchronisation to learn
+ * which, when insert != 0). */
 int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const size_t* id_spaces,
                          const size_t* id_space_offsets, size_t num_id_spaces, int insert,
                          float** elements, uint64_t* row_index, uint64_t* class_row_base,

@@ -128,7 +128,7 @@ def test_tiered_table_matches_oracle(D):
 
 @pytest.mark.parametrize("D", [16, 128])
 def test_tiered_embedding_trains_like_a_dense_table(D):
-    """BASELINE config 3 in miniature: a one-hot embedding whose table lives in host memory behind
+    """BASELINE config 4 in miniature: a one-hot embedding whose table lives in host memory behind
     the cache; forward rows and the SGD-updated table must follow a plain in-memory table"""
     import torch
     from hugectr_amd.cache import TieredEmbedding

@@ -214,7 +214,7 @@ def test_dcnv2_embedding_collection_script_trains(tmp_path, plan, dynamic):
     reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
                                       source=[p.source], eval_source=p.eval_source,
                                       slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
-    # dynamic hash tables (max_vocabulary_size = -1, BASELINE config 4) take any optimizer
+    # dynamic hash tables (max_vocabulary_size = -1, BASELINE config 5) take any optimizer
     opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam if dynamic
                                   else hugectr.Optimizer_t.AdaGrad,
                                   update_type=hugectr.Update_t.Global, initial_accu_value=0.0)
