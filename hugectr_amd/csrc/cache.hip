@@ -144,53 +144,64 @@ __global__ void __launch_bounds__(kBlock)
     if (i > 0 && sorted_set[i - 1] == set) continue;  // not the head of its run
     long long my_key = set_keys[(size_t)set * kSetSlots + lane];
     unsigned long long my_cnt = counters[(size_t)set * kSetSlots + lane];
-    for (size_t j = i; j < len && sorted_set[j] == set; j++) {
-      const uint32_t p = sorted_pos[j];
-      const K key = keys[p];
-      const long long k64 = widen(key);
-      const float* src = values + (value_index ? (size_t)value_index[p] : (size_t)p) * (size_t)D;
-      const unsigned long long hit = ballot64(my_key == k64);
-      int target = -1;
-      if (hit) {
-        const int h = __ffsll((long long)hit) - 1;
-        if (REPLACE) {
-          if (lane == h) {
-            my_cnt = gc;
-            counters[(size_t)set * kSetSlots + h] = gc;
+    // the run is consumed 64 entries at a time: one coalesced load of (position, key) per chunk,
+    // then the entries are broadcast lane by lane -- a set that receives 100 k copies of a hot
+    // key costs a few cycles per copy instead of two dependent global loads
+    for (size_t j0 = i;; j0 += 64) {
+      const size_t jj = j0 + lane;
+      const bool in_run = jj < len && sorted_set[jj] == set;
+      const uint32_t my_p = in_run ? sorted_pos[jj] : 0u;
+      const long long my_k = in_run ? widen(keys[my_p]) : 0ll;
+      const int cnt = __popcll(ballot64(in_run));  // the run is contiguous: lanes [0, cnt)
+      for (int e = 0; e < cnt; e++) {
+        const uint32_t p = (uint32_t)__shfl((int)my_p, e);
+        const long long k64 = __shfl(my_k, e);
+        const unsigned long long hit = ballot64(my_key == k64);
+        int target = -1;
+        if (hit) {
+          const int h = __ffsll((long long)hit) - 1;
+          if (REPLACE) {
+            if (lane == h) {
+              my_cnt = gc;
+              counters[(size_t)set * kSetSlots + h] = gc;
+            }
+          } else {
+            target = h;
           }
-        } else {
-          target = h;
-        }
-      } else if (REPLACE) {
-        // probing order: slab (key % 2) first (Mod_Hash, nv_gpu_cache.hpp:49), then the other
-        const int first_slab = (int)((unsigned long long)k64 & 1ull);
-        const unsigned long long empties = ballot64(my_key == empty_key);
-        unsigned long long cand = empties;
-        if (!cand) {  // LRU: smallest counter, ties by probing order
-          unsigned long long mn = my_cnt;
+        } else if (REPLACE) {
+          // probing order: slab (key % 2) first (Mod_Hash, nv_gpu_cache.hpp:49), then the other
+          const int first_slab = (int)((unsigned long long)k64 & 1ull);
+          const unsigned long long empties = ballot64(my_key == empty_key);
+          unsigned long long cand = empties;
+          if (!cand) {  // LRU: smallest counter, ties by probing order
+            unsigned long long mn = my_cnt;
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(mn, o);
-            mn = other < mn ? other : mn;
+            for (int o = 32; o > 0; o >>= 1) {
+              const unsigned long long other = __shfl_xor(mn, o);
+              mn = other < mn ? other : mn;
+            }
+            cand = ballot64(my_cnt == mn);
           }
-          cand = ballot64(my_cnt == mn);
+          const unsigned long long lo = cand & 0xFFFFFFFFull, hi = cand >> 32;
+          const unsigned long long a = first_slab == 0 ? lo : hi;  // first slab in probing order
+          const unsigned long long b = first_slab == 0 ? hi : lo;
+          if (a)
+            target = (__ffsll((long long)a) - 1) + 32 * first_slab;
+          else
+            target = (__ffsll((long long)b) - 1) + 32 * (1 - first_slab);
+          if (lane == target) {
+            my_key = k64;
+            my_cnt = gc;
+            set_keys[(size_t)set * kSetSlots + target] = k64;
+            counters[(size_t)set * kSetSlots + target] = gc;
+          }
         }
-        const unsigned long long lo = cand & 0xFFFFFFFFull, hi = cand >> 32;
-        const unsigned long long a = first_slab == 0 ? lo : hi;  // first slab in probing order
-        const unsigned long long b = first_slab == 0 ? hi : lo;
-        if (a)
-          target = (__ffsll((long long)a) - 1) + 32 * first_slab;
-        else
-          target = (__ffsll((long long)b) - 1) + 32 * (1 - first_slab);
-        if (lane == target) {
-          my_key = k64;
-          my_cnt = gc;
-          set_keys[(size_t)set * kSetSlots + target] = k64;
-          counters[(size_t)set * kSetSlots + target] = gc;
+        if (target >= 0) {
+          const float* src = values + (value_index ? (size_t)value_index[p] : (size_t)p) * (size_t)D;
+          wave_copy<V4>(lane, D, vals + ((size_t)set * kSetSlots + target) * (size_t)D, src);
         }
       }
-      if (target >= 0)
-        wave_copy<V4>(lane, D, vals + ((size_t)set * kSetSlots + target) * (size_t)D, src);
+      if (cnt < 64) break;
     }
   }
 }
