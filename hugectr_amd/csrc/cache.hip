@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kBlock)
         if (hit) {
           const int h = __ffsll((long long)hit) - 1;
           if (REPLACE) {
-            if (lane == h) {
+            if (lane == h && my_cnt != gc) {  // (later copies of a key of this call: nothing to do)
               my_cnt = gc;
               counters[(size_t)set * kSetSlots + h] = gc;
             }
