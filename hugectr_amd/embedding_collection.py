@@ -150,7 +150,12 @@ class EmbeddingCollection:
         assert all(t.ev_size == self.ev for t in tables), "one ev_size per collection"
         self.L = len(config.lookups)
         self.lookup_table = [tables.index(t) for t, _, _, _ in config.lookups]
-        self.combiner = [0 if str(c).lower() in ("sum", "0") else 1 for _, _, _, c in config.lookups]
+        # "concat" keeps every key's vector; with one key per bucket (the one-hot configurations that
+        # use it, R/test/embedding_collection_test/dgx_a100_one_hot.py:287) it equals "sum"
+        names = [str(c).lower().split(".")[-1] for _, _, _, c in config.lookups]
+        self.concat_lookups = [l for l, c in enumerate(names) if c == "concat"]
+        # (callers that know the hotness per lookup reject multi-hot concat: hugectr.Model does)
+        self.combiner = [0 if c in ("sum", "0", "concat") else 1 for c in names]
         sm = config.ownership(tables, self.world)
         # owners of every table, ascending GPU order (shard id = position in that list)
         self.owners = [[g for g in range(self.world) if sm[g][t]] for t in range(len(tables))]

@@ -466,6 +466,9 @@ class Model:
                 raise RuntimeError("embedding_collection inputs carry one slot per lookup "
                                    "(DataReaderSparseParam(name, hotness, fixed, 1))")
             params.append(p)
+            if str(cfg.lookups[len(params) - 1][3]).lower().endswith("concat") and p.max_nnz() > 1:
+                raise RuntimeError(f"lookup '{bottom}': combiner 'concat' is supported for one-hot "
+                                   "inputs only")
             # the readers add cumulative slot offsets for the legacy embeddings; tables of a
             # collection are indexed by the raw key
             offsets.append(int(cum[slot_of_param[bottom]]) if cum is not None else 0)

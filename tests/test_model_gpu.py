@@ -330,13 +330,17 @@ def _ebc_model_worker(rank, world, port, folder, ret):
         sm, ss = sharding.generate_plan(SIZES, hot, 1, 2, args, False)
         ebc = hugectr.EmbeddingCollectionConfig()
         ebc.embedding_lookup(table_config=tables, bottom_name=[f"data{i}" for i in range(26)],
-                             top_name="sparse_embedding", combiner=["sum"] * 26)
+                             top_name="sparse_embedding",
+                             combiner=["concat" if h == 1 else "sum" for h in hot])
         ebc.shard(shard_matrix=sm, shard_strategy=ss)
         model.add(ebc)
         D, T = hugectr.DenseLayer, hugectr.Layer_t
+        # (the reshape of R/test/embedding_collection_test/dgx_a100_one_hot.py:309-315)
+        model.add(D(layer_type=T.Reshape, bottom_names=["sparse_embedding"],
+                    top_names=["sparse_embedding1"], shape=[-1, 26, 16]))
         model.add(D(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"], num_outputs=[32, 16],
                     act_type=hugectr.Activation_t.Relu))
-        model.add(D(layer_type=T.Interaction, bottom_names=["mlp1", "sparse_embedding"],
+        model.add(D(layer_type=T.Interaction, bottom_names=["mlp1", "sparse_embedding1"],
                     top_names=["interaction1"]))
         model.add(D(layer_type=T.MLP, bottom_names=["interaction1"], top_names=["mlp2"],
                     num_outputs=[64, 1],
