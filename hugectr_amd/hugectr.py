@@ -424,7 +424,17 @@ class Model:
             self._shapes[se.sparse_embedding_name] = (p.slot_num, se.embedding_vec_size)
         self._ebc = []
         for cfg in self.ebc_configs:
-            self._ebc.append(self._compile_ebc(cfg, sp, B, Be))
+            subs = self._split_by_ev_size(cfg)
+            for sub, ids in subs:
+                rt = self._compile_ebc(sub, sp, B, Be, declare_shapes=len(subs) == 1)
+                rt.update(parent=cfg, ids=ids, whole=len(subs) == 1)
+                self._ebc.append(rt)
+            if len(subs) > 1:  # mixed vector sizes: outputs are concatenated in lookup order
+                if cfg.top_name:
+                    self._shapes[cfg.top_name] = (sum(t.ev_size for t, _, _, _ in cfg.lookups),)
+                else:
+                    for t, _, top, _ in cfg.lookups:
+                        self._shapes[top] = (t.ev_size,)
         # dense modules
         self._mods = torch.nn.ModuleDict()
         self._loss_layer = None
@@ -437,7 +447,34 @@ class Model:
                                         self.device)
         self._compiled = True
 
-    def _compile_ebc(self, cfg: EmbeddingCollectionConfig, sp, B, Be):
+    def _split_by_ev_size(self, cfg: EmbeddingCollectionConfig):
+        """the runtime keeps one vector size per collection: lookups of a config that mixes sizes
+        (wide 1 + deep 16 ...) run as one collection per size, each with the parent's placement"""
+        sizes = sorted({t.ev_size for t, _, _, _ in cfg.lookups})
+        if len(sizes) == 1:
+            return [(cfg, list(range(len(cfg.lookups))))]
+        tables = []
+        for t, _, _, _ in cfg.lookups:
+            if t not in tables:
+                tables.append(t)
+        own = cfg.ownership(tables, self.world)
+        out = []
+        for ev in sizes:
+            ids = [l for l, (t, _, _, _) in enumerate(cfg.lookups) if t.ev_size == ev]
+            sub = EmbeddingCollectionConfig()
+            sub.lookups = [cfg.lookups[l] for l in ids]
+            sub_tables = []
+            for t, _, _, _ in sub.lookups:
+                if t not in sub_tables:
+                    sub_tables.append(t)
+            sub.shard_matrix = [[int(own[g][tables.index(t)]) for t in sub_tables]
+                                for g in range(self.world)]
+            if any(not any(row[c] for row in sub.shard_matrix) for c in range(len(sub_tables))):
+                raise RuntimeError("embedding_collection: a table has no owner")
+            out.append((sub, ids))
+        return out
+
+    def _compile_ebc(self, cfg: EmbeddingCollectionConfig, sp, B, Be, declare_shapes=True):
         """embedding_collection of the model (R/HugeCTR/src/pybind/add_embedding_collection.cpp):
         one runtime for the training batch, one for the evaluation batch, sharing the tables"""
         o = self.opt
@@ -490,11 +527,12 @@ class Model:
                     ev.det, ev.det_opt = train.det, train.det_opt
                     ev.training = False  # evaluation never inserts: unseen keys read as zeros
         L, evs = train.L, train.ev
-        if cfg.top_name:
-            self._shapes[cfg.top_name] = (L, evs)
-        else:
-            for _, _, top, _ in cfg.lookups:
-                self._shapes[top] = (evs,)
+        if declare_shapes:
+            if cfg.top_name:
+                self._shapes[cfg.top_name] = (L, evs)
+            else:
+                for _, _, top, _ in cfg.lookups:
+                    self._shapes[top] = (evs,)
         return dict(cfg=cfg, train=train, eval=ev, params=params,
                     offsets=torch.tensor(offsets, dtype=torch.int64, device=self.device))
 
@@ -665,12 +703,23 @@ class Model:
             if train:
                 E = E.detach().requires_grad_(True)
                 leaves[("ebc", i)] = E
-            cfg = rt["cfg"]
-            if cfg.top_name:
-                tensors[cfg.top_name] = E
-            else:
-                for l, (_, _, top, _) in enumerate(cfg.lookups):
-                    tensors[top] = E[:, l, :]
+            cfg = rt["parent"]
+            if rt["whole"]:
+                if cfg.top_name:
+                    tensors[cfg.top_name] = E
+                else:
+                    for l, (_, _, top, _) in enumerate(cfg.lookups):
+                        tensors[top] = E[:, l, :]
+            else:  # one of several collections of a mixed-size config
+                for j, l in enumerate(rt["ids"]):
+                    if cfg.top_name:
+                        tensors[(id(cfg), l)] = E[:, j, :].float()
+                    else:
+                        tensors[cfg.lookups[l][2]] = E[:, j, :]
+        for cfg in self.ebc_configs:
+            if cfg.top_name and (id(cfg), 0) in tensors:
+                tensors[cfg.top_name] = torch.cat(
+                    [tensors.pop((id(cfg), l)) for l in range(len(cfg.lookups))], dim=1)
         logit = self._forward_dense(tensors, train)
         label = batch["label"].float()
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)

@@ -392,3 +392,57 @@ def test_embedding_collection_model_two_ranks_on_one_gpu(tmp_path):
         if ret.get(r) != "ok":
             print(f"--- rank {r} ---\n{ret.get(r)}")
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def test_wdl_embedding_collection_mixed_vector_sizes(tmp_path):
+    """Wide & Deep on ONE embedding_collection config that mixes vector sizes (wide tables ev = 1,
+    deep tables ev = 16, BASELINE config 5's model family): dynamic hash tables
+    (max_vocabulary_size = -1), per-lookup top names + Concat as in
+    R/samples/ftrl/dlrm_train_ftrl.py:222-245"""
+    import hugectr_amd.hugectr as hugectr
+    hot = [1, 2] + [1] * 24
+    p = _gen(tmp_path, hugectr, n_train=4096, n_eval=512, nnz=hot)
+    solver = hugectr.CreateSolver(batchsize=512, batchsize_eval=512, lr=0.05, vvgpu=[[0]],
+                                  i64_input_key=True, max_eval_batches=1,
+                                  use_embedding_collection=True)
+    reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
+                                      source=[p.source], eval_source=p.eval_source,
+                                      slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.AdaGrad,
+                                  update_type=hugectr.Update_t.Global)
+    model = hugectr.Model(solver, reader, opt)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                                for i in range(26)]))
+    wide, deep = [0, 1], list(range(2, 10))
+    ebc = hugectr.EmbeddingCollectionConfig()
+    for i in wide:
+        ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"w{i}", -1, 1),
+                             bottom_name=f"data{i}", top_name=f"wide{i}", combiner="sum")
+    for i in deep:
+        ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"d{i}", -1, 16),
+                             bottom_name=f"data{i}", top_name=f"deep{i}", combiner="sum")
+    ebc.shard(shard_matrix=[[f"w{i}" for i in wide] + [f"d{i}" for i in deep]],
+              shard_strategy=[("mp", [f"w{i}" for i in wide] + [f"d{i}" for i in deep])])
+    model.add(ebc)
+    D, T = hugectr.DenseLayer, hugectr.Layer_t
+    model.add(D(layer_type=T.Concat, bottom_names=[f"deep{i}" for i in deep] + ["dense"],
+                top_names=["concat1"]))
+    model.add(D(layer_type=T.MLP, bottom_names=["concat1"], top_names=["mlp1"], num_outputs=[64, 1],
+                activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Non]))
+    model.add(D(layer_type=T.Concat, bottom_names=[f"wide{i}" for i in wide], top_names=["wide"]))
+    model.add(D(layer_type=T.ReduceSum, bottom_names=["wide"], top_names=["wide_sum"], axis=1))
+    model.add(D(layer_type=T.Add, bottom_names=["mlp1", "wide_sum"], top_names=["add1"]))
+    model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["add1", "label"],
+                top_names=["loss"]))
+    model.compile()
+    assert len(model._ebc) == 2 and {rt["train"].ev for rt in model._ebc} == {1, 16}
+    model.train()
+    first = model.get_current_loss()
+    model.fit(max_iter=200, display=0, eval_interval=0, snapshot=0)
+    assert model.get_current_loss() < min(first, 0.55)
+    # the wide table of feature C1 (which decides the label) has learnt a per-key bias
+    wide_rt = [rt for rt in model._ebc if rt["train"].ev == 1][0]["train"]
+    k, v = wide_rt.det.export(wide_rt.class_of_table[0])
+    assert k.numel() > 10 and float(v.abs().max()) > 0.1
