@@ -515,6 +515,8 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   e->opt.momentum_factor = p.momentum_factor;
   e->opt.scaler = p.scaler;
   e->opt.atomic_update = p.atomic_update;
+  // OptimizerTensor<TypeEmbeddingComp>: fp16 embeddings keep their optimizer state in fp16
+  e->opt.state_half = p.out_dtype == HCTR_EMB_F16 ? 1 : 0;
   if (hipMemset(e->slot_id, 0, V * sizeof(uint64_t)) != hipSuccess ||
       hipMemset(e->table, 0, V * D * sizeof(float)) != hipSuccess) {
     set_error("hipMemset failed");

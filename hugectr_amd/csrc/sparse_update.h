@@ -14,6 +14,7 @@ struct OptState {
   int atomic_update = 0;
   float ftrl_lambda1 = 0.f, ftrl_lambda2 = 0.f, ftrl_beta = 0.f;  // EBC static tables only
   uint64_t times = 0;  // Adam step counter (incremented before each update)
+  int state_half = 0;  // optimizer state holds fp16 values (fp16 embeddings)
 };
 
 constexpr int kOptStoreSumId = 1000;  // internal: table[row] = per-row gradient sum

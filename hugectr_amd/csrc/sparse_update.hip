@@ -173,7 +173,22 @@ struct OptConst {
   float alpha_t_common;  // lr / (1 - beta1) (lazy adam)
   float ftrl_l1, ftrl_l2b;  // lambda1, lambda2 + beta / lr
   unsigned long long times;
+  int state_half;  // optimizer state carries fp16 values
 };
+
+// OptimizerTensor<TypeEmbeddingComp> (R/HugeCTR/include/optimizer.hpp:284-296): with fp16 embeddings
+// the reference keeps m / v / accumulators in fp16 -- every kernel converts the stored value to
+// float, computes in float and converts the result back on the store; the weight update of the
+// same step uses the unrounded float.  Here the state arrays stay fp32 and hold fp16-representable
+// values: same numbers, the footprint saving is not taken.
+__device__ __forceinline__ float state_store(int state_half, float x) {
+  if (!state_half) return x;
+  // the fp32 result first, THEN the conversion (two roundings, as the reference's float math +
+  // TypeConvertFunc does): without the barrier the compiler folds a preceding multiply into one
+  // mixed-precision instruction that rounds the exact product straight to fp16
+  asm volatile("" : "+v"(x));
+  return __half2float(__float2half_rn(x));
+}
 
 // internal pseudo-optimizer of hctr_updater_reduce_presorted: table[row] = gradient sum (no read)
 constexpr int kOptStoreSum = 1000;
@@ -198,24 +213,24 @@ __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w,
       const float p = (1.f - 2.f * (float)signbit(zi)) * o.ftrl_l1 - zi;
       const float q = sqn / o.lr + o.ftrl_l2b;
       w = p / q * (float)signbit(o.ftrl_l1 - fabsf(zi));
-      *s0p = ni;
-      *s1p = zi;
+      *s0p = state_store(o.state_half, ni);
+      *s1p = state_store(o.state_half, zi);
     } break;
     case HCTR_OPT_ADAGRAD: {  // opt_adagrad_kernel :410-437 (Global == Local)
       float accum = *s0p + gi * gi;
-      *s0p = accum;
+      *s0p = state_store(o.state_half, accum);
       w += -o.lr * gi / (sqrtf(accum) + o.epsilon);
     } break;
     case HCTR_OPT_ADAM:
       if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_adam_kernel :379-408
         float mi = o.beta1 * *s0p + (1.0f - o.beta1) * gi;
         float vi = o.beta2 * *s1p + (1.0f - o.beta2) * gi * gi;
-        *s0p = mi;
-        *s1p = vi;
+        *s0p = state_store(o.state_half, mi);
+        *s1p = state_store(o.state_half, vi);
         w += -o.alpha_t * mi / (sqrtf(vi) + o.epsilon);
       } else if (o.update_type == HCTR_UPDATE_GLOBAL) {  // opt_adam_kernel_global :241-265
-        *s0p = *s0p + (1.0f - o.beta1) * gi / o.beta1;
-        *s1p = *s1p + (1.0f - o.beta2) * gi * gi / o.beta2;
+        *s0p = state_store(o.state_half, *s0p + (1.0f - o.beta1) * gi / o.beta1);
+        *s1p = state_store(o.state_half, *s1p + (1.0f - o.beta2) * gi * gi / o.beta2);
       } else {  // opt_adam_kernel_lazy :524-561
         unsigned long long pt = *ptp;
         *ptp = o.times;
@@ -227,29 +242,29 @@ __device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w,
         w += -a * mi / (sqrtf(vi) + o.epsilon);
         mi = b1ps * mi + (1.0f - o.beta1) * gi;
         vi = powf(o.beta2, (float)skipped) * vi + (1.0f - o.beta2) * gi * gi;
-        *s0p = mi;
-        *s1p = vi;
+        *s0p = state_store(o.state_half, mi);
+        *s1p = state_store(o.state_half, vi);
       }
       break;
     case HCTR_OPT_MOMENTUM_SGD:
       if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_momentum_sgd_kernel :440-465
         float mo = o.mf * *s0p - o.lr * gi;
-        *s0p = mo;
+        *s0p = state_store(o.state_half, mo);
         w += mo;
       } else {  // opt_momentum_sgd_kernel_global :292-312
-        *s0p = *s0p - o.lr * gi / o.mf;
+        *s0p = state_store(o.state_half, *s0p - o.lr * gi / o.mf);
       }
       break;
     case HCTR_OPT_NESTEROV:
       if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_nesterov_kernel :468-494
         float accm_old = *s0p;
         float accm_new = o.mf * accm_old - o.lr * gi;
-        *s0p = accm_new;
+        *s0p = state_store(o.state_half, accm_new);
         w += -o.mf * accm_old + (1.0f + o.mf) * accm_new;
       } else {  // nesterov_local_update_kernel_global :352-375
         float accm = *s0p;
         accm -= o.lr * gi;
-        *s0p = accm;
+        *s0p = state_store(o.state_half, accm);
         w -= (1.0f + o.mf) * (o.lr * gi);
       }
       break;
@@ -893,20 +908,21 @@ __global__ void __launch_bounds__(kBlock)
 // ---- global (whole-table) sweeps ----------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
     adam_global_sweep_kernel(size_t n, float beta1, float beta2, float eps, float alpha_t,
-                             float* __restrict__ m, float* __restrict__ v, float* __restrict__ w) {
+                             int state_half, float* __restrict__ m, float* __restrict__ v,
+                             float* __restrict__ w) {
   // adam_update_kernel_global :269-288
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
     float mi = beta1 * m[i];
     float vi = beta2 * v[i];
-    m[i] = mi;
-    v[i] = vi;
+    m[i] = state_store(state_half, mi);
+    v[i] = state_store(state_half, vi);
     w[i] += -alpha_t * mi / (sqrtf(vi) + eps);
   }
 }
 
 __global__ void __launch_bounds__(kBlock)
-    momentum_global_sweep_kernel(size_t n, float factor, float* __restrict__ mo,
+    momentum_global_sweep_kernel(size_t n, float factor, int state_half, float* __restrict__ mo,
                                  float* __restrict__ w) {
   // momentum_sgd_update_kernel_global :316-329
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
@@ -914,19 +930,19 @@ __global__ void __launch_bounds__(kBlock)
     float m = mo[i];
     m *= factor;
     w[i] += m;
-    mo[i] = m;
+    mo[i] = state_store(state_half, m);
   }
 }
 
 __global__ void __launch_bounds__(kBlock)
-    nesterov_global_sweep_kernel(size_t n, float mu, float* __restrict__ accm,
+    nesterov_global_sweep_kernel(size_t n, float mu, int state_half, float* __restrict__ accm,
                                  float* __restrict__ w) {
   // nesterov_global_update_kernel_global :333-347
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
     float a = accm[i];
     a *= mu;
-    accm[i] = a;
+    accm[i] = state_store(state_half, a);
     w[i] += a * mu;
   }
 }
@@ -1009,6 +1025,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   o.alpha_t_common = opt.lr / (1.0f - opt.beta1);
   o.ftrl_l1 = opt.ftrl_lambda1;
   o.ftrl_l2b = opt.ftrl_lambda2 + opt.ftrl_beta / opt.lr;
+  o.state_half = opt.state_half;
   const size_t table_elems = u.max_vocab * (size_t)D;
 
   if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
@@ -1021,7 +1038,8 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
 
   if (opt.optimizer == HCTR_OPT_NESTEROV && opt.update_type == HCTR_UPDATE_GLOBAL) {
     hipLaunchKernelGGL(nesterov_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
-                       dim3(kBlock), 0, s, table_elems, opt.momentum_factor, state0, table);
+                       dim3(kBlock), 0, s, table_elems, opt.momentum_factor, opt.state_half, state0,
+                       table);
     HCTR_LAUNCH_CHECK();
   }
 
@@ -1114,11 +1132,12 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     if (opt.optimizer == HCTR_OPT_ADAM) {
       hipLaunchKernelGGL(adam_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
                          dim3(kBlock), 0, s, table_elems, opt.beta1, opt.beta2, opt.epsilon,
-                         o.alpha_t, state0, state1, table);
+                         o.alpha_t, opt.state_half, state0, state1, table);
       HCTR_LAUNCH_CHECK();
     } else if (opt.optimizer == HCTR_OPT_MOMENTUM_SGD) {
       hipLaunchKernelGGL(momentum_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
-                         dim3(kBlock), 0, s, table_elems, opt.momentum_factor, state0, table);
+                         dim3(kBlock), 0, s, table_elems, opt.momentum_factor, opt.state_half,
+                         state0, table);
       HCTR_LAUNCH_CHECK();
     }
   }

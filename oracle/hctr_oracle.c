@@ -374,6 +374,39 @@ static void odd_even_sort_pairs(hco_pair* a, int64_t n) {
   }
 }
 
+float hco_round_half(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint32_t sign = u & 0x80000000u;
+  uint32_t a = u & 0x7FFFFFFFu;
+  float out;
+  if (a >= 0x7F800000u) return x; /* inf / nan stay */
+  if (a >= 0x477FF000u) {         /* >= 65520: rounds to inf in binary16 */
+    uint32_t inf = sign | 0x7F800000u;
+    memcpy(&out, &inf, 4);
+    return out;
+  }
+  if (a < 0x38800000u) { /* below the smallest normal half (2^-14): subnormal grid of 2^-24 */
+    /* adding 0.5f puts the fp32 ulp at 2^-24: the add itself rounds to nearest even */
+    float ax;
+    memcpy(&ax, &a, 4);
+    volatile float t = ax + 0.5f;
+    float r = t - 0.5f;
+    uint32_t ru;
+    memcpy(&ru, &r, 4);
+    ru |= sign;
+    memcpy(&out, &ru, 4);
+    return out;
+  }
+  /* normal range: keep 10 mantissa bits, round to nearest even on the 13 dropped ones */
+  const uint32_t lsb = (a >> 13) & 1u;
+  a += 0xFFFu + lsb;
+  a &= ~0x1FFFu;
+  a |= sign;
+  memcpy(&out, &a, 4);
+  return out;
+}
+
 int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64_t* row_offset,
                           const uint64_t* value_index, const float* wgrad,
                           const hco_opt_params* opt, float* table, float* state0, float* state1,
@@ -399,6 +432,7 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
     if (i == 0 || pairs[i].idx != pairs[i - 1].idx) run_off[nuniq++] = i;
   run_off[nuniq] = nnz;
 
+#define ST(x) (opt->state_half ? hco_round_half(x) : (x))
   const float lr = opt->lr, scaler = opt->scaler;
   const float b1 = opt->beta1, b2 = opt->beta2, eps = opt->epsilon, mf = opt->momentum_factor;
   /* alpha_t = lr * sqrt(1-beta2^t)/(1-beta1^t): AdamOptHyperParams::bias(), optimizer.hpp:58-60 */
@@ -411,7 +445,7 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
   if (opt->optimizer == HCO_OPT_NESTEROV && opt->update_type == HCO_UPDATE_GLOBAL) {
     for (int64_t f = 0; f < vocab * D; f++) {
       float accm = state0[f] * mf;
-      state0[f] = accm;
+      state0[f] = ST(accm);
       table[f] += accm * mf;
     }
   }
@@ -432,19 +466,19 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
           break;
         case HCO_OPT_ADAGRAD: { /* opt_adagrad_kernel :410-437 */
           float accum = state0[f] + gi * gi;
-          state0[f] = accum;
+          state0[f] = ST(accum);
           table[f] += -lr * gi / (sqrtf(accum) + eps);
         } break;
         case HCO_OPT_ADAM:
           if (opt->update_type == HCO_UPDATE_LOCAL) { /* opt_adam_kernel :379-408 */
             float mi = b1 * state0[f] + (1.0f - b1) * gi;
             float vi = b2 * state1[f] + (1.0f - b2) * gi * gi;
-            state0[f] = mi;
-            state1[f] = vi;
+            state0[f] = ST(mi);
+            state1[f] = ST(vi);
             table[f] += -alpha_t * mi / (sqrtf(vi) + eps);
           } else if (opt->update_type == HCO_UPDATE_GLOBAL) { /* opt_adam_kernel_global :241-265 */
-            state0[f] = state0[f] + (1.0f - b1) * gi / b1;
-            state1[f] = state1[f] + (1.0f - b2) * gi * gi / b2;
+            state0[f] = ST(state0[f] + (1.0f - b1) * gi / b1);
+            state1[f] = ST(state1[f] + (1.0f - b2) * gi * gi / b2);
           } else { /* opt_adam_kernel_lazy :524-561 */
             uint64_t pt = prev_time[f];
             prev_time[f] = opt->times;
@@ -456,29 +490,29 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
             table[f] += -a * mi / (sqrtf(vi) + eps);
             mi = b1ps * mi + (1.0f - b1) * gi;
             vi = powf(b2, (float)skipped) * vi + (1.0f - b2) * gi * gi;
-            state0[f] = mi;
-            state1[f] = vi;
+            state0[f] = ST(mi);
+            state1[f] = ST(vi);
           }
           break;
         case HCO_OPT_MOMENTUM:
           if (opt->update_type == HCO_UPDATE_LOCAL) { /* opt_momentum_sgd_kernel :440-465 */
             float mo = mf * state0[f] - lr * gi;
-            state0[f] = mo;
+            state0[f] = ST(mo);
             table[f] += mo;
           } else { /* opt_momentum_sgd_kernel_global :292-312 */
-            state0[f] = state0[f] - lr * gi / mf;
+            state0[f] = ST(state0[f] - lr * gi / mf);
           }
           break;
         case HCO_OPT_NESTEROV:
           if (opt->update_type == HCO_UPDATE_LOCAL) { /* opt_nesterov_kernel :468-494 */
             float accm_old = state0[f];
             float accm_new = mf * accm_old - lr * gi;
-            state0[f] = accm_new;
+            state0[f] = ST(accm_new);
             table[f] += -mf * accm_old + (1.0f + mf) * accm_new;
           } else { /* nesterov_local_update_kernel_global :352-375 */
             float accm = state0[f];
             accm -= lr * gi;
-            state0[f] = accm;
+            state0[f] = ST(accm);
             table[f] -= (1.0f + mf) * (lr * gi);
           }
           break;
@@ -493,8 +527,8 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
       for (int64_t f = 0; f < vocab * D; f++) {
         float mi = b1 * state0[f];
         float vi = b2 * state1[f];
-        state0[f] = mi;
-        state1[f] = vi;
+        state0[f] = ST(mi);
+        state1[f] = ST(vi);
         table[f] += -alpha_t * mi / (sqrtf(vi) + eps);
       }
     } else if (opt->optimizer == HCO_OPT_MOMENTUM) { /* momentum_sgd_update_kernel_global */
@@ -502,10 +536,11 @@ int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64
         float mo = state0[f];
         mo *= mf;
         table[f] += mo;
-        state0[f] = mo;
+        state0[f] = ST(mo);
       }
     }
   }
+#undef ST
   free(run_off);
   free(pairs);
   free(tmp);

@@ -76,7 +76,12 @@ typedef struct {
   float momentum_factor;       /* momentum: factor, nesterov: mu */
   float scaler;
   uint64_t times; /* adam step counter AFTER increment (t starts at 1) */
+  int state_half; /* OptimizerTensor<__half> (optimizer.hpp:284-296): state stored in fp16 (q6) */
 } hco_opt_params;
+
+/* float -> IEEE binary16 (round to nearest even) -> float, what
+ * TypeConvertFunc<__half, float> / <float, __half> do around every state store */
+float hco_round_half(float x);
 
 /* returns number of unique rows; table/state0/state1/prev_time are [vocab, D] */
 int64_t hco_update_params(int64_t buckets, int64_t D, int64_t vocab, const int64_t* row_offset,

@@ -28,7 +28,7 @@ def build(force=False):
 class OptParamsC(Structure):
     _fields_ = [("optimizer", c_int), ("update_type", c_int), ("lr", c_float), ("beta1", c_float),
                 ("beta2", c_float), ("epsilon", c_float), ("momentum_factor", c_float),
-                ("scaler", c_float), ("times", c_uint64)]
+                ("scaler", c_float), ("times", c_uint64), ("state_half", c_int)]
 
 
 def _p(a):

@@ -388,3 +388,56 @@ def test_mixed_precision_forward_wgrad_update(oracle, dtype, D, combiner, one_ho
         torch.cuda.synchronize()
         oracle.update_params(ro, vi, want_wg, _oracle_opt(oracle, opt, it + 1), table)
         assert_close(emb.table().cpu().numpy(), table, 1e-5, 1e-6, f"table {dtype} it{it}")
+
+
+@pytest.mark.parametrize("name,kw", [o for o in OPTS if o[0] != "sgd"],
+                         ids=[o[0] for o in OPTS if o[0] != "sgd"])
+def test_fp16_embedding_keeps_fp16_valued_optimizer_state(oracle, name, kw):
+    """with fp16 embeddings the reference's optimizer state is OptimizerTensor<__half>
+    (optimizer.hpp:284-296): read as float, stored back rounded to fp16, the weight step of the
+    same launch uses the unrounded value.  The state arrays here hold exactly those fp16 values."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(11)
+    # every row occurs at most once per batch: the per-row gradient is a single fp16 value, so GPU
+    # and oracle feed the SAME float into the fp16 rounding of the state (with summed gradients a
+    # last-bit difference of the fp32 sum can flip an fp16 ulp of v, which Adam amplifies)
+    B, S, hot, vps, D, combiner = 32, 6, 1, 64, 16, 0
+    V = S * vps + 16
+    opt = ha.OptParams(lr=0.05, scaler=4.0, **kw)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S * hot, S, combiner, opt,
+                                 out_dtype=torch.float16)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    ns = {1: 2, 3: 1, 5: 1, 4: 1}[opt.optimizer]
+    s0 = np.zeros_like(table)
+    s1 = np.zeros_like(table) if ns >= 2 else None
+    pt = np.ones(table.shape, dtype=np.uint64) if name == "adam_lazy" else None
+    ht = oracle.HashTable(V, 8)
+    for it in range(4):
+        ro = np.arange(B * S + 1, dtype=np.int64)
+        keys = np.stack([s_ * vps + rng.permutation(vps)[:B] for s_ in range(S)], 1).reshape(-1)
+        keys = keys.astype(np.int64)
+        emb.forward(True, _t(torch, ro), _t(torch, keys))
+        vi = ht.get_insert(keys)
+        g = (rng.standard_normal((B * S, D)) * 8).astype(np.float32)
+        emb.backward(_t(torch, g).to(torch.float16).view(B, S, D).contiguous())
+        want_wg = oracle.backward_mixed(ro, g, D, combiner, "f16")
+        emb.update_params()
+        torch.cuda.synchronize()
+        oo = _oracle_opt(oracle, opt, it + 1)
+        oo.state_half = 1
+        oracle.update_params(ro, vi, want_wg, oo, table, s0, s1, pt)
+        assert_close(emb.table().cpu().numpy(), table, 1e-5, 1e-6, f"{name} table it{it}")
+        for k, want in ((0, s0), (1, s1)):
+            if want is None:
+                continue
+            got = emb.opt_state(k).cpu().numpy()
+            assert (got == got.astype(np.float16).astype(np.float32)).all(), "state not fp16-valued"
+            if name == "adam_lazy":  # powf is not correctly rounded: allow an fp16 ulp
+                assert_close(got, want, 1e-3, 1e-7, f"{name} state{k} it{it}")
+            else:  # float multiply / add, then ONE conversion: the same bits as the oracle
+                assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"{name} state{k} it{it}"
+    assert np.abs(s0).max() > 0

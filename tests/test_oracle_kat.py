@@ -275,3 +275,21 @@ def test_powerlaw_keys_range_and_skew(oracle):
     counts = np.bincount(k, minlength=1000)
     assert counts[:2].min() > counts[2:].max() and counts[:10].sum() > 0.5 * k.size
     assert (oracle.powerlaw_keys(1234, 100, 1000, 1.3) == k[:100]).all()  # seeded, reproducible
+
+
+def test_round_half_matches_ieee_binary16(oracle):
+    """the oracle's software float -> binary16 -> float rounding (fp16 optimizer state)
+    against numpy's float16: normals, ties to even, subnormals, overflow to inf, signed zero"""
+    import ctypes
+    L = oracle.lib()
+    L.hco_round_half.restype = ctypes.c_float
+    L.hco_round_half.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([
+        rng.standard_normal(5000).astype(np.float32) * np.float32(10) ** rng.integers(-9, 6, 5000).astype(np.float32),
+        np.array([0, -0.0, 65504, 65519.9, 65520, 70000, -65520, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8,
+                  2.9e-8, 1e-10, 0.1, 1 + 2 ** -11, 1 + 2 ** -11 + 2 ** -20, 1 + 3 * 2 ** -11], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).astype(np.float32)
+    got = np.array([L.hco_round_half(float(x)) for x in xs], np.float32)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
