@@ -263,6 +263,28 @@ class Input:
         self.sparse_params: List[DataReaderSparseParam] = list(data_reader_sparse_param_array)
 
 
+class AllReduceAlgo(enum.Enum):  # R/HugeCTR/include/pybind/common_wrapper.hpp:199-201
+    OneShot = 0
+    NCCL = 1
+
+
+class TrainingCallback:
+    """R/HugeCTR/include/training_callback.hpp:20-26; pass instances in
+    CreateSolver(training_callbacks=[...]).  on_eval_end returning True stops fit() early."""
+
+    def on_training_start(self):
+        pass
+
+    def on_training_end(self, current_iter: int):
+        pass
+
+    def on_eval_start(self, current_iter: int) -> bool:
+        return False
+
+    def on_eval_end(self, current_iter: int, eval_results: Dict[str, float]) -> bool:
+        return False
+
+
 class CommunicationStrategy(enum.Enum):  # R/HugeCTR/include/embedding/common.hpp
     Uniform = 0
     Hierarchical = 1
@@ -835,6 +857,10 @@ class Model:
         it = 0
         limit = max_iter if num_epochs <= 0 else 10 ** 12
         self._eval_buf = []
+        callbacks = list(getattr(s, "training_callbacks", None) or [])
+        for tc in callbacks:  # model.cpp:869-872
+            tc.on_training_start()
+        stopped = False
         while it < limit:
             if not self.train():
                 break
@@ -849,16 +875,30 @@ class Model:
                     and self.reader.has_eval():
                 self._eval_buf = []
                 te = time.time()
+                for tc in callbacks:  # model.cpp:921-924 (iter counts from 0 there)
+                    tc.on_eval_start(it - 1)
                 for _ in range(s.max_eval_batches):
                     if not self.eval():
                         break
                 torch.cuda.synchronize()
+                metrics = self.get_eval_metrics()
                 if self.rank == 0:
-                    for name, v in self.get_eval_metrics():
+                    for name, v in metrics:
                         print(f"[HCTR][INFO] Evaluation, {name}: {v:.6f}")
                     print(f"[HCTR][INFO] Eval Time for {s.max_eval_batches} iters: {time.time() - te:.6f}s")
+                early = False
+                for tc in callbacks:  # model.cpp:935-943
+                    early = bool(tc.on_eval_end(it - 1, dict(metrics))) or early
+                if early:
+                    for tc in callbacks:
+                        tc.on_training_end(it - 1)
+                    stopped = True
+                    break
             if snapshot > 0 and it % snapshot == 0 and snapshot_prefix:
                 self.save_params_to_files(snapshot_prefix, it)
+        if not stopped:
+            for tc in callbacks:  # model.cpp:991-994
+                tc.on_training_end(max(it - 1, 0))
         torch.cuda.synchronize()
         if self.rank == 0:
             print(f"[HCTR][INFO] Finish {it} iterations with batchsize: {s.batchsize} in "

@@ -446,3 +446,37 @@ def test_wdl_embedding_collection_mixed_vector_sizes(tmp_path):
     wide_rt = [rt for rt in model._ebc if rt["train"].ev == 1][0]["train"]
     k, v = wide_rt.det.export(wide_rt.class_of_table[0])
     assert k.numel() > 10 and float(v.abs().max()) > 0.1
+
+
+def test_training_callbacks_and_early_stop(tmp_path):
+    """fit() drives hugectr.TrainingCallback as the reference does (model.cpp:869-994):
+    start -> (eval start, eval end(results))* -> end; on_eval_end returning True stops training"""
+    import sys
+    import hugectr_amd.hugectr as hugectr
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ckpt_fixture as fx
+    log = []
+
+    class CB(hugectr.TrainingCallback):
+        def on_training_start(self):
+            log.append("start")
+
+        def on_training_end(self, it):
+            log.append(("end", it))
+
+        def on_eval_start(self, it):
+            log.append(("eval_start", it))
+            return False
+
+        def on_eval_end(self, it, results):
+            log.append(("eval_end", it, sorted(results)))
+            return it >= 19            # stop at the second evaluation
+
+    m = fx.dlrm(fx.gen(str(tmp_path / "d")))
+    m.solver.training_callbacks = [CB()]
+    m.compile()
+    m.fit(max_iter=100, display=0, eval_interval=10, snapshot=0)
+    assert log == ["start", ("eval_start", 9), ("eval_end", 9, ["AUC", "AverageLoss"]),
+                   ("eval_start", 19), ("eval_end", 19, ["AUC", "AverageLoss"]), ("end", 19)]
+    assert m._iter == 20
