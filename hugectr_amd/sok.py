@@ -22,8 +22,10 @@ lives on its target GPU.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Union
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -96,7 +98,11 @@ class _VariableBase:
     dimension: int
     target_gpu: int  # -1: distributed over all GPUs
 
-    def __init__(self):
+    _count = 0
+
+    def __init__(self, name: Optional[str] = None):
+        _VariableBase._count += 1
+        self.name = name or f"sok_variable_{_VariableBase._count}"
         # autograd handle: lookups take it as an input so that backward reaches the variable
         self._token = torch.zeros(1, device="cuda", requires_grad=True)
         self._pending: List[tuple] = []  # (row_offset, rows/keys, bucket grads | None, key grads | None)
@@ -113,8 +119,9 @@ class _VariableBase:
 class DistributedVariable(_VariableBase):
     """rows sharded round-robin: global row r -> GPU r % N, local row r // N"""
 
-    def __init__(self, initial_value: torch.Tensor, target_gpu: int = -1):
-        super().__init__()
+    def __init__(self, initial_value: torch.Tensor, target_gpu: int = -1,
+                 name: Optional[str] = None):
+        super().__init__(name)
         v = torch.as_tensor(initial_value, dtype=torch.float32)
         assert v.dim() == 2
         self.global_shape = tuple(v.shape)
@@ -149,14 +156,14 @@ class LocalizedVariable(DistributedVariable):
     pass
 
 
-def Variable(initial_value, mode: Optional[str] = None, **_kw):
+def Variable(initial_value, mode: Optional[str] = None, name: Optional[str] = None, **_kw):
     """sok.Variable: mode None / "distributed" -> DistributedVariable, "localized:<gpu>" ->
     LocalizedVariable on that GPU (distributed_variable.py:26-125)"""
     if mode is None or mode == "distributed":
-        return DistributedVariable(initial_value)
+        return DistributedVariable(initial_value, name=name)
     if mode.startswith("localized"):
         gpu = int(mode.split(":")[1]) if ":" in mode else 0
-        return LocalizedVariable(initial_value, target_gpu=gpu)
+        return LocalizedVariable(initial_value, target_gpu=gpu, name=name)
     raise ValueError(f"unknown mode {mode!r}")
 
 
@@ -165,8 +172,8 @@ class DynamicVariable(_VariableBase):
 
     def __init__(self, dimension: int, initializer: Union[str, float, None] = None,
                  key_type=torch.int64, init_capacity: int = 1 << 20, mode: Optional[str] = None,
-                 seed: int = 0):
-        super().__init__()
+                 seed: int = 0, name: Optional[str] = None):
+        super().__init__(name)
         self.dimension = int(dimension)
         self.key_type = key_type
         self.target_gpu = -1
@@ -448,6 +455,15 @@ class OptimizerWrapper:
                 for ro, rows, keys, w, g, comb in pend:
                     self._step_static(var, ro, rows, w, g, comb)
 
+    def _ensure_dynamic(self, var: "DynamicVariable"):
+        """the variable's fused optimizer (and its state table) for this wrapper's optimizer"""
+        if var._opt is None or var._opt.p.optimizer != self.code:
+            hp = self.hp
+            var._opt = DynamicTableOptimizer(
+                var._det, self.code, hp["lr"], hp["beta1"], hp["beta2"], hp["epsilon"],
+                hp["momentum"], hp["rmsprop_beta"], hp["ftrl_lambda1"], hp["ftrl_lambda2"],
+                hp["ftrl_beta"], hp["scaler"])
+
     # static variable: the path's sort + segmented reduce + optimizer on the local shard
     def _step_static(self, var: DistributedVariable, ro, rows, w, g, comb):
         if self.name in ("rmsprop", "ftrl"):
@@ -507,12 +523,157 @@ class OptimizerWrapper:
                                         ptr(urow), ptr(ukey), ptr(wg), stream_ptr()))
         uniq = ukey[:nu.value].to(keys.dtype)
         sums = wg[:nu.value]
-        if var._opt is None or var._opt.p.optimizer != self.code:
-            hp = self.hp
-            var._opt = DynamicTableOptimizer(
-                var._det, self.code, hp["lr"], hp["beta1"], hp["beta2"], hp["epsilon"],
-                hp["momentum"], hp["rmsprop_beta"], hp["ftrl_lambda1"], hp["ftrl_lambda2"],
-                hp["ftrl_beta"], hp["scaler"])
+        self._ensure_dynamic(var)
         var._opt.set_learning_rate(self.hp["lr"])
         ev = torch.arange(0, (uniq.numel() + 1) * D, D, dtype=torch.int32, device=kg.device)
         var._opt.update(uniq.contiguous(), ev, sums.view(-1))
+
+
+# ---- dump / load (R/sparse_operation_kit/sparse_operation_kit/dump_load.py; byte layout in
+#      sok_format.py): per variable `<name>-key`, `<name>-weight` and, when the optimizer holds
+#      state for it, `<name>-<Optimizer>-<slot>`; plus one `meta_info`.  GPU 0 writes. -------------
+from . import sok_format as _fmt  # noqa: E402
+
+# slot names follow the TF optimizers the reference wraps (optimizer.get_slot_names())
+_SLOTS = {"sgd": [], "adam": ["m", "v"], "adagrad": ["accumulator"], "momentum": ["momentum"],
+          "nesterov": ["momentum"], "rmsprop": ["rms"], "ftrl": ["accumulator", "linear"]}
+# get_sok_optimizer_name (dump_load.py:126-143) looks for one of these in the class name
+_OPT_FILE_NAME = {"sgd": "SGD", "adam": "Adam", "adagrad": "Adagrad", "ftrl": "Ftrl",
+                  "momentum": "SGD", "nesterov": "SGD", "rmsprop": "RMSprop"}
+
+
+def filter_variables(variables):
+    """(sok variables, the others) -- sok.filter_variables (sparse_operation_kit/__init__.py)"""
+    a = [v for v in variables if isinstance(v, _VariableBase)]
+    return a, [v for v in variables if not isinstance(v, _VariableBase)]
+
+
+def _gather_rounds(keys: torch.Tensor, mats: List[torch.Tensor], shared: bool):
+    """the reference's write order (save_table_to_filesystem_*): rows go out in rounds of at most
+    64 MiB; with several GPUs a round holds that slice of every rank, rank after rank"""
+    n = keys.numel()
+    if not shared or _WORLD == 1:
+        return keys, mats
+    D = mats[0].shape[1] if mats else 1
+    total = torch.tensor([n], dtype=torch.int64, device=keys.device)
+    sizes = _all_gather_cat(total)
+    rounds, per = _fmt.rows_per_round(int(sizes.max()), D, 4)
+    ks, ms = [], [[] for _ in mats]
+    for r in range(rounds):
+        a, b = min(r * per, n), min((r + 1) * per, n)
+        ks.append(_all_gather_cat(keys[a:b]))
+        for j, m in enumerate(mats):
+            ms[j].append(_all_gather_cat(m[a:b].reshape(-1)).view(-1, m.shape[1]))
+    return torch.cat(ks), [torch.cat(x) for x in ms]
+
+
+def _var_arrays(var, optimizer):
+    """(keys int64 [n], weight [n, D], [state matrices in slot order]) of this rank"""
+    D = var.dimension
+    slots = _SLOTS[optimizer.name] if optimizer is not None else []
+    if isinstance(var, DynamicVariable):
+        k, w = var._det.export(0)
+        order = torch.argsort(k)
+        k, w = k[order].to(torch.int64), w[order]
+        states = []
+        if slots and var._opt is not None and var._opt.states is not None:
+            sk, sv = var._opt.states.export(0)
+            sv = sv[torch.argsort(sk)]
+            if sv.shape[0] == k.numel():
+                states = [sv[:, j * D:(j + 1) * D].contiguous() for j in range(len(slots))]
+        return k, w, states
+    n = var.weight.shape[0]
+    if var.target_gpu >= 0:
+        k = torch.arange(n, dtype=torch.int64, device=var.weight.device)
+    else:
+        k = torch.arange(n, dtype=torch.int64, device=var.weight.device) * _WORLD + _RANK
+    states = [t for t in var._states[:len(slots)]] if len(var._states) >= len(slots) else []
+    return k, var.weight, states
+
+
+def dump(path: str, dump_vars, optimizer: Optional["OptimizerWrapper"] = None):
+    """sok.dump(path, sok_vars, optimizer): the reference's directory layout and byte format"""
+    if not isinstance(dump_vars, (list, tuple)):
+        dump_vars = [dump_vars]
+    os.makedirs(path, exist_ok=True)
+    infos = []
+    opt_name = _OPT_FILE_NAME[optimizer.name] if optimizer is not None else ""
+    slots = _SLOTS[optimizer.name] if optimizer is not None else []
+    for var in dump_vars:
+        k, w, states = _var_arrays(var, optimizer)
+        shared = var.target_gpu < 0
+        writer = 0 if shared else var.target_gpu
+        if shared:
+            k, mats = _gather_rounds(k, [w] + states, True)
+            w, states = mats[0], mats[1:]
+        if isinstance(var, DynamicVariable) and _RANK == writer and k.numel() == 0:
+            raise Exception(f"dynamic table don't have value in it , table_name: {var.name}")
+        if _RANK == writer:
+            fname = os.path.join(path, _fmt.file_table_name(var.name))
+            kn = k.cpu().numpy().astype(np.int64 if shared or isinstance(var, DynamicVariable)
+                                        else np.uint64)
+            _fmt.write_array_file(fname + "-key", var.name, _fmt.FILE_KEY, "", kn)
+            _fmt.write_array_file(fname + "-weight", var.name, _fmt.FILE_EMB, "",
+                                  w.detach().cpu().numpy().astype(np.float32))
+            for slot, st in zip(slots, states):
+                _fmt.write_array_file(f"{fname}-{opt_name}-{slot}", var.name, _fmt.FILE_OPT_STATE,
+                                      slot, st.detach().cpu().numpy().astype(np.float32))
+        infos.append(_fmt.VarInfo(var.name, opt_name, _fmt.DTYPE_INDEX[np.dtype(np.int64)],
+                                  _fmt.DTYPE_INDEX[np.dtype(np.float32)], int(k.numel()),
+                                  var.dimension))
+    if _RANK == 0:
+        _fmt.save_meta_file(path, infos)
+    if _WORLD > 1:
+        dist.barrier()
+
+
+def load(path: str, load_vars, optimizer: Optional["OptimizerWrapper"] = None):
+    """sok.load(path, sok_vars, optimizer): every rank reads the files and keeps its own keys"""
+    if not isinstance(load_vars, (list, tuple)):
+        load_vars = [load_vars]
+    meta = _fmt.load_meta_file(path)
+    opt_name = _OPT_FILE_NAME[optimizer.name] if optimizer is not None else ""
+    slots = _SLOTS[optimizer.name] if optimizer is not None else []
+    for var in load_vars:
+        if var.name not in meta:
+            raise Exception(f"table {var.name} is not in the meta_info of {path}")
+        fname = os.path.join(path, _fmt.file_table_name(var.name))
+        state_paths = [f"{fname}-{opt_name}-{slot}" for slot in slots]
+        state_paths = [p for p in state_paths if os.path.exists(p)] if slots else []
+        ok, msg, n, ev = _fmt.check_weight_files(fname + "-key", fname + "-weight", state_paths)
+        if not ok:
+            raise Exception(msg)
+        if ev != var.dimension:
+            raise Exception(f"{var.name}: file vectors have {ev} elements, the variable {var.dimension}")
+        keys = _fmt.read_array_file(fname + "-key").astype(np.int64)
+        w = _fmt.read_array_file(fname + "-weight").reshape(n, ev).astype(np.float32)
+        states = [_fmt.read_array_file(p).reshape(n, ev).astype(np.float32) for p in state_paths]
+        if var.target_gpu >= 0:
+            mine = np.full(n, _RANK == var.target_gpu)
+        else:
+            mine = keys % _WORLD == _RANK
+        keys, w, states = keys[mine], w[mine], [x[mine] for x in states]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        kt = torch.from_numpy(keys).to(dev)
+        wt = torch.from_numpy(w).to(dev)
+        if isinstance(var, DynamicVariable):
+            if kt.numel():
+                assign(var, kt.to(var.key_type), wt)
+            if states and len(states) == len(slots) and kt.numel():
+                optimizer._ensure_dynamic(var)
+                st = var._opt.states
+                sk = kt.to(var.key_type)
+                st.lookup(sk)
+                st.scatter_update(sk, torch.from_numpy(np.concatenate(states, axis=1)).to(dev))
+        else:
+            rows = var.key_map(kt)
+            if rows.numel() and int(rows.max()) >= var.weight.shape[0]:
+                raise Exception(f"{var.name}: the file holds more rows than the variable")
+            var.weight[rows] = wt
+            if states and len(states) == len(slots):
+                while len(var._states) < len(slots):
+                    var._states.append(torch.zeros_like(var.weight))
+                for j, x in enumerate(states):
+                    var._states[j][rows] = torch.from_numpy(x).to(dev)
+    if _WORLD > 1:
+        dist.barrier()

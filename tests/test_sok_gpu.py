@@ -169,6 +169,22 @@ def _worker(rank, world, port, ret):
             assert torch.allclose(out, ids.row_lengths.float().unsqueeze(1).expand(-1, 8))
             seen |= set(vals[vals % world == rank].tolist())
             assert dyn.size == len(seen)              # only the keys this rank owns live here
+        # dump from both ranks (GPU 0 writes), load into fresh variables on both ranks
+        import tempfile
+        from hugectr_amd import sok_format as fmt
+        d = os.path.join(tempfile.gettempdir(), f"sok_dump_{port}")
+        var.name, loc.name, dyn.name = "dist_var", "loc_var", "dyn_var"
+        sok.dump(d, [var, loc, dyn])
+        keys = fmt.read_array_file(os.path.join(d, "dist_var-key"))
+        # one round: rank 0's rows (keys 0, 2, 4 ...) then rank 1's (1, 3, 5 ...)
+        assert keys.tolist() == list(range(0, 37, 2)) + list(range(1, 37, 2))
+        assert fmt.read_array_file(os.path.join(d, "loc_var-key")).dtype == np.uint64
+        var2 = sok.Variable(np.zeros((37, 8), np.float32), name="dist_var")
+        loc2 = sok.Variable(np.zeros((37, 8), np.float32), mode="localized:1", name="loc_var")
+        dyn2 = sok.DynamicVariable(8, initializer="zeros", name="dyn_var")
+        sok.load(d, [var2, loc2, dyn2])
+        assert torch.equal(var2.weight, var.weight) and torch.equal(loc2.weight, loc.weight)
+        assert dyn2.size == dyn.size
         ret[rank] = "ok"
     except Exception as e:  # surface the failure in the parent
         import traceback
@@ -191,3 +207,61 @@ def test_sok_two_ranks_on_one_gpu_gloo():
         if ret.get(r) != "ok":
             print(f"--- rank {r} ---\n{ret.get(r)}")
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def test_dump_load_roundtrip_in_the_reference_layout(tmp_path):
+    """sok.dump / sok.load: files in the reference's layout (byte format pinned on the CPU in
+    tests/test_sok_format_cpu.py); weights, keys and optimizer state survive the round trip"""
+    import torch
+    from hugectr_amd import sok, sok_format as fmt
+    sok.init()
+    rng = np.random.default_rng(3)
+    D = 8
+    tab = rng.standard_normal((50, D)).astype(np.float32)
+    var = sok.Variable(tab, name="emb/user:0")
+    dyn = sok.DynamicVariable(D, initializer="0.5", name="dyn_table")
+    opt = sok.OptimizerWrapper("adam", lr=0.05)
+    for step in range(2):
+        lens = rng.integers(1, 4, size=16)
+        vals = rng.integers(0, 50, size=int(lens.sum()))
+        ids = sok.Ragged(torch.from_numpy(vals).cuda(), torch.from_numpy(lens).cuda())
+        # (static and dynamic variables go through separate lookups, as in the reference)
+        outs = [sok.lookup_sparse(var, ids, combiners="sum"),
+                sok.lookup_sparse(dyn, ids, combiners="mean")]
+        sum((o * o).sum() for o in outs).backward()
+        opt.step([var, dyn])
+    sok.dump(str(tmp_path), [var, dyn], opt)
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["meta_info", "emb_user_0-key", "emb_user_0-weight", "emb_user_0-Adam-m",
+                            "emb_user_0-Adam-v", "dyn_table-key", "dyn_table-weight",
+                            "dyn_table-Adam-m", "dyn_table-Adam-v"])
+    meta = fmt.load_meta_file(str(tmp_path))
+    assert meta["emb/user:0"].emb_num == 50 and meta["emb/user:0"].opt_name == "Adam"
+    assert meta["dyn_table"].emb_num == dyn.size and meta["dyn_table"].emb_length == D
+    assert fmt.read_file_head(str(tmp_path / "dyn_table-Adam-v")) == ("dyn_table", 2, "v", 5)
+    keys = fmt.read_array_file(str(tmp_path / "dyn_table-key"))
+    assert (np.diff(keys) > 0).all()                       # sorted by key, as the reference writes
+    var2 = sok.Variable(np.zeros_like(tab), name="emb/user:0")
+    dyn2 = sok.DynamicVariable(D, initializer="zeros", name="dyn_table")
+    opt2 = sok.OptimizerWrapper("adam", lr=0.05)
+    sok.load(str(tmp_path), [var2, dyn2], opt2)
+    assert torch.equal(var2.weight, var.weight)
+    assert all(torch.equal(a, b) for a, b in zip(var2._states, var._states)) and len(var2._states) == 2
+    k1, v1 = sok.export(dyn)
+    k2, v2 = sok.export(dyn2)
+    o1, o2 = torch.argsort(k1), torch.argsort(k2)
+    assert torch.equal(k1[o1], k2[o2]) and torch.equal(v1[o1], v2[o2])
+    s1k, s1v = dyn._opt.states.export(0)
+    s2k, s2v = dyn2._opt.states.export(0)
+    assert torch.equal(s1v[torch.argsort(s1k)], s2v[torch.argsort(s2k)])
+    # training continues identically from the restored state
+    lens = rng.integers(1, 4, size=16)
+    vals = rng.integers(0, 50, size=int(lens.sum()))
+    ids = sok.Ragged(torch.from_numpy(vals).cuda(), torch.from_numpy(lens).cuda())
+    opt2.times = opt.times
+    for vs, o in (((var, dyn), opt), ((var2, dyn2), opt2)):
+        outs = [sok.lookup_sparse(vs[0], ids, combiners="sum"),
+                sok.lookup_sparse(vs[1], ids, combiners="mean")]
+        sum((x * x).sum() for x in outs).backward()
+        o.step(list(vs))
+    assert torch.allclose(var2.weight, var.weight, rtol=1e-6, atol=1e-7)
