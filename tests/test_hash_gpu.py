@@ -1,5 +1,6 @@
 """GPU parity: hash / index stage, bit-exact against the sequential CPU restatement."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -78,6 +79,22 @@ def test_murmur_hash_bit_exact(oracle, key_bytes):
     _lib.check(_lib.lib.hctr_hash_keys(_lib.ptr(kt), ktype, keys.size, _lib.ptr(out), _lib.stream_ptr()))
     got = out.cpu().numpy().view(np.uint32)
     assert (got == oracle.hash_keys(keys, key_bytes)).all()
+    # ... and the reference's own functor, compiled from its header (oracle/_ref, built where the
+    # reference is mounted; it travels with the repository snapshot)
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref",
+                       "libref_hash.so")
+    if os.path.exists(ref):
+        import ctypes
+        L = ctypes.CDLL(ref)
+        want = np.empty(keys.size, np.uint32)
+        if key_bytes == 4:
+            k = keys.astype(np.uint32)
+            L.ref_murmur3_u32_many(ctypes.c_void_p(k.ctypes.data), ctypes.c_size_t(k.size),
+                                   ctypes.c_void_p(want.ctypes.data))
+        else:
+            L.ref_murmur3_i64_many(ctypes.c_void_p(keys.ctypes.data), ctypes.c_size_t(keys.size),
+                                   ctypes.c_void_p(want.ctypes.data))
+        assert (got == want).all()
     # published vector: 4 zero bytes, seed 0
     if key_bytes == 4:
         z = torch.zeros(1, dtype=torch.int32, device="cuda")
