@@ -142,6 +142,23 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// keys that arrived through the key-route all-to-all, already in the owner's bucket order
+// [source peer][local lookup][b_local]: key -> row of the rank's flat table, in place
+__global__ void __launch_bounds__(kBlock)
+    ebc_routed_keys_to_indices_kernel(size_t nb, size_t bpg, int n_local,
+                                      const int* __restrict__ d3, const long long* __restrict__ rs,
+                                      const long long* __restrict__ out_range,
+                                      uint64_t* __restrict__ keys) {
+  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < nb;
+       ob += (size_t)gridDim.x * kBlock) {
+    const int ll = (int)((ob / bpg) % (size_t)n_local);
+    const LookupDesc d = load_desc(d3, rs, ll);
+    if (d.row_start < 0) continue;  // dynamic table: the key itself is the handle
+    for (long long q = out_range[ob]; q < out_range[ob + 1]; q++)
+      keys[q] = (uint64_t)(d.row_start + (long long)keys[q] / d.num_shards);
+  }
+}
+
 template <typename K>
 __global__ void __launch_bounds__(kBlock)
     keys_to_indices_kernel(size_t n, const K* __restrict__ keys, long long table_start,
@@ -429,6 +446,21 @@ int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const in
   if (rc == HCTR_OK && d_nnz)
     HCTR_HIP(hipMemcpyAsync(d_nnz, d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
   return rc;
+}
+
+int hctr_ebc_routed_keys_to_indices(size_t batch_per_gpu, int world, int num_local_lookups,
+                                    const int32_t* lookup_desc, const int64_t* row_start,
+                                    const int64_t* out_bucket_range, uint64_t* keys_inout,
+                                    hctr_stream_t stream) {
+  HCTR_REQUIRE(world >= 1 && num_local_lookups >= 0, "arguments");
+  const size_t nb = (size_t)world * (size_t)num_local_lookups * batch_per_gpu;
+  if (nb == 0) return HCTR_OK;
+  HCTR_REQUIRE(lookup_desc && row_start && out_bucket_range && keys_inout, "null pointer");
+  hipLaunchKernelGGL(ebc_routed_keys_to_indices_kernel, dim3(grid_for(nb, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), nb, batch_per_gpu, num_local_lookups, lookup_desc,
+                     (const long long*)row_start, (const long long*)out_bucket_range, keys_inout);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
 }
 
 int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,

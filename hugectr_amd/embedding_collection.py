@@ -104,10 +104,12 @@ class EmbeddingCollection:
                  initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
                  key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None,
                  ftrl=(0.0, 0.0, 0.0), storage: Optional[str] = None, initializer: str = "",
-                 init_capacity: int = 1 << 20, **opt_kw):
+                 init_capacity: int = 1 << 20, key_route: str = "allgather", **opt_kw):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert key_route in ("allgather", "a2a")
+        self.key_route = key_route
         self._setup(config, global_batch, lr, optimizer, scaler, epsilon, initial_accu_value,
                     out_dtype, batch_major, key_dtype, max_hotness, seed, ftrl, storage,
                     initializer, init_capacity, **opt_kw)
@@ -117,6 +119,7 @@ class EmbeddingCollection:
         """single-process construction of one rank's shard (tests / tools)"""
         self = cls.__new__(cls)
         self.group, self.world, self.rank = None, world, rank
+        self.key_route = "allgather"
         self._setup(*a, **kw)
         return self
 
@@ -216,6 +219,15 @@ class EmbeddingCollection:
         for r in range(self.world):
             n_local_of.append([l for l in range(self.L) if r in self.owners[self.lookup_table[l]]])
         self.n_local_of = [len(x) for x in n_local_of]
+        # key-route all-to-all: what every destination GPU resolves (its lookups, its shard ids)
+        self._dest_desc = []
+        for r in range(self.world):
+            d = []
+            for l in n_local_of[r]:
+                t = self.lookup_table[l]
+                d += [l, len(self.owners[t]), self.owners[t].index(r)]
+            self._dest_desc.append(torch.tensor(d or [0, 1, 0], dtype=torch.int32, device=self.dev))
+        self._neg = torch.full((max(self.L, 1),), -1, dtype=torch.int64, device=self.dev)
         self.max_shards = max(len(o) for o in self.owners)
         blk_base, acc = [], 0
         for r in range(self.world):
@@ -269,9 +281,14 @@ class EmbeddingCollection:
         dist.all_gather_into_tensor(all_lens, lens.to(cdev), group=self.group)
         all_lens = all_lens.to(self.dev).view(self.world, self.L, self.bpg)
         n_all = all_lens.sum(dim=(1, 2)).tolist()  # host sync (counts)
-        parts = [torch.empty(n, dtype=keys.dtype, device=cdev) for n in n_all]
-        dist.all_gather(parts, keys.contiguous().to(cdev), group=self.group)
-        parts = [q.to(self.dev) for q in parts]
+        # ranks hold different numbers of keys: gather buffers padded to the longest share
+        m = max(max(n_all), 1)
+        mine = torch.zeros(m, dtype=keys.dtype, device=cdev)
+        mine[:keys.numel()] = keys.to(cdev)
+        gathered = torch.empty(self.world * m, dtype=keys.dtype, device=cdev)
+        dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        gathered = gathered.to(self.dev)
+        parts = [gathered[r * m:r * m + n_all[r]] for r in range(self.world)]
         # per-rank offsets of each lookup's key segment
         seg = all_lens.sum(dim=2)                       # [world, L] keys per (rank, lookup)
         seg_off = torch.zeros((self.world, self.L + 1), dtype=torch.int64, device=self.dev)
@@ -314,6 +331,70 @@ class EmbeddingCollection:
                                     ptr(self.indices), ptr(self.table), ptr(send),
                                     _DT[self.out_dtype], stream_ptr()))
         return send
+
+    # -- the reference's key route for data-parallel input: two all-to-alls -------------------------
+    def route_send(self, keys: torch.Tensor, bucket_range: torch.Tensor):
+        """this rank's share of the batch (feature-major, bucket = lookup * batch/world + b_local)
+        -> per destination GPU: (lengths of its buckets [n_local_of[p] * batch/world], its keys)"""
+        kt = _lib.KEY_I64 if keys.dtype == torch.int64 else _lib.KEY_U32
+        br = bucket_range
+        # total keys of my buckets: the Average divisor on the receiving side (network_forward)
+        self.counts.copy_((br[1:] - br[:-1]).to(torch.int64))
+        if getattr(self, "_ws_local", None) is None:
+            self._ws_local = torch.empty(lib.hctr_ebc_route_workspace_bytes(self.bpg, max(self.L, 1))
+                                         + 64, dtype=torch.uint8, device=self.dev)
+        lens, out = [], []
+        for p in range(self.world):
+            nl = self.n_local_of[p]
+            rng = torch.zeros(nl * self.bpg + 1, dtype=torch.int64, device=self.dev)
+            ks = torch.empty(max(keys.numel(), 1), dtype=torch.int64, device=self.dev)
+            if nl:
+                check(lib.hctr_ebc_route_keys(self.bpg, 1, nl, ptr(self._dest_desc[p]), ptr(self._neg),
+                                              ptr(keys), ptr(br), kt, ptr(rng), ptr(ks), None,
+                                              ptr(self._ws_local), stream_ptr()))
+            lens.append(rng[1:] - rng[:-1])
+            out.append((ks, rng))
+        ends = torch.stack([r[-1] for _, r in out]).tolist()  # host sync (key counts, as the reference)
+        return lens, [ks[:n] for (ks, _), n in zip(out, ends)]
+
+    def route_recv(self, lens_all: torch.Tensor, keys_all: torch.Tensor):
+        """lengths / keys received from every source GPU, source-major = my bucket order
+        [source][local lookup][b_local] -> the routed CSR the pooling and the update work on"""
+        n = int(keys_all.numel())
+        self._nnz_host = n
+        self.out_range[0] = 0
+        torch.cumsum(lens_all, 0, out=self.out_range[1:self.nb + 1])
+        self.indices[:n] = keys_all
+        self.d_nnz.fill_(n)
+        check(lib.hctr_ebc_routed_keys_to_indices(self.bpg, self.world, self.n_local,
+                                                  ptr(self.d_desc), ptr(self.d_row_start),
+                                                  ptr(self.out_range), ptr(self.indices),
+                                                  stream_ptr()))
+
+    def pool_routed(self) -> torch.Tensor:
+        send = torch.empty((max(self.nb, 1), self.ev), dtype=self.out_dtype, device=self.dev)
+        if self.n_local == 0:
+            return send[:0]
+        if self.dynamic:
+            return self._dynamic_pool(send)
+        check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
+                                    ptr(self.indices), ptr(self.table), ptr(send),
+                                    _DT[self.out_dtype], stream_ptr()))
+        return send
+
+    def _forward_a2a_route(self, keys: torch.Tensor, bucket_range: torch.Tensor) -> torch.Tensor:
+        from .parallel import all_to_all_single
+        lens, ks = self.route_send(keys, bucket_range)
+        send_l = torch.cat(lens)
+        recv_l = torch.empty(self.world * self.n_local * self.bpg, dtype=torch.int64, device=self.dev)
+        all_to_all_single(recv_l, send_l, [self.n_local * self.bpg] * self.world,
+                          [n * self.bpg for n in self.n_local_of], group=self.group)
+        recv_counts = recv_l.view(self.world, -1).sum(1).tolist()  # host sync (counts)
+        recv_k = torch.empty(sum(recv_counts), dtype=torch.int64, device=self.dev)
+        all_to_all_single(recv_k, torch.cat(ks), recv_counts, [int(k.numel()) for k in ks],
+                          group=self.group)
+        self.route_recv(recv_l, recv_k)
+        return self.pool_routed()
 
     def _dynamic_pool(self, send: torch.Tensor) -> torch.Tensor:
         """self.indices holds the routed raw keys in [peer][local lookup][b_local] bucket order:
@@ -389,8 +470,11 @@ class EmbeddingCollection:
 
     # -- whole passes --------------------------------------------------------------------------------
     def forward(self, keys: torch.Tensor, bucket_range: torch.Tensor) -> torch.Tensor:
-        gk, gbr = self._allgather_keys(keys, bucket_range)
-        send = self.route_and_pool(gk, gbr)
+        if self.key_route == "a2a" and self.world > 1 and dist.is_initialized():
+            send = self._forward_a2a_route(keys, bucket_range)
+        else:
+            gk, gbr = self._allgather_keys(keys, bucket_range)
+            send = self.route_and_pool(gk, gbr)
         recv = self._a2a(send, self.send_counts, self.recv_counts)
         return self.network_forward(recv)
 

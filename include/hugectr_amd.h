@@ -219,6 +219,17 @@ int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t t
  *                 marks a dynamic table: the key itself is written to out_indices
  * Output buckets are ordered [peer][local lookup][b_local] (= the all-to-all send layout):
  *   out_bucket_range int64 [world * num_local_lookups * batch/world + 1], out_indices [<= nnz]. */
+/* The reference's own key route (DataDistributor, sparse_data_distribution_op_impl.cu:215-395) for
+ * data-parallel input is two all-to-alls: bucket lengths, then keys.  Sender: one
+ * hctr_ebc_route_keys call per destination on the LOCAL batch (batch = batch/world, world = 1,
+ * the destination's lookup_desc, row_start < 0) yields that destination's lengths and keys.
+ * Receiver: the received keys are already in its bucket order [source][local lookup][b_local];
+ * out_bucket_range = prefix sum of the received lengths, and this call turns the keys into rows of
+ * its flat table in place (keys_to_indices.cu:31-42; lookups with row_start < 0 keep the key). */
+int hctr_ebc_routed_keys_to_indices(size_t batch_per_gpu, int world, int num_local_lookups,
+                                    const int32_t* lookup_desc, const int64_t* row_start,
+                                    const int64_t* out_bucket_range, uint64_t* keys_inout,
+                                    hctr_stream_t stream);
 size_t hctr_ebc_route_workspace_bytes(size_t batch, int num_local_lookups);
 int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const int32_t* lookup_desc,
                         const int64_t* row_start, const void* keys, const void* bucket_range,

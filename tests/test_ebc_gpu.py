@@ -2,6 +2,7 @@
 network forward / backward -> static-table optimizer) vs the CPU restatement of the reference's
 EmbeddingReferenceCPU (R/test/utest/embedding_collection/reference_embedding.hpp:32-237)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -121,3 +122,127 @@ def test_ebc_forward_backward_update(oracle, world, shard, batch_major, opt_name
                 ks = np.arange(sid, vocabs[t], len(owners))
                 assert_close(e.table[s0:s0 + ks.size].cpu().numpy(), dense[row_start[t] + ks],
                              1e-5, 1e-6, f"table {t} shard {sid} it{it}")
+
+
+@pytest.mark.parametrize("world,shard", [(2, "table"), (4, "row"), (2, "mixed")])
+@pytest.mark.parametrize("storage", ["static", "dynamic"])
+def test_key_route_all_to_all_equals_the_gathered_route(world, shard, storage):
+    """the reference's DataDistributor route for data-parallel input (bucket lengths a2a, keys a2a,
+    sparse_data_distribution_op_impl.cu:215-395) must hand every owner exactly the CSR it finds by
+    filtering the gathered global batch: same bucket ranges, same row indices, same pooled vectors"""
+    import torch
+    import hugectr_amd as ha
+    rng = np.random.default_rng(world)
+    B, ev = 32, 16
+    vocabs = [50, 7, 300, 12]
+    lookup_table = [0, 1, 2, 3, 2]
+    T, L = len(vocabs), len(lookup_table)
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l in range(L):
+        cfg.embedding_lookup(tcfg[lookup_table[l]], f"in{l}", f"out{l}", "sum" if l % 2 else "mean")
+    if shard == "table":
+        sm = [[1 if t % world == g else 0 for t in range(T)] for g in range(world)]
+    elif shard == "row":
+        sm = [[1] * T for _ in range(world)]
+    else:
+        sm = [[1 if g == 0 else 0, 1, 1, 1 if g == world - 1 else 0] for g in range(world)]
+    cfg.shard(sm)
+    kw = dict(max_hotness=4, storage=storage, initializer="0.5", init_capacity=16)
+    a = [ha.EmbeddingCollection.for_rank(r, world, cfg, B, **kw) for r in range(world)]  # a2a route
+    g = [ha.EmbeddingCollection.for_rank(r, world, cfg, B, **kw) for r in range(world)]  # gathered
+    if storage == "static":
+        for x, y in zip(a, g):
+            x.table.copy_(y.table)
+    bpg = B // world
+    for it in range(2):
+        keys, br = _make_inputs(rng, B, vocabs, lookup_table, 4)
+        gk, gbr = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        want = [e.route_and_pool(gk, gbr) for e in g]
+        # every rank's own share, feature-major: bucket = lookup * bpg + b_local
+        sends = []
+        for r in range(world):
+            lens, ks = [], []
+            for l in range(L):
+                for b in range(r * bpg, (r + 1) * bpg):
+                    q0, q1 = br[l * B + b], br[l * B + b + 1]
+                    lens.append(q1 - q0)
+                    ks.append(keys[q0:q1])
+            lbr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            lk = np.concatenate(ks).astype(np.int64) if ks else np.zeros(0, np.int64)
+            sends.append(a[r].route_send(torch.from_numpy(lk).cuda(), torch.from_numpy(lbr).cuda()))
+        for p in range(world):  # the two all-to-alls
+            lens_all = torch.cat([sends[s][0][p] for s in range(world)])
+            keys_all = torch.cat([sends[s][1][p] for s in range(world)])
+            a[p].route_recv(lens_all, keys_all)
+            got = a[p].pool_routed()
+            nb, n = a[p].nb, g[p]._nnz_host if storage == "dynamic" else int(g[p].out_range[g[p].nb])
+            assert torch.equal(a[p].out_range[:nb + 1], g[p].out_range[:nb + 1]), f"ranges rank{p}"
+            assert a[p]._nnz_host == n
+            assert torch.equal(a[p].indices[:n], g[p].indices[:n]), f"indices rank{p}"
+            assert torch.equal(a[p].counts, g[p].counts), f"bucket counts rank{p}"
+            assert torch.equal(got, want[p]), f"pooled vectors rank{p}"
+
+
+def _route_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import hugectr_amd as ha
+        rng = np.random.default_rng(5)                      # same stream on both ranks
+        B, ev = 64, 16
+        vocabs = [50, 7, 300, 12]
+        lookup_table = [0, 1, 2, 3, 2]
+        L = len(lookup_table)
+        tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
+        cfg = ha.EmbeddingCollectionConfig()
+        for l in range(L):
+            cfg.embedding_lookup(tcfg[lookup_table[l]], f"in{l}", f"out{l}", "sum" if l % 2 else "mean")
+        cfg.shard([[1, 1, 1, 0], [0, 1, 1, 1]])             # tables 1, 2 row-sharded over both
+        ea = ha.EmbeddingCollection(cfg, B, lr=0.1, max_hotness=4, key_route="a2a", seed=3)
+        eg = ha.EmbeddingCollection(cfg, B, lr=0.1, max_hotness=4, key_route="allgather", seed=3)
+        assert torch.equal(ea.table, eg.table)
+        bpg = B // world
+        for it in range(3):
+            keys, br = _make_inputs(rng, B, vocabs, lookup_table, 4)
+            lens, ks = [], []
+            for l in range(L):
+                for b in range(rank * bpg, (rank + 1) * bpg):
+                    q0, q1 = br[l * B + b], br[l * B + b + 1]
+                    lens.append(q1 - q0)
+                    ks.append(keys[q0:q1])
+            lbr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+            lk = torch.from_numpy(np.concatenate(ks).astype(np.int64)).cuda()
+            oa, og = ea.forward(lk, lbr), eg.forward(lk, lbr)
+            assert torch.equal(oa, og), f"forward it{it}"
+            grad = torch.from_numpy(rng.standard_normal((world,) + tuple(oa.shape)).astype(np.float32))[rank].cuda()
+            ea.backward_and_update(grad)
+            eg.backward_and_update(grad)
+            assert torch.equal(ea.table, eg.table), f"tables it{it}"
+        ret[rank] = "ok"
+    except Exception as ex:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_route_all_to_all_two_ranks_on_one_gpu():
+    """EmbeddingCollection.forward / backward_and_update with the key-route all-to-all on 2
+    processes (gloo, both on this GPU): identical outputs and tables to the all-gather route"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_route_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for r in range(2):
+        if ret.get(r) != "ok":
+            print(f"--- rank {r} ---\n{ret.get(r)}")
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
