@@ -128,6 +128,12 @@ class DistributedExchange:
             return partial.view(self.bpg, self.slot_num, self.vec)
         out = torch.empty((self.bpg, self.slot_num, self.vec), dtype=partial.dtype,
                           device=partial.device)
+        if _staged(partial):  # (gloo reduces in fp32 on the host: the 2-ranks-on-one-GPU tests)
+            o = torch.empty(out.shape, dtype=torch.float32)
+            dist.reduce_scatter_tensor(o, partial.float().cpu().contiguous(), op=dist.ReduceOp.SUM,
+                                       group=self.group)
+            out.copy_(o)
+            return out
         dist.reduce_scatter_tensor(out, partial.contiguous(), op=dist.ReduceOp.SUM, group=self.group)
         return out
 
@@ -135,5 +141,10 @@ class DistributedExchange:
         if self.world == 1:
             return grad.view(self.batch, self.slot_num, self.vec)
         out = torch.empty((self.batch, self.slot_num, self.vec), dtype=grad.dtype, device=grad.device)
+        if _staged(grad):
+            o = torch.empty(out.shape, dtype=grad.dtype)
+            dist.all_gather_into_tensor(o, grad.contiguous().cpu(), group=self.group)
+            out.copy_(o)
+            return out
         dist.all_gather_into_tensor(out, grad.contiguous(), group=self.group)
         return out

@@ -480,3 +480,78 @@ def test_training_callbacks_and_early_stop(tmp_path):
     assert log == ["start", ("eval_start", 9), ("eval_end", 9, ["AUC", "AverageLoss"]),
                    ("eval_start", 19), ("eval_end", 19, ["AUC", "AverageLoss"]), ("end", 19)]
     assert m._iter == 20
+
+
+def _legacy_model_worker(rank, world, port, folder, kind, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hugectr_amd.hugectr as hugectr
+        solver = hugectr.CreateSolver(batchsize=256, batchsize_eval=256, lr=0.01, vvgpu=[[0, 1]],
+                                      i64_input_key=True, max_eval_batches=1)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.Parquet,
+            source=[os.path.join(folder, "train", "_file_list.txt")],
+            eval_source=os.path.join(folder, "val", "_file_list.txt"), slot_size_array=SIZES,
+            check_type=hugectr.Check_t.Non)
+        opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam,
+                                      update_type=hugectr.Update_t.Local)
+        model = hugectr.Model(solver, reader, opt)
+        model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                                data_reader_sparse_param_array=[
+                                    hugectr.DataReaderSparseParam("data1", 1, True, 26)]))
+        D, T = hugectr.DenseLayer, hugectr.Layer_t
+        localized = kind == "localized"
+        model.add(hugectr.SparseEmbedding(
+            embedding_type=(hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash if localized
+                            else hugectr.Embedding_t.DistributedSlotSparseEmbeddingHash),
+            workspace_size_per_gpu_in_mb=4, slot_size_array=SIZES if localized else [],
+            embedding_vec_size=16, combiner="sum", sparse_embedding_name="emb", bottom_name="data1",
+            optimizer=opt))
+        model.add(D(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"], num_outputs=[32, 16],
+                    act_type=hugectr.Activation_t.Relu))
+        model.add(D(layer_type=T.Interaction, bottom_names=["mlp1", "emb"], top_names=["inter"]))
+        model.add(D(layer_type=T.MLP, bottom_names=["inter"], top_names=["mlp2"], num_outputs=[64, 1],
+                    activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Non]))
+        model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+                    top_names=["loss"]))
+        model.compile()
+        model.train()
+        first = model.get_current_loss()
+        model.fit(max_iter=200, display=0, eval_interval=100, snapshot=0)
+        last = model.get_current_loss()
+        assert last < min(first, 0.6), (first, last)
+        flat = torch.cat([q.detach().flatten().float() for q in model._dense_params]).cpu()
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])
+        ret[rank] = "ok"
+    except Exception as ex:
+        import traceback
+        ret[rank] = "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["localized", "distributed"])
+def test_legacy_embedding_model_two_ranks_on_one_gpu(tmp_path, kind):
+    """hugectr.Model with a Localized / Distributed SparseEmbedding on 2 processes (gloo, this one
+    GPU): slot- / key-sharded tables, the exchange of the reference (all-to-all + reorder, or
+    reduce-scatter / all-gather), data-parallel dense tower"""
+    import hugectr_amd.hugectr as hugectr
+    import torch.multiprocessing as mp
+    _gen(tmp_path, hugectr, n_train=4096, n_eval=512)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000 + (7 if kind == "localized" else 11)
+    procs = [ctx.Process(target=_legacy_model_worker, args=(r, 2, port, str(tmp_path), kind, ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r in range(2):
+        if ret.get(r) != "ok":
+            print(f"--- rank {r} ---\n{ret.get(r)}")
+    assert ret.get(0) == "ok" and ret.get(1) == "ok"
