@@ -9,9 +9,11 @@ Mirrors `class IEmbedding` (R/HugeCTR/include/embedding.hpp:26-67) and
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -149,8 +151,81 @@ class SparseEmbeddingHash:
         return w
 
     def update_params(self):
+        if not getattr(self, "_trainable", True):  # IEmbedding::freeze (embedding.hpp:64-66)
+            self._top_grad = None
+            return
         check(lib.hctr_emb_update_params(self._h, stream_ptr()))
         self._top_grad = None
+
+    def freeze(self):
+        self._trainable = False
+
+    def unfreeze(self):
+        self._trainable = True
+
+    def is_trainable(self) -> bool:
+        return getattr(self, "_trainable", True)
+
+    # -- optimizer state files (SparseEmbeddingFunctors::dump_opt_states / load_opt_states,
+    #    R/HugeCTR/src/embeddings/opt_states_functor.cu:24-250): one file; for every state tensor of
+    #    the optimizer in turn (Adam: m, v; AdaGrad / Momentum / Nesterov: one) the raw
+    #    [max_vocabulary_size_per_gpu, D] arrays of all GPUs in rank order, in the embedding type
+    #    (fp16 when the embedding runs in fp16, float otherwise)
+    def _opt_state_count(self) -> int:
+        k = 0
+        while self.opt_state(k) is not None:
+            k += 1
+        return k
+
+    def dump_opt_states(self, write_path: str):
+        import torch.distributed as dist
+        ns = self._opt_state_count()
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        np_dt = np.float16 if self.out_dtype == torch.float16 else np.float32
+        mine = self.max_vocabulary_size_per_gpu * self.embedding_vec_size * np.dtype(np_dt).itemsize
+        sizes = [mine]
+        if world > 1:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, mine)
+        total = sum(sizes)
+        if rank == 0:
+            with open(write_path, "wb") as f:
+                f.truncate(total * ns)
+        if world > 1:
+            dist.barrier()
+        if ns:
+            mm = np.memmap(write_path, dtype=np.uint8, mode="r+")
+            for k in range(ns):
+                off = k * total + sum(sizes[:rank])
+                a = self.opt_state(k).detach().cpu().numpy().astype(np_dt)
+                mm[off:off + mine] = a.reshape(-1).view(np.uint8)
+            mm.flush()
+            del mm
+        if world > 1:
+            dist.barrier()
+
+    def load_opt_states(self, read_path: str):
+        import torch.distributed as dist
+        ns = self._opt_state_count()
+        world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        np_dt = np.float16 if self.out_dtype == torch.float16 else np.float32
+        n = self.max_vocabulary_size_per_gpu * self.embedding_vec_size
+        mine = n * np.dtype(np_dt).itemsize
+        sizes = [mine]
+        if world > 1:
+            sizes = [None] * world
+            dist.all_gather_object(sizes, mine)
+        total = sum(sizes)
+        if os.path.getsize(read_path) != total * ns:
+            raise _lib.HugeCTRAmdError(f"{read_path}: {os.path.getsize(read_path)} bytes, the "
+                                       f"optimizer states of this embedding take {total * ns}")
+        mm = np.memmap(read_path, dtype=np.uint8, mode="r")
+        for k in range(ns):
+            off = k * total + sum(sizes[:rank])
+            a = np.frombuffer(mm[off:off + mine].tobytes(), dtype=np_dt).astype(np.float32)
+            self.opt_state(k).copy_(torch.from_numpy(a).view(self.max_vocabulary_size_per_gpu,
+                                                             self.embedding_vec_size))
+        del mm
 
     def set_learning_rate(self, lr: float):
         check(lib.hctr_emb_set_learning_rate(self._h, lr))

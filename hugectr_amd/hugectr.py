@@ -762,7 +762,9 @@ class Model:
         for i, rt in enumerate(self._ebc):
             rt["train"].lr = self._lr
             rt["train"].backward_and_update(leaves[("ebc", i)].grad.contiguous())
-        if self._dense_opt is not None:
+        if self._dense_opt is not None and getattr(self, "_dense_frozen", False):
+            self._dense_opt.zero_grad(set_to_none=True)
+        elif self._dense_opt is not None:
             if self.world > 1:
                 for q in self._dense_params:
                     if q.grad is not None:
@@ -916,6 +918,8 @@ class Model:
             if localized:
                 slot.cpu().numpy().astype("<u8").tofile(os.path.join(d, "slot_id"))
             vec.cpu().numpy().astype("<f4").tofile(os.path.join(d, "emb_vector"))
+            if h._opt_state_count():  # <prefix><i>_opt_sparse_<iter>.model (model.cpp:1244-1246)
+                h.dump_opt_states(f"{prefix}{i}_opt_sparse_{iteration}.model")
         for i, rt in enumerate(self._ebc):
             d = f"{prefix}_ebc{i}_sparse_{iteration}.model"
             os.makedirs(d, exist_ok=True)
@@ -981,6 +985,28 @@ class Model:
             h.load_parameters(torch.from_numpy(keys[mine]),
                               torch.from_numpy(slot[mine]) if slot is not None else None,
                               torch.from_numpy(vec[mine]))
+
+    def load_sparse_optimizer_states(self, paths: Sequence[str]):
+        for path, (name, (se, p, h, _, _)) in zip(paths, self._emb.items()):
+            h.load_opt_states(path)
+
+    # Model::freeze_embedding / unfreeze_embedding / freeze_dense / unfreeze_dense
+    # (model_wrapper.hpp:147-156): a frozen part keeps computing, its weights stop moving
+    def freeze_embedding(self, embedding_name: Optional[str] = None):
+        for name, (se, p, h, _, _) in self._emb.items():
+            if embedding_name is None or name == embedding_name:
+                h.freeze()
+
+    def unfreeze_embedding(self, embedding_name: Optional[str] = None):
+        for name, (se, p, h, _, _) in self._emb.items():
+            if embedding_name is None or name == embedding_name:
+                h.unfreeze()
+
+    def freeze_dense(self):
+        self._dense_frozen = True
+
+    def unfreeze_dense(self):
+        self._dense_frozen = False
 
     def load_dense_weights(self, path: str):
         flat = torch.from_numpy(np.fromfile(path, dtype="<f4")).to(self.device)

@@ -555,3 +555,42 @@ def test_legacy_embedding_model_two_ranks_on_one_gpu(tmp_path, kind):
         if ret.get(r) != "ok":
             print(f"--- rank {r} ---\n{ret.get(r)}")
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+def test_freeze_and_optimizer_state_files(tmp_path):
+    """IEmbedding::freeze / Model.freeze_embedding / freeze_dense, and the sparse optimizer state
+    file (<prefix><i>_opt_sparse_<iter>.model: m then v, raw [max_vocabulary_size_per_gpu, D]
+    arrays -- opt_states_functor.cu:24-128)"""
+    import sys
+    import hugectr_amd.hugectr as hugectr
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ckpt_fixture as fx
+    m = fx.dcn(fx.gen(str(tmp_path / "d")))          # Adam, Distributed embedding, vec 4
+    m.compile()
+    m.fit(max_iter=3, display=0, eval_interval=0, snapshot=0)
+    h = list(m._emb.values())[0][2]
+    dense0 = [q.detach().clone() for q in m._dense_params]
+    table0 = h.table().clone()
+    m.freeze_embedding()
+    assert not h.is_trainable()
+    m.fit(max_iter=2, display=0, eval_interval=0, snapshot=0)
+    assert torch.equal(h.table(), table0)                               # embedding stood still
+    assert any(not torch.equal(a, b) for a, b in zip(dense0, m._dense_params))
+    m.unfreeze_embedding("sparse_embedding1")
+    m.freeze_dense()
+    dense1 = [q.detach().clone() for q in m._dense_params]
+    m.fit(max_iter=2, display=0, eval_interval=0, snapshot=0)
+    assert all(torch.equal(a, b) for a, b in zip(dense1, m._dense_params))
+    assert not torch.equal(h.table(), table0)
+    m.save_params_to_files(str(tmp_path / "ck"), 7)
+    f = tmp_path / "ck0_opt_sparse_7.model"
+    V, D = h.get_max_vocabulary_size(), 4
+    raw = np.fromfile(f, dtype="<f4")
+    assert raw.size == 2 * V * D
+    assert (raw[:V * D].reshape(V, D) == h.opt_state(0).cpu().numpy()).all()      # m first
+    assert (raw[V * D:].reshape(V, D) == h.opt_state(1).cpu().numpy()).all()      # then v
+    s0 = h.opt_state(0).clone()
+    h.opt_state(0).zero_()
+    m.load_sparse_optimizer_states([str(f)])
+    assert torch.equal(h.opt_state(0), s0)
