@@ -263,6 +263,43 @@ class Input:
         self.sparse_params: List[DataReaderSparseParam] = list(data_reader_sparse_param_array)
 
 
+class LearningRateScheduler:
+    """R/HugeCTR/include/learning_rate_scheduler.hpp:20-90: linear warm-up over warmup_steps, then
+    the base rate, then (decay_start > 0) polynomial decay over decay_steps down to end_lr"""
+
+    def __init__(self, base_lr: float, warmup_steps: int = 1, decay_start: int = 0,
+                 decay_steps: int = 1, decay_power: float = 2.0, end_lr: float = 0.0):
+        if base_lr < 0 or warmup_steps < 0 or decay_steps < 0 or decay_power < 1.0 or end_lr < 0:
+            raise RuntimeError("base_lr < 0 || warmup_steps < 0 || decay_steps < 0 || "
+                               "decay_power < 1.0 || end_lr < 0.f")
+        self.base_lr, self.warmup_steps, self.decay_start = base_lr, warmup_steps, decay_start
+        self.decay_steps, self.decay_power, self.end_lr = decay_steps, decay_power, end_lr
+        self.step, self.current_lr = 0, 0.0
+
+    def get_next(self) -> float:
+        self.step += 1
+        st = self.step
+        if st <= self.warmup_steps:
+            self.current_lr = st * self.base_lr / self.warmup_steps
+        elif self.decay_start != 0:
+            if st <= self.decay_start:
+                self.current_lr = self.base_lr
+            elif st <= self.decay_start + self.decay_steps:
+                f = ((self.decay_start + self.decay_steps - st) / float(self.decay_steps)) ** self.decay_power
+                self.current_lr = max(self.base_lr * f, self.end_lr)
+            else:
+                self.current_lr = self.end_lr
+        else:
+            self.current_lr = self.base_lr
+        return self.current_lr
+
+    def get_lr(self) -> float:
+        return self.current_lr
+
+    def get_step(self) -> int:
+        return self.step
+
+
 class AllReduceAlgo(enum.Enum):  # R/HugeCTR/include/pybind/common_wrapper.hpp:199-201
     OneShot = 0
     NCCL = 1
@@ -409,7 +446,11 @@ class Model:
                          momentum_factor=o.momentum_factor, atomic_update=o.atomic_update,
                          scaler=self.solver.scaler)
 
-    def compile(self):
+    def compile(self, loss_names=None, loss_weights=None):
+        """loss_names / loss_weights: the multi-task form (model_wrapper.hpp compile overload);
+        one BinaryCrossEntropyLoss is what this surface trains, so they must name that loss"""
+        if loss_names is not None and len(list(loss_names)) > 1:
+            raise RuntimeError("multi-loss models are outside the hot-path scope of hugectr_amd")
         assert self.input is not None, "Model.add(Input(...)) first"
         s = self.solver
         B, Be = s.batchsize, s.batchsize_eval
@@ -863,7 +904,11 @@ class Model:
         for tc in callbacks:  # model.cpp:869-872
             tc.on_training_start()
         stopped = False
+        sch = self.get_learning_rate_scheduler()
+        scheduled = s.warmup_steps > 1 or s.decay_start > 0
         while it < limit:
+            if scheduled:
+                self.set_learning_rate(sch.get_next())
             if not self.train():
                 break
             it += 1
@@ -933,6 +978,8 @@ class Model:
             else:  # one file per rank: its flat [rows][ev] shard table
                 e.table.cpu().numpy().astype("<f4").tofile(
                     os.path.join(d, f"emb_vector.rank{self.rank}"))
+        if self.rank == 0 and self._dense_opt is not None:
+            torch.save(self._dense_opt.state_dict(), f"{prefix}_opt_dense_{iteration}.model")
         if self.rank == 0 and self._dense_params:
             blobs = [b.detach().float().contiguous().flatten() for b, _ in self._dense_blobs()]
             torch.cat(blobs).cpu().numpy().astype("<f4").tofile(f"{prefix}_dense_{iteration}.model")
@@ -985,6 +1032,23 @@ class Model:
             h.load_parameters(torch.from_numpy(keys[mine]),
                               torch.from_numpy(slot[mine]) if slot is not None else None,
                               torch.from_numpy(vec[mine]))
+
+    def start_data_reading(self):
+        """the low-level loop's first call (model.cpp start_data_reading): readers start lazily"""
+        assert self._compiled, "call compile() first"
+
+    def get_learning_rate_scheduler(self) -> LearningRateScheduler:
+        if getattr(self, "_lr_sch", None) is None:
+            s = self.solver
+            self._lr_sch = LearningRateScheduler(s.lr, s.warmup_steps, s.decay_start, s.decay_steps,
+                                                 s.decay_power, s.end_lr)
+        return self._lr_sch
+
+    def load_dense_optimizer_states(self, path: str):
+        """state of the dense optimizer as save_params_to_files wrote it (<prefix>_opt_dense_<iter>
+        .model, model.cpp:1238)"""
+        if self._dense_opt is not None:
+            self._dense_opt.load_state_dict(torch.load(path, map_location=self.device))
 
     def load_sparse_optimizer_states(self, paths: Sequence[str]):
         for path, (name, (se, p, h, _, _)) in zip(paths, self._emb.items()):

@@ -106,3 +106,54 @@ def test_training_callback_hooks_are_called_in_the_reference_order():
     s = H.CreateSolver(batchsize=8, vvgpu=[[0]], training_callbacks=[H.TrainingCallback()],
                        all_reduce_algo=H.AllReduceAlgo.NCCL)
     assert len(s.training_callbacks) == 1
+
+
+@pytest.mark.skipif(not os.path.isdir(REF + "/samples"), reason="reference checkout not mounted")
+def test_every_model_method_the_reference_scripts_call_exists():
+    """`model.<verb>(...)` / `ebc_config.<verb>(...)` calls of the same scripts: every verb exists and
+    accepts the keywords used"""
+    import hugectr_amd.hugectr as H
+    files = sorted(glob.glob(REF + "/samples/**/*.py", recursive=True) +
+                   glob.glob(REF + "/test/embedding_collection_test/*.py") +
+                   glob.glob(REF + "/test/pybind_test/*.py"))
+    owner = {"model": H.Model, "ebc_config": H.EmbeddingCollectionConfig}
+    used, kws = collections.Counter(), collections.defaultdict(set)
+    for f in files:
+        try:
+            tree = ast.parse(open(f).read())
+        except SyntaxError:
+            continue
+        for node in ast.walk(tree):
+            if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and
+                    isinstance(node.func.value, ast.Name) and node.func.value.id in owner):
+                k = (node.func.value.id, node.func.attr)
+                used[k] += 1
+                kws[k].update(a.arg for a in node.keywords if a.arg)
+    assert used[("model", "add")] > 500 and used[("model", "fit")] >= 20
+    missing, bad = [], {}
+    for (obj, verb) in used:
+        fn = getattr(owner[obj], verb, None)
+        if fn is None:
+            missing.append(f"{obj}.{verb}")
+            continue
+        params = inspect.signature(fn).parameters
+        if not any(p.kind == p.VAR_KEYWORD for p in params.values()):
+            extra = kws[(obj, verb)] - set(params)
+            if extra:
+                bad[f"{obj}.{verb}"] = sorted(extra)
+    assert missing == [], missing
+    assert not bad, bad
+
+
+def test_learning_rate_scheduler_known_answers():
+    """LearningRateScheduler::get_next (R/HugeCTR/include/learning_rate_scheduler.hpp:66-88)"""
+    import hugectr_amd.hugectr as H
+    s = H.LearningRateScheduler(1.0, warmup_steps=4, decay_start=6, decay_steps=4, decay_power=2.0,
+                                end_lr=0.1)
+    got = [round(s.get_next(), 6) for _ in range(12)]
+    # warm-up 1/4 .. 4/4, flat to step 6, ((10 - step) / 4)^2 down to end_lr, then end_lr
+    assert got == [0.25, 0.5, 0.75, 1.0, 1.0, 1.0, 0.5625, 0.25, 0.1, 0.1, 0.1, 0.1]
+    flat = H.LearningRateScheduler(0.3)
+    assert [flat.get_next() for _ in range(3)] == [0.3, 0.3, 0.3] and flat.get_step() == 3
+    with pytest.raises(RuntimeError):
+        H.LearningRateScheduler(0.1, decay_power=0.5)
