@@ -594,3 +594,36 @@ def test_freeze_and_optimizer_state_files(tmp_path):
     h.opt_state(0).zero_()
     m.load_sparse_optimizer_states([str(f)])
     assert torch.equal(h.opt_state(0), s0)
+
+
+def test_low_level_training_loop(tmp_path):
+    """the loop of R/test/pybind_test/model_test.py:1209-1230: start_data_reading, the solver's
+    learning-rate schedule (warm-up + decay) applied by hand, train / eval / get_eval_metrics"""
+    import sys
+    import hugectr_amd.hugectr as hugectr
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_ckpt_fixture as fx
+    m = fx.dlrm(fx.gen(str(tmp_path / "d")))
+    m.solver.warmup_steps, m.solver.decay_start, m.solver.decay_steps = 5, 20, 10
+    m.solver.end_lr = 0.001
+    m.compile()
+    m.start_data_reading()
+    sch = m.get_learning_rate_scheduler()
+    lrs = []
+    for it in range(40):
+        lr = sch.get_next()
+        m.set_learning_rate(lr)
+        lrs.append(lr)
+        assert m.train()
+        if it % 10 == 0 and it:
+            m._eval_buf = []
+            for _ in range(1):
+                m.eval()
+            names = [n for n, _ in m.get_eval_metrics()]
+            assert names == ["AUC", "AverageLoss"]
+    assert lrs[0] == pytest.approx(0.01 / 5) and lrs[4] == pytest.approx(0.01)
+    assert lrs[19] == pytest.approx(0.01) and lrs[24] == pytest.approx(0.01 * 0.25)
+    assert lrs[-1] == pytest.approx(0.001)
+    h = list(m._emb.values())[0][2]
+    assert np.isfinite(m.get_current_loss()) and h.get_vocabulary_size() > 0
