@@ -265,8 +265,11 @@ class ParquetReader:
         for s, c in enumerate(self.cat_cols):
             col = t[c]
             if str(col.type).startswith("list"):
-                lists = col.to_pylist()
-                cats.append([np.asarray(v, np.int64) + self.slot_offsets[s] for v in lists])
+                # multi-hot column: (row offsets, flat keys) straight from the Arrow buffers
+                arr = col.combine_chunks()
+                off = arr.offsets.to_numpy().astype(np.int64)
+                vals = arr.values.to_numpy().astype(np.int64)[off[0]:off[-1]] + self.slot_offsets[s]
+                cats.append((off - off[0], vals))
             else:
                 cats.append(col.to_numpy().astype(np.int64) + self.slot_offsets[s])
         self._buf, self._pos = (label, dense, cats), 0
@@ -296,15 +299,22 @@ class ParquetReader:
                 keys = np.stack([g[a:b] for g in group], 1).reshape(-1)
                 ro = np.arange(B * p.slot_num + 1, dtype=np.int64)
             else:
+                # ragged group: bucket (sample, slot) order, vectorised per slot
                 lens = np.empty((B, p.slot_num), np.int64)
-                parts = []
-                for i in range(B):
-                    for s, g in enumerate(group):
-                        v = g[a + i] if isinstance(g, list) else g[a + i:a + i + 1]
-                        lens[i, s] = len(v)
-                        parts.append(v)
-                keys = np.concatenate(parts) if parts else np.empty(0, np.int64)
+                for s, g in enumerate(group):
+                    lens[:, s] = (g[0][a + 1:b + 1] - g[0][a:b]) if isinstance(g, tuple) else 1
                 ro = np.concatenate([[0], np.cumsum(lens.reshape(-1))]).astype(np.int64)
+                keys = np.empty(int(ro[-1]), np.int64)
+                starts = ro[:-1].reshape(B, p.slot_num)
+                for s, g in enumerate(group):
+                    if isinstance(g, tuple):
+                        off, vals = g
+                        seg = vals[off[a]:off[b]]
+                        # destination of every key: its bucket's start + position inside the bucket
+                        inner = np.arange(seg.size) - np.repeat(off[a:b] - off[a], lens[:, s])
+                        keys[np.repeat(starts[:, s], lens[:, s]) + inner] = seg
+                    else:
+                        keys[starts[:, s]] = g[a:b]
             kt = torch.from_numpy(keys)
             rt = torch.from_numpy(ro)
             if self.key_dtype != torch.int64:

@@ -184,3 +184,49 @@ def test_raw_reader_reads_the_reference_converters_file():
                 assert ro.tolist() == list(range(0, B * hot[i] + 1, hot[i]))
                 assert (keys.view(B, hot[i]).numpy() == src[str(i)][a:a + B]).all()
         assert r.next_batch() is None
+
+
+def test_parquet_multi_hot_columns(tmp_path):
+    """list-typed categorical columns (multi-hot) next to scalar ones: bucket order (sample, slot),
+    slot offsets added, one DataReaderSparseParam per column or one over several columns"""
+    import pyarrow.parquet as pq
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd import data
+    sizes = [50, 7, 1000, 3]
+    hot = [3, 1, 2, 1]
+    p = hugectr.tools.DataGeneratorParams(
+        format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=2, num_slot=4,
+        i64_input_key=True, source=str(tmp_path / "train" / "_file_list.txt"),
+        eval_source=str(tmp_path / "val" / "_file_list.txt"), slot_size_array=sizes, nnz_array=hot,
+        dist_type=hugectr.Distribution_t.PowerLaw, power_law_type=hugectr.PowerLaw_t.Short,
+        num_files=1, eval_num_files=1, num_samples_per_file=96, num_samples=96, eval_num_samples=32)
+    hugectr.tools.DataGenerator(p).generate()
+    t = pq.read_table(str(tmp_path / "train" / "gen_0.parquet"))
+    cols = [t[f"C{i + 1}"].to_pylist() for i in range(4)]
+    offs = np.array([0, 50, 57, 1057])
+    for params in ([hugectr.DataReaderSparseParam("all", hot, True, 4)],
+                   [hugectr.DataReaderSparseParam(f"d{i}", hot[i], True, 1) for i in range(4)]):
+        inp = hugectr.Input(label_dim=1, label_name="label", dense_dim=2, dense_name="dense",
+                            data_reader_sparse_param_array=params)
+        r = data.ParquetReader(p.source, inp, sizes, 32, 0, 1, torch.device("cpu"), True, False)
+        for nb in range(3):
+            b = r.next_batch()
+            a = nb * 32
+            if len(params) == 1:
+                ro, keys = b["sparse"]["all"]
+                want, lens = [], []
+                for i in range(a, a + 32):
+                    for s in range(4):
+                        v = cols[s][i] if isinstance(cols[s][i], list) else [cols[s][i]]
+                        want += [k + offs[s] for k in v]
+                        lens.append(len(v))
+                assert keys.tolist() == want
+                assert ro.tolist() == np.concatenate([[0], np.cumsum(lens)]).tolist()
+            else:
+                for s in range(4):
+                    ro, keys = b["sparse"][f"d{s}"]
+                    want = []
+                    for i in range(a, a + 32):
+                        v = cols[s][i] if isinstance(cols[s][i], list) else [cols[s][i]]
+                        want += [k + offs[s] for k in v]
+                    assert keys.tolist() == want and ro.numel() == 33
