@@ -482,3 +482,150 @@ class EmbeddingCollection:
         send = self.network_backward(grad)
         top = self._a2a(send, self.recv_counts, self.send_counts)
         self.apply_gradients(top)
+
+
+class DataParallelCollection:
+    """Replicated ("dp") tables of an embedding_collection
+    (R/HugeCTR/embedding/data_parallel_embedding.cpp; shard_strategy ("dp", [...]) of
+    EmbeddingCollectionConfig.shard): every GPU holds the whole table -- identically initialised,
+    SURVEY q14 -- and resolves the lookups of ITS OWN samples, so nothing of these lookups crosses
+    the all-to-all; the replicas stay in step through one all-reduce of the (dense) per-row gradient
+    sums (communication.cpp:145-157), after which every GPU applies the same sparse optimizer
+    step to the rows any GPU touched.  Small tables only: the all-reduce moves rows x ev floats.
+
+    forward(gkeys, gbucket_range): the replicated global batch, feature-major over the collection's
+    own lookups (bucket = lookup * batch + b) -> [batch/world, lookups, ev]."""
+
+    def __init__(self, config: EmbeddingCollectionConfig, global_batch: int, lr: float = 0.01,
+                 optimizer: int = _lib.OPT_SGD, scaler: float = 1.0, epsilon: float = 1e-7,
+                 initial_accu_value: float = 0.0, out_dtype=torch.float32, max_hotness: int = 1,
+                 seed: int = 0, group=None, ftrl=(0.0, 0.0, 0.0), rank=None, world=None):
+        self.group = group
+        self.world = world if world is not None else (
+            dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
+        assert global_batch % self.world == 0
+        if optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_FTRL):
+            raise _lib.HugeCTRAmdError("EBC static tables support SGD, AdaGrad and Ftrl")
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.B, self.bpg = global_batch, global_batch // self.world
+        self.lr, self.optimizer, self.scaler, self.epsilon = lr, optimizer, scaler, epsilon
+        self.out_dtype, self.ftrl = out_dtype, tuple(float(x) for x in ftrl)
+        tables: List[EmbeddingTableConfig] = []
+        for t, _, _, _ in config.lookups:
+            if t not in tables:
+                tables.append(t)
+        self.tables, self.ev = tables, tables[0].ev_size
+        assert all(t.ev_size == self.ev for t in tables), "one ev_size per collection"
+        self.L = len(config.lookups)
+        names = [str(c).lower().split(".")[-1] for _, _, _, c in config.lookups]
+        self.combiner = [0 if c in ("sum", "0", "concat") else 1 for c in names]
+        starts, rows = [], 0
+        for t in tables:
+            starts.append(rows)
+            rows += t.max_vocabulary_size
+        self.rows = max(rows, 1)
+        self.table = torch.empty((self.rows, self.ev), dtype=torch.float32, device=self.dev)
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(seed * 1000003 + 99991)  # replica-uniform: the SAME stream on every rank
+        for t, s0 in zip(tables, starts):
+            b = (1.0 / t.max_vocabulary_size) ** 0.5
+            self.table[s0:s0 + t.max_vocabulary_size].uniform_(-b, b, generator=g)
+        self.accum = self.ftrl_z = None
+        if optimizer == _lib.OPT_ADAGRAD:
+            self.accum = torch.full_like(self.table, initial_accu_value)
+        if optimizer == _lib.OPT_FTRL:
+            self.accum, self.ftrl_z = torch.zeros_like(self.table), torch.zeros_like(self.table)
+        desc, rs = [], []
+        for l, (t, _, _, _) in enumerate(config.lookups):
+            desc += [l, 1, 0]
+            rs.append(starts[tables.index(t)])
+        self.d_desc = torch.tensor(desc, dtype=torch.int32, device=self.dev)
+        self.d_row_start = torch.tensor(rs, dtype=torch.int64, device=self.dev)
+        self.mean_ids = [l for l in range(self.L) if self.combiner[l] == 1]
+        self.max_nnz = self.B * self.L * max(1, max_hotness)
+        nb = self.world * self.L * self.bpg
+        self.ws = torch.empty(lib.hctr_ebc_route_workspace_bytes(self.B, self.L) + 64,
+                              dtype=torch.uint8, device=self.dev)
+        self.out_range = torch.zeros(nb + 1, dtype=torch.int64, device=self.dev)
+        self.indices = torch.empty(self.max_nnz, dtype=torch.int64, device=self.dev)
+        self._reduce = ctypes.c_void_p()   # per-row gradient sums of my samples
+        check(lib.hctr_updater_create(self.max_nnz, self.rows, self.ev, ctypes.byref(self._reduce)))
+        self._apply = ctypes.c_void_p()    # optimizer step on the touched rows
+        check(lib.hctr_updater_create(self.rows, self.rows, self.ev, ctypes.byref(self._apply)))
+        if optimizer == _lib.OPT_FTRL:
+            check(lib.hctr_updater_set_ftrl(self._apply, *self.ftrl))
+        self._times = 0
+
+    def __del__(self):
+        for name in ("_reduce", "_apply"):
+            u = getattr(self, name, None)
+            if u is not None and u.value:
+                lib.hctr_updater_destroy(u)
+                setattr(self, name, ctypes.c_void_p())
+
+    def forward(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
+        kt = _lib.KEY_I64 if gkeys.dtype == torch.int64 else _lib.KEY_U32
+        check(lib.hctr_ebc_route_keys(self.B, self.world, self.L, ptr(self.d_desc),
+                                      ptr(self.d_row_start), ptr(gkeys), ptr(gbucket_range), kt,
+                                      ptr(self.out_range), ptr(self.indices), None, ptr(self.ws),
+                                      stream_ptr()))
+        n = self.L * self.bpg
+        # buckets are ordered [peer][lookup][b_local]: my own samples are the segment peer == rank
+        self._seg = self.out_range[self.rank * n:(self.rank + 1) * n + 1]
+        pooled = torch.empty((n, self.ev), dtype=self.out_dtype, device=self.dev)
+        check(lib.hctr_forward_pool(n, self.ev, 0, ptr(self._seg), _lib.KEY_I64, ptr(self.indices),
+                                    ptr(self.table), ptr(pooled), _DT[self.out_dtype], stream_ptr()))
+        pooled = pooled.view(self.L, self.bpg, self.ev)
+        self._cnt = None
+        if self.mean_ids:  # Average divides by the bucket's key count when > 0 (generic_lookup.cuh:343-348)
+            cnt = (self._seg[1:] - self._seg[:-1]).view(self.L, self.bpg).clamp(min=1)
+            self._cnt = cnt[self.mean_ids].unsqueeze(-1).to(torch.float32)
+            pooled[self.mean_ids] = (pooled[self.mean_ids].float() / self._cnt).to(self.out_dtype)
+        return pooled.permute(1, 0, 2).contiguous()
+
+    def backward_local(self, grad: torch.Tensor):
+        """grad [batch/world, lookups, ev] -> (dense per-row gradient sums [rows, ev] fp32 of MY
+        samples, touched-row flags [rows]) -- the operands of the all-reduce"""
+        g = grad.permute(1, 0, 2).contiguous()
+        if self.mean_ids:
+            g[self.mean_ids] = (g[self.mean_ids].float() / self._cnt).to(g.dtype)
+        n = self.L * self.bpg
+        seg0 = int(self._seg[0])  # host sync: where my segment starts in the routed key list
+        nnz = int(self._seg[-1]) - seg0
+        dense = torch.zeros((self.rows, self.ev), dtype=torch.float32, device=self.dev)
+        touched = torch.zeros(self.rows, dtype=torch.float32, device=self.dev)
+        if nnz:
+            rng = (self._seg - seg0).contiguous()
+            rows = self.indices[seg0:seg0 + nnz]
+            urow = torch.empty(nnz, dtype=torch.int64, device=self.dev)
+            wg = torch.empty((nnz, self.ev), dtype=torch.float32, device=self.dev)
+            nu = ctypes.c_size_t()
+            check(lib.hctr_ebc_local_reduce(self._reduce, n, nnz, ptr(rng), ptr(rows), self.rows, None,
+                                            ptr(g), _DT[g.dtype], ctypes.byref(nu), ptr(urow), None,
+                                            ptr(wg), stream_ptr()))
+            u = urow[:nu.value]
+            dense[u] = wg[:nu.value]
+            touched[u] = 1.0
+        return dense, touched
+
+    def apply_reduced(self, dense: torch.Tensor, touched: torch.Tensor):
+        """the same optimizer step on every GPU: rows any GPU touched, summed gradients"""
+        self._times += 1
+        rows = torch.nonzero(touched > 0).view(-1)  # host sync (count)
+        n = int(rows.numel())
+        if n == 0:
+            return
+        ro = torch.arange(n + 1, dtype=torch.int64, device=self.dev)
+        check(lib.hctr_updater_update(self._apply, n, n, ptr(ro), ptr(rows), ptr(dense[rows]), _lib.F32,
+                                      self.optimizer, _lib.UPDATE_LOCAL, self.lr, 0.9, 0.999,
+                                      self.epsilon, 0.0, self.scaler, self._times, ptr(self.table),
+                                      ptr(self.accum), ptr(self.ftrl_z), stream_ptr()))
+
+    def backward_and_update(self, grad: torch.Tensor):
+        dense, touched = self.backward_local(grad)
+        if self.world > 1 and dist.is_initialized():
+            from .parallel import all_reduce
+            all_reduce(dense, group=self.group)      # communication.cpp:145-157
+            all_reduce(touched, group=self.group)
+        self.apply_reduced(dense, touched)

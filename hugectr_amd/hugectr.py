@@ -28,8 +28,8 @@ import torch.distributed as dist
 from . import _lib
 from .dense import FusedMLP
 from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward_reorder
-from .embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfig,  # noqa: F401
-                                   EmbeddingTableConfig)
+from .embedding_collection import (DataParallelCollection, EmbeddingCollection,  # noqa: F401
+                                   EmbeddingCollectionConfig, EmbeddingTableConfig)
 from .layers import MultiCrossLayer, interaction
 from .parallel import DistributedExchange, LocalizedExchange
 from .parallel import all_reduce as _all_reduce
@@ -488,6 +488,8 @@ class Model:
         self._ebc = []
         for cfg in self.ebc_configs:
             subs = self._split_by_ev_size(cfg)
+            if len(subs) == 1:
+                subs[0][0].top_name = cfg.top_name
             for sub, ids in subs:
                 rt = self._compile_ebc(sub, sp, B, Be, declare_shapes=len(subs) == 1)
                 rt.update(parent=cfg, ids=ids, whole=len(subs) == 1)
@@ -513,8 +515,16 @@ class Model:
     def _split_by_ev_size(self, cfg: EmbeddingCollectionConfig):
         """the runtime keeps one vector size per collection: lookups of a config that mixes sizes
         (wide 1 + deep 16 ...) run as one collection per size, each with the parent's placement"""
+        dp_names = set()
+        if isinstance(cfg.shard_strategy, (list, tuple)):
+            for kind, names in cfg.shard_strategy:
+                if str(kind).lower() == "dp":
+                    dp_names.update(str(n) for n in names)
+        # dynamic tables cannot be replicated (they grow independently): keep them model parallel
+        dp_names = {n for n in dp_names
+                    if all(t.max_vocabulary_size >= 0 for t, _, _, _ in cfg.lookups if t.name == n)}
         sizes = sorted({t.ev_size for t, _, _, _ in cfg.lookups})
-        if len(sizes) == 1:
+        if len(sizes) == 1 and not dp_names:
             return [(cfg, list(range(len(cfg.lookups))))]
         tables = []
         for t, _, _, _ in cfg.lookups:
@@ -522,8 +532,19 @@ class Model:
                 tables.append(t)
         own = cfg.ownership(tables, self.world)
         out = []
+        for ev in sizes:  # replicated ("dp") tables: one data-parallel collection per vector size
+            ids = [l for l, (t, _, _, _) in enumerate(cfg.lookups)
+                   if t.ev_size == ev and t.name in dp_names]
+            if ids:
+                sub = EmbeddingCollectionConfig()
+                sub.lookups = [cfg.lookups[l] for l in ids]
+                sub.shard_strategy = "dp"
+                out.append((sub, ids))
         for ev in sizes:
-            ids = [l for l, (t, _, _, _) in enumerate(cfg.lookups) if t.ev_size == ev]
+            ids = [l for l, (t, _, _, _) in enumerate(cfg.lookups)
+                   if t.ev_size == ev and t.name not in dp_names]
+            if not ids:
+                continue
             sub = EmbeddingCollectionConfig()
             sub.lookups = [cfg.lookups[l] for l in ids]
             sub_tables = []
@@ -580,6 +601,22 @@ class Model:
         if dynamic:
             kw.update(beta1=o.beta1, beta2=o.beta2, momentum_factor=o.momentum_factor,
                       init_capacity=1 << 16)
+        if cfg.shard_strategy == "dp":  # replicated tables: no all-to-all, gradient all-reduce
+            dkw = {k: v for k, v in kw.items() if k != "batch_major"}
+            train = DataParallelCollection(cfg, B, **dkw)
+            ev = None
+            if Be > 0:
+                ev = train if Be == B else DataParallelCollection(cfg, Be, **dkw)
+                ev.table, ev.accum, ev.ftrl_z = train.table, train.accum, train.ftrl_z
+            L, evs = train.L, train.ev
+            if declare_shapes:
+                if cfg.top_name:
+                    self._shapes[cfg.top_name] = (L, evs)
+                else:
+                    for _, _, top, _ in cfg.lookups:
+                        self._shapes[top] = (evs,)
+            return dict(cfg=cfg, train=train, eval=ev, params=params,
+                        offsets=torch.tensor(offsets, dtype=torch.int64, device=self.device))
         train = EmbeddingCollection(cfg, B, **kw)
         ev = None
         if Be > 0:
@@ -611,6 +648,8 @@ class Model:
         base = torch.cumsum(ends, 0) - ends                      # first key of every lookup
         gbr = torch.cat([r[:-1] + base[l] for l, r in enumerate(ros)] + [ends.sum().view(1)])
         gk = torch.cat([k - rt["offsets"][l] for l, k in enumerate(keys)])
+        if isinstance(e, DataParallelCollection):
+            return e.forward(gk, gbr)
         send = e.route_and_pool(gk, gbr)
         recv = e._a2a(send, e.send_counts, e.recv_counts)
         return e.network_forward(recv)
@@ -969,7 +1008,7 @@ class Model:
             d = f"{prefix}_ebc{i}_sparse_{iteration}.model"
             os.makedirs(d, exist_ok=True)
             e = rt["train"]
-            if e.dynamic:  # per local table: the keys it holds and their vectors
+            if getattr(e, "dynamic", False):  # per local table: the keys it holds and their vectors
                 for t, c in e.class_of_table.items():
                     k, v = e.det.export(c)
                     k.cpu().numpy().astype("<i8").tofile(os.path.join(d, f"key.table{t}.rank{self.rank}"))

@@ -246,3 +246,58 @@ def test_key_route_all_to_all_two_ranks_on_one_gpu():
         if ret.get(r) != "ok":
             print(f"--- rank {r} ---\n{ret.get(r)}")
     assert ret.get(0) == "ok" and ret.get(1) == "ok"
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("opt_name", ["sgd", "adagrad", "ftrl"])
+def test_data_parallel_tables(oracle, world, opt_name):
+    """replicated ("dp") tables: every rank resolves its own samples, the per-row gradient sums are
+    all-reduced (emulated here by adding the ranks' operands), every replica takes the same step;
+    forward and tables against the same EBC oracle as the model-parallel tables"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    from hugectr_amd.embedding_collection import DataParallelCollection
+    rng = np.random.default_rng(world + 50)
+    B, ev = 32, 16
+    vocabs = [50, 7, 30]
+    lookup_table = [0, 1, 2, 1]
+    combiners = ["sum", "mean", "mean", "sum"]
+    T, L = len(vocabs), len(lookup_table)
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l in range(L):
+        cfg.embedding_lookup(tcfg[lookup_table[l]], f"in{l}", f"out{l}", combiners[l])
+    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "ftrl": _lib.OPT_FTRL}[opt_name]
+    ftrl = (0.02, 0.05, 0.3)
+    ranks = [DataParallelCollection(cfg, B, lr=0.1, optimizer=opt, scaler=2.0, epsilon=1e-6,
+                                    max_hotness=4, ftrl=ftrl, rank=r, world=world, seed=4)
+             for r in range(world)]
+    assert all(torch.equal(ranks[0].table, e.table) for e in ranks)      # replica-uniform init
+    row_start = np.concatenate([[0], np.cumsum(vocabs)[:-1]]).astype(np.int64)
+    dense = ranks[0].table.cpu().numpy().copy()
+    accum, ftrl_z = np.zeros_like(dense), np.zeros_like(dense)
+    comb = [0 if c == "sum" else 1 for c in combiners]
+    bpg = B // world
+    for it in range(3):
+        keys, br = _make_inputs(rng, B, vocabs, lookup_table, 4)
+        gk, gbr = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        outs = [e.forward(gk, gbr) for e in ranks]                        # [bpg, L, ev]
+        want = oracle.ebc_forward(B, lookup_table, ev, comb, keys, br, row_start, dense,
+                                  num_gpus=world, batch_major=True)
+        for d in range(world):
+            assert_close(outs[d].cpu().numpy().reshape(-1), want[d], 1e-5, 1e-6, f"dp fwd rank{d}")
+        grads = [rng.standard_normal(outs[d].shape).astype(np.float32) for d in range(world)]
+        parts = [ranks[d].backward_local(torch.from_numpy(grads[d]).cuda()) for d in range(world)]
+        total = sum(p[0] for p in parts)
+        touched = sum(p[1] for p in parts)
+        for e in ranks:
+            e.apply_reduced(total.clone(), touched.clone())
+        torch.cuda.synchronize()
+        oracle.ebc_backward_update(B, lookup_table, ev, comb, keys, br, row_start, dense,
+                                   np.stack([g.reshape(-1) for g in grads]),
+                                   optimizer={"sgd": 0, "adagrad": 1, "ftrl": 2}[opt_name], lr=0.1,
+                                   scaler=2.0, epsilon=1e-6, accum=accum, num_gpus=world,
+                                   batch_major=True, ftrl=ftrl, ftrl_z=ftrl_z)
+        assert all(torch.equal(ranks[0].table, e.table) for e in ranks), "replicas diverged"
+        assert_close(ranks[0].table.cpu().numpy(), dense, 1e-5, 1e-6, f"dp tables it{it}")

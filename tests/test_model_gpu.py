@@ -326,8 +326,11 @@ def _ebc_model_worker(rank, world, port, folder, ret):
                                     for i in range(26)]))
         tables = [hugectr.EmbeddingTableConfig(name=str(i), max_vocabulary_size=SIZES[i], ev_size=16)
                   for i in range(26)]
-        args = sharding.mi355x_args(sharding_plan="auto", ev_size=16, num_gpus_per_node=2)
+        # tables under 78 rows (5e-6 GB at ev 16, fp32) are replicated: ("dp", [...]) in the plan
+        args = sharding.mi355x_args(sharding_plan="auto", ev_size=16, num_gpus_per_node=2,
+                                    dp_sharding_threshold=5e-6)
         sm, ss = sharding.generate_plan(SIZES, hot, 1, 2, args, False)
+        assert dict(ss)["dp"] == [str(i) for i, v in enumerate(SIZES) if v < 78]
         ebc = hugectr.EmbeddingCollectionConfig()
         ebc.embedding_lookup(table_config=tables, bottom_name=[f"data{i}" for i in range(26)],
                              top_name="sparse_embedding",
@@ -348,16 +351,26 @@ def _ebc_model_worker(rank, world, port, folder, ret):
         model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
                     top_names=["loss"]))
         model.compile()
-        e = model._ebc[0]["train"]
-        owned = [t for t in range(26) if rank in e.owners[t]]
-        assert owned and len(owned) < 26          # the planner split the tables over the 2 ranks
+        from hugectr_amd.embedding_collection import DataParallelCollection
+        dp = [rt["train"] for rt in model._ebc if isinstance(rt["train"], DataParallelCollection)]
+        mp_ = [rt["train"] for rt in model._ebc if not isinstance(rt["train"], DataParallelCollection)]
+        assert len(dp) == 1 and len(mp_) == 1 and dp[0].L == sum(v < 78 for v in SIZES)
+        e = mp_[0]
+        owned = [t for t in range(len(e.tables)) if rank in e.owners[t]]
+        assert owned and len(owned) < len(e.tables)   # the planner split the big tables over the ranks
         before = e.table.clone()
+        dp_before = dp[0].table.clone()
         model.train()
         first = model.get_current_loss()
         model.fit(max_iter=200, display=0, eval_interval=0, snapshot=0)
         last = model.get_current_loss()
         assert last < min(first, 0.64), (first, last)
-        assert (e.table != before).any()
+        assert (e.table != before).any() and (dp[0].table != dp_before).any()
+        # the replicated tables stay identical on both ranks
+        rep = dp[0].table.detach().flatten().cpu()
+        both = [torch.empty_like(rep) for _ in range(world)]
+        dist.all_gather(both, rep)
+        assert torch.equal(both[0], both[1])
         # data-parallel dense weights stay identical on both ranks
         flat = torch.cat([q.detach().flatten().float() for q in model._dense_params]).cpu()
         both = [torch.empty_like(flat) for _ in range(world)]
