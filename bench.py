@@ -230,6 +230,8 @@ def main():
     # flat master / gradient / 16-bit buffers: backward writes gradients in place, the SGD step and
     # the shadow refresh are one kernel per MLP, the data-parallel all-reduce needs no packing
     flat_mode = amp and C == 1 and a.graph != "on"
+    # HCTR_BENCH_HEAD=0 keeps the logit layer + loss as separate library / HIP calls (A/B runs)
+    head_fused = amp and os.environ.get("HCTR_BENCH_HEAD", "1") != "0" and top.can_fuse_bce_head()
     if flat_mode:
         bottom.flatten()
         top.flatten()
@@ -263,6 +265,11 @@ def main():
         if on_E_grad is not None:
             E.register_hook(on_E_grad)
         z = ha.interaction(xb.to(edt), E)
+        if amp and head_fused:
+            # last layer + BCE + their backward in one pass over the last hidden activations
+            loss = top.forward_bce(z, label_k, 1.0 / (Bc * C))
+            loss.backward()
+            return loss.detach() / C
         logit = top(z)
         if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
             loss, dlogit = bce_with_logits(logit, label_k, 1.0 / (Bc * C))

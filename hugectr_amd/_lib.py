@@ -155,6 +155,9 @@ _SIGNATURES = {
     "hctr_emb_update_rows": (c_int, [_P, c_size_t, _P, _P, _P, c_int, _P]),
     "hctr_relu_bwd_bias_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_relu_bwd_bias": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, c_int, _P]),
+    "hctr_logit_head_workspace_bytes": (c_size_t, [c_int]),
+    "hctr_logit_head": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int,
+                                _P]),
     "hctr_sum_groups": (c_int, [c_int, c_size_t, _P, c_int, _P, _P]),
     "hctr_sgd_shadow": (c_int, [c_size_t, c_float, c_float, _P, _P, _P, c_int, _P]),
     "hctr_bce_loss_workspace_bytes": (c_size_t, []),

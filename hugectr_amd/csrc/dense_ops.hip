@@ -1022,6 +1022,180 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) *loss = tot / (float)batch;
 }
 
+// ---- logit head: the last fully connected layer (K -> 1), BinaryCrossEntropyLoss and their
+//      backward in ONE pass over the activations (MLPLayer's last GEMM + loss.cu:231-262).  As
+//      library calls this is a GEMV forward, a rank-1 dgrad and a K = batch reduction for the weight
+//      gradient -- three badly shaped GEMMs (16 + 17 + 69 us at batch 65536, K = 256) around the
+//      loss kernels; here every row of x is read once: z = x.w + b, loss term, dz = (sigmoid(z) -
+//      y) * grad_scale, dx = dz * w written back, dw / db / loss accumulated per wavefront and
+//      reduced in fixed order (deterministic).
+constexpr int kHeadBlocks = 1024;
+constexpr int kHeadMaxSeg = 8;  // K <= 64 lanes * 4 elements * 8 segments = 2048
+
+template <typename T>
+__device__ __forceinline__ float4 ld4_as_f32(const T* p);
+template <>
+__device__ __forceinline__ float4 ld4_as_f32<__hip_bfloat16>(const __hip_bfloat16* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u),
+                     __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+}
+template <>
+__device__ __forceinline__ float4 ld4_as_f32<__half>(const __half* p) {
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  const __half2 a = *reinterpret_cast<const __half2*>(&r.x), b = *reinterpret_cast<const __half2*>(&r.y);
+  const float2 fa = __half22float2(a), fb = __half22float2(b);
+  return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+template <typename T>
+__device__ __forceinline__ void st4_from_f32(T* p, float4 v);
+template <>
+__device__ __forceinline__ void st4_from_f32<__hip_bfloat16>(__hip_bfloat16* p, float4 v) {
+  __hip_bfloat16 h[4] = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z),
+                         __float2bfloat16(v.w)};
+  *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(h);
+}
+template <>
+__device__ __forceinline__ void st4_from_f32<__half>(__half* p, float4 v) {
+  __half h[4] = {__float2half_rn(v.x), __float2half_rn(v.y), __float2half_rn(v.z),
+                 __float2half_rn(v.w)};
+  *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(h);
+}
+
+// partial layout per block: [K dw][1 db][1 loss].  A wavefront takes ROWS rows per iteration (ROWS
+// independent row loads in flight); NSEG = ceil(K / 256) segments of 64 lanes x 4 elements.
+template <typename T, int NSEG, int ROWS>
+__global__ void __launch_bounds__(kBlock)
+    logit_head_kernel(size_t batch, int K, const T* __restrict__ x, const T* __restrict__ w,
+                      const T* __restrict__ bias, const float* __restrict__ label,
+                      float grad_scale, T* __restrict__ dx, float* __restrict__ partial) {
+  extern __shared__ float lds[];  // [waves][K + 2]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 wr[NSEG], acc[NSEG];
+#pragma unroll
+  for (int j = 0; j < NSEG; j++) {
+    const int k = j * 256 + lane * 4;
+    wr[j] = k < K ? ld4_as_f32<T>(w + k) : zero4;
+    acc[j] = zero4;
+  }
+  const float b0 = ld_as_f32(bias, 0);
+  float db = 0.f, loss = 0.f;
+  const size_t nw = (size_t)gridDim.x * (kBlock / 64);
+  for (size_t r0 = ((size_t)blockIdx.x * (kBlock / 64) + wv) * ROWS; r0 < batch; r0 += nw * ROWS) {
+    float4 xv[ROWS][NSEG];
+    float dot[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+      const size_t r = r0 + i;
+      dot[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NSEG; j++) {
+        const int k = j * 256 + lane * 4;
+        xv[i][j] = (r < batch && k < K) ? ld4_as_f32<T>(x + r * (size_t)K + k) : zero4;
+        dot[i] += xv[i][j].x * wr[j].x + xv[i][j].y * wr[j].y + xv[i][j].z * wr[j].z +
+                  xv[i][j].w * wr[j].w;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < ROWS; i++) dot[i] += __shfl_xor(dot[i], o);
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+      const size_t r = r0 + i;
+      if (r >= batch) break;  // wave-uniform
+      const float z = dot[i] + b0;
+      const float y = label[r];
+      float g, l;
+      if (z >= 0.f) {
+        const float e = expf(-z);
+        g = (1.f - y) - e / (1.f + e);
+        l = z * (1.f - y) + logf(1.f + e);
+      } else {
+        const float e = expf(z);
+        g = -y + e / (1.f + e);
+        l = -z * y + logf(1.f + e);
+      }
+      const float dz = g * grad_scale;
+      loss += l;
+      db += dz;
+#pragma unroll
+      for (int j = 0; j < NSEG; j++) {
+        const int k = j * 256 + lane * 4;
+        if (k < K) {
+          acc[j].x += dz * xv[i][j].x;
+          acc[j].y += dz * xv[i][j].y;
+          acc[j].z += dz * xv[i][j].z;
+          acc[j].w += dz * xv[i][j].w;
+          if (dx)
+            st4_from_f32<T>(dx + r * (size_t)K + k, make_float4(dz * wr[j].x, dz * wr[j].y,
+                                                                 dz * wr[j].z, dz * wr[j].w));
+        }
+      }
+    }
+  }
+  // wavefronts of the block -> LDS -> one partial per block (waves added in order)
+  float* mine = lds + wv * (K + 2);
+#pragma unroll
+  for (int j = 0; j < NSEG; j++) {
+    const int k = j * 256 + lane * 4;
+    if (k < K) {
+      mine[k] = acc[j].x;
+      mine[k + 1] = acc[j].y;
+      mine[k + 2] = acc[j].z;
+      mine[k + 3] = acc[j].w;
+    }
+  }
+  if (lane == 0) {
+    mine[K] = db;
+    mine[K + 1] = loss;
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * (K + 2);
+  for (int k = threadIdx.x; k < K + 2; k += kBlock) {
+    float t = 0.f;
+    for (int q = 0; q < kBlock / 64; q++) t += lds[q * (K + 2) + k];
+    out[k] = t;
+  }
+}
+
+// fixed-order sum of the block partials: a 1024-thread workgroup owns 64 columns; 16 row groups sum
+// consecutive chunks of the partial blocks (coalesced 256-byte reads), then the group sums are
+// added in group order
+__global__ void __launch_bounds__(1024)
+    logit_head_finish_kernel(int blocks, int K, size_t batch, const float* __restrict__ partial,
+                             float* __restrict__ dw, float* __restrict__ db,
+                             float* __restrict__ loss) {
+  __shared__ float part[16][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + c;
+  const int chunk = (blocks + 15) / 16;
+  const int b0 = grp * chunk, b1 = min(blocks, b0 + chunk);
+  float t = 0.f;
+  if (k < K + 2) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {  // 8 independent loads in flight, added in order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(b + u) * (K + 2) + k];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t += v[u];
+    }
+    for (; b < b1; b++) t += partial[(size_t)b * (K + 2) + k];
+  }
+  part[grp][c] = t;
+  __syncthreads();
+  if (grp == 0 && k < K + 2) {
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; g++) tot += part[g][c];
+    if (k < K) dw[k] = tot;
+    else if (k == K) *db = tot;
+    else *loss = tot / (float)batch;
+  }
+}
+
 constexpr int kCrossBwdWaves = 256 * 4;  // waves used by the cross backward (deterministic reduce)
 
 }  // namespace
@@ -1402,6 +1576,47 @@ int hctr_bce_loss(size_t batch, const void* logit, const float* label, float gra
   }
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(kBlock), 0, s, blocks, batch, workspace, loss);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_logit_head_workspace_bytes(int k) { return (size_t)kHeadBlocks * (k + 2) * sizeof(float); }
+
+int hctr_logit_head(size_t batch, int k, const void* x, const void* w, const void* bias,
+                    const float* label, float grad_scale, void* dx, float* dw, float* db,
+                    float* loss, float* workspace, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(batch > 0 && k >= 4 && k % 4 == 0 && k <= 256 * kHeadMaxSeg,
+               "logit head: K must be a multiple of 4 and <= 2048");
+  HCTR_REQUIRE(dtype == HCTR_EMB_F16 || dtype == HCTR_EMB_BF16, "16-bit activations");
+  HCTR_REQUIRE(x && w && bias && label && dw && db && loss && workspace, "null pointer");
+  HCTR_REQUIRE(reinterpret_cast<uintptr_t>(x) % 8 == 0 && reinterpret_cast<uintptr_t>(w) % 8 == 0 &&
+                   (dx == nullptr || reinterpret_cast<uintptr_t>(dx) % 8 == 0),
+               "8-byte aligned buffers");
+  hipStream_t s = as_stream(stream);
+  const int nseg = (k + 255) / 256;
+  const int rows = nseg <= 1 ? 8 : (nseg <= 2 ? 4 : (nseg <= 4 ? 2 : 1));
+  const int blocks = (int)std::min<size_t>(
+      (size_t)kHeadBlocks, ceil_div<size_t>(batch, (size_t)(kBlock / 64) * rows));
+  const size_t lds = (size_t)(kBlock / 64) * (k + 2) * sizeof(float);
+#define HCTR_HEAD(T_, NSEG_, ROWS_)                                                               \
+  hipLaunchKernelGGL((logit_head_kernel<T_, NSEG_, ROWS_>), dim3(blocks), dim3(kBlock), lds, s,   \
+                     batch, k, (const T_*)x, (const T_*)w, (const T_*)bias, label, grad_scale,    \
+                     (T_*)dx, workspace)
+#define HCTR_HEAD_T(T_)                       \
+  if (nseg <= 1) HCTR_HEAD(T_, 1, 8);         \
+  else if (nseg <= 2) HCTR_HEAD(T_, 2, 4);    \
+  else if (nseg <= 4) HCTR_HEAD(T_, 4, 2);    \
+  else HCTR_HEAD(T_, 8, 1);
+  if (dtype == HCTR_EMB_BF16) {
+    HCTR_HEAD_T(__hip_bfloat16)
+  } else {
+    HCTR_HEAD_T(__half)
+  }
+#undef HCTR_HEAD_T
+#undef HCTR_HEAD
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(logit_head_finish_kernel, dim3(ceil_div<int>(k + 2, 64)), dim3(1024), 0, s,
+                     blocks, k, batch, workspace, dw, db, loss);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

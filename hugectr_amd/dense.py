@@ -116,6 +116,36 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw.float(), db, None, None, None, None, None, None
 
 
+class _LogitHeadFn(torch.autograd.Function):
+    """loss = mean BCE(x @ w^T + b, label) with the whole backward of the head computed in the same
+    pass (hctr_logit_head): dx, dw, db exist when forward returns.  backward() hands dx on; it
+    assumes the unit upstream gradient of `loss.backward()` -- scale through grad_scale."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, b_master, w16, b16, label, grad_scale: float, gw=None, gb=None):
+        x = x.contiguous()
+        B, K = x.shape
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = gw if gw is not None else torch.empty((1, K), dtype=torch.float32, device=dev)
+        db = gb if gb is not None else torch.empty(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.hctr_logit_head_workspace_bytes(K) // 4, dtype=torch.float32, device=dev)
+        check(lib.hctr_logit_head(B, K, ptr(x), ptr(w16), ptr(b16), ptr(label.contiguous()),
+                                  float(grad_scale), ptr(dx), ptr(dw), ptr(db), ptr(loss), ptr(ws),
+                                  _DT16[x.dtype], stream_ptr()))
+        ctx.flat = gw is not None
+        ctx.dx = dx
+        ctx.dw, ctx.db = (None, None) if ctx.flat else (dw, db)
+        return loss
+
+    @staticmethod
+    def backward(ctx, _grad_loss):
+        dx, dw, db = ctx.dx, ctx.dw, ctx.db
+        ctx.dx = ctx.dw = ctx.db = None
+        return dx, dw, db, None, None, None, None, None, None
+
+
 class FusedMLP(torch.nn.Module):
     """Stack of Linear(+ReLU) layers with fp32 master weights and 16-bit compute copies.
 
@@ -187,6 +217,29 @@ class FusedMLP(torch.nn.Module):
             torch._foreach_copy_(self._w16 + self._b16,
                                  [w.detach() for w in self.weights] +
                                  [b.detach() for b in self.biases])
+
+    def can_fuse_bce_head(self) -> bool:
+        k = self.dims[-2]
+        return (self.dims[-1] == 1 and not self.relu[-1] and k % 4 == 0 and k <= 2048 and
+                self.dtype in _DT16)
+
+    def forward_bce(self, x, label, grad_scale: float):
+        """the stack up to the last hidden layer, then logit layer + BinaryCrossEntropyLoss + the
+        head's backward in one kernel: returns the mean loss [1]; `loss.backward()` continues
+        through the hidden layers (gradients of the head are already in place)"""
+        assert self.can_fuse_bce_head()
+        if not self._w16:
+            self.refresh_shadow()
+        x = x.to(self.dtype)
+        n = len(self.weights)
+        for i in range(n - 1):
+            x = _LinearFn.apply(x, self.weights[i], self.biases[i], self._w16[i], self._b16[i],
+                                self.relu[i], self.wgrad_groups,
+                                self._gw[i] if self._gw else None,
+                                self._gb[i] if self._gb else None)
+        return _LogitHeadFn.apply(x, self.weights[-1], self.biases[-1], self._w16[-1], self._b16[-1],
+                                  label, grad_scale, self._gw[-1] if self._gw else None,
+                                  self._gb[-1] if self._gb else None)
 
     def forward(self, x):
         if not self._w16:

@@ -464,6 +464,17 @@ size_t hctr_bce_loss_workspace_bytes(void);
 int hctr_bce_loss(size_t batch, const void* logit, const float* label, float grad_scale,
                   void* dlogit, float* loss, float* workspace, int dtype, hctr_stream_t stream);
 
+/* Logit head: the network's last fully connected layer (K -> 1) + BinaryCrossEntropyLoss + both
+ * backward passes in one sweep over the activations (MLPLayer's last layer,
+ * R/HugeCTR/src/layers/mlp_layer.cu, and R/HugeCTR/src/loss.cu:231-262): z = x.w + bias,
+ * *loss = mean_i bce(z_i, label_i), dz = (sigmoid(z) - label) * grad_scale, dx[i][:] = dz_i * w
+ * (NULL to skip), dw[k] = sum_i dz_i x[i][k], *db = sum_i dz_i (fp32, fixed-order sums).
+ * x / w / bias / dx 16-bit (hctr_emb_dtype_t F16 or BF16), K % 4 == 0, K <= 2048. */
+size_t hctr_logit_head_workspace_bytes(int k);
+int hctr_logit_head(size_t batch, int k, const void* x, const void* w, const void* bias,
+                    const float* label, float grad_scale, void* dx, float* dw, float* db,
+                    float* loss, float* workspace, int dtype, hctr_stream_t stream);
+
 /* DCN v2 fused epilogue: out = x0 * (h + b) + x_l  (fused_matrix_elementwise_dot_add,
  * multi_cross_layer.cu:426-463); the two GEMMs stay in the caller's BLAS. */
 int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,

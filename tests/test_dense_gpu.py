@@ -257,3 +257,66 @@ def test_fused_mlp_flat_mode_equals_parameter_mode():
         for wa, wb in zip(a._w16 + a._b16, b._w16 + b._b16):
             # the masters agree to one fp32 ulp (fma vs mul+sub), so a bf16 rounding may flip
             assert (wa.float() - wb.float()).norm() <= 1e-2 * wa.float().norm() + 1e-6
+
+
+@pytest.mark.parametrize("B,K", [(4096, 256), (1000, 64), (777, 520), (300, 2048), (5, 4)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_logit_head_matches_torch(B, K, dtype):
+    """last FC layer (K -> 1) + BCE loss + dx / dw / db in one kernel vs the fp32 formulas"""
+    import torch
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = 2 if dtype == "bf16" else 1
+    g = torch.Generator(device="cuda").manual_seed(B + K)
+    x = torch.randn((B, K), device="cuda", generator=g).to(tdt)
+    w = (torch.randn((1, K), device="cuda", generator=g) / K ** 0.5).to(tdt)
+    b = torch.tensor([0.1], device="cuda").to(tdt)
+    y = (torch.rand((B, 1), device="cuda", generator=g) < 0.4).float()
+    scale = 1.0 / B
+    dx = torch.empty_like(x)
+    dw = torch.empty((1, K), dtype=torch.float32, device="cuda")
+    db = torch.empty(1, dtype=torch.float32, device="cuda")
+    loss = torch.empty(1, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.hctr_logit_head_workspace_bytes(K) // 4, dtype=torch.float32, device="cuda")
+    check(lib.hctr_logit_head(B, K, ptr(x), ptr(w), ptr(b), ptr(y), scale, ptr(dx), ptr(dw), ptr(db),
+                              ptr(loss), ptr(ws), code, stream_ptr()))
+    xf, wf = x.double(), w.double()
+    z = xf @ wf.t() + b.double()
+    want_loss = torch.nn.functional.binary_cross_entropy_with_logits(z, y.double())
+    dz = (torch.sigmoid(z) - y.double()) * scale
+    assert abs(float(loss) - float(want_loss)) < 2e-6 * max(1.0, abs(float(want_loss)))
+    assert torch.allclose(dw.double(), dz.t() @ xf, rtol=1e-4, atol=1e-7)
+    assert abs(float(db) - float(dz.sum())) < 1e-6
+    tol = 2 ** -7 if dtype == "bf16" else 2 ** -10          # one rounding of the 16-bit store
+    atol = 1e-9 if dtype == "bf16" else 6e-8                # (fp16: gradients this small are subnormal)
+    assert torch.allclose(dx.double(), dz * wf, rtol=tol, atol=atol)
+    # deterministic: a second launch gives the same bits
+    dw2, loss2 = torch.empty_like(dw), torch.empty_like(loss)
+    check(lib.hctr_logit_head(B, K, ptr(x), ptr(w), ptr(b), ptr(y), scale, None, ptr(dw2), ptr(db),
+                              ptr(loss2), ptr(ws), code, stream_ptr()))
+    assert torch.equal(dw, dw2) and torch.equal(loss, loss2)
+
+
+def test_fused_mlp_bce_head_equals_the_unfused_tower():
+    """FusedMLP.forward_bce (head fused) vs forward + bce_with_logits + backward: same gradients up
+    to the 16-bit rounding of the logits the unfused path goes through"""
+    import torch
+    from hugectr_amd.dense import FusedMLP, bce_with_logits
+    torch.manual_seed(0)
+    B = 2048
+    a = FusedMLP([96, 64, 32, 1], last_relu=False).cuda()
+    b = FusedMLP([96, 64, 32, 1], last_relu=False).cuda()
+    b.load_state_dict(a.state_dict())
+    a.flatten()
+    b.flatten()
+    x = torch.randn((B, 96), device="cuda").bfloat16()
+    y = (torch.rand((B, 1), device="cuda") < 0.5).float()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    la = a.forward_bce(xa, y, 1.0 / B)
+    la.backward()
+    logit = b(xb)
+    lb, dlogit = bce_with_logits(logit, y, 1.0 / B)
+    logit.backward(dlogit)
+    assert abs(float(la) - float(lb)) < 2e-3
+    assert torch.allclose(a.flat_g, b.flat_g, rtol=5e-2, atol=2e-4)
+    assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=5e-2, atol=2e-5)
