@@ -72,6 +72,9 @@ def test_new_entry_points_validate_before_touching_the_device():
     assert L.hctr_bce_loss(0, None, None, 1.0, None, None, None, 0, None) == -1
     assert L.hctr_forward_pool_weighted(4, 0, 0, None, None, None, None, None, None) == -1
     assert L.hctr_ebc_routed_keys_to_indices(8, 2, 3, None, None, None, None, None) == -1
+    assert L.hctr_logit_head(8, 6, None, None, None, None, 1.0, None, None, None, None, None, 2,
+                             None) == -1
+    assert "multiple of 4" in _lib.last_error()
     assert L.hctr_forward_pool_ptrs(4, 16, 2, None, None, None, 0, None) == -1
     assert "combiner" in _lib.last_error()
     assert L.hctr_det_lookup_rows(None, None, 0, None, None, 0, 1, None, None, None, None) == -1
