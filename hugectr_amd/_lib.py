@@ -158,6 +158,9 @@ _SIGNATURES = {
     "hctr_logit_head_workspace_bytes": (c_size_t, [c_int]),
     "hctr_logit_head": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int,
                                 _P]),
+    "hctr_skinny_fc_fwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "hctr_skinny_fc_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "hctr_skinny_fc_bwd": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_sum_groups": (c_int, [c_int, c_size_t, _P, c_int, _P, _P]),
     "hctr_sgd_shadow": (c_int, [c_size_t, c_float, c_float, _P, _P, _P, c_int, _P]),
     "hctr_bce_loss_workspace_bytes": (c_size_t, []),

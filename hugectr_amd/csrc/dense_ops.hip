@@ -1196,6 +1196,238 @@ __global__ void __launch_bounds__(1024)
   }
 }
 
+// ---- first layer of the bottom MLP: y = relu(x W^T + b) with a handful of input features (K <= 16,
+//      DLRM: 13 dense features -> 512).  As a GEMM it is all output traffic and no arithmetic
+//      (library kernel: 30 us forward; ReLU backward + bias + a K = batch weight-gradient GEMM with
+//      13 columns: 72 us).  Here 128 lanes own one row at a time, a lane 4 consecutive outputs
+//      with their K weights in registers; the backward folds dz = dy * (y > 0) into the
+//      weight-gradient sum, so dz is never written (the layer has no data gradient).
+constexpr int kSkinnyK = 16;       // padded K
+constexpr int kSkinnyBlocks = 256;
+constexpr int kSkinnyLanes = 128;  // lanes per row, 4 outputs each (N <= 512)
+constexpr int kSkinnyBwdBlock = 1024;
+constexpr int kSkinnyUnroll = 2;   // rows per step and row group in the backward (x2 in flight)
+constexpr int kSkinnyAhead = 4;    // rows of x the forward keeps in flight per row group
+
+template <typename T>
+__device__ __forceinline__ float round16(float v);
+template <>
+__device__ __forceinline__ float round16<__hip_bfloat16>(float v) {
+  return __bfloat162float(__float2bfloat16(v));
+}
+template <>
+__device__ __forceinline__ float round16<__half>(float v) {
+  return __half2float(__float2half_rn(v));
+}
+
+template <typename T>
+__device__ __forceinline__ float4 cvt4_as_f32(uint2 r);
+template <>
+__device__ __forceinline__ float4 cvt4_as_f32<__hip_bfloat16>(uint2 r) {
+  return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u),
+                     __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+}
+template <>
+__device__ __forceinline__ float4 cvt4_as_f32<__half>(uint2 r) {
+  const float2 fa = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
+  const float2 fb = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+  return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// x fp32 [B][K] (rounded to T on load, as the 16-bit GEMM path does), w T [N][K], bias T [N].
+// The only load in the row loop is the row's K features: kept kSkinnyAhead rows ahead in a
+// register ring, so the loop streams stores instead of waiting on one small load per row.  Row
+// numbers are wave-uniform (scalar registers); rows past the end are clamped for the loads and
+// skipped by a scalar branch.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+    skinny_fc_fwd_kernel(size_t batch, int K, int N, const float* __restrict__ x,
+                         const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int col = threadIdx.x % kSkinnyLanes;
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kSkinnyLanes);
+  const bool live = col * 4 < N;
+  const int n0 = live ? col * 4 : 0;
+  const int kl = lane < K ? lane : 0;
+  v2f wr[4][kSkinnyK / 2];
+  float br[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    br[j] = ld_as_f32(bias, (size_t)(n0 + j));
+#pragma unroll
+    for (int k = 0; k < kSkinnyK; k++) {
+      // clamped index + select: 64 independent loads, no branch (and no wait) per element
+      const float t = ld_as_f32(w, (size_t)(n0 + j) * K + (k < K ? k : K - 1));
+      const float v = k < K ? t : 0.f;
+      if (k & 1) wr[j][k / 2].y = v;
+      else wr[j][k / 2].x = v;
+    }
+  }
+  constexpr int kRows = kBlock / kSkinnyLanes;
+  const size_t step = (size_t)gridDim.x * kRows;
+  const size_t first = (size_t)blockIdx.x * kRows + sub;
+  const size_t last = batch - 1;
+  float ring[kSkinnyAhead];
+#pragma unroll
+  for (int u = 0; u < kSkinnyAhead; u++)
+    ring[u] = x[min(first + (size_t)u * step, last) * (size_t)K + kl];
+  for (size_t r0 = first; r0 < batch; r0 += step * kSkinnyAhead) {
+#pragma unroll
+    for (int u = 0; u < kSkinnyAhead; u++) {
+      const size_t r = r0 + (size_t)u * step;
+      const float xl = lane < K ? round16<T>(ring[u]) : 0.f;
+      ring[u] = x[min(r + step * kSkinnyAhead, last) * (size_t)K + kl];
+      if (r < batch) {  // scalar condition
+        v2f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kSkinnyK; k += 2) {
+          const v2f xk = v2f{__shfl(xl, k), __shfl(xl, k + 1)};
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j] += xk * wr[j][k / 2];
+        }
+        if (live)
+          st4_from_f32<T>(y + r * (size_t)N + n0,
+                          make_float4(fmaxf(acc[0].x + acc[0].y + br[0], 0.f),
+                                      fmaxf(acc[1].x + acc[1].y + br[1], 0.f),
+                                      fmaxf(acc[2].x + acc[2].y + br[2], 0.f),
+                                      fmaxf(acc[3].x + acc[3].y + br[3], 0.f)));
+      }
+    }
+  }
+}
+
+// partial per block: [N][kSkinnyK] dw and [N] db interleaved as [N][kSkinnyK + 1].  The loads of the
+// next kSkinnyUnroll rows (raw 16-bit words) are issued before the current ones are consumed; row
+// numbers are scalar, rows past the end are clamped for the loads and count with weight zero.
+template <typename T>
+__global__ void __launch_bounds__(kSkinnyBwdBlock)
+    skinny_fc_bwd_kernel(size_t batch, int K, int N, const float* __restrict__ x,
+                         const T* __restrict__ dy, const T* __restrict__ y,
+                         float* __restrict__ partial) {
+  extern __shared__ float lds[];  // [N * (kSkinnyK + 1)]
+  const int lane = threadIdx.x & 63;
+  const int col = threadIdx.x % kSkinnyLanes;
+  const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kSkinnyLanes);
+  const bool live = col * 4 < N;
+  const int n0 = live ? col * 4 : 0;
+  const int kl = lane < K ? lane : 0;
+  v2f acc[4][kSkinnyK / 2];
+  float dbv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    dbv[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kSkinnyK / 2; k++) acc[j][k] = v2f{0.f, 0.f};
+  }
+  constexpr int kRows = kSkinnyBwdBlock / kSkinnyLanes;
+  const size_t step = (size_t)gridDim.x * kRows;
+  const size_t first = (size_t)blockIdx.x * kRows + sub;
+  const size_t last = batch - 1;
+  uint2 g[kSkinnyUnroll], a[kSkinnyUnroll];
+  float xl[kSkinnyUnroll];
+#pragma unroll
+  for (int u = 0; u < kSkinnyUnroll; u++) {
+    const size_t r = min(first + (size_t)u * step, last);
+    g[u] = *reinterpret_cast<const uint2*>(dy + r * (size_t)N + n0);
+    a[u] = *reinterpret_cast<const uint2*>(y + r * (size_t)N + n0);
+    xl[u] = x[r * (size_t)K + kl];
+  }
+  for (size_t r0 = first; r0 < batch; r0 += step * kSkinnyUnroll) {
+    uint2 gn[kSkinnyUnroll], an[kSkinnyUnroll];
+    float xn[kSkinnyUnroll];
+#pragma unroll
+    for (int u = 0; u < kSkinnyUnroll; u++) {
+      const size_t r = min(r0 + (size_t)(u + kSkinnyUnroll) * step, last);
+      gn[u] = *reinterpret_cast<const uint2*>(dy + r * (size_t)N + n0);
+      an[u] = *reinterpret_cast<const uint2*>(y + r * (size_t)N + n0);
+      xn[u] = x[r * (size_t)K + kl];
+    }
+#pragma unroll
+    for (int u = 0; u < kSkinnyUnroll; u++) {
+      if (r0 + (size_t)u * step < batch) {  // scalar condition
+        // dz as the unfused path hands it to its GEMM
+        const float4 gf = cvt4_as_f32<T>(g[u]), af = cvt4_as_f32<T>(a[u]);
+        const float d[4] = {af.x > 0.f ? gf.x : 0.f, af.y > 0.f ? gf.y : 0.f,
+                            af.z > 0.f ? gf.z : 0.f, af.w > 0.f ? gf.w : 0.f};
+        const float xr = lane < K ? round16<T>(xl[u]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dbv[j] += d[j];
+#pragma unroll
+        for (int k = 0; k < kSkinnyK; k += 2) {
+          const v2f xk = v2f{__shfl(xr, k), __shfl(xr, k + 1)};
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[j][k / 2] += xk * d[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSkinnyUnroll; u++) {
+      g[u] = gn[u];
+      a[u] = an[u];
+      xl[u] = xn[u];
+    }
+  }
+  // the block's row groups add their sums in a fixed order through LDS
+  const int stride = kSkinnyK + 1;
+  for (int q = 0; q < kRows; q++) {
+    if (sub == q && live) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float* d = lds + (size_t)(n0 + j) * stride;
+#pragma unroll
+        for (int k = 0; k < kSkinnyK; k++) {
+          const float v = (k & 1) ? acc[j][k / 2].y : acc[j][k / 2].x;
+          d[k] = (q == 0 ? 0.f : d[k]) + v;
+        }
+        d[kSkinnyK] = (q == 0 ? 0.f : d[kSkinnyK]) + dbv[j];
+      }
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * N * stride;
+  for (int i = threadIdx.x; i < N * stride; i += kSkinnyBwdBlock) out[i] = lds[i];
+}
+
+// dw [N][K] and db [N] from the block partials: 64 elements per block, 16 groups of lanes each sum
+// a consecutive chunk of the partial blocks (8 loads in flight), group sums added in group order
+__global__ void __launch_bounds__(1024)
+    skinny_fc_finish_kernel(int blocks, int K, int N, const float* __restrict__ partial,
+                            float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float part[16][64];
+  const int stride = kSkinnyK + 1;
+  const int total = N * stride;
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  const int chunk = (blocks + 15) / 16;
+  const int b0 = grp * chunk, b1 = min(blocks, b0 + chunk);
+  float t = 0.f;
+  if (i < total) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(b + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; u++) t += v[u];
+    }
+    for (; b < b1; b++) t += partial[(size_t)b * total + i];
+  }
+  part[grp][c] = t;
+  __syncthreads();
+  if (grp == 0 && i < total) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) tot += part[q][c];
+    const int n = i / stride, k = i % stride;
+    if (k == kSkinnyK) db[n] = tot;
+    else if (k < K) dw[(size_t)n * K + k] = tot;
+  }
+}
+
 constexpr int kCrossBwdWaves = 256 * 4;  // waves used by the cross backward (deterministic reduce)
 
 }  // namespace
@@ -1617,6 +1849,59 @@ int hctr_logit_head(size_t batch, int k, const void* x, const void* w, const voi
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(logit_head_finish_kernel, dim3(ceil_div<int>(k + 2, 64)), dim3(1024), 0, s,
                      blocks, k, batch, workspace, dw, db, loss);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+static int skinny_check(size_t batch, int k, int n, int dtype) {
+  HCTR_REQUIRE(batch > 0 && k >= 1 && k <= kSkinnyK, "skinny fc: 1 <= K <= 16");
+  HCTR_REQUIRE(n >= 4 && n % 4 == 0 && n <= 512, "skinny fc: N a multiple of 4, <= 512");
+  HCTR_REQUIRE(dtype == HCTR_EMB_F16 || dtype == HCTR_EMB_BF16, "16-bit weights / activations");
+  return HCTR_OK;
+}
+
+int hctr_skinny_fc_fwd(size_t batch, int k, int n, const float* x, const void* w, const void* bias,
+                       void* y, int dtype, hctr_stream_t stream) {
+  HCTR_TRY(skinny_check(batch, k, n, dtype));
+  HCTR_REQUIRE(x && w && bias && y, "null pointer");
+  HCTR_REQUIRE(reinterpret_cast<uintptr_t>(y) % 8 == 0, "8-byte aligned output");
+  hipStream_t s = as_stream(stream);
+  const int blocks = (int)std::min<size_t>(1024, ceil_div<size_t>(batch, kBlock / kSkinnyLanes));
+  if (dtype == HCTR_EMB_BF16)
+    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(kBlock), 0, s, batch,
+                       k, n, x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,
+                       (__hip_bfloat16*)y);
+  else
+    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__half>, dim3(blocks), dim3(kBlock), 0, s, batch, k, n, x,
+                       (const __half*)w, (const __half*)bias, (__half*)y);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+size_t hctr_skinny_fc_bwd_workspace_bytes(int n) {
+  return (size_t)kSkinnyBlocks * n * (kSkinnyK + 1) * sizeof(float);
+}
+
+int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* dy, const void* y,
+                       float* dw, float* db, float* workspace, int dtype, hctr_stream_t stream) {
+  HCTR_TRY(skinny_check(batch, k, n, dtype));
+  HCTR_REQUIRE(x && dy && y && dw && db && workspace, "null pointer");
+  HCTR_REQUIRE(reinterpret_cast<uintptr_t>(dy) % 8 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0,
+               "8-byte aligned activations");
+  hipStream_t s = as_stream(stream);
+  const int blocks = (int)std::min<size_t>(
+      (size_t)kSkinnyBlocks, ceil_div<size_t>(batch, kSkinnyBwdBlock / kSkinnyLanes));
+  const size_t lds = (size_t)n * (kSkinnyK + 1) * sizeof(float);
+  if (dtype == HCTR_EMB_BF16)
+    hipLaunchKernelGGL(skinny_fc_bwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(kSkinnyBwdBlock), lds, s,
+                       batch, k, n, x, (const __hip_bfloat16*)dy, (const __hip_bfloat16*)y,
+                       workspace);
+  else
+    hipLaunchKernelGGL(skinny_fc_bwd_kernel<__half>, dim3(blocks), dim3(kSkinnyBwdBlock), lds, s, batch, k, n,
+                       x, (const __half*)dy, (const __half*)y, workspace);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(skinny_fc_finish_kernel, dim3(ceil_div<int>(n * (kSkinnyK + 1), 64)),
+                     dim3(1024), 0, s, blocks, k, n, workspace, dw, db);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -14,6 +14,8 @@ kernels).  What this module fixes is how they are *issued* for the DLRM shapes
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Sequence
 
 import torch
@@ -114,6 +116,41 @@ class _LinearFn(torch.autograd.Function):
         if ctx.gw is not None:  # gradients live in the flat buffer; nothing for autograd to keep
             return dx, None, None, None, None, None, None, None, None
         return dx, dw.float(), db, None, None, None, None, None, None
+
+
+class _SkinnyFirstFn(torch.autograd.Function):
+    """y = relu(x @ W^T + b) for an input with a handful of features (x fp32 [B, K <= 16], no data
+    gradient): hctr_skinny_fc_fwd / _bwd; the backward reads dy and y once and leaves dw / db, no
+    dz tensor in between."""
+
+    @staticmethod
+    def forward(ctx, x, w_master, b_master, w16, b16, gw=None, gb=None):
+        x = x.contiguous()
+        B, K = x.shape
+        N = w16.shape[0]
+        y = torch.empty((B, N), dtype=w16.dtype, device=x.device)
+        check(lib.hctr_skinny_fc_fwd(B, K, N, ptr(x), ptr(w16), ptr(b16), ptr(y), _DT16[w16.dtype],
+                                     stream_ptr()))
+        ctx.gw, ctx.gb = gw, gb
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, K = x.shape
+        N = y.shape[1]
+        dev = x.device
+        dw = ctx.gw if ctx.gw is not None else torch.empty((N, K), dtype=torch.float32, device=dev)
+        db = ctx.gb if ctx.gb is not None else torch.empty(N, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.hctr_skinny_fc_bwd_workspace_bytes(N) // 4, dtype=torch.float32,
+                         device=dev)
+        check(lib.hctr_skinny_fc_bwd(B, K, N, ptr(x), ptr(dy), ptr(y), ptr(dw), ptr(db), ptr(ws),
+                                     _DT16[y.dtype], stream_ptr()))
+        if ctx.gw is not None:
+            return None, None, None, None, None, None, None
+        return None, dw, db, None, None, None, None
 
 
 class _LogitHeadFn(torch.autograd.Function):
@@ -218,6 +255,24 @@ class FusedMLP(torch.nn.Module):
                                  [w.detach() for w in self.weights] +
                                  [b.detach() for b in self.biases])
 
+    def _skinny_first(self, x) -> bool:
+        """first layer through the few-input-features kernels?  (fp32 input without a gradient)"""
+        return (self.relu[0] and self.dims[0] <= 16 and self.dims[1] % 4 == 0 and
+                self.dims[1] <= 512 and self.dtype in _DT16 and x.is_cuda and
+                x.dtype == torch.float32 and not x.requires_grad and
+                os.environ.get("HCTR_SKINNY_FC", "1") != "0")
+
+    def _layer(self, i, x):
+        gw = self._gw[i] if self._gw else None
+        gb = self._gb[i] if self._gb else None
+        if i == 0 and self._skinny_first(x):
+            return _SkinnyFirstFn.apply(x, self.weights[0], self.biases[0], self._w16[0],
+                                        self._b16[0], gw, gb)
+        if x.dtype != self.dtype:
+            x = x.to(self.dtype)
+        return _LinearFn.apply(x, self.weights[i], self.biases[i], self._w16[i], self._b16[i],
+                               self.relu[i], self.wgrad_groups, gw, gb)
+
     def can_fuse_bce_head(self) -> bool:
         k = self.dims[-2]
         return (self.dims[-1] == 1 and not self.relu[-1] and k % 4 == 0 and k <= 2048 and
@@ -230,13 +285,11 @@ class FusedMLP(torch.nn.Module):
         assert self.can_fuse_bce_head()
         if not self._w16:
             self.refresh_shadow()
-        x = x.to(self.dtype)
         n = len(self.weights)
         for i in range(n - 1):
-            x = _LinearFn.apply(x, self.weights[i], self.biases[i], self._w16[i], self._b16[i],
-                                self.relu[i], self.wgrad_groups,
-                                self._gw[i] if self._gw else None,
-                                self._gb[i] if self._gb else None)
+            x = self._layer(i, x)
+        if x.dtype != self.dtype:
+            x = x.to(self.dtype)
         return _LogitHeadFn.apply(x, self.weights[-1], self.biases[-1], self._w16[-1], self._b16[-1],
                                   label, grad_scale, self._gw[-1] if self._gw else None,
                                   self._gb[-1] if self._gb else None)
@@ -244,10 +297,6 @@ class FusedMLP(torch.nn.Module):
     def forward(self, x):
         if not self._w16:
             self.refresh_shadow()
-        x = x.to(self.dtype)
         for i in range(len(self.weights)):
-            x = _LinearFn.apply(x, self.weights[i], self.biases[i], self._w16[i], self._b16[i],
-                                self.relu[i], self.wgrad_groups,
-                                self._gw[i] if self._gw else None,
-                                self._gb[i] if self._gb else None)
+            x = self._layer(i, x)
         return x

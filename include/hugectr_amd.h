@@ -475,6 +475,17 @@ int hctr_logit_head(size_t batch, int k, const void* x, const void* w, const voi
                     const float* label, float grad_scale, void* dx, float* dw, float* db,
                     float* loss, float* workspace, int dtype, hctr_stream_t stream);
 
+/* First layer of an MLP with a handful of input features (DLRM bottom MLP: 13 -> 512; MLPLayer,
+ * R/HugeCTR/src/layers/mlp_layer.cu): y = relu(x W^T + b), x fp32 [batch][K] (rounded to the 16-bit
+ * type like the GEMM path), W [N][K] / bias [N] / y 16-bit, 1 <= K <= 16, N % 4 == 0, N <= 512.
+ * bwd: dz = dy * (y > 0) is folded into dw[N][K] = dz^T x and db[N] = sum dz (fp32, fixed-order
+ * sums); dz itself is not produced -- the first layer has no data gradient. */
+int hctr_skinny_fc_fwd(size_t batch, int k, int n, const float* x, const void* w, const void* bias,
+                       void* y, int dtype, hctr_stream_t stream);
+size_t hctr_skinny_fc_bwd_workspace_bytes(int n);
+int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* dy, const void* y,
+                       float* dw, float* db, float* workspace, int dtype, hctr_stream_t stream);
+
 /* DCN v2 fused epilogue: out = x0 * (h + b) + x_l  (fused_matrix_elementwise_dot_add,
  * multi_cross_layer.cu:426-463); the two GEMMs stay in the caller's BLAS. */
 int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,

@@ -320,3 +320,74 @@ def test_fused_mlp_bce_head_equals_the_unfused_tower():
     assert abs(float(la) - float(lb)) < 2e-3
     assert torch.allclose(a.flat_g, b.flat_g, rtol=5e-2, atol=2e-4)
     assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=5e-2, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,K,N", [(4096, 13, 512), (1000, 13, 256), (777, 16, 128), (37, 1, 4),
+                                   (9000, 7, 508)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_skinny_first_layer_matches_torch(B, K, N, dtype):
+    """first MLP layer with a handful of input features: forward and the fused
+    ReLU-backward + dw + db against fp64 formulas on the same 16-bit operands"""
+    import torch
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    code = 2 if dtype == "bf16" else 1
+    g = torch.Generator(device="cuda").manual_seed(B + K + N)
+    x = torch.randn((B, K), device="cuda", generator=g)
+    w = (torch.randn((N, K), device="cuda", generator=g) / K ** 0.5).to(tdt)
+    b = (torch.randn(N, device="cuda", generator=g) * 0.1).to(tdt)
+    y = torch.empty((B, N), dtype=tdt, device="cuda")
+    check(lib.hctr_skinny_fc_fwd(B, K, N, ptr(x), ptr(w), ptr(b), ptr(y), code, stream_ptr()))
+    x16 = x.to(tdt).double()
+    want = torch.relu(x16 @ w.double().t() + b.double())
+    tol = 2 ** -7 if dtype == "bf16" else 2 ** -10
+    assert torch.allclose(y.double(), want, rtol=tol, atol=1e-6)
+    # the rounded result itself: equal to rounding the fp64 value except at rounding ties
+    assert (y != want.to(tdt)).float().mean() < 1e-3
+
+    dy = (torch.randn((B, N), device="cuda", generator=g) / B).to(tdt)
+    dw = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    db = torch.empty(N, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.hctr_skinny_fc_bwd_workspace_bytes(N) // 4, dtype=torch.float32,
+                     device="cuda")
+    check(lib.hctr_skinny_fc_bwd(B, K, N, ptr(x), ptr(dy), ptr(y), ptr(dw), ptr(db), ptr(ws), code,
+                                 stream_ptr()))
+    dz = dy.double() * (y > 0)
+    want_dw, want_db = dz.t() @ x16, dz.sum(0)
+    bound_w = 2e-6 * (dz.abs().t() @ x16.abs()) + 1e-12
+    assert bool(((dw.double() - want_dw).abs() <= bound_w).all())
+    assert bool(((db.double() - want_db).abs() <= 2e-6 * dz.abs().sum(0) + 1e-12).all())
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    check(lib.hctr_skinny_fc_bwd(B, K, N, ptr(x), ptr(dy), ptr(y), ptr(dw2), ptr(db2), ptr(ws), code,
+                                 stream_ptr()))
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_fused_mlp_skinny_first_layer_equals_the_gemm_path(monkeypatch):
+    """FusedMLP on fp32 dense features: the few-features kernels for layer 1 against the library
+    GEMM path (HCTR_SKINNY_FC=0) -- same 16-bit activations up to accumulation order, same
+    gradients in the flat buffer"""
+    import torch
+    from hugectr_amd.dense import FusedMLP
+    torch.manual_seed(1)
+    B = 4096
+    a = FusedMLP([13, 512, 256, 128], last_relu=True).cuda()
+    b = FusedMLP([13, 512, 256, 128], last_relu=True).cuda()
+    b.load_state_dict(a.state_dict())
+    a.flatten()
+    b.flatten()
+    x = torch.rand((B, 13), device="cuda")
+    gy = (torch.randn((B, 128), device="cuda") / B).bfloat16()
+    assert a._skinny_first(x)
+    ya = a(x)
+    ya.backward(gy)
+    monkeypatch.setenv("HCTR_SKINNY_FC", "0")
+    assert not b._skinny_first(x)
+    yb = b(x)
+    yb.backward(gy)
+    assert (ya.float() - yb.float()).norm() <= 2e-3 * yb.float().norm()
+    ga, gb = a.flat_g, b.flat_g
+    assert (ga - gb).norm() <= 5e-3 * gb.norm()
+    # layer-1 gradients specifically (the part that changed hands)
+    for va, vb in ((a._gw[0], b._gw[0]), (a._gb[0], b._gb[0])):
+        assert (va - vb).norm() <= 5e-3 * vb.norm() + 1e-9
