@@ -1207,7 +1207,6 @@ constexpr int kSkinnyBlocks = 256;
 constexpr int kSkinnyLanes = 128;  // lanes per row, 4 outputs each (N <= 512)
 constexpr int kSkinnyBwdBlock = 1024;
 constexpr int kSkinnyUnroll = 2;   // rows per step and row group in the backward (x2 in flight)
-constexpr int kSkinnyAhead = 4;    // rows of x the forward keeps in flight per row group
 
 template <typename T>
 __device__ __forceinline__ float round16(float v);
@@ -1237,20 +1236,19 @@ __device__ __forceinline__ float4 cvt4_as_f32<__half>(uint2 r) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // x fp32 [B][K] (rounded to T on load, as the 16-bit GEMM path does), w T [N][K], bias T [N].
-// The only load in the row loop is the row's K features: kept kSkinnyAhead rows ahead in a
-// register ring, so the loop streams stores instead of waiting on one small load per row.  Row
-// numbers are wave-uniform (scalar registers); rows past the end are clamped for the loads and
-// skipped by a scalar branch.
+// A block owns R consecutive rows: their features are staged (rounded, zero-padded to kSkinnyK)
+// in LDS once, so the row loop has no global load to wait on -- broadcast LDS reads, packed FMAs
+// and a stream of stores.
 template <typename T>
 __global__ void __launch_bounds__(kBlock)
-    skinny_fc_fwd_kernel(size_t batch, int K, int N, const float* __restrict__ x,
+    skinny_fc_fwd_kernel(size_t batch, int K, int N, int R, const float* __restrict__ x,
                          const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
+  extern __shared__ float xs[];  // [R][kSkinnyK]
   const int col = threadIdx.x % kSkinnyLanes;
   const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kSkinnyLanes);
   const bool live = col * 4 < N;
   const int n0 = live ? col * 4 : 0;
-  const int kl = lane < K ? lane : 0;
+  const size_t rb = (size_t)blockIdx.x * R;
   v2f wr[4][kSkinnyK / 2];
   float br[4];
 #pragma unroll
@@ -1265,38 +1263,37 @@ __global__ void __launch_bounds__(kBlock)
       else wr[j][k / 2].x = v;
     }
   }
-  constexpr int kRows = kBlock / kSkinnyLanes;
-  const size_t step = (size_t)gridDim.x * kRows;
-  const size_t first = (size_t)blockIdx.x * kRows + sub;
   const size_t last = batch - 1;
-  float ring[kSkinnyAhead];
+  for (int idx = threadIdx.x; idx < R * kSkinnyK; idx += kBlock) {
+    const int row = idx / kSkinnyK, k = idx % kSkinnyK;
+    const float t = x[min(rb + row, last) * (size_t)K + (k < K ? k : K - 1)];
+    xs[idx] = k < K ? round16<T>(t) : 0.f;
+  }
+  __syncthreads();
+  constexpr int kRows = kBlock / kSkinnyLanes;
+  for (int row = sub; row < R; row += kRows) {
+    const size_t r = rb + row;
+    if (r >= batch) break;  // scalar condition
+    const float4* xp = reinterpret_cast<const float4*>(xs + row * kSkinnyK);
+    v2f acc[4];
 #pragma unroll
-  for (int u = 0; u < kSkinnyAhead; u++)
-    ring[u] = x[min(first + (size_t)u * step, last) * (size_t)K + kl];
-  for (size_t r0 = first; r0 < batch; r0 += step * kSkinnyAhead) {
+    for (int j = 0; j < 4; j++) acc[j] = v2f{0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < kSkinnyAhead; u++) {
-      const size_t r = r0 + (size_t)u * step;
-      const float xl = lane < K ? round16<T>(ring[u]) : 0.f;
-      ring[u] = x[min(r + step * kSkinnyAhead, last) * (size_t)K + kl];
-      if (r < batch) {  // scalar condition
-        v2f acc[4];
+    for (int q = 0; q < kSkinnyK / 4; q++) {
+      const float4 xv = xp[q];  // same address in every lane: broadcast
+      const v2f lo = v2f{xv.x, xv.y}, hi = v2f{xv.z, xv.w};
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[j] = v2f{0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < kSkinnyK; k += 2) {
-          const v2f xk = v2f{__shfl(xl, k), __shfl(xl, k + 1)};
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[j] += xk * wr[j][k / 2];
-        }
-        if (live)
-          st4_from_f32<T>(y + r * (size_t)N + n0,
-                          make_float4(fmaxf(acc[0].x + acc[0].y + br[0], 0.f),
-                                      fmaxf(acc[1].x + acc[1].y + br[1], 0.f),
-                                      fmaxf(acc[2].x + acc[2].y + br[2], 0.f),
-                                      fmaxf(acc[3].x + acc[3].y + br[3], 0.f)));
+      for (int j = 0; j < 4; j++) {
+        acc[j] += lo * wr[j][2 * q];
+        acc[j] += hi * wr[j][2 * q + 1];
       }
     }
+    if (live)
+      st4_from_f32<T>(y + r * (size_t)N + n0,
+                      make_float4(fmaxf(acc[0].x + acc[0].y + br[0], 0.f),
+                                  fmaxf(acc[1].x + acc[1].y + br[1], 0.f),
+                                  fmaxf(acc[2].x + acc[2].y + br[2], 0.f),
+                                  fmaxf(acc[3].x + acc[3].y + br[3], 0.f)));
   }
 }
 
@@ -1866,14 +1863,18 @@ int hctr_skinny_fc_fwd(size_t batch, int k, int n, const float* x, const void* w
   HCTR_REQUIRE(x && w && bias && y, "null pointer");
   HCTR_REQUIRE(reinterpret_cast<uintptr_t>(y) % 8 == 0, "8-byte aligned output");
   hipStream_t s = as_stream(stream);
-  const int blocks = (int)std::min<size_t>(1024, ceil_div<size_t>(batch, kBlock / kSkinnyLanes));
+  // R consecutive rows per block (even, <= 256: 16 KB of LDS), about 4 blocks per CU
+  size_t rows = ceil_div<size_t>(batch, 1024);
+  rows = std::min<size_t>(256, (rows + 1) / 2 * 2);
+  const int blocks = (int)ceil_div<size_t>(batch, rows);
+  const size_t lds = rows * kSkinnyK * sizeof(float);
   if (dtype == HCTR_EMB_BF16)
-    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(kBlock), 0, s, batch,
-                       k, n, x, (const __hip_bfloat16*)w, (const __hip_bfloat16*)bias,
-                       (__hip_bfloat16*)y);
+    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(kBlock), lds, s,
+                       batch, k, n, (int)rows, x, (const __hip_bfloat16*)w,
+                       (const __hip_bfloat16*)bias, (__hip_bfloat16*)y);
   else
-    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__half>, dim3(blocks), dim3(kBlock), 0, s, batch, k, n, x,
-                       (const __half*)w, (const __half*)bias, (__half*)y);
+    hipLaunchKernelGGL(skinny_fc_fwd_kernel<__half>, dim3(blocks), dim3(kBlock), lds, s, batch, k, n,
+                       (int)rows, x, (const __half*)w, (const __half*)bias, (__half*)y);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -120,17 +120,21 @@ class _LinearFn(torch.autograd.Function):
 
 class _SkinnyFirstFn(torch.autograd.Function):
     """y = relu(x @ W^T + b) for an input with a handful of features (x fp32 [B, K <= 16], no data
-    gradient): hctr_skinny_fc_fwd / _bwd; the backward reads dy and y once and leaves dw / db, no
-    dz tensor in between."""
+    gradient).  The backward (hctr_skinny_fc_bwd) reads dy and y once and leaves dw / db, no dz
+    tensor in between; the forward is the library GEMM unless HCTR_SKINNY_FC_FWD=hip selects
+    hctr_skinny_fc_fwd."""
 
     @staticmethod
     def forward(ctx, x, w_master, b_master, w16, b16, gw=None, gb=None):
         x = x.contiguous()
         B, K = x.shape
         N = w16.shape[0]
-        y = torch.empty((B, N), dtype=w16.dtype, device=x.device)
-        check(lib.hctr_skinny_fc_fwd(B, K, N, ptr(x), ptr(w16), ptr(b16), ptr(y), _DT16[w16.dtype],
-                                     stream_ptr()))
+        if os.environ.get("HCTR_SKINNY_FC_FWD", "gemm") == "hip":
+            y = torch.empty((B, N), dtype=w16.dtype, device=x.device)
+            check(lib.hctr_skinny_fc_fwd(B, K, N, ptr(x), ptr(w16), ptr(b16), ptr(y),
+                                         _DT16[w16.dtype], stream_ptr()))
+        else:  # the library GEMM is the faster forward at 13 -> 512 (30 us against 43 us)
+            y = torch._addmm_activation(b16, x.to(w16.dtype), w16.t(), use_gelu=False)
         ctx.gw, ctx.gb = gw, gb
         ctx.save_for_backward(x, y)
         return y

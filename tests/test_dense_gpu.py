@@ -363,7 +363,8 @@ def test_skinny_first_layer_matches_torch(B, K, N, dtype):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
-def test_fused_mlp_skinny_first_layer_equals_the_gemm_path(monkeypatch):
+@pytest.mark.parametrize("fwd", ["gemm", "hip"])
+def test_fused_mlp_skinny_first_layer_equals_the_gemm_path(monkeypatch, fwd):
     """FusedMLP on fp32 dense features: the few-features kernels for layer 1 against the library
     GEMM path (HCTR_SKINNY_FC=0) -- same 16-bit activations up to accumulation order, same
     gradients in the flat buffer"""
@@ -379,6 +380,7 @@ def test_fused_mlp_skinny_first_layer_equals_the_gemm_path(monkeypatch):
     x = torch.rand((B, 13), device="cuda")
     gy = (torch.randn((B, 128), device="cuda") / B).bfloat16()
     assert a._skinny_first(x)
+    monkeypatch.setenv("HCTR_SKINNY_FC_FWD", fwd)
     ya = a(x)
     ya.backward(gy)
     monkeypatch.setenv("HCTR_SKINNY_FC", "0")
