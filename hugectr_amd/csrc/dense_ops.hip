@@ -10,6 +10,8 @@
 //   :671-812 (bprop) -- 4 element-wise kernels + a gemv per layer in the reference; here all layers
 //   run in one launch with x0/x_l held in registers (one wavefront per row).
 #include <hip/hip_bf16.h>
+#include <cstdlib>
+#include <cstring>
 #include <hip/hip_fp16.h>
 
 #include "block_prims.h"
@@ -1206,6 +1208,7 @@ constexpr int kSkinnyK = 16;       // padded K
 constexpr int kSkinnyBlocks = 256;
 constexpr int kSkinnyLanes = 128;  // lanes per row, 4 outputs each (N <= 512)
 constexpr int kSkinnyBwdBlock = 1024;
+constexpr bool kSkinnyBwdMfmaDefault = true;
 constexpr int kSkinnyUnroll = 2;   // rows per step and row group in the backward (x2 in flight)
 
 template <typename T>
@@ -1381,6 +1384,92 @@ __global__ void __launch_bounds__(kSkinnyBwdBlock)
           d[k] = (q == 0 ? 0.f : d[k]) + v;
         }
         d[kSkinnyK] = (q == 0 ? 0.f : d[kSkinnyK]) + dbv[j];
+      }
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.x * N * stride;
+  for (int i = threadIdx.x; i < N * stride; i += kSkinnyBwdBlock) out[i] = lds[i];
+}
+
+// The same backward on the matrix cores.  v_mfma_f32_16x16x4_f32 takes ONE f32 per lane for A and
+// for B, so nothing has to be transposed: with D[i][j] = sum_k A[i][k] B[k][j], k = 4 batch rows,
+// j = input feature (16 columns: K features, then a column of ones whose sum is db), and
+// i = 16 outputs, a lane that loaded 8 consecutive outputs of row (lane >> 4) feeds them to 8
+// instructions -- instruction t owns the outputs {8 i + t}: which outputs form a tile is free.
+// Products of 16-bit values are exact in f32; the sums are f32 in a fixed order.  A wavefront owns
+// 128 outputs x a share of the rows (8 accumulators of 4 registers), 16 rows per step in flight;
+// the wavefronts of a block that share outputs add up through LDS in a fixed order.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kMfmaUnroll = 4;  // 4-row groups per step and wavefront
+
+template <typename T>
+__global__ void __launch_bounds__(kSkinnyBwdBlock)
+    skinny_fc_bwd_mfma_kernel(size_t batch, int K, int N, const float* __restrict__ x,
+                              const T* __restrict__ dy, const T* __restrict__ y,
+                              float* __restrict__ partial) {
+  extern __shared__ float lds[];  // [N * (kSkinnyK + 1)]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kWaves = kSkinnyBwdBlock / 64;
+  const int ngroups = (N + 127) / 128;
+  const int rsets = kWaves / ngroups;
+  const int ng = wv % ngroups, rs = wv / ngroups;
+  const bool active = rs < rsets;  // wave-uniform
+  const int c = lane & 15, ri = lane >> 4;
+  const int n0 = ng * 128 + 8 * c;
+  const bool has_n = n0 < N;
+  const int n0c = has_n ? n0 : 0;
+  const int kc = c < K ? c : K - 1;
+  v4f acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; t++) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+  const size_t last = batch - 1;
+  const size_t step = (size_t)gridDim.x * rsets;
+  if (active) {
+    for (size_t g16 = (size_t)blockIdx.x * rsets + rs; g16 * 16 < batch; g16 += step) {
+      uint4 gq[kMfmaUnroll], aq[kMfmaUnroll];
+      float xv[kMfmaUnroll];
+#pragma unroll
+      for (int u = 0; u < kMfmaUnroll; u++) {
+        const size_t r = min(g16 * 16 + u * 4 + ri, last);
+        gq[u] = *reinterpret_cast<const uint4*>(dy + r * (size_t)N + n0c);
+        aq[u] = *reinterpret_cast<const uint4*>(y + r * (size_t)N + n0c);
+        xv[u] = x[r * (size_t)K + kc];
+      }
+#pragma unroll
+      for (int u = 0; u < kMfmaUnroll; u++) {
+        const bool ok = has_n && g16 * 16 + u * 4 + ri < batch;
+        const float4 g0 = cvt4_as_f32<T>(make_uint2(gq[u].x, gq[u].y));
+        const float4 g1 = cvt4_as_f32<T>(make_uint2(gq[u].z, gq[u].w));
+        const float4 a0 = cvt4_as_f32<T>(make_uint2(aq[u].x, aq[u].y));
+        const float4 a1 = cvt4_as_f32<T>(make_uint2(aq[u].z, aq[u].w));
+        const float d[8] = {(ok && a0.x > 0.f) ? g0.x : 0.f, (ok && a0.y > 0.f) ? g0.y : 0.f,
+                            (ok && a0.z > 0.f) ? g0.z : 0.f, (ok && a0.w > 0.f) ? g0.w : 0.f,
+                            (ok && a1.x > 0.f) ? g1.x : 0.f, (ok && a1.y > 0.f) ? g1.y : 0.f,
+                            (ok && a1.z > 0.f) ? g1.z : 0.f, (ok && a1.w > 0.f) ? g1.w : 0.f};
+        const float b = c < K ? round16<T>(xv[u]) : (c == K ? 1.f : 0.f);
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[t], b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // acc[t][reg] = column c of output ng * 128 + 8 * (4 * ri + reg) + t; column K carries db
+  const int stride = kSkinnyK + 1;
+  const int col = c == K ? kSkinnyK : c;
+  for (int q = 0; q < rsets; q++) {
+    if (active && rs == q && c <= K) {
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int n = ng * 128 + 8 * (4 * ri + reg) + t;
+          if (n < N) {
+            float* d = lds + (size_t)n * stride + col;
+            *d = (q == 0 ? 0.f : *d) + acc[t][reg];
+          }
+        }
       }
     }
     __syncthreads();
@@ -1890,9 +1979,30 @@ int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* d
   HCTR_REQUIRE(reinterpret_cast<uintptr_t>(dy) % 8 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0,
                "8-byte aligned activations");
   hipStream_t s = as_stream(stream);
+  const size_t lds = (size_t)n * (kSkinnyK + 1) * sizeof(float);
+  // matrix-core form: needs a spare input column for db and 16-byte rows (HCTR_SKINNY_BWD=valu|mfma)
+  const char* mode = getenv("HCTR_SKINNY_BWD");
+  const bool want_mfma = mode ? strcmp(mode, "valu") != 0 : kSkinnyBwdMfmaDefault;
+  if (want_mfma && k < kSkinnyK && n % 8 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(y) % 16 == 0) {
+    const int rsets = (kSkinnyBwdBlock / 64) / ceil_div<int>(n, 128);
+    const int blocks = (int)std::min<size_t>((size_t)kSkinnyBlocks,
+                                             ceil_div<size_t>(batch, (size_t)rsets * 16));
+    if (dtype == HCTR_EMB_BF16)
+      hipLaunchKernelGGL(skinny_fc_bwd_mfma_kernel<__hip_bfloat16>, dim3(blocks),
+                         dim3(kSkinnyBwdBlock), lds, s, batch, k, n, x, (const __hip_bfloat16*)dy,
+                         (const __hip_bfloat16*)y, workspace);
+    else
+      hipLaunchKernelGGL(skinny_fc_bwd_mfma_kernel<__half>, dim3(blocks), dim3(kSkinnyBwdBlock), lds,
+                         s, batch, k, n, x, (const __half*)dy, (const __half*)y, workspace);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(skinny_fc_finish_kernel, dim3(ceil_div<int>(n * (kSkinnyK + 1), 64)),
+                       dim3(1024), 0, s, blocks, k, n, workspace, dw, db);
+    HCTR_LAUNCH_CHECK();
+    return HCTR_OK;
+  }
   const int blocks = (int)std::min<size_t>(
       (size_t)kSkinnyBlocks, ceil_div<size_t>(batch, kSkinnyBwdBlock / kSkinnyLanes));
-  const size_t lds = (size_t)n * (kSkinnyK + 1) * sizeof(float);
   if (dtype == HCTR_EMB_BF16)
     hipLaunchKernelGGL(skinny_fc_bwd_kernel<__hip_bfloat16>, dim3(blocks), dim3(kSkinnyBwdBlock), lds, s,
                        batch, k, n, x, (const __hip_bfloat16*)dy, (const __hip_bfloat16*)y,

@@ -323,13 +323,16 @@ def test_fused_mlp_bce_head_equals_the_unfused_tower():
 
 
 @pytest.mark.parametrize("B,K,N", [(4096, 13, 512), (1000, 13, 256), (777, 16, 128), (37, 1, 4),
-                                   (9000, 7, 508)])
+                                   (9000, 7, 508), (300, 7, 136), (5000, 15, 384), (3, 13, 512)])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_skinny_first_layer_matches_torch(B, K, N, dtype):
+@pytest.mark.parametrize("bwd", ["valu", "mfma"])
+def test_skinny_first_layer_matches_torch(B, K, N, dtype, bwd, monkeypatch):
     """first MLP layer with a handful of input features: forward and the fused
-    ReLU-backward + dw + db against fp64 formulas on the same 16-bit operands"""
+    ReLU-backward + dw + db (vector-ALU and matrix-core forms; the latter falls back to the former
+    for K = 16 or N % 8 != 0) against fp64 formulas on the same 16-bit operands"""
     import torch
     from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    monkeypatch.setenv("HCTR_SKINNY_BWD", bwd)
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     code = 2 if dtype == "bf16" else 1
     g = torch.Generator(device="cuda").manual_seed(B + K + N)
