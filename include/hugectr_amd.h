@@ -479,7 +479,10 @@ int hctr_logit_head(size_t batch, int k, const void* x, const void* w, const voi
  * R/HugeCTR/src/layers/mlp_layer.cu): y = relu(x W^T + b), x fp32 [batch][K] (rounded to the 16-bit
  * type like the GEMM path), W [N][K] / bias [N] / y 16-bit, 1 <= K <= 16, N % 4 == 0, N <= 512.
  * bwd: dz = dy * (y > 0) is folded into dw[N][K] = dz^T x and db[N] = sum dz (fp32, fixed-order
- * sums); dz itself is not produced -- the first layer has no data gradient. */
+ * sums); dz itself is not produced -- the first layer has no data gradient.  Runs on the matrix
+ * cores (v_mfma_f32_16x16x4_f32) when K < 16, N % 8 == 0 and dy / y are 16-byte aligned, on the
+ * vector ALU otherwise or when the environment has HCTR_SKINNY_BWD=valu; both forms are
+ * deterministic, they differ from each other in summation order only. */
 int hctr_skinny_fc_fwd(size_t batch, int k, int n, const float* x, const void* w, const void* bias,
                        void* y, int dtype, hctr_stream_t stream);
 size_t hctr_skinny_fc_bwd_workspace_bytes(int n);
