@@ -5,7 +5,7 @@ Nothing here touches oracle/ (the CPU oracle is test infrastructure only).
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32,
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t,
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -22,7 +22,7 @@ import json
 import os
 import struct
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch

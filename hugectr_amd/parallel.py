@@ -17,8 +17,6 @@ tensors with gloo (tests/test_parallel_cpu.py).
 """
 from __future__ import annotations
 
-from typing import List
-
 import torch
 import torch.distributed as dist
 

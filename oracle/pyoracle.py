@@ -6,7 +6,7 @@ leg -- never by the product package hugectr_amd/.
 import ctypes
 import os
 import subprocess
-from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_float, c_int, c_int64, c_uint32, c_uint64, c_void_p
 
 import numpy as np
 

@@ -1,7 +1,6 @@
 """GPU parity: embedding_collection path (key routing -> keys_to_indices -> pooled lookup ->
 network forward / backward -> static-table optimizer) vs the CPU restatement of the reference's
 EmbeddingReferenceCPU (R/test/utest/embedding_collection/reference_embedding.hpp:32-237)."""
-import ctypes
 import os
 
 import numpy as np

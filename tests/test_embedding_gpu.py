@@ -1,6 +1,5 @@
 """GPU parity: sparse embedding forward / backward / update through the C ABI vs the CPU oracle.
 Forward and index stage: bit-exact.  Optimizer state/weights: rel 1e-5 (north star: 1e-3)."""
-import ctypes
 
 import numpy as np
 import pytest

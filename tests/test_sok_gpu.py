@@ -3,7 +3,6 @@ optimizer step against plain PyTorch (embedding_bag, the role tf.nn.embedding_lo
 in R/sparse_operation_kit/sparse_operation_kit/test/function_test), static and dynamic variables,
 and a 2-process run (gloo, both ranks on this one GPU) of the sharded route."""
 import os
-import sys
 
 import numpy as np
 import pytest

@@ -1,6 +1,6 @@
 """Probe: weight-gradient GEMM dW = dY^T X with K = batch = 65536 -- library call vs split-K via bmm,
 and _addmm_activation availability."""
-import torch, time
+import torch
 torch.manual_seed(0)
 dev = "cuda"
 B = 65536
