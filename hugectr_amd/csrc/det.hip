@@ -104,19 +104,6 @@ __global__ void __launch_bounds__(kBlock)
     out[i] = idx[i] != kInvalidIndex ? rows + idx[i] * (uint64_t)dim : nullptr;
 }
 
-// pointer and / or globally numbered row (row_base + row inside the class) of every key
-__global__ void __launch_bounds__(kBlock)
-    det_rows_kernel(const uint64_t* __restrict__ idx, size_t n, float* rows, int dim,
-                    uint64_t row_base, float** __restrict__ out_ptr,
-                    uint64_t* __restrict__ out_row) {
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * kBlock) {
-    const uint64_t r = idx[i];
-    if (out_ptr) out_ptr[i] = r != kInvalidIndex ? rows + r * (uint64_t)dim : nullptr;
-    if (out_row) out_row[i] = r != kInvalidIndex ? row_base + r : kInvalidIndex;
-  }
-}
-
 // ---- one launch over all id spaces of a call (instead of one hash pass per id space) -------------
 struct DetClassDesc {
   const HtEntry* tab;
