@@ -5,14 +5,22 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
  * checker / the reported CPU baseline.  The product path is hugectr_amd/csrc (HIP, gfx950).
  *
- * PARITY STATUS: the reference (R = /root/reference) stores no golden vectors for this path
- * (all its tests draw random data at run time and compare GPU vs CPU in-process) and neither its
- * product code nor its CPU test oracle can be compiled here (every TU pulls in cublas/curand/nvml/
- * mpi/nccl through HugeCTR/include/common.hpp:18-38).  What IS pinned:
- *   - the hash:  public-domain MurmurHash3_x86_32 known-answer vectors (tests/test_oracle_kat.py);
- *   - closed-form optimizer steps, layout facts and hand-worked small cases taken from the
- *     reference sources cited per function below.
- * Everything else is "parity unpinned": a line-by-line restatement checked only against itself.
+ * PARITY STATUS: the reference (R = /root/reference) stores no golden vectors for this path (all
+ * its tests draw random data at run time and compare GPU vs CPU in-process) and its product code
+ * cannot be compiled here (every TU pulls in cublas/curand/nvml/mpi/nccl through
+ * HugeCTR/include/common.hpp:18-38).  Pinned against code compiled FROM THE REFERENCE CHECKOUT
+ * (oracle/Makefile `ref` -> oracle/_ref/, built where the checkout is present):
+ *   - hash / index stage: the reference's MurmurHash3 functor and gpu_cache hashes
+ *     (tests/test_ref_hash_cpu.py), plus public MurmurHash3_x86_32 known-answer vectors;
+ *   - forward sum / mean, backward, and EVERY optimizer x Local / Global / LazyGlobal, fp32 and
+ *     fp16 outputs / state: the reference's own CPU test oracle SparseEmbeddingHashCpu
+ *     (R/test/utest/embedding/sparse_embedding_hash_cpu.hpp), compiled with a declarations-only
+ *     stand-in for common.hpp (oracle/ref_shims/) and driven over several training steps from
+ *     Norm dataset + sparse model files (tests/test_ref_embedding_cpu.py): sum forward / wgrad
+ *     bit-equal, tables within 5e-7.
+ * Not pinned that way ("parity unpinned", checked against closed forms, hand-worked cases and the
+ * independent numpy fixtures in tests/golden/): the Interaction / Cross references (the
+ * reference's are inline in CUDA-bound gtest files), the EBC references, the reorder maps.
  *
  * All functions are plain C, single-threaded unless `threads > 1` is passed where offered.
  */
