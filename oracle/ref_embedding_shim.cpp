@@ -1,5 +1,5 @@
 /* TEST INFRASTRUCTURE ONLY -- C entry points around the reference's own CPU oracle of the legacy
- * sparse embedding, SparseEmbeddingHashCpu<long long, float / __half>
+ * sparse embedding, SparseEmbeddingHashCpu<long long | unsigned, float / __half>
  * (R/test/utest/embedding/sparse_embedding_hash_cpu.hpp:52-1015), compiled from the reference
  * checkout into oracle/_ref/libref_embedding.so (oracle/Makefile, target `ref`).  One step is what
  * the reference tests drive (localized_slot_sparse_embedding_hash_test.cu:181-519): read a batch
@@ -9,9 +9,9 @@
 #include <utest/embedding/sparse_embedding_hash_cpu.hpp>
 
 namespace {
-template <typename Emb>
+template <typename Emb, typename Key = long long>
 struct Handle {
-  SparseEmbeddingHashCpu<long long, Emb> e;
+  SparseEmbeddingHashCpu<Key, Emb> e;
   int batch, slots, dim, vocab;
   template <typename... A>
   Handle(int b, int s, int d, int v, A&&... a)
@@ -19,6 +19,7 @@ struct Handle {
 };
 using H32 = Handle<float>;
 using H16 = Handle<__half>;
+using HU32 = Handle<float, unsigned int>;  // `fp16` argument == 2: u32 keys, fp32 vectors
 }  // namespace
 
 extern "C" {
@@ -43,6 +44,10 @@ void* ref_emb_create(int fp16, int batch, int max_feature_num, int vocab, int di
   p.hyperparams.nesterov.mu = momentum_or_mu;
   const Check_t chk = check_sum ? Check_t::Sum : Check_t::None;
   try {
+    if (fp16 == 2)
+      return new HU32(batch, slot_num, dim, vocab, batch, max_feature_num, vocab, dim, slot_num,
+                      label_dim, dense_dim, chk, num_records, combiner, p, std::string(file_list),
+                      std::string(model_dir), SparseEmbedding_t::Localized);
     if (fp16)
       return new H16(batch, slot_num, dim, vocab, batch, max_feature_num, vocab, dim, slot_num,
                      label_dim, dense_dim, chk, num_records, combiner, p, std::string(file_list),
@@ -57,7 +62,8 @@ void* ref_emb_create(int fp16, int batch, int max_feature_num, int vocab, int di
 }
 
 void ref_emb_destroy(void* h, int fp16) {
-  if (fp16) delete static_cast<H16*>(h);
+  if (fp16 == 2) delete static_cast<HU32*>(h);
+  else if (fp16) delete static_cast<H16*>(h);
   else delete static_cast<H32*>(h);
 }
 
@@ -65,7 +71,7 @@ void ref_emb_destroy(void* h, int fp16) {
  * [batch][slot][dim] (the fp16 instance's values widened); either may be NULL */
 int ref_emb_step(void* h, int fp16, int train, float* fwd, float* wgrad) {
   try {
-    if (fp16) {
+    if (fp16 == 1) {
       H16* o = static_cast<H16*>(h);
       const size_t n = (size_t)o->batch * o->slots * o->dim;
       o->e.forward();
@@ -77,15 +83,18 @@ int ref_emb_step(void* h, int fp16, int train, float* fwd, float* wgrad) {
         o->e.update_params();
       }
     } else {
-      H32* o = static_cast<H32*>(h);
-      const size_t n = (size_t)o->batch * o->slots * o->dim;
-      o->e.forward();
-      if (fwd) std::memcpy(fwd, o->e.get_forward_results(), n * sizeof(float));
-      if (train) {
-        o->e.backward();
-        if (wgrad) std::memcpy(wgrad, o->e.get_backward_results(), n * sizeof(float));
-        o->e.update_params();
-      }
+      auto run = [&](auto* o) {
+        const size_t n = (size_t)o->batch * o->slots * o->dim;
+        o->e.forward();
+        if (fwd) std::memcpy(fwd, o->e.get_forward_results(), n * sizeof(float));
+        if (train) {
+          o->e.backward();
+          if (wgrad) std::memcpy(wgrad, o->e.get_backward_results(), n * sizeof(float));
+          o->e.update_params();
+        }
+      };
+      if (fp16 == 2) run(static_cast<HU32*>(h));
+      else run(static_cast<H32*>(h));
     }
   } catch (const std::exception& ex) {
     std::fprintf(stderr, "ref_emb_step: %s\n", ex.what());
@@ -96,14 +105,12 @@ int ref_emb_step(void* h, int fp16, int train, float* fwd, float* wgrad) {
 
 /* the table: keys [vocab] and vectors [vocab][dim] in the oracle's row order */
 void ref_emb_table(void* h, int fp16, long long* keys, float* values) {
-  if (fp16) {
-    H16* o = static_cast<H16*>(h);
-    std::memcpy(keys, o->e.get_hash_table_key_ptr(), (size_t)o->vocab * sizeof(long long));
+  auto get = [&](auto* o) {
+    for (int i = 0; i < o->vocab; i++) keys[i] = (long long)o->e.get_hash_table_key_ptr()[i];
     std::memcpy(values, o->e.get_hash_table_value_ptr(), (size_t)o->vocab * o->dim * sizeof(float));
-  } else {
-    H32* o = static_cast<H32*>(h);
-    std::memcpy(keys, o->e.get_hash_table_key_ptr(), (size_t)o->vocab * sizeof(long long));
-    std::memcpy(values, o->e.get_hash_table_value_ptr(), (size_t)o->vocab * o->dim * sizeof(float));
-  }
+  };
+  if (fp16 == 2) get(static_cast<HU32*>(h));
+  else if (fp16) get(static_cast<H16*>(h));
+  else get(static_cast<H32*>(h));
 }
 }

@@ -176,3 +176,51 @@ def test_eval_forward_reads_on(dataset):
             assert np.array_equal(po.forward(ro, ht.get_mark(keys), table0, D, 0), fwd)
     finally:
         L.ref_emb_destroy(h, 0)
+
+
+@pytest.mark.parametrize("comb", [0, 1])
+def test_u32_keys_match_the_reference_cpu_oracle(tmp_path, comb):
+    """TypeHashKey = unsigned int: 4-byte keys in the Norm file and in the hash (the model file
+    keeps 8-byte keys, which the reference narrows on load)"""
+    L = _ref()
+    rng = np.random.default_rng(5)
+    n = B * 2
+    label = rng.random((n, 1), dtype=np.float32)
+    dense = rng.random((n, 2), dtype=np.float32)
+    cats = [rng.integers(0, V, size=(n, h)).astype(np.int64) for h in HOT]
+    write_norm(str(tmp_path / "d.bin"), label, dense, cats, i64_key=False, check_sum=True)
+    (tmp_path / "list.txt").write_text(f"1\n{tmp_path}/d.bin\n")
+    os.makedirs(tmp_path / "model")
+    mkeys = rng.permutation(V).astype(np.int64)
+    table0 = rng.uniform(-0.1, 0.1, (V, D)).astype(np.float32)
+    mkeys.tofile(tmp_path / "model" / "key")
+    table0.tofile(tmp_path / "model" / "emb_vector")
+    lr, scaler = 0.1, 1.0
+    h = L.ref_emb_create(2, B, sum(HOT), V, D, S, 1, 2, 1, n, comb, REF_OPT["adagrad"], 0, lr, scaler,
+                         0.9, 0.999, 1e-6, 0.0, str(tmp_path / "list.txt").encode(),
+                         str(tmp_path / "model").encode())
+    assert h
+    ht = po.HashTable(V, 4)
+    ht.get_insert(mkeys.astype(np.uint32))
+    table = table0.copy()
+    s0, s1 = np.zeros_like(table), np.zeros_like(table)
+    pt = np.ones(V * D, dtype=np.uint64)
+    try:
+        for st in range(2):
+            fwd = np.empty((B * S, D), np.float32)
+            wg = np.empty((B * S, D), np.float32)
+            assert L.ref_emb_step(h, 2, 1, fwd.ctypes.data, wg.ctypes.data) == 0
+            ro, keys = _batch(cats, st)
+            vi = ht.get_mark(keys.astype(np.uint32))
+            f = po.forward(ro, vi, table, D, comb)
+            w = po.backward(ro, f, D, comb)
+            o = po.OptParamsC(MY_OPT["adagrad"], 0, lr, 0.9, 0.999, 1e-6, 0.0, scaler, st + 1, 0)
+            po.update_params(ro, vi, w, o, table, s0, s1, pt)
+            rk = np.empty(V, np.int64)
+            rv = np.empty((V, D), np.float32)
+            L.ref_emb_table(h, 2, rk.ctypes.data, rv.ctypes.data)
+            assert (rk == mkeys).all()
+            assert np.allclose(f, fwd, rtol=1e-6, atol=1e-7) and np.allclose(w, wg, rtol=1e-6, atol=1e-7)
+            assert np.allclose(table, rv, rtol=0, atol=5e-7)
+    finally:
+        L.ref_emb_destroy(h, 2)
