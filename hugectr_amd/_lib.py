@@ -72,6 +72,8 @@ _SIGNATURES = {
     "hctr_emb_destroy": (c_int, [_P]),
     "hctr_emb_init_params": (c_int, [_P, _P]),
     "hctr_emb_forward": (c_int, [_P, c_int, _P, _P, c_size_t, _P, _P]),
+    "hctr_emb_forward_scale": (c_int, [_P, c_int, _P, _P]),
+    "hctr_emb_poll_overflow": (c_int, [_P, _P]),
     "hctr_emb_backward": (c_int, [_P, _P, _P]),
     "hctr_emb_get_wgrad": (c_int, [_P, _P, _P]),
     "hctr_emb_update_params": (c_int, [_P, _P]),

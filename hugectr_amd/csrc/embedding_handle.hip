@@ -9,6 +9,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "block_prims.h"
@@ -173,6 +174,35 @@ __global__ void scatter_rows_kernel(const uint64_t* __restrict__ rows, size_t n,
   }
 }
 
+// forward_scale_kernel / forward_scale_align2_kernel (forward_scale_functor.cu:28-77): the
+// distributed embedding pools with SUM, reduce-scatters, and only then divides a mean bucket by
+// its key count over all GPUs.  T = float: x * (1/n).  16-bit T with an even vector size (the
+// reference's align2 kernel): the scaler is rounded to T and the product is formed in T
+// (__hmul2), otherwise float multiply + one rounding.
+template <typename T, typename K>
+__global__ void __launch_bounds__(kBlock)
+    forward_scale_kernel(size_t buckets, int D, const K* __restrict__ ro, T* __restrict__ x) {
+  const size_t total = buckets * (size_t)D;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const size_t u = i / D;
+    const long long n = (long long)ro[u + 1] - (long long)ro[u];
+    if (n <= 1) continue;
+    const float sc = 1.0f / (float)n;
+    if constexpr (std::is_same<T, float>::value) {
+      x[i] = x[i] * sc;
+    } else if constexpr (std::is_same<T, __half>::value) {
+      const float v = __half2float(x[i]);
+      x[i] = (D % 2 == 0) ? __float2half_rn(v * __half2float(__float2half_rn(sc)))
+                          : __float2half_rn(v * sc);
+    } else {
+      const float v = __bfloat162float(x[i]);
+      x[i] = (D % 2 == 0) ? __float2bfloat16(v * __bfloat162float(__float2bfloat16(sc)))
+                          : __float2bfloat16(v * sc);
+    }
+  }
+}
+
 __global__ void iota_kernel(uint64_t* p, size_t n, uint64_t base) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x)
@@ -207,6 +237,11 @@ struct hctr_embedding {
     void* ro = nullptr;               // key-typed [buckets + 1]
     void* keys = nullptr;             // key-typed [nnz]
     uint64_t* value_index = nullptr;  // [nnz]
+    // distributed + mean on N > 1 GPUs: the unfiltered full-batch row offsets.  Their bucket
+    // lengths are what the reference gets from all_reduce(row_offsets) (the per-GPU filtered
+    // counts add up to the full counts): the divisor of forward_scale and of backward_mean
+    // (distributed_slot_sparse_embedding_hash.hpp:181-197,216-221).
+    void* ro_full = nullptr;  // key-typed [batch * slot_num + 1]
   };
   BatchBufs tb, eb;
   void*& ro = tb.ro;
@@ -217,6 +252,9 @@ struct hctr_embedding {
   uint64_t* h_nnz = nullptr;  // pinned
   hipEvent_t nnz_event = nullptr;
   bool nnz_pending = false;
+  uint32_t* h_err = nullptr;  // pinned copy of the hash table's error flags (poll_overflow)
+  hipEvent_t err_event = nullptr;
+  bool err_pending = false;
   size_t last_exact_nnz = 0;     // world > 1: exact live nnz of the previous train batch
   bool presort_enabled = true;   // HCTR_PRESORT=0 disables the side-stream sort
   size_t cur_buckets = 0;
@@ -226,6 +264,10 @@ struct hctr_embedding {
 
   size_t buckets_per_sample() const {
     return p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH ? (size_t)spg : p.slot_num;
+  }
+  // the mean's divisor comes from the full CSR, after the reduce-scatter
+  bool scale_after_reduce() const {
+    return p.embedding_type == HCTR_EMB_DISTRIBUTED_SLOT_HASH && p.world > 1 && p.combiner == 1;
   }
 };
 
@@ -237,11 +279,14 @@ int free_all(hctr_embedding* e) {
   e->prof.destroy();
   void* ptrs[] = {e->table,  e->state0,  e->state1,         e->prev_time, e->slot_id,
                   e->tb.ro,  e->tb.keys, e->tb.value_index, e->eb.ro,     e->eb.keys,
-                  e->eb.value_index,     e->lens,           e->tile_sums, e->d_nnz};
+                  e->eb.value_index,     e->lens,           e->tile_sums, e->d_nnz,
+                  e->tb.ro_full,         e->eb.ro_full};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (e->h_nnz) (void)hipHostFree(e->h_nnz);
   if (e->nnz_event) (void)hipEventDestroy(e->nnz_event);
+  if (e->h_err) (void)hipHostFree(e->h_err);
+  if (e->err_event) (void)hipEventDestroy(e->err_event);
   return HCTR_OK;
 }
 
@@ -338,6 +383,9 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   HCTR_REQUIRE(bb.ro != nullptr, "forward: batch size 0 configured for this mode");
   HCTR_TRY(filter_keys<K>(e, bb, batch, ro_in, keys_in, nnz, &ro, &keys, &buckets, s));
   if (buckets == 0) return HCTR_OK;
+  if (bb.ro_full)
+    HCTR_HIP(hipMemcpyAsync(bb.ro_full, ro_in, (batch * e->p.slot_num + 1) * sizeof(K),
+                            hipMemcpyDeviceToDevice, s));
   // the live key count of this rank is ro[buckets] (device); nnz is its host upper bound
   const K* d_live = ro + buckets;
   // widen the live count to the uint64 the hash kernels read
@@ -377,7 +425,10 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   // more keys than buckets in the full-batch CSR (host numbers) -> the flat multi-hot walk
   const size_t full_buckets = batch * (size_t)e->p.slot_num;
   const bool multi_hot = nnz > full_buckets + full_buckets / 2;
-  HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, e->p.combiner, ro,
+  // distributed on N > 1 GPUs pools partial SUMS (forward_per_gpu is called with combiner 0,
+  // distributed_slot_sparse_embedding_hash.hpp:162-170); hctr_emb_forward_scale divides later
+  const int pool_combiner = e->scale_after_reduce() ? 0 : e->p.combiner;
+  HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, pool_combiner, ro,
                                  e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype,
                                  multi_hot, s));
   e->prof.end(0, s);
@@ -491,12 +542,15 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
     HCTR_ALLOC(bb.ro, (bsz * e->buckets_per_sample() + 1) * e->key_bytes);
     HCTR_ALLOC(bb.keys, nn * e->key_bytes);
     HCTR_ALLOC(bb.value_index, nn * sizeof(uint64_t));
+    if (e->scale_after_reduce()) HCTR_ALLOC(bb.ro_full, (bsz * p.slot_num + 1) * e->key_bytes);
   }
   HCTR_ALLOC(e->lens, (e->buckets_max + 1) * e->key_bytes);
   HCTR_ALLOC(e->tile_sums, (ceil_div<size_t>(e->buckets_max + 1, kTile) + 1) * 8);
   HCTR_ALLOC(e->d_nnz, 8);
 #undef HCTR_ALLOC
   if (hipHostMalloc((void**)&e->h_nnz, 8, hipHostMallocDefault) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_err, 8, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->nnz_event, hipEventDisableTiming) != hipSuccess) {
     set_error("pinned host / event allocation failed");
     return fail(HCTR_ERR_HIP);
@@ -589,6 +643,36 @@ int hctr_emb_forward(hctr_embedding* e, int is_train, const void* row_offset, co
                                   (const long long*)keys, nnz, out, s);
 }
 
+int hctr_emb_forward_scale(hctr_embedding* e, int is_train, void* out_local,
+                           hctr_stream_t stream) {
+  HCTR_REQUIRE(e && out_local, "null pointer");
+  if (!e->scale_after_reduce()) return HCTR_OK;  // pooled with the final divisor already
+  const hctr_embedding::BatchBufs& bb = is_train ? e->tb : e->eb;
+  HCTR_REQUIRE(bb.ro_full != nullptr, "forward_scale: batch size 0 configured for this mode");
+  const size_t batch = is_train ? e->p.train_batch_size : e->p.evaluate_batch_size;
+  const size_t bpg = batch / (size_t)e->p.world;
+  const size_t buckets = bpg * e->p.slot_num, first = (size_t)e->p.rank * buckets;
+  if (buckets == 0) return HCTR_OK;
+  const int D = (int)e->p.embedding_vec_size;
+  hipStream_t s = as_stream(stream);
+  const int grid = grid_for(buckets * (size_t)D, kBlock);
+#define HCTR_FS(T, K)                                                                         \
+  hipLaunchKernelGGL((forward_scale_kernel<T, K>), dim3(grid), dim3(kBlock), 0, s, buckets, D, \
+                     (const K*)bb.ro_full + first, (T*)out_local)
+  if (e->p.key_type == HCTR_KEY_U32) {
+    if (e->p.out_dtype == HCTR_EMB_F32) HCTR_FS(float, uint32_t);
+    else if (e->p.out_dtype == HCTR_EMB_F16) HCTR_FS(__half, uint32_t);
+    else HCTR_FS(__hip_bfloat16, uint32_t);
+  } else {
+    if (e->p.out_dtype == HCTR_EMB_F32) HCTR_FS(float, long long);
+    else if (e->p.out_dtype == HCTR_EMB_F16) HCTR_FS(__half, long long);
+    else HCTR_FS(__hip_bfloat16, long long);
+  }
+#undef HCTR_FS
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
 int hctr_emb_index(hctr_embedding* e, int is_train, const void* row_offset, const void* keys,
                    size_t nnz, hctr_stream_t stream) {
   HCTR_REQUIRE(e, "null handle");
@@ -630,8 +714,9 @@ int hctr_emb_backward(hctr_embedding* e, const void* top_grad, hctr_stream_t str
 int hctr_emb_get_wgrad(hctr_embedding* e, void* wgrad, hctr_stream_t stream) {
   HCTR_REQUIRE(e && wgrad, "null pointer");
   HCTR_REQUIRE(e->top_grad, "get_wgrad() before backward()");
-  return materialize_wgrad(e->cur_buckets, (int)e->p.embedding_vec_size, e->p.combiner, e->ro,
-                           e->p.key_type, e->top_grad, wgrad, e->p.out_dtype, as_stream(stream));
+  return materialize_wgrad(e->cur_buckets, (int)e->p.embedding_vec_size, e->p.combiner,
+                           e->tb.ro_full ? e->tb.ro_full : e->ro, e->p.key_type, e->top_grad,
+                           wgrad, e->p.out_dtype, as_stream(stream));
 }
 
 int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
@@ -646,6 +731,7 @@ int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
     e->nnz_pending = false;
   }
   e->opt.times++;  // update_params(): adam.times++ before the update (…hash.hpp:346-347)
+  e->upd.scale_row_offset = e->tb.ro_full;  // NULL unless distributed + mean + N > 1
   return e->upd.update(e->cur_buckets, nnz, e->p.combiner, e->ro, e->p.key_type, e->value_index,
                        e->top_grad, e->p.out_dtype, e->opt, e->table, e->state0, e->state1,
                        e->prev_time, s);
@@ -677,6 +763,24 @@ int hctr_emb_check_overflow(hctr_embedding* e, hctr_stream_t stream) {
     // check_overflow, localized_slot_sparse_embedding_hash.hpp:552-569
     set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
     return HCTR_ERR_OVERFLOW;
+  }
+  return HCTR_OK;
+}
+
+int hctr_emb_poll_overflow(hctr_embedding* e, hctr_stream_t stream) {
+  HCTR_REQUIRE(e, "null handle");
+  hipStream_t s = as_stream(stream);
+  if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {
+    e->err_pending = false;
+    if (*e->h_err != 0u) {
+      set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
+      return HCTR_ERR_OVERFLOW;
+    }
+  }
+  if (!e->err_pending) {
+    HCTR_HIP(hipMemcpyAsync(e->h_err, e->ht.d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HCTR_HIP(hipEventRecord(e->err_event, s));
+    e->err_pending = true;
   }
   return HCTR_OK;
 }

@@ -178,7 +178,12 @@ __global__ void __launch_bounds__(1024)
     const uint64_t c0 = *d_counter;
     *d_base = c0;
     *d_new_count = carry;
-    *d_counter = c0 + carry;
+    // more unseen keys than free rows: the counter stops at the capacity, ht_assign_kernel gives
+    // the keys beyond it no row (kInvalidIndex -> they pool as zeros and are skipped by the
+    // update, like an eval miss), and error bit 1 makes check_overflow() fail as the reference's
+    // does (localized_slot_sparse_embedding_hash.hpp:552-569) -- nothing is read or written
+    // outside the [capacity] row arrays
+    *d_counter = (c0 + carry > capacity) ? capacity : c0 + carry;
     if (c0 + carry > capacity) atomicOr(d_error, 2u);
     *d_latched = 1u;
     *d_pending = 0u;
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(kBlock)
                      const uint64_t* d_n, const uint32_t* d_pending,
                      const uint32_t* __restrict__ tile_sums, size_t n_tiles,
                      const uint64_t* d_base, uint64_t* __restrict__ new_positions,
-                     SlotIdSink sink) {
+                     SlotIdSink sink, uint64_t capacity) {
   if (*d_pending == 0u) return;
   __shared__ uint32_t smem[kBlock / 64 + 1];
   const size_t nl = live_count(d_n, n);
@@ -230,10 +235,12 @@ __global__ void __launch_bounds__(kBlock)
       if (f) {
         uint64_t rank = (uint64_t)run + ex;
         uint64_t fin = base + rank;
+        if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
         tab[o & ~kPendingBit].val = fin;
         out[i] = fin;
         new_positions[rank] = (uint64_t)i;
-        if (sink.slot_id != nullptr) record_slot_id(sink, (uint64_t)i, fin);
+        if (sink.slot_id != nullptr && fin != kInvalidIndex)
+          record_slot_id(sink, (uint64_t)i, fin);
       }
       run += tot;
     }
@@ -461,7 +468,7 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
                      d_latched, d_counter, d_base, d_new_count, capacity, d_error);
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(ht_assign_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
-                     d_latched, tile_sums, n_tiles, d_base, new_positions, sink);
+                     d_latched, tile_sums, n_tiles, d_base, new_positions, sink, capacity);
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(ht_resolve_kernel, dim3(grid_for(n, kBlock, 512)), dim3(kBlock), 0, s,
                      entries, out, n, d_n, d_latched);

@@ -51,6 +51,9 @@ struct SparseUpdater {
   // presorted mode: the caller supplies the sorted (row, bucket) list (unique-row exchange)
   const uint32_t* ext_rows = nullptr;
   const uint32_t* ext_buckets = nullptr;
+  // mean combiner: CSR whose bucket lengths are the divisor, when it is not row_offset itself
+  // (distributed embedding on N > 1 GPUs: the unfiltered full-batch offsets); same offset type
+  const void* scale_row_offset = nullptr;
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;

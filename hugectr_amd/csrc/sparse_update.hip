@@ -340,12 +340,18 @@ __device__ __forceinline__ void row_store(const OptConst& o, uint64_t row, int l
   }
 }
 
+// A key that found no row (hash table overflow, or an unseen key of an index-only call) carries
+// kInvalidIndex; as a 32-bit sort key that is 0xFFFFFFFF, which create() keeps out of the legal row
+// range.  Such positions sort behind every live row and their run is dropped by every writer.
+constexpr uint64_t kNoRow = 0xFFFFFFFFull;
+
 template <int LPR>
 __device__ __forceinline__ void apply_row_vec4(const OptConst& o, uint64_t row, int l, float4 gi,
                                                float* __restrict__ table,
                                                float* __restrict__ state0,
                                                float* __restrict__ state1,
                                                unsigned long long* __restrict__ prev_time) {
+  if (row == kNoRow) return;
   RowRegs r;
   row_load<LPR>(o, row, l, r, table, state0, state1, prev_time);
   row_compute(o, gi, r);
@@ -421,7 +427,10 @@ __global__ void __launch_bounds__(kBlock)
                       const GradT* __restrict__ grad, float* __restrict__ gsum,
                       float* __restrict__ head, float* __restrict__ tail,
                       uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
-                      float* __restrict__ direct_out) {
+                      float* __restrict__ direct_out, const OffT* __restrict__ scale_ro) {
+  // scale_ro: the CSR whose bucket lengths divide a mean gradient.  The distributed embedding
+  // divides by the bucket's key count over ALL GPUs (backward() with the all-reduced row offsets,
+  // distributed_slot_sparse_embedding_hash.hpp:216-221), not by this rank's filtered count.
   // direct_out != nullptr (hctr_updater_reduce_presorted): the sum of a finished run goes to
   // direct_out[row] instead of gsum[run start] -- no apply pass is needed afterwards
   typedef typename Load4<GradT>::raw Raw;
@@ -480,9 +489,9 @@ __global__ void __launch_bounds__(kBlock)
         (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
     const uint32_t next_row0 = (uint32_t)__shfl((int)nrow[0], gshift, 64);
 #define HCTR_RUN_DST(q_)                                                                        \
-  (direct_out != nullptr                                                                        \
+  ((direct_out != nullptr && seg_row_at<NPL, ML>(mrow, (q_), gshift) != 0xFFFFFFFFu)             \
        ? direct_out + (size_t)seg_row_at<NPL, ML>(mrow, (q_), gshift) * D                       \
-       : gsum + (base + (size_t)(q_)) * D)
+       : gsum + (base + (size_t)(q_)) * D) /* a run of keys without a row has no output row */
     const bool ends_at_tile_end = end == nnz || next_row0 != cur_row;
     int q0 = 0;
     bool head_mode = false;
@@ -530,7 +539,7 @@ __global__ void __launch_bounds__(kBlock)
           bsel = (q - T) < cnt_la ? bq : b_q0;
         }
         v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
-        nb[k] = combiner == 1 ? bucket_len(row_offset, kOff32, bsel) : 1;
+        nb[k] = combiner == 1 ? bucket_len(scale_ro, kOff32, bsel) : 1;
       }
 #pragma unroll
       for (int k = 0; k < QB; k++) {
@@ -584,7 +593,7 @@ __global__ void __launch_bounds__(kBlock)
           for (int j = 1; j < NPL; j++) src = (q / ML == j) ? nbkt[j] : src;
           const uint32_t bsel = (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
           v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
-          nb[k] = combiner == 1 ? bucket_len(row_offset, kOff32, bsel) : 1;
+          nb[k] = combiner == 1 ? bucket_len(scale_ro, kOff32, bsel) : 1;
         }
 #pragma unroll
         for (int k = 0; k < QC; k++) {
@@ -638,7 +647,7 @@ __global__ void __launch_bounds__(kBlock)
       if (is_start) {
         const size_t e2 = (p / T + 2) * T;  // first position after the tile following p's tile
         const bool is_long = e2 < nnz && sorted_rows[e2] == row;
-        active = !is_long;
+        active = !is_long && (uint64_t)row != kNoRow;
       }
     }
     unsigned long long mask = __ballot(active);
@@ -837,7 +846,7 @@ __global__ void __launch_bounds__(kBlock)
                                const uint32_t* __restrict__ run_start,
                                const SortK* __restrict__ sorted_rows,
                                const uint32_t* __restrict__ sorted_buckets,
-                               const OffT* __restrict__ row_offset, int combiner, int D,
+                               const OffT* __restrict__ scale_ro, int combiner, int D,
                                const GradT* __restrict__ grad, OptConst o,
                                float* __restrict__ table, float* __restrict__ state0,
                                float* __restrict__ state1,
@@ -850,13 +859,14 @@ __global__ void __launch_bounds__(kBlock)
     const uint32_t off = run_start[r];
     const uint32_t cnt = run_start[r + 1] - off;
     const uint64_t row = (uint64_t)sorted_rows[off];
+    if (row == kNoRow) continue;
     for (int v = lane; v < D; v += 64) {
       float gi = 0.0f;
       for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t b = sorted_buckets[off + k];
         float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
         if (combiner == 1) {
-          long long n = (long long)row_offset[b + 1] - (long long)row_offset[b];
+          long long n = (long long)scale_ro[b + 1] - (long long)scale_ro[b];
           if (n > 1) {
             const float sc = 1.0f / (float)n;  // even sizes: align2 rule (16-bit scaler)
             gv = Load4<GradT>::rnd(gv * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc));
@@ -884,14 +894,16 @@ template <typename OffT, typename GradT>
 __global__ void __launch_bounds__(kBlock)
     sgd_atomic_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
                       const uint64_t* __restrict__ value_index, const GradT* __restrict__ grad,
-                      float lr_scale, float* __restrict__ table) {
+                      float lr_scale, float* __restrict__ table,
+                      const OffT* __restrict__ scale_ro) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
   for (size_t u = wave; u < buckets; u += nwaves) {
     const long long off = (long long)row_offset[u];
     const int n = (int)((long long)row_offset[u + 1] - off);
-    float sc = (combiner == 1 && n > 1) ? 1.0f / (float)n : 1.0f;
+    const int ns = (int)((long long)scale_ro[u + 1] - (long long)scale_ro[u]);
+    float sc = (combiner == 1 && ns > 1) ? 1.0f / (float)ns : 1.0f;
     if (D % 2 == 0) sc = Load4<GradT>::rnd(sc);  // align2 rule (backward_functor.cu:83-104)
     for (int v = lane; v < D; v += 64) {
       float gv = Load4<GradT>::ld1(grad + u * (size_t)D + v);
@@ -1008,6 +1020,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                  const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
                  float* state0, float* state1, uint64_t* prev_time, hipStream_t s) {
   const int D = u.D;
+  const OffT* sro = u.scale_row_offset ? (const OffT*)u.scale_row_offset : ro;
   OptConst o;
   o.optimizer = opt.optimizer;
   o.update_type = opt.update_type;
@@ -1031,7 +1044,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
     const float lr_scale = opt.lr / opt.scaler;
     hipLaunchKernelGGL((sgd_atomic_kernel<OffT, GradT>), dim3(grid_for(buckets * 64, kBlock)),
-                       dim3(kBlock), 0, s, buckets, D, combiner, ro, vi, grad, lr_scale, table);
+                       dim3(kBlock), 0, s, buckets, D, combiner, ro, vi, grad, lr_scale, table, sro);
     HCTR_LAUNCH_CHECK();
     return HCTR_OK;
   }
@@ -1073,7 +1086,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT>),                             \
                        dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,  \
                        kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail,                \
-                       u.span_list, u.span_count, direct);                                        \
+                       u.span_list, u.span_count, direct, sro);                                   \
     HCTR_LAUNCH_CHECK();                                                                          \
     if (direct == nullptr) {                                                                      \
       hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                   \
@@ -1121,7 +1134,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       HCTR_LAUNCH_CHECK();
       hipLaunchKernelGGL((update_rows_generic_kernel<OffT, SortK, GradT>),
                          dim3(grid_for(nnz * 64, kBlock)), dim3(kBlock), 0, s, u.d_num_runs,
-                         u.run_start, kout, vout, ro, combiner, D, grad, o, table,
+                         u.run_start, kout, vout, sro, combiner, D, grad, o, table,
                          state0, state1, (unsigned long long*)prev_time);
     }
     HCTR_LAUNCH_CHECK();

@@ -342,9 +342,12 @@ class RawReader:
     Linux AIO worker threads -- I/O engines are outside the scope contract, the FORMAT is not)."""
 
     def __init__(self, path: str, inp, slot_size_array, batch, rank, world, device, num_samples,
-                 float_label_dense: bool, repeat: bool, async_param=None):
+                 float_label_dense: bool, repeat: bool, async_param=None, i64_key: bool = True):
         self.inp, self.batch, self.rank, self.world, self.device = inp, batch, rank, world, device
         self.repeat = repeat
+        # keys AND row offsets carry the model's key type (solver.i64_input_key), as the
+        # reference's SparseTensor<TypeKey> does
+        self.key_dtype = torch.int64 if i64_key else torch.int32
         # two conventions exist in the reference:
         # * the multi-hot async reader (AsyncParam, split_batch.cu:28-66): the label word is ALWAYS
         #   an int32 (cast to float), dense words are floats when is_dense_float else ints fed
@@ -400,8 +403,8 @@ class RawReader:
             ro = np.concatenate([[0], np.cumsum(np.tile(hot, B))]).astype(np.int64)
             col += w
             s0 += p.slot_num
-            out["sparse"][p.top_name] = (torch.from_numpy(ro).to(self.device),
-                                         torch.from_numpy(keys).to(self.device))
+            out["sparse"][p.top_name] = (torch.from_numpy(ro).to(self.device, self.key_dtype),
+                                         torch.from_numpy(keys).to(self.device, self.key_dtype))
         return out
 
 
@@ -422,12 +425,12 @@ def make_reader(rp, inp, solver, rank, world, device):
     if fmt == "RawAsync":
         train = RawReader(rp.source[0], inp, rp.slot_size_array, solver.batchsize, rank, world,
                           device, rp.num_samples, rp.float_label_dense, solver.repeat_dataset,
-                          rp.async_param)
+                          rp.async_param, solver.i64_input_key)
         evalr = None
         if rp.eval_source and os.path.exists(rp.eval_source) and solver.batchsize_eval > 0:
             evalr = RawReader(rp.eval_source, inp, rp.slot_size_array, solver.batchsize_eval, rank,
                               world, device, rp.eval_num_samples, rp.float_label_dense, True,
-                              rp.async_param)
+                              rp.async_param, solver.i64_input_key)
         return _Readers(train, evalr)
     if fmt != "Parquet":
         # the reference's Python path rejects Norm/Raw as deprecated (add_input.cpp:318-325)

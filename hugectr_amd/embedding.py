@@ -114,6 +114,7 @@ class SparseEmbeddingHash:
         batch = self.train_batch_size if is_train else self.evaluate_batch_size
         assert row_offset.is_cuda and row_offset.is_contiguous()
         assert row_offset.numel() == batch * self.slot_num + 1, "row_offset must have batch*slots+1"
+        self._check_key_types(row_offset, keys)
         if nnz is None:
             nnz = int(keys.numel())
         if out is None:
@@ -123,9 +124,32 @@ class SparseEmbeddingHash:
                                    ptr(out), stream_ptr()))
         return out
 
+    def forward_scale(self, is_train: bool, out_local: torch.Tensor) -> torch.Tensor:
+        """SparseEmbeddingFunctors::forward_scale: the distributed embedding with combiner mean on
+        world > 1 GPUs divides AFTER the reduce-scatter, by each bucket's key count over all GPUs
+        (R/HugeCTR/include/embeddings/distributed_slot_sparse_embedding_hash.hpp:181-197).
+        out_local [batch/world, slot_num, D] = this rank's reduce-scatter output, scaled in place;
+        a no-op in every other configuration."""
+        assert out_local.is_cuda and out_local.is_contiguous() and out_local.dtype == self.out_dtype
+        batch = self.train_batch_size if is_train else self.evaluate_batch_size
+        assert out_local.numel() == batch // self.world * self.slot_num * self.embedding_vec_size
+        check(lib.hctr_emb_forward_scale(self._h, 1 if is_train else 0, ptr(out_local),
+                                         stream_ptr()))
+        return out_local
+
+    def _check_key_types(self, row_offset: torch.Tensor, keys: torch.Tensor):
+        """the C ABI takes raw pointers: keys and row offsets must have the handle's key width"""
+        want = 8 if self.key_dtype == torch.int64 else 4
+        for name, t in (("row_offset", row_offset), ("keys", keys)):
+            if t.element_size() != want or t.is_floating_point():
+                raise TypeError(f"{name} is {t.dtype}, this embedding takes "
+                                f"{'int64' if want == 8 else 'uint32 / int32'} "
+                                "(solver.i64_input_key decides)")
+
     def index(self, is_train: bool, row_offset: torch.Tensor, keys: torch.Tensor,
               nnz: Optional[int] = None):
         """index stage only (filter + hash): rows in value_index(); no gather"""
+        self._check_key_types(row_offset, keys)
         if nnz is None:
             nnz = int(keys.numel())
         check(lib.hctr_emb_index(self._h, 1 if is_train else 0, ptr(row_offset), ptr(keys), nnz,
@@ -243,6 +267,11 @@ class SparseEmbeddingHash:
 
     def check_overflow(self):
         check(lib.hctr_emb_check_overflow(self._h, stream_ptr()))
+
+    def poll_overflow(self):
+        """check_overflow without the host synchronisation: raises once a completed copy of the
+        error flags shows that the table ran out of rows (at most two calls late)"""
+        check(lib.hctr_emb_poll_overflow(self._h, stream_ptr()))
 
     def reset(self):
         check(lib.hctr_emb_reset(self._h, stream_ptr()))

@@ -376,6 +376,9 @@ def _max_vocab_from_workspace(ws_mb: int, opt: OptParamsPy, vec: int) -> int:
     states = {Optimizer_t.Adam: 2, Optimizer_t.AdaGrad: 1, Optimizer_t.MomentumSGD: 1,
               Optimizer_t.Nesterov: 1, Optimizer_t.SGD: 0, Optimizer_t.Ftrl: 2,
               Optimizer_t.RMSProp: 1}[Optimizer_t(opt.optimizer_type)]
+    if Optimizer_t(opt.optimizer_type) == Optimizer_t.Adam and \
+            Update_t(opt.update_type) == Update_t.LazyGlobal:
+        states += 1  # the per-element prev_time copy (model.cpp:189-192)
     return (ws_mb * 1024 * 1024) // ((1 + states) * 4 * vec)
 
 
@@ -469,9 +472,10 @@ class Model:
                 max_vocab = 0  # derived from the slot sizes by the library
             else:
                 assert se.workspace_size_per_gpu_in_mb > 0, "workspace_size_per_gpu_in_mb or slot_size_array"
-                max_vocab = _max_vocab_from_workspace(se.workspace_size_per_gpu_in_mb,
-                                                      se.optimizer or self.opt,
-                                                      se.embedding_vec_size)
+                max_vocab = _max_vocab_from_workspace(
+                    se.workspace_size_per_gpu_in_mb,
+                    se.optimizer if (se.optimizer is not None and se.optimizer.initialized)
+                    else self.opt, se.embedding_vec_size)
             h = SparseEmbeddingHash(int(se.embedding_type), B, Be, max_vocab, se.embedding_vec_size,
                                     p.max_feature_num(), p.slot_num, se.combiner, opt,
                                     slot_size_array=ssa, key_dtype=key_dtype,
@@ -795,7 +799,9 @@ class Model:
                 E = forward_reorder(recv, bpg, p.slot_num, se.embedding_vec_size, self.world) \
                     if self.world > 1 else pooled.view(bpg, p.slot_num, se.embedding_vec_size)
             else:
-                E = ex[mode].forward(pooled)
+                # reduce-scatter of the partial sums, then the mean's division by the bucket's
+                # key count over all GPUs (a no-op unless distributed + mean + world > 1)
+                E = h.forward_scale(train, ex[mode].forward(pooled).contiguous())
             if train:
                 E = E.detach().requires_grad_(True)
                 leaves[name] = E
@@ -827,7 +833,11 @@ class Model:
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
         if not train:
             return loss, torch.sigmoid(logit)
-        (loss * self.solver.scaler).backward()
+        # the logit gradient is (sigmoid - y) * scaler / batch_per_gpu / total_gpu_count
+        # (BinaryCrossEntropy_Kernel, R/HugeCTR/src/loss.cu:242-249): every gradient below --
+        # the embeddings' top gradients included -- is a share of the GLOBAL-batch mean, and the
+        # dense all-reduce is a plain sum
+        (loss * (self.solver.scaler / self.world)).backward()
         for name, (se, p, h, ex, localized) in self._emb.items():
             g = leaves[name].grad
             if localized:
@@ -849,7 +859,6 @@ class Model:
                 for q in self._dense_params:
                     if q.grad is not None:
                         _all_reduce(q.grad)
-                        q.grad /= self.world
             if self.solver.scaler != 1.0:
                 for q in self._dense_params:
                     if q.grad is not None:
@@ -861,11 +870,20 @@ class Model:
                     m.refresh_shadow()
         return loss, None
 
+    def check_overflow(self, blocking: bool = True):
+        """Model::check_overflow (R/HugeCTR/src/pybind/model.cpp:1088: called by every train()):
+        raises when an embedding saw more distinct keys than max_vocabulary_size_per_gpu.  train()
+        uses the non-blocking form (the flag of an earlier iteration, no host sync on the path);
+        eval / fit's end / save use the blocking one."""
+        for (_, _, h, _, _) in self._emb.values():
+            h.check_overflow() if blocking else h.poll_overflow()
+
     def train(self) -> bool:
         assert self._compiled
         batch = self.reader.next_batch(train=True)
         if batch is None:
             return False
+        self.check_overflow(blocking=False)
         loss, _ = self._run_batch(batch, True)
         self._loss_t = loss.detach()
         self._iter += 1
@@ -875,6 +893,8 @@ class Model:
         batch = self.reader.next_batch(train=False)
         if batch is None:
             return False
+        if not getattr(self, "_eval_buf", None):
+            self.check_overflow()
         with torch.no_grad():
             loss, prob = self._run_batch(batch, False)
         self._eval_buf.append((prob.detach().float().flatten(), batch["label"].float().flatten(),
@@ -986,22 +1006,48 @@ class Model:
             for tc in callbacks:  # model.cpp:991-994
                 tc.on_training_end(max(it - 1, 0))
         torch.cuda.synchronize()
+        self.check_overflow()
         if self.rank == 0:
             print(f"[HCTR][INFO] Finish {it} iterations with batchsize: {s.batchsize} in "
                   f"{time.time() - t0:.2f}s.")
 
     # -- checkpoints: directory layout of the reference (SURVEY §5 "Checkpoint / resume") ----------
     def save_params_to_files(self, prefix: str, iteration: int = 0):
+        self.check_overflow()
         for i, (name, (se, p, h, _, localized)) in enumerate(self._emb.items()):
             keys, slot, vec = h.dump_parameters()
+            # ONE directory <prefix><i>_sparse_<iter>.model with key / slot_id / emb_vector, the
+            # ranks' rows one after another in rank order -- the merged layout the reference writes
+            # (dump_parameters, localized_slot_sparse_embedding_hash.cu:1260-1340: every GPU's
+            # offset is the sum of the counts before it), so that load_sparse_weights (which keeps
+            # the keys / slots a rank owns) reads it back on any number of ranks
             d = f"{prefix}{i}_sparse_{iteration}.model"
+            n, D = int(keys.numel()), se.embedding_vec_size
+            counts = [n]
             if self.world > 1:
-                d += f".rank{self.rank}"
-            os.makedirs(d, exist_ok=True)
-            keys.cpu().numpy().astype("<i8").tofile(os.path.join(d, "key"))
+                counts = [None] * self.world
+                dist.all_gather_object(counts, n)
+            first, total = sum(counts[:self.rank]), sum(counts)
+            files = [("key", "<i8", 1, keys)]
             if localized:
-                slot.cpu().numpy().astype("<u8").tofile(os.path.join(d, "slot_id"))
-            vec.cpu().numpy().astype("<f4").tofile(os.path.join(d, "emb_vector"))
+                files.append(("slot_id", "<u8", 1, slot))
+            files.append(("emb_vector", "<f4", D, vec))
+            if self.rank == 0:
+                os.makedirs(d, exist_ok=True)
+                for fn, dt, w, _ in files:
+                    with open(os.path.join(d, fn), "wb") as f:
+                        f.truncate(total * w * np.dtype(dt).itemsize)
+            if self.world > 1:
+                dist.barrier()
+            for fn, dt, w, t in files:
+                if n == 0:
+                    continue
+                mm = np.memmap(os.path.join(d, fn), dtype=dt, mode="r+", shape=(total * w,))
+                mm[first * w:(first + n) * w] = t.cpu().numpy().astype(dt).reshape(-1)
+                mm.flush()
+                del mm
+            if self.world > 1:
+                dist.barrier()
             if h._opt_state_count():  # <prefix><i>_opt_sparse_<iter>.model (model.cpp:1244-1246)
                 h.dump_opt_states(f"{prefix}{i}_opt_sparse_{iteration}.model")
         for i, rt in enumerate(self._ebc):

@@ -164,6 +164,18 @@ int hctr_emb_init_params(hctr_embedding* emb, hctr_stream_t stream);
 int hctr_emb_forward(hctr_embedding* emb, int is_train, const void* row_offset, const void* keys,
                      size_t nnz, void* out, hctr_stream_t stream);
 
+/* SparseEmbeddingFunctors::forward_scale (R/HugeCTR/src/embeddings/forward_scale_functor.cu:28-77,
+ * called at distributed_slot_sparse_embedding_hash.hpp:181-197): distributed embedding with
+ * combiner mean on world > 1 GPUs.  hctr_emb_forward then writes partial SUMS; after the caller's
+ * reduce-scatter this divides out_local [batch/world][slot_num][D] (this rank's samples) in place
+ * by each bucket's key count over ALL GPUs (n > 1 only; 16-bit + even D: scaler rounded to the
+ * type first, the reference's align2 kernel).  The count comes from the full-batch row offsets
+ * hctr_emb_forward was given -- every rank holds them, so the reference's all_reduce(row_offsets)
+ * (all_reduce_functor.cu:55) needs no collective here.  backward / update_params divide the
+ * gradients by the same global counts (hpp:216-221).  No-op in every other configuration. */
+int hctr_emb_forward_scale(hctr_embedding* emb, int is_train, void* out_local,
+                           hctr_stream_t stream);
+
 /* IEmbedding::backward after the all-to-all: top_grad has the layout of forward's `out`.
  * Zero-copy: only records the pointer; the gradient must stay valid until update_params. */
 int hctr_emb_backward(hctr_embedding* emb, const void* top_grad, hctr_stream_t stream);
@@ -181,6 +193,13 @@ int hctr_emb_get_vocabulary_size(hctr_embedding* emb, hctr_stream_t stream, size
 size_t hctr_emb_get_max_vocabulary_size(const hctr_embedding* emb);
 size_t hctr_emb_slots_on_rank(const hctr_embedding* emb);
 int hctr_emb_check_overflow(hctr_embedding* emb, hctr_stream_t stream);
+/* IEmbedding::check_overflow as Model::train calls it on every iteration
+ * (R/HugeCTR/src/pybind/model.cpp:1088) without its host synchronisation: reports
+ * HCTR_ERR_OVERFLOW once an earlier, already completed device-to-host copy of the table's error
+ * flags shows an overflow (at most two calls late), then queues the next copy on `stream`.  Safe
+ * to be late: keys that found no free row resolve to "no row" (pooled as zeros, skipped by the
+ * update) -- nothing is read or written outside the table. */
+int hctr_emb_poll_overflow(hctr_embedding* emb, hctr_stream_t stream);
 
 /* dump_parameters / load_parameters (buffer form, R/.../localized_slot_sparse_embedding_hash.cu
  * :383-440,1260-1340): keys int64, slot_id size_t (localized), emb_vector fp32, all DEVICE

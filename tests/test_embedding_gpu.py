@@ -215,6 +215,99 @@ def test_multi_rank_partition_single_process(oracle, world, emb_type):
             assert e.slots_on_rank == S
 
 
+def _seq_sum(parts, dt):
+    """rank-order sum of the per-rank partial tensors in the embedding type (what the emulated
+    reduce-scatter of this test does: every add rounds to the type)"""
+    import torch
+    acc = parts[0].clone()
+    for q in parts[1:]:
+        acc = (acc + q).to(acc.dtype)
+    return acc
+
+
+@pytest.mark.parametrize("opt_kw", [dict(optimizer=6, atomic_update=False), dict(optimizer=6, atomic_update=True),
+                                    dict(optimizer=3)])
+@pytest.mark.parametrize("D", [16, 11])
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_mean_divides_by_the_global_count(oracle, world, dt, D, opt_kw):
+    """DistributedSlotSparseEmbeddingHash, combiner mean, N > 1 GPUs
+    (R/HugeCTR/include/embeddings/distributed_slot_sparse_embedding_hash.hpp:152-221): every GPU
+    pools partial SUMS of the keys it owns (key % N), the reduce-scatter adds them, and only then
+    forward_scale divides by the bucket's key count over all GPUs; backward divides the gathered top
+    gradient by the same global count.  Ragged multi-hot with empty and single-key buckets, all
+    shards driven from one process (collectives emulated by tensor arithmetic).  The result must be
+    the world = 1 result: fp32 within 1e-6, fp16 bit-exact against the align2 rule."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(100 * world + D)
+    B, S, hot, vps = 32, 5, 6, 40
+    V = S * vps
+    ro, keys = make_csr(rng, B, S, hot, vps)
+    tdt = torch.float32 if dt == "f32" else torch.float16
+    dense = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+    opt = ha.OptParams(lr=0.05, scaler=1.0 if dt == "f32" else 128.0, **opt_kw)
+    shards, owns = [], []
+    for r in range(world):
+        e = ha.SparseEmbeddingHash(_lib.EMB_DISTRIBUTED, B, B, V, D, S * hot, S, 1, opt,
+                                   out_dtype=tdt, rank=r, world=world)
+        kk = np.arange(V, dtype=np.int64)
+        own = kk[kk % world == r]
+        e.load_parameters(torch.from_numpy(own), None, torch.from_numpy(dense[own]))
+        shards.append(e)
+        owns.append(own)
+    n = (ro[1:] - ro[:-1]).astype(np.float32)
+    sc = np.where(n > 1, np.float32(1) / np.maximum(n, 1), np.float32(1)).astype(np.float32)
+    bpg = B // world
+    for is_train in (True, False):
+        parts = [e.forward(is_train, _t(torch, ro), _t(torch, keys)) for e in shards]
+        torch.cuda.synchronize()
+        for r, e in enumerate(shards):  # partial SUMS over the rank's keys, in key order
+            fro, fkeys = oracle.distributed_filter(ro, keys, B, S, r, world)
+            want = oracle.round_to(oracle.forward(fro, fkeys.astype(np.uint64), dense, D, 0), dt)
+            got = parts[r].float().cpu().numpy().reshape(-1, D)
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), "partial sums"
+        summed = _seq_sum(parts, dt)  # reduce-scatter(sum): rank r keeps sample slice r
+        for r, e in enumerate(shards):
+            loc = summed[r * bpg:(r + 1) * bpg].contiguous()
+            before = loc.float().cpu().numpy().reshape(-1, D)
+            e.forward_scale(is_train, loc)
+            got = loc.float().cpu().numpy().reshape(-1, D)
+            scr = sc[r * bpg * S:(r + 1) * bpg * S, None]
+            if dt == "f32":
+                want = before * scr
+            elif D % 2 == 0:
+                want = oracle.round_to(before * oracle.round_to(scr, dt), dt)
+            else:
+                want = oracle.round_to(before * scr, dt)
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), "forward_scale"
+            one = oracle.forward(ro, keys.astype(np.uint64), dense, D, 1)[r * bpg * S:(r + 1) * bpg * S]
+            assert_close(got, one, 1e-6 if dt == "f32" else 2e-3, 1e-6 if dt == "f32" else 2e-3,
+                         "distributed mean vs world = 1")
+    # backward: the all-gathered top gradient [B, S, D] reaches every rank
+    g = oracle.round_to(rng.standard_normal((B * S, D)).astype(np.float32), dt)
+    wg = oracle.backward_mixed(ro, g, D, 1, dt)  # divides by the GLOBAL count
+    table = dense.copy()
+    o = _oracle_opt(oracle, opt, 1)
+    o.state_half = 1 if dt == "f16" else 0  # q6: fp16 embeddings keep fp16-valued state
+    st = np.zeros_like(table)
+    if opt.optimizer == _lib.OPT_ADAGRAD:
+        oracle.update_params(ro, keys.astype(np.uint64), wg, o, table, st)
+    else:
+        oracle.update_params(ro, keys.astype(np.uint64), wg, o, table)
+    for r, e in enumerate(shards):
+        top = _t(torch, g).to(tdt).view(B, S, D)
+        e.backward(top)
+        got_wg = e.get_wgrad().float().cpu().numpy().reshape(-1, D)
+        assert (got_wg.view(np.uint32) == wg.view(np.uint32)).all(), "wgrad uses the global count"
+        e.update_params()
+        torch.cuda.synchronize()
+        got = e.table().cpu().numpy()[:owns[r].size]
+        tol = 1e-5 if not opt.atomic_update else 1e-4
+        assert_close(got, table[owns[r]], tol, tol, f"rank {r} table after the update")
+
+
 def test_dump_load_roundtrip(oracle):
     import torch
     import hugectr_amd as ha

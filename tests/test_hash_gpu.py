@@ -161,3 +161,51 @@ def test_overflow_is_flagged():
     emb.forward(True, ro, keys)
     with pytest.raises(ha.HugeCTRAmdError):
         emb.check_overflow()
+
+
+@pytest.mark.parametrize("D", [16, 11])
+def test_overflow_keys_get_no_row_and_nothing_is_touched_out_of_bounds(D):
+    """A table with 8 rows that meets 40 distinct keys: 8 of them get the rows 0..7 (which ones is
+    decided by who claims one of the floor(8 / 0.75) = 10 physical slots first -- the reference's
+    full table is a race too), every other key resolves to "no row" -- pooled as zeros, skipped by
+    the update, absent from the dump -- the row counter stops at the capacity, and the overflow
+    is reported by the blocking and by the polled check.  (Before: rows >= capacity were handed out
+    and read / written past the table.)"""
+    import numpy as np
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    B, S, V = 10, 4, 8
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=1.0, atomic_update=False)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, B, V, D, S, S, 0, opt)
+    emb.table().fill_(1.0)
+    ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
+    keys = torch.arange(100, 100 + B * S, dtype=torch.int64, device="cuda")
+    for it in range(2):  # second pass: the overflowed keys try again and still get nothing
+        out = emb.forward(True, ro, keys)
+        torch.cuda.synchronize()
+        vi = emb.value_index(B * S).cpu().numpy().view(np.uint64)
+        live = vi != np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert live.sum() == V and sorted(vi[live].tolist()) == list(range(V))
+        if it == 0:
+            first = vi.copy()
+        assert (vi == first).all(), "a key changed its row"
+        o = out.float().cpu().numpy().reshape(B * S, D)
+        assert (o[live] == 1.0).all() and (o[~live] == 0.0).all()
+        assert emb.get_vocabulary_size() == V
+    g = torch.ones(B, S, D, device="cuda")
+    emb.backward(g)
+    emb.update_params()
+    torch.cuda.synchronize()
+    assert (emb.table().cpu().numpy() == 0.0).all()  # 1 - lr * 1 on the 8 live rows, no more
+    k, sid, vec = emb.dump_parameters()
+    assert sorted(k.cpu().tolist()) == sorted((100 + np.nonzero(live)[0]).tolist())
+    with pytest.raises(ha.HugeCTRAmdError):
+        emb.check_overflow()
+    with pytest.raises(ha.HugeCTRAmdError):
+        for _ in range(3):  # the polled form may lag by two calls
+            emb.poll_overflow()
+            torch.cuda.synchronize()
+    # eval on the same keys: get_mark of a key that holds no row is a miss
+    out = emb.forward(False, ro, keys).float().cpu().numpy().reshape(B * S, D)
+    assert (out == 0.0).all()  # live rows were stepped to 1 - lr * 1 = 0, the rest are misses

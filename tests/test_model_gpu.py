@@ -641,3 +641,126 @@ def test_low_level_training_loop(tmp_path):
     assert lrs[-1] == pytest.approx(0.001)
     h = list(m._emb.values())[0][2]
     assert np.isfinite(m.get_current_loss()) and h.get_vocabulary_size() > 0
+
+
+# ---- N ranks == 1 rank (the embeddings' gradients must be shares of the GLOBAL-batch
+# mean, loss.cu:242-249; VERDICT r1: distributed + mean divides by the global key count) ------------
+_PAR_HOT = [3, 1, 2, 1, 4, 1, 1, 2, 1, 3, 1, 1, 1, 2, 1, 1, 1, 5, 1, 2, 1, 1, 2, 1, 1, 1]
+
+
+def _parity_model(hugectr, folder, kind, combiner, world, mixed=False):
+    solver = hugectr.CreateSolver(batchsize=256, batchsize_eval=256, lr=0.05,
+                                  vvgpu=[list(range(world))], i64_input_key=True,
+                                  max_eval_batches=1, use_mixed_precision=mixed,
+                                  scaler=128.0 if mixed else 1.0)
+    reader = hugectr.DataReaderParams(
+        data_reader_type=hugectr.DataReaderType_t.Parquet,
+        source=[os.path.join(folder, "train", "_file_list.txt")],
+        eval_source=os.path.join(folder, "val", "_file_list.txt"), slot_size_array=SIZES,
+        check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.SGD,
+                                  update_type=hugectr.Update_t.Local, atomic_update=False)
+    model = hugectr.Model(solver, reader, opt)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", _PAR_HOT, False, 26)]))
+    D, T = hugectr.DenseLayer, hugectr.Layer_t
+    localized = kind == "localized"
+    model.add(hugectr.SparseEmbedding(
+        embedding_type=(hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash if localized
+                        else hugectr.Embedding_t.DistributedSlotSparseEmbeddingHash),
+        workspace_size_per_gpu_in_mb=4, slot_size_array=SIZES if localized else [],
+        embedding_vec_size=16, combiner=combiner, sparse_embedding_name="emb", bottom_name="data1",
+        optimizer=opt))
+    model.add(D(layer_type=T.Reshape, bottom_names=["emb"], top_names=["flat"], leading_dim=26 * 16))
+    model.add(D(layer_type=T.Concat, bottom_names=["flat", "dense"], top_names=["cat"]))
+    model.add(D(layer_type=T.MLP, bottom_names=["cat"], top_names=["mlp"], num_outputs=[64, 32, 1],
+                activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Relu,
+                             hugectr.Activation_t.Non]))
+    model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp", "label"],
+                top_names=["loss"]))
+    model.compile()
+    model.load_sparse_weights([os.path.join(folder, "init_sparse")])
+    return model
+
+
+def _parity_run(model, steps):
+    losses = []
+    for _ in range(steps):
+        assert model.train()
+        losses.append(model.get_current_loss())
+    h = list(model._emb.values())[0][2]
+    k, _, v = h.dump_parameters()
+    dense = torch.cat([q.detach().flatten().float() for q in model._dense_params]).cpu()
+    return losses, k.cpu().numpy(), v.cpu().numpy(), dense.numpy()
+
+
+def _parity_worker(rank, world, port, folder, kind, combiner, steps, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hugectr_amd.hugectr as hugectr
+        model = _parity_model(hugectr, folder, kind, combiner, world)
+        losses, k, v, dense = _parity_run(model, steps)
+        # the merged checkpoint directory written by all ranks loads back into the same tables
+        model.save_params_to_files(os.path.join(folder, "ck_"), 3)
+        ret[rank] = ("ok", losses, k, v, dense)
+    except Exception as ex:
+        import traceback
+        ret[rank] = ("".join(traceback.format_exception(type(ex), ex, ex.__traceback__)),)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,combiner", [("localized", "sum"), ("localized", "mean"),
+                                           ("distributed", "sum"), ("distributed", "mean")])
+def test_two_ranks_train_like_one_rank(tmp_path, kind, combiner):
+    """The same model, initial weights and global batches on 1 rank and on 2 ranks (gloo, this one
+    GPU): after 6 SGD steps the losses, every embedding vector (as a key -> vector map) and the
+    dense weights agree to fp32 rounding.  Catches gradients that are a share of the per-GPU mean
+    instead of the global one, and a mean combiner that divides by a rank's key count."""
+    import hugectr_amd.hugectr as hugectr
+    import torch.multiprocessing as mp
+    from numpy.testing import assert_allclose
+    _gen(tmp_path, hugectr, n_train=2048, n_eval=512, nnz=_PAR_HOT)
+    rng = np.random.default_rng(3)
+    V = sum(SIZES)
+    d = tmp_path / "init_sparse"
+    d.mkdir()
+    np.arange(V, dtype="<i8").tofile(d / "key")
+    np.repeat(np.arange(26), SIZES).astype("<u8").tofile(d / "slot_id")
+    (rng.standard_normal((V, 16)) * 0.1).astype("<f4").tofile(d / "emb_vector")
+    steps = 6
+    one = _parity_run(_parity_model(hugectr, str(tmp_path), kind, combiner, 1), steps)
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000 + 13
+    procs = [ctx.Process(target=_parity_worker,
+                         args=(r, 2, port, str(tmp_path), kind, combiner, steps, ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r in range(2):
+        assert ret.get(r) is not None and ret[r][0] == "ok", ret.get(r)
+    # rank-local losses average to the global-batch loss
+    two_loss = (np.array(ret[0][1]) + np.array(ret[1][1])) / 2
+    assert_allclose(two_loss, np.array(one[0]), rtol=2e-5)
+    assert_allclose(ret[0][4], one[3], rtol=2e-4, atol=2e-6)      # dense weights
+    assert_allclose(ret[1][4], one[3], rtol=2e-4, atol=2e-6)
+    k2 = np.concatenate([ret[0][2], ret[1][2]])
+    v2 = np.concatenate([ret[0][3], ret[1][3]])
+    assert len(np.unique(k2)) == k2.size == one[1].size
+    o1, o2 = np.argsort(one[1]), np.argsort(k2)
+    assert (one[1][o1] == k2[o2]).all()
+    assert_allclose(v2[o2], one[2][o1], rtol=2e-4, atol=2e-6)
+    moved = np.abs(one[2][o1] - np.fromfile(d / "emb_vector", "<f4").reshape(V, 16)).max()
+    assert moved > 1e-4, "the embedding did not train"
+    # merged multi-rank checkpoint: one directory, every key once, same vectors
+    ck = tmp_path / "ck_0_sparse_3.model"
+    kk = np.fromfile(ck / "key", "<i8")
+    vv = np.fromfile(ck / "emb_vector", "<f4").reshape(-1, 16)
+    assert kk.size == k2.size and (np.sort(kk) == k2[o2]).all()
+    assert (vv[np.argsort(kk)] == v2[o2]).all()
