@@ -59,14 +59,53 @@ def mlp(dims, last_relu):
     return torch.nn.Sequential(*layers)
 
 
-def cpu_baseline(sizes, alpha, D, seed, budget_s=20.0):
-    """The CPU oracle (oracle/hctr_oracle.c, a line-by-line port of the reference's CPU test path
-    R/test/utest/embedding/sparse_embedding_hash_cpu.hpp) timed on this box's host cores on a
-    bounded sample of the same workload: same slot structure and key distribution, tables scaled
-    to 1/64 of the rows, B = 8192, forward + backward + SGD update (no dense tower)."""
+def cpu_baseline(sizes, alpha, D, seed, budget_s=10.0):
+    """CPU baselines on this box's host cores, on bounded samples (DESIGN.md "Measurement").
+
+    kind "reference": the REFERENCE'S OWN CPU path -- oracle/_ref/libref_embedding.so, i.e.
+    `SparseEmbeddingHashCpu` (R/test/utest/embedding/sparse_embedding_hash_cpu.hpp) compiled from
+    the reference checkout; its forward() starts with read_a_batch (:343-377), the reference's own
+    parse of the Norm dataset records, followed by hash lookup, pooling, backward and
+    update_params (:920-1015).  Single-threaded, as that code is.  Timed on (a) the bench workload's
+    shape -- 26 Criteo-1TB slots, D = 128, SGD, power-law one-hot keys, tables scaled 1/64,
+    B = 1024 -- which is `value`, and (b) BASELINE configs[0] / SURVEY C1 exactly: README DCN
+    slot sizes, B = 1024, D = 16, Adam (Global), up to 20 warm-up + 200 timed iterations inside a
+    time bound.  Its `cpu_csr_sort` (:541-561) is an O(nnz^2) odd-even transposition sort:
+    ~7e8 compare-swaps per 1024-sample batch dominate every iteration (and make B = 8192, 64x
+    that, impractical).
+
+    kind "port" (key `port`): oracle/hctr_oracle.c, the line-by-line C restatement with a stable
+    O(n log n) sort and OpenMP, embedding forward + backward + SGD only, B = 8192, tables 1/64."""
     from oracle import pyoracle as orc
+    from oracle import ref_baseline as rb
     scale = 64
     ssz = [max(1, v // scale) for v in sizes]
+    cores = os.cpu_count() or 1
+    out = {}
+    # ---- the reference's own CPU path (reader + embedding), 1 thread --------------------------
+    if rb.available():
+        c3 = rb.time_reference_cpu(ssz, 1024, D, "sgd", 0, alpha, 2, 40, budget_s, seed=seed,
+                                   lr=0.01)
+        c1 = rb.time_reference_cpu(rb.C1_SLOTS, 1024, 16, "adam", 1, 1.3, 20, 200, 4.0 * budget_s,
+                                   seed=seed + 1, lr=0.001)
+        out.update({
+            "value": c3["samples_per_s"], "unit": "samples/s", "cores": 1, "kind": "reference",
+            "sample": f"reference SparseEmbeddingHashCpu (read_a_batch + hash + forward + backward "
+                      f"+ SGD update, single-threaded as written): {c3['iters']} timed iterations "
+                      f"after {c3['warmup_iters']} warm-up, {c3['seconds']:.1f} s of CPU work, "
+                      f"B=1024, 26 Criteo-1TB slots one-hot power-law alpha={alpha}, D={D}, tables "
+                      f"scaled 1/{scale} ({c3['rows']} rows); O(nnz^2) odd-even sort inside "
+                      f"({c3['s_per_iter'] * 1e3:.0f} ms / iteration); host has {cores} logical cpus",
+            "c1_dcn_readme": {
+                "value": c1["samples_per_s"], "unit": "samples/s", "cores": 1, "kind": "reference",
+                "sample": f"BASELINE configs[0] (SURVEY C1): README DCN slot sizes "
+                          f"({c1['rows']} rows), B=1024, 26 slots one-hot power-law alpha=1.3, "
+                          f"D=16, Adam Global, {c1['warmup_iters']} warm-up + {c1['iters']} timed "
+                          f"iterations ({c1['seconds']:.1f} s; the target 20 + 200 is cut by the "
+                          f"time bound), reader + embedding fwd/bwd/update, no dense tower",
+                "ms_per_iteration": c1["s_per_iter"] * 1e3},
+        })
+    # ---- the port (restated oracle), embedding only, 1 and many threads -------------------------
     V, S, B = sum(ssz), len(ssz), 8192
     rng = np.random.default_rng(seed)
     table = (rng.random((V, D), dtype=np.float32) - 0.5) * 0.1
@@ -74,7 +113,6 @@ def cpu_baseline(sizes, alpha, D, seed, budget_s=20.0):
     g = rng.standard_normal((B * S, D)).astype(np.float32)
     opt = orc.OptParamsC()
     opt.optimizer, opt.update_type, opt.lr, opt.scaler, opt.times = orc.OPT_SGD, 0, 0.01, 1.0, 1
-    cores = os.cpu_count() or 1
     threads = min(cores, 64)
     res = {}
     for label, th in (("1t", 1), ("mt", threads)):
@@ -91,82 +129,34 @@ def cpu_baseline(sizes, alpha, D, seed, budget_s=20.0):
             res.setdefault(label, []).append(time.perf_counter() - t1)
             n += 1
     best = {k: B / float(np.median(v)) for k, v in res.items()}
-    return {"value": best["mt"], "unit": "samples/s", "cores": threads, "kind": "port",
+    port = {"value": best["mt"], "unit": "samples/s", "cores": threads, "kind": "port",
             "value_1_thread": best["1t"],
             "sample": f"{len(res['1t'])} + {len(res['mt'])} batches (1 thread + {threads} threads, "
                       f"{sum(res['1t']) + sum(res['mt']):.1f} s of CPU work): "
-                      f"embedding fwd+bwd+SGD update only (no dense tower), B={B}, 26 Criteo-1TB "
-                      f"slots one-hot power-law alpha={alpha}, D={D}, tables scaled 1/{scale} "
-                      f"({V} rows), host has {cores} logical cpus"}
+                      f"embedding fwd+bwd+SGD update only (no reader, no dense tower), B={B}, 26 "
+                      f"Criteo-1TB slots one-hot power-law alpha={alpha}, D={D}, tables scaled "
+                      f"1/{scale} ({V} rows), host has {cores} logical cpus"}
+    if out:
+        out["port"] = port
+        return out
+    return port  # oracle/_ref absent (it is built where the reference checkout is present)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=65536,
-                    help="batch PER GPU (BASELINE config 3: 65536); weak scaling: global = N * batch")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="capture the per-sub-batch dense tower (bottom MLP, interaction, top MLP, "
-                         "loss, backward) in a HIP graph; auto = when chunks > 1")
-    ap.add_argument("--chunks", type=int, default=0,
-                    help="sub-batches per step whose all-to-all overlaps the dense tower of the "
-                         "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
-                         "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
-                         "is what the overlap could save at N = 8, so no split is the default")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique", "unique16"],
-                    help="multi-GPU payload of the embedding exchange: rows = one pooled vector / "
-                         "gradient per (sample, slot) as the reference; unique = every distinct row "
-                         "once per destination + per-row gradient sums "
-                         "(hugectr_amd/unique_exchange.py), sums on the wire in fp32; unique16 = "
-                         "the same with the sums in the pooled vectors' 16-bit type (the precision "
-                         "class of the per-sample gradients the rows payload ships; opt-in); auto = "
-                         "time rows and unique during warm-up and keep the faster")
-    ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
-    ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--table-scale", type=float, default=1.0)
-    ap.add_argument("--nbatches", type=int, default=8)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dense-dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--sgd-atomic", action="store_true")
-    ap.add_argument("--emb-dtype", default="bf16", choices=["bf16", "fp32"],
-                    help="type of the pooled vectors / top gradients (tables, accumulation and the "
-                         "sparse optimizer are always fp32).  bf16 = the reference's mixed-precision "
-                         "mode (use_mixed_precision: fp16 embedding output) with bf16.")
-    ap.add_argument("--tunable", default="auto", choices=["auto", "tune", "off"],
-                    help="dense-tower GEMM solution selection through PyTorch TunableOp: auto = use "
-                         "the committed hugectr_amd/tuning/tunableop_gfx950.csv if present (no "
-                         "tuning at run time); tune = search during warm-up (outside the timed "
-                         "region) and write --tunable-file; off = library heuristics")
-    ap.add_argument("--tunable-file", default=os.path.join(ROOT, "hugectr_amd", "tuning",
-                                                           "tunableop_gfx950.csv"))
-    a = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
-            # functional check of the N > 1 orchestration with all ranks on ONE GPU (collectives
-            # staged through the host); never used for measurements
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
+def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
+    """one measurement of the DLRM Criteo-1TB step at `precision` (see --precision); returns the
+    JSON object of that leg.  Builds (and releases) its own embedding: the 89.5 GiB table exists
+    once at a time."""
     import hugectr_amd as ha
     from hugectr_amd import _lib
     from hugectr_amd.parallel import LocalizedExchange
     from hugectr_amd.parallel import all_reduce as par_all_reduce
 
+    # precision -> (pooled-vector type, dense-tower type, loss scaler)
+    edt, ddt, scaler = {"fp16": (torch.float16, torch.float16, 1024.0),
+                        "bf16": (torch.bfloat16, torch.bfloat16, 1.0),
+                        "fp32": (torch.float32, torch.float32, 1.0)}[precision]
+    esz = 2 if edt != torch.float32 else 4
+    amp = ddt != torch.float32
     sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
     S, D = len(sizes), a.dim
     Bl = a.batch                     # samples per GPU per step (fixed: weak scaling)
@@ -182,9 +172,7 @@ def main():
     max_rows = max(sum(v for i, v in enumerate(sizes) if i % world == r) for r in range(world))
 
     # ---- the embedding (this rank's slots), SGD as in the reference DLRM samples -----------------
-    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.sgd_atomic, scaler=1.0)
-    edt = torch.bfloat16 if a.emb_dtype == "bf16" else torch.float32
-    esz = 2 if a.emb_dtype == "bf16" else 4
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.sgd_atomic, scaler=scaler)
     emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, max_rows, D, S, S, 0, opt,
                                  slot_size_array=sizes, out_dtype=edt, rank=rank, world=world,
                                  seed=1234)
@@ -204,10 +192,8 @@ def main():
     set_mode(mode["name"])
 
     # ---- synthetic data, resident in HBM before the timed region ---------------------------------
-    rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
     ro = torch.arange(0, B * S + 1, dtype=torch.int64, device=dev)
-    key_batches = [torch.from_numpy(make_keys(rng, B, sizes, a.alpha)).to(dev)
-                   for _ in range(a.nbatches)]
+    key_batches = shared["keys"]
     g = torch.Generator(device=dev)
     g.manual_seed(99 + rank)
     dense_batches = [torch.rand((Bl, DENSE_DIM), device=dev, generator=g) for _ in range(a.nbatches)]
@@ -217,11 +203,10 @@ def main():
     # ---- dense tower (PyTorch-ROCm / hipBLASLt GEMMs; interaction is our HIP kernel) ---------------
     torch.manual_seed(7)
     n_ins = S + 1
-    amp = a.dense_dtype == "bf16"
     if amp:
         from hugectr_amd.dense import FusedMLP, bce_with_logits
-        bottom = FusedMLP([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
-        top = FusedMLP([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
+        bottom = FusedMLP([DENSE_DIM] + BOTTOM, last_relu=True, dtype=ddt).to(dev)
+        top = FusedMLP([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False, dtype=ddt).to(dev)
     else:
         bottom = mlp([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
         top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
@@ -267,12 +252,12 @@ def main():
         z = ha.interaction(xb.to(edt), E)
         if amp and head_fused:
             # last layer + BCE + their backward in one pass over the last hidden activations
-            loss = top.forward_bce(z, label_k, 1.0 / (Bc * C))
+            loss = top.forward_bce(z, label_k, scaler / (Bc * C))
             loss.backward()
             return loss.detach() / C
         logit = top(z)
         if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
-            loss, dlogit = bce_with_logits(logit, label_k, 1.0 / (Bc * C))
+            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bc * C))
             logit.backward(dlogit)
             return loss / C
         loss = loss_fn(logit.float(), label_k) / C
@@ -311,10 +296,14 @@ def main():
             dense_opt.zero_grad(set_to_none=True)
 
     def dense_update():
-        if flat_mode:
-            bottom.sgd_step(0.01)
-            top.sgd_step(0.01)
+        if flat_mode:  # w -= lr * g / scaler (the loss scaler leaves the gradients here)
+            bottom.sgd_step(0.01, 1.0 / scaler)
+            top.sgd_step(0.01, 1.0 / scaler)
             return
+        if scaler != 1.0:
+            for q in dense_params:
+                if q.grad is not None:
+                    q.grad /= scaler
         dense_opt.step()
         dense_opt.zero_grad(set_to_none=(graph is None))
         if amp:
@@ -354,7 +343,7 @@ def main():
             ux.prefetch(ro, nxt)
             z = ha.interaction_indexed(xb.to(edt), rows, row_of, on_emb_grad=ux.backward_begin)
             logit = top(z)
-            loss, dlogit = bce_with_logits(logit, label_k, 1.0 / Bl)
+            loss, dlogit = bce_with_logits(logit, label_k, scaler / Bl)
             logit.backward(dlogit)
         else:
             sent = {}
@@ -471,7 +460,7 @@ def main():
         set_mode(min(timing, key=timing.get))
         mode["timing_ms"] = {k: v * 1e3 for k, v in timing.items()}
     pool_prof = emb.profile().get("gather_pool", (0.0, 0))
-    for i in range(a.warmup):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     if a.tunable == "tune":
@@ -494,7 +483,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loss = None
-    for i in range(a.warmup, a.warmup + a.steps):
+    for i in range(warmup, warmup + steps):
         loss = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -529,12 +518,17 @@ def main():
 
     out = {
         "metric": "samples/sec (whole node) + embedding-gather HBM GB/s, DLRM Criteo-1TB",
-        "value": B * a.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
+        "value": B * steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 tables/accumulate/sparse SGD, " +
-                  ("bf16 pooled vectors+grads, " if a.emb_dtype == "bf16" else "f32 pooled vectors, ") +
-                  ("bf16 dense GEMMs" if amp else "f32 dense")),
+        "dtype": {"fp16": "fp16 = the reference's mixed precision (use_mixed_precision, scaler 1024): "
+                          "fp16 pooled vectors + top gradients + dense GEMMs (fp32 accumulate), "
+                          "fp32 tables / pooling accumulation / sparse SGD, loss scaling",
+                  "fp32": "fp32 = the reference's default: fp32 tables, pooled vectors, gradients, "
+                          "sparse SGD and dense GEMMs (interaction: fp32 I/O, 3x bf16-split MFMA)",
+                  "bf16": "bf16 (not a reference mode): bf16 pooled vectors + top gradients + dense "
+                          "GEMMs, fp32 tables / pooling accumulation / sparse SGD"}[precision],
+        "precision": precision,
         "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
         "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
                                "LocalizedSlotSparseEmbeddingHash, emb_dim=128, bs=65536 per GPU, SGD",
@@ -550,10 +544,285 @@ def main():
                      "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3},
         "stage_us_per_step": stage_us,
     }
+    del emb, ux, exch, pooled, top_grad, bottom, top, dense_params, dense_opt
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+# R/README.md:72-74 (DCN quick start) and R/samples/deepfm/deepfm_parquet.py:33-60
+C1_SLOTS = [39884, 39043, 17289, 7420, 20263, 3, 7120, 1543, 39884, 39043, 17289, 7420, 20263, 3,
+            7120, 1543, 63, 63, 39884, 39043, 17289, 7420, 20263, 3, 7120, 1543]
+C2_SLOTS = [203931, 18598, 14092, 7012, 18977, 4, 6385, 1245, 49, 186213, 71328, 67288, 11, 2168,
+            7338, 61, 4, 932, 15, 204515, 141526, 199433, 60919, 9137, 71, 34]
+
+
+class _CycleReader:
+    """batches already resident in HBM (the bench contract), handed out round robin"""
+
+    def __init__(self, batches):
+        self.b, self.i = batches, 0
+
+    def next_batch(self, train: bool):
+        self.i += 1
+        return self.b[(self.i - 1) % len(self.b)]
+
+    def has_eval(self):
+        return False
+
+
+def small_config_leg(cfg, steps, warmup, dev):
+    """BASELINE configs[0] (c1: the README's DCN on its synthetic Parquet data, bs 1024) and
+    configs[1] (c2: DeepFM, Criteo-Kaggle slot sizes, DistributedSlotSparseEmbeddingHash, D = 16,
+    bs 16384) -- the reference's own scripts (R/README.md:59-150, R/samples/deepfm/
+    deepfm_parquet.py) written against the `hugectr` surface of this repo; data generated by
+    hugectr.tools.DataGenerator, read once through the Parquet reader and then served from HBM.
+    One step = Model.train(): embedding forward, dense tower forward + backward, sparse Adam
+    (Global) update, dense Adam step."""
+    import shutil
+    import tempfile
+    import hugectr_amd.hugectr as hugectr
+    c1 = cfg == "c1"
+    slots = C1_SLOTS if c1 else C2_SLOTS
+    B, D, nb = (1024, 16, 16) if c1 else (16384, 16, 8)
+    i64 = not c1  # the README generates u32 keys (i64_input_key = False), the DeepFM sample i64
+    tmp = tempfile.mkdtemp(prefix=f"hctr_bench_{cfg}_")
+    try:
+        hugectr.tools.DataGenerator(hugectr.tools.DataGeneratorParams(
+            format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=13, num_slot=26,
+            i64_input_key=i64, source=os.path.join(tmp, "train", "_file_list.txt"),
+            eval_source="", slot_size_array=slots, dist_type=hugectr.Distribution_t.PowerLaw,
+            power_law_type=hugectr.PowerLaw_t.Short, num_files=1, eval_num_files=0,
+            num_samples_per_file=B * nb, num_samples=B * nb, eval_num_samples=0)).generate()
+        solver = hugectr.CreateSolver(max_eval_batches=1, batchsize_eval=B, batchsize=B, lr=0.001,
+                                      vvgpu=[[0]], repeat_dataset=True, i64_input_key=i64)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.Parquet,
+            source=[os.path.join(tmp, "train", "_file_list.txt")], eval_source="",
+            slot_size_array=slots, check_type=hugectr.Check_t.Non)
+        optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.Adam,
+                                            update_type=hugectr.Update_t.Global, beta1=0.9,
+                                            beta2=0.999, epsilon=1e-7)
+        m = hugectr.Model(solver, reader, optimizer)
+        L, T = hugectr.DenseLayer, hugectr.Layer_t
+        m.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", 1, True, 26)]))
+        m.add(hugectr.SparseEmbedding(
+            embedding_type=hugectr.Embedding_t.DistributedSlotSparseEmbeddingHash,
+            workspace_size_per_gpu_in_mb=75 if c1 else 300, embedding_vec_size=D, combiner="sum",
+            sparse_embedding_name="sparse_embedding1", bottom_name="data1", optimizer=optimizer))
+        if c1:  # R/README.md:116-146
+            m.add(L(layer_type=T.Reshape, bottom_names=["sparse_embedding1"], top_names=["reshape1"],
+                    leading_dim=416))
+            m.add(L(layer_type=T.Concat, bottom_names=["reshape1", "dense"], top_names=["concat1"]))
+            m.add(L(layer_type=T.MultiCross, bottom_names=["concat1"], top_names=["multicross1"],
+                    num_layers=6))
+            m.add(L(layer_type=T.InnerProduct, bottom_names=["concat1"], top_names=["fc1"],
+                    num_output=1024))
+            m.add(L(layer_type=T.ReLU, bottom_names=["fc1"], top_names=["relu1"]))
+            m.add(L(layer_type=T.Dropout, bottom_names=["relu1"], top_names=["dropout1"],
+                    dropout_rate=0.5))
+            m.add(L(layer_type=T.Concat, bottom_names=["dropout1", "multicross1"],
+                    top_names=["concat2"]))
+            m.add(L(layer_type=T.InnerProduct, bottom_names=["concat2"], top_names=["fc2"],
+                    num_output=1))
+            m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["fc2", "label"],
+                    top_names=["loss"]))
+        else:  # R/samples/deepfm/deepfm_parquet.py:111-300 with embedding_vec_size 16
+            m.add(L(layer_type=T.Reshape, bottom_names=["sparse_embedding1"], top_names=["reshape1"],
+                    leading_dim=D))
+            m.add(L(layer_type=T.Slice, bottom_names=["reshape1"], top_names=["slice11", "slice12"],
+                    ranges=[(0, D - 1), (D - 1, D)]))
+            m.add(L(layer_type=T.Reshape, bottom_names=["slice11"], top_names=["reshape2"],
+                    leading_dim=26 * (D - 1)))
+            m.add(L(layer_type=T.Reshape, bottom_names=["slice12"], top_names=["reshape3"],
+                    leading_dim=26))
+            m.add(L(layer_type=T.WeightMultiply, bottom_names=["dense"],
+                    top_names=["weight_multiply1"], weight_dims=[13, D - 1]))
+            m.add(L(layer_type=T.WeightMultiply, bottom_names=["dense"],
+                    top_names=["weight_multiply2"], weight_dims=[13, 1]))
+            m.add(L(layer_type=T.Concat, bottom_names=["reshape2", "weight_multiply1"],
+                    top_names=["concat1"]))
+            prev = "concat1"
+            for i in (1, 2, 3):
+                m.add(L(layer_type=T.InnerProduct, bottom_names=[prev], top_names=[f"fc{i}"],
+                        num_output=400))
+                m.add(L(layer_type=T.ReLU, bottom_names=[f"fc{i}"], top_names=[f"relu{i}"]))
+                m.add(L(layer_type=T.Dropout, bottom_names=[f"relu{i}"], top_names=[f"dropout{i}"],
+                        dropout_rate=0.5))
+                prev = f"dropout{i}"
+            m.add(L(layer_type=T.InnerProduct, bottom_names=[prev], top_names=["fc4"], num_output=1))
+            m.add(L(layer_type=T.FmOrder2, bottom_names=["concat1"], top_names=["fmorder2"],
+                    out_dim=D - 1))
+            m.add(L(layer_type=T.ReduceSum, bottom_names=["fmorder2"], top_names=["reducesum1"],
+                    axis=1))
+            m.add(L(layer_type=T.Concat, bottom_names=["reshape3", "weight_multiply2"],
+                    top_names=["concat2"]))
+            m.add(L(layer_type=T.ReduceSum, bottom_names=["concat2"], top_names=["reducesum2"],
+                    axis=1))
+            m.add(L(layer_type=T.Add, bottom_names=["fc4", "reducesum1", "reducesum2"],
+                    top_names=["add"]))
+            m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["add", "label"],
+                    top_names=["loss"]))
+        m.compile()
+        batches = [m.reader.next_batch(True) for _ in range(nb)]
+        m.reader = _CycleReader(batches)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    h = list(m._emb.values())[0][2]
+    for _ in range(warmup):
+        m.train()
+    torch.cuda.synchronize()
+    h.profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = h.profile()
+    h.profiling(False)
+    m.check_overflow()
+    K = 8 if i64 else 4
+    nnz = B * 26
+    alg = nnz * (K + 8 + D * 4) + nnz * D * 4
+    pool_ms, pool_n = prof["gather_pool"]
+    ach = alg / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
+    return {
+        "metric": "samples/sec, " + ("DCN README synthetic (BASELINE configs[0])" if c1 else
+                                     "DeepFM Criteo-Kaggle shape, D=16 (BASELINE configs[1])"),
+        "value": B * steps / el, "unit": "samples/s", "n_gpus": 1, "steps": steps,
+        "warmup": warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32 (reference default: fp32 tables, vectors, dense tower)",
+        "data": "synthetic power-law alpha=1.3 (hugectr.tools.DataGenerator, PowerLaw_t.Short), "
+                "one-hot, resident in HBM",
+        "config": {"workload": ("BASELINE configs[0]: DCN, README synthetic slot sizes, "
+                                "DistributedSlotSparseEmbeddingHash, D=16, bs=1024, Adam Global"
+                                if c1 else
+                                "BASELINE configs[1]: DeepFM, Criteo-Kaggle slot sizes, "
+                                "DistributedSlotSparseEmbeddingHash, D=16, bs=16384, Adam Global"),
+                   "surface": "hugectr_amd.hugectr Model.train()", "batch": B, "slots": 26,
+                   "emb_dim": D, "table_rows_total": int(sum(slots)),
+                   "max_vocabulary_size_per_gpu": h.get_max_vocabulary_size(),
+                   "final_loss": m.get_current_loss()},
+        "roofline": {"bound": "hbm", "kernel": "gather + pool (64-byte rows)",
+                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "launches": pool_n,
+                     "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3},
+        "stage_us_per_step": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=65536,
+                    help="batch PER GPU (BASELINE config 3: 65536); weak scaling: global = N * batch")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the per-sub-batch dense tower (bottom MLP, interaction, top MLP, "
+                         "loss, backward) in a HIP graph; auto = when chunks > 1")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="sub-batches per step whose all-to-all overlaps the dense tower of the "
+                         "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
+                         "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
+                         "is what the overlap could save at N = 8, so no split is the default")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique", "unique16"],
+                    help="multi-GPU payload of the embedding exchange: rows = one pooled vector / "
+                         "gradient per (sample, slot) as the reference; unique = every distinct row "
+                         "once per destination + per-row gradient sums "
+                         "(hugectr_amd/unique_exchange.py), sums on the wire in fp32; unique16 = "
+                         "the same with the sums in the pooled vectors' 16-bit type (the precision "
+                         "class of the per-sample gradients the rows payload ships; opt-in); auto = "
+                         "time rows and unique during warm-up and keep the faster")
+    ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--table-scale", type=float, default=1.0)
+    ap.add_argument("--nbatches", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sgd-atomic", action="store_true")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "bf16"],
+                    help="precision of the MAIN line.  fp16 = the reference's mixed precision "
+                         "(use_mixed_precision=True, scaler=1024: fp16 pooled vectors / top "
+                         "gradients / dense GEMMs, loss scaling; the MLPerf DLRM configuration of "
+                         "the reference), fp32 = the reference's default (everything fp32), bf16 = "
+                         "not a reference mode (MI355X-native 16-bit type, no loss scaling).  "
+                         "Tables, pooling accumulation and the sparse optimizer are fp32 in all "
+                         "three.")
+    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all"],
+                    help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
+                         "other two precisions on the same workload and BASELINE configs[0] / [1] "
+                         "(DCN README, DeepFM Criteo-Kaggle, D = 16) through the hugectr surface; "
+                         "auto = all of them when --config c3 runs on one GPU")
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"],
+                    help="c3 = BASELINE configs[2], DLRM Criteo-1TB (the metric's configuration); "
+                         "c1 / c2 = configs[0] / [1] as the main line")
+    ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--tunable", default="auto", choices=["auto", "tune", "off"],
+                    help="dense-tower GEMM solution selection through PyTorch TunableOp: auto = use "
+                         "the committed hugectr_amd/tuning/tunableop_gfx950.csv if present (no "
+                         "tuning at run time); tune = search during warm-up (outside the timed "
+                         "region) and write --tunable-file; off = library heuristics")
+    ap.add_argument("--tunable-file", default=os.path.join(ROOT, "hugectr_amd", "tuning",
+                                                           "tunableop_gfx950.csv"))
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
+            # functional check of the N > 1 orchestration with all ranks on ONE GPU (collectives
+            # staged through the host); never used for measurements
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    if a.config != "c3":
+        out = small_config_leg(a.config, a.steps, a.warmup, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
+    sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
+    shared = {"keys": [torch.from_numpy(make_keys(rng, a.batch * world, sizes, a.alpha)).to(dev)
+                       for _ in range(a.nbatches)]}
+    out = dlrm_leg(a, a.precision, a.steps, a.warmup, world, rank, dev, shared)
+    if rank == 0 and world == 1 and a.extra != "none":
+        extra = {}
+        for prec in ("fp32", "fp16", "bf16"):
+            if prec == a.precision:
+                continue
+            try:
+                leg = dlrm_leg(a, prec, a.extra_steps, max(a.nbatches, 4), world, rank, dev, shared)
+                extra[prec] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup",
+                                                   "dtype", "roofline", "stage_us_per_step")}
+                extra[prec]["final_loss"] = leg["config"]["final_loss"]
+            except Exception as e:  # an extra leg never takes the main line down
+                extra[prec] = {"error": repr(e)}
+        for cfg in ("c1", "c2"):
+            try:
+                extra[cfg] = small_config_leg(cfg, 50, 20, dev)
+            except Exception as e:
+                extra[cfg] = {"error": repr(e)}
+        out["extra"] = extra
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(CRITEO_1TB, a.alpha, D, 4321)
+                out["cpu_baseline"] = cpu_baseline(CRITEO_1TB, a.alpha, a.dim, 4321)
             except Exception as e:  # the oracle is a reported baseline, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

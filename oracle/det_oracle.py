@@ -3,8 +3,10 @@ oracle/): det::DynamicEmbeddingTable semantics
 (R/third_party/dynamic_embedding_table/dynamic_embedding_table.cu:129-260,
 cuCollections/include/cuco/detail/dynamic_map_kernels.cuh:100-260) and the optimizer formulas of
 R/HugeCTR/embedding_storage/optimizers.cuh:29-233, as plain Python dicts + numpy float32.
-Parity unpinned (the reference cannot run here and seeds its random initializer from
-std::random_device); constant initializers and all optimizer steps are exact restatements."""
+The optimizer steps and the lookup / update flow are PINNED against the reference's own CPU mirror
+of the table (R/HugeCTR/embedding_storage/dynamic_embedding_cpu.hpp + optimizers.hpp compiled into
+oracle/_ref/libref_det.so; tests/test_ref_det_cpu.py).  The random initializer stays unpinned (the
+reference seeds it from std::random_device); constant initializers are exact."""
 import numpy as np
 
 f32 = np.float32
@@ -57,7 +59,9 @@ def update(weights: DetOracle, states: DetOracle, opt, keys, id_spaces, offsets,
     """dynamic_embedding.cu:176-330: state lookup (zeros), per-element formula, scatter_add"""
     lr, scaler = f32(lr), f32(scaler)
     b1, b2, eps, mom, rb = f32(beta1), f32(beta2), f32(eps), f32(momentum), f32(rms_beta)
-    bias = f32(np.sqrt(1.0 - float(beta2) ** times) / (1.0 - float(beta1) ** times))
+    # AdamOptHyperParams::bias() (optimizer.hpp:58-60): std::pow(float beta, uint64 times) promotes
+    # the FLOAT beta to double -- 0.999f, not 0.999 (found by pinning against the reference build)
+    bias = f32(np.sqrt(1.0 - float(b2) ** times) / (1.0 - float(b1) ** times))
     lr_scaled_bias = lr * bias
     l2b = f32(lambda2) + f32(ftrl_beta) / lr
     pos = 0

@@ -44,7 +44,13 @@ typedef struct DataSetHeader_ {
 } DataSetHeader;
 
 struct FtrlOptHyperParams { float beta = 0.f, lambda1 = 0.f, lambda2 = 0.f; };
-struct AdamOptHyperParams { uint64_t times = 0; float beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-7f; };
+struct AdamOptHyperParams {
+  uint64_t times = 0; float beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-7f;
+  // optimizer.hpp:58-60 (used by the dynamic-table CPU mirror, oracle/ref_det_shim.cpp)
+  inline float bias() const {
+    return std::sqrt(1 - std::pow(beta2, times)) / (1 - std::pow(beta1, times));
+  }
+};
 struct RMSPropOptHyperParams { float beta = 0.9f, epsilon = 1e-7f; };
 struct AdaGradOptHyperParams { float initial_accu_value = 0.f, epsilon = 1e-7f; };
 struct MomentumSGDOptHyperParams { float factor = 0.1f; };
@@ -65,6 +71,19 @@ struct OptParams {
   OptHyperParams hyperparams;
   Update_t update_type{Update_t::Local};
   float scaler{};
+  // state vectors per weight: optimizer.hpp:30-140 (`num_parameters_per_weight` of each
+  // hyper-parameter struct: Ftrl 2, Adam 2, RMSProp / AdaGrad / MomentumSGD / Nesterov 1, SGD 0)
+  inline size_t num_parameters_per_weight() const {
+    switch (optimizer) {
+      case Optimizer_t::Ftrl:
+      case Optimizer_t::Adam: return 2;
+      case Optimizer_t::RMSProp:
+      case Optimizer_t::AdaGrad:
+      case Optimizer_t::MomentumSGD:
+      case Optimizer_t::Nesterov: return 1;
+      default: return 0;
+    }
+  }
 };
 
 }  // namespace HugeCTR

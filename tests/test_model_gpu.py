@@ -27,7 +27,8 @@ def _gen(tmp_path, hugectr, n_train=8192, n_eval=2048, nnz=None):
     import pyarrow.parquet as pq
     for f in glob.glob(str(tmp_path / "*" / "*.parquet")):
         t = pq.read_table(f)
-        lab = (t["C1"].to_numpy() % 2).astype(np.float32)
+        one_hot = next(f"C{i + 1}" for i in range(26) if not nnz or nnz[i] == 1)
+        lab = (t[one_hot].to_numpy() % 2).astype(np.float32)
         t = t.set_column(t.schema.get_field_index("label"), "label", pa.array(lab, type=pa.float32()))
         pq.write_table(t, f)
     return p
