@@ -420,8 +420,24 @@ class _Readers:
         return self.evalr is not None
 
 
+def _resolve(path: str) -> str:
+    """a dataset path of a script as is, or -- when it does not exist and HCTR_DATA_ROOT is set --
+    under that root (scripts of the reference name absolute container paths like
+    /data/train_data.bin, R/test/embedding_collection_test/dgx_a100_one_hot.py:236-237)"""
+    root = os.environ.get("HCTR_DATA_ROOT")
+    if path and root and not os.path.exists(path):
+        cand = os.path.join(root, path.lstrip("/"))
+        if os.path.exists(cand):
+            return cand
+    return path
+
+
 def make_reader(rp, inp, solver, rank, world, device):
     fmt = getattr(rp.data_reader_type, "name", str(rp.data_reader_type))
+    import copy
+    rp = copy.copy(rp)
+    rp.source = [_resolve(p) for p in rp.source]
+    rp.eval_source = _resolve(rp.eval_source)
     if fmt == "RawAsync":
         train = RawReader(rp.source[0], inp, rp.slot_size_array, solver.batchsize, rank, world,
                           device, rp.num_samples, rp.float_label_dense, solver.repeat_dataset,

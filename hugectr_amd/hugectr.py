@@ -168,7 +168,52 @@ def CreateSolver(**kw) -> Solver:
     if s.use_mixed_precision and s.scaler not in (128.0, 256.0, 512.0, 1024.0):
         # solver_wrapper / parser check: mixed precision requires one of these loss scalers
         raise RuntimeError("use_mixed_precision requires scaler in {128, 256, 512, 1024}")
+    _launch_one_process_per_gpu(sum(len(v) for v in s.vvgpu))
     return s
+
+
+def _launch_one_process_per_gpu(n_gpus: int):
+    """`python train.py` with vvgpu = [[0 .. N-1]]: the reference drives its N GPUs from one process
+    (one OpenMP thread per GPU, R/HugeCTR/src/pybind/model.cpp:1100).  Here one PROCESS drives one
+    GPU, so a script that asks for N > 1 GPUs and was not started by torch.distributed.run is
+    started again as N ranks (RCCL rendezvous on 127.0.0.1) and this process only waits for them.
+    Happens in CreateSolver, the first hugectr call of the reference's scripts, so that little of
+    the script runs twice."""
+    import sys
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ or dist.is_initialized():
+        return
+    script = sys.argv[0] if sys.argv else ""
+    if not script or not os.path.isfile(script):
+        raise RuntimeError(f"vvgpu lists {n_gpus} GPUs: launch one process per GPU "
+                           "(python -m torch.distributed.run --nproc-per-node N script.py); the "
+                           "automatic relaunch needs a script file in sys.argv[0]")
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           script] + list(sys.argv[1:])
+    print(f"[HCTR][INFO] vvgpu lists {n_gpus} GPUs: starting one process per GPU: {' '.join(cmd)}",
+          flush=True)
+    raise SystemExit(subprocess.call(cmd))
+
+
+def _join_process_group():
+    """a rank started by torch.distributed.run (by hand or by _launch_one_process_per_gpu) joins
+    the job: RCCL ("nccl") unless HCTR_DIST_BACKEND says otherwise (the CPU / one-GPU tests use
+    gloo)"""
+    if dist.is_initialized() or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("HCTR_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
 
 
 class Alignment_t(enum.Enum):
@@ -409,6 +454,7 @@ class Model:
         if not torch.cuda.is_available():
             raise RuntimeError("hugectr_amd needs a HIP device (MI355X); there is no CPU fallback")
         self.solver, self.reader_params, self.opt = solver, reader_params, opt
+        _join_process_group()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         n_gpus = sum(len(v) for v in solver.vvgpu)
@@ -416,6 +462,8 @@ class Model:
             raise RuntimeError(f"vvgpu lists {n_gpus} GPUs but {self.world} rank(s) are running: "
                                "launch one process per GPU (torch.distributed.run)")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("HCTR_RANKS_ON_ONE_GPU") == "1":  # functional tests on a 1-GPU box
+            local = 0
         self.device = torch.device("cuda", local)
         torch.cuda.set_device(self.device)
         torch.manual_seed(solver.seed + 1)
@@ -446,7 +494,14 @@ class Model:
         return OptParams(optimizer=int(o.optimizer_type), update_type=int(o.update_type),
                          lr=self._lr, beta1=o.beta1, beta2=o.beta2, epsilon=o.epsilon,
                          initial_accu_value=o.initial_accu_value,
-                         momentum_factor=o.momentum_factor, atomic_update=o.atomic_update,
+                         momentum_factor=o.momentum_factor,
+                         # CreateOptimizer's default atomic_update=True (optimizer_wrapper.hpp:40)
+                         # is read as PERMISSION for an order-nondeterministic update, not as a
+                         # demand for fp32 atomics: the sorted, segmented update is 5x faster under
+                         # power-law duplicates and deterministic.  HCTR_SGD_ATOMIC=1
+                         # selects the reference's literal opt_sgd_atomic_kernel form.
+                         atomic_update=bool(o.atomic_update) and
+                         os.environ.get("HCTR_SGD_ATOMIC") == "1",
                          scaler=self.solver.scaler)
 
     def compile(self, loss_names=None, loss_weights=None):

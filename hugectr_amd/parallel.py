@@ -61,10 +61,14 @@ def localized_split_sizes(batch: int, slot_num: int, vec: int, rank: int, world:
 class LocalizedExchange:
     """all-to-all of pooled vectors (forward) and of top gradients (backward)."""
 
-    def __init__(self, batch: int, slot_num: int, vec: int, group=None):
+    def __init__(self, batch: int, slot_num: int, vec: int, group=None,
+                 always_collective: bool = False):
+        """always_collective: issue the collective even in a group of one (a self-send through
+        the communicator; tests/test_rccl_gpu.py runs the RCCL code path on a 1-GPU box this way)"""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.single = self.world == 1 and not (always_collective and dist.is_initialized())
         assert batch % self.world == 0, "batch must be divisible by the number of GPUs"
         self.batch, self.slot_num, self.vec = batch, slot_num, vec
         self.bpg = batch // self.world
@@ -74,7 +78,7 @@ class LocalizedExchange:
         """pooled [B, S_r, D] (== [peer][B/N][S_r][D]) -> recv buffer [sum_j (B/N) S_j D]"""
         flat = pooled.reshape(-1)
         assert flat.numel() == sum(self.send)
-        if self.world == 1:
+        if self.single:
             return flat
         out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
         all_to_all_single(out, flat, self.recv, self.send, group=self.group)
@@ -85,7 +89,7 @@ class LocalizedExchange:
     def forward_async(self, pooled: torch.Tensor):
         flat = pooled.reshape(-1)
         assert flat.numel() == sum(self.send)
-        if self.world == 1:
+        if self.single:
             return flat, None
         out = torch.empty(sum(self.recv), dtype=pooled.dtype, device=pooled.device)
         work = all_to_all_single(out, flat, self.recv, self.send, group=self.group, async_op=True)
@@ -95,7 +99,7 @@ class LocalizedExchange:
         """grad_send [sum_j (B/N) S_j D] -> out (flat view of [B, S_r, D], caller-owned)"""
         flat = grad_send.reshape(-1)
         assert flat.numel() == sum(self.recv) and out.numel() == sum(self.send)
-        if self.world == 1:
+        if self.single:
             out.copy_(flat)
             return None
         return all_to_all_single(out, flat, self.send, self.recv, group=self.group, async_op=True)
@@ -105,7 +109,7 @@ class LocalizedExchange:
         flat = grad_send.reshape(-1)
         assert flat.numel() == sum(self.recv)
         s_r = slots_on_rank(self.slot_num, self.rank, self.world)
-        if self.world == 1:
+        if self.single:
             return flat.view(self.batch, s_r, self.vec)
         out = torch.empty(sum(self.send), dtype=grad_send.dtype, device=grad_send.device)
         all_to_all_single(out, flat, self.send, self.recv, group=self.group)
@@ -115,14 +119,16 @@ class LocalizedExchange:
 class DistributedExchange:
     """reduce-scatter (forward) / all-gather (backward) of the distributed-slot embedding."""
 
-    def __init__(self, batch: int, slot_num: int, vec: int, group=None):
+    def __init__(self, batch: int, slot_num: int, vec: int, group=None,
+                 always_collective: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.single = self.world == 1 and not (always_collective and dist.is_initialized())
         self.batch, self.slot_num, self.vec = batch, slot_num, vec
         self.bpg = batch // self.world
 
     def forward(self, partial: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.single:
             return partial.view(self.bpg, self.slot_num, self.vec)
         out = torch.empty((self.bpg, self.slot_num, self.vec), dtype=partial.dtype,
                           device=partial.device)
@@ -136,7 +142,7 @@ class DistributedExchange:
         return out
 
     def backward(self, grad: torch.Tensor) -> torch.Tensor:
-        if self.world == 1:
+        if self.single:
             return grad.view(self.batch, self.slot_num, self.vec)
         out = torch.empty((self.batch, self.slot_num, self.vec), dtype=grad.dtype, device=grad.device)
         if _staged(grad):
