@@ -5,6 +5,13 @@ Nothing here touches oracle/ (the CPU oracle is test infrastructure only).
 """
 import ctypes
 import os
+
+# torch FIRST: the PyTorch-ROCm wheel bundles its own HIP runtime (torch/lib/libamdhip64.so) and
+# libhugectr_amd.so names the system one.  Streams and device pointers cross this boundary, so both
+# must be the SAME runtime instance: with torch's already in the process the loader resolves this
+# library's libamdhip64.so.7 to it.  Loaded the other way round (a script whose first import is
+# `hugectr`) the process ends up with two runtimes and the second one finds no device.
+import torch  # noqa: F401,E402
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t,
                     c_uint64, c_void_p)
 

@@ -732,7 +732,9 @@ class Model:
             acts = L.activations or [L.act_type] * len(L.num_outputs)
             last_relu = acts[-1] == Activation_t.Relu
             self._mods[key] = FusedMLP(dims, last_relu,
-                                       dtype=torch.bfloat16 if self.solver.use_mixed_precision
+                                       # use_mixed_precision = the reference's fp16 mode
+                                       # (solver_wrapper.hpp:127-150: __half layers + loss scaler)
+                                       dtype=torch.float16 if self.solver.use_mixed_precision
                                        else torch.float32)
             self._shapes[L.top_names[0]] = (dims[-1],)
         elif t in (Layer_t.ReLU, Layer_t.Sigmoid, Layer_t.Dropout, Layer_t.Softmax, Layer_t.ELU):
@@ -895,6 +897,8 @@ class Model:
         (loss * (self.solver.scaler / self.world)).backward()
         for name, (se, p, h, ex, localized) in self._emb.items():
             g = leaves[name].grad
+            if os.environ.get("HCTR_DEBUG_LOSS_CURVE"):
+                self._last_emb_grad = g.detach().clone()
             if localized:
                 if self.world > 1:
                     g = backward_reorder(g.contiguous(), self.bpg, p.slot_num,
