@@ -363,6 +363,56 @@ struct hctr_updater {
   }
 };
 
+
+// ILookup::lookup of the static (ragged) table: ragged_static_embedding_table_lookup_kernel,
+// R/HugeCTR/embedding_storage/ragged_static_embedding.cu:33-51.  `keys` are the indices
+// keys_to_indices produced (globally numbered over the group's tables); position tid belongs to
+// the id space whose offset range holds it; the id space's slot in the table's own (ascending)
+// id-space list gives its first index, its element offset in the flat fp32 array and its vector
+// size.  One thread per key, two binary searches over a handful of entries, one pointer store.
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    static_lookup_kernel(const K* __restrict__ keys, size_t num_keys,
+                         const uint32_t* __restrict__ id_space_offset, size_t num_id_space_offset,
+                         const int* __restrict__ id_space_list,
+                         const int* __restrict__ local_id_space_list, size_t num_local,
+                         const uint64_t* __restrict__ table_index_start, float* emb_table,
+                         const uint64_t* __restrict__ table_ev_offset,
+                         const int* __restrict__ local_ev_size, float** __restrict__ emb_vec,
+                         uint32_t* d_error) {
+  for (size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x; tid < num_keys;
+       tid += (size_t)gridDim.x * kBlock) {
+    // last i with id_space_offset[i] <= tid  (bs_upper_bound_sub_one)
+    size_t lo = 0, hi = num_id_space_offset;
+    while (lo < hi) {
+      const size_t mid = (lo + hi) >> 1;
+      if ((size_t)id_space_offset[mid] <= tid) lo = mid + 1;
+      else hi = mid;
+    }
+    const int id_space = id_space_list[lo - 1];
+    size_t a = 0, b = num_local;
+    while (a < b) {
+      const size_t mid = (a + b) >> 1;
+      if (local_id_space_list[mid] <= id_space) a = mid + 1;
+      else b = mid;
+    }
+    if (a == 0 || local_id_space_list[a - 1] != id_space) {
+      atomicOr(d_error, 1u);  // the table does not hold this id space
+      emb_vec[tid] = nullptr;
+      continue;
+    }
+    const size_t t = a - 1;
+    const uint64_t idx = (uint64_t)keys[tid];
+    const uint64_t rows = (table_index_start[t + 1] - table_index_start[t]);
+    if (idx < table_index_start[t] || idx - table_index_start[t] >= rows) {
+      atomicOr(d_error, 2u);  // index outside the table's shard
+      emb_vec[tid] = nullptr;
+      continue;
+    }
+    emb_vec[tid] = emb_table + table_ev_offset[t] + (idx - table_index_start[t]) * (uint64_t)local_ev_size[t];
+  }
+}
+
 extern "C" {
 
 int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t table_start,
@@ -379,6 +429,35 @@ int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t t
                        0, s, n, (const long long*)keys, (long long)table_start, num_shards, out);
   else
     HCTR_REQUIRE(false, "key_type");
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_static_lookup(const void* keys, int key_type, size_t num_keys,
+                       const uint32_t* num_keys_per_table_offset, size_t num_table_offset,
+                       const int32_t* table_id_list, const int32_t* local_table_ids,
+                       size_t num_local_tables, const uint64_t* table_index_start,
+                       float* emb_table, const uint64_t* table_ev_offset,
+                       const int32_t* local_ev_sizes, float** embedding_vec, uint32_t* d_error,
+                       hctr_stream_t stream) {
+  if (num_keys == 0) return HCTR_OK;
+  HCTR_REQUIRE(keys && num_keys_per_table_offset && table_id_list && local_table_ids &&
+                   table_index_start && emb_table && table_ev_offset && local_ev_sizes &&
+                   embedding_vec && d_error,
+               "null pointer");
+  HCTR_REQUIRE(num_table_offset >= 2 && num_local_tables >= 1, "empty table lists");
+  hipStream_t s = as_stream(stream);
+  const int grid = grid_for(num_keys, kBlock);
+#define HCTR_SL(K)                                                                             \
+  hipLaunchKernelGGL(static_lookup_kernel<K>, dim3(grid), dim3(kBlock), 0, s, (const K*)keys,   \
+                     num_keys, num_keys_per_table_offset, num_table_offset, table_id_list,      \
+                     local_table_ids, num_local_tables, table_index_start, emb_table,           \
+                     table_ev_offset, local_ev_sizes, embedding_vec, d_error)
+  if (key_type == HCTR_KEY_U32) HCTR_SL(uint32_t);
+  else if (key_type == HCTR_KEY_I64) HCTR_SL(long long);
+  else if (key_type == 2) HCTR_SL(uint64_t);  // the uint64 indices of hctr_ebc_keys_to_indices
+  else HCTR_REQUIRE(false, "key_type");
+#undef HCTR_SL
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

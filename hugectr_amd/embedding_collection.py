@@ -104,7 +104,8 @@ class EmbeddingCollection:
                  initial_accu_value: float = 0.0, out_dtype=torch.float32, batch_major: bool = False,
                  key_dtype=torch.int64, max_hotness: int = 1, seed: int = 0, group=None,
                  ftrl=(0.0, 0.0, 0.0), storage: Optional[str] = None, initializer: str = "",
-                 init_capacity: int = 1 << 20, key_route: str = "allgather", **opt_kw):
+                 init_capacity: int = 1 << 20, key_route: str = "allgather",
+                 hotness: Optional[List[int]] = None, **opt_kw):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -112,7 +113,7 @@ class EmbeddingCollection:
         self.key_route = key_route
         self._setup(config, global_batch, lr, optimizer, scaler, epsilon, initial_accu_value,
                     out_dtype, batch_major, key_dtype, max_hotness, seed, ftrl, storage,
-                    initializer, init_capacity, **opt_kw)
+                    initializer, init_capacity, hotness=hotness, **opt_kw)
 
     @classmethod
     def for_rank(cls, rank, world, *a, **kw):
@@ -123,12 +124,66 @@ class EmbeddingCollection:
         self._setup(*a, **kw)
         return self
 
+
+    # -- multi-hot "concat" (Combiner::Concat, R/HugeCTR/embedding/operators/generic_lookup.cuh:
+    #    511-1084 one_to_one_*; CPU reference reference_embedding.hpp:125-139): the output of such a
+    #    lookup is max_hotness vectors side by side, key r of the bucket in slot r, missing keys
+    #    zero.  That is exactly max_hotness one-key "sum" lookups on the same table, lookup (l, r)
+    #    holding key r of every bucket -- so the collection runs on that expanded lookup list (same
+    #    routing, pooling, all-to-all, update kernels) and the CSR is re-cut on the way in.  In the
+    #    batch-major output the r-th slot of lookup l is column block ev_offset(l) + r * ev, the
+    #    reference's layout.
+    def _expand_concat_lookups(self, config, hotness, batch_major):
+        self._virt = None
+        names = [str(c).lower().split(".")[-1] for _, _, _, c in config.lookups]
+        if hotness is None or not any(c == "concat" and h > 1 for c, h in zip(names, hotness)):
+            self.L_user = len(config.lookups)
+            self.virt_span = [(l, 1) for l in range(self.L_user)]
+            return config
+        if not batch_major:
+            raise _lib.HugeCTRAmdError("multi-hot 'concat' lookups need the batch-major output "
+                                       "(the layout of EmbeddingCollectionConfig's list form)")
+        exp = EmbeddingCollectionConfig()
+        exp.__dict__.update({k: v for k, v in config.__dict__.items() if k != "lookups"})
+        exp.lookups = []
+        self._virt, self.virt_span = [], []
+        for l, ((t, bottom, top, c), h) in enumerate(zip(config.lookups, hotness)):
+            reps = int(h) if names[l] == "concat" else 1
+            self.virt_span.append((len(exp.lookups), reps))
+            for r in range(reps):
+                exp.lookups.append((t, bottom, top, "sum" if reps > 1 else c))
+                self._virt.append((l, r, reps > 1))
+        self.L_user = len(config.lookups)
+        return exp
+
+    def _expand_csr(self, keys: torch.Tensor, bucket_range: torch.Tensor, batch: int):
+        """feature-major CSR over the USER's lookups (bucket = lookup * batch + b) -> the same over
+        the expanded lookups: lookup (l, r) of a multi-hot concat lookup gets key r of each bucket"""
+        if self._virt is None:
+            return keys, bucket_range
+        br = bucket_range.to(torch.int64)
+        lens = (br[1:] - br[:-1]).view(self.L_user, batch)
+        starts = br[:-1].view(self.L_user, batch)
+        ks, ls = [], []
+        for l, r, split in self._virt:
+            if not split:
+                ks.append(keys[int(br[l * batch]):int(br[(l + 1) * batch])])
+                ls.append(lens[l])
+            else:
+                m = lens[l] > r
+                ks.append(keys[starts[l][m] + r])
+                ls.append(m.to(torch.int64))
+        nbr = torch.zeros(len(self._virt) * batch + 1, dtype=torch.int64, device=keys.device)
+        torch.cumsum(torch.cat(ls), 0, out=nbr[1:])
+        return torch.cat(ks), nbr.to(bucket_range.dtype)
+
     def _setup(self, config, global_batch, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1.0,
                epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
                key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0),
                storage=None, initializer="", init_capacity=1 << 20, beta1=0.9, beta2=0.999,
-               momentum_factor=0.9, rmsprop_beta=0.9):
+               momentum_factor=0.9, rmsprop_beta=0.9, hotness=None):
         assert global_batch % self.world == 0
+        config = self._expand_concat_lookups(config, hotness, batch_major)
         if storage is None:  # max_vocabulary_size < 0 means dynamic (embedding_storage/common.hpp:78,
             # embedding_table.cpp:27-34: one dynamic table makes the whole group dynamic)
             storage = "dynamic" if any(t.max_vocabulary_size < 0 for t, _, _, _ in config.lookups) \
@@ -154,10 +209,10 @@ class EmbeddingCollection:
         self.L = len(config.lookups)
         self.lookup_table = [tables.index(t) for t, _, _, _ in config.lookups]
         # "concat" keeps every key's vector; with one key per bucket (the one-hot configurations that
-        # use it, R/test/embedding_collection_test/dgx_a100_one_hot.py:287) it equals "sum"
+        # use it, R/test/embedding_collection_test/dgx_a100_one_hot.py:287) it equals "sum";
+        # multi-hot concat lookups were split into one-key lookups by _expand_concat_lookups
         names = [str(c).lower().split(".")[-1] for _, _, _, c in config.lookups]
         self.concat_lookups = [l for l, c in enumerate(names) if c == "concat"]
-        # (callers that know the hotness per lookup reject multi-hot concat: hugectr.Model does)
         self.combiner = [0 if c in ("sum", "0", "concat") else 1 for c in names]
         sm = config.ownership(tables, self.world)
         # owners of every table, ascending GPU order (shard id = position in that list)
@@ -314,6 +369,8 @@ class EmbeddingCollection:
     def route_and_pool(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
         """global CSR -> pooled partial vectors in the all-to-all send layout
         [peer][local lookup][b_local][ev]"""
+        if self._virt is not None and gbucket_range.numel() == self.L_user * self.B + 1:
+            gkeys, gbucket_range = self._expand_csr(gkeys, gbucket_range, self.B)
         kt = _lib.KEY_I64 if gkeys.dtype == torch.int64 else _lib.KEY_U32
         check(lib.hctr_ebc_bucket_counts(self.B, self.world, self.rank, self.L, ptr(gbucket_range),
                                          kt, ptr(self.counts), stream_ptr()))
@@ -470,6 +527,9 @@ class EmbeddingCollection:
 
     # -- whole passes --------------------------------------------------------------------------------
     def forward(self, keys: torch.Tensor, bucket_range: torch.Tensor) -> torch.Tensor:
+        if self._virt is not None:  # this rank's share of the batch, user lookups -> expanded
+            batch = (bucket_range.numel() - 1) // self.L_user
+            keys, bucket_range = self._expand_csr(keys, bucket_range, batch)
         if self.key_route == "a2a" and self.world > 1 and dist.is_initialized():
             send = self._forward_a2a_route(keys, bucket_range)
         else:
@@ -629,3 +689,25 @@ class DataParallelCollection:
             all_reduce(dense, group=self.group)      # communication.cpp:145-157
             all_reduce(touched, group=self.group)
         self.apply_reduced(dense, touched)
+
+
+def static_lookup(indices: torch.Tensor, num_keys_per_table_offset: torch.Tensor,
+                  table_id_list: torch.Tensor, local_table_ids: torch.Tensor,
+                  table_index_start: torch.Tensor, emb_table: torch.Tensor,
+                  table_ev_offset: torch.Tensor, local_ev_sizes: torch.Tensor):
+    """embedding::ILookup::lookup for a static (ragged) table shard -- the SOK plug-in point
+    (R/HugeCTR/embedding/embedding_table.hpp:22-33, ragged_static_embedding.cu:33-51): returns
+    (ptrs, error_flags) where ptrs[i] (int64 view of float*) is the device address of position
+    i's fp32 vector inside `emb_table`; feed ptrs to `hctr_forward_pool_ptrs`.  All arguments are
+    device tensors: indices uint64-valued int64 (hctr_ebc_keys_to_indices numbering) or int32 /
+    int64 keys, offsets uint32-valued int32, id lists int32, index / element offsets int64."""
+    n = indices.numel()
+    ptrs = torch.zeros(max(n, 1), dtype=torch.int64, device=indices.device)
+    err = torch.zeros(1, dtype=torch.int32, device=indices.device)
+    kt = 2 if indices.dtype == torch.int64 else 0
+    check(lib.hctr_static_lookup(ptr(indices), kt, n, ptr(num_keys_per_table_offset),
+                                 num_keys_per_table_offset.numel(), ptr(table_id_list),
+                                 ptr(local_table_ids), local_table_ids.numel(),
+                                 ptr(table_index_start), ptr(emb_table), ptr(table_ev_offset),
+                                 ptr(local_ev_sizes), ptr(ptrs), ptr(err), stream_ptr()))
+    return ptrs[:n], err

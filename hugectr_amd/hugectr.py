@@ -554,11 +554,14 @@ class Model:
                 rt.update(parent=cfg, ids=ids, whole=len(subs) == 1)
                 self._ebc.append(rt)
             if len(subs) > 1:  # mixed vector sizes: outputs are concatenated in lookup order
+                def width(t, bottom, c):  # a multi-hot concat lookup is max_hotness vectors wide
+                    h = sp[bottom].max_nnz() if str(c).lower().endswith("concat") else 1
+                    return t.ev_size * max(h, 1)
                 if cfg.top_name:
-                    self._shapes[cfg.top_name] = (sum(t.ev_size for t, _, _, _ in cfg.lookups),)
+                    self._shapes[cfg.top_name] = (sum(width(t, b, c) for t, b, _, c in cfg.lookups),)
                 else:
-                    for t, _, top, _ in cfg.lookups:
-                        self._shapes[top] = (t.ev_size,)
+                    for t, b, top, c in cfg.lookups:
+                        self._shapes[top] = (width(t, b, c),)
         # dense modules
         self._mods = torch.nn.ModuleDict()
         self._loss_layer = None
@@ -646,9 +649,6 @@ class Model:
                 raise RuntimeError("embedding_collection inputs carry one slot per lookup "
                                    "(DataReaderSparseParam(name, hotness, fixed, 1))")
             params.append(p)
-            if str(cfg.lookups[len(params) - 1][3]).lower().endswith("concat") and p.max_nnz() > 1:
-                raise RuntimeError(f"lookup '{bottom}': combiner 'concat' is supported for one-hot "
-                                   "inputs only")
             # the readers add cumulative slot offsets for the legacy embeddings; tables of a
             # collection are indexed by the raw key
             offsets.append(int(cum[slot_of_param[bottom]]) if cum is not None else 0)
@@ -657,6 +657,7 @@ class Model:
                   initial_accu_value=o.initial_accu_value, out_dtype=self.emb_dtype,
                   batch_major=True, max_hotness=hot, seed=self.solver.seed,
                   ftrl=(o.lambda1, o.lambda2, o.beta))
+        ekw = dict(kw, hotness=[p.max_nnz() for p in params])  # multi-hot concat lookups
         if dynamic:
             kw.update(beta1=o.beta1, beta2=o.beta2, momentum_factor=o.momentum_factor,
                       init_capacity=1 << 16)
@@ -676,22 +677,22 @@ class Model:
                         self._shapes[top] = (evs,)
             return dict(cfg=cfg, train=train, eval=ev, params=params,
                         offsets=torch.tensor(offsets, dtype=torch.int64, device=self.device))
-        train = EmbeddingCollection(cfg, B, **kw)
+        train = EmbeddingCollection(cfg, B, **ekw)
         ev = None
         if Be > 0:
-            ev = train if (Be == B and not dynamic) else EmbeddingCollection(cfg, Be, **kw)
+            ev = train if (Be == B and not dynamic) else EmbeddingCollection(cfg, Be, **ekw)
             if ev is not train:  # same tables, own per-batch scratch
                 ev.table, ev.accum, ev.ftrl_z = train.table, train.accum, train.ftrl_z
                 if dynamic:
                     ev.det, ev.det_opt = train.det, train.det_opt
                     ev.training = False  # evaluation never inserts: unseen keys read as zeros
-        L, evs = train.L, train.ev
+        L, evs = train.L, train.ev  # (L counts a multi-hot concat lookup once per key slot)
         if declare_shapes:
             if cfg.top_name:
                 self._shapes[cfg.top_name] = (L, evs)
             else:
-                for _, _, top, _ in cfg.lookups:
-                    self._shapes[top] = (evs,)
+                for (_, _, top, _), (_, reps) in zip(cfg.lookups, train.virt_span):
+                    self._shapes[top] = (reps * evs,)
         return dict(cfg=cfg, train=train, eval=ev, params=params,
                     offsets=torch.tensor(offsets, dtype=torch.int64, device=self.device))
 
@@ -873,14 +874,20 @@ class Model:
                 if cfg.top_name:
                     tensors[cfg.top_name] = E
                 else:
+                    span = getattr(rt["train"], "virt_span", None)
                     for l, (_, _, top, _) in enumerate(cfg.lookups):
-                        tensors[top] = E[:, l, :]
+                        v0, reps = span[l] if span else (l, 1)
+                        tensors[top] = E[:, v0, :] if reps == 1 else \
+                            E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
             else:  # one of several collections of a mixed-size config
+                span = getattr(rt["train"], "virt_span", None)
                 for j, l in enumerate(rt["ids"]):
+                    v0, reps = span[j] if span else (j, 1)
+                    Ej = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
                     if cfg.top_name:
-                        tensors[(id(cfg), l)] = E[:, j, :].float()
+                        tensors[(id(cfg), l)] = Ej.float()
                     else:
-                        tensors[cfg.lookups[l][2]] = E[:, j, :]
+                        tensors[cfg.lookups[l][2]] = Ej
         for cfg in self.ebc_configs:
             if cfg.top_name and (id(cfg), 0) in tensors:
                 tensors[cfg.top_name] = torch.cat(

@@ -228,6 +228,27 @@ int hctr_emb_profile_get(hctr_embedding* emb, int which, double* total_ms, uint6
 int hctr_ebc_keys_to_indices(const void* keys, int key_type, size_t n, int64_t table_start,
                              int num_shards, uint64_t* out, hctr_stream_t stream);
 
+/* embedding::ILookup::lookup(keys, num_keys, num_keys_per_table_offset, num_table_offset,
+ * table_id_list, float** embedding_vec) (R/HugeCTR/embedding/embedding_table.hpp:22-33) for the
+ * STATIC table, RaggedStaticEmbeddingTable::lookup (R/HugeCTR/embedding_storage/
+ * ragged_static_embedding.cu:33-51,553-575): embedding_vec[i] = address of key i's fp32 vector
+ * inside the caller-owned flat table.  keys = indices as hctr_ebc_keys_to_indices numbers them
+ * (key_type HCTR_KEY_U32 / HCTR_KEY_I64, or 2 = the uint64 that function writes); position i
+ * belongs to table_id_list[t] for num_keys_per_table_offset[t] <= i < [t + 1].  The table is
+ * described as the reference's is: local_table_ids [n] ascending, table_index_start [n + 1] (first
+ * index of each table and the end), table_ev_offset [n] (element offset of each table in
+ * emb_table), local_ev_sizes [n].  All arrays DEVICE.  *d_error (device uint32, caller-zeroed): bit
+ * 0 = a position names a table this shard does not hold, bit 1 = index outside the table; such
+ * positions get NULL (hctr_forward_pool_ptrs adds 0 for NULL).  The dynamic table's counterpart is
+ * hctr_det_lookup_rows. */
+int hctr_static_lookup(const void* keys, int key_type, size_t num_keys,
+                       const uint32_t* num_keys_per_table_offset, size_t num_table_offset,
+                       const int32_t* table_id_list, const int32_t* local_table_ids,
+                       size_t num_local_tables, const uint64_t* table_index_start,
+                       float* emb_table, const uint64_t* table_ev_offset,
+                       const int32_t* local_ev_sizes, float** embedding_vec, uint32_t* d_error,
+                       hctr_stream_t stream);
+
 /* Key routing on the gathered global CSR (DataDistributor semantics,
  * R/HugeCTR/embedding/data_distributor/key_filtering_operators.cu:37-300, with the SOK
  * all-gather flow): for every lookup resolved on this rank keep the keys with

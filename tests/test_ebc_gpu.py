@@ -300,3 +300,163 @@ def test_data_parallel_tables(oracle, world, opt_name):
                                    batch_major=True, ftrl=ftrl, ftrl_z=ftrl_z)
         assert all(torch.equal(ranks[0].table, e.table) for e in ranks), "replicas diverged"
         assert_close(ranks[0].table.cpu().numpy(), dense, 1e-5, 1e-6, f"dp tables it{it}")
+
+
+def test_static_table_ilookup_returns_vector_addresses():
+    """ILookup::lookup(keys, num_keys, num_keys_per_table_offset, num_table_offset, table_id_list,
+    float** embedding_vec) on a static table shard (ragged_static_embedding.cu:33-51): tables of
+    different vector sizes in one flat array; every position's pointer must be the address of its
+    vector, pooling through the pointers must equal pooling through row indices bit for bit, and
+    positions that name a foreign table / an index outside the shard are flagged and get NULL."""
+    import torch
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    from hugectr_amd.embedding_collection import static_lookup
+    rng = np.random.default_rng(8)
+    local_ids = [1, 4, 6]                  # this shard holds tables 1, 4 and 6 of the group
+    rows, evs = [50, 7, 300], [8, 16, 4]
+    idx_start = np.concatenate([[100], 100 + np.cumsum(rows)]).astype(np.int64)  # index numbering
+    ev_off = np.concatenate([[0], np.cumsum(np.array(rows) * np.array(evs))[:-1]]).astype(np.int64)
+    table = torch.randn(int(sum(r * e for r, e in zip(rows, evs))), device="cuda")
+    # positions: table 4 x 20, table 1 x 33, table 6 x 41 (the call's own table order)
+    order, counts = [4, 1, 6], [20, 33, 41]
+    idx = np.concatenate([rng.integers(idx_start[local_ids.index(t)],
+                                       idx_start[local_ids.index(t) + 1], c)
+                          for t, c in zip(order, counts)]).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dt)
+    args = (dev(offs, torch.int32), dev(order, torch.int32), dev(local_ids, torch.int32),
+            dev(idx_start, torch.int64), table, dev(ev_off, torch.int64), dev(evs, torch.int32))
+    ptrs, err = static_lookup(dev(idx, torch.int64), *args)
+    assert int(err) == 0
+    want, pos = [], 0
+    for t, c in zip(order, counts):
+        j = local_ids.index(t)
+        for q in range(c):
+            want.append(table.data_ptr() + 4 * (ev_off[j] + (idx[pos] - idx_start[j]) * evs[j]))
+            pos += 1
+    assert ptrs.cpu().tolist() == want
+    # pooling through the pointers == pooling through rows (one table, ragged buckets)
+    j = 2
+    n, ev = 64, evs[j]
+    lens = rng.integers(0, 5, 24)
+    br = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    n = int(br[-1])
+    ridx = rng.integers(0, rows[j], n).astype(np.int64)
+    p2, err = static_lookup(dev(ridx + idx_start[j], torch.int64), dev([0, n], torch.int32),
+                            dev([6], torch.int32), *args[2:])
+    assert int(err) == 0
+    out_p = torch.empty(24, ev, device="cuda")
+    check(lib.hctr_forward_pool_ptrs(24, ev, 1, ptr(dev(br, torch.int64)), ptr(p2), ptr(out_p),
+                                     _lib.F32, stream_ptr()))
+    sub = table[ev_off[j]:ev_off[j] + rows[j] * ev].view(rows[j], ev)
+    out_i = torch.empty(24, ev, device="cuda")
+    check(lib.hctr_forward_pool(24, ev, 1, ptr(dev(br, torch.int64)), _lib.KEY_I64,
+                                ptr(dev(ridx, torch.int64)), ptr(sub), ptr(out_i), _lib.F32,
+                                stream_ptr()))
+    assert torch.equal(out_p, out_i)
+    # a table this shard does not hold (bit 0) and an index beyond the shard (bit 1)
+    bad, err = static_lookup(dev([idx_start[0], idx_start[1] + 10 ** 6], torch.int64),
+                             dev([0, 1, 2], torch.int32), dev([5, 4], torch.int32), *args[2:])
+    assert int(err) == 3 and bad.cpu().tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_multi_hot_concat_combiner(oracle, world):
+    """Combiner::Concat with several keys per bucket (generic_lookup.cuh one_to_one_*; CPU
+    reference reference_embedding.hpp:125-139, pinned in tests/test_ref_ebc_cpu.py for sum / average):
+    the batch-major output of the lookup is max_hotness vectors side by side, key r in slot r,
+    missing keys zero; the backward hands slot r's gradient to key r.  Checked against a plain
+    numpy statement of those two rules, next to a sum and an average lookup on shared tables, on 1
+    and 2 ranks (single process), with an SGD step."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    from hugectr_amd.embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfig,
+                                                  EmbeddingTableConfig)
+    rng = np.random.default_rng(2 + world)
+    ev, B = 8, 16
+    bpg = B // world
+    rows = [40, 9]
+    tabs = [EmbeddingTableConfig(f"t{i}", r, ev) for i, r in enumerate(rows)]
+    cfg = EmbeddingCollectionConfig()
+    spec = [(0, "concat", 3), (1, "sum", 4), (0, "mean", 2), (1, "concat", 2)]
+    cfg.embedding_lookup(table_config=[tabs[t] for t, _, _ in spec],
+                         bottom_name=[f"d{i}" for i in range(len(spec))], top_name="emb",
+                         combiner=[c for _, c, _ in spec])
+    cfg.shard(shard_matrix=[["t0", "t1"]] * world, shard_strategy=[("mp", ["t0", "t1"])])
+    hot = [h for _, _, h in spec]
+    shards = [EmbeddingCollection.for_rank(r, world, cfg, B, lr=0.5, optimizer=_lib.OPT_SGD,
+                                           batch_major=True, max_hotness=max(hot), hotness=hot)
+              for r in range(world)]
+    # logical tables: key k of table t lives on shard k % world at local row k // world
+    full = [rng.standard_normal((r, ev)).astype(np.float32) for r in rows]
+    for r, e in enumerate(shards):
+        for t in e.local_tables:
+            ns = len(e.owners[t])
+            sid = e.owners[t].index(r)
+            n = -(-rows[t] // ns)
+            blk = np.zeros((n, ev), np.float32)
+            own = np.arange(sid, rows[t], ns)
+            blk[:own.size] = full[t][own]
+            s0 = e.row_start_of_table[t]
+            e.table[s0:s0 + n] = torch.from_numpy(blk).cuda()
+    lens = np.concatenate([rng.integers(0, h + 1, B) for h in hot])
+    br = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    keys = np.concatenate([rng.integers(0, rows[t], int(lens[l * B:(l + 1) * B].sum()))
+                           for l, (t, _, _) in enumerate(spec)]).astype(np.int64)
+    widths = [ev * (h if c == "concat" else 1) for (_, c, h) in spec]
+    off = np.concatenate([[0], np.cumsum(widths)])
+    want = np.zeros((B, off[-1]), np.float32)
+    for l, (t, c, h) in enumerate(spec):
+        for b in range(B):
+            ks = keys[br[l * B + b]:br[l * B + b + 1]]
+            if c == "concat":
+                for r, k in enumerate(ks):
+                    want[b, off[l] + r * ev:off[l] + (r + 1) * ev] = full[t][k]
+            elif len(ks):
+                v = full[t][ks].sum(0, dtype=np.float32)
+                want[b, off[l]:off[l] + ev] = v / np.float32(len(ks)) if c == "mean" else v
+    gk, gbr = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+    sends = [e.route_and_pool(gk, gbr) for e in shards]
+    outs = []
+    for dst, e in enumerate(shards):  # emulate the all-to-all: dst gets its sample slice
+        parts = []
+        for src, es in enumerate(shards):
+            blk = sends[src].view(world, es.n_local, bpg, ev)[dst]
+            parts.append(blk.reshape(-1, ev))
+        outs.append(e.network_forward(torch.cat(parts)))
+    got = torch.cat([o.reshape(bpg, -1) for o in outs]).float().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert shards[0].L == sum(h if c == "concat" else 1 for _, c, h in spec)
+    # backward + SGD: slot r's gradient reaches key r
+    g = rng.standard_normal((B, off[-1])).astype(np.float32)
+    ref = [f.copy() for f in full]
+    acc = [np.zeros_like(f) for f in full]
+    for l, (t, c, h) in enumerate(spec):
+        for b in range(B):
+            ks = keys[br[l * B + b]:br[l * B + b + 1]]
+            for r, k in enumerate(ks):
+                if c == "concat":
+                    acc[t][k] += g[b, off[l] + r * ev:off[l] + (r + 1) * ev]
+                else:
+                    acc[t][k] += g[b, off[l]:off[l] + ev] / (len(ks) if c == "mean" else 1)
+    for t in range(len(rows)):
+        ref[t] -= 0.5 * acc[t]
+    gt = torch.from_numpy(g).cuda()
+    bsend = [e.network_backward(gt[d * bpg:(d + 1) * bpg].contiguous().view(bpg, e.L, ev))
+             for d, e in enumerate(shards)]
+    for own, e in enumerate(shards):  # the mirror all-to-all
+        parts = []
+        for d in range(world):
+            base = sum(shards[d].n_local_of[:own]) * bpg
+            parts.append(bsend[d][base:base + e.n_local * bpg])
+        e.apply_gradients(torch.cat(parts))
+    torch.cuda.synchronize()
+    for r, e in enumerate(shards):
+        for t in e.local_tables:
+            ns = len(e.owners[t])
+            own = np.arange(e.owners[t].index(r), rows[t], ns)
+            s0 = e.row_start_of_table[t]
+            np.testing.assert_allclose(e.table[s0:s0 + own.size].cpu().numpy(), ref[t][own],
+                                       rtol=1e-5, atol=1e-5)
