@@ -347,13 +347,13 @@ def test_static_table_ilookup_returns_vector_addresses():
                             dev([6], torch.int32), *args[2:])
     assert int(err) == 0
     out_p = torch.empty(24, ev, device="cuda")
-    check(lib.hctr_forward_pool_ptrs(24, ev, 1, ptr(dev(br, torch.int64)), ptr(p2), ptr(out_p),
-                                     _lib.F32, stream_ptr()))
+    d_br, d_ridx = dev(br, torch.int64), dev(ridx, torch.int64)  # (kept alive across the launches)
+    check(lib.hctr_forward_pool_ptrs(24, ev, 1, ptr(d_br), ptr(p2), ptr(out_p), _lib.F32,
+                                     stream_ptr()))
     sub = table[ev_off[j]:ev_off[j] + rows[j] * ev].view(rows[j], ev)
     out_i = torch.empty(24, ev, device="cuda")
-    check(lib.hctr_forward_pool(24, ev, 1, ptr(dev(br, torch.int64)), _lib.KEY_I64,
-                                ptr(dev(ridx, torch.int64)), ptr(sub), ptr(out_i), _lib.F32,
-                                stream_ptr()))
+    check(lib.hctr_forward_pool(24, ev, 1, ptr(d_br), _lib.KEY_I64, ptr(d_ridx), ptr(sub),
+                                ptr(out_i), _lib.F32, stream_ptr()))
     assert torch.equal(out_p, out_i)
     # a table this shard does not hold (bit 0) and an index beyond the shard (bit 1)
     bad, err = static_lookup(dev([idx_start[0], idx_start[1] + 10 ** 6], torch.int64),
