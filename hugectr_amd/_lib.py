@@ -126,6 +126,8 @@ _SIGNATURES = {
     "hctr_det_rows": (c_int, [_P, c_size_t, POINTER(_P), _SZP]),
     "hctr_det_lookup_rows": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, c_int, _P, _P,
                                      POINTER(c_uint64), _P]),
+    "hctr_radix_sort_temp_bytes": (c_size_t, [c_size_t]),
+    "hctr_radix_sort_pairs_u32": (c_int, [_P, c_size_t, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "hctr_static_lookup": (c_int, [_P, c_int, c_size_t, _P, c_size_t, _P, _P, c_size_t, _P, _P, _P,
                                    _P, _P, _P, _P]),
     "hctr_forward_pool_ptrs": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),

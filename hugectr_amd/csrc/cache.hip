@@ -20,11 +20,11 @@
 // Calls on one cache are ordered by their streams; calls from unordered streams need external
 // ordering (the reference's per-set mutexes are not reproduced).
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstring>
 
 #include "common.h"
+#include "radix_sort.h"
 #include "scan.h"
 
 namespace hctr {
@@ -356,14 +356,7 @@ struct hctr_cache {
     HCTR_HIP(hipMalloc(&pos_out, c * 4));
     HCTR_HIP(hipMalloc(&tile_sums, (c / 1024 + 2) * 8));
     HCTR_HIP(hipMalloc(&d_total, 8));
-    size_t tb = 0;
-    if (rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (const uint32_t*)nullptr, (uint32_t*)nullptr, c, 0, 32, nullptr,
-                                  false) != hipSuccess) {
-      set_error("rocprim::radix_sort_pairs (size query) failed");
-      return HCTR_ERR_HIP;
-    }
-    sort_temp_bytes = tb ? tb : 16;
+    sort_temp_bytes = radix_sort_temp_bytes(c);
     HCTR_HIP(hipMalloc(&sort_temp, sort_temp_bytes));
     cap = c;
     return HCTR_OK;
@@ -408,13 +401,12 @@ int cache_modify_typed(hctr_cache* c, bool replace, const K* keys, size_t len, c
   hipLaunchKernelGGL(cache_setid_kernel<K>, dim3(grid_for(len, kBlock, 4096)), dim3(kBlock), 0, s,
                      keys, len, d_len, c->num_sets, c->set_in, c->pos_in);
   HCTR_LAUNCH_CHECK();
-  size_t tb = c->sort_temp_bytes;
-  // stable sort by set id: inside a set the keys keep their position order
-  if (rocprim::radix_sort_pairs(c->sort_temp, tb, c->set_in, c->set_out, c->pos_in, c->pos_out, len,
-                                0, 32, s, false) != hipSuccess) {
-    set_error("rocprim::radix_sort_pairs failed");
-    return HCTR_ERR_HIP;
-  }
+  // stable sort by set id: inside a set the keys keep their position order.  Key bits: the set
+  // ids plus one, so that the padding id (all ones) of positions beyond *d_len sorts last
+  int set_bits = 1;
+  while (set_bits < 31 && ((size_t)1 << set_bits) < c->num_sets) set_bits++;
+  HCTR_TRY(radix_sort_pairs_u32(c->sort_temp, c->sort_temp_bytes, c->set_in, c->set_out, c->pos_in,
+                                c->pos_out, len, set_bits + 1, s));
   const int grid = grid_for(len * 64, kBlock, 1 << 16);
   const bool v4 = vec4_ok(c->D, values, c->vals);
 #define HCTR_CM(R_, V_)                                                                          \

@@ -24,6 +24,9 @@ struct SparseUpdater {
   size_t max_vocab = 0;
   int D = 0;
   bool key32 = true;  // sort keys fit 32 bits
+  // rows handed out so far are < row_bound (0 = unknown): the sort then covers log2(row_bound)
+  // key bits instead of log2(max_vocab) -- one digit pass less while a table is filling up
+  size_t row_bound = 0;
   // sort buffers
   void* sort_keys_in = nullptr;
   void* sort_keys_out = nullptr;

@@ -9,6 +9,7 @@
 // "group" of D/4 lanes owns a row with 16-byte accesses.  Gradient accumulation per row is in
 // ascending bucket id, exactly the reference's order (stable sort), then / scaler.
 #include "sparse_update.h"
+#include "radix_sort.h"
 
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
@@ -982,9 +983,34 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// HCTR_SORT=rocprim selects the library's one-sweep sort (A/B measurements); default: radix_sort.hip
+inline bool use_library_sort() {
+  static const bool v = [] {
+    const char* e = getenv("HCTR_SORT");
+    return e != nullptr && e[0] == 'r';
+  }();
+  return v;
+}
+
 template <typename SortK>
 int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, const uint32_t* vin,
                uint32_t* vout, size_t n, int end_bit, hipStream_t s) {
+  static_assert(sizeof(SortK) == 4, "32-bit sort keys");
+  if (temp == nullptr) {  // size query: room for either implementation
+    size_t lib = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, lib, kin, kout, vin, vout, n, 0,
+                                             (unsigned)end_bit, s, false);
+    if (e != hipSuccess) {
+      set_error(std::string("rocprim::radix_sort_pairs: ") + hipGetErrorString(e));
+      return HCTR_ERR_HIP;
+    }
+    const size_t own = radix_sort_temp_bytes(n);
+    temp_bytes = lib > own ? lib : own;
+    return HCTR_OK;
+  }
+  if (!use_library_sort())
+    return radix_sort_pairs_u32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout,
+                                n, end_bit, s);
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0,
                                            (unsigned)end_bit, s, false);
   if (e != hipSuccess) {
@@ -1005,7 +1031,9 @@ int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const
   HCTR_LAUNCH_CHECK();
   // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
   int end_bit = 1;
-  while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= u.max_vocab) end_bit++;
+  // (row_bound: the caller may know that only the first row_bound rows of the table exist yet)
+  const size_t top = (u.row_bound > 0 && u.row_bound < u.max_vocab) ? u.row_bound : u.max_vocab;
+  while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= top) end_bit++;
   end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
   size_t tb = u.sort_temp_bytes;
   if (u.prof) u.prof->begin(2, s);

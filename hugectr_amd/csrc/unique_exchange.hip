@@ -20,9 +20,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include "radix_sort.h"
 #include "scan.h"
 
 namespace hctr {
@@ -174,12 +174,7 @@ int hctr_uniq_create(size_t max_positions, hctr_uniq** out) {
             hipMalloc(&u->gid, (n + 1) * 4) == hipSuccess &&
             hipMalloc(&u->tile_sums, (n / 1024 + 2) * 8) == hipSuccess &&
             hipMalloc(&u->d_total, 8) == hipSuccess;
-  size_t tb = 0;
-  if (ok)
-    ok = rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                   (const uint32_t*)nullptr, (uint32_t*)nullptr, n, 0, 32, nullptr,
-                                   false) == hipSuccess;
-  u->temp_bytes = tb ? tb : 16;
+  u->temp_bytes = radix_sort_temp_bytes(n);
   if (ok) ok = hipMalloc(&u->sort_temp, u->temp_bytes) == hipSuccess;
   if (!ok) {
     set_error("hctr_uniq_create: allocation failed");
@@ -225,13 +220,8 @@ int hctr_uniq_plan(hctr_uniq* u, size_t positions, size_t positions_per_peer, in
   hipLaunchKernelGGL(uniq_keys_kernel, dim3(grid), dim3(kBlock), 0, s, positions,
                      positions_per_peer, value_index, rowbits, u->keys_in, u->vals_in);
   HCTR_LAUNCH_CHECK();
-  size_t tb = u->temp_bytes;
-  if (rocprim::radix_sort_pairs(u->sort_temp, tb, u->keys_in, u->keys_out, u->vals_in, u->vals_out,
-                                positions, 0, (unsigned)(rowbits + peerbits), s,
-                                false) != hipSuccess) {
-    set_error("rocprim::radix_sort_pairs failed");
-    return HCTR_ERR_HIP;
-  }
+  HCTR_TRY(radix_sort_pairs_u32(u->sort_temp, u->temp_bytes, u->keys_in, u->keys_out, u->vals_in,
+                                u->vals_out, positions, rowbits + peerbits, s));
   hipLaunchKernelGGL(uniq_flags_kernel, dim3(grid), dim3(kBlock), 0, s, positions, u->keys_out,
                      u->flags);
   HCTR_LAUNCH_CHECK();

@@ -308,6 +308,18 @@ int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64
                         float momentum_factor, float scaler, uint64_t times, float* table,
                         float* state0, float* state1, hctr_stream_t stream);
 
+/* cub::DeviceRadixSort::SortPairs as the sparse optimizer calls it (R/HugeCTR/src/optimizers/
+ * sparse_optimizer.cu:657-676: keys = row indices, values = bucket ids, bits [0, end_bit)): a stable
+ * LSD radix sort of (uint32 key, uint32 value) pairs sized for <= 2^24 pairs -- three short
+ * launches per 10-bit digit, no inter-workgroup waits (csrc/radix_sort.hip).  Sorts by key bits
+ * [0, 10 * ceil(end_bit / 10)); inputs are left untouched.  temp: DEVICE workspace of
+ * hctr_radix_sort_temp_bytes(n) bytes.  hctr_emb_update_params / hctr_updater_update use it
+ * internally. */
+size_t hctr_radix_sort_temp_bytes(size_t n);
+int hctr_radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* keys_in,
+                              uint32_t* keys_out, const uint32_t* vals_in, uint32_t* vals_out,
+                              size_t n, int end_bit, hctr_stream_t stream);
+
 /* LocalReduceIndexCalculation + LocalReduce (R/HugeCTR/embedding/operators/index_calculation.cu,
  * model_backward.cu:113-...): the Wgrad{unique_keys, ev_start_indices, data} a grouped table's
  * update() consumes (R/HugeCTR/embedding/common.hpp:352-373).  row_ids[nnz] < = max_row_id identify
