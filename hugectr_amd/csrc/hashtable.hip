@@ -48,47 +48,82 @@ __global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
   }
 }
 
+// one key, the full protocol: probe (linear), claim an empty slot for an unseen key, hand back the
+// row or the pending marker (see the header of this file)
+template <typename K>
+__device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
+                                                    K key, size_t i, uint64_t* __restrict__ out,
+                                                    uint32_t* d_pending, uint32_t* d_error) {
+  const long long empty = KeyTraits<K>::empty;
+  const long long k64 = widen<K>(key);
+  uint64_t slot = (uint64_t)murmur3_key(key) % size;
+  bool ok = false;
+  for (uint64_t probes = 0; probes < size; ++probes) {
+    long long cur = tab[slot].key;
+    if (cur == k64) {
+      ok = true;
+      break;
+    }
+    if (cur == empty) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot].key),
+                                         (unsigned long long)empty, (unsigned long long)k64);
+      if (old == (unsigned long long)empty || old == (unsigned long long)k64) {
+        ok = true;
+        break;
+      }
+    }
+    slot = (slot + 1 == size) ? 0 : slot + 1;
+  }
+  if (!ok) {
+    atomicOr(d_error, 1u);
+    out[i] = kInvalidIndex;
+    return;
+  }
+  unsigned long long v = tab[slot].val;
+  if (v < kPendingBit) {
+    out[i] = v;
+  } else {
+    atomicMin(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
+    out[i] = kPendingBit | slot;
+    *d_pending = 1u;  // benign race: all writers store 1
+  }
+}
+
+// Steady state = every key is in the table and sits in its home slot or close to it, so the
+// kernel is one dependent 16-byte read per key: a thread takes kHtUnroll keys at a time and has
+// their home entries in flight together (key and row in ONE 16-byte load); only a key whose home
+// entry is not its own (collision, or unseen) walks the full protocol above.
+constexpr int kHtUnroll = 4;
+
 template <typename K>
 __global__ void __launch_bounds__(kBlock)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
                            uint32_t* d_pending, uint32_t* d_error) {
   const size_t nl = live_count(d_n, n);
-  const long long empty = KeyTraits<K>::empty;
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
-       i += (size_t)gridDim.x * kBlock) {
-    const K key = keys[i];
-    const long long k64 = widen<K>(key);
-    uint64_t slot = (uint64_t)murmur3_key(key) % size;
-    bool ok = false;
-    for (uint64_t probes = 0; probes < size; ++probes) {
-      long long cur = tab[slot].key;
-      if (cur == k64) {
-        ok = true;
-        break;
-      }
-      if (cur == empty) {
-        unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot].key),
-                                           (unsigned long long)empty, (unsigned long long)k64);
-        if (old == (unsigned long long)empty || old == (unsigned long long)k64) {
-          ok = true;
-          break;
-        }
-      }
-      slot = (slot + 1 == size) ? 0 : slot + 1;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i0 = blockIdx.x * (size_t)kBlock + threadIdx.x; i0 < nl;
+       i0 += nthreads * kHtUnroll) {
+    K key[kHtUnroll];
+    uint64_t slot[kHtUnroll];
+    ulonglong2 ent[kHtUnroll];
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      key[u] = keys[i < nl ? i : i0];
+      slot[u] = (uint64_t)murmur3_key(key[u]) % size;
     }
-    if (!ok) {
-      atomicOr(d_error, 1u);
-      out[i] = kInvalidIndex;
-      continue;
-    }
-    unsigned long long v = tab[slot].val;
-    if (v < kPendingBit) {
-      out[i] = v;
-    } else {
-      atomicMin(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
-      out[i] = kPendingBit | slot;
-      *d_pending = 1u;  // benign race: all writers store 1
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++)
+      ent[u] = *reinterpret_cast<const ulonglong2*>(&tab[slot[u]]);
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      if (i >= nl) continue;
+      if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
+        out[i] = ent[u].y;
+      else
+        ht_probe_insert_one<K>(tab, size, key[u], i, out, d_pending, d_error);
     }
   }
 }
@@ -265,22 +300,43 @@ __global__ void __launch_bounds__(kBlock)
                    size_t n, const uint64_t* d_n, uint64_t* __restrict__ out) {
   const size_t nl = live_count(d_n, n);
   const long long empty = KeyTraits<K>::empty;
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
-       i += (size_t)gridDim.x * kBlock) {
-    const K key = keys[i];
-    const long long k64 = widen<K>(key);
-    uint64_t slot = (uint64_t)murmur3_key(key) % size;
-    uint64_t res = kInvalidIndex;
-    for (uint64_t probes = 0; probes <= size; ++probes) {
-      long long cur = tab[slot].key;
-      if (cur == k64) {
-        res = tab[slot].val;
-        break;
-      }
-      if (cur == empty) break;
-      slot = (slot + 1 == size) ? 0 : slot + 1;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  for (size_t i0 = blockIdx.x * (size_t)kBlock + threadIdx.x; i0 < nl;
+       i0 += nthreads * kHtUnroll) {
+    K key[kHtUnroll];
+    uint64_t slot[kHtUnroll];
+    ulonglong2 ent[kHtUnroll];
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      key[u] = keys[i < nl ? i : i0];
+      slot[u] = (uint64_t)murmur3_key(key[u]) % size;
     }
-    out[i] = res;
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++)  // home entries of kHtUnroll keys in flight together
+      ent[u] = *reinterpret_cast<const ulonglong2*>(&tab[slot[u]]);
+#pragma unroll
+    for (int u = 0; u < kHtUnroll; u++) {
+      const size_t i = i0 + (size_t)u * nthreads;
+      if (i >= nl) continue;
+      const long long k64 = widen<K>(key[u]);
+      uint64_t res = kInvalidIndex;
+      if ((long long)ent[u].x == k64) {
+        res = ent[u].y;
+      } else if ((long long)ent[u].x != empty) {  // collision: walk on
+        uint64_t sl = (slot[u] + 1 == size) ? 0 : slot[u] + 1;
+        for (uint64_t probes = 1; probes <= size; ++probes) {
+          const long long cur = tab[sl].key;
+          if (cur == k64) {
+            res = tab[sl].val;
+            break;
+          }
+          if (cur == empty) break;
+          sl = (sl + 1 == size) ? 0 : sl + 1;
+        }
+      }
+      out[i] = res;
+    }
   }
 }
 
@@ -448,7 +504,7 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
     sink.world = sink_in->world;
     sink.localized = sink_in->localized;
   }
-  const int grid = grid_for(n, kBlock);
+  const int grid = grid_for(ceil_div<size_t>(n, kHtUnroll), kBlock, 1 << 16);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
                        size, (const uint32_t*)keys, n, d_n, out, d_pending, d_error);
