@@ -252,16 +252,16 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
         z = ha.interaction(xb.to(edt), E)
         if amp and head_fused:
             # last layer + BCE + their backward in one pass over the last hidden activations
-            loss = top.forward_bce(z, label_k, scaler / (Bc * C))
+            loss = top.forward_bce(z, label_k, scaler / (Bc * C * world))
             loss.backward()
             return loss.detach() / C
         logit = top(z)
         if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
-            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bc * C))
+            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bc * C * world))
             logit.backward(dlogit)
             return loss / C
         loss = loss_fn(logit.float(), label_k) / C
-        loss.backward()
+        (loss / world).backward()
         return loss.detach()
 
     use_graph = a.graph == "on" or (a.graph == "auto" and C > 1)
@@ -312,15 +312,13 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
 
     def finish_step():
         if world > 1 and flat_mode:
-            for m in (bottom, top):
+            for m in (bottom, top):  # gradients are shares of the global-batch mean: plain sum
                 par_all_reduce(m.flat_g)
-                m.flat_g /= world
             return
         if world > 1:
             grads = [p.grad for p in dense_params]
             flat = torch.cat([x.reshape(-1) for x in grads])
             par_all_reduce(flat)
-            flat /= world
             off = 0
             for x in grads:
                 x.copy_(flat[off:off + x.numel()].view_as(x))
@@ -343,7 +341,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
             ux.prefetch(ro, nxt)
             z = ha.interaction_indexed(xb.to(edt), rows, row_of, on_emb_grad=ux.backward_begin)
             logit = top(z)
-            loss, dlogit = bce_with_logits(logit, label_k, scaler / Bl)
+            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bl * world))
             logit.backward(dlogit)
         else:
             sent = {}
@@ -515,6 +513,24 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
         except Exception:
             pmc = None
     stage_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}
+    # ---- per-rank diagnosis of a multi-GPU run: what each rank resolved, what it shipped --------
+    per_rank = None
+    if world > 1:
+        if mode["name"] == "rows":
+            sent = sum(exch.send) - exch.send[rank]      # elements to the other ranks, one way
+            xb = {"payload": "rows", "bytes_out_forward": sent * esz, "bytes_out_backward":
+                  (sum(exch.recv) - exch.recv[rank]) * esz}
+        else:
+            us, ur = ux.u_send or [0] * world, ux.u_recv or [0] * world
+            gsz = 2 if mode["name"] == "unique16" else 4
+            xb = {"payload": mode["name"], "distinct_rows_out": sum(us) - us[rank],
+                  "positions": ux.P,
+                  "bytes_out_forward": (sum(us) - us[rank]) * D * esz + (ux.P - ux.P // world) * 8,
+                  "bytes_out_backward": (sum(ur) - ur[rank]) * D * gsz}
+        mine = {"rank": rank, "slots": spr, "table_rows": my_rows, "stage_us": stage_us,
+                "exchange": xb}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     out = {
         "metric": "samples/sec (whole node) + embedding-gather HBM GB/s, DLRM Criteo-1TB",
@@ -544,6 +560,8 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
                      "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3},
         "stage_us_per_step": stage_us,
     }
+    if per_rank is not None:
+        out["per_rank"] = per_rank
     del emb, ux, exch, pooled, top_grad, bottom, top, dense_params, dense_opt
     import gc
     gc.collect()
