@@ -975,8 +975,18 @@ class Model:
             return []
         p = torch.cat([a for a, _, _ in self._eval_buf])
         y = torch.cat([b for _, b, _ in self._eval_buf])
-        return [("AUC", _auc(p, y)), ("AverageLoss", float(torch.stack(
-            [c for _, _, c in self._eval_buf]).mean()))]
+        loss = torch.stack([c for _, _, c in self._eval_buf]).mean().float().view(1)
+        if self.world > 1:  # the metric is over the samples of ALL GPUs (metrics.cu gathers them)
+            staged = dist.get_backend() == "gloo"
+            dv = torch.device("cpu") if staged else self.device
+            ps = [torch.empty(p.numel(), dtype=p.dtype, device=dv) for _ in range(self.world)]
+            ys = [torch.empty(y.numel(), dtype=y.dtype, device=dv) for _ in range(self.world)]
+            dist.all_gather(ps, p.to(dv).contiguous())
+            dist.all_gather(ys, y.to(dv).contiguous())
+            p, y = torch.cat(ps).to(self.device), torch.cat(ys).to(self.device)
+            _all_reduce(loss)
+            loss /= self.world
+        return [("AUC", _auc(p, y)), ("AverageLoss", float(loss))]
 
     def set_learning_rate(self, lr: float):
         self._lr = lr
@@ -1338,14 +1348,19 @@ _ACT_NAME = {Activation_t.Relu: "Relu", Activation_t.Non: "None", Activation_t.U
 
 
 def _auc(p: torch.Tensor, y: torch.Tensor) -> float:
-    order = torch.argsort(p)
-    y = y[order]
+    """area under the ROC curve = Mann-Whitney U with tied scores sharing their average rank (a
+    tie between a positive and a negative counts one half, the trapezoid rule of the reference's
+    AUC metric, R/HugeCTR/src/metrics.cu)"""
+    p, order = torch.sort(p.double())
+    y = y[order].double()
     n_pos = float(y.sum())
     n_neg = float(y.numel() - n_pos)
     if n_pos == 0 or n_neg == 0:
         return 0.5
-    ranks = torch.arange(1, y.numel() + 1, device=y.device, dtype=torch.float64)
-    return float(((ranks * y).sum() - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg))
+    _, inv, cnt = torch.unique_consecutive(p, return_inverse=True, return_counts=True)
+    last = torch.cumsum(cnt, 0).double()               # 1-based rank of the last member of a tie
+    avg = (last - (cnt.double() - 1) / 2)[inv]         # average rank of every member
+    return float(((avg * y).sum() - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg))
 
 
 class tools:  # hugectr.tools.* (R/HugeCTR/include/pybind/data_generator_wrapper.hpp:29-69)

@@ -230,3 +230,16 @@ def test_parquet_multi_hot_columns(tmp_path):
                         v = cols[s][i] if isinstance(cols[s][i], list) else [cols[s][i]]
                         want += [k + offs[s] for k in v]
                     assert keys.tolist() == want and ro.numel() == 33
+
+
+def test_auc_shares_ranks_among_tied_scores():
+    """hugectr.Model's AUC: ties between a positive and a negative count one half"""
+    import torch
+    from sklearn.metrics import roc_auc_score
+    from hugectr_amd.hugectr import _auc
+    rng = np.random.default_rng(0)
+    for digits in (1, 2, 6):
+        p = np.round(rng.random(800), digits)
+        y = (rng.random(800) < 0.35).astype(np.float64)
+        assert abs(_auc(torch.from_numpy(p), torch.from_numpy(y)) - roc_auc_score(y, p)) < 1e-12
+    assert _auc(torch.zeros(10), torch.tensor([0., 1.] * 5)) == 0.5
