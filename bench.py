@@ -505,11 +505,15 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
     if pool_n == 0:  # unique-row exchange: the pool kernel only ran in the warm-up comparison
         pool_ms, pool_n = pool_prof
     achieved = alg_bytes / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate passes on
+    # this workload (profiles/r2_pmc_hbm_traffic_<precision>.json; a bench process cannot read the
+    # counters of its own kernels), attached only to the leg whose output width they were taken on
     pmc = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_gather_pool.json")
-    if world == 1 and os.path.exists(pmc_path):
+    pmc_path = os.path.join(ROOT, "profiles",
+                            f"r2_pmc_hbm_traffic_{'fp32' if esz == 4 else 'fp16'}.json")
+    if world == 1 and D == 128 and a.batch == 65536 and a.alpha == 1.1 and os.path.exists(pmc_path):
         try:
-            pmc = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path))["kernels"]["pool_vec4_kernel"]["hbm_bytes_per_launch"]
         except Exception:
             pmc = None
     stage_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}
@@ -556,6 +560,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
         "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
+                     "traffic_source": os.path.relpath(pmc_path, ROOT) if pmc else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
                      "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3},
         "stage_us_per_step": stage_us,
