@@ -623,7 +623,11 @@ __global__ void __launch_bounds__(kBlock)
 // Phase B: one lane inspects one sorted position; run starts of runs that are not "long" are
 // compacted with a wave ballot and handed to lane groups, which read the run's gradient sum from
 // gsum[position] and apply the optimizer to the row (one coalesced D*4-byte RMW per row).
-template <int LPR, typename OffT, typename SortK>
+// kSgd: plain SGD known at compile time -- one float4 of state per row instead of the generic
+// RowRegs (w, two state vectors, four time stamps: 148 VGPRs, 3 waves per SIMD), 8 rows per lane
+// group in flight instead of 4 (93 VGPRs).  Same arithmetic, same bits; seg_apply 98 -> 70 us at
+// the bench shape.
+template <int LPR, typename OffT, typename SortK, bool kSgd>
 __global__ void __launch_bounds__(kBlock)
     seg_apply_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                      const SortK* __restrict__ sorted_rows, const float* __restrict__ gsum,
@@ -654,7 +658,7 @@ __global__ void __launch_bounds__(kBlock)
     unsigned long long mask = __ballot(active);
     // R rows per group per step: all gsum / table / state reads of a step are issued before the
     // first optimizer evaluation
-    constexpr int R = 4;
+    constexpr int R = kSgd ? 8 : 4;
     while (mask != 0ull) {
       int src[R];
 #pragma unroll
@@ -671,20 +675,42 @@ __global__ void __launch_bounds__(kBlock)
       }
       uint32_t r2[R];
       float4 gi[R];
-      RowRegs rr[R];
+      if constexpr (kSgd) {
+        float4 w[R];
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
-        if (src[k] >= 0) {
-          gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
-          row_load<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+        for (int k = 0; k < R; k++) {
+          r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
+          if (src[k] >= 0) {
+            gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
+            w[k] = *reinterpret_cast<const float4*>(table + (uint64_t)r2[k] * D + l * 4);
+          }
         }
-      }
 #pragma unroll
-      for (int k = 0; k < R; k++) {
-        if (src[k] >= 0) {
-          row_compute(o, gi[k], rr[k]);
-          row_store<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+        for (int k = 0; k < R; k++) {
+          if (src[k] >= 0) {  // row_compute + apply_opt(HCTR_OPT_SGD): w += -lr * (g / scaler)
+            w[k].x += -o.lr * (gi[k].x / o.scaler);
+            w[k].y += -o.lr * (gi[k].y / o.scaler);
+            w[k].z += -o.lr * (gi[k].z / o.scaler);
+            w[k].w += -o.lr * (gi[k].w / o.scaler);
+            *reinterpret_cast<float4*>(table + (uint64_t)r2[k] * D + l * 4) = w[k];
+          }
+        }
+      } else {
+        RowRegs rr[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
+          if (src[k] >= 0) {
+            gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
+            row_load<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          if (src[k] >= 0) {
+            row_compute(o, gi[k], rr[k]);
+            row_store<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+          }
         }
       }
     }
@@ -1117,10 +1143,16 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                        u.span_list, u.span_count, direct, sro);                                   \
     HCTR_LAUNCH_CHECK();                                                                          \
     if (direct == nullptr) {                                                                      \
-      hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK>),                                   \
-                         dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro,   \
-                         kout, u.gsum, o, table, state0, state1,                                  \
-                         (unsigned long long*)prev_time);                                         \
+      if (o.optimizer == HCTR_OPT_SGD)                                                            \
+        hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, true>),                           \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           kout, u.gsum, o, table, state0, state1,                                \
+                           (unsigned long long*)prev_time);                                       \
+      else                                                                                        \
+        hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, false>),                          \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           kout, u.gsum, o, table, state0, state1,                                \
+                           (unsigned long long*)prev_time);                                       \
       HCTR_LAUNCH_CHECK();                                                                        \
     }                                                                                             \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
