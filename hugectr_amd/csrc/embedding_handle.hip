@@ -24,27 +24,48 @@ namespace hctr {
 
 int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
                           const uint64_t* vi, const float* table, void* out, int out_dtype,
-                          bool multi_hot, hipStream_t s);
+                          bool multi_hot, hipStream_t s, const uint32_t* one_hot);
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 1024;
 
+// world == 1: private copy of the row offsets (what hipMemcpyAsync did) that also clears *one_hot
+// when a bucket does not hold exactly one key -- the gather then takes its one-hot loop, which
+// needs no row offsets (embedding_kernels.hip).  *one_hot is preset non-zero by the caller.
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    copy_offsets_check_kernel(const K* __restrict__ ro, size_t n_offsets, K* __restrict__ dst,
+                              uint32_t* __restrict__ one_hot) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_offsets;
+       i += (size_t)gridDim.x * kBlock) {
+    const K v = ro[i];
+    dst[i] = v;
+    bad |= v != (K)i;  // lengths all 1 and ro[0] == 0  <=>  ro[i] == i for every i
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
+}
+
 // ---- localized: keep buckets whose slot % world == rank ----------------------------------------
 // (select_value_and_rowoffset_by_slot_id_kernel, localized_slot_sparse_embedding_hash.cu:35-54)
 template <typename K>
 __global__ void __launch_bounds__(kBlock)
     localized_lens_kernel(const K* __restrict__ ro, size_t batch, int S, int spg, int rank,
-                          int world, K* __restrict__ lens) {
+                          int world, K* __restrict__ lens, uint32_t* __restrict__ one_hot) {
   const size_t total = batch * (size_t)spg;
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
        i += (size_t)gridDim.x * kBlock) {
     const size_t b = i / spg;
     const int j = (int)(i % spg);
     const size_t t = b * S + rank + (size_t)world * j;
-    lens[i] = ro[t + 1] - ro[t];
+    const K len = ro[t + 1] - ro[t];
+    lens[i] = len;
+    bad |= len != (K)1;
   }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
 }
 
 template <typename K>
@@ -69,14 +90,18 @@ __global__ void __launch_bounds__(kBlock)
 template <typename K>
 __global__ void __launch_bounds__(kBlock)
     distributed_lens_kernel(const K* __restrict__ ro, const K* __restrict__ keys, size_t buckets,
-                            int rank, int world, K* __restrict__ lens) {
+                            int rank, int world, K* __restrict__ lens,
+                            uint32_t* __restrict__ one_hot) {
+  bool bad = false;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < buckets;
        i += (size_t)gridDim.x * kBlock) {
     K c = 0;
     for (size_t q = (size_t)ro[i]; q < (size_t)ro[i + 1]; q++)
       c += ((keys[q] % (K)world) == (K)rank) ? 1 : 0;
     lens[i] = c;
+    bad |= c != (K)1;
   }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
 }
 
 template <typename K>
@@ -242,6 +267,7 @@ struct hctr_embedding {
     // counts add up to the full counts): the divisor of forward_scale and of backward_mean
     // (distributed_slot_sparse_embedding_hash.hpp:181-197,216-221).
     void* ro_full = nullptr;  // key-typed [batch * slot_num + 1]
+    uint32_t* one_hot = nullptr;  // device flag: every bucket of the filtered CSR holds one key
   };
   BatchBufs tb, eb;
   void*& ro = tb.ro;
@@ -289,7 +315,7 @@ int free_all(hctr_embedding* e) {
   void* ptrs[] = {e->table,  e->state0,  e->state1,         e->prev_time, e->slot_id,
                   e->tb.ro,  e->tb.keys, e->tb.value_index, e->eb.ro,     e->eb.keys,
                   e->eb.value_index,     e->lens,           e->tile_sums, e->d_nnz,
-                  e->tb.ro_full,         e->eb.ro_full};
+                  e->tb.ro_full,         e->eb.ro_full,     e->tb.one_hot, e->eb.one_hot};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (e->h_nnz) (void)hipHostFree(e->h_nnz);
@@ -345,10 +371,13 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
   const bool localized = e->p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH;
   const size_t buckets = batch * e->buckets_per_sample();
   *buckets_out = buckets;
+  HCTR_HIP(hipMemsetAsync(bb.one_hot, 1, sizeof(uint32_t), s));  // non-zero = "one-hot so far"
   if (world == 1) {
     // nothing to filter: keep a private copy of the row offsets (update_params needs them after
     // the caller's buffers may have been recycled); keys are consumed by the hash stage now.
-    HCTR_HIP(hipMemcpyAsync(bb.ro, ro_in, (buckets + 1) * sizeof(K), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(copy_offsets_check_kernel<K>, dim3(grid_for(buckets + 1, kBlock, 1024)),
+                       dim3(kBlock), 0, s, ro_in, buckets + 1, (K*)bb.ro, bb.one_hot);
+    HCTR_LAUNCH_CHECK();
     *ro_out = (const K*)bb.ro;
     *keys_out = keys_in;
     return HCTR_OK;
@@ -362,7 +391,7 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
   (void)nnz;
   if (localized) {
     hipLaunchKernelGGL(localized_lens_kernel<K>, dim3(grid_for(buckets, kBlock)), dim3(kBlock), 0,
-                       s, ro_in, batch, S, e->spg, rank, world, (K*)e->lens);
+                       s, ro_in, batch, S, e->spg, rank, world, (K*)e->lens, bb.one_hot);
     HCTR_LAUNCH_CHECK();
     HCTR_TRY(exclusive_scan_lens<K>(e, bb.ro, buckets, s));
     hipLaunchKernelGGL(localized_copy_keys_kernel<K>, dim3(grid_for(buckets, kBlock)),
@@ -371,7 +400,7 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
     HCTR_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(distributed_lens_kernel<K>, dim3(grid_for(buckets, kBlock)), dim3(kBlock),
-                       0, s, ro_in, keys_in, buckets, rank, world, (K*)e->lens);
+                       0, s, ro_in, keys_in, buckets, rank, world, (K*)e->lens, bb.one_hot);
     HCTR_LAUNCH_CHECK();
     HCTR_TRY(exclusive_scan_lens<K>(e, bb.ro, buckets, s));
     hipLaunchKernelGGL(distributed_copy_keys_kernel<K>, dim3(grid_for(buckets, kBlock)),
@@ -459,7 +488,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   const int pool_combiner = e->scale_after_reduce() ? 0 : e->p.combiner;
   HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, pool_combiner, ro,
                                  e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype,
-                                 multi_hot, s));
+                                 multi_hot, s, bb.one_hot));
   e->prof.end(0, s);
   if (nnz > 0 && is_train && e->presort_enabled &&
       !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
@@ -571,6 +600,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
     HCTR_ALLOC(bb.ro, (bsz * e->buckets_per_sample() + 1) * e->key_bytes);
     HCTR_ALLOC(bb.keys, nn * e->key_bytes);
     HCTR_ALLOC(bb.value_index, nn * sizeof(uint64_t));
+    HCTR_ALLOC(bb.one_hot, 64);
     if (e->scale_after_reduce()) HCTR_ALLOC(bb.ro_full, (bsz * p.slot_num + 1) * e->key_bytes);
   }
   HCTR_ALLOC(e->lens, (e->buckets_max + 1) * e->key_bytes);
