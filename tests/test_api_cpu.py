@@ -148,6 +148,14 @@ def test_raw_format_reader(tmp_path, float_ld):
         assert (b["label"].numpy() == label[a + 32:a + 64]).all()     # rank 1 of 2
         nb += 1
     assert nb == 4  # 300 // 64, tail dropped
+    # keys AND row offsets carry the model's key type: solver.i64_input_key = False hands the
+    # u32 embedding 4-byte values (int64 arrays were read as uint32 by the C ABI)
+    r32 = data.RawReader(path, inp, sizes, 64, 1, 2, torch.device("cpu"), 0, float_ld, False,
+                         i64_key=False)
+    b32 = r32.next_batch()
+    ro, keys = b32["sparse"]["wide"]
+    assert ro.dtype == torch.int32 and keys.dtype == torch.int32
+    assert (keys.view(64, 3).numpy() == cats[:64, :3] + np.array([0, 0, 40])).all()
 
 
 def test_raw_reader_reads_the_reference_converters_file():
