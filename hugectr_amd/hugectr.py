@@ -183,10 +183,14 @@ def _launch_one_process_per_gpu(n_gpus: int):
     if n_gpus <= 1 or "WORLD_SIZE" in os.environ or dist.is_initialized():
         return
     script = sys.argv[0] if sys.argv else ""
-    if not script or not os.path.isfile(script):
-        raise RuntimeError(f"vvgpu lists {n_gpus} GPUs: launch one process per GPU "
-                           "(python -m torch.distributed.run --nproc-per-node N script.py); the "
-                           "automatic relaunch needs a script file in sys.argv[0]")
+    main_file = getattr(sys.modules.get("__main__"), "__file__", None)
+    # only a script started as `python train.py` is started again: not a test runner, a notebook
+    # kernel or `python -m something` whose argv[0] happens to be a file
+    direct = bool(main_file) and os.path.isfile(script) and \
+        os.path.abspath(main_file) == os.path.abspath(script) and "pytest" not in sys.modules and \
+        os.environ.get("HCTR_NO_RELAUNCH") != "1"
+    if not direct:
+        return  # (Model() reports the mismatch between vvgpu and the running ranks)
     import socket
     import subprocess
     with socket.socket() as so:
