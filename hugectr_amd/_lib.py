@@ -73,6 +73,8 @@ _SIGNATURES = {
     "hctr_forward_pool_weighted": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "hctr_expand_key_grads": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P]),
     "hctr_forward_pool_multihot": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_forward_pool_mapped": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int,
+                                         c_size_t, c_size_t, _P]),
     "hctr_forward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_backward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_emb_create": (c_int, [POINTER(EmbeddingParams), POINTER(_P)]),
@@ -162,6 +164,7 @@ _SIGNATURES = {
     "hctr_interaction_bwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int,
                                              _P]),
     "hctr_updater_set_ftrl": (c_int, [_P, c_float, c_float, c_float]),
+    "hctr_updater_set_grad_map": (c_int, [_P, c_size_t, c_size_t]),
     "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,
                                               c_size_t, _P, _P]),
     "hctr_emb_index": (c_int, [_P, c_int, _P, _P, c_size_t, _P]),

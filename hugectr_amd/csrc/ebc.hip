@@ -650,6 +650,16 @@ int hctr_updater_set_ftrl(hctr_updater* u, float lambda1, float lambda2, float b
   return HCTR_OK;
 }
 
+int hctr_updater_set_grad_map(hctr_updater* u, size_t samples, size_t lookups) {
+  HCTR_REQUIRE(u, "null handle");
+  HCTR_REQUIRE((samples == 0 && lookups == 0) ||
+                   (samples > 0 && lookups > 0 && samples * lookups <= 0xFFFFFFFFull),
+               "samples / lookups");
+  u->impl.map_inner = (uint32_t)samples;
+  u->impl.map_outer = (uint32_t)lookups;
+  return HCTR_OK;
+}
+
 int hctr_updater_destroy(hctr_updater* u) {
   if (!u) return HCTR_OK;
   (void)hipDeviceSynchronize();

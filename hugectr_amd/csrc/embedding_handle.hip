@@ -24,7 +24,8 @@ namespace hctr {
 
 int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
                           const uint64_t* vi, const float* table, void* out, int out_dtype,
-                          bool multi_hot, hipStream_t s, const uint32_t* one_hot);
+                          bool multi_hot, hipStream_t s, const uint32_t* one_hot,
+                          uint32_t map_inner = 0, uint32_t map_outer = 0);
 
 namespace {
 

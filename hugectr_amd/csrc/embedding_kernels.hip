@@ -74,6 +74,20 @@ __device__ __forceinline__ float mean_product<__hip_bfloat16>(float sum, float s
   return __bfloat162float(__float2bfloat16(sum)) * __bfloat162float(__float2bfloat16(sc));
 }
 
+// Output row of bucket u.  Identity, or -- embedding_collection on one GPU with a batch-major
+// output -- the transpose of the [lookup][sample] bucket order the owner pools in into
+// [sample][lookup]: the reorder the reference runs as a separate pass after its all-to-all
+// (NetworkForward, R/HugeCTR/embedding/operators/network_forward.cu) folded into the store address.
+struct OutMap {
+  uint32_t inner;  // samples per lookup (0 = identity)
+  uint32_t outer;  // lookups
+};
+__device__ __forceinline__ size_t out_row(size_t u, OutMap m) {
+  if (m.inner == 0u) return u;
+  const uint32_t v = (uint32_t)u;
+  return (size_t)(v % m.inner) * m.outer + v / m.inner;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }
@@ -93,7 +107,7 @@ template <int LPR, int BU, typename OffT, typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_vec4_kernel(size_t buckets, int combiner, const OffT* __restrict__ row_offset,
                      const uint64_t* __restrict__ value_index, const float* __restrict__ table,
-                     OutT* __restrict__ out, const uint32_t* __restrict__ one_hot) {
+                     OutT* __restrict__ out, const uint32_t* __restrict__ one_hot, OutMap om) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;  // groups per block
   const int g = threadIdx.x / LPR;
@@ -124,7 +138,7 @@ __global__ void __launch_bounds__(kBlock)
           // sum = 0.0f + row, one key: mean == sum (n = 1)
           const float4 v = make_float4(0.f + (live ? r[k].x : 0.f), 0.f + (live ? r[k].y : 0.f),
                                        0.f + (live ? r[k].z : 0.f), 0.f + (live ? r[k].w : 0.f));
-          Store4<OutT>::st(out + (u0 + k) * (size_t)D + l * 4, v);
+          Store4<OutT>::st(out + out_row(u0 + k, om) * (size_t)D + l * 4, v);
         }
       }
     }
@@ -180,7 +194,7 @@ __global__ void __launch_bounds__(kBlock)
           v.z = mean_product<OutT>(v.z, sc);
           v.w = mean_product<OutT>(v.w, sc);
         }
-        Store4<OutT>::st(out + u * (size_t)D + l * 4, v);
+        Store4<OutT>::st(out + out_row(u, om) * (size_t)D + l * 4, v);
       }
     }
   }
@@ -195,7 +209,7 @@ template <int LPR, int NB, int JU, typename OffT, typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_flat_kernel(size_t buckets, int combiner, const OffT* __restrict__ row_offset,
                      const uint64_t* __restrict__ value_index, const float* __restrict__ table,
-                     OutT* __restrict__ out) {
+                     OutT* __restrict__ out, OutMap om) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   const int g = threadIdx.x / LPR;
@@ -247,7 +261,7 @@ __global__ void __launch_bounds__(kBlock)
                 v.z = mean_product<OutT>(v.z, sc);
                 v.w = mean_product<OutT>(v.w, sc);
               }
-              Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
+              Store4<OutT>::st(out + out_row(u0 + (size_t)cur, om) * (size_t)D + l * 4, v);
             }
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             cur = b;
@@ -272,14 +286,14 @@ __global__ void __launch_bounds__(kBlock)
         v.z = mean_product<OutT>(v.z, sc);
         v.w = mean_product<OutT>(v.w, sc);
       }
-      Store4<OutT>::st(out + (u0 + (size_t)cur) * (size_t)D + l * 4, v);
+      Store4<OutT>::st(out + out_row(u0 + (size_t)cur, om) * (size_t)D + l * 4, v);
     }
     // empty buckets pool to zeros
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       const int len = e[i] - (i > 0 ? e[i - 1] : 0);
       if (i < nb && len == 0)
-        Store4<OutT>::st(out + (u0 + (size_t)i) * (size_t)D + l * 4,
+        Store4<OutT>::st(out + out_row(u0 + (size_t)i, om) * (size_t)D + l * 4,
                          make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
@@ -290,7 +304,7 @@ template <typename OffT, typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_generic_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
                         const uint64_t* __restrict__ value_index, const float* __restrict__ table,
-                        OutT* __restrict__ out) {
+                        OutT* __restrict__ out, OutMap om) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
@@ -306,7 +320,7 @@ __global__ void __launch_bounds__(kBlock)
       }
       // even sizes take the reference's align2 rule also here (e.g. D = 6, 10)
       const float m = (D % 2 == 0) ? mean_product<OutT>(sum, sc) : sum * sc;
-      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? m : sum);
+      Store4<OutT>::st1(out + out_row(u, om) * (size_t)D + v, (combiner == 1) ? m : sum);
     }
   }
 }
@@ -545,18 +559,18 @@ __global__ void __launch_bounds__(kBlock)
 template <typename OffT, typename OutT>
 int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint64_t* vi,
                 const float* table, OutT* out, bool multi_hot, hipStream_t s,
-                const uint32_t* one_hot) {
+                const uint32_t* one_hot, OutMap om) {
 #define HCTR_POOL_CASE(LPR_, BU_)                                                              \
   {                                                                                            \
     constexpr int GPB = kBlock / LPR_;                                                         \
     if (multi_hot) {                                                                           \
       const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)8), GPB, 256 * 8);          \
       hipLaunchKernelGGL((pool_flat_kernel<LPR_, 8, 8, OffT, OutT>), dim3(grid), dim3(kBlock), \
-                         0, s, buckets, combiner, ro, vi, table, out);                         \
+                         0, s, buckets, combiner, ro, vi, table, out, om);                     \
     } else {                                                                                   \
       const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)BU_), GPB, 256 * 8);        \
       hipLaunchKernelGGL((pool_vec4_kernel<LPR_, BU_, OffT, OutT>), dim3(grid), dim3(kBlock), \
-                         0, s, buckets, combiner, ro, vi, table, out, one_hot);                \
+                         0, s, buckets, combiner, ro, vi, table, out, one_hot, om);            \
     }                                                                                          \
   }
   const bool aligned = (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
@@ -573,13 +587,13 @@ int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint6
       default: {
         const int grid = grid_for(buckets * 64, kBlock);
         hipLaunchKernelGGL((pool_generic_kernel<OffT, OutT>), dim3(grid), dim3(kBlock), 0, s,
-                           buckets, D, combiner, ro, vi, table, out);
+                           buckets, D, combiner, ro, vi, table, out, om);
       }
     }
   } else {
     const int grid = grid_for(buckets * 64, kBlock);
     hipLaunchKernelGGL((pool_generic_kernel<OffT, OutT>), dim3(grid), dim3(kBlock), 0, s, buckets,
-                       D, combiner, ro, vi, table, out);
+                       D, combiner, ro, vi, table, out, om);
   }
 #undef HCTR_POOL_CASE
   HCTR_LAUNCH_CHECK();
@@ -640,8 +654,15 @@ int launch_reorder(size_t bpg, int S, int D, int N, const void* in, void* out, i
 
 int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, int key_type,
                           const uint64_t* vi, const float* table, void* out, int out_dtype,
-                          bool multi_hot, hipStream_t s, const uint32_t* one_hot) {
+                          bool multi_hot, hipStream_t s, const uint32_t* one_hot,
+                          uint32_t map_inner = 0, uint32_t map_outer = 0) {
   if (buckets == 0) return HCTR_OK;
+  const OutMap om{map_inner, map_outer};
+  if (map_inner != 0u &&
+      ((size_t)map_inner * map_outer != buckets || buckets > (size_t)0xFFFFFFFFu)) {
+    set_error("output map: inner * outer must equal the bucket count (< 2^32)");
+    return HCTR_ERR_INVALID_ARG;
+  }
   // HCTR_POOL_KERNEL=bucket|flat pins the kernel (measurements); default: the caller's hint
   static const int forced = [] {
     const char* v = getenv("HCTR_POOL_KERNEL");
@@ -653,13 +674,13 @@ int forward_pool_dispatch(size_t buckets, int D, int combiner, const void* ro, i
   switch (out_dtype) {                                                                            \
     case HCTR_EMB_F32:                                                                            \
       return launch_pool<OffT, float>(buckets, D, combiner, (const OffT*)ro, vi, table,           \
-                                      (float*)out, multi_hot, s, one_hot);                        \
+                                      (float*)out, multi_hot, s, one_hot, om);                      \
     case HCTR_EMB_F16:                                                                            \
       return launch_pool<OffT, __half>(buckets, D, combiner, (const OffT*)ro, vi, table,          \
-                                       (__half*)out, multi_hot, s, one_hot);                      \
+                                       (__half*)out, multi_hot, s, one_hot, om);                    \
     case HCTR_EMB_BF16:                                                                           \
       return launch_pool<OffT, __hip_bfloat16>(buckets, D, combiner, (const OffT*)ro, vi, table,  \
-                                               (__hip_bfloat16*)out, multi_hot, s, one_hot);     \
+                                               (__hip_bfloat16*)out, multi_hot, s, one_hot, om);   \
     default:                                                                                      \
       set_error("out_dtype");                                                                     \
       return HCTR_ERR_INVALID_ARG;                                                                \
@@ -787,6 +808,20 @@ int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const
   HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
   return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
                                table, out, out_dtype, true, as_stream(stream), nullptr);
+}
+
+int hctr_forward_pool_mapped(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                             int key_type, const uint64_t* value_index, const float* table,
+                             void* out, int out_dtype, int multi_hot, size_t samples,
+                             size_t lookups, hctr_stream_t stream) {
+  HCTR_REQUIRE(vec_size > 0, "vec_size");
+  HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
+  HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
+  HCTR_REQUIRE(samples > 0 && lookups > 0 && samples <= 0xFFFFFFFFull && lookups <= 0xFFFFFFFFull,
+               "samples / lookups");
+  return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
+                               table, out, out_dtype, multi_hot != 0, as_stream(stream), nullptr,
+                               (uint32_t)samples, (uint32_t)lookups);
 }
 
 int hctr_forward_reorder(size_t batch_per_gpu, int slot_num, int vec_size, int gpu_num,

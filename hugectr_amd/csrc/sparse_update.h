@@ -57,6 +57,10 @@ struct SparseUpdater {
   // mean combiner: CSR whose bucket lengths are the divisor, when it is not row_offset itself
   // (distributed embedding on N > 1 GPUs: the unfiltered full-batch offsets); same offset type
   const void* scale_row_offset = nullptr;
+  // gradient map (embedding_collection on one GPU, batch-major output): bucket u's gradient row is
+  // (u % map_inner) * map_outer + u / map_inner of `grad` -- the [sample][lookup] gradient read in
+  // place instead of being transposed into bucket order first.  0 = identity.  Sum combiner only.
+  uint32_t map_inner = 0, map_outer = 0;
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;

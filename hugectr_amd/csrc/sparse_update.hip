@@ -80,16 +80,20 @@ template <typename OffT, typename SortK>
 __global__ void __launch_bounds__(kBlock)
     expand_pairs_kernel(size_t buckets, size_t n_sort, const OffT* __restrict__ row_offset,
                         const uint64_t* __restrict__ value_index, SortK* __restrict__ keys,
-                        uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count) {
+                        uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count,
+                        uint32_t map_inner, uint32_t map_outer) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (tid == 0) span_count[0] = span_count[1] = 0u;  // long-run lists of seg_reduce / seg_combine
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   for (size_t u = tid; u < buckets; u += nthreads) {
     const size_t off = (size_t)row_offset[u], end = (size_t)row_offset[u + 1];
+    // the payload is the gradient row of the bucket (SparseUpdater::map_inner)
+    const uint32_t g = map_inner ? ((uint32_t)u % map_inner) * map_outer + (uint32_t)u / map_inner
+                                 : (uint32_t)u;
     for (size_t j = off; j < end && j < n_sort; j++) {
       keys[j] = (SortK)value_index[j];
-      vals[j] = (uint32_t)u;
+      vals[j] = g;
     }
   }
   // padding (host upper bound > live nnz): sorts to the end, never forms a counted run
@@ -1053,7 +1057,8 @@ int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const
   SortK* kin = (SortK*)u.sort_keys_in;
   SortK* kout = (SortK*)u.sort_keys_out;
   hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
-                     dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count);
+                     dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count,
+                     u.map_inner, u.map_outer);
   HCTR_LAUNCH_CHECK();
   // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
   int end_bit = 1;
@@ -1094,6 +1099,14 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   o.ftrl_l2b = opt.ftrl_lambda2 + opt.ftrl_beta / opt.lr;
   o.state_half = opt.state_half;
   const size_t table_elems = u.max_vocab * (size_t)D;
+
+  if (u.map_inner != 0u) {
+    if (combiner != 0 || u.ext_rows != nullptr || (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) ||
+        (size_t)u.map_inner * u.map_outer != buckets) {
+      set_error("gradient map: sum combiner, sorted update, samples * lookups == buckets only");
+      return HCTR_ERR_INVALID_ARG;
+    }
+  }
 
   if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
     const float lr_scale = opt.lr / opt.scaler;

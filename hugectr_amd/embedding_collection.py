@@ -27,6 +27,7 @@ with several owners row-wise (`key % num_shards` picks the owner in ascending GP
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -315,6 +316,17 @@ class EmbeddingCollection:
             check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
         self._nnz_host = 0
+        # One GPU, static tables, no Average lookup: the send layout [peer][lookup][b][ev] IS the
+        # feature-major output and there is nothing to exchange, so the two reorder passes around
+        # the all-to-all (network_forward / network_backward) drop out; the batch-major output is
+        # the same buckets stored (and their gradients read) through a transposed address
+        # (hctr_forward_pool_mapped, hctr_updater_set_grad_map).  HCTR_EBC_DIRECT=0 keeps the
+        # staged path (tests compare the two).
+        self._multi_hot = max_hotness > 1
+        self._direct = (self.world == 1 and not self.dynamic and self.n_local == self.L
+                        and all(c == 0 for c in self.combiner)
+                        and os.environ.get("HCTR_EBC_DIRECT", "1") != "0")
+        self._map_on = False
 
     def __del__(self):
         u = getattr(self, "_upd", None)
@@ -366,15 +378,22 @@ class EmbeddingCollection:
         return out
 
     # -- stages (public so that tests can emulate the collectives in one process) ------------------
-    def route_and_pool(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
+    def route_and_pool(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor,
+                       direct: bool = False) -> torch.Tensor:
         """global CSR -> pooled partial vectors in the all-to-all send layout
-        [peer][local lookup][b_local][ev]"""
+        [peer][local lookup][b_local][ev] (direct: straight into the output, see _setup)"""
         if self._virt is not None and gbucket_range.numel() == self.L_user * self.B + 1:
             gkeys, gbucket_range = self._expand_csr(gkeys, gbucket_range, self.B)
         kt = _lib.KEY_I64 if gkeys.dtype == torch.int64 else _lib.KEY_U32
-        check(lib.hctr_ebc_bucket_counts(self.B, self.world, self.rank, self.L, ptr(gbucket_range),
-                                         kt, ptr(self.counts), stream_ptr()))
-        send = torch.empty((max(self.nb, 1), self.ev), dtype=self.out_dtype, device=self.dev)
+        if not direct:  # bucket lengths of my samples: the Average divisor of network_*
+            check(lib.hctr_ebc_bucket_counts(self.B, self.world, self.rank, self.L,
+                                             ptr(gbucket_range), kt, ptr(self.counts),
+                                             stream_ptr()))
+        if direct:
+            shape = (self.bpg, self.L, self.ev) if self.batch_major else (self.L, self.bpg, self.ev)
+            send = torch.empty(shape, dtype=self.out_dtype, device=self.dev)
+        else:
+            send = torch.empty((max(self.nb, 1), self.ev), dtype=self.out_dtype, device=self.dev)
         if self.n_local == 0:
             return send[:0]
         check(lib.hctr_ebc_route_keys(self.B, self.world, self.n_local, ptr(self.d_desc),
@@ -384,10 +403,33 @@ class EmbeddingCollection:
         if self.dynamic:
             return self._dynamic_pool(send)
         self._nnz_host = int(gkeys.numel())  # upper bound; the live count stays on the device
+        if direct:
+            # (samples, lookups) = (0, 0) would be the identity map; the ABI spells identity as
+            # the plain entry points
+            if self.batch_major:
+                check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
+                                                   _lib.KEY_I64, ptr(self.indices), ptr(self.table),
+                                                   ptr(send), _DT[self.out_dtype],
+                                                   1 if self._multi_hot else 0, self.bpg, self.L,
+                                                   stream_ptr()))
+            else:
+                pool = lib.hctr_forward_pool_multihot if self._multi_hot else lib.hctr_forward_pool
+                check(pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
+                           ptr(self.indices), ptr(self.table), ptr(send), _DT[self.out_dtype],
+                           stream_ptr()))
+            return send
         check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
                                     ptr(self.indices), ptr(self.table), ptr(send),
                                     _DT[self.out_dtype], stream_ptr()))
         return send
+
+    def forward_global(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
+        """replicated global feature-major CSR -> this rank's output rows"""
+        send = self.route_and_pool(gkeys, gbucket_range, self._direct)
+        if self._direct:
+            return send
+        recv = self._a2a(send, self.send_counts, self.recv_counts)
+        return self.network_forward(recv)
 
     # -- the reference's key route for data-parallel input: two all-to-alls -------------------------
     def route_send(self, keys: torch.Tensor, bucket_range: torch.Tensor):
@@ -511,13 +553,19 @@ class EmbeddingCollection:
                                             stream_ptr()))
         return send
 
-    def apply_gradients(self, top_grad: torch.Tensor):
-        """top_grad: [peer][local lookup][b_local][ev] gradients of my pooled partial vectors"""
+    def apply_gradients(self, top_grad: torch.Tensor, direct: bool = False):
+        """top_grad: [peer][local lookup][b_local][ev] gradients of my pooled partial vectors
+        (direct: the gradient of the output itself, in the output's layout)"""
         if self.n_local == 0:
             return
         self._times += 1
         if self.dynamic:
             return self._dynamic_apply(top_grad.contiguous())
+        mapped = direct and self.batch_major
+        if mapped != self._map_on:
+            check(lib.hctr_updater_set_grad_map(self._upd, self.bpg if mapped else 0,
+                                                self.L if mapped else 0))
+            self._map_on = mapped
         check(lib.hctr_updater_update(self._upd, self.nb, self._nnz_host, ptr(self.out_range),
                                       ptr(self.indices), ptr(top_grad.contiguous()),
                                       _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,
@@ -534,11 +582,15 @@ class EmbeddingCollection:
             send = self._forward_a2a_route(keys, bucket_range)
         else:
             gk, gbr = self._allgather_keys(keys, bucket_range)
-            send = self.route_and_pool(gk, gbr)
+            send = self.route_and_pool(gk, gbr, self._direct)
+        if self._direct:
+            return send
         recv = self._a2a(send, self.send_counts, self.recv_counts)
         return self.network_forward(recv)
 
     def backward_and_update(self, grad: torch.Tensor):
+        if self._direct:  # the gradient of the output is the gradient of my buckets
+            return self.apply_gradients(grad, True)
         send = self.network_backward(grad)
         top = self._a2a(send, self.recv_counts, self.send_counts)
         self.apply_gradients(top)

@@ -714,9 +714,7 @@ class Model:
         gk = torch.cat([k - rt["offsets"][l] for l, k in enumerate(keys)])
         if isinstance(e, DataParallelCollection):
             return e.forward(gk, gbr)
-        send = e.route_and_pool(gk, gbr)
-        recv = e._a2a(send, e.send_counts, e.recv_counts)
-        return e.network_forward(recv)
+        return e.forward_global(gk, gbr)
 
     def _in_width(self, name):
         shp = self._shapes[name]

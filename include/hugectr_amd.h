@@ -99,6 +99,15 @@ int hctr_expand_key_grads(size_t buckets, int vec_size, int combiner, const int6
 int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const void* row_offset,
                       int key_type, const uint64_t* value_index, const float* table, void* out,
                       int out_dtype, hctr_stream_t stream);
+/* same contract with the store address transposed: buckets are numbered lookup * samples + sample
+ * (samples * lookups == buckets) and bucket u lands in output row sample * lookups + lookup --
+ * the batch-major output of embedding_collection on one GPU, where the reference's reorder after
+ * the all-to-all (R/HugeCTR/embedding/operators/network_forward.cu) has nothing to exchange and
+ * reduces to this address map.  multi_hot != 0 picks the flat-range kernel. */
+int hctr_forward_pool_mapped(size_t buckets, int vec_size, int combiner, const void* row_offset,
+                             int key_type, const uint64_t* value_index, const float* table,
+                             void* out, int out_dtype, int multi_hot, size_t samples,
+                             size_t lookups, hctr_stream_t stream);
 /* pooling through per-key row pointers -- what embedding::ILookup::lookup(keys, ..., float**
  * embedding_vec) hands to the pooling kernel (R/HugeCTR/embedding/embedding_table.hpp:22-33,
  * generic_lookup.cuh:318-416): rows[j] = device address of key j's fp32 vector, NULL = key not in
@@ -302,6 +311,13 @@ int hctr_updater_destroy(hctr_updater* u);
 /* Ftrl hyper-parameters for optimizer = HCTR_OPT_FTRL (FtrlOptimizer,
  * R/HugeCTR/embedding_storage/ragged_static_embedding.cu:159-290): state0 = n, state1 = z */
 int hctr_updater_set_ftrl(hctr_updater* u, float lambda1, float lambda2, float beta);
+/* One-GPU embedding_collection with a batch-major ([sample][lookup][vec]) output: buckets are
+ * numbered lookup * samples + sample, their gradient row is sample * lookups + lookup of `grad`.
+ * The reference transposes in a pass of its own on both sides of the all-to-all
+ * (R/HugeCTR/embedding/operators/network_backward.cu); with one GPU there is no exchange, so the
+ * transpose is an address computation of the update (and of hctr_forward_pool_mapped).  Sum
+ * combiner only; (0, 0) switches the map off. */
+int hctr_updater_set_grad_map(hctr_updater* u, size_t samples, size_t lookups);
 int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
                         const uint64_t* indices, const void* grad, int grad_dtype, int optimizer,
                         int update_type, float lr, float beta1, float beta2, float epsilon,

@@ -460,3 +460,79 @@ def test_multi_hot_concat_combiner(oracle, world):
             s0 = e.row_start_of_table[t]
             np.testing.assert_allclose(e.table[s0:s0 + own.size].cpu().numpy(), ref[t][own],
                                        rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch_major", [False, True])
+@pytest.mark.parametrize("max_hot", [1, 5])
+@pytest.mark.parametrize("opt_name,dtype", [("sgd", "float32"), ("adagrad", "bfloat16"),
+                                            ("ftrl", "float16")])
+def test_one_gpu_direct_path_equals_staged(monkeypatch, batch_major, max_hot, opt_name, dtype):
+    """One GPU, sum lookups: pooling straight into the output (transposed store for batch-major) and
+    the update reading the output's gradient in place must reproduce, bit for bit, the staged
+    route -> pool -> network_forward / network_backward -> update path the reference runs
+    (R/HugeCTR/embedding/model_parallel_embedding.cpp forward_per_gpu / backward_per_gpu)."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(11 + max_hot)
+    B, ev = 96, 32
+    vocabs = [70, 9, 400]
+    lookup_table = [0, 1, 2, 2, 0]
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l, t in enumerate(lookup_table):
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", "sum")
+    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "ftrl": _lib.OPT_FTRL}[opt_name]
+    kw = dict(lr=0.1, optimizer=opt, scaler=4.0, epsilon=1e-6, batch_major=batch_major,
+              max_hotness=max_hot, ftrl=(0.02, 0.05, 0.3), out_dtype=getattr(torch, dtype), seed=3)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", "0")
+    staged = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", "1")
+    direct = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    assert direct._direct and not staged._direct
+    assert torch.equal(staged.table, direct.table)
+    for step in range(3):
+        if max_hot == 1:
+            keys = np.concatenate([rng.integers(0, vocabs[t], size=B) for t in lookup_table]).astype(np.int64)
+            br = np.arange(len(lookup_table) * B + 1, dtype=np.int64)
+        else:
+            keys, br = _make_inputs(rng, B, vocabs, lookup_table, max_hot)
+        kt, brt = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        a, b = staged.forward(kt, brt), direct.forward(kt, brt)
+        assert a.shape == b.shape and torch.equal(a, b), step
+        g = torch.randn(a.shape, device="cuda").to(a.dtype)
+        staged.backward_and_update(g)
+        direct.backward_and_update(g)
+        assert torch.equal(staged.table, direct.table), step
+        if staged.accum is not None:
+            assert torch.equal(staged.accum, direct.accum), step
+    # an Average lookup keeps the staged path (its divisor lives in network_forward)
+    cfg2 = ha.EmbeddingCollectionConfig()
+    cfg2.embedding_lookup(tcfg[0], "i", "o", "mean")
+    assert not ha.EmbeddingCollection.for_rank(0, 1, cfg2, B, **kw)._direct
+
+
+def test_forward_pool_mapped_rejects_bad_shapes():
+    import torch
+    from hugectr_amd import _lib
+    ro = torch.arange(7, dtype=torch.int64, device="cuda")
+    vi = torch.zeros(6, dtype=torch.int64, device="cuda")
+    tab = torch.zeros((4, 8), device="cuda")
+    out = torch.zeros((6, 8), device="cuda")
+    rc = _lib.lib.hctr_forward_pool_mapped(6, 8, 0, _lib.ptr(ro), _lib.KEY_I64, _lib.ptr(vi), _lib.ptr(tab),
+                                           _lib.ptr(out), _lib.F32, 0, 4, 2, _lib.stream_ptr())
+    assert rc != 0  # samples * lookups != buckets
+    u = __import__("ctypes").c_void_p()
+    _lib.check(_lib.lib.hctr_updater_create(6, 4, 8, __import__("ctypes").byref(u)))
+    _lib.check(_lib.lib.hctr_updater_set_grad_map(u, 3, 2))
+    g = torch.zeros((6, 8), device="cuda")
+    rc = _lib.lib.hctr_updater_update(u, 6, 6, _lib.ptr(ro), _lib.ptr(vi), _lib.ptr(g), _lib.F32,
+                                      _lib.OPT_SGD, _lib.UPDATE_LOCAL, 0.1, 0.9, 0.999, 1e-7, 0.0, 1.0, 1,
+                                      _lib.ptr(tab), None, None, _lib.stream_ptr())
+    assert rc == 0  # hctr_updater_update is sum-only: the map is accepted
+    _lib.check(_lib.lib.hctr_updater_set_grad_map(u, 4, 2))
+    rc = _lib.lib.hctr_updater_update(u, 6, 6, _lib.ptr(ro), _lib.ptr(vi), _lib.ptr(g), _lib.F32,
+                                      _lib.OPT_SGD, _lib.UPDATE_LOCAL, 0.1, 0.9, 0.999, 1e-7, 0.0, 1.0, 1,
+                                      _lib.ptr(tab), None, None, _lib.stream_ptr())
+    assert rc != 0  # 4 * 2 != 6 buckets
+    _lib.lib.hctr_updater_destroy(u)
