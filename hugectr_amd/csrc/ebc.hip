@@ -97,6 +97,36 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// One GPU owning every lookup whole (num_shards == 1, local lookup order == global order): the
+// owner's buckets ARE the input buckets, so count + scan + index collapse into one pass --
+// out_range = bucket_range (as int64), row = row_start(lookup) + key.  Also raises the one-hot
+// flag the pooling kernel's offset-free loop keys on (every bucket exactly its own key).
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ebc_route_whole_kernel(size_t total, size_t batch, const long long* __restrict__ rs,
+                           const K* __restrict__ keys, const K* __restrict__ bucket_range,
+                           long long* __restrict__ out_range, uint64_t* __restrict__ out_idx,
+                           unsigned long long* __restrict__ d_nnz,
+                           uint32_t* __restrict__ one_hot) {
+  bool ragged = false;
+  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < total;
+       ob += (size_t)gridDim.x * kBlock) {
+    const size_t b0 = (size_t)bucket_range[ob], b1 = (size_t)bucket_range[ob + 1];
+    out_range[ob] = (long long)b0;
+    if (ob == total - 1) {
+      out_range[total] = (long long)b1;
+      if (d_nnz) *d_nnz = (unsigned long long)b1;
+    }
+    ragged |= (b0 != ob) | (b1 != ob + 1);
+    const long long r0 = rs[ob / batch];
+    for (size_t q = b0; q < b1; q++) {
+      const long long k = (long long)keys[q];
+      out_idx[q] = r0 < 0 ? (uint64_t)k : (uint64_t)(r0 + k);
+    }
+  }
+  if (one_hot && ragged) *one_hot = 0u;
+}
+
 // ---- LocalReduceIndexCalculation + LocalReduce (R/HugeCTR/embedding/operators/
 //      index_calculation.cu, model_backward.cu:113-...): sort the keys of the local lookups by
 //      row id, find the unique ones, sum the gradients of every unique row (ascending position).
@@ -525,6 +555,39 @@ int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const in
   if (rc == HCTR_OK && d_nnz)
     HCTR_HIP(hipMemcpyAsync(d_nnz, d_total, sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
   return rc;
+}
+
+int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start, const void* keys,
+                         const void* bucket_range, int key_type, int64_t* out_bucket_range,
+                         uint64_t* out_indices, uint64_t* d_nnz, uint32_t* one_hot,
+                         hctr_stream_t stream) {
+  HCTR_REQUIRE(num_lookups >= 0, "num_lookups");
+  hipStream_t s = as_stream(stream);
+  const size_t nb = (size_t)num_lookups * batch;
+  if (one_hot) HCTR_HIP(hipMemsetAsync(one_hot, nb > 0 ? 1 : 0, sizeof(uint32_t), s));
+  if (nb == 0) {
+    HCTR_HIP(hipMemsetAsync(out_bucket_range, 0, sizeof(int64_t), s));
+    if (d_nnz) HCTR_HIP(hipMemsetAsync(d_nnz, 0, sizeof(uint64_t), s));
+    return HCTR_OK;
+  }
+  HCTR_REQUIRE(row_start && bucket_range && out_bucket_range && out_indices, "null pointer");
+  const int grid = grid_for(nb, kBlock);
+  if (key_type == HCTR_KEY_U32) {
+    hipLaunchKernelGGL(ebc_route_whole_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, nb, batch,
+                       (const long long*)row_start, (const uint32_t*)keys,
+                       (const uint32_t*)bucket_range, (long long*)out_bucket_range, out_indices,
+                       (unsigned long long*)d_nnz, one_hot);
+  } else if (key_type == HCTR_KEY_I64) {
+    hipLaunchKernelGGL(ebc_route_whole_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, nb, batch,
+                       (const long long*)row_start, (const long long*)keys,
+                       (const long long*)bucket_range, (long long*)out_bucket_range, out_indices,
+                       (unsigned long long*)d_nnz, one_hot);
+  } else {
+    set_error("key_type");
+    return HCTR_ERR_INVALID_ARG;
+  }
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
 }
 
 int hctr_ebc_routed_keys_to_indices(size_t batch_per_gpu, int world, int num_local_lookups,

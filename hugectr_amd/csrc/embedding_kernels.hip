@@ -813,14 +813,16 @@ int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const
 int hctr_forward_pool_mapped(size_t buckets, int vec_size, int combiner, const void* row_offset,
                              int key_type, const uint64_t* value_index, const float* table,
                              void* out, int out_dtype, int multi_hot, size_t samples,
-                             size_t lookups, hctr_stream_t stream) {
+                             size_t lookups, const uint32_t* one_hot, hctr_stream_t stream) {
   HCTR_REQUIRE(vec_size > 0, "vec_size");
   HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
   HCTR_REQUIRE(buckets == 0 || (row_offset && value_index && table && out), "null pointer");
-  HCTR_REQUIRE(samples > 0 && lookups > 0 && samples <= 0xFFFFFFFFull && lookups <= 0xFFFFFFFFull,
+  HCTR_REQUIRE((samples == 0 && lookups == 0) || (samples > 0 && lookups > 0 &&
+                                                  samples <= 0xFFFFFFFFull &&
+                                                  lookups <= 0xFFFFFFFFull),
                "samples / lookups");
   return forward_pool_dispatch(buckets, vec_size, combiner, row_offset, key_type, value_index,
-                               table, out, out_dtype, multi_hot != 0, as_stream(stream), nullptr,
+                               table, out, out_dtype, multi_hot != 0, as_stream(stream), one_hot,
                                (uint32_t)samples, (uint32_t)lookups);
 }
 

@@ -327,6 +327,7 @@ class EmbeddingCollection:
                         and all(c == 0 for c in self.combiner)
                         and os.environ.get("HCTR_EBC_DIRECT", "1") != "0")
         self._map_on = False
+        self.d_one_hot = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
     def __del__(self):
         u = getattr(self, "_upd", None)
@@ -396,6 +397,22 @@ class EmbeddingCollection:
             send = torch.empty((max(self.nb, 1), self.ev), dtype=self.out_dtype, device=self.dev)
         if self.n_local == 0:
             return send[:0]
+        if direct:
+            # every lookup whole on this rank: one pass (hctr_ebc_route_whole), and the gather keys
+            # its offset-free loop on the one-hot flag that pass leaves on the device
+            check(lib.hctr_ebc_route_whole(self.B, self.L, ptr(self.d_row_start), ptr(gkeys),
+                                           ptr(gbucket_range), kt, ptr(self.out_range),
+                                           ptr(self.indices), ptr(self.d_nnz), ptr(self.d_one_hot),
+                                           stream_ptr()))
+            self._nnz_host = int(gkeys.numel())
+            bm = self.batch_major
+            check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
+                                               _lib.KEY_I64, ptr(self.indices), ptr(self.table),
+                                               ptr(send), _DT[self.out_dtype],
+                                               1 if self._multi_hot else 0, self.bpg if bm else 0,
+                                               self.L if bm else 0, ptr(self.d_one_hot),
+                                               stream_ptr()))
+            return send
         check(lib.hctr_ebc_route_keys(self.B, self.world, self.n_local, ptr(self.d_desc),
                                       ptr(self.d_row_start), ptr(gkeys), ptr(gbucket_range), kt,
                                       ptr(self.out_range), ptr(self.indices), ptr(self.d_nnz),
@@ -403,21 +420,6 @@ class EmbeddingCollection:
         if self.dynamic:
             return self._dynamic_pool(send)
         self._nnz_host = int(gkeys.numel())  # upper bound; the live count stays on the device
-        if direct:
-            # (samples, lookups) = (0, 0) would be the identity map; the ABI spells identity as
-            # the plain entry points
-            if self.batch_major:
-                check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
-                                                   _lib.KEY_I64, ptr(self.indices), ptr(self.table),
-                                                   ptr(send), _DT[self.out_dtype],
-                                                   1 if self._multi_hot else 0, self.bpg, self.L,
-                                                   stream_ptr()))
-            else:
-                pool = lib.hctr_forward_pool_multihot if self._multi_hot else lib.hctr_forward_pool
-                check(pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
-                           ptr(self.indices), ptr(self.table), ptr(send), _DT[self.out_dtype],
-                           stream_ptr()))
-            return send
         check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
                                     ptr(self.indices), ptr(self.table), ptr(send),
                                     _DT[self.out_dtype], stream_ptr()))

@@ -103,11 +103,13 @@ int hctr_forward_pool_multihot(size_t buckets, int vec_size, int combiner, const
  * (samples * lookups == buckets) and bucket u lands in output row sample * lookups + lookup --
  * the batch-major output of embedding_collection on one GPU, where the reference's reorder after
  * the all-to-all (R/HugeCTR/embedding/operators/network_forward.cu) has nothing to exchange and
- * reduces to this address map.  multi_hot != 0 picks the flat-range kernel. */
+ * reduces to this address map; (samples, lookups) = (0, 0) is the identity.  multi_hot != 0
+ * picks the flat-range kernel.  one_hot (DEVICE u32, may be NULL): non-zero promises
+ * row_offset[i] == i for all i, and the kernel then walks the keys without reading row_offset. */
 int hctr_forward_pool_mapped(size_t buckets, int vec_size, int combiner, const void* row_offset,
                              int key_type, const uint64_t* value_index, const float* table,
                              void* out, int out_dtype, int multi_hot, size_t samples,
-                             size_t lookups, hctr_stream_t stream);
+                             size_t lookups, const uint32_t* one_hot, hctr_stream_t stream);
 /* pooling through per-key row pointers -- what embedding::ILookup::lookup(keys, ..., float**
  * embedding_vec) hands to the pooling kernel (R/HugeCTR/embedding/embedding_table.hpp:22-33,
  * generic_lookup.cuh:318-416): rows[j] = device address of key j's fp32 vector, NULL = key not in
@@ -284,6 +286,15 @@ int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const in
                         const int64_t* row_start, const void* keys, const void* bucket_range,
                         int key_type, int64_t* out_bucket_range, uint64_t* out_indices,
                         uint64_t* d_nnz, void* workspace, hctr_stream_t stream);
+/* hctr_ebc_route_keys for the one-GPU case in which this rank owns every lookup whole (world = 1,
+ * num_shards = 1 everywhere, lookup_desc = identity): nothing is filtered, so the output CSR is the
+ * input CSR and the three passes (count, scan, index) are one.  one_hot (DEVICE u32, may be NULL)
+ * is left non-zero iff every bucket holds exactly its own key (bucket_range[i] == i) -- the flag
+ * hctr_forward_pool_mapped takes. */
+int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start, const void* keys,
+                         const void* bucket_range, int key_type, int64_t* out_bucket_range,
+                         uint64_t* out_indices, uint64_t* d_nnz, uint32_t* one_hot,
+                         hctr_stream_t stream);
 /* total key count of each (lookup, local sample) bucket of this rank: Average divides by it on
  * the receiving side (R/HugeCTR/embedding/operators/network_forward.cu:272-283) */
 int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,

@@ -520,7 +520,7 @@ def test_forward_pool_mapped_rejects_bad_shapes():
     tab = torch.zeros((4, 8), device="cuda")
     out = torch.zeros((6, 8), device="cuda")
     rc = _lib.lib.hctr_forward_pool_mapped(6, 8, 0, _lib.ptr(ro), _lib.KEY_I64, _lib.ptr(vi), _lib.ptr(tab),
-                                           _lib.ptr(out), _lib.F32, 0, 4, 2, _lib.stream_ptr())
+                                           _lib.ptr(out), _lib.F32, 0, 4, 2, None, _lib.stream_ptr())
     assert rc != 0  # samples * lookups != buckets
     u = __import__("ctypes").c_void_p()
     _lib.check(_lib.lib.hctr_updater_create(6, 4, 8, __import__("ctypes").byref(u)))
