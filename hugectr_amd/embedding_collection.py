@@ -182,7 +182,10 @@ class EmbeddingCollection:
                epsilon=1e-7, initial_accu_value=0.0, out_dtype=torch.float32, batch_major=False,
                key_dtype=torch.int64, max_hotness=1, seed=0, ftrl=(0.0, 0.0, 0.0),
                storage=None, initializer="", init_capacity=1 << 20, beta1=0.9, beta2=0.999,
-               momentum_factor=0.9, rmsprop_beta=0.9, hotness=None):
+               momentum_factor=0.9, rmsprop_beta=0.9, hotness=None, tables_from=None):
+        # tables_from: another collection of the same config (the training one) whose tables and
+        # optimizer state this one uses -- the evaluation runtime of a model owns per-batch
+        # scratch only (a second copy of 100+ GB tables would not even fit for a moment)
         assert global_batch % self.world == 0
         config = self._expand_concat_lookups(config, hotness, batch_major)
         if storage is None:  # max_vocabulary_size < 0 means dynamic (embedding_storage/common.hpp:78,
@@ -229,7 +232,15 @@ class EmbeddingCollection:
             rows += -(-max(tables[t].max_vocabulary_size, 0) // ns)
         self.local_rows = max(rows, 1)
         self.accum = self.ftrl_z = self.table = None
-        if self.dynamic:
+        if tables_from is not None:
+            src = tables_from
+            assert src.dynamic == self.dynamic and src.local_rows == self.local_rows
+            self.table, self.accum, self.ftrl_z = src.table, src.accum, src.ftrl_z
+            if self.dynamic:
+                self.class_of_table = src.class_of_table
+                self.det, self.det_opt = src.det, src.det_opt
+                self.local_rows = 1
+        elif self.dynamic:
             # one class of the dynamic table per local table shard; max_vocabulary_size is only a
             # hint here, the maps grow on demand (dynamic_embedding.cu:41-75)
             from .dynamic_table import DynamicEmbeddingTable, DynamicTableOptimizer
@@ -299,7 +310,10 @@ class EmbeddingCollection:
         self.send_counts = [self.n_local * self.bpg * self.ev] * self.world
         self.recv_counts = [n * self.bpg * self.ev for n in self.n_local_of]
         # scratch
-        self.max_nnz = self.B * max(1, self.L) * max(1, max_hotness)
+        # key capacity of one batch: the declared hotness of every lookup when the caller knows it
+        # (a 100-hot table beside one-hot ones must not size all 26 lookups for 100 keys)
+        self.max_nnz = self.B * (max(1, sum(int(h) for h in hotness)) if hotness
+                                 else max(1, self.L) * max(1, max_hotness))
         nb = self.world * max(self.n_local, 0) * self.bpg
         self.nb = nb
         self.ws = torch.empty(lib.hctr_ebc_route_workspace_bytes(self.B, max(self.n_local, 1)) + 64,

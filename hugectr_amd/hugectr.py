@@ -684,12 +684,11 @@ class Model:
         train = EmbeddingCollection(cfg, B, **ekw)
         ev = None
         if Be > 0:
-            ev = train if (Be == B and not dynamic) else EmbeddingCollection(cfg, Be, **ekw)
-            if ev is not train:  # same tables, own per-batch scratch
-                ev.table, ev.accum, ev.ftrl_z = train.table, train.accum, train.ftrl_z
-                if dynamic:
-                    ev.det, ev.det_opt = train.det, train.det_opt
-                    ev.training = False  # evaluation never inserts: unseen keys read as zeros
+            # same tables, own per-batch scratch
+            ev = train if (Be == B and not dynamic) else EmbeddingCollection(
+                cfg, Be, tables_from=train, **ekw)
+            if ev is not train and dynamic:
+                ev.training = False  # evaluation never inserts: unseen keys read as zeros
         L, evs = train.L, train.ev  # (L counts a multi-hot concat lookup once per key slot)
         if declare_shapes:
             if cfg.top_name:

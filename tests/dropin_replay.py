@@ -18,6 +18,34 @@ def _resolve(mod, path):
     return o
 
 
+class ReplayCallback:
+    """mixin of the stand-in for a script-side hugectr.TrainingCallback subclass (its code cannot
+    travel as data; its class name and plain attributes do): counts what fit() tells it"""
+
+    def __init__(self, name, attrs):
+        self.name, self.attrs = name, dict(attrs)
+        self.events = []
+
+    def on_training_start(self):
+        self.events.append(("training_start",))
+
+    def on_training_end(self, current_iter):
+        self.events.append(("training_end", current_iter))
+
+    def on_eval_start(self, current_iter):
+        self.events.append(("eval_start", current_iter))
+        return False
+
+    def on_eval_end(self, current_iter, eval_results):
+        self.events.append(("eval_end", current_iter, dict(eval_results)))
+        return False
+
+
+def make_callback(mod, v):
+    cls = type(v["callback"], (ReplayCallback, mod.TrainingCallback), {})
+    return cls(v["callback"], v["attrs"])
+
+
 def replay(mod, calls, before=None, substitute=None):
     """executes the recorded calls on `mod`; before(i, target, args, kwargs) may edit args / kwargs
     in place (test-speed caps); substitute(target) may return a callable that takes the place of
@@ -36,6 +64,8 @@ def replay(mod, calls, before=None, substitute=None):
                 return {k: dec(x) for k, x in v["dict"].items()}
             if "pairs" in v and len(v) == 1:
                 return {dec(k): dec(x) for k, x in v["pairs"]}
+            if "callback" in v:
+                return make_callback(mod, v)
             raise ValueError(v)
         return v
 

@@ -33,6 +33,15 @@ SCRIPTS = {
                           "8192", "--max_iter", "24", "--eval_interval", "12",
                           "--max_eval_batches", "2", "--display_interval", "8", "--lr", "0.5",
                           "--warmup_steps", "4", "--decay_start", "12", "--decay_steps", "8"]),
+    # MLPerf DLRM-DCNv2 (BASELINE configs[4]'s API family: embedding_collection, multi-hot inputs,
+    # the sample's own sharding planner -- imported from the checkout while recording -- and a
+    # hugectr.TrainingCallback subclass of the sample's mlperf_logger package)
+    "dlrm_mlperf_dcnv2": ("samples/dlrm/train.py",
+                          ["--num_gpus_per_node", "1", "--batchsize", "8192", "--batchsize_eval",
+                           "8192", "--max_iter", "24", "--eval_interval", "12",
+                           "--max_eval_batches", "2", "--display_interval", "8", "--lr", "0.005",
+                           "--sharding_plan", "auto", "--memory_cap_for_embedding", "250",
+                           "--use_mixed_precision", "--scaler", "1024"]),
 }
 
 
@@ -45,6 +54,13 @@ class Recorder:
             return {"name": v._path}
         if isinstance(v, _Obj):
             return {"ref": v._idx}
+        if isinstance(v, _CallbackBase):
+            # an instance of a script-side subclass of hugectr.TrainingCallback: code cannot
+            # travel as data, so the class name and its plain public attributes do; the replaying
+            # test supplies a TrainingCallback of its own in that place
+            return {"callback": type(v).__name__,
+                    "attrs": {k: x for k, x in sorted(vars(v).items())
+                              if not k.startswith("_") and isinstance(x, (int, float, str, bool))}}
         if isinstance(v, (list, tuple)):
             return [self.enc(x) for x in v]
         if isinstance(v, dict):
@@ -83,6 +99,42 @@ class _Name:
         return isinstance(other, _Name) and other._path == self._path
 
 
+class _CallbackBase:
+    """hugectr.TrainingCallback while recording: scripts subclass it (samples/dlrm/mlperf_logger)"""
+
+
+class _Quiet:
+    """stands in for MLPerf's logging objects (mlperf_common / mlperf_logging are not installed
+    and are no part of the hugectr surface): every attribute is a callable that returns another"""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return _Quiet()
+
+    def __call__(self, *a, **k):
+        return _Quiet()
+
+
+def _mlperf_stubs():
+    mods = {}
+    for name in ("mlperf_logging", "mlperf_logging.mllog", "mlperf_logging.mllog.constants",
+                 "mlperf_common", "mlperf_common.frameworks", "mlperf_common.frameworks.hugectr",
+                 "mlperf_common.logging"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        mods[name] = m
+    mods["mlperf_logging.mllog.constants"].__getattr__ = lambda attr: attr  # a constant = its name
+    mods["mlperf_logging.mllog"].constants = mods["mlperf_logging.mllog.constants"]
+    mods["mlperf_logging"].mllog = mods["mlperf_logging.mllog"]
+    mods["mlperf_common.frameworks.hugectr"].HCTRCommunicationHandler = _Quiet
+    mods["mlperf_common.logging"].MLLoggerWrapper = _Quiet
+    return mods
+
+
 class _Obj:
     """the result of a recorded call; its methods are recorded too"""
 
@@ -99,7 +151,8 @@ class _Obj:
 
 def _stub_modules(rec):
     m = types.ModuleType("hugectr")
-    m.__getattr__ = lambda attr: _Name(rec, attr)  # PEP 562
+    m.__getattr__ = lambda attr: (_CallbackBase if attr == "TrainingCallback"
+                                  else _Name(rec, attr))  # PEP 562
     m.__path__ = []
     t = types.ModuleType("hugectr.tools")
     t.__getattr__ = lambda attr: _Name(rec, f"tools.{attr}")
@@ -109,20 +162,27 @@ def _stub_modules(rec):
 
 def record(script_path, argv):
     rec = Recorder()
-    saved = {k: sys.modules.get(k) for k in ("hugectr", "hugectr.tools", "mpi4py")}
-    saved_argv = sys.argv
-    sys.modules.update(_stub_modules(rec))
+    stubs = {**_stub_modules(rec), **_mlperf_stubs()}
+    before = set(sys.modules)
+    saved = {k: sys.modules.get(k) for k in list(stubs) + ["mpi4py"]}
+    saved_argv, saved_getsize = sys.argv, os.path.getsize
+    sys.modules.update(stubs)
     if saved["mpi4py"] is None:
         sys.path.insert(0, os.path.join(ROOT, "hugectr_amd", "compat"))
+    # packages that sit next to the script (samples/dlrm/sharding, mlperf_logger)
+    sys.path.insert(0, os.path.dirname(script_path))
+    # scripts log the row count of dataset files that only exist on a training machine
+    os.path.getsize = lambda f: saved_getsize(f) if os.path.exists(f) else 0
     try:
         sys.argv = [script_path] + list(argv)
         runpy.run_path(script_path, run_name="__main__")
     finally:
-        sys.argv = saved_argv
+        sys.argv, os.path.getsize = saved_argv, saved_getsize
+        sys.path.remove(os.path.dirname(script_path))
+        for k in set(sys.modules) - before:  # script-side packages must not outlive the recording
+            sys.modules.pop(k, None)
         for k, v in saved.items():
-            if v is None:
-                sys.modules.pop(k, None)
-            else:
+            if v is not None:
                 sys.modules[k] = v
         if saved["mpi4py"] is None:
             sys.path.remove(os.path.join(ROOT, "hugectr_amd", "compat"))

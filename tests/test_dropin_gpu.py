@@ -1,11 +1,13 @@
 """Drop-in boundary on the GPU: the exact calls the reference's own UNMODIFIED training scripts make
 (tests/golden/script_traces.json, recorded from R/samples/dcn/dcn_parquet.py,
-R/samples/deepfm/deepfm_parquet.py, R/samples/wdl/wdl_1gpu.py and
-R/test/embedding_collection_test/dgx_a100_one_hot.py by tests/golden/make_script_traces.py) are
+R/samples/deepfm/deepfm_parquet.py, R/samples/wdl/wdl_1gpu.py,
+R/test/embedding_collection_test/dgx_a100_one_hot.py and the MLPerf DLRM-DCNv2 sample
+R/samples/dlrm/train.py by tests/golden/make_script_traces.py) are
 executed against `import hugectr` -- this repo's module of the reference's name -- on an MI355X,
 with generated data where the scripts expect theirs.  The GPU box has no reference checkout, which
 is why the scripts travel as recorded calls; where the checkout exists the script files themselves
 are run with runpy as well.  Only test-speed caps are applied (iterations, evaluation batches)."""
+import gc
 import math
 import os
 import subprocess
@@ -41,15 +43,18 @@ def _make_data(hugectr, calls, tmp_path):
             eval_num_samples=Be)).generate()
         return
     assert fmt == "DataReaderType_t.RawAsync"
-    # Raw file of the multi-hot async reader: per sample {label i32, dense f32 x 13, one u32 key
-    # per table (within the table; the reader adds the table offsets)}
+    # Raw file of the multi-hot async reader: per sample {label i32, dense f32 x 13, then for
+    # every table its hotness u32 keys (within the table; the reader adds the table offsets)}
+    hot = [c["args"][1] for c in calls if c["call"] == "DataReaderSparseParam"]
+    assert len(hot) == len(sizes)
     rng = np.random.default_rng(0)
     for path, n in ((reader["source"][0], B * 4), (reader["eval_source"], Be * 2)):
         f = os.path.join(str(tmp_path), path.lstrip("/"))
         os.makedirs(os.path.dirname(f), exist_ok=True)
-        a = np.zeros((n, 1 + 13 + len(sizes)), dtype="<u4")
-        keys = np.stack([np.minimum(rng.zipf(1.3, n) - 1, v - 1) for v in sizes], 1)
-        a[:, 0] = (keys[:, 2] % 2).astype("<i4").view("<u4")  # a learnable label
+        a = np.zeros((n, 1 + 13 + sum(hot)), dtype="<u4")
+        keys = np.concatenate([np.minimum(rng.zipf(1.3, (n, h)) - 1, v - 1)
+                               for v, h in zip(sizes, hot)], 1)
+        a[:, 0] = (keys[:, sum(hot[:2])] % 2).astype("<i4").view("<u4")  # a learnable label
         a[:, 1:14] = rng.random((n, 13), dtype=np.float32).view("<u4")
         a[:, 14:] = keys.astype("<u4")
         a.tofile(f)
@@ -79,10 +84,19 @@ def test_reference_script_calls_run_on_the_gpu(script, tmp_path, monkeypatch, ca
     assert model._iter == 24
     out = capsys.readouterr().out
     assert "Finish 24 iterations" in out and "Evaluation, AUC" in out
+    for cb in _find(tr["calls"], "CreateSolver")["kwargs"].get("training_callbacks", []):
+        # the script's hugectr.TrainingCallback subclass (samples/dlrm/mlperf_logger): its stand-in
+        # must have been driven through the whole protocol (training_callback.hpp:20-26)
+        live = next(c for c in model.solver.training_callbacks if c.name == cb["callback"])
+        kinds = [e[0] for e in live.events]
+        assert kinds[0] == "training_start" and kinds[-1] == "training_end"
+        evals = [e for e in live.events if e[0] == "eval_end"]
+        assert len(evals) == 2 and all("AUC" in e[2] for e in evals)
     solver = _find(tr["calls"], "CreateSolver")["kwargs"]
     if solver.get("gen_loss_summary", True):
         assert math.isfinite(model.get_current_loss())
     del model, res
+    gc.collect()  # (Model <-> layers reference cycles hold 100+ GB tables until collected)
     torch.cuda.empty_cache()
 
 
