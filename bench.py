@@ -96,6 +96,10 @@ def cpu_baseline(sizes, alpha, D, seed, budget_s=10.0):
                       f"B=1024, 26 Criteo-1TB slots one-hot power-law alpha={alpha}, D={D}, tables "
                       f"scaled 1/{scale} ({c3['rows']} rows); O(nnz^2) odd-even sort inside "
                       f"({c3['s_per_iter'] * 1e3:.0f} ms / iteration); host has {cores} logical cpus",
+            # the reference's three calls timed separately: forward() =
+            # read_a_batch + hash get/insert + pooling, backward(), update_params() = sort /
+            # unduplicate + optimizer
+            "stage_ms_per_iteration": c3["stage_ms_per_iter"],
             "c1_dcn_readme": {
                 "value": c1["samples_per_s"], "unit": "samples/s", "cores": 1, "kind": "reference",
                 "sample": f"BASELINE configs[0] (SURVEY C1): README DCN slot sizes "
@@ -103,7 +107,8 @@ def cpu_baseline(sizes, alpha, D, seed, budget_s=10.0):
                           f"D=16, Adam Global, {c1['warmup_iters']} warm-up + {c1['iters']} timed "
                           f"iterations ({c1['seconds']:.1f} s; the target 20 + 200 is cut by the "
                           f"time bound), reader + embedding fwd/bwd/update, no dense tower",
-                "ms_per_iteration": c1["s_per_iter"] * 1e3},
+                "ms_per_iteration": c1["s_per_iter"] * 1e3,
+                "stage_ms_per_iteration": c1["stage_ms_per_iter"]},
         })
     # ---- the port (restated oracle), embedding only, 1 and many threads -------------------------
     V, S, B = sum(ssz), len(ssz), 8192

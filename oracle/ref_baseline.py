@@ -43,6 +43,7 @@ def _lib():
     L.ref_emb_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                ctypes.c_void_p]
     L.ref_emb_destroy.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.ref_emb_stage_seconds.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     return L
 
 
@@ -112,6 +113,8 @@ def time_reference_cpu(slot_sizes, batch, dim, optimizer, update_type, alpha, wa
                 done_w += 1
                 if time.perf_counter() - t_w > budget_s / 4:  # the warm-up shares the bound
                     break
+            st0 = (ctypes.c_double * 3)()
+            L.ref_emb_stage_seconds(h, 0, st0)
             t0 = time.perf_counter()
             done = 0
             while done < iters:
@@ -121,10 +124,14 @@ def time_reference_cpu(slot_sizes, batch, dim, optimizer, update_type, alpha, wa
                 if done >= 2 and time.perf_counter() - t0 > budget_s:
                     break
             el = time.perf_counter() - t0
+            st1 = (ctypes.c_double * 3)()
+            L.ref_emb_stage_seconds(h, 0, st1)
+            stages = {k: (st1[i] - st0[i]) / done * 1e3 for i, k in enumerate(
+                ("forward_read_hash_pool", "backward", "update_sort_optimizer"))}
         finally:
             L.ref_emb_destroy(h, 0)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return {"samples_per_s": batch * done / el, "iters": done, "warmup_iters": done_w,
             "seconds": el, "s_per_iter": el / done, "batch": batch, "rows": V, "dim": dim,
-            "nnz_per_batch": batch * S}
+            "nnz_per_batch": batch * S, "stage_ms_per_iter": stages}

@@ -6,6 +6,8 @@
  * of the Norm dataset, forward, backward with the forward output as the top gradient, update. */
 #include <common.hpp>  // oracle/ref_shims/common.hpp
 
+#include <chrono>
+
 #include <utest/embedding/sparse_embedding_hash_cpu.hpp>
 
 namespace {
@@ -13,6 +15,10 @@ template <typename Emb, typename Key = long long>
 struct Handle {
   SparseEmbeddingHashCpu<Key, Emb> e;
   int batch, slots, dim, vocab;
+  // wall seconds spent in the reference's three calls since creation (stages
+  // timed separately): forward() = read_a_batch + hash get/insert + pooling, backward(),
+  // update_params() = sort / unduplicate + optimizer
+  double stage_s[3] = {0.0, 0.0, 0.0};
   template <typename... A>
   Handle(int b, int s, int d, int v, A&&... a)
       : e(std::forward<A>(a)...), batch(b), slots(s), dim(d), vocab(v) {}
@@ -84,13 +90,25 @@ int ref_emb_step(void* h, int fp16, int train, float* fwd, float* wgrad) {
       }
     } else {
       auto run = [&](auto* o) {
+        using clk = std::chrono::steady_clock;
+        auto secs = [](clk::time_point a, clk::time_point b) {
+          return std::chrono::duration<double>(b - a).count();
+        };
         const size_t n = (size_t)o->batch * o->slots * o->dim;
+        auto t0 = clk::now();
         o->e.forward();
+        auto t1 = clk::now();
+        o->stage_s[0] += secs(t0, t1);
         if (fwd) std::memcpy(fwd, o->e.get_forward_results(), n * sizeof(float));
         if (train) {
+          t0 = clk::now();
           o->e.backward();
+          t1 = clk::now();
+          o->stage_s[1] += secs(t0, t1);
           if (wgrad) std::memcpy(wgrad, o->e.get_backward_results(), n * sizeof(float));
+          t0 = clk::now();
           o->e.update_params();
+          o->stage_s[2] += secs(t0, clk::now());
         }
       };
       if (fp16 == 2) run(static_cast<HU32*>(h));
@@ -101,6 +119,14 @@ int ref_emb_step(void* h, int fp16, int train, float* fwd, float* wgrad) {
     return 1;
   }
   return 0;
+}
+
+/* seconds in forward / backward / update_params since creation (fp32 instances only) */
+void ref_emb_stage_seconds(void* h, int fp16, double* out3) {
+  const double* s = fp16 == 2 ? static_cast<HU32*>(h)->stage_s
+                    : fp16    ? static_cast<H16*>(h)->stage_s
+                              : static_cast<H32*>(h)->stage_s;
+  for (int i = 0; i < 3; i++) out3[i] = s[i];
 }
 
 /* the table: keys [vocab] and vectors [vocab][dim] in the oracle's row order */
