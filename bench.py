@@ -744,6 +744,86 @@ def small_config_leg(cfg, steps, warmup, dev):
     }
 
 
+# R/samples/dlrm/train.py:29-83 (MLPerf DLRM-DCNv2): tables capped at 40 M rows, keys per sample
+MLPERF_TABLES = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282,
+                 10, 2209, 11938, 155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973,
+                 108, 36]
+MLPERF_HOTNESS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+
+
+def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128):
+    """embedding_collection on one GPU (the reference's current-generation path):
+    forward and backward + update of the collection alone, through EmbeddingCollection.forward /
+    backward_and_update.  kind = "one_hot": Criteo-1TB tables, one key per table (the shape of the
+    main line, R/test/embedding_collection_test/dgx_a100_one_hot.py); "multi_hot": the MLPerf
+    DLRM-DCNv2 tables and hotness (214 keys per sample)."""
+    from hugectr_amd import _lib
+    from hugectr_amd.embedding_collection import (EmbeddingCollection, EmbeddingCollectionConfig,
+                                                  EmbeddingTableConfig)
+    sizes = CRITEO_1TB if kind == "one_hot" else MLPERF_TABLES
+    hot = [1] * 26 if kind == "one_hot" else MLPERF_HOTNESS
+    cfg = EmbeddingCollectionConfig()
+    tabs = [EmbeddingTableConfig(f"t{i}", v, D) for i, v in enumerate(sizes)]
+    cfg.embedding_lookup(tabs, [f"b{i}" for i in range(26)], "sparse_embedding", ["sum"] * 26)
+    ebc = EmbeddingCollection(cfg, B, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1024.0,
+                              out_dtype=torch.float16, batch_major=True, max_hotness=max(hot),
+                              hotness=hot)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    batches = []
+    for _ in range(2):  # feature-major CSR: bucket = table * B + sample, hot[t] keys each
+        ks = []
+        for v, h in zip(sizes, hot):
+            u = torch.rand(B * h, device=dev, generator=g, dtype=torch.float32).double()
+            a = 1.0 - alpha
+            y = ((float(v) ** a - 1.0) * u + 1.0) ** (1.0 / a)
+            ks.append((torch.round(y) - 1).clamp_(0, v - 1).to(torch.int64))
+        br = torch.zeros(26 * B + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.tensor(hot, device=dev).repeat_interleave(B), 0, out=br[1:])
+        batches.append((torch.cat(ks), br))
+    out = ebc.forward(*batches[0])
+    grad = (torch.randn(out.shape, device=dev) * 1e-3).to(out.dtype)
+
+    def timed(fn):
+        for i in range(warmup):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps * 1e3
+
+    fwd_us = timed(lambda i: ebc.forward(*batches[i % 2]))
+
+    def train(i):
+        ebc.forward(*batches[i % 2])
+        ebc.backward_and_update(grad)
+    both_us = timed(train)
+    nnz = B * sum(hot)
+    alg = nnz * (8 + 8 + D * 4) + B * 26 * D * 2
+    ach = alg / (fwd_us * 1e-6) / 1e9
+    return {
+        "workload": ("embedding_collection, Criteo-1TB tables, one-hot" if kind == "one_hot" else
+                     "embedding_collection, MLPerf DLRM-DCNv2 tables and hotness (214 keys / "
+                     "sample), R/samples/dlrm/train.py:29-83") +
+                    f", B={B}, D={D}, fp16 output [B][26][D], SGD, power-law alpha={alpha}; the "
+                    "collection alone (no dense tower)",
+        "direct_one_gpu_path": bool(ebc._direct), "keys_per_batch": nnz,
+        "table_rows_total": int(sum(sizes)),
+        "forward_us": fwd_us, "forward_backward_update_us": both_us,
+        "backward_update_us": both_us - fwd_us,
+        "value": B / (both_us * 1e-6), "unit": "samples/s (embedding path only)",
+        "roofline": {"bound": "hbm", "kernel": "whole forward (key -> row pass + gather/pool): a "
+                                               "lower bound on the gather kernel's own rate",
+                     "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -781,11 +861,13 @@ def main():
                          "not a reference mode (MI355X-native 16-bit type, no loss scaling).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in all "
                          "three.")
-    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all"],
+    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all", "ebc"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other two precisions on the same workload and BASELINE configs[0] / [1] "
                          "(DCN README, DeepFM Criteo-Kaggle, D = 16) through the hugectr surface; "
-                         "auto = all of them when --config c3 runs on one GPU")
+                         "auto = all of them when --config c3 runs on one GPU, plus the "
+                         "embedding_collection legs (one-hot Criteo-1TB, multi-hot MLPerf DCNv2); "
+                         "ebc = only those")
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"],
                     help="c3 = BASELINE configs[2], DLRM Criteo-1TB (the metric's configuration); "
                          "c1 / c2 = configs[0] / [1] as the main line")
@@ -832,7 +914,7 @@ def main():
     if rank == 0 and world == 1 and a.extra != "none":
         extra = {}
         for prec in ("fp32", "fp16", "bf16"):
-            if prec == a.precision:
+            if prec == a.precision or a.extra == "ebc":
                 continue
             try:
                 leg = dlrm_leg(a, prec, a.extra_steps, max(a.nbatches, 4), world, rank, dev, shared)
@@ -842,10 +924,20 @@ def main():
             except Exception as e:  # an extra leg never takes the main line down
                 extra[prec] = {"error": repr(e)}
         for cfg in ("c1", "c2"):
+            if a.extra == "ebc":
+                continue
             try:
                 extra[cfg] = small_config_leg(cfg, 50, 20, dev)
             except Exception as e:
                 extra[cfg] = {"error": repr(e)}
+        import gc
+        for kind in ("one_hot", "multi_hot"):
+            gc.collect()
+            torch.cuda.empty_cache()  # (100 GB tables: the previous leg's must be gone first)
+            try:
+                extra["ebc_" + kind] = ebc_leg(kind, a.extra_steps, 3, dev, a.alpha)
+            except Exception as e:
+                extra["ebc_" + kind] = {"error": repr(e)}
         out["extra"] = extra
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:

@@ -67,4 +67,36 @@ __device__ __forceinline__ T block_reduce_sum(T v, T* smem) {
   return r;
 }
 
+// Walks a CSR key-parallel: f(bucket, key position) for every key of every bucket, one wavefront
+// per 64 consecutive buckets with its lanes striding THE KEYS of those buckets -- coalesced and
+// balanced whatever the bucket lengths (a thread-per-bucket loop over a 100-hot table reads its
+// keys 800 bytes apart).  Lane b holds row_offset[base + b]; the bucket of a key position is the
+// last of those <= it, found by a 6-step search over the lanes' registers.
+// Must be called by whole wavefronts (all 64 lanes), blockDim a multiple of 64.
+template <typename OffT, typename F>
+__device__ __forceinline__ void for_each_key_wave(size_t buckets, const OffT* __restrict__ row_offset,
+                                                  F f) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  for (size_t base = wave * 64; base < buckets; base += nwaves * 64) {
+    const int nb = (int)(buckets - base < (size_t)64 ? buckets - base : (size_t)64);
+    const unsigned long long mine =
+        (unsigned long long)row_offset[base + (size_t)(lane < nb ? lane : nb)];
+    const unsigned long long first = __shfl(mine, 0, 64);
+    const unsigned long long end = (unsigned long long)row_offset[base + (size_t)nb];
+    for (unsigned long long jb = first; jb < end; jb += 64) {
+      const unsigned long long j = jb + (unsigned)lane;
+      int lo = 0;  // largest b in [0, nb) with offset[b] <= j (empty buckets in between skipped)
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1) {
+        const int probe = lo + step;
+        const unsigned long long v = __shfl(mine, probe < nb ? probe : 0, 64);
+        if (probe < nb && v <= j) lo = probe;
+      }
+      if (j < end) f(base + (size_t)lo, (size_t)j);
+    }
+  }
+}
+
 }  // namespace hctr

@@ -18,6 +18,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include "block_prims.h"
 #include "common.h"
 #include "scan.h"
 #include "sparse_update.h"
@@ -118,12 +119,13 @@ __global__ void __launch_bounds__(kBlock)
       if (d_nnz) *d_nnz = (unsigned long long)b1;
     }
     ragged |= (b0 != ob) | (b1 != ob + 1);
-    const long long r0 = rs[ob / batch];
-    for (size_t q = b0; q < b1; q++) {
-      const long long k = (long long)keys[q];
-      out_idx[q] = r0 < 0 ? (uint64_t)k : (uint64_t)(r0 + k);
-    }
   }
+  // keys: lanes stride the keys of 64 buckets (block_prims.h), coalesced for any hotness
+  for_each_key_wave(total, bucket_range, [&](size_t ob, size_t q) {
+    const long long r0 = rs[ob / batch];
+    const long long k = (long long)keys[q];
+    out_idx[q] = r0 < 0 ? (uint64_t)k : (uint64_t)(r0 + k);
+  });
   if (one_hot && ragged) *one_hot = 0u;
 }
 

@@ -86,16 +86,14 @@ __global__ void __launch_bounds__(kBlock)
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (tid == 0) span_count[0] = span_count[1] = 0u;  // long-run lists of seg_reduce / seg_combine
   const size_t nthreads = (size_t)gridDim.x * kBlock;
-  for (size_t u = tid; u < buckets; u += nthreads) {
-    const size_t off = (size_t)row_offset[u], end = (size_t)row_offset[u + 1];
-    // the payload is the gradient row of the bucket (SparseUpdater::map_inner)
-    const uint32_t g = map_inner ? ((uint32_t)u % map_inner) * map_outer + (uint32_t)u / map_inner
-                                 : (uint32_t)u;
-    for (size_t j = off; j < end && j < n_sort; j++) {
-      keys[j] = (SortK)value_index[j];
-      vals[j] = g;
-    }
-  }
+  // key-parallel (block_prims.h): the payload is the gradient row of the key's bucket
+  // (SparseUpdater::map_inner)
+  for_each_key_wave(buckets, row_offset, [&](size_t u, size_t j) {
+    if (j >= n_sort) return;
+    keys[j] = (SortK)value_index[j];
+    vals[j] = map_inner ? ((uint32_t)u % map_inner) * map_outer + (uint32_t)u / map_inner
+                        : (uint32_t)u;
+  });
   // padding (host upper bound > live nnz): sorts to the end, never forms a counted run
   for (size_t j = nnz + tid; j < n_sort; j += nthreads) {
     keys[j] = (SortK)~(SortK)0;
