@@ -371,6 +371,44 @@ def test_update_power_law_duplicates(oracle, D, opt_kw):
         keys = np.roll(keys, 7)  # different run/tile alignment in the second step
 
 
+@pytest.mark.parametrize("D,dt", [(128, "fp16"), (16, "fp32"), (64, "bf16")])
+@pytest.mark.parametrize("combiner,hot", [(0, 1), (1, 5)])
+def test_sgd_apply_folded_into_the_reduce_is_bit_equal(monkeypatch, D, dt, combiner, hot):
+    """plain SGD applies each unique row where its gradient sum completes (seg_reduce_kernel
+    <.., kFuseSgd>); HCTR_SGD_FUSED=0 parks the sums and applies them in a second pass
+    (seg_apply).  Same arithmetic -> same bits, on skewed keys with long runs and ragged buckets."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(23)
+    B = 4096
+    sizes = [3, 10, 1000, 50000, 1, 97, 200000]
+    S = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    lens = rng.integers(0 if hot > 1 else 1, hot + 1, size=B * S)
+    ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+    keys = (np.minimum(rng.pareto(1.1, size=slot_of.size).astype(np.int64),
+                       np.array(sizes)[slot_of] - 1) + offs[slot_of]).astype(np.int64)
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[dt]
+    tables = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("HCTR_SGD_FUSED", fused)
+        opt = ha.OptParams(lr=0.05, scaler=128.0, optimizer=_lib.OPT_SGD, atomic_update=False)
+        emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, int(sum(sizes)), D, S * hot, S, combiner,
+                                     opt, out_dtype=tdt, seed=7)
+        emb.init_params()
+        g_rng = np.random.default_rng(5)
+        for _ in range(3):
+            emb.forward(True, _t(torch, ro), _t(torch, keys))
+            g = torch.from_numpy(g_rng.standard_normal((B, S, D)).astype(np.float32)).cuda().to(tdt)
+            emb.backward(g)
+            emb.update_params()
+        torch.cuda.synchronize()
+        tables.append(emb.table().clone())
+    assert torch.equal(tables[0], tables[1])
+
+
 @pytest.mark.parametrize("presort", ["1", "0"])
 def test_rank_shard_updates_with_presort_guess(oracle, presort, monkeypatch):
     """world = 2, rank 1 of a localized embedding over several train steps whose per-rank nnz
