@@ -422,7 +422,9 @@ __device__ __forceinline__ uint32_t seg_row_at(const uint32_t (&mrow)[NPL], int 
   return (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
 }
 
-template <int LPR, typename OffT, typename SortK, typename GradT, bool kFuseSgd>
+constexpr int kFuseNone = 0, kFuseSgd = 1, kFuseAdaGrad = 2;
+
+template <int LPR, typename OffT, typename SortK, typename GradT, int kFuse>
 __global__ void __launch_bounds__(kBlock)
     seg_reduce_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                       const SortK* __restrict__ sorted_rows,
@@ -431,11 +433,13 @@ __global__ void __launch_bounds__(kBlock)
                       float* __restrict__ head, float* __restrict__ tail,
                       uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
                       float* __restrict__ direct_out, const OffT* __restrict__ scale_ro,
-                      float fuse_lr, float fuse_scaler) {
-  // kFuseSgd: plain SGD applied where a run's sum is complete -- table[row] += -lr * (sum / scaler)
-  // right here (direct_out = the table) instead of parking the sum in gsum for seg_apply.  Every
-  // row is one run owned by one lane group, so nobody else touches it; the arithmetic is
-  // seg_apply's, bit for bit, without the gsum round trip (2 x D x 4 bytes per unique row).
+                      OptConst fuse_o, float* __restrict__ fuse_state0) {
+  // kFuse (kFuseSgd / kFuseAdaGrad): the optimizer applied where a run's sum is complete --
+  // e.g. table[row] += -lr * (sum / scaler) -- right here (direct_out = the table) instead of
+  // parking the sum in gsum for seg_apply.  Every row is one run owned by one lane group, so
+  // nobody else touches it; the arithmetic is seg_apply's (apply_opt), bit for bit, without the
+  // gsum round trip (2 x D x 4 bytes per unique row).  Optimizers with two state vectors or
+  // time stamps keep the two-pass form (their row registers would cost the gather its occupancy).
   // Measured (MI355X): one-hot Criteo-1TB update 231 -> 209 us, embedding_collection one-hot
   // backward+update 365 -> 295 us, multi-hot MLPerf shape 2.15 -> 1.84 ms.  (No-return fp32
   // atomic adds in place of the read-modify-write were 2x SLOWER: 496 us / 4.2 ms.)
@@ -504,17 +508,22 @@ __global__ void __launch_bounds__(kBlock)
        ? direct_out + (size_t)seg_row_at<NPL, ML>(mrow, (q_), gshift) * D                       \
        : gsum + (base + (size_t)(q_)) * D) /* a run of keys without a row has no output row */
     auto emit_run = [&](int q_run, const float4& a) {
-      if constexpr (kFuseSgd) {
+      if constexpr (kFuse == kFuseSgd) {
         const uint32_t r = seg_row_at<NPL, ML>(mrow, q_run, gshift);
         if (r != 0xFFFFFFFFu) {
           float4* wp = reinterpret_cast<float4*>(direct_out + (size_t)r * D + l * 4);
           float4 w = *wp;
-          w.x += -fuse_lr * (a.x / fuse_scaler);
-          w.y += -fuse_lr * (a.y / fuse_scaler);
-          w.z += -fuse_lr * (a.z / fuse_scaler);
-          w.w += -fuse_lr * (a.w / fuse_scaler);
+          w.x += -fuse_o.lr * (a.x / fuse_o.scaler);
+          w.y += -fuse_o.lr * (a.y / fuse_o.scaler);
+          w.z += -fuse_o.lr * (a.z / fuse_o.scaler);
+          w.w += -fuse_o.lr * (a.w / fuse_o.scaler);
           *wp = w;
         }
+      } else if constexpr (kFuse == kFuseAdaGrad) {
+        OptConst oo = fuse_o;
+        oo.optimizer = HCTR_OPT_ADAGRAD;  // (compile-time: the state loads / stores fold)
+        apply_row_vec4<LPR>(oo, (uint64_t)seg_row_at<NPL, ML>(mrow, q_run, gshift), l, a,
+                            direct_out, fuse_state0, nullptr, nullptr);
       } else {
         *reinterpret_cast<float4*>(HCTR_RUN_DST(q_run) + l * 4) = a;
       }
@@ -1171,24 +1180,25 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     // plain SGD: the apply pass folds into the reduce (seg_reduce_kernel<.., kFuseSgd>);
     // HCTR_SGD_FUSED=0 keeps the two-pass form (measurements, the bit-equality test)
     const char* fuse_env = getenv("HCTR_SGD_FUSED");  // (read per call: tests flip it in-process)
-    const bool fuse_sgd =
-        !(fuse_env && fuse_env[0] == '0') && o.optimizer == HCTR_OPT_SGD && direct == nullptr;
+    int fuse = kFuseNone;
+    if (!(fuse_env && fuse_env[0] == '0') && direct == nullptr) {
+      if (o.optimizer == HCTR_OPT_SGD) fuse = kFuseSgd;
+      if (o.optimizer == HCTR_OPT_ADAGRAD) fuse = kFuseAdaGrad;
+    }
+#define HCTR_SEG_REDUCE(LPR_, FUSE_, OUT_)                                                        \
+  hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT, FUSE_>),                        \
+                     dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,    \
+                     kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail, u.span_list,     \
+                     u.span_count, OUT_, sro, o, state0)
 #define HCTR_SEG_CASE(LPR_)                                                                       \
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
     const size_t seg_tiles = ceil_div<size_t>(nnz, (size_t)kSegTile);                             \
-    if (fuse_sgd)                                                                                 \
-      hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT, true>),                     \
-                         dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets,    \
-                         ro, kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail,          \
-                         u.span_list, u.span_count, table, sro, o.lr, o.scaler);                  \
-    else                                                                                          \
-      hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT, false>),                    \
-                         dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets,    \
-                         ro, kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail,          \
-                         u.span_list, u.span_count, direct, sro, 0.f, 1.f);                       \
+    if (fuse == kFuseSgd) HCTR_SEG_REDUCE(LPR_, kFuseSgd, table);                                     \
+    else if (fuse == kFuseAdaGrad) HCTR_SEG_REDUCE(LPR_, kFuseAdaGrad, table);                        \
+    else HCTR_SEG_REDUCE(LPR_, kFuseNone, direct);                                                    \
     HCTR_LAUNCH_CHECK();                                                                          \
-    if (direct == nullptr && !fuse_sgd) {                                                         \
+    if (direct == nullptr && fuse == kFuseNone) {                                                 \
       if (o.optimizer == HCTR_OPT_SGD)                                                            \
         hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, true>),                           \
                            dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
@@ -1225,6 +1235,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       }
     }
 #undef HCTR_SEG_CASE
+#undef HCTR_SEG_REDUCE
     if (!done) {
       // generic embedding_vec_size: run detection + one wavefront per unique row
       const size_t n_tiles = ceil_div<size_t>(nnz, kTile);

@@ -373,10 +373,11 @@ def test_update_power_law_duplicates(oracle, D, opt_kw):
 
 @pytest.mark.parametrize("D,dt", [(128, "fp16"), (16, "fp32"), (64, "bf16")])
 @pytest.mark.parametrize("combiner,hot", [(0, 1), (1, 5)])
-def test_sgd_apply_folded_into_the_reduce_is_bit_equal(monkeypatch, D, dt, combiner, hot):
-    """plain SGD applies each unique row where its gradient sum completes (seg_reduce_kernel
-    <.., kFuseSgd>); HCTR_SGD_FUSED=0 parks the sums and applies them in a second pass
-    (seg_apply).  Same arithmetic -> same bits, on skewed keys with long runs and ragged buckets."""
+@pytest.mark.parametrize("opt_name", ["sgd", "adagrad"])
+def test_sgd_apply_folded_into_the_reduce_is_bit_equal(monkeypatch, D, dt, combiner, hot, opt_name):
+    """SGD and AdaGrad apply each unique row where its gradient sum completes (seg_reduce_kernel
+    <.., kFuseSgd / kFuseAdaGrad>); HCTR_SGD_FUSED=0 parks the sums and applies them in a second
+    pass (seg_apply).  Same arithmetic -> same bits, on skewed keys with long runs and ragged buckets."""
     import torch
     import hugectr_amd as ha
     from hugectr_amd import _lib
@@ -394,7 +395,8 @@ def test_sgd_apply_folded_into_the_reduce_is_bit_equal(monkeypatch, D, dt, combi
     tables = []
     for fused in ("1", "0"):
         monkeypatch.setenv("HCTR_SGD_FUSED", fused)
-        opt = ha.OptParams(lr=0.05, scaler=128.0, optimizer=_lib.OPT_SGD, atomic_update=False)
+        opt = ha.OptParams(lr=0.05, scaler=128.0, atomic_update=False, initial_accu_value=0.0,
+                           optimizer=_lib.OPT_SGD if opt_name == "sgd" else _lib.OPT_ADAGRAD)
         emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, int(sum(sizes)), D, S * hot, S, combiner,
                                      opt, out_dtype=tdt, seed=7)
         emb.init_params()

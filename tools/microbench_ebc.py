@@ -34,7 +34,9 @@ def main():
                          ["sum"] * 26)
     storage = sys.argv[1] if len(sys.argv) > 1 else "static"
     bm = len(sys.argv) > 2 and sys.argv[2] == "bm"  # batch-major output
-    ebc = EmbeddingCollection.for_rank(0, 1, cfg, B, lr=0.01, optimizer=_lib.OPT_SGD,
+    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "ftrl": _lib.OPT_FTRL}[
+        sys.argv[3] if len(sys.argv) > 3 else "sgd"]
+    ebc = EmbeddingCollection.for_rank(0, 1, cfg, B, lr=0.01, optimizer=opt,
                                        out_dtype=torch.bfloat16, max_hotness=1, storage=storage,
                                        init_capacity=1 << 21, batch_major=bm)
     rng = np.random.default_rng(0)
@@ -43,7 +45,7 @@ def main():
     br = torch.arange(0, 26 * B + 1, dtype=torch.int64, device="cuda")
     out = ebc.forward(kt, br)
     g = torch.randn(out.shape, device="cuda").to(out.dtype)
-    print({"storage": storage, "batch_major": bm, "direct": ebc._direct, "forward_us": round(timed(lambda: ebc.forward(kt, br)), 1),
+    print({"storage": storage, "batch_major": bm, "direct": ebc._direct, "optimizer": opt, "forward_us": round(timed(lambda: ebc.forward(kt, br)), 1),
            "backward+update_us": round(timed(lambda: ebc.backward_and_update(g)), 1),
            "out_shape": list(out.shape)})
 
