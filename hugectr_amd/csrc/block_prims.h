@@ -85,16 +85,27 @@ __device__ __forceinline__ void for_each_key_wave(size_t buckets, const OffT* __
         (unsigned long long)row_offset[base + (size_t)(lane < nb ? lane : nb)];
     const unsigned long long first = __shfl(mine, 0, 64);
     const unsigned long long end = (unsigned long long)row_offset[base + (size_t)nb];
-    for (unsigned long long jb = first; jb < end; jb += 64) {
-      const unsigned long long j = jb + (unsigned)lane;
-      int lo = 0;  // largest b in [0, nb) with offset[b] <= j (empty buckets in between skipped)
+    // kKW key positions per lane per trip: their searches and f's loads overlap
+    constexpr int kKW = 4;
+    for (unsigned long long jb = first; jb < end; jb += 64 * kKW) {
+      int lo[kKW];
 #pragma unroll
-      for (int step = 32; step >= 1; step >>= 1) {
-        const int probe = lo + step;
-        const unsigned long long v = __shfl(mine, probe < nb ? probe : 0, 64);
-        if (probe < nb && v <= j) lo = probe;
+      for (int k = 0; k < kKW; k++) {
+        const unsigned long long j = jb + (unsigned)(k * 64 + lane);
+        lo[k] = 0;  // largest b in [0, nb) with offset[b] <= j (empty buckets in between skipped)
+        if (jb + (unsigned)(k * 64) >= end) continue;  // (wave-uniform: nothing left for this k)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+          const int probe = lo[k] + step;
+          const unsigned long long v = __shfl(mine, probe < nb ? probe : 0, 64);
+          if (probe < nb && v <= j) lo[k] = probe;
+        }
       }
-      if (j < end) f(base + (size_t)lo, (size_t)j);
+#pragma unroll
+      for (int k = 0; k < kKW; k++) {
+        const unsigned long long j = jb + (unsigned)(k * 64 + lane);
+        if (j < end) f(base + (size_t)lo[k], (size_t)j);
+      }
     }
   }
 }

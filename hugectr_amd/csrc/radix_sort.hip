@@ -60,9 +60,18 @@ __global__ void __launch_bounds__(kRsBlock)
     const size_t i = base + (size_t)r * 64;
     key[r] = i < n ? keys[i] : 0xFFFFFFFFu;
   }
+  // Row ids of a power-law batch are small numbers: in the upper digits most lanes of a wavefront
+  // hold the SAME value, and 64 LDS atomics on one address serialise.  The lanes that agree with
+  // lane 0 are counted with one ballot and added once; the rest take the plain atomic.
 #pragma unroll
-  for (int r = 0; r < kRsRounds; r++)
-    if (base + (size_t)r * 64 < n) atomicAdd(&h[(key[r] >> shift) & (kRsBins - 1)], 1u);
+  for (int r = 0; r < kRsRounds; r++) {
+    const bool valid = base + (size_t)r * 64 < n;
+    const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+    const unsigned long long same = __ballot(valid && d == d0);
+    if (valid && d != d0) atomicAdd(&h[d], 1u);
+    if (lane == 0 && same != 0ull) atomicAdd(&h[d0], (uint32_t)__popcll(same));
+  }
   __syncthreads();
   for (int b = threadIdx.x; b < kRsBins; b += kRsBlock) {
     hist[(size_t)blockIdx.x * kRsBins + b] = h[b];
