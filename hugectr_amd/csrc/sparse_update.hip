@@ -848,22 +848,32 @@ __global__ void __launch_bounds__(kCombBlock)
     const size_t t0 = big_list[bi];
     const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
     const float4 own = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
-    size_t n_heads = 0;
-    for (;;) {
-      const size_t tt = t0 + 1 + n_heads + threadIdx.x;
-      const bool match = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+    // length of the run in tiles: tiles [t0 + 1, lo) begin with `row`, tile hi does not (or is
+    // the end).  1024 evenly spaced probes per round -- a run of 30 000 tiles is measured in two
+    // rounds instead of thirty dependent 1024-tile steps.
+    size_t lo = t0 + 1, hi = n_tiles;
+    while (lo < hi) {
+      const size_t step = (hi - lo + kCombBlock - 1) / kCombBlock;
+      const size_t probe = lo + (size_t)threadIdx.x * step;
+      const bool match = probe < hi && sorted_rows[probe * kSegTile] == row;
       const unsigned long long bal = __ballot(match);
       if (lane == 0) lead[wave] = (~bal == 0ull) ? 64 : __ffsll((long long)~bal) - 1;
       __syncthreads();
-      int tot = 0;
+      int m = 0;  // leading matches over the whole workgroup
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        if (tot == w * 64) tot += lead[w];
+        if (m == w * 64) m += lead[w];
       }
       __syncthreads();
-      n_heads += (size_t)tot;
-      if (tot < kCombBlock) break;
+      if (m == 0) {
+        hi = lo;
+      } else {
+        const size_t first_miss = lo + (size_t)m * step;  // probe m: mismatch, or beyond hi
+        lo = lo + (size_t)(m - 1) * step + 1;
+        if (first_miss < hi) hi = first_miss;
+      }
     }
+    const size_t n_heads = lo - (t0 + 1);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (size_t i = (size_t)g; i < n_heads; i += (size_t)GPB * CU) {
       float4 h[CU];
