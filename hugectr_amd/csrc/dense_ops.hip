@@ -1521,6 +1521,28 @@ constexpr int kCrossBwdWaves = 256 * 4;  // waves used by the cross backward (de
 
 using namespace hctr;
 
+namespace hctr {
+namespace {
+// single-wavefront workgroups per CU of the 16-bit interaction kernels (which: 0 forward,
+// 1 backward); HCTR_INTER_WAVES=f,b overrides (measurements)
+int inter_waves_per_cu(int which) {
+  static const int v[2] = {[] {
+                             const char* e = getenv("HCTR_INTER_WAVES");
+                             int f = 8;
+                             if (e) f = atoi(e);
+                             return f > 0 ? f : 8;
+                           }(),
+                           [] {
+                             const char* e = getenv("HCTR_INTER_WAVES");
+                             const char* c = e ? strchr(e, ',') : nullptr;
+                             int b = c ? atoi(c + 1) : 8;
+                             return b > 0 ? b : 8;
+                           }()};
+  return v[which];
+}
+}  // namespace
+}  // namespace hctr
+
 extern "C" {
 
 static int interaction_fwd_impl(size_t batch, int n_emb, int width, const void* mlp,
@@ -1564,7 +1586,8 @@ static int interaction_fwd_impl(size_t batch, int n_emb, int width, const void* 
   } else if ((dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16) && n_ins <= 32 && a16 &&
              (width == 128 || width == 64 || width == 32 || width == 16)) {
     const int stage_len = (out_len + 7) & ~7;
-    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
+    const size_t gmax = (size_t)256 * (size_t)inter_waves_per_cu(0);
+    const int grid1 = (int)(batch < gmax ? batch : gmax);
     const bool bf = dtype == HCTR_EMB_BF16;
 #define HCTR_IFWD16(W_)                                                                         \
   {                                                                                             \
@@ -1670,7 +1693,8 @@ static int interaction_bwd_impl(size_t batch, int n_emb, int width, const void* 
              reinterpret_cast<uintptr_t>(mlp_grad) % 16 == 0 &&
              reinterpret_cast<uintptr_t>(emb_grad) % 16 == 0 &&
              (width == 128 || width == 64 || width == 32)) {
-    const int grid1 = (int)(batch < (size_t)(256 * 8) ? batch : (size_t)(256 * 8));
+    const size_t gmax = (size_t)256 * (size_t)inter_waves_per_cu(1);
+    const int grid1 = (int)(batch < gmax ? batch : gmax);
     const int n_pairs = n_ins * (n_ins - 1) / 2;
     const bool bf = dtype == HCTR_EMB_BF16;
 #define HCTR_IBWD16(W_)                                                                          \
