@@ -75,7 +75,8 @@ _SIGNATURES = {
     "hctr_forward_pool_multihot": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
     "hctr_forward_pool_mapped": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, c_int,
                                          c_size_t, c_size_t, _P, _P]),
-    "hctr_ebc_route_whole": (c_int, [c_size_t, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "hctr_ebc_route_whole": (c_int, [c_size_t, c_int, _P, _P, _P, c_int, _P, _P, _P, _P, c_size_t,
+                                     _P]),
     "hctr_forward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_backward_reorder": (c_int, [c_size_t, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "hctr_emb_create": (c_int, [POINTER(EmbeddingParams), POINTER(_P)]),

@@ -72,22 +72,26 @@ __device__ __forceinline__ T block_reduce_sum(T v, T* smem) {
 // balanced whatever the bucket lengths (a thread-per-bucket loop over a 100-hot table reads its
 // keys 800 bytes apart).  Lane b holds row_offset[base + b]; the bucket of a key position is the
 // last of those <= it, found by a 6-step search over the lanes' registers.
+// gridDim.y wavefronts share a 64-bucket chunk, taking its trips round robin: with mixed hotness
+// (one 100-hot table among one-hot ones) the heavy chunks would otherwise be the kernel's tail.
 // Must be called by whole wavefronts (all 64 lanes), blockDim a multiple of 64.
 template <typename OffT, typename F>
 __device__ __forceinline__ void for_each_key_wave(size_t buckets, const OffT* __restrict__ row_offset,
                                                   F f) {
+  constexpr int kKW = 4;  // key positions per lane per trip: their searches and f's loads overlap
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const unsigned part = blockIdx.y, parts = gridDim.y;
   for (size_t base = wave * 64; base < buckets; base += nwaves * 64) {
     const int nb = (int)(buckets - base < (size_t)64 ? buckets - base : (size_t)64);
+    const unsigned long long first = (unsigned long long)row_offset[base];
+    const unsigned long long end = (unsigned long long)row_offset[base + (size_t)nb];
+    if (first + (unsigned long long)part * (64 * kKW) >= end) continue;  // no trip for this part
     const unsigned long long mine =
         (unsigned long long)row_offset[base + (size_t)(lane < nb ? lane : nb)];
-    const unsigned long long first = __shfl(mine, 0, 64);
-    const unsigned long long end = (unsigned long long)row_offset[base + (size_t)nb];
-    // kKW key positions per lane per trip: their searches and f's loads overlap
-    constexpr int kKW = 4;
-    for (unsigned long long jb = first; jb < end; jb += 64 * kKW) {
+    for (unsigned long long jb = first + (unsigned long long)part * (64 * kKW); jb < end;
+         jb += (unsigned long long)parts * (64 * kKW)) {
       int lo[kKW];
 #pragma unroll
       for (int k = 0; k < kKW; k++) {

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(kBlock)
                            unsigned long long* __restrict__ d_nnz,
                            uint32_t* __restrict__ one_hot) {
   bool ragged = false;
-  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < total;
+  for (size_t ob = (size_t)blockIdx.x * kBlock + threadIdx.x; ob < total && blockIdx.y == 0;
        ob += (size_t)gridDim.x * kBlock) {
     const size_t b0 = (size_t)bucket_range[ob], b1 = (size_t)bucket_range[ob + 1];
     out_range[ob] = (long long)b0;
@@ -562,7 +562,7 @@ int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const in
 int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start, const void* keys,
                          const void* bucket_range, int key_type, int64_t* out_bucket_range,
                          uint64_t* out_indices, uint64_t* d_nnz, uint32_t* one_hot,
-                         hctr_stream_t stream) {
+                         size_t nnz_hint, hctr_stream_t stream) {
   HCTR_REQUIRE(num_lookups >= 0, "num_lookups");
   hipStream_t s = as_stream(stream);
   const size_t nb = (size_t)num_lookups * batch;
@@ -573,7 +573,8 @@ int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start
     return HCTR_OK;
   }
   HCTR_REQUIRE(row_start && bucket_range && out_bucket_range && out_indices, "null pointer");
-  const int grid = grid_for(nb, kBlock);
+  const size_t avg = nnz_hint > 0 ? (nnz_hint + nb - 1) / nb : 1;  // wavefronts per bucket chunk
+  const dim3 grid(grid_for(nb, kBlock), (unsigned)(avg > 16 ? 16 : avg));
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ebc_route_whole_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, nb, batch,
                        (const long long*)row_start, (const uint32_t*)keys,

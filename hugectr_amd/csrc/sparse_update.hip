@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(kBlock)
                         uint32_t map_inner, uint32_t map_outer) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (tid == 0) span_count[0] = span_count[1] = 0u;  // long-run lists of seg_reduce / seg_combine
+  if (tid == 0 && blockIdx.y == 0) span_count[0] = span_count[1] = 0u;  // long-run lists
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   // key-parallel (block_prims.h): the payload is the gradient row of the key's bucket
   // (SparseUpdater::map_inner)
@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(kBlock)
                         : (uint32_t)u;
   });
   // padding (host upper bound > live nnz): sorts to the end, never forms a counted run
+  if (blockIdx.y != 0) return;
   for (size_t j = nnz + tid; j < n_sort; j += nthreads) {
     keys[j] = (SortK)~(SortK)0;
     vals[j] = 0xFFFFFFFFu;
@@ -1097,7 +1098,11 @@ int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const
                hipStream_t s) {
   SortK* kin = (SortK*)u.sort_keys_in;
   SortK* kout = (SortK*)u.sort_keys_out;
-  hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock)),
+  // wavefronts per 64-bucket chunk = the average bucket length (for_each_key_wave): one for
+  // one-hot input, 8 for the MLPerf multi-hot shape whose 100-hot table would otherwise be the tail
+  const size_t avg = buckets > 0 ? (n + buckets - 1) / buckets : 1;
+  const unsigned parts = (unsigned)(avg < 1 ? 1 : (avg > 16 ? 16 : avg));
+  hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock), parts),
                      dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count,
                      u.map_inner, u.map_outer);
   HCTR_LAUNCH_CHECK();

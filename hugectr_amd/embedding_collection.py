@@ -417,7 +417,7 @@ class EmbeddingCollection:
             check(lib.hctr_ebc_route_whole(self.B, self.L, ptr(self.d_row_start), ptr(gkeys),
                                            ptr(gbucket_range), kt, ptr(self.out_range),
                                            ptr(self.indices), ptr(self.d_nnz), ptr(self.d_one_hot),
-                                           stream_ptr()))
+                                           int(gkeys.numel()), stream_ptr()))
             self._nnz_host = int(gkeys.numel())
             bm = self.batch_major
             check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),

@@ -290,11 +290,12 @@ int hctr_ebc_route_keys(size_t batch, int world, int num_local_lookups, const in
  * num_shards = 1 everywhere, lookup_desc = identity): nothing is filtered, so the output CSR is the
  * input CSR and the three passes (count, scan, index) are one.  one_hot (DEVICE u32, may be NULL)
  * is left non-zero iff every bucket holds exactly its own key (bucket_range[i] == i) -- the flag
- * hctr_forward_pool_mapped takes. */
+ * hctr_forward_pool_mapped takes.  nnz_hint: the host's key count (or upper bound; 0 = unknown),
+ * a launch-shape hint only. */
 int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start, const void* keys,
                          const void* bucket_range, int key_type, int64_t* out_bucket_range,
                          uint64_t* out_indices, uint64_t* d_nnz, uint32_t* one_hot,
-                         hctr_stream_t stream);
+                         size_t nnz_hint, hctr_stream_t stream);
 /* total key count of each (lookup, local sample) bucket of this rank: Average divides by it on
  * the receiving side (R/HugeCTR/embedding/operators/network_forward.cu:272-283) */
 int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,
