@@ -1144,7 +1144,14 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   o.ftrl_l1 = opt.ftrl_lambda1;
   o.ftrl_l2b = opt.ftrl_lambda2 + opt.ftrl_beta / opt.lr;
   o.state_half = opt.state_half;
-  const size_t table_elems = u.max_vocab * (size_t)D;
+  // Global update types sweep the table (sparse_optimizer.cu:269-347 run over all
+  // max_vocabulary_size_per_gpu rows).  A row that was never handed out has zero state,
+  // and zero state is a fixed point of every sweep (m = v = 0 stay 0, w += -alpha * 0 / (0 + eps)
+  // leaves w's bits alone): sweeping the rows handed out so far -- row_bound, the same upper bound
+  // the sort's key width uses -- gives the identical table for a fraction of the traffic while a
+  // table fills up (DeepFM / Criteo-Kaggle, 33.7 M rows x 16: 12.9 GB per step down to the live rows).
+  const size_t live_rows = (u.row_bound > 0 && u.row_bound < u.max_vocab) ? u.row_bound : u.max_vocab;
+  const size_t table_elems = live_rows * (size_t)D;
 
   if (u.map_inner != 0u) {
     if (combiner != 0 || u.ext_rows != nullptr || (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) ||
