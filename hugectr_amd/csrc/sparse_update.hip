@@ -1327,6 +1327,34 @@ int update_grad(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, cons
 
 }  // namespace
 
+// This file is compiled three times (Makefile): HCTR_SU_PART 0 = everything but the segmented
+// update's kernel instantiations, 1 / 2 = those for 32-bit / 64-bit row offsets (63 instances of
+// seg_reduce_kernel each) -- the three objects build side by side instead of one 3-minute TU.
+#ifndef HCTR_SU_PART
+#define HCTR_SU_PART 0
+#endif
+int update_grad_u32(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const uint32_t* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s);
+int update_grad_i64(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const long long* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s);
+#if HCTR_SU_PART == 1
+int update_grad_u32(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const uint32_t* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  return update_grad<uint32_t>(u, buckets, nnz, combiner, ro, vi, grad, grad_dtype, opt, table, s0,
+                               s1, pt, s);
+}
+#elif HCTR_SU_PART == 2
+int update_grad_i64(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const long long* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  return update_grad<long long>(u, buckets, nnz, combiner, ro, vi, grad, grad_dtype, opt, table,
+                                s0, s1, pt, s);
+}
+#else
+
 int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   max_nnz = max_nnz_ > 0 ? max_nnz_ : 1;
   max_vocab = max_vocab_;
@@ -1447,13 +1475,11 @@ int SparseUpdater::update(size_t buckets, size_t nnz, int combiner, const void* 
     return HCTR_ERR_UNSUPPORTED;
   }
   if (key_type == HCTR_KEY_U32)
-    return update_grad<uint32_t>(*this, buckets, nnz, combiner, (const uint32_t*)row_offset,
-                                 value_index, top_grad, grad_dtype, opt, table, state0, state1,
-                                 prev_time, s);
+    return update_grad_u32(*this, buckets, nnz, combiner, (const uint32_t*)row_offset, value_index,
+                           top_grad, grad_dtype, opt, table, state0, state1, prev_time, s);
   if (key_type == HCTR_KEY_I64)
-    return update_grad<long long>(*this, buckets, nnz, combiner, (const long long*)row_offset,
-                                  value_index, top_grad, grad_dtype, opt, table, state0, state1,
-                                  prev_time, s);
+    return update_grad_i64(*this, buckets, nnz, combiner, (const long long*)row_offset, value_index,
+                           top_grad, grad_dtype, opt, table, state0, state1, prev_time, s);
   set_error("key_type");
   return HCTR_ERR_INVALID_ARG;
 }
@@ -1478,5 +1504,6 @@ int materialize_wgrad(size_t buckets, int D, int combiner, const void* ro, int k
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
+#endif  // HCTR_SU_PART
 
 }  // namespace hctr
