@@ -465,6 +465,28 @@ __global__ void __launch_bounds__(kBlock)
   constexpr unsigned long long kGroupMask = ML >= 64 ? ~0ull : ((1ull << ML) - 1ull);
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + T - 1) / T;
+  // kFuse: the row update of a finished run is completed when the NEXT run finishes -- its row
+  // (and accumulator) read travels while the next run's gradients are added, instead of stalling
+  // the lane group (one-hot update 205 -> 195 us, multi-hot backward + update 1.73 -> 1.59 ms)
+  uint32_t pend_row = 0xFFFFFFFFu;
+  float4 pend_w = make_float4(0.f, 0.f, 0.f, 0.f), pend_d = pend_w;
+  RowRegs pend_rr;  // kFuseAdaGrad: row + accumulator in flight, pend_d = the run's gradient sum
+  auto pend_flush = [&]() {
+    if (pend_row != 0xFFFFFFFFu) {
+      if constexpr (kFuse == kFuseAdaGrad) {
+        OptConst oo = fuse_o;
+        oo.optimizer = HCTR_OPT_ADAGRAD;  // (compile-time: the state loads / stores fold)
+        row_compute(oo, pend_d, pend_rr);
+        row_store<LPR>(oo, (uint64_t)pend_row, l, pend_rr, direct_out, fuse_state0, nullptr, nullptr);
+      } else {
+        pend_w.x += pend_d.x;
+        pend_w.y += pend_d.y;
+        pend_w.z += pend_d.z;
+        pend_w.w += pend_d.w;
+        *reinterpret_cast<float4*>(direct_out + (size_t)pend_row * D + l * 4) = pend_w;
+      }
+    }
+  };
   for (size_t tile = (size_t)blockIdx.x * GPB + g; tile < n_tiles;
        tile += (size_t)gridDim.x * GPB) {
     const size_t base = tile * T;
@@ -512,19 +534,24 @@ __global__ void __launch_bounds__(kBlock)
       if constexpr (kFuse == kFuseSgd) {
         const uint32_t r = seg_row_at<NPL, ML>(mrow, q_run, gshift);
         if (r != 0xFFFFFFFFu) {
-          float4* wp = reinterpret_cast<float4*>(direct_out + (size_t)r * D + l * 4);
-          float4 w = *wp;
-          w.x += -fuse_o.lr * (a.x / fuse_o.scaler);
-          w.y += -fuse_o.lr * (a.y / fuse_o.scaler);
-          w.z += -fuse_o.lr * (a.z / fuse_o.scaler);
-          w.w += -fuse_o.lr * (a.w / fuse_o.scaler);
-          *wp = w;
+          pend_flush();
+          pend_d.x = -fuse_o.lr * (a.x / fuse_o.scaler);
+          pend_d.y = -fuse_o.lr * (a.y / fuse_o.scaler);
+          pend_d.z = -fuse_o.lr * (a.z / fuse_o.scaler);
+          pend_d.w = -fuse_o.lr * (a.w / fuse_o.scaler);
+          pend_row = r;
+          pend_w = *reinterpret_cast<const float4*>(direct_out + (size_t)r * D + l * 4);
         }
       } else if constexpr (kFuse == kFuseAdaGrad) {
-        OptConst oo = fuse_o;
-        oo.optimizer = HCTR_OPT_ADAGRAD;  // (compile-time: the state loads / stores fold)
-        apply_row_vec4<LPR>(oo, (uint64_t)seg_row_at<NPL, ML>(mrow, q_run, gshift), l, a,
-                            direct_out, fuse_state0, nullptr, nullptr);
+        const uint32_t r = seg_row_at<NPL, ML>(mrow, q_run, gshift);
+        if (r != 0xFFFFFFFFu) {
+          pend_flush();
+          OptConst oo = fuse_o;
+          oo.optimizer = HCTR_OPT_ADAGRAD;
+          pend_d = a;
+          pend_row = r;
+          row_load<LPR>(oo, (uint64_t)r, l, pend_rr, direct_out, fuse_state0, nullptr, nullptr);
+        }
       } else {
         *reinterpret_cast<float4*>(HCTR_RUN_DST(q_run) + l * 4) = a;
       }
@@ -653,6 +680,7 @@ __global__ void __launch_bounds__(kBlock)
       if (l == 0) span_list[atomicAdd(span_count, 1u)] = (uint32_t)tile;
     }
   }
+  if constexpr (kFuse != kFuseNone) pend_flush();
 }
 #undef HCTR_RUN_DST
 
