@@ -135,6 +135,8 @@ _SIGNATURES = {
     "hctr_static_lookup": (c_int, [_P, c_int, c_size_t, _P, c_size_t, _P, _P, c_size_t, _P, _P, _P,
                                    _P, _P, _P, _P]),
     "hctr_forward_pool_ptrs": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_forward_pool_ptrs_mapped": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, c_size_t,
+                                              c_size_t, _P]),
     "hctr_ebc_routed_keys_to_indices": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P]),
     "hctr_ebc_local_reduce": (c_int, [_P, c_size_t, c_size_t, _P, _P, c_uint64, _P, _P, c_int, _SZP,
                                       _P, _P, _P, _P]),

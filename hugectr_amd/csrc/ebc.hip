@@ -134,13 +134,15 @@ __global__ void __launch_bounds__(kBlock)
 //      row id, find the unique ones, sum the gradients of every unique row (ascending position).
 __global__ void __launch_bounds__(kBlock)
     lr_expand_kernel(size_t buckets, const long long* __restrict__ bucket_range,
-                     uint32_t* __restrict__ pos_bucket, uint32_t* __restrict__ pos_iota) {
-  for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < buckets;
-       b += (size_t)gridDim.x * kBlock)
-    for (long long q = bucket_range[b]; q < bucket_range[b + 1]; q++) {
-      pos_bucket[q] = (uint32_t)b;
-      pos_iota[q] = (uint32_t)q;
-    }
+                     uint32_t* __restrict__ pos_bucket, uint32_t* __restrict__ pos_iota,
+                     uint32_t map_inner, uint32_t map_outer) {
+  // key-parallel (block_prims.h); the bucket is recorded as its gradient row
+  // (SparseUpdater::map_inner: batch-major output of a one-GPU collection)
+  for_each_key_wave(buckets, bucket_range, [&](size_t b, size_t q) {
+    pos_bucket[q] = map_inner ? ((uint32_t)b % map_inner) * map_outer + (uint32_t)b / map_inner
+                              : (uint32_t)b;
+    pos_iota[q] = (uint32_t)q;
+  });
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -808,8 +810,11 @@ int hctr_ebc_local_reduce(hctr_updater* u, size_t buckets, size_t nnz, const int
   hipStream_t s = as_stream(stream);
   unsigned bits = 1;
   while (bits < 64 && (max_row_id >> bits) != 0) bits++;
-  hipLaunchKernelGGL(lr_expand_kernel, dim3(grid_for(buckets, kBlock, 4096)), dim3(kBlock), 0, s,
-                     buckets, (const long long*)bucket_range, u->lr_pos_bucket, u->lr_pos_in);
+  HCTR_REQUIRE(u->impl.map_inner == 0u || (size_t)u->impl.map_inner * u->impl.map_outer == buckets,
+               "gradient map: samples * lookups must equal the bucket count");
+  hipLaunchKernelGGL(lr_expand_kernel, dim3(grid_for(buckets, kBlock)), dim3(kBlock), 0, s,
+                     buckets, (const long long*)bucket_range, u->lr_pos_bucket, u->lr_pos_in,
+                     u->impl.map_inner, u->impl.map_outer);
   HCTR_LAUNCH_CHECK();
   size_t tb = u->lr_temp_bytes;
   // stable: equal rows keep ascending positions, so a row's gradients are summed in ascending
@@ -835,8 +840,15 @@ int hctr_ebc_local_reduce(hctr_updater* u, size_t buckets, size_t nnz, const int
   HCTR_HIP(hipMemcpyAsync(&nu, u->lr_num_unique, sizeof(nu), hipMemcpyDeviceToHost, s));
   HCTR_HIP(hipStreamSynchronize(s));
   *num_unique = (size_t)nu;
-  return hctr_updater_reduce_presorted(u, nnz, buckets, bucket_range, u->lr_cid, u->lr_sbucket,
-                                       grad, grad_dtype, (size_t)nu, wgrad, stream);
+  // the sorted bucket list already names gradient rows: the presorted reduce runs unmapped
+  const uint32_t mi = u->impl.map_inner, mo = u->impl.map_outer;
+  u->impl.map_inner = u->impl.map_outer = 0u;
+  const int rc = hctr_updater_reduce_presorted(u, nnz, buckets, bucket_range, u->lr_cid,
+                                               u->lr_sbucket, grad, grad_dtype, (size_t)nu, wgrad,
+                                               stream);
+  u->impl.map_inner = mi;
+  u->impl.map_outer = mo;
+  return rc;
 }
 
 }  // extern "C"

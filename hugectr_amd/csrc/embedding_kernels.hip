@@ -332,7 +332,8 @@ __global__ void __launch_bounds__(kBlock)
 template <int LPR, int BU, typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_ptrs_vec4_kernel(size_t buckets, int combiner, const long long* __restrict__ row_offset,
-                          const float* const* __restrict__ rows, OutT* __restrict__ out) {
+                          const float* const* __restrict__ rows, OutT* __restrict__ out,
+                          OutMap om) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   const int g = threadIdx.x / LPR;
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(kBlock)
           v.z = mean_product<OutT>(v.z, sc);
           v.w = mean_product<OutT>(v.w, sc);
         }
-        Store4<OutT>::st(out + u * (size_t)D + l * 4, v);
+        Store4<OutT>::st(out + out_row(u, om) * (size_t)D + l * 4, v);
       }
     }
   }
@@ -384,7 +385,8 @@ template <typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_ptrs_generic_kernel(size_t buckets, int D, int combiner,
                              const long long* __restrict__ row_offset,
-                             const float* const* __restrict__ rows, OutT* __restrict__ out) {
+                             const float* const* __restrict__ rows, OutT* __restrict__ out,
+                             OutMap om) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
@@ -399,21 +401,21 @@ __global__ void __launch_bounds__(kBlock)
         sum += (r != nullptr) ? r[v] : 0.0f;
       }
       const float m = (D % 2 == 0) ? mean_product<OutT>(sum, sc) : sum * sc;
-      Store4<OutT>::st1(out + u * (size_t)D + v, (combiner == 1) ? m : sum);
+      Store4<OutT>::st1(out + out_row(u, om) * (size_t)D + v, (combiner == 1) ? m : sum);
     }
   }
 }
 
 template <typename OutT>
 int launch_pool_ptrs(size_t buckets, int D, int combiner, const long long* ro,
-                     const float* const* rows, OutT* out, hipStream_t s) {
+                     const float* const* rows, OutT* out, hipStream_t s, OutMap om) {
   // row stores are hipMalloc'ed ([capacity][D] fp32): rows are 16-byte aligned iff D % 4 == 0
   const bool aligned = reinterpret_cast<uintptr_t>(out) % 16 == 0;
 #define HCTR_PP(LPR_)                                                                          \
   case LPR_:                                                                                    \
     hipLaunchKernelGGL((pool_ptrs_vec4_kernel<LPR_, 4, OutT>),                                  \
                        dim3(grid_for(ceil_div<size_t>(buckets, 4), kBlock / LPR_, 256 * 8)),    \
-                       dim3(kBlock), 0, s, buckets, combiner, ro, rows, out);                   \
+                       dim3(kBlock), 0, s, buckets, combiner, ro, rows, out, om);               \
     break;
   bool done = aligned && D % 4 == 0;
   if (done) {
@@ -425,7 +427,7 @@ int launch_pool_ptrs(size_t buckets, int D, int combiner, const long long* ro,
 #undef HCTR_PP
   if (!done)
     hipLaunchKernelGGL((pool_ptrs_generic_kernel<OutT>), dim3(grid_for(buckets * 64, kBlock)),
-                       dim3(kBlock), 0, s, buckets, D, combiner, ro, rows, out);
+                       dim3(kBlock), 0, s, buckets, D, combiner, ro, rows, out, om);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
@@ -711,27 +713,48 @@ int hctr_forward_pool(size_t buckets, int vec_size, int combiner, const void* ro
                                table, out, out_dtype, false, as_stream(stream), nullptr);
 }
 
-int hctr_forward_pool_ptrs(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
-                           const float* const* rows, void* out, int out_dtype,
-                           hctr_stream_t stream) {
+static int forward_pool_ptrs_impl(size_t buckets, int vec_size, int combiner,
+                                  const int64_t* row_offset, const float* const* rows, void* out,
+                                  int out_dtype, OutMap om, hctr_stream_t stream) {
   HCTR_REQUIRE(vec_size > 0, "vec_size");
   HCTR_REQUIRE(combiner == 0 || combiner == 1, "combiner must be 0 (sum) or 1 (mean)");
   if (buckets == 0) return HCTR_OK;
   HCTR_REQUIRE(row_offset && rows && out, "null pointer");
+  HCTR_REQUIRE(om.inner == 0u || ((size_t)om.inner * om.outer == buckets &&
+                                  buckets <= (size_t)0xFFFFFFFFu),
+               "output map: samples * lookups must equal the bucket count (< 2^32)");
   hipStream_t s = as_stream(stream);
   const long long* ro = (const long long*)row_offset;
   switch (out_dtype) {
     case HCTR_EMB_F32:
-      return launch_pool_ptrs<float>(buckets, vec_size, combiner, ro, rows, (float*)out, s);
+      return launch_pool_ptrs<float>(buckets, vec_size, combiner, ro, rows, (float*)out, s, om);
     case HCTR_EMB_F16:
-      return launch_pool_ptrs<__half>(buckets, vec_size, combiner, ro, rows, (__half*)out, s);
+      return launch_pool_ptrs<__half>(buckets, vec_size, combiner, ro, rows, (__half*)out, s, om);
     case HCTR_EMB_BF16:
       return launch_pool_ptrs<__hip_bfloat16>(buckets, vec_size, combiner, ro, rows,
-                                              (__hip_bfloat16*)out, s);
+                                              (__hip_bfloat16*)out, s, om);
     default:
       HCTR_REQUIRE(false, "out_dtype");
   }
   return HCTR_OK;
+}
+
+int hctr_forward_pool_ptrs(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
+                           const float* const* rows, void* out, int out_dtype,
+                           hctr_stream_t stream) {
+  return forward_pool_ptrs_impl(buckets, vec_size, combiner, row_offset, rows, out, out_dtype,
+                                OutMap{0u, 0u}, stream);
+}
+
+int hctr_forward_pool_ptrs_mapped(size_t buckets, int vec_size, int combiner,
+                                  const int64_t* row_offset, const float* const* rows, void* out,
+                                  int out_dtype, size_t samples, size_t lookups,
+                                  hctr_stream_t stream) {
+  HCTR_REQUIRE(samples <= 0xFFFFFFFFull && lookups <= 0xFFFFFFFFull &&
+                   ((samples == 0) == (lookups == 0)),
+               "samples / lookups");
+  return forward_pool_ptrs_impl(buckets, vec_size, combiner, row_offset, rows, out, out_dtype,
+                                OutMap{(uint32_t)samples, (uint32_t)lookups}, stream);
 }
 
 int hctr_forward_pool_weighted(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,

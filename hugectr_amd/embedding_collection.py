@@ -330,14 +330,14 @@ class EmbeddingCollection:
             check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
         self._nnz_host = 0
-        # One GPU, static tables, no Average lookup: the send layout [peer][lookup][b][ev] IS the
+        # One GPU, no Average lookup (static or dynamic tables): the send layout [peer][lookup][b][ev] IS the
         # feature-major output and there is nothing to exchange, so the two reorder passes around
         # the all-to-all (network_forward / network_backward) drop out; the batch-major output is
         # the same buckets stored (and their gradients read) through a transposed address
         # (hctr_forward_pool_mapped, hctr_updater_set_grad_map).  HCTR_EBC_DIRECT=0 keeps the
         # staged path (tests compare the two).
         self._multi_hot = max_hotness > 1
-        self._direct = (self.world == 1 and not self.dynamic and self.n_local == self.L
+        self._direct = (self.world == 1 and self.n_local == self.L
                         and all(c == 0 for c in self.combiner)
                         and os.environ.get("HCTR_EBC_DIRECT", "1") != "0")
         self._map_on = False
@@ -418,6 +418,8 @@ class EmbeddingCollection:
                                            ptr(gbucket_range), kt, ptr(self.out_range),
                                            ptr(self.indices), ptr(self.d_nnz), ptr(self.d_one_hot),
                                            int(gkeys.numel()), stream_ptr()))
+            if self.dynamic:  # (row_start < 0: the pass kept the raw keys)
+                return self._dynamic_pool(send, True)
             self._nnz_host = int(gkeys.numel())
             bm = self.batch_major
             check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
@@ -511,7 +513,7 @@ class EmbeddingCollection:
         self.route_recv(recv_l, recv_k)
         return self.pool_routed()
 
-    def _dynamic_pool(self, send: torch.Tensor) -> torch.Tensor:
+    def _dynamic_pool(self, send: torch.Tensor, direct: bool = False) -> torch.Tensor:
         """self.indices holds the routed raw keys in [peer][local lookup][b_local] bucket order:
         one (peer, lookup) segment = one id space of the dynamic table.  The segment offsets are
         read on the host, like the id_space_offset of the reference's lookup
@@ -524,8 +526,11 @@ class EmbeddingCollection:
         keys = self.indices[:nnz]
         ptrs, rows, base = self.det.lookup_rows(keys, self.seg_class, seg, insert=self.training)
         self._dyn_rows, self._dyn_base = rows, base
-        check(lib.hctr_forward_pool_ptrs(self.nb, self.ev, 0, ptr(self.out_range), ptr(ptrs),
-                                         ptr(send), _DT[self.out_dtype], stream_ptr()))
+        bm = direct and self.batch_major  # one GPU: pooled straight into the batch-major output
+        check(lib.hctr_forward_pool_ptrs_mapped(self.nb, self.ev, 0, ptr(self.out_range), ptr(ptrs),
+                                                ptr(send), _DT[self.out_dtype],
+                                                self.bpg if bm else 0, self.L if bm else 0,
+                                                stream_ptr()))
         return send
 
     def _dynamic_apply(self, top_grad: torch.Tensor):
@@ -575,13 +580,13 @@ class EmbeddingCollection:
         if self.n_local == 0:
             return
         self._times += 1
-        if self.dynamic:
-            return self._dynamic_apply(top_grad.contiguous())
         mapped = direct and self.batch_major
         if mapped != self._map_on:
             check(lib.hctr_updater_set_grad_map(self._upd, self.bpg if mapped else 0,
                                                 self.L if mapped else 0))
             self._map_on = mapped
+        if self.dynamic:
+            return self._dynamic_apply(top_grad.contiguous())
         check(lib.hctr_updater_update(self._upd, self.nb, self._nnz_host, ptr(self.out_range),
                                       ptr(self.indices), ptr(top_grad.contiguous()),
                                       _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,

@@ -117,6 +117,12 @@ int hctr_forward_pool_mapped(size_t buckets, int vec_size, int combiner, const v
 int hctr_forward_pool_ptrs(size_t buckets, int vec_size, int combiner, const int64_t* row_offset,
                            const float* const* rows, void* out, int out_dtype,
                            hctr_stream_t stream);
+/* same with the transposed store of hctr_forward_pool_mapped (one-GPU embedding_collection on
+ * dynamic tables, batch-major output); (samples, lookups) = (0, 0) is the identity */
+int hctr_forward_pool_ptrs_mapped(size_t buckets, int vec_size, int combiner,
+                                  const int64_t* row_offset, const float* const* rows, void* out,
+                                  int out_dtype, size_t samples, size_t lookups,
+                                  hctr_stream_t stream);
 
 /* forward_reorder / backward_reorder: R/HugeCTR/src/embeddings/forward_reorder_functor.cu:26-98,
  * backward_reorder_functor.cu.  in [gpu][b][slot_in_gpu][D] <-> out [b][slot][D]. */

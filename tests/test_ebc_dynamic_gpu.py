@@ -267,3 +267,45 @@ def test_ebc_dynamic_other_optimizers(opt_name):
             assert set(k.tolist()) == set(w.maps[c].keys())
             ref = np.stack([w.maps[c][int(x)] for x in k]) if k.size else np.zeros((0, ev), np.float32)
             assert_close(v, ref, 2e-5, 2e-6, f"{opt_name} class {c} it{it}")
+
+
+@pytest.mark.parametrize("batch_major", [False, True])
+@pytest.mark.parametrize("opt_name,dtype", [("sgd", "float32"), ("adam", "float16"), ("adagrad", "bfloat16")])
+def test_one_gpu_direct_path_on_dynamic_tables_equals_staged(monkeypatch, batch_major, opt_name, dtype):
+    """One GPU, dynamic tables: pooling through the row pointers straight into the output
+    (transposed store for batch-major) and the local reduce reading the output's gradient in place
+    give the bits of the staged route -> pool -> network_forward / network_backward path."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(31)
+    B, ev = 64, 32
+    vocabs = [70, 9, 400]
+    lookup_table = [0, 1, 2, 2, 0]
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", -1, ev) for i in range(len(vocabs))]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l, t in enumerate(lookup_table):
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", "sum")
+    opt = {"sgd": _lib.OPT_SGD, "adam": _lib.OPT_ADAM, "adagrad": _lib.OPT_ADAGRAD}[opt_name]
+    kw = dict(lr=0.05, optimizer=opt, scaler=4.0, epsilon=1e-6, batch_major=batch_major,
+              max_hotness=4, out_dtype=getattr(torch, dtype), seed=3, storage="dynamic",
+              initializer="", init_capacity=16)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", "0")
+    staged = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", "1")
+    direct = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    assert direct._direct and direct.dynamic and not staged._direct
+    L = len(lookup_table)
+    for step in range(4):
+        lens = rng.integers(0, 5, size=L * B).astype(np.int64)
+        br = np.zeros(L * B + 1, np.int64)
+        np.cumsum(lens, out=br[1:])
+        keys = np.concatenate([rng.integers(0, vocabs[lookup_table[l]], size=int(lens[l * B:(l + 1) * B].sum()))
+                               for l in range(L)]).astype(np.int64)
+        kt, brt = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        a, b = staged.forward(kt, brt), direct.forward(kt, brt)
+        assert a.shape == b.shape and torch.equal(a, b), step
+        g = torch.randn(a.shape, device="cuda").to(a.dtype)
+        staged.backward_and_update(g)
+        direct.backward_and_update(g)
+    assert staged.det.size() == direct.det.size() > 0
