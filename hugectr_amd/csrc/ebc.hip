@@ -20,6 +20,7 @@
 
 #include "block_prims.h"
 #include "common.h"
+#include "radix_sort.h"
 #include "scan.h"
 #include "sparse_update.h"
 
@@ -135,18 +136,21 @@ __global__ void __launch_bounds__(kBlock)
 __global__ void __launch_bounds__(kBlock)
     lr_expand_kernel(size_t buckets, const long long* __restrict__ bucket_range,
                      uint32_t* __restrict__ pos_bucket, uint32_t* __restrict__ pos_iota,
-                     uint32_t map_inner, uint32_t map_outer) {
+                     uint32_t map_inner, uint32_t map_outer, const uint64_t* __restrict__ row_ids,
+                     uint32_t* __restrict__ rows32) {
   // key-parallel (block_prims.h); the bucket is recorded as its gradient row
   // (SparseUpdater::map_inner: batch-major output of a one-GPU collection)
   for_each_key_wave(buckets, bucket_range, [&](size_t b, size_t q) {
     pos_bucket[q] = map_inner ? ((uint32_t)b % map_inner) * map_outer + (uint32_t)b / map_inner
                               : (uint32_t)b;
     pos_iota[q] = (uint32_t)q;
+    if (rows32) rows32[q] = (uint32_t)row_ids[q];  // 32-bit sort keys (row ids < 2^32)
   });
 }
 
+template <typename RowT>
 __global__ void __launch_bounds__(kBlock)
-    lr_flags_kernel(size_t n, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ flags) {
+    lr_flags_kernel(size_t n, const RowT* __restrict__ sorted, uint32_t* __restrict__ flags) {
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock)
     flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1u : 0u;
@@ -154,8 +158,9 @@ __global__ void __launch_bounds__(kBlock)
 
 // heads_before[i] = number of run heads in [0, i): compact id of position i = heads_before[i] +
 // flag[i] - 1
+template <typename RowT>
 __global__ void __launch_bounds__(kBlock)
-    lr_emit_kernel(size_t n, const uint64_t* __restrict__ sorted, const uint32_t* __restrict__ pos,
+    lr_emit_kernel(size_t n, const RowT* __restrict__ sorted, const uint32_t* __restrict__ pos,
                    const uint32_t* __restrict__ flags, const uint32_t* __restrict__ heads_before,
                    const uint32_t* __restrict__ pos_bucket, const uint64_t* __restrict__ src_keys,
                    uint32_t* __restrict__ sorted_cid, uint32_t* __restrict__ sorted_bucket,
@@ -169,7 +174,7 @@ __global__ void __launch_bounds__(kBlock)
     sorted_cid[i] = cid;
     sorted_bucket[i] = pos_bucket[p];
     if (f) {
-      unique_rows[cid] = sorted[i];
+      unique_rows[cid] = (uint64_t)sorted[i];
       if (unique_keys) unique_keys[cid] = src_keys[p];
     }
     if (i == n - 1) *d_num_unique = (uint64_t)cid + 1;
@@ -358,6 +363,7 @@ struct hctr_updater {
   uint64_t* lr_sorted = nullptr;
   uint32_t *lr_pos_in = nullptr, *lr_pos_out = nullptr, *lr_pos_bucket = nullptr;
   uint32_t *lr_flags = nullptr, *lr_heads = nullptr, *lr_cid = nullptr, *lr_sbucket = nullptr;
+  uint32_t* lr_rows32 = nullptr;  // row ids as 32-bit sort keys (own radix sort)
   void* lr_temp = nullptr;
   size_t lr_temp_bytes = 0;
   unsigned long long *lr_tile_sums = nullptr, *lr_total = nullptr;
@@ -374,6 +380,7 @@ struct hctr_updater {
     HCTR_HIP(hipMalloc(&lr_heads, (n + 1) * 4));
     HCTR_HIP(hipMalloc(&lr_cid, n * 4));
     HCTR_HIP(hipMalloc(&lr_sbucket, n * 4));
+    HCTR_HIP(hipMalloc(&lr_rows32, n * 4));
     HCTR_HIP(hipMalloc(&lr_tile_sums, (n / 1024 + 2) * 8));
     HCTR_HIP(hipMalloc(&lr_total, 8));
     HCTR_HIP(hipMalloc(&lr_num_unique, 8));
@@ -384,13 +391,15 @@ struct hctr_updater {
       set_error("rocprim::radix_sort_pairs (size query) failed");
       return HCTR_ERR_HIP;
     }
-    lr_temp_bytes = tb ? tb : 16;
+    const size_t own = radix_sort_temp_bytes(n);
+    lr_temp_bytes = tb > own ? tb : own;
+    if (lr_temp_bytes == 0) lr_temp_bytes = 16;
     HCTR_HIP(hipMalloc(&lr_temp, lr_temp_bytes));
     return HCTR_OK;
   }
   void lr_free() {
     void* ptrs[] = {lr_sorted, lr_pos_in, lr_pos_out, lr_pos_bucket, lr_flags, lr_heads, lr_cid,
-                    lr_sbucket, lr_temp, lr_tile_sums, lr_total, lr_num_unique};
+                    lr_sbucket, lr_temp, lr_tile_sums, lr_total, lr_num_unique, lr_rows32};
     for (void* q : ptrs)
       if (q) (void)hipFree(q);
     lr_sorted = nullptr;
@@ -812,27 +821,45 @@ int hctr_ebc_local_reduce(hctr_updater* u, size_t buckets, size_t nnz, const int
   while (bits < 64 && (max_row_id >> bits) != 0) bits++;
   HCTR_REQUIRE(u->impl.map_inner == 0u || (size_t)u->impl.map_inner * u->impl.map_outer == buckets,
                "gradient map: samples * lookups must equal the bucket count");
+  // row ids below 2^32 (every table this side of 4 G rows): 32-bit keys through the path's own
+  // radix sort; wider ids keep the library's 64-bit sort
+  const bool k32 = max_row_id < 0xFFFFFFF0ull;
   hipLaunchKernelGGL(lr_expand_kernel, dim3(grid_for(buckets, kBlock)), dim3(kBlock), 0, s,
                      buckets, (const long long*)bucket_range, u->lr_pos_bucket, u->lr_pos_in,
-                     u->impl.map_inner, u->impl.map_outer);
+                     u->impl.map_inner, u->impl.map_outer, row_ids, k32 ? u->lr_rows32 : nullptr);
   HCTR_LAUNCH_CHECK();
-  size_t tb = u->lr_temp_bytes;
   // stable: equal rows keep ascending positions, so a row's gradients are summed in ascending
   // bucket order
-  if (rocprim::radix_sort_pairs(u->lr_temp, tb, row_ids, u->lr_sorted, u->lr_pos_in, u->lr_pos_out,
-                                nnz, 0, bits, s, false) != hipSuccess) {
-    set_error("rocprim::radix_sort_pairs failed");
-    return HCTR_ERR_HIP;
+  uint32_t* sorted32 = reinterpret_cast<uint32_t*>(u->lr_sorted);
+  if (k32) {
+    HCTR_TRY(radix_sort_pairs_u32(u->lr_temp, u->lr_temp_bytes, u->lr_rows32, sorted32, u->lr_pos_in,
+                                  u->lr_pos_out, nnz, (int)bits, s));
+  } else {
+    size_t tb = u->lr_temp_bytes;
+    if (rocprim::radix_sort_pairs(u->lr_temp, tb, row_ids, u->lr_sorted, u->lr_pos_in,
+                                  u->lr_pos_out, nnz, 0, bits, s, false) != hipSuccess) {
+      set_error("rocprim::radix_sort_pairs failed");
+      return HCTR_ERR_HIP;
+    }
   }
   const int grid = grid_for(nnz, kBlock, 4096);
-  hipLaunchKernelGGL(lr_flags_kernel, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
-                     u->lr_flags);
+  if (k32)
+    hipLaunchKernelGGL(lr_flags_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, nnz, sorted32,
+                       u->lr_flags);
+  else
+    hipLaunchKernelGGL(lr_flags_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
+                       u->lr_flags);
   HCTR_LAUNCH_CHECK();
   HCTR_TRY(exclusive_scan_to_offsets<uint32_t>(u->lr_flags, nnz, u->lr_tile_sums, u->lr_total,
                                                u->lr_heads, s));
-  hipLaunchKernelGGL(lr_emit_kernel, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
-                     u->lr_pos_out, u->lr_flags, u->lr_heads, u->lr_pos_bucket, keys, u->lr_cid,
-                     u->lr_sbucket, unique_row_ids, unique_keys, u->lr_num_unique);
+  if (k32)
+    hipLaunchKernelGGL(lr_emit_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, nnz, sorted32,
+                       u->lr_pos_out, u->lr_flags, u->lr_heads, u->lr_pos_bucket, keys, u->lr_cid,
+                       u->lr_sbucket, unique_row_ids, unique_keys, u->lr_num_unique);
+  else
+    hipLaunchKernelGGL(lr_emit_kernel<uint64_t>, dim3(grid), dim3(kBlock), 0, s, nnz, u->lr_sorted,
+                       u->lr_pos_out, u->lr_flags, u->lr_heads, u->lr_pos_bucket, keys, u->lr_cid,
+                       u->lr_sbucket, unique_row_ids, unique_keys, u->lr_num_unique);
   HCTR_LAUNCH_CHECK();
   // the caller sizes the optimizer step from the count (the reference reads num_unique_keys on the
   // host at the same point, dynamic_embedding.cu:186-190)
