@@ -90,6 +90,12 @@ __device__ __forceinline__ void for_each_key_wave(size_t buckets, const OffT* __
     if (first + (unsigned long long)part * (64 * kKW) >= end) continue;  // no trip for this part
     const unsigned long long mine =
         (unsigned long long)row_offset[base + (size_t)(lane < nb ? lane : nb)];
+    // one key in every bucket of the chunk (one-hot input): lane = bucket = key position
+    if (end - first == (unsigned long long)nb &&
+        __all(lane >= nb || mine == first + (unsigned)lane)) {
+      if (lane < nb) f(base + (size_t)lane, (size_t)(first + (unsigned)lane));
+      continue;
+    }
     for (unsigned long long jb = first + (unsigned long long)part * (64 * kKW); jb < end;
          jb += (unsigned long long)parts * (64 * kKW)) {
       int lo[kKW];
