@@ -749,6 +749,88 @@ def small_config_leg(cfg, steps, warmup, dev):
     }
 
 
+def dlrm_ebc_model_leg(steps, warmup, dev, B=65536, alpha=1.1):
+    """The main line's model (DLRM, Criteo-1TB tables, D = 128, SGD, mixed precision) written the
+    way the reference's embedding_collection script writes it
+    (R/test/embedding_collection_test/dgx_a100_one_hot.py:223-330) against the `hugectr` surface of
+    this repo: RawAsync input (one u32 key per table), EmbeddingTableConfig /
+    EmbeddingCollectionConfig.embedding_lookup(...).shard(...), bottom MLP, Interaction, top MLP,
+    BCE -- one step = Model.train().  What a dropped-in script gets, next to the hand-driven main
+    line."""
+    import shutil
+    import tempfile
+    import hugectr_amd.hugectr as hugectr
+    nb = 4
+    tmp = tempfile.mkdtemp(prefix="hctr_bench_ebc_model_")
+    try:
+        rng = np.random.default_rng(77)
+        a = np.zeros((B * nb, 1 + 13 + 26), dtype="<u4")
+        keys = np.stack([powerlaw(rng, B * nb, v, alpha) for v in CRITEO_1TB], 1)
+        a[:, 0] = (keys[:, 2] % 2).astype("<i4").view("<u4")
+        a[:, 1:14] = rng.random((B * nb, 13), dtype=np.float32).view("<u4")
+        a[:, 14:] = keys.astype("<u4")
+        f = os.path.join(tmp, "train_data.bin")
+        a.tofile(f)
+        solver = hugectr.CreateSolver(max_eval_batches=1, batchsize_eval=B, batchsize=B, lr=0.5,
+                                      vvgpu=[[0]], repeat_dataset=True, i64_input_key=False,
+                                      use_mixed_precision=True, scaler=1024.0,
+                                      use_embedding_collection=True)
+        optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.SGD,
+                                            update_type=hugectr.Update_t.Local, atomic_update=True)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.RawAsync, source=[f], eval_source="",
+            check_type=hugectr.Check_t.Non, num_samples=B * nb, eval_num_samples=0,
+            slot_size_array=CRITEO_1TB,
+            async_param=hugectr.AsyncParam(1, 4, 512000, 4, 512, True, hugectr.Alignment_t.Non,
+                                           multi_hot_reader=True, is_dense_float=True))
+        m = hugectr.Model(solver, reader, optimizer)
+        m.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam(f"data{i}", 1, True, 1)
+                                for i in range(26)]))
+        tables = [hugectr.EmbeddingTableConfig(name=str(i), max_vocabulary_size=v, ev_size=128)
+                  for i, v in enumerate(CRITEO_1TB)]
+        ebc = hugectr.EmbeddingCollectionConfig(use_exclusive_keys=True)
+        ebc.embedding_lookup(table_config=tables, bottom_name=[f"data{i}" for i in range(26)],
+                             top_name="sparse_embedding", combiner=["concat"] * 26)
+        names = [str(i) for i in range(26)]
+        ebc.shard(shard_matrix=[names], shard_strategy=[("mp", names)])
+        m.add(ebc)
+        L, T, A = hugectr.DenseLayer, hugectr.Layer_t, hugectr.Activation_t
+        m.add(L(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"],
+                num_outputs=BOTTOM, act_type=A.Relu))
+        m.add(L(layer_type=T.Reshape, bottom_names=["sparse_embedding"],
+                top_names=["sparse_embedding1"], shape=[-1, 26, 128]))
+        m.add(L(layer_type=T.Interaction, bottom_names=["mlp1", "sparse_embedding1"],
+                top_names=["interaction1"]))
+        m.add(L(layer_type=T.MLP, bottom_names=["interaction1"], top_names=["mlp2"],
+                num_outputs=TOP, activations=[A.Relu] * 4 + [A.Non]))
+        m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+                top_names=["loss"]))
+        m.compile()
+        batches = [m.reader.next_batch(True) for _ in range(nb)]
+        m.reader = _CycleReader(batches)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for _ in range(warmup):
+        m.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m.check_overflow()
+    return {"workload": "DLRM Criteo-1TB (the main line's model) as the reference's "
+                        "embedding_collection script builds it, through hugectr.Model.train(): "
+                        f"B={B}, D=128, SGD, use_mixed_precision (scaler 1024), static tables, "
+                        "batches resident in HBM",
+            "surface": "hugectr_amd.hugectr Model.train() + EmbeddingCollectionConfig",
+            "value": B * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3,
+            "steps": steps, "warmup": warmup, "final_loss": m.get_current_loss(),
+            "direct_one_gpu_path": bool(m._ebc[0]["train"]._direct)}
+
+
 # R/samples/dlrm/train.py:29-83 (MLPerf DLRM-DCNv2): tables capped at 40 M rows, keys per sample
 MLPERF_TABLES = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282,
                  10, 2209, 11938, 155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973,
@@ -866,7 +948,7 @@ def main():
                          "not a reference mode (MI355X-native 16-bit type, no loss scaling).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in all "
                          "three.")
-    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all", "ebc"],
+    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all", "ebc", "model"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other two precisions on the same workload and BASELINE configs[0] / [1] "
                          "(DCN README, DeepFM Criteo-Kaggle, D = 16) through the hugectr surface; "
@@ -919,7 +1001,7 @@ def main():
     if rank == 0 and world == 1 and a.extra != "none":
         extra = {}
         for prec in ("fp32", "fp16", "bf16"):
-            if prec == a.precision or a.extra == "ebc":
+            if prec == a.precision or a.extra in ("ebc", "model"):
                 continue
             try:
                 leg = dlrm_leg(a, prec, a.extra_steps, max(a.nbatches, 4), world, rank, dev, shared)
@@ -929,14 +1011,23 @@ def main():
             except Exception as e:  # an extra leg never takes the main line down
                 extra[prec] = {"error": repr(e)}
         for cfg in ("c1", "c2"):
-            if a.extra == "ebc":
+            if a.extra in ("ebc", "model"):
                 continue
             try:
                 extra[cfg] = small_config_leg(cfg, 50, 20, dev)
             except Exception as e:
                 extra[cfg] = {"error": repr(e)}
         import gc
+        if a.extra != "ebc":
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                extra["dlrm_ebc_model"] = dlrm_ebc_model_leg(a.extra_steps, 4, dev, alpha=a.alpha)
+            except Exception as e:
+                extra["dlrm_ebc_model"] = {"error": repr(e)}
         for kind in ("one_hot", "multi_hot"):
+            if a.extra == "model":
+                continue
             gc.collect()
             torch.cuda.empty_cache()  # (100 GB tables: the previous leg's must be gone first)
             try:

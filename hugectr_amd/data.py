@@ -374,6 +374,18 @@ class RawReader:
         ssa = list(slot_size_array)
         self.slot_offsets = (np.concatenate([[0], np.cumsum(ssa)[:-1]]).astype(np.int64) if ssa
                              else np.zeros(len(self.hot), np.int64))
+        # embedding_collection models: Model.compile names, per collection, the inputs of its
+        # lookups in lookup order; the reader then hands over the collection's global
+        # feature-major CSR (raw keys, bucket = lookup * batch + sample) ready-made -- cutting it
+        # out of 26 per-input tensors on the GPU costs ~100 tiny launches per step
+        self.ebc_groups = []
+        self._col_of = {}
+        col, s0 = inp.label_dim + inp.dense_dim, 0
+        for p in inp.sparse_params:
+            hot = self.hot[s0:s0 + p.slot_num]
+            self._col_of[p.top_name] = (col, sum(hot), p.slot_num)
+            col += sum(hot)
+            s0 += p.slot_num
 
     def next_batch(self):
         B = self.batch
@@ -405,6 +417,19 @@ class RawReader:
             s0 += p.slot_num
             out["sparse"][p.top_name] = (torch.from_numpy(ro).to(self.device, self.key_dtype),
                                          torch.from_numpy(keys).to(self.device, self.key_dtype))
+        if self.ebc_groups:
+            out["ebc"] = []
+            for names in self.ebc_groups:
+                ks, lens = [], []
+                for n in names:
+                    c0, w, slots = self._col_of[n]
+                    assert slots == 1, "embedding_collection inputs carry one slot per lookup"
+                    ks.append(blk[:, c0:c0 + w].astype(np.int64).reshape(-1))
+                    lens.append(np.full(B, w, np.int64))
+                gbr = np.zeros(len(names) * B + 1, np.int64)
+                np.cumsum(np.concatenate(lens), out=gbr[1:])
+                out["ebc"].append((torch.from_numpy(np.concatenate(ks)).to(self.device),
+                                   torch.from_numpy(gbr).to(self.device)))
         return out
 
 

@@ -576,6 +576,13 @@ class Model:
         self._dense_opt = self._make_dense_opt()
         self.reader = _data.make_reader(self.reader_params, self.input, s, self.rank, self.world,
                                         self.device)
+        # readers that can (Raw) hand every collection its global CSR ready-made (data.RawReader)
+        groups = [[p.top_name for p in rt["params"]] for rt in self._ebc]
+        for j, rt in enumerate(self._ebc):
+            rt["index"] = j
+        for r in (getattr(self.reader, "train", None), getattr(self.reader, "evalr", None)):
+            if r is not None and hasattr(r, "ebc_groups"):
+                r.ebc_groups = groups
         self._compiled = True
 
     def _split_by_ev_size(self, cfg: EmbeddingCollectionConfig):
@@ -702,6 +709,12 @@ class Model:
     def _ebc_forward(self, rt, batch, train: bool) -> torch.Tensor:
         """global feature-major CSR of the collection's lookups -> [batch/world, lookups, ev]"""
         e = rt["train"] if train else rt["eval"]
+        pre = batch.get("ebc")
+        if pre is not None:  # the reader built the collection's CSR (raw keys) on the host
+            gk, gbr = pre[rt["index"]]
+            if isinstance(e, DataParallelCollection):
+                return e.forward(gk, gbr)
+            return e.forward_global(gk, gbr)
         ros, keys = [], []
         for p in rt["params"]:
             ro, k = batch["sparse"][p.top_name]
