@@ -371,6 +371,46 @@ def test_update_power_law_duplicates(oracle, D, opt_kw):
         keys = np.roll(keys, 7)  # different run/tile alignment in the second step
 
 
+@pytest.mark.parametrize("combiner", [0, 1])
+def test_update_walks_giant_and_empty_buckets(oracle, combiner):
+    """the key-parallel CSR walk of the (row, bucket) expansion (for_each_key_wave): a bucket of
+    5000 keys (many trips of one wavefront chunk, shared by several wavefronts), runs of empty
+    buckets across chunk borders, a bucket count that is no multiple of 64 -- forward and two SGD
+    steps against the oracle"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(41)
+    B, S, D = 37, 3, 16
+    lens = rng.integers(0, 4, size=B * S)
+    lens[5] = 5000
+    lens[60:70] = 0
+    lens[-1] = 700
+    ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    V = 900
+    slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+    keys = (rng.integers(0, V // S, size=slot_of.size) + slot_of * (V // S)).astype(np.int64)
+    opt = ha.OptParams(lr=0.05, scaler=1.0, optimizer=_lib.OPT_SGD, atomic_update=False)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, int(lens.reshape(B, S).sum(1).max()), S,
+                                 combiner, opt)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    ht = oracle.HashTable(V, 8)
+    for it in range(2):
+        out = emb.forward(True, _t(torch, ro), _t(torch, keys))
+        vi = ht.get_insert(keys)
+        want = oracle.forward(ro, vi, table, D, combiner)
+        assert_close(out.cpu().numpy().reshape(-1, D), want, 1e-5, 1e-6, f"forward it{it}")
+        g = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+        emb.backward(_t(torch, g).view(B, S, D))
+        emb.update_params()
+        torch.cuda.synchronize()
+        wg = oracle.backward(ro, g, D, combiner)
+        oracle.update_params(ro, vi, wg, _oracle_opt(oracle, opt, it + 1), table, None, None, None)
+        assert_close(emb.table().cpu().numpy(), table, 2e-4, 2e-5, f"table it{it}")
+
+
 @pytest.mark.parametrize("D,dt", [(128, "fp16"), (16, "fp32"), (64, "bf16")])
 @pytest.mark.parametrize("combiner,hot", [(0, 1), (1, 5)])
 @pytest.mark.parametrize("opt_name", ["sgd", "adagrad"])
