@@ -250,6 +250,13 @@ class ParquetReader:
             else np.zeros(len(self.cat_cols), np.int64)
         self._file_idx, self._buf, self._pos = 0, None, 0
         self._epoch_done = False
+        # embedding_collection models (see RawReader.ebc_groups): slot of every one-slot input
+        self.ebc_groups = []
+        self._slot_of = {}
+        s0 = 0
+        for p in inp.sparse_params:
+            self._slot_of[p.top_name] = (s0, p.slot_num)
+            s0 += p.slot_num
 
     def _load_next_file(self) -> bool:
         if self._file_idx >= len(self.files):
@@ -320,6 +327,25 @@ class ParquetReader:
             if self.key_dtype != torch.int64:
                 kt, rt = kt.to(torch.int32), rt.to(torch.int32)
             out["sparse"][p.top_name] = (rt.to(self.device), kt.to(self.device))
+        if self.ebc_groups:  # the collections' global feature-major CSRs, raw keys
+            out["ebc"] = []
+            for names in self.ebc_groups:
+                ks, lens = [], []
+                for n in names:
+                    s, slots = self._slot_of[n]
+                    assert slots == 1, "embedding_collection inputs carry one slot per lookup"
+                    g = cats[s]
+                    if isinstance(g, tuple):
+                        off, vals = g
+                        ks.append(vals[off[a]:off[b]] - self.slot_offsets[s])
+                        lens.append(off[a + 1:b + 1] - off[a:b])
+                    else:
+                        ks.append(g[a:b] - self.slot_offsets[s])
+                        lens.append(np.ones(B, np.int64))
+                gbr = np.zeros(len(names) * B + 1, np.int64)
+                np.cumsum(np.concatenate(lens), out=gbr[1:])
+                out["ebc"].append((torch.from_numpy(np.concatenate(ks).astype(np.int64)).to(self.device),
+                                   torch.from_numpy(gbr).to(self.device)))
         return out
 
 

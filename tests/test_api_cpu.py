@@ -251,3 +251,52 @@ def test_auc_shares_ranks_among_tied_scores():
         y = (rng.random(800) < 0.35).astype(np.float64)
         assert abs(_auc(torch.from_numpy(p), torch.from_numpy(y)) - roc_auc_score(y, p)) < 1e-12
     assert _auc(torch.zeros(10), torch.tensor([0., 1.] * 5)) == 0.5
+
+
+def _ebc_csr_from_inputs(b, names, offsets, B):
+    """what Model._ebc_forward assembles from the per-input tensors when a reader has no
+    ready-made CSR: feature-major, raw keys (slot offsets taken off again)"""
+    ks, lens = [], []
+    for n, o in zip(names, offsets):
+        ro, k = b["sparse"][n]
+        ks.append(k.to(torch.int64) - o)
+        lens.append((ro[1:] - ro[:-1]).to(torch.int64))
+    br = torch.zeros(len(names) * B + 1, dtype=torch.int64)
+    br[1:] = torch.cumsum(torch.cat(lens), 0)
+    return torch.cat(ks), br
+
+
+def test_readers_hand_an_embedding_collection_its_global_csr(tmp_path):
+    """Parquet (scalar + list columns) and Raw (static hotness): the `ebc` entry of a batch equals
+    the CSR cut out of the per-input tensors, for lookups in a different order than the inputs"""
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd import data
+    sizes, hot = [50, 7, 1000, 3], [3, 1, 2, 1]
+    offs = [0, 50, 57, 1057]
+    params = [hugectr.DataReaderSparseParam(f"d{i}", hot[i], True, 1) for i in range(4)]
+    inp = hugectr.Input(label_dim=1, label_name="label", dense_dim=2, dense_name="dense",
+                        data_reader_sparse_param_array=params)
+    groups = [["d2", "d0", "d3"], ["d1"]]
+    goffs = [[offs[2], offs[0], offs[3]], [offs[1]]]
+    p = hugectr.tools.DataGeneratorParams(
+        format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=2, num_slot=4,
+        i64_input_key=True, source=str(tmp_path / "train" / "_file_list.txt"),
+        eval_source=str(tmp_path / "val" / "_file_list.txt"), slot_size_array=sizes, nnz_array=hot,
+        dist_type=hugectr.Distribution_t.PowerLaw, power_law_type=hugectr.PowerLaw_t.Short,
+        num_files=1, eval_num_files=1, num_samples_per_file=96, num_samples=96, eval_num_samples=32)
+    hugectr.tools.DataGenerator(p).generate()
+    rng = np.random.default_rng(3)
+    n = 96
+    cats = np.concatenate([rng.integers(0, v, size=(n, h)) for v, h in zip(sizes, hot)], axis=1)
+    raw = str(tmp_path / "train.bin")
+    data.write_raw(raw, rng.integers(0, 2, size=(n, 1)), rng.random((n, 2)), cats, float_label_dense=True)
+    readers = [data.ParquetReader(p.source, inp, sizes, 32, 0, 1, torch.device("cpu"), True, False),
+               data.RawReader(raw, inp, sizes, 32, 0, 1, torch.device("cpu"), 0, True, False)]
+    for r in readers:
+        r.ebc_groups = groups
+        for _ in range(3):
+            b = r.next_batch()
+            assert len(b["ebc"]) == 2
+            for (gk, gbr), names, o in zip(b["ebc"], groups, goffs):
+                wk, wbr = _ebc_csr_from_inputs(b, names, o, 32)
+                assert gk.dtype == torch.int64 and torch.equal(gk, wk) and torch.equal(gbr, wbr)
