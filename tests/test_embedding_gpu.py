@@ -372,7 +372,8 @@ def test_update_power_law_duplicates(oracle, D, opt_kw):
 
 
 @pytest.mark.parametrize("combiner", [0, 1])
-def test_update_walks_giant_and_empty_buckets(oracle, combiner):
+@pytest.mark.parametrize("key32", [False, True])
+def test_update_walks_giant_and_empty_buckets(oracle, combiner, key32):
     """the key-parallel CSR walk of the (row, bucket) expansion (for_each_key_wave): a bucket of
     5000 keys (many trips of one wavefront chunk, shared by several wavefronts), runs of empty
     buckets across chunk borders, a bucket count that is no multiple of 64 -- forward and two SGD
@@ -391,14 +392,15 @@ def test_update_walks_giant_and_empty_buckets(oracle, combiner):
     slot_of = np.repeat(np.tile(np.arange(S), B), lens)
     keys = (rng.integers(0, V // S, size=slot_of.size) + slot_of * (V // S)).astype(np.int64)
     opt = ha.OptParams(lr=0.05, scaler=1.0, optimizer=_lib.OPT_SGD, atomic_update=False)
+    kdt = torch.int32 if key32 else torch.int64  # (u32 keys AND u32 row offsets, as the reader hands them)
     emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, int(lens.reshape(B, S).sum(1).max()), S,
-                                 combiner, opt)
+                                 combiner, opt, key_dtype=kdt)
     emb.init_params()
     torch.cuda.synchronize()
     table = emb.table().cpu().numpy().copy()
-    ht = oracle.HashTable(V, 8)
+    ht = oracle.HashTable(V, 4 if key32 else 8)
     for it in range(2):
-        out = emb.forward(True, _t(torch, ro), _t(torch, keys))
+        out = emb.forward(True, _t(torch, ro).to(kdt), _t(torch, keys).to(kdt))
         vi = ht.get_insert(keys)
         want = oracle.forward(ro, vi, table, D, combiner)
         assert_close(out.cpu().numpy().reshape(-1, D), want, 1e-5, 1e-6, f"forward it{it}")
