@@ -12,6 +12,10 @@ Flow per rank (one process per GPU), following SparseOperationKit's lookup_spars
   ->  hctr_forward_pool into the all-to-all send layout  ->  all-to-all of embedding vectors
   ->  hctr_ebc_network_forward (sum row-shard partials, Average scaling)  ->  [lookup][b][ev]
 Backward is the mirror; the update runs on the owner with the segmented sparse optimizer.
+One GPU (world = 1, sum / concat lookups): there is no peer, the send layout already is the
+feature-major output, and the two reorder passes drop out -- hctr_ebc_route_whole (one index pass)
+-> hctr_forward_pool_mapped straight into the output (transposed store address for batch-major)
+-> the update reads the output's gradient in place (hctr_updater_set_grad_map); `_direct` below.
 
 storage="dynamic" (embedding::DynamicEmbeddingTable, R/HugeCTR/embedding_storage/
 dynamic_embedding.cu:21-330; BASELINE config 5): the local shards are classes of one hctr_det table
