@@ -939,10 +939,10 @@ class Model:
                 for q in self._dense_params:
                     if q.grad is not None:
                         _all_reduce(q.grad)
-            if self.solver.scaler != 1.0:
-                for q in self._dense_params:
-                    if q.grad is not None:
-                        q.grad /= self.solver.scaler
+            if self.solver.scaler != 1.0:  # one multi-tensor launch, not one per parameter
+                grads = [q.grad for q in self._dense_params if q.grad is not None]
+                if grads:
+                    torch._foreach_div_(grads, self.solver.scaler)
             self._dense_opt.step()
             self._dense_opt.zero_grad(set_to_none=True)
             for m in self._mods.values():
