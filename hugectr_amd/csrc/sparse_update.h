@@ -43,8 +43,9 @@ struct SparseUpdater {
   float* seg_tail = nullptr;    // [tiles][D]
   float* gsum = nullptr;           // [max_nnz][D] per-run gradient sums, indexed by run start
   uint32_t* span_list = nullptr;   // [tiles] tiles in which a long (multi-tile) run starts
-  uint32_t* span_count = nullptr;  // device counters: [0] span_list, [1] big_list
-  uint32_t* big_list = nullptr;    // [tiles] start tiles of runs longer than kCombBigTiles tiles
+  uint32_t* span_count = nullptr;  // device counters: [0] span_list, [2..3] big runs / chunks (u64)
+  uint32_t* big_list = nullptr;    // [4][tiles] runs longer than kCombBigTiles tiles (seg_combine_big)
+  size_t big_stride = 0;
   Profiler* prof = nullptr;
   bool allow_ftrl = false;  // the legacy embedding rejects Ftrl as the reference does (q9)
   // the (row, bucket) sort needs only the index stage's output, not the gradients: presort() runs

@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(kBlock)
                         uint32_t map_inner, uint32_t map_outer) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (tid == 0 && blockIdx.y == 0) span_count[0] = span_count[1] = 0u;  // long-run lists
+  if (tid == 0 && blockIdx.y == 0)  // long-run lists of seg_reduce / seg_combine
+    span_count[0] = span_count[1] = span_count[2] = span_count[3] = 0u;
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   // key-parallel (block_prims.h): the payload is the gradient row of the key's bucket
   // (SparseUpdater::map_inner)
@@ -791,6 +792,7 @@ __global__ void __launch_bounds__(kBlock)
 // the result does not depend on scheduling.
 constexpr int kCombBigTiles = 64;
 constexpr int kCombBlock = 1024;
+constexpr int kCombBigChunk = 2048;  // tile partials one workgroup of the big kernel adds
 
 template <int LPR, typename OffT, typename SortK>
 __global__ void __launch_bounds__(kBlock)
@@ -800,7 +802,7 @@ __global__ void __launch_bounds__(kBlock)
                        float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
                        const float* __restrict__ head, const float* __restrict__ tail,
                        const uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
-                       uint32_t* __restrict__ big_list) {
+                       uint32_t* __restrict__ big_list, size_t big_stride) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   constexpr int CU = 8;
@@ -825,12 +827,43 @@ __global__ void __launch_bounds__(kBlock)
       n_heads += (size_t)ld;
       if (ld < LPR) break;
       if (n_heads > (size_t)kCombBigTiles) {
-        if (l == 0) big_list[atomicAdd(span_count + 1, 1u)] = (uint32_t)t0;
         parked = true;
         break;
       }
     }
-    if (parked) continue;
+    if (parked) {
+      // a big run: measure it to the end (LPR evenly spaced probes per round; tiles < lo begin
+      // with `row`, tile hi does not) and register its chunks of kCombBigChunk tile partials --
+      // seg_combine_big_kernel gives every chunk a workgroup of its own
+      size_t lo = t0 + 1 + n_heads, hi = n_tiles;
+      while (lo < hi) {
+        const size_t step = (hi - lo + LPR - 1) / LPR;
+        const size_t probe = lo + (size_t)l * step;
+        const bool match = probe < hi && sorted_rows[probe * kSegTile] == row;
+        const unsigned long long gm = (__ballot(match) >> gshift) & kGroupMask;
+        const int m = gm == kGroupMask ? LPR : __ffsll((long long)~gm) - 1;
+        if (m == 0) {
+          hi = lo;
+        } else {
+          const size_t first_miss = lo + (size_t)m * step;
+          lo = lo + (size_t)(m - 1) * step + 1;
+          if (first_miss < hi) hi = first_miss;
+        }
+      }
+      if (l == 0) {
+        const size_t n = lo - (t0 + 1);
+        const unsigned long long nch = (n + kCombBigChunk - 1) / kCombBigChunk;
+        // one 64-bit counter: runs in the upper half, chunks in the lower -- the chunk bases
+        // then ascend with the slot numbers (binary search in the big kernel)
+        const unsigned long long old = atomicAdd(
+            reinterpret_cast<unsigned long long*>(span_count + 2), (1ull << 32) | nch);
+        const size_t slot = (size_t)(old >> 32);
+        big_list[slot] = (uint32_t)t0;
+        big_list[big_stride + slot] = (uint32_t)n;
+        big_list[2 * big_stride + slot] = (uint32_t)(old & 0xFFFFFFFFull);
+      }
+      continue;
+    }
     for (size_t i = 0; i < n_heads; i += CU) {
       float4 h[CU];
 #pragma unroll
@@ -858,74 +891,68 @@ __global__ void __launch_bounds__(kCombBlock)
                            const SortK* __restrict__ sorted_rows, OptConst o,
                            float* __restrict__ table, float* __restrict__ state0,
                            float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
-                           const float* __restrict__ head, const float* __restrict__ tail,
-                           const uint32_t* __restrict__ big_list,
-                           const uint32_t* __restrict__ span_count) {
+                           float* head, const float* __restrict__ tail, uint32_t* big_list,
+                           size_t big_stride, const uint32_t* __restrict__ span_count) {
+  // Work item = one chunk (kCombBigChunk tile partials) of one big run.  A row with a million
+  // gradients is 30 000 partials: one workgroup adding them all was the tail of the whole update
+  // (a single CU's bandwidth); now its chunks run side by side.  Every chunk sum has a fixed order
+  // (group q adds partials q, q + GPB, ...; the GPB group sums are added q = 0..GPB-1), a chunk's
+  // sum is parked in the slot of its own first partial, and the workgroup that finishes LAST (a
+  // counter per run) adds tail + chunk sums in chunk order and applies the optimizer: the result
+  // does not depend on which workgroup that is.
   constexpr int D = LPR * 4;
   constexpr int GPB = kCombBlock / LPR;
-  constexpr int NW = kCombBlock / 64;
   constexpr int CU = 8;
   __shared__ float4 part[kCombBlock];
-  __shared__ int lead[NW];
+  __shared__ int is_last;
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t nnz = (size_t)row_offset[buckets];
-  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
-  const uint32_t n_big = span_count[1];
-  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
-    const size_t t0 = big_list[bi];
-    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
-    const float4 own = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
-    // length of the run in tiles: tiles [t0 + 1, lo) begin with `row`, tile hi does not (or is
-    // the end).  1024 evenly spaced probes per round -- a run of 30 000 tiles is measured in two
-    // rounds instead of thirty dependent 1024-tile steps.
-    size_t lo = t0 + 1, hi = n_tiles;
-    while (lo < hi) {
-      const size_t step = (hi - lo + kCombBlock - 1) / kCombBlock;
-      const size_t probe = lo + (size_t)threadIdx.x * step;
-      const bool match = probe < hi && sorted_rows[probe * kSegTile] == row;
-      const unsigned long long bal = __ballot(match);
-      if (lane == 0) lead[wave] = (~bal == 0ull) ? 64 : __ffsll((long long)~bal) - 1;
-      __syncthreads();
-      int m = 0;  // leading matches over the whole workgroup
-#pragma unroll
-      for (int w = 0; w < NW; w++) {
-        if (m == w * 64) m += lead[w];
-      }
-      __syncthreads();
-      if (m == 0) {
-        hi = lo;
-      } else {
-        const size_t first_miss = lo + (size_t)m * step;  // probe m: mismatch, or beyond hi
-        lo = lo + (size_t)(m - 1) * step + 1;
-        if (first_miss < hi) hi = first_miss;
-      }
+  const unsigned long long ctr = *reinterpret_cast<const unsigned long long*>(span_count + 2);
+  const uint32_t n_big = (uint32_t)(ctr >> 32);
+  const uint32_t total = (uint32_t)(ctr & 0xFFFFFFFFull);
+  const uint32_t* big_t0 = big_list;
+  const uint32_t* big_len = big_list + big_stride;
+  const uint32_t* big_base = big_list + 2 * big_stride;
+  uint32_t* big_done = big_list + 3 * big_stride;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    uint32_t lo = 0, hi = n_big;  // the run whose chunks include w: last slot with base <= w
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (big_base[mid] <= w) lo = mid;
+      else hi = mid;
     }
-    const size_t n_heads = lo - (t0 + 1);
+    const uint32_t slot = lo;
+    const size_t t0 = big_t0[slot];
+    const size_t n_heads = big_len[slot];
+    const uint32_t c = w - big_base[slot];
+    const uint32_t nch = (uint32_t)((n_heads + kCombBigChunk - 1) / kCombBigChunk);
+    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    const size_t h0 = (size_t)c * kCombBigChunk;
+    const size_t h1 = h0 + kCombBigChunk < n_heads ? h0 + kCombBigChunk : n_heads;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)g; i < n_heads; i += (size_t)GPB * CU) {
+    for (size_t i = h0 + (size_t)g; i < h1; i += (size_t)GPB * CU) {
       float4 h[CU];
 #pragma unroll
-      for (int c = 0; c < CU; c++) {
-        const size_t ii = i + (size_t)c * GPB;
-        const size_t tt = t0 + 1 + (ii < n_heads ? ii : i);
-        h[c] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
+      for (int k = 0; k < CU; k++) {
+        const size_t ii = i + (size_t)k * GPB;
+        const size_t tt = t0 + 1 + (ii < h1 ? ii : i);
+        h[k] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
       }
 #pragma unroll
-      for (int c = 0; c < CU; c++) {
-        if (i + (size_t)c * GPB < n_heads) {
-          acc.x += h[c].x;
-          acc.y += h[c].y;
-          acc.z += h[c].z;
-          acc.w += h[c].w;
+      for (int k = 0; k < CU; k++) {
+        if (i + (size_t)k * GPB < h1) {
+          acc.x += h[k].x;
+          acc.y += h[k].y;
+          acc.z += h[k].z;
+          acc.w += h[k].w;
         }
       }
     }
     part[threadIdx.x] = acc;
     __syncthreads();
     if (g == 0) {
-      float4 tot = own;
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nch == 1u) tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
 #pragma unroll 8
       for (int q = 0; q < GPB; q++) {
         const float4 pq = part[q * LPR + l];
@@ -934,9 +961,35 @@ __global__ void __launch_bounds__(kCombBlock)
         tot.z += pq.z;
         tot.w += pq.w;
       }
-      apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+      if (nch == 1u) {
+        apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+      } else {  // every partial of this chunk has been read (the barrier above): reuse slot h0
+        *reinterpret_cast<float4*>(head + (t0 + 1 + h0) * D + l * 4) = tot;
+        __threadfence();
+      }
     }
     __syncthreads();
+    if (nch > 1u) {
+      if (threadIdx.x == 0) is_last = atomicAdd(big_done + slot, 1u) == nch - 1u ? 1 : 0;
+      __syncthreads();
+      if (is_last != 0) {
+        if (g == 0) {
+          __threadfence();
+          float4 tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+          for (uint32_t c2 = 0; c2 < nch; c2++) {
+            float* p = head + (t0 + 1 + (size_t)c2 * kCombBigChunk) * D + l * 4;
+            // (sums other workgroups parked: read past this CU's vector cache)
+            tot.x += __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.y += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.z += __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.w += __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+        }
+        if (threadIdx.x == 0) big_done[slot] = 0u;  // clean for the next update
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -1212,7 +1265,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       static_assert(sizeof(SortK) == 4, "presorted lists carry 32-bit rows");
       kout = (SortK*)const_cast<uint32_t*>(u.ext_rows);
       vout = u.ext_buckets;
-      HCTR_HIP(hipMemsetAsync(u.span_count, 0, 2 * sizeof(uint32_t), s));
+      HCTR_HIP(hipMemsetAsync(u.span_count, 0, 4 * sizeof(uint32_t), s));
     } else if (u.early_n >= nnz && u.early_vi == vi && u.early_buckets == buckets) {
       // (row, bucket) pairs of this batch were sorted on the side stream right after the index
       // stage (SparseUpdater::presort); padding keys sit behind the live ones
@@ -1264,12 +1317,12 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
                        dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, s, buckets, ro, \
                        kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
-                       u.seg_tail, u.span_list, u.span_count, u.big_list);                        \
+                       u.seg_tail, u.span_list, u.span_count, u.big_list, u.big_stride);          \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_combine_big_kernel<LPR_, OffT, SortK>), dim3(256), dim3(kCombBlock),  \
                        0, s, buckets, ro, kout, o, table, state0, state1,                         \
                        (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.big_list,        \
-                       u.span_count);                                                             \
+                       u.big_stride, u.span_count);                                               \
   }
     if (a16 && D % 4 == 0) {
       done = true;
@@ -1420,9 +1473,14 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&gsum, max_nnz * (size_t)D * sizeof(float)));
   HCTR_HIP(hipMalloc(&span_list, seg_tiles * sizeof(uint32_t)));
-  HCTR_HIP(hipMalloc(&span_count, 2 * sizeof(uint32_t)));  // [0] long runs, [1] parked big runs
-  HCTR_HIP(hipMemset(span_count, 0, 2 * sizeof(uint32_t)));
-  HCTR_HIP(hipMalloc(&big_list, seg_tiles * sizeof(uint32_t)));
+  // [0] long runs, [1] unused, [2..3] one 64-bit counter: big runs (upper half) / their chunks
+  HCTR_HIP(hipMalloc(&span_count, 4 * sizeof(uint32_t)));
+  HCTR_HIP(hipMemset(span_count, 0, 4 * sizeof(uint32_t)));
+  // per big run: start tile, length in tile partials, first chunk number, finished-chunk counter
+  // (the counters start at zero and every update leaves them at zero)
+  big_stride = seg_tiles;
+  HCTR_HIP(hipMalloc(&big_list, 4 * seg_tiles * sizeof(uint32_t)));
+  HCTR_HIP(hipMemset(big_list, 0, 4 * seg_tiles * sizeof(uint32_t)));
   return HCTR_OK;
 }
 

@@ -615,3 +615,40 @@ def test_fp16_embedding_keeps_fp16_valued_optimizer_state(oracle, name, kw):
             else:  # float multiply / add, then ONE conversion: the same bits as the oracle
                 assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"{name} state{k} it{it}"
     assert np.abs(s0).max() > 0
+
+
+@pytest.mark.parametrize("D", [16, 128])
+def test_row_with_a_quarter_million_gradients(D):
+    """one row collects 250 000 gradients (7 800 tile partials): seg_combine_big_kernel adds them as
+    four chunks on four workgroups, the last one to finish adds the chunk sums in chunk order --
+    right to float64 within summation error, and the same bits every time"""
+    import ctypes
+    import torch
+    from hugectr_amd import _lib
+    lib, ptr = _lib.lib, _lib.ptr
+    rng = np.random.default_rng(D)
+    V, nb = 64, 300_000
+    rows = rng.integers(1, V, size=nb)
+    rows[rng.random(nb) < 0.83] = 0          # ~250 k positions of row 0
+    rows[1000:1000 + 70_000] = 5             # and one run of ~2 200 partials (more than one chunk)
+    ro = torch.arange(nb + 1, dtype=torch.int64, device="cuda")
+    idx = torch.from_numpy(rows.astype(np.int64)).cuda()
+    g = (rng.standard_normal((nb, D)) * 0.01).astype(np.float32)
+    gt = torch.from_numpy(g).cuda()
+    t0 = rng.standard_normal((V, D)).astype(np.float32)
+    want = t0.astype(np.float64)
+    np.subtract.at(want, rows, 0.5 * g.astype(np.float64) / 2.0)
+    u = ctypes.c_void_p()
+    _lib.check(lib.hctr_updater_create(nb, V, D, ctypes.byref(u)))
+    outs = []
+    for _ in range(3):
+        tab = torch.from_numpy(t0).cuda()
+        _lib.check(lib.hctr_updater_update(u, nb, nb, ptr(ro), ptr(idx), ptr(gt), _lib.F32, _lib.OPT_SGD,
+                                           _lib.UPDATE_LOCAL, 0.5, 0.9, 0.999, 1e-7, 0.0, 2.0, 1, ptr(tab),
+                                           None, None, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(tab.clone())
+    lib.hctr_updater_destroy(u)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    err = np.abs(outs[0].cpu().numpy().astype(np.float64) - want).max()
+    assert err < 2e-3, err  # row 0 moved by ~ sqrt(250k) * 0.01 * 0.25: fp32 partial sums
