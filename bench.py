@@ -50,15 +50,6 @@ def make_keys(rng, batch, sizes, alpha):
     return keys.reshape(-1)
 
 
-def mlp(dims, last_relu):
-    layers = []
-    for i in range(len(dims) - 1):
-        layers.append(torch.nn.Linear(dims[i], dims[i + 1]))
-        if i < len(dims) - 2 or last_relu:
-            layers.append(torch.nn.ReLU())
-    return torch.nn.Sequential(*layers)
-
-
 def cpu_baseline(sizes, alpha, D, seed, budget_s=10.0):
     """CPU baselines on this box's host cores, on bounded samples (DESIGN.md "Measurement").
 
@@ -147,353 +138,123 @@ def cpu_baseline(sizes, alpha, D, seed, budget_s=10.0):
     return port  # oracle/_ref absent (it is built where the reference checkout is present)
 
 
-def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
-    """one measurement of the DLRM Criteo-1TB step at `precision` (see --precision); returns the
-    JSON object of that leg.  Builds (and releases) its own embedding: the 89.5 GiB table exists
-    once at a time."""
-    import hugectr_amd as ha
+def gen_keys(gen, n, sizes, alpha, dev):
+    """[n, len(sizes)] int64 keys with the readers' cumulative slot offsets added
+    (R/HugeCTR/src/pybind/add_input.cpp:315-317), drawn on the GPU: IntPowerLawDataSimulator's
+    inverse CDF (R/HugeCTR/include/data_generator.hpp:108-129), uniform when alpha <= 0.  Every
+    rank seeds the same generator, so all ranks hold the same full-batch CSR (reader semantics)."""
+    cols, off = [], 0
+    for v in sizes:
+        u = torch.rand(n, device=dev, generator=gen, dtype=torch.float32).double()
+        if alpha <= 0:
+            k = (u * v).to(torch.int64).clamp_(0, v - 1)
+        else:
+            e = 1.0 - alpha
+            y = ((float(v) ** e - 1.0) * u + 1.0) ** (1.0 / e)
+            k = (torch.round(y) - 1).clamp_(0, v - 1).to(torch.int64)
+        cols.append(k + off)
+        off += v
+    return torch.stack(cols, 1).reshape(-1)
+
+
+def build_dlrm(B, sizes, D, precision, world, lr=0.01, overlap=True):
+    """BASELINE configs[2] written against the `hugectr` surface: DLRM (bottom MLP 512-256-128,
+    dot Interaction, top MLP 1024-1024-512-256-1, BinaryCrossEntropyLoss) over ONE
+    LocalizedSlotSparseEmbeddingHash with the Criteo-1TB slot_size_array, SGD, global batch B over
+    `world` GPUs -- the layer list of R/samples/dlrm/train.py:406-470 on the legacy embedding the
+    configuration names."""
+    import hugectr_amd.hugectr as hugectr
+    S = len(sizes)
+    mixed = precision == "fp16"
+    solver = hugectr.CreateSolver(
+        max_eval_batches=1, batchsize_eval=B, batchsize=B, lr=lr, vvgpu=[list(range(world))],
+        repeat_dataset=True, i64_input_key=True, use_mixed_precision=mixed,
+        scaler=1024.0 if mixed else 1.0,
+        train_intra_iteration_overlap=overlap, train_inter_iteration_overlap=overlap)
+    optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.SGD,
+                                        update_type=hugectr.Update_t.Local, atomic_update=True)
+    reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
+                                      source=["(batches resident in HBM)"], eval_source="",
+                                      check_type=hugectr.Check_t.Non, slot_size_array=sizes)
+    m = hugectr.Model(solver, reader, optimizer)
+    L, T, A = hugectr.DenseLayer, hugectr.Layer_t, hugectr.Activation_t
+    m.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=DENSE_DIM, dense_name="dense",
+                        data_reader_sparse_param_array=[
+                            hugectr.DataReaderSparseParam("data1", 1, True, S)]))
+    m.add(hugectr.SparseEmbedding(
+        embedding_type=hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash,
+        slot_size_array=sizes, embedding_vec_size=D, combiner="sum",
+        sparse_embedding_name="sparse_embedding1", bottom_name="data1", optimizer=optimizer))
+    m.add(L(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"], num_outputs=BOTTOM,
+            act_type=A.Relu))
+    m.add(L(layer_type=T.Interaction, bottom_names=["mlp1", "sparse_embedding1"],
+            top_names=["interaction1"]))
+    m.add(L(layer_type=T.MLP, bottom_names=["interaction1"], top_names=["mlp2"], num_outputs=TOP,
+            activations=[A.Relu] * (len(TOP) - 1) + [A.Non]))
+    m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+            top_names=["loss"]))
+    return m
+
+
+def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alpha=None,
+             sizes=None, label=None):
+    """one measurement of the DLRM Criteo-1TB step through hugectr.Model.train() -- the product
+    surface, on 1 or N GPUs -- at `precision` (see --precision).  scaling = "weak": a.batch
+    samples per GPU (global batch N x a.batch); "strong": global batch a.batch (per GPU a.batch/N),
+    BASELINE configs[2] read literally.  Every step sees a batch it has not seen before (keys are
+    inserted live).  Builds and releases its own model: the 89.5 GiB table exists once at a time."""
     from hugectr_amd import _lib
-    from hugectr_amd.parallel import LocalizedExchange
-    from hugectr_amd.parallel import all_reduce as par_all_reduce
-
-    # precision -> (pooled-vector type, dense-tower type, loss scaler)
-    edt, ddt, scaler = {"fp16": (torch.float16, torch.float16, 1024.0),
-                        "bf16": (torch.bfloat16, torch.bfloat16, 1.0),
-                        "fp32": (torch.float32, torch.float32, 1.0)}[precision]
-    esz = 2 if edt != torch.float32 else 4
-    amp = ddt != torch.float32
-    sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
+    alpha = a.alpha if alpha is None else alpha
+    sizes = sizes or [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
     S, D = len(sizes), a.dim
-    Bl = a.batch                     # samples per GPU per step (fixed: weak scaling)
-    B = Bl * world                   # global batch every rank resolves its slots for
-    C = a.chunks if a.chunks > 0 else 1
-    assert Bl % C == 0
-    Bc = Bl // C                     # samples per GPU per sub-batch
-    Bsub = Bc * world                # one sub-batch = a "global batch" of the reference layout:
-    #   global sample g belongs to sub-batch g // Bsub and to rank (g % Bsub) // Bc, so the pooled
-    #   vectors [B, S_r, D] in natural order are already [sub-batch][peer][Bc][S_r][D].
-    spr = S // world + (1 if rank < S % world else 0)
-    my_rows = sum(v for i, v in enumerate(sizes) if i % world == rank)
-    max_rows = max(sum(v for i, v in enumerate(sizes) if i % world == r) for r in range(world))
-
-    # ---- the embedding (this rank's slots), SGD as in the reference DLRM samples -----------------
-    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.sgd_atomic, scaler=scaler)
-    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, max_rows, D, S, S, 0, opt,
-                                 slot_size_array=sizes, out_dtype=edt, rank=rank, world=world,
-                                 seed=1234)
-    emb.init_params()
-    exch = LocalizedExchange(Bsub, S, D)
-    ux = None
-    if world > 1 and C == 1 and a.exchange != "rows":
-        from hugectr_amd.unique_exchange import UniqueExchange
-        ux = UniqueExchange(emb, Bl, S, D)
-    mode = {"name": a.exchange if (ux is not None and a.exchange != "auto") else "rows"}
-
-    def set_mode(name):
-        mode["name"] = name
-        if ux is not None and name != "rows":
-            ux.set_sum_dtype(edt if name == "unique16" else torch.float32)
-
-    set_mode(mode["name"])
-
-    # ---- synthetic data, resident in HBM before the timed region ---------------------------------
+    Bl = a.batch if scaling == "weak" else a.batch // world
+    B = Bl * world
+    esz = 2 if precision == "fp16" else 4
+    m = build_dlrm(B, sizes, D, precision, world, overlap=not a.no_overlap)
+    # ---- synthetic batches, resident in HBM before the timed region; one per step ----------------
+    sel = 0
+    if world > 1 and os.environ.get("HCTR_EXCHANGE", "auto") == "auto" and not a.no_overlap:
+        sel = m._SEL_WARM + 2 * m._SEL_TIMED + m._SEL_SWITCH + 1  # the exchange selection's steps
+    nb = a.nbatches if a.nbatches > 0 else sel + warmup + steps + 1
+    gk = torch.Generator(device=dev)
+    gk.manual_seed(1234)                     # the same full-batch CSR on every rank
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(99 + rank)
     ro = torch.arange(0, B * S + 1, dtype=torch.int64, device=dev)
-    key_batches = shared["keys"]
-    g = torch.Generator(device=dev)
-    g.manual_seed(99 + rank)
-    dense_batches = [torch.rand((Bl, DENSE_DIM), device=dev, generator=g) for _ in range(a.nbatches)]
-    label_batches = [(torch.rand((Bl, 1), device=dev, generator=g) < 0.5).float()
-                     for _ in range(a.nbatches)]
+    batches, uniq = [], []
+    for _ in range(nb):
+        keys = gen_keys(gk, B, sizes, alpha, dev)
+        dense = torch.rand((Bl, DENSE_DIM), device=dev, generator=gd)
+        lab = (torch.rand((Bl, 1), device=dev, generator=gd) < 0.5).float()
+        batches.append({"dense": dense, "label": lab, "sparse": {"data1": (ro, keys)}})
+    for bt in batches[-4:]:  # distinct rows per batch on this rank's slots: the compulsory reads
+        k = bt["sparse"]["data1"][1].view(B, S)[:, rank::world]
+        uniq.append(int(torch.unique(k).numel()))
+    m.reader_override = _CycleReader(batches)
+    m.compile()
+    se, p, emb, ex, _ = m._emb["sparse_embedding1"]
+    spr = emb.slots_on_rank
+    my_rows = sum(v for i, v in enumerate(sizes) if i % world == rank)
 
-    # ---- dense tower (PyTorch-ROCm / hipBLASLt GEMMs; interaction is our HIP kernel) ---------------
-    torch.manual_seed(7)
-    n_ins = S + 1
-    if amp:
-        from hugectr_amd.dense import FusedMLP, bce_with_logits
-        bottom = FusedMLP([DENSE_DIM] + BOTTOM, last_relu=True, dtype=ddt).to(dev)
-        top = FusedMLP([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False, dtype=ddt).to(dev)
-    else:
-        bottom = mlp([DENSE_DIM] + BOTTOM, last_relu=True).to(dev)
-        top = mlp([D + n_ins * (n_ins - 1) // 2 + 1] + TOP, last_relu=False).to(dev)
-    dense_params = list(bottom.parameters()) + list(top.parameters())
-    dense_opt = torch.optim.SGD(dense_params, lr=0.01)
-    # flat master / gradient / 16-bit buffers: backward writes gradients in place, the SGD step and
-    # the shadow refresh are one kernel per MLP, the data-parallel all-reduce needs no packing
-    flat_mode = amp and C == 1 and a.graph != "on"
-    # HCTR_BENCH_HEAD=0 keeps the logit layer + loss as separate library / HIP calls (A/B runs)
-    head_fused = amp and os.environ.get("HCTR_BENCH_HEAD", "1") != "0" and top.can_fuse_bce_head()
-    if flat_mode:
-        bottom.flatten()
-        top.flatten()
-    loss_fn = torch.nn.BCEWithLogitsLoss()
-    pooled = torch.empty((B, spr, D), dtype=edt, device=dev)
-    top_grad = torch.empty((B, spr, D), dtype=edt, device=dev) if world > 1 or C > 1 else None
+    def sync():
+        m._drain_prefetch()
+        torch.cuda.synchronize()
 
-    tuned = "off"
-    if a.tunable == "tune" or (a.tunable == "auto" and os.path.exists(a.tunable_file)):
-        import torch.cuda.tunable as tunable
-        tunable.enable(True)
-        tunable.set_filename(a.tunable_file)
-        if a.tunable == "tune":
-            tunable.tuning_enable(True)
-            tunable.set_max_tuning_duration(30)
-            tunable.set_max_tuning_iterations(20)
-            tuned = "tuned-now"
-        else:
-            tunable.tuning_enable(False)
-            tunable.read_file(a.tunable_file)
-            tuned = "file"
-    def dense_chunk(dense_k, label_k, E, get_E=None, on_E_grad=None):
-        """bottom MLP -> interaction -> top MLP -> BCE (scaled 1/C) -> backward.  E is a leaf; when
-        get_E is given the bottom MLP is launched first (it does not need the embeddings, so it runs
-        under the all-to-all) and get_E() waits for / reorders the received vectors.  on_E_grad(g)
-        fires as soon as dL/dE exists -- before the bottom MLP's backward -- so the gradient
-        all-to-all starts under the rest of the backward pass."""
-        xb = bottom(dense_k)
-        if get_E is not None:
-            E = get_E()
-        if on_E_grad is not None:
-            E.register_hook(on_E_grad)
-        z = ha.interaction(xb.to(edt), E)
-        if amp and head_fused:
-            # last layer + BCE + their backward in one pass over the last hidden activations
-            loss = top.forward_bce(z, label_k, scaler / (Bc * C * world))
-            loss.backward()
-            return loss.detach() / C
-        logit = top(z)
-        if amp:  # fused BCE forward + logit gradient (HIP), mean over the step's Bl samples
-            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bc * C * world))
-            logit.backward(dlogit)
-            return loss / C
-        loss = loss_fn(logit.float(), label_k) / C
-        (loss / world).backward()
-        return loss.detach()
-
-    use_graph = a.graph == "on" or (a.graph == "auto" and C > 1)
-    graph = None
-    if use_graph:
-        # static buffers + whole fwd/bwd capture of one sub-batch; parameter gradients exist before
-        # the capture so that backward ACCUMULATES into them across the C replays of a step
-        st_dense = torch.zeros((Bc, DENSE_DIM), device=dev)
-        st_label = torch.zeros((Bc, 1), device=dev)
-        st_E = torch.zeros((Bc, S, D), dtype=edt, device=dev).requires_grad_(True)
-        for q in dense_params:
-            q.grad = torch.zeros_like(q)
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    st_E.grad = None
-                    dense_chunk(st_dense, st_label, st_E)
-            torch.cuda.current_stream().wait_stream(side)
-            st_E.grad = None
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                st_loss = dense_chunk(st_dense, st_label, st_E)
-            for q in dense_params:
-                q.grad.zero_()
-        except Exception as e:  # capture is an optimisation: fall back to eager launches
-            if rank == 0:
-                print(f"[bench] HIP-graph capture failed ({e!r}); running the dense tower eagerly",
-                      file=sys.stderr)
-            graph = None
-            dense_opt.zero_grad(set_to_none=True)
-
-    def dense_update():
-        if flat_mode:  # w -= lr * g / scaler (the loss scaler leaves the gradients here)
-            bottom.sgd_step(0.01, 1.0 / scaler)
-            top.sgd_step(0.01, 1.0 / scaler)
-            return
-        if scaler != 1.0:
-            for q in dense_params:
-                if q.grad is not None:
-                    q.grad /= scaler
-        dense_opt.step()
-        dense_opt.zero_grad(set_to_none=(graph is None))
-        if amp:
-            bottom.refresh_shadow()
-            top.refresh_shadow()
-
-    def finish_step():
-        if world > 1 and flat_mode:
-            for m in (bottom, top):  # gradients are shares of the global-batch mean: plain sum
-                par_all_reduce(m.flat_g)
-            return
-        if world > 1:
-            grads = [p.grad for p in dense_params]
-            flat = torch.cat([x.reshape(-1) for x in grads])
-            par_all_reduce(flat)
-            off = 0
-            for x in grads:
-                x.copy_(flat[off:off + x.numel()].view_as(x))
-                off += x.numel()
-
-    def step_unique(i):
-        """same step with the unique-row exchange.  With 16-bit vectors the received distinct rows
-        are never expanded: the interaction kernels read them through the (sample, slot) -> row
-        table; the gradient sums leave from inside backward."""
-        keys = key_batches[i % a.nbatches]
-        ux.forward_begin(ro, keys)
-        nxt = key_batches[(i + 1) % a.nbatches]
-        dense_k, label_k = dense_batches[i % a.nbatches], label_batches[i % a.nbatches]
-        if amp and edt != torch.float32:
-            xb = bottom(dense_k)                       # runs under the row all-to-all
-            rows, row_of = ux.forward_finish(indexed=True)
-            # next batch's index stage, plan, counts and (index, bucket) exchange: side stream,
-            # under this step's dense tower; issued after this step's row all-to-all so that the
-            # communicator serves the critical-path transfer first
-            ux.prefetch(ro, nxt)
-            z = ha.interaction_indexed(xb.to(edt), rows, row_of, on_emb_grad=ux.backward_begin)
-            logit = top(z)
-            loss, dlogit = bce_with_logits(logit, label_k, scaler / (Bl * world))
-            logit.backward(dlogit)
-        else:
-            sent = {}
-
-            def get_E():
-                sent["E"] = ux.forward_finish().detach().requires_grad_(True)
-                ux.prefetch(ro, nxt)
-                return sent["E"]
-
-            loss = dense_chunk(dense_k, label_k, None, get_E=get_E, on_E_grad=ux.backward_begin)
-        finish_step()
-        ux.backward_finish()
-        dense_update()
-        return loss
-
-    def step(i):
-        if mode["name"] != "rows":
-            return step_unique(i)
-        keys = key_batches[i % a.nbatches]
-        dense = dense_batches[i % a.nbatches]
-        label = label_batches[i % a.nbatches]
-        emb.forward(True, ro, keys, out=pooled)
-        recvs, works = [None] * C, [None] * C
-        recvs[0], works[0] = exch.forward_async(pooled[0:Bsub])
-        back = []
-        total = None
-        tg = top_grad
-        for k in range(C):
-            if k + 1 < C:  # next sub-batch's vectors travel while this one's dense tower runs
-                recvs[k + 1], works[k + 1] = exch.forward_async(pooled[(k + 1) * Bsub:(k + 2) * Bsub])
-            if graph is not None:
-                if works[k] is not None:
-                    works[k].wait()
-                if world > 1:
-                    ha.forward_reorder(recvs[k], Bc, S, D, world, out=st_E.detach())
-                else:
-                    st_E.detach().copy_(recvs[k].view(Bc, S, D))
-                st_dense.copy_(dense[k * Bc:(k + 1) * Bc])
-                st_label.copy_(label[k * Bc:(k + 1) * Bc])
-                graph.replay()
-                Eg, loss = st_E.grad, st_loss
-            else:
-                sent = {}
-
-                def get_E(k=k):
-                    if works[k] is not None:
-                        works[k].wait()
-                    E = (ha.forward_reorder(recvs[k], Bc, S, D, world) if world > 1
-                         else recvs[k].view(Bc, S, D))
-                    sent["E"] = E.detach().requires_grad_(True)
-                    return sent["E"]
-
-                def on_E_grad(g, k=k):
-                    # runs inside backward, right after the interaction's backward kernel.  The
-                    # hook must not keep `g` alive: autograd then steals it for E.grad instead of
-                    # cloning 436 MB
-                    gsend = (ha.backward_reorder(g.contiguous(), Bc, S, D, world) if world > 1
-                             else g.reshape(-1))
-                    sent["w"] = exch.backward_async(
-                        gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
-                    sent["buf"] = gsend if world > 1 else None
-
-                loss = dense_chunk(dense[k * Bc:(k + 1) * Bc], label[k * Bc:(k + 1) * Bc], None,
-                                   get_E=get_E,
-                                   on_E_grad=on_E_grad if top_grad is not None else None)
-                if top_grad is None:
-                    tg = sent["E"].grad
-                else:
-                    back.append((sent["w"], sent["buf"]))
-                total = loss.clone() if total is None else total + loss
-                continue
-            total = loss.clone() if total is None else total + loss
-            if top_grad is None:
-                tg = Eg
-            else:
-                gsend = ha.backward_reorder(Eg, Bc, S, D, world) if world > 1 else Eg.reshape(-1)
-                w = exch.backward_async(gsend, top_grad[k * Bsub:(k + 1) * Bsub].view(-1))
-                back.append((w, gsend))
-        for w, _ in back:
-            if w is not None:
-                w.wait()
-        finish_step()
-        emb.backward(tg)
-        emb.update_params()
-        dense_update()  # (static graph gradient buffers are zeroed in place, not released)
-        return total
-
+    for _ in range(sel):
+        m.train()
     emb.profiling(True)
-    if ux is not None and a.exchange == "auto":
-        # measure, don't guess: a few steps of each payload during warm-up, keep the faster one
-        # (the decision is taken on the max over ranks, so every rank takes the same one)
-        timing = {}
-        # every cycled batch once first: the tables then hold all keys, so neither candidate is
-        # timed on steps that insert (and RCCL's first-call setup is out of the way)
-        set_mode("rows")
-        for i in range(a.nbatches):
-            step(i)
-        for name in ("rows", "unique"):  # unique16 changes the wire precision: opt-in only
-            set_mode(name)
-            try:
-                for i in range(2):
-                    step(i)
-            except Exception as e:  # e.g. keys x peers beyond the 32-bit sort key: same on every rank
-                if rank == 0:
-                    print(f"[bench] exchange '{name}' unavailable: {e!r}", file=sys.stderr)
-                timing[name] = float("inf")
-                continue
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for i in range(2, 5):
-                step(i)
-            torch.cuda.synchronize()  # (also drains the unique exchange's prefetch stream)
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            if dist.get_backend() != "gloo":
-                t = t.to(dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            timing[name] = float(t.item()) / 3
-        set_mode(min(timing, key=timing.get))
-        mode["timing_ms"] = {k: v * 1e3 for k, v in timing.items()}
-    pool_prof = emb.profile().get("gather_pool", (0.0, 0))
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if a.tunable == "tune":
-        tunable.tuning_enable(False)  # keep the chosen solutions, stop searching
-        if rank == 0:
-            # TunableOp writes its CSV at process exit; also write it now in the same format so
-            # the file exists even if the interpreter is torn down abnormally.
-            try:
-                os.makedirs(os.path.dirname(a.tunable_file), exist_ok=True)
-                with open(a.tunable_file + ".now", "w") as f:
-                    for k, v in tunable.get_validators():
-                        f.write(f"Validator,{k},{v}\n")
-                    for r in tunable.get_results():
-                        f.write(",".join(str(x) for x in r) + "\n")
-            except Exception as e:  # diagnostics only
-                print("tunable dump failed:", e, file=sys.stderr)
-    emb.profiling(True)
+    for _ in range(warmup):
+        m.train()
+    sync()
+    rows_before = emb.get_vocabulary_size()
+    emb.profiling(True)  # (re-arms the counters: the stage times cover the timed steps only)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss = None
-    for i in range(warmup, warmup + steps):
-        loss = step(i)
-    torch.cuda.synchronize()
+    for _ in range(steps):
+        m.train()
+    sync()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -506,83 +267,113 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, shared):
         elapsed = float(t.item())
     prof = emb.profile()
     emb.profiling(False)
-    emb.check_overflow()
+    m.check_overflow()
+    new_keys = (emb.get_vocabulary_size() - rows_before) / max(steps, 1)
+    xrep = m.exchange_report()["sparse_embedding1"]
 
-    # ---- roofline of the gather+pool kernel (algorithmic bytes, DESIGN.md / SURVEY 8d) ------------
+    # ---- roofline of the gather+pool kernel (DESIGN.md section 5 / SURVEY 8d) -------------------
     nnz_g = B * spr  # one-hot: one key per (sample, slot on this rank)
     alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz
+    U = sum(uniq) / max(len(uniq), 1)
+    # compulsory = what must cross the HBM interface even with a perfect cache: every key and row
+    # index once, every DISTINCT row once, every output element once
+    comp_bytes = nnz_g * 8 + nnz_g * 8 + U * D * 4 + B * spr * D * esz
     pool_ms, pool_n = prof["gather_pool"]
-    if pool_n == 0:  # unique-row exchange: the pool kernel only ran in the warm-up comparison
-        pool_ms, pool_n = pool_prof
-    achieved = alg_bytes / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9 if pool_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC counters: collected with rocprofv3 in separate passes on
-    # this workload (profiles/r2_pmc_hbm_traffic_<precision>.json; a bench process cannot read the
-    # counters of its own kernels), attached only to the leg whose output width they were taken on
-    pmc = None
-    pmc_path = os.path.join(ROOT, "profiles",
-                            f"r2_pmc_hbm_traffic_{'fp32' if esz == 4 else 'fp16'}.json")
-    if world == 1 and D == 128 and a.batch == 65536 and a.alpha == 1.1 and os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))["kernels"]["pool_vec4_kernel"]["hbm_bytes_per_launch"]
-        except Exception:
-            pmc = None
+    pool_s = pool_ms / max(pool_n, 1) * 1e-3
+    achieved = alg_bytes / pool_s / 1e9 if pool_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (rocprofv3, separate passes, tools/measure_round.sh
+    # -> profiles/r3_pmc_hbm_traffic_<label>.json, stamped with the commit it was taken on; a bench
+    # process cannot read the counters of its own kernels)
+    pmc, pmc_src = None, None
+    tag = label or ("fp32" if esz == 4 else "fp16")
+    for rnd in ("r3", "r2"):
+        pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{tag}.json")
+        if (world == 1 and D == 128 and a.batch == 65536 and a.table_scale == 1.0 and
+                os.path.exists(pmc_path)):
+            try:
+                j = json.load(open(pmc_path))
+                if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
+                    pmc = j["kernels"]["pool_vec4_kernel"]["hbm_bytes_per_launch"]
+                    pmc_src = os.path.relpath(pmc_path, ROOT) + (
+                        f" @ {j['commit']}" if j.get("commit") else "")
+                    break
+            except Exception:
+                pmc = None
     stage_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}
-    # ---- per-rank diagnosis of a multi-GPU run: what each rank resolved, what it shipped --------
+    # update (a12): SURVEY 8(d) bytes = nnz (8 + K) + B S_g D E (gradients read) + U D 4 x 2 (rows)
+    upd_bytes = nnz_g * 16 + B * spr * D * esz + U * D * 4 * 2
+    upd_s = (stage_us.get("sort", 0.0) + stage_us.get("segmented_update", 0.0)) * 1e-6
+    idx_bytes = nnz_g * (8 + 16 + 8)
+    idx_s = stage_us.get("hash_index", 0.0) * 1e-6
     per_rank = None
     if world > 1:
-        if mode["name"] == "rows":
-            sent = sum(exch.send) - exch.send[rank]      # elements to the other ranks, one way
-            xb = {"payload": "rows", "bytes_out_forward": sent * esz, "bytes_out_backward":
-                  (sum(exch.recv) - exch.recv[rank]) * esz}
-        else:
-            us, ur = ux.u_send or [0] * world, ux.u_recv or [0] * world
-            gsz = 2 if mode["name"] == "unique16" else 4
-            xb = {"payload": mode["name"], "distinct_rows_out": sum(us) - us[rank],
-                  "positions": ux.P,
-                  "bytes_out_forward": (sum(us) - us[rank]) * D * esz + (ux.P - ux.P // world) * 8,
-                  "bytes_out_backward": (sum(ur) - ur[rank]) * D * gsz}
         mine = {"rank": rank, "slots": spr, "table_rows": my_rows, "stage_us": stage_us,
-                "exchange": xb}
+                "exchange": xrep, "new_keys_per_step": new_keys}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
-
     out = {
         "metric": "samples/sec (whole node) + embedding-gather HBM GB/s, DLRM Criteo-1TB",
         "value": B * steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": scaling, "vs_baseline": None,
         "dtype": {"fp16": "fp16 = the reference's mixed precision (use_mixed_precision, scaler 1024): "
                           "fp16 pooled vectors + top gradients + dense GEMMs (fp32 accumulate), "
                           "fp32 tables / pooling accumulation / sparse SGD, loss scaling",
                   "fp32": "fp32 = the reference's default: fp32 tables, pooled vectors, gradients, "
-                          "sparse SGD and dense GEMMs (interaction: fp32 I/O, 3x bf16-split MFMA)",
-                  "bf16": "bf16 (not a reference mode): bf16 pooled vectors + top gradients + dense "
-                          "GEMMs, fp32 tables / pooling accumulation / sparse SGD"}[precision],
+                          "sparse SGD and dense GEMMs (interaction: fp32 I/O, 3x bf16-split MFMA)"
+                  }[precision],
         "precision": precision,
-        "data": f"synthetic power-law alpha={a.alpha} (uniform if 0), one-hot, resident in HBM",
+        "data": f"synthetic power-law alpha={alpha} (uniform if 0), one-hot, resident in HBM, a "
+                f"new batch every step ({nb} batches)",
         "config": {"workload": "BASELINE configs[2]: DLRM Criteo-1TB slot_size_array, "
-                               "LocalizedSlotSparseEmbeddingHash, emb_dim=128, bs=65536 per GPU, SGD",
-                   "batch_per_gpu": Bl, "global_batch": B, "sub_batches_per_step": C, "dense_tower_hip_graph": graph is not None,
-                   "exchange": mode["name"] if world > 1 else "none (1 GPU)",
-                   "exchange_warmup_ms_per_step": mode.get("timing_ms"), "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
-                   "table_rows_this_rank": my_rows, "parallelism": f"slot-sharded x{world} + dp{world}",
-                   "final_loss": float(loss.detach()), "dense_gemm_selection": tuned},
+                               "LocalizedSlotSparseEmbeddingHash, emb_dim=128, SGD, bs=65536 " +
+                               ("per GPU (weak scaling)" if scaling == "weak" else
+                                "global (strong scaling)"),
+                   "surface": "hugectr.Model.train() (hugectr_amd/hugectr.py): CreateSolver, "
+                              "SparseEmbedding, DenseLayer MLP / Interaction / BinaryCrossEntropyLoss",
+                   "batch_per_gpu": Bl, "global_batch": B,
+                   "exchange": xrep["payload"],
+                   "exchange_selection_ms_per_step": xrep.get("selection_ms_per_step"),
+                   "intra_iteration_overlap": xrep["intra_iteration_overlap"],
+                   "inter_iteration_overlap": xrep["inter_iteration_overlap"],
+                   "slots": S, "emb_dim": D, "table_rows_total": sum(sizes),
+                   "table_rows_this_rank": my_rows,
+                   "parallelism": f"slot-sharded x{world} + dp{world}",
+                   "new_keys_per_step": new_keys, "distinct_rows_per_batch": U,
+                   "final_loss": m.get_current_loss(),
+                   "dense_gemm_selection": getattr(m, "_gemm_selection", "off")},
         "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
-                     "traffic_source": os.path.relpath(pmc_path, ROOT) if pmc else None,
+                     "traffic_source": pmc_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
-                     "avg_launch_us": pool_ms / max(pool_n, 1) * 1e3,
-                     # duplicates counted.  Power-law keys repeat hot rows, which L2 /
-                     # Infinity Cache serve -- `traffic` is what actually crossed the HBM interface,
-                     # so `achieved` can pass the HBM peak while traffic / time stays below it
-                     "hbm_traffic_gbps": (pmc / (pool_ms / max(pool_n, 1) * 1e-3) / 1e9)
-                     if pmc and pool_ms > 0 else None},
+                     "avg_launch_us": pool_s * 1e6,
+                     # SURVEY 8(d) counts duplicate rows; power-law keys repeat hot rows, which L2
+                     # / Infinity Cache serve, so `frac` can reach 1 without saying much about the
+                     # kernel.  compulsory_bytes counts every DISTINCT row once: the bytes no cache
+                     # can remove; `traffic` is what the counters saw cross the HBM interface
+                     "compulsory_bytes": comp_bytes,
+                     "frac_compulsory": (comp_bytes / pool_s / 1e9 / HBM_PEAK_GBPS)
+                     if pool_ms > 0 else None,
+                     "hbm_traffic_gbps": (pmc / pool_s / 1e9) if pmc and pool_ms > 0 else None},
+        "roofline_update": {"bound": "hbm", "kernels": "radix sort of (row, bucket) pairs + "
+                            "segmented reduce with the optimizer folded in + long-run combine",
+                            "achieved": (upd_bytes / upd_s / 1e9) if upd_s > 0 else None,
+                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": (upd_bytes / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
+                            "algorithmic_bytes": upd_bytes, "us": upd_s * 1e6, "traffic": None},
+        "roofline_index": {"bound": "hbm", "kernels": "hash index stage (filter + probe / insert)",
+                           "achieved": (idx_bytes / idx_s / 1e9) if idx_s > 0 else None,
+                           "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": (idx_bytes / idx_s / 1e9 / HBM_PEAK_GBPS) if idx_s > 0 else None,
+                           "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6},
         "stage_us_per_step": stage_us,
+        "embedding_ms_per_step": sum(stage_us.values()) * 1e-3,
     }
     if per_rank is not None:
         out["per_rank"] = per_rank
-    del emb, ux, exch, pooled, top_grad, bottom, top, dense_params, dense_opt
+    m._drain_prefetch()
+    del m, emb, ex, batches
     import gc
     gc.collect()
     torch.cuda.empty_cache()
@@ -843,7 +634,7 @@ MLPERF_TABLES = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 4000000
 MLPERF_HOTNESS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 
 
-def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128):
+def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
     """embedding_collection on one GPU (the reference's current-generation path):
     forward and backward + update of the collection alone, through EmbeddingCollection.forward /
     backward_and_update.  kind = "one_hot": Criteo-1TB tables, one key per table (the shape of the
@@ -857,13 +648,20 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128):
     cfg = EmbeddingCollectionConfig()
     tabs = [EmbeddingTableConfig(f"t{i}", v, D) for i, v in enumerate(sizes)]
     cfg.embedding_lookup(tabs, [f"b{i}" for i in range(26)], "sparse_embedding", ["sum"] * 26)
+    kw = {}
+    if dynamic:
+        # BASELINE configs[4]'s embedding half: the same collection on DYNAMIC hash tables
+        # (EmbeddingTableConfig(max_vocabulary_size=-1), R/HugeCTR/embedding_storage/
+        # dynamic_embedding.cu:130-330): keys are inserted on first sight, rows found by probing
+        kw = dict(storage="dynamic", init_capacity=1 << 22)
     ebc = EmbeddingCollection(cfg, B, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1024.0,
                               out_dtype=torch.float16, batch_major=True, max_hotness=max(hot),
-                              hotness=hot)
+                              hotness=hot, **kw)
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     batches = []
-    for _ in range(2):  # feature-major CSR: bucket = table * B + sample, hot[t] keys each
+    nbat = 2 if not dynamic else 2 + warmup  # (dynamic tables: the inserts happen in warm-up)
+    for _ in range(nbat):  # feature-major CSR: bucket = table * B + sample, hot[t] keys each
         ks = []
         for v, h in zip(sizes, hot):
             u = torch.rand(B * h, device=dev, generator=g, dtype=torch.float32).double()
@@ -888,19 +686,22 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / steps * 1e3
 
-    fwd_us = timed(lambda i: ebc.forward(*batches[i % 2]))
+    fwd_us = timed(lambda i: ebc.forward(*batches[i % nbat]))
 
     def train(i):
-        ebc.forward(*batches[i % 2])
+        ebc.forward(*batches[i % nbat])
         ebc.backward_and_update(grad)
     both_us = timed(train)
     nnz = B * sum(hot)
-    alg = nnz * (8 + 8 + D * 4) + B * 26 * D * 2
+    # dynamic tables: + the 16-byte hash probe per key in place of the static index arithmetic
+    alg = nnz * (8 + 8 + D * 4) + B * 26 * D * 2 + (nnz * 16 if dynamic else 0)
     ach = alg / (fwd_us * 1e-6) / 1e9
     return {
         "workload": ("embedding_collection, Criteo-1TB tables, one-hot" if kind == "one_hot" else
                      "embedding_collection, MLPerf DLRM-DCNv2 tables and hotness (214 keys / "
                      "sample), R/samples/dlrm/train.py:29-83") +
+                    (" on DYNAMIC hash tables (BASELINE configs[4], embedding half)" if dynamic
+                     else "") +
                     f", B={B}, D={D}, fp16 output [B][26][D], SGD, power-law alpha={alpha}; the "
                     "collection alone (no dense tower)",
         "direct_one_gpu_path": bool(ebc._direct), "keys_per_batch": nnz,
@@ -916,62 +717,128 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128):
     }
 
 
+def tiered_leg(steps, warmup, dev, alpha=1.1, rows=20_000_000, D=128, n=1 << 20):
+    """BASELINE configs[3] at the size one box's host memory takes: a [rows, D] fp32 table in
+    pinned host memory behind the HBM embedding cache (R/gpu_cache/include/nv_gpu_cache.hpp,
+    uvm_table.hpp:133-174), one-hot power-law keys, a NEW batch every call.  lookup = cache Query +
+    miss fill straight out of host memory + Replace; update = per-row gradient sums + write-through
+    SGD.  Bound by the host link (PCIe 5 x16: 64 GB/s per direction), not by HBM."""
+    from hugectr_amd.cache import TieredEmbedding
+    sets = 1 << 16  # 4.2 M cached rows = 2.1 GB of HBM for a 10 GB table
+    te = TieredEmbedding(rows, D, sets, n, lr=0.01)
+    te.table.host[:] = 0.01
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+
+    def draw():
+        u = torch.rand(n, device=dev, generator=g, dtype=torch.float32).double()
+        e = 1.0 - alpha
+        y = ((float(rows) ** e - 1.0) * u + 1.0) ** (1.0 / e) if alpha > 0 else u * rows + 1
+        k = (torch.round(y) - 1).clamp_(0, rows - 1).to(torch.int64)
+        return (k * 7919) % rows  # hot rows scattered over the table
+    nb = warmup + steps
+    batches = [draw() for _ in range(2 * nb + 8)]
+    grad = torch.randn((n, D), device=dev) * 1e-3
+    for k in batches[:8]:  # the cache settles at the stream's hit rate
+        te.forward(k)
+    miss = []
+
+    def timed(fn, first):
+        for i in range(warmup):
+            fn(batches[first + i])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            fn(batches[first + warmup + i])
+            miss.append(te.table._miss.clone())
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps * 1e3
+    look_us = timed(lambda k: te.forward(k), 8)
+    miss_rate = float(torch.stack(miss).double().mean()) / n
+    miss.clear()
+
+    def train(k):
+        te.forward(k)
+        te.backward_update(grad)
+    both_us = timed(train, 8 + nb)
+    link_bytes = miss_rate * n * D * 4
+    LINK = 64.0
+    return {
+        "workload": f"tiered table (BASELINE configs[3] in miniature): {rows} x {D} fp32 rows "
+                    f"({rows * D * 4 / 2**30:.1f} GiB) in pinned host memory, {sets * 64} cached "
+                    f"rows in HBM, {n} one-hot power-law (alpha={alpha}) keys per call, a new "
+                    "batch every call",
+        "lookup_us": look_us, "lookup_update_us": both_us, "update_us": both_us - look_us,
+        "miss_rate": miss_rate, "value": n / (both_us * 1e-6),
+        "unit": "keys/s (lookup + write-through SGD)",
+        "roofline": {"bound": "host link (PCIe 5 x16, per direction)", "peak": LINK,
+                     "unit": "GB/s", "achieved": link_bytes / (look_us * 1e-6) / 1e9,
+                     "frac": link_bytes / (look_us * 1e-6) / 1e9 / LINK,
+                     "algorithmic_bytes_per_launch": link_bytes, "traffic": None,
+                     "note": "bytes = missed rows x D x 4 crossing the link during the lookup; "
+                             "the cache hits (HBM) ride along in the same time"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536,
-                    help="batch PER GPU (BASELINE config 3: 65536); weak scaling: global = N * batch")
-    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="capture the per-sub-batch dense tower (bottom MLP, interaction, top MLP, "
-                         "loss, backward) in a HIP graph; auto = when chunks > 1")
-    ap.add_argument("--chunks", type=int, default=0,
-                    help="sub-batches per step whose all-to-all overlaps the dense tower of the "
-                         "previous one.  Default 1: measured on MI355X, 4 sub-batches of 16384 cost "
-                         "+2.1 ms of dense-tower time per step (smaller GEMMs / reductions), which "
-                         "is what the overlap could save at N = 8, so no split is the default")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "rows", "unique", "unique16"],
-                    help="multi-GPU payload of the embedding exchange: rows = one pooled vector / "
-                         "gradient per (sample, slot) as the reference; unique = every distinct row "
-                         "once per destination + per-row gradient sums "
-                         "(hugectr_amd/unique_exchange.py), sums on the wire in fp32; unique16 = "
-                         "the same with the sums in the pooled vectors' 16-bit type (the precision "
-                         "class of the per-sample gradients the rows payload ships; opt-in); auto = "
-                         "time rows and unique during warm-up and keep the faster")
+                    help="BASELINE config 3's 65536: per GPU on the main (weak-scaling) line, "
+                         "global on the strong-scaling line")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
+                    help="N > 1: weak = 65536 samples per GPU (the main line), strong = global "
+                         "batch 65536 (the reference's `batchsize` is global, "
+                         "solver_wrapper.hpp:127-150); both = the weak line with the strong one "
+                         "under the key `strong` of the same JSON object")
+    ap.add_argument("--exchange", default=None, choices=["auto", "rows", "unique", "unique16"],
+                    help="multi-GPU payload of the embedding exchange (sets HCTR_EXCHANGE, read by "
+                         "hugectr.Model): rows = one pooled vector / gradient per (sample, slot) "
+                         "as the reference; unique = every distinct row once per destination + "
+                         "per-row gradient sums (hugectr_amd/unique_exchange.py); unique16 = the "
+                         "same with 16-bit sums on the wire; auto (default) = Model.train() times "
+                         "rows and unique over its first steps and keeps the faster")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="train_intra/inter_iteration_overlap = False: blocking collectives in line")
     ap.add_argument("--alpha", type=float, default=1.1, help="power-law exponent; 0 = uniform")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--table-scale", type=float, default=1.0)
-    ap.add_argument("--nbatches", type=int, default=8)
+    ap.add_argument("--nbatches", type=int, default=0,
+                    help="batches resident in HBM; 0 = one per step (warm-up included): every "
+                         "step then meets keys it has not seen (inserts live), as real data does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sgd-atomic", action="store_true")
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32", "bf16"],
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "fp32"],
                     help="precision of the MAIN line.  fp16 = the reference's mixed precision "
                          "(use_mixed_precision=True, scaler=1024: fp16 pooled vectors / top "
                          "gradients / dense GEMMs, loss scaling; the MLPerf DLRM configuration of "
-                         "the reference), fp32 = the reference's default (everything fp32), bf16 = "
-                         "not a reference mode (MI355X-native 16-bit type, no loss scaling).  "
-                         "Tables, pooling accumulation and the sparse optimizer are fp32 in all "
-                         "three.")
-    ap.add_argument("--extra", default="auto", choices=["auto", "none", "all", "ebc", "model"],
+                         "the reference), fp32 = the reference's default (everything fp32).  "
+                         "Tables, pooling accumulation and the sparse optimizer are fp32 in both.")
+    ap.add_argument("--extra", default="auto",
+                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
-                         "other two precisions on the same workload and BASELINE configs[0] / [1] "
-                         "(DCN README, DeepFM Criteo-Kaggle, D = 16) through the hugectr surface; "
-                         "auto = all of them when --config c3 runs on one GPU, plus the "
-                         "embedding_collection legs (one-hot Criteo-1TB, multi-hot MLPerf DCNv2); "
-                         "ebc = only those")
+                         "other precision on the same workload, `uniform_big_tables` (no key "
+                         "repeats: the discriminating roofline), BASELINE configs[0] / [1] (DCN "
+                         "README, DeepFM Criteo-Kaggle, D = 16) through the hugectr surface, the "
+                         "embedding_collection legs (one-hot Criteo-1TB, multi-hot MLPerf DCNv2, "
+                         "dynamic tables = configs[4]'s embedding half) and the tiered table "
+                         "(configs[3]); auto = all of them when --config c3 runs on one GPU")
     ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3"],
                     help="c3 = BASELINE configs[2], DLRM Criteo-1TB (the metric's configuration); "
                          "c1 / c2 = configs[0] / [1] as the main line")
     ap.add_argument("--extra-steps", type=int, default=10)
-    ap.add_argument("--tunable", default="auto", choices=["auto", "tune", "off"],
-                    help="dense-tower GEMM solution selection through PyTorch TunableOp: auto = use "
-                         "the committed hugectr_amd/tuning/tunableop_gfx950.csv if present (no "
-                         "tuning at run time); tune = search during warm-up (outside the timed "
-                         "region) and write --tunable-file; off = library heuristics")
-    ap.add_argument("--tunable-file", default=os.path.join(ROOT, "hugectr_amd", "tuning",
-                                                           "tunableop_gfx950.csv"))
+    ap.add_argument("--tunable", default="auto", choices=["auto", "off"],
+                    help="dense-tower GEMM solution selection: auto = hugectr.Model reads the "
+                         "committed hugectr_amd/tuning/tunableop_gfx950.csv (solver."
+                         "use_algorithm_search); off = library heuristics")
     a = ap.parse_args()
+    if a.exchange:
+        os.environ["HCTR_EXCHANGE"] = a.exchange
+    if a.tunable == "off":
+        os.environ["HCTR_TUNABLEOP"] = "off"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -980,14 +847,16 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
+        # functional check of the N > 1 orchestration with all ranks on ONE GPU (collectives
+        # staged through the host); never used for measurements
         local_rank = 0
+        os.environ["HCTR_DIST_BACKEND"] = "gloo"
+        os.environ["HCTR_RANKS_ON_ONE_GPU"] = "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("HCTR_BENCH_BACKEND") == "gloo":
-            # functional check of the N > 1 orchestration with all ranks on ONE GPU (collectives
-            # staged through the host); never used for measurements
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -998,47 +867,73 @@ def main():
             print(json.dumps(out))
         return
 
-    rng = np.random.default_rng(1234)  # every rank draws the same full-batch CSR (reader semantics)
-    sizes = [max(1, int(v * a.table_scale)) for v in CRITEO_1TB]
-    shared = {"keys": [torch.from_numpy(make_keys(rng, a.batch * world, sizes, a.alpha)).to(dev)
-                       for _ in range(a.nbatches)]}
-    out = dlrm_leg(a, a.precision, a.steps, a.warmup, world, rank, dev, shared)
+    import gc
+    first = "strong" if a.scaling == "strong" else "weak"
+    out = dlrm_leg(a, a.precision, a.steps, a.warmup, world, rank, dev, scaling=first)
+    if world > 1 and a.scaling == "both":
+        # BASELINE configs[2] read literally: global batch 65536 over N GPUs
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            out["strong"] = dlrm_leg(a, a.precision, a.steps, a.warmup, world, rank, dev,
+                                     scaling="strong")
+        except Exception as e:  # (raised on every rank alike)
+            out["strong"] = {"error": repr(e)}
+    elif world == 1:
+        out["strong"] = "at N = 1 the strong-scaling line (global batch 65536) IS this line"
     if rank == 0 and world == 1 and a.extra != "none":
         extra = {}
-        for prec in ("fp32", "fp16", "bf16"):
-            if prec == a.precision or a.extra in ("ebc", "model"):
-                continue
-            try:
-                leg = dlrm_leg(a, prec, a.extra_steps, max(a.nbatches, 4), world, rank, dev, shared)
-                extra[prec] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup",
-                                                   "dtype", "roofline", "stage_us_per_step")}
-                extra[prec]["final_loss"] = leg["config"]["final_loss"]
-            except Exception as e:  # an extra leg never takes the main line down
-                extra[prec] = {"error": repr(e)}
-        for cfg in ("c1", "c2"):
-            if a.extra in ("ebc", "model"):
-                continue
-            try:
-                extra[cfg] = small_config_leg(cfg, 50, 20, dev)
-            except Exception as e:
-                extra[cfg] = {"error": repr(e)}
-        import gc
-        if a.extra != "ebc":
-            gc.collect()
-            torch.cuda.empty_cache()
-            try:
-                extra["dlrm_ebc_model"] = dlrm_ebc_model_leg(a.extra_steps, 4, dev, alpha=a.alpha)
-            except Exception as e:
-                extra["dlrm_ebc_model"] = {"error": repr(e)}
-        for kind in ("one_hot", "multi_hot"):
-            if a.extra == "model":
-                continue
+        sel = a.extra
+
+        def run(name, kinds, fn):
+            if sel not in kinds:
+                return
             gc.collect()
             torch.cuda.empty_cache()  # (100 GB tables: the previous leg's must be gone first)
             try:
-                extra["ebc_" + kind] = ebc_leg(kind, a.extra_steps, 3, dev, a.alpha)
-            except Exception as e:
-                extra["ebc_" + kind] = {"error": repr(e)}
+                extra[name] = fn()
+            except Exception as e:  # an extra leg never takes the main line down
+                extra[name] = {"error": repr(e)}
+
+        def other_precision():
+            prec = "fp32" if a.precision == "fp16" else "fp16"
+            leg = dlrm_leg(a, prec, a.extra_steps, 4, world, rank, dev)
+            r = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype",
+                                     "roofline", "roofline_update", "stage_us_per_step")}
+            r["final_loss"] = leg["config"]["final_loss"]
+            return r
+
+        def uniform_big():
+            # no cache-resident table, no repeated row: the seven tables of >= 2.9 M rows in all
+            # 26 slots (the largest four twice over), uniform keys -- every row read is a
+            # compulsory HBM read, so this leg's roofline fraction says what the KERNEL does
+            big = sorted([v for v in CRITEO_1TB if v >= 2900000], reverse=True)
+            sizes = [big[i % len(big)] for i in range(26)]
+            leg = dlrm_leg(a, a.precision, a.extra_steps, 4, world, rank, dev, alpha=0.0,
+                           sizes=sizes, label="uniform_big_tables")
+            r = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup",
+                                     "roofline", "roofline_update", "roofline_index",
+                                     "stage_us_per_step", "data")}
+            r["workload"] = ("the main line's model with 26 slots over the seven Criteo-1TB tables "
+                             f"of >= 2.9 M rows ({sum(sizes)} rows, {sum(sizes) * 512 / 2**30:.0f} "
+                             "GiB), uniform keys: nothing is cache-resident, no row repeats")
+            r["distinct_rows_per_batch"] = leg["config"]["distinct_rows_per_batch"]
+            r["new_keys_per_step"] = leg["config"]["new_keys_per_step"]
+            return r
+
+        run(("fp32" if a.precision == "fp16" else "fp16"), ("auto", "all"), other_precision)
+        run("uniform_big_tables", ("auto", "all", "uniform"), uniform_big)
+        run("c1", ("auto", "all"), lambda: small_config_leg("c1", 50, 20, dev))
+        run("c2", ("auto", "all"), lambda: small_config_leg("c2", 50, 20, dev))
+        run("dlrm_ebc_model", ("auto", "all", "model"),
+            lambda: dlrm_ebc_model_leg(a.extra_steps, 4, dev, alpha=a.alpha))
+        run("ebc_one_hot", ("auto", "all", "ebc"),
+            lambda: ebc_leg("one_hot", a.extra_steps, 3, dev, a.alpha))
+        run("ebc_multi_hot", ("auto", "all", "ebc"),
+            lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha))
+        run("ebc_dynamic_multi_hot", ("auto", "all", "ebc", "next"),
+            lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha, dynamic=True))
+        run("tiered", ("auto", "all", "next"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
         out["extra"] = extra
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:

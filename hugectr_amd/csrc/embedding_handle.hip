@@ -795,9 +795,12 @@ int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
   }
   e->opt.times++;  // update_params(): adam.times++ before the update (…hash.hpp:346-347)
   e->upd.scale_row_offset = e->tb.ro_full;  // NULL unless distributed + mean + N > 1
-  return e->upd.update(e->cur_buckets, nnz, e->p.combiner, e->ro, e->p.key_type, e->value_index,
-                       e->top_grad, e->p.out_dtype, e->opt, e->table, e->state0, e->state1,
-                       e->prev_time, s);
+  const int rc = e->upd.update(e->cur_buckets, nnz, e->p.combiner, e->ro, e->p.key_type,
+                               e->value_index, e->top_grad, e->p.out_dtype, e->opt, e->table,
+                               e->state0, e->state1, e->prev_time, s);
+  // key-typed, batch-sized: never left behind for update_rows (int64 offsets of another length)
+  e->upd.scale_row_offset = nullptr;
+  return rc;
 }
 
 int hctr_emb_set_learning_rate(hctr_embedding* e, float lr) {

@@ -147,16 +147,20 @@ __global__ void __launch_bounds__(kRsBlock)
     const bool valid = base + (size_t)r * 64 < n;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
     unsigned long long m = 0ull;
-    if (valid) {
-      atomicOr(const_cast<unsigned long long*>(&mm[d]), 1ull << lane);
-      m = mm[d];                      // (LDS operations of a wavefront complete in order)
-    }
+    // LDS operations of one wavefront complete in issue order; the wave barriers keep the
+    // COMPILER from moving the OR, the read-back and the clear across each other (they sit in
+    // divergent branches it could otherwise reschedule)
+    if (valid) atomicOr(const_cast<unsigned long long*>(&mm[d]), 1ull << lane);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) m = mm[d];
+    __builtin_amdgcn_wave_barrier();
     const uint32_t rank = (uint32_t)__popcll(m & lt), cnt = (uint32_t)__popcll(m);
     info[r] = rank | (cnt << 8);
     if (valid && rank == 0u) {
       mm[d] = 0ull;
       atomicAdd(&wh[wave][d], cnt);
     }
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();  // (the masks are all zero again: stage becomes the sorted tile)
   // per digit value (4 per thread): keys of this tile, global first position, local first position
@@ -196,13 +200,16 @@ __global__ void __launch_bounds__(kRsBlock)
     const bool valid = i < n;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
     const uint32_t v = valid ? vin[i] : 0u;
+    uint32_t first = 0u;
+    if (valid) first = cur[d];                       // every lane of the match group reads ...
+    __builtin_amdgcn_wave_barrier();
     if (valid) {
-      const uint32_t first = cur[d];                 // every lane of the match group reads ...
       const uint32_t rank = info[r] & 0xFFu;
       if (rank == 0u) cur[d] = first + (info[r] >> 8);  // ... before its leader advances
       lkey[first + rank] = key[r];
       lval[first + rank] = v;
     }
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
 #pragma unroll

@@ -1056,7 +1056,8 @@ __global__ void __launch_bounds__(kBlock)
   for (size_t u = wave; u < buckets; u += nwaves) {
     const long long off = (long long)row_offset[u];
     const int n = (int)((long long)row_offset[u + 1] - off);
-    const int ns = (int)((long long)scale_ro[u + 1] - (long long)scale_ro[u]);
+    // (the scaling CSR is read for the mean combiner only)
+    const int ns = combiner == 1 ? (int)((long long)scale_ro[u + 1] - (long long)scale_ro[u]) : 1;
     float sc = (combiner == 1 && ns > 1) ? 1.0f / (float)ns : 1.0f;
     if (D % 2 == 0) sc = Load4<GradT>::rnd(sc);  // align2 rule (backward_functor.cu:83-104)
     for (int v = lane; v < D; v += 64) {

@@ -26,11 +26,11 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .dense import FusedMLP
+from .dense import FusedMLP, bce_with_logits
 from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward_reorder
 from .embedding_collection import (DataParallelCollection, EmbeddingCollection,  # noqa: F401
                                    EmbeddingCollectionConfig, EmbeddingTableConfig)
-from .layers import MultiCrossLayer, interaction
+from .layers import MultiCrossLayer, interaction, interaction_indexed
 from .parallel import DistributedExchange, LocalizedExchange
 from .parallel import all_reduce as _all_reduce
 from . import data as _data
@@ -202,6 +202,29 @@ def _launch_one_process_per_gpu(n_gpus: int):
     print(f"[HCTR][INFO] vvgpu lists {n_gpus} GPUs: starting one process per GPU: {' '.join(cmd)}",
           flush=True)
     raise SystemExit(subprocess.call(cmd))
+
+
+def _use_gemm_selection(solver) -> str:
+    """solver.use_algorithm_search (the reference searches cublasGemmEx algorithms when the layers
+    are built, solver_wrapper.hpp:139): here the dense GEMMs of torch / hipBLASLt take the
+    solutions recorded in hugectr_amd/tuning/tunableop_gfx950.csv through PyTorch TunableOp --
+    read only, nothing is tuned at run time.  HCTR_TUNABLEOP=off keeps the library heuristics."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning",
+                        "tunableop_gfx950.csv")
+    if not solver.use_algorithm_search or os.environ.get("HCTR_TUNABLEOP", "file") == "off" or \
+            not os.path.exists(path):
+        return "off"
+    try:
+        import torch.cuda.tunable as tunable
+        if not tunable.is_enabled():
+            tunable.enable(True)
+            tunable.set_filename(path)
+            tunable.tuning_enable(False)
+            tunable.write_file_on_exit(False)  # the recorded selections are read, never rewritten
+            tunable.read_file(path)
+        return "file"
+    except Exception:  # an optimisation only
+        return "off"
 
 
 def _join_process_group():
@@ -450,6 +473,34 @@ class _WeightMultiply(torch.nn.Module):
         return (x.unsqueeze(2) * self.w.unsqueeze(0)).reshape(x.shape[0], -1)
 
 
+class _Pending:
+    """an embedding output that is still in flight (all-to-all issued, not waited for): resolved
+    by the first dense layer that names it, so every layer in front of that one -- the bottom
+    MLP of a DLRM -- is enqueued under the exchange (the reference's intra-iteration overlap:
+    bottom_network_fprop does not wait for the embedding's network forward,
+    R/HugeCTR/src/pybind/model_pipeline.cpp:299-346)"""
+
+    def __init__(self, resolve):
+        self.resolve = resolve
+
+
+class _IndexedEmb:
+    """embedding output of the unique-row exchange kept as (distinct rows, (sample, slot) -> row):
+    the Interaction layer reads the rows through the table, the [B, S, D] tensor is never written"""
+
+    def __init__(self, rows, row_of, on_grad):
+        self.rows, self.row_of, self.on_grad = rows, row_of, on_grad
+
+
+class _Tensors(dict):
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _Pending):
+            v = v.resolve()
+            dict.__setitem__(self, k, v)
+        return v
+
+
 class Model:
     """hugectr.Model for one rank.  Supported graph: Input -> SparseEmbedding* -> DenseLayer* with
     one BinaryCrossEntropyLoss."""
@@ -574,8 +625,11 @@ class Model:
         self._mods.to(self.device)
         self._dense_params = [p for p in self._mods.parameters()]
         self._dense_opt = self._make_dense_opt()
-        self.reader = _data.make_reader(self.reader_params, self.input, s, self.rank, self.world,
-                                        self.device)
+        # Model.reader_override: anything with next_batch(train) / has_eval() handing out batches
+        # in the readers' layout (data.py) -- bench.py serves batches resident in HBM this way
+        self.reader = getattr(self, "reader_override", None) or _data.make_reader(
+            self.reader_params, self.input, s, self.rank, self.world, self.device)
+        self._gemm_selection = _use_gemm_selection(s)
         # readers that can (Raw) hand every collection its global CSR ready-made (data.RawReader)
         groups = [[p.top_name for p in rt["params"]] for rt in self._ebc]
         for j, rt in enumerate(self._ebc):
@@ -583,7 +637,157 @@ class Model:
         for r in (getattr(self.reader, "train", None), getattr(self.reader, "evalr", None)):
             if r is not None and hasattr(r, "ebc_groups"):
                 r.ebc_groups = groups
+        self._plan_execution()
         self._compiled = True
+
+    def _plan_execution(self):
+        """what the training step may fuse and overlap, decided once from the graph:
+
+        * dense SGD on flat buffers: when every trainable dense tensor lives in a 16-bit FusedMLP
+          and the optimizer is SGD (the reference's DLRM configurations), backward writes the
+          gradients into one flat buffer per MLP, the data-parallel all-reduce runs on it as is
+          and the step + refresh of the 16-bit copy is one kernel (`hctr_sgd_shadow`);
+        * logit head: an MLP whose last layer (K -> 1, no activation) feeds only the
+          BinaryCrossEntropyLoss computes that layer, the loss and both backward products in one
+          pass (`hctr_logit_head`);
+        * solver.train_intra_iteration_overlap (model_pipeline.cpp:299-346): on N > 1 GPUs the
+          localized embedding's all-to-all is asynchronous -- dense layers that do not read the
+          embedding are enqueued under it, the gradient all-to-all starts from inside backward as
+          soon as dL/dE exists;
+        * solver.train_inter_iteration_overlap: batch i + 1's index stage and exchange plan run on
+          a side stream under batch i's dense tower (unique-row payload, `unique_exchange.py`);
+        * the payload of the exchange (HCTR_EXCHANGE = rows | unique | unique16 | auto): rows = one
+          pooled vector / gradient per (sample, slot), the reference's; unique = every distinct
+          row once per destination + per-row gradient sums (one-hot sum lookups only); auto
+          (default when both overlaps are on) times both over a few training steps and keeps the
+          faster one -- the same decision on every rank."""
+        s = self.solver
+        consumers: Dict[str, list] = {}
+        for i, L in enumerate(self.layers):
+            for pos, b in enumerate(L.bottom_names):
+                consumers.setdefault(b, []).append((i, pos))
+        self._consumers = consumers
+        fused_ok = os.environ.get("HCTR_MODEL_FUSED_DENSE", "1") != "0"
+        # -- flat dense SGD -----------------------------------------------------------------------
+        mlps = [m for m in self._mods.values() if isinstance(m, FusedMLP)]
+        in_mlps = sum(sum(q.numel() for q in m.parameters()) for m in mlps)
+        total = sum(q.numel() for q in self._dense_params)
+        self._flat_mlps = []
+        if (fused_ok and mlps and in_mlps == total and s.use_mixed_precision and
+                Optimizer_t(self.opt.optimizer_type) == Optimizer_t.SGD):
+            for m in mlps:
+                m.flatten()
+            self._flat_mlps = mlps
+            self._dense_opt = None
+        # -- logit head -----------------------------------------------------------------------------
+        self._head_layer = None
+        if fused_ok and self._loss_layer is not None and s.use_mixed_precision:
+            logit_name = self._loss_layer.bottom_names[0]
+            for i, L in enumerate(self.layers):
+                if (L.layer_type == Layer_t.MLP and L.top_names[0] == logit_name and
+                        len(consumers.get(logit_name, [])) == 1 and
+                        self._mods[f"l{i}"].can_fuse_bce_head()):
+                    self._head_layer = i
+        # -- exchange of the localized embeddings on N > 1 GPUs -----------------------------------
+        self._intra = bool(s.train_intra_iteration_overlap) and self.world > 1
+        self._inter = bool(s.train_inter_iteration_overlap) and self.world > 1
+        want = os.environ.get("HCTR_EXCHANGE", "auto" if (self._intra and self._inter) else "rows")
+        if want not in ("rows", "unique", "unique16", "auto"):
+            raise RuntimeError("HCTR_EXCHANGE must be rows, unique, unique16 or auto")
+        self._xstate = {}
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            st = {"mode": "rows", "ux": None, "select": None, "indexed": False, "timing_ms": None}
+            one_hot = p.is_fixed_length and p.max_nnz() == 1
+            if (self.world > 1 and localized and one_hot and se.combiner == 0 and
+                    want != "rows" and self._intra and
+                    (se.embedding_vec_size * (2 if s.use_mixed_precision else 4)) % 16 == 0):
+                try:
+                    from .unique_exchange import UniqueExchange
+                    st["ux"] = UniqueExchange(h, self.bpg, p.slot_num, se.embedding_vec_size)
+                except Exception as e:  # e.g. positions x peers beyond the 32-bit sort key
+                    if self.rank == 0:
+                        print(f"[HCTR][WARNING] unique-row exchange unavailable for {name}: {e!r}")
+                if st["ux"] is not None:
+                    cons = consumers.get(name, [])
+                    st["indexed"] = (len(cons) == 1 and cons[0][1] == 1 and
+                                     self.layers[cons[0][0]].layer_type == Layer_t.Interaction and
+                                     s.use_mixed_precision)
+                    if want == "auto":
+                        st["select"] = {"it": 0, "t0": 0.0, "t": {}}
+                    else:
+                        self._set_exchange(st, want)
+            self._xstate[name] = st
+        self._lookahead = None     # (batch i + 1) fetched early for the inter-iteration prefetch
+
+    def _set_exchange(self, st, mode: str):
+        st["mode"] = mode
+        if st["ux"] is not None and mode != "rows":
+            st["ux"].set_sum_dtype(self.emb_dtype if mode == "unique16" else torch.float32)
+
+    # iterations of the exchange selection (HCTR_EXCHANGE=auto): the first ones insert most keys
+    # (slow whatever the payload), then 3 timed steps of each payload after 2 untimed ones
+    _SEL_WARM, _SEL_TIMED, _SEL_SWITCH = 8, 3, 2
+
+    def _select_exchange(self, st):
+        """called at the start of every train() while the selection of one embedding's payload is
+        running; every step is a real training step (both payloads give the same model up to fp32
+        rounding), only the clock reads add host synchronisations -- to 2 x 2 of the first 16"""
+        sel = st["select"]
+        W, T, S = self._SEL_WARM, self._SEL_TIMED, self._SEL_SWITCH
+        it = sel["it"]
+        sel["it"] += 1
+        marks = {W: ("rows", None), W + T: ("unique", "rows"), W + T + S: ("unique", None),
+                 W + 2 * T + S: (None, "unique")}
+        if it not in marks:
+            return
+        nxt, done = marks[it]
+        if done is not None or it in (W, W + T + S):
+            if st["ux"] is not None:
+                st["ux"].drain()
+            torch.cuda.synchronize()
+        if done is not None:
+            sel["t"][done] = time.perf_counter() - sel["t0"]
+        if it in (W, W + T + S):
+            if dist.is_initialized():
+                dist.barrier()
+            sel["t0"] = time.perf_counter()
+        if nxt is not None:
+            self._set_exchange(st, nxt)
+            return
+        t = torch.tensor([sel["t"]["rows"], sel["t"]["unique"]], dtype=torch.float64)
+        if dist.get_backend() != "gloo":
+            t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the slowest rank decides, the same on all
+        t = t.cpu()
+        st["timing_ms"] = {"rows": float(t[0]) / T * 1e3, "unique": float(t[1]) / T * 1e3}
+        self._set_exchange(st, "rows" if float(t[0]) <= float(t[1]) else "unique")
+        st["select"] = None
+
+    def exchange_report(self) -> dict:
+        """per localized embedding: the payload in use, the selection's timings and what this
+        rank shipped in the last step (for bench.py's `config.exchange` / `per_rank`)"""
+        out = {}
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            st = self._xstate[name]
+            esz = 2 if self.solver.use_mixed_precision else 4
+            D = se.embedding_vec_size
+            r = {"payload": st["mode"] if self.world > 1 else "none (1 GPU)",
+                 "selection_ms_per_step": st["timing_ms"],
+                 "intra_iteration_overlap": self._intra, "inter_iteration_overlap": self._inter}
+            if self.world > 1 and localized and st["mode"] == "rows":
+                e = ex["train"]
+                r["bytes_out_forward"] = (sum(e.send) - e.send[self.rank]) * esz
+                r["bytes_out_backward"] = (sum(e.recv) - e.recv[self.rank]) * esz
+            elif self.world > 1 and st["ux"] is not None and st["ux"].u_send is not None:
+                ux = st["ux"]
+                us, ur = ux.u_send, ux.u_recv
+                gsz = 2 if st["mode"] == "unique16" else 4
+                r.update(distinct_rows_out=sum(us) - us[self.rank], positions=ux.P,
+                         bytes_out_forward=(sum(us) - us[self.rank]) * D * esz +
+                         (ux.P - ux.P // self.world) * 8,
+                         bytes_out_backward=(sum(ur) - ur[self.rank]) * D * gsz)
+            out[name] = r
+        return out
 
     def _split_by_ev_size(self, cfg: EmbeddingCollectionConfig):
         """the runtime keeps one vector size per collection: lookups of a config that mixes sizes
@@ -808,11 +1012,17 @@ class Model:
         return torch.optim.SGD(self._dense_params, lr=lr)
 
     # -- execution ---------------------------------------------------------------------------------
-    def _forward_dense(self, tensors: Dict[str, torch.Tensor], train: bool):
-        logit = None
+    def _forward_dense(self, tensors: Dict[str, torch.Tensor], train: bool, head=None):
+        """the dense layers in graph order.  head = (label, grad_scale) lets the MLP that feeds
+        only the loss run its logit layer + BinaryCrossEntropyLoss + their backward as one pass;
+        returns (logit or None, fused loss or None)"""
+        logit, fused_loss = None, None
         for i, L in enumerate(self.layers):
             t, key = L.layer_type, f"l{i}"
             x = [tensors[b] for b in L.bottom_names]
+            if t == Layer_t.MLP and head is not None and i == self._head_layer:
+                fused_loss = self._mods[key].forward_bce(x[0].reshape(x[0].shape[0], -1), *head)
+                continue
             if t in (Layer_t.InnerProduct, Layer_t.MLP, Layer_t.MultiCross, Layer_t.FmOrder2):
                 y = self._mods[key](x[0].reshape(x[0].shape[0], -1).float()
                                     if t != Layer_t.MLP else x[0].reshape(x[0].shape[0], -1))
@@ -848,28 +1058,38 @@ class Model:
             elif t == Layer_t.ReduceSum:
                 y = x[0].sum(dim=L.axis, keepdim=True)
             elif t == Layer_t.Interaction:
-                dt = x[1].dtype
-                y = interaction(x[0].to(dt).contiguous(), x[1].contiguous())
+                if isinstance(x[1], _IndexedEmb):
+                    e = x[1]
+                    y = interaction_indexed(x[0].to(e.rows.dtype).contiguous(), e.rows, e.row_of,
+                                            on_emb_grad=e.on_grad)
+                else:
+                    dt = x[1].dtype
+                    y = interaction(x[0].to(dt).contiguous(), x[1].contiguous())
             elif t == Layer_t.BinaryCrossEntropyLoss:
-                logit = x[0].float()
+                if fused_loss is None:
+                    logit = x[0].float()
                 continue
             else:
                 raise RuntimeError(t)
             tensors[L.top_names[0]] = y
-        return logit
+        return logit, fused_loss
 
-    def _run_batch(self, batch, train: bool):
+    def _emb_forward(self, name, batch, nxt, train: bool, tensors, leaves, after):
+        """forward of one legacy embedding into `tensors[name]`; `after` collects what has to run
+        once backward is through (wait for the gradient exchange, backward + sparse update)"""
+        se, p, h, ex, localized = self._emb[name]
+        st = self._xstate[name]
         mode = "train" if train else "eval"
-        tensors = {self.input.dense_name: batch["dense"], self.input.label_name: batch["label"]}
-        leaves = {}
-        for name, (se, p, h, ex, localized) in self._emb.items():
-            ro, keys = batch["sparse"][se.bottom_name]
+        bpg = self.bpg if train else self.bpg_eval
+        S, D, W = p.slot_num, se.embedding_vec_size, self.world
+        ro, keys = batch["sparse"][se.bottom_name]
+        if not train or W == 1 or not localized or not self._intra:
+            # one GPU, evaluation, the distributed embedding, or no intra-iteration overlap asked
+            # for: blocking collectives, in line
             pooled = h.forward(train, ro, keys)
-            bpg = self.bpg if train else self.bpg_eval
             if localized:
                 recv = ex[mode].forward(pooled)
-                E = forward_reorder(recv, bpg, p.slot_num, se.embedding_vec_size, self.world) \
-                    if self.world > 1 else pooled.view(bpg, p.slot_num, se.embedding_vec_size)
+                E = forward_reorder(recv, bpg, S, D, W) if W > 1 else pooled.view(bpg, S, D)
             else:
                 # reduce-scatter of the partial sums, then the mean's division by the bucket's
                 # key count over all GPUs (a no-op unless distributed + mean + world > 1)
@@ -877,7 +1097,74 @@ class Model:
             if train:
                 E = E.detach().requires_grad_(True)
                 leaves[name] = E
+
+                def finish(E=E):
+                    g = E.grad
+                    if os.environ.get("HCTR_DEBUG_LOSS_CURVE"):
+                        self._last_emb_grad = g.detach().clone()
+                    if localized and W > 1:
+                        g = backward_reorder(g.contiguous(), bpg, S, D, W)
+                    top = ex["train"].backward(g.contiguous())
+                    h.backward(top.contiguous())
+                    h.update_params()
+                after.append(finish)
             tensors[name] = E
+            return
+        if st["mode"] != "rows":
+            # unique-row payload: every distinct row once per destination, per-row gradient sums
+            # back; the next batch's index stage + plan + count exchange on a side stream
+            ux = st["ux"]
+            ux.forward_begin(ro, keys)
+            nk = nxt["sparse"][se.bottom_name] if (nxt is not None and self._inter) else None
+
+            def resolve():
+                if st["indexed"]:
+                    rows, row_of = ux.forward_finish(indexed=True)
+                    E = _IndexedEmb(rows, row_of, ux.backward_begin)
+                else:
+                    E = ux.forward_finish().detach().requires_grad_(True)
+                    E.register_hook(lambda g: ux.backward_begin(g))
+                if nk is not None:  # after this batch's row all-to-all: the communicator serves
+                    ux.prefetch(*nk)  # the critical-path transfer first
+                return E
+            tensors[name] = _Pending(resolve)
+            after.append(ux.backward_finish)
+            return
+        # rows payload, asynchronous: the reference's all-to-all of pooled vectors / top gradients
+        pooled = h.forward(True, ro, keys)
+        e = ex["train"]
+        recv, work = e.forward_async(pooled)
+        top_grad = torch.empty_like(pooled)
+        sent = {}
+
+        def on_grad(g):
+            # inside backward, right behind the consumer's backward kernel; must not keep `g`
+            gsend = backward_reorder(g.contiguous(), bpg, S, D, W)
+            sent["work"] = e.backward_async(gsend, top_grad.view(-1))
+            sent["buf"] = gsend  # stays alive until the collective has read it
+
+        def resolve():
+            if work is not None:
+                work.wait()
+            E = forward_reorder(recv, bpg, S, D, W).requires_grad_(True)
+            E.register_hook(on_grad)
+            return E
+
+        def finish():
+            if sent.get("work") is not None:
+                sent["work"].wait()
+            sent.clear()
+            h.backward(top_grad)
+            h.update_params()
+        tensors[name] = _Pending(resolve)
+        after.append(finish)
+
+    def _run_batch(self, batch, train: bool, nxt=None):
+        tensors = _Tensors({self.input.dense_name: batch["dense"],
+                            self.input.label_name: batch["label"]})
+        leaves, after = {}, []
+        for name in self._emb:
+            self._emb_forward(name, batch, nxt, train, tensors, leaves, after)
         for i, rt in enumerate(self._ebc):
             E = self._ebc_forward(rt, batch, train)
             if train:
@@ -906,51 +1193,71 @@ class Model:
             if cfg.top_name and (id(cfg), 0) in tensors:
                 tensors[cfg.top_name] = torch.cat(
                     [tensors.pop((id(cfg), l)) for l in range(len(cfg.lookups))], dim=1)
-        logit = self._forward_dense(tensors, train)
         label = batch["label"].float()
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
-        if not train:
-            return loss, torch.sigmoid(logit)
         # the logit gradient is (sigmoid - y) * scaler / batch_per_gpu / total_gpu_count
         # (BinaryCrossEntropy_Kernel, R/HugeCTR/src/loss.cu:242-249): every gradient below --
         # the embeddings' top gradients included -- is a share of the GLOBAL-batch mean, and the
         # dense all-reduce is a plain sum
-        (loss * (self.solver.scaler / self.world)).backward()
-        for name, (se, p, h, ex, localized) in self._emb.items():
-            g = leaves[name].grad
-            if os.environ.get("HCTR_DEBUG_LOSS_CURVE"):
-                self._last_emb_grad = g.detach().clone()
-            if localized:
-                if self.world > 1:
-                    g = backward_reorder(g.contiguous(), self.bpg, p.slot_num,
-                                         se.embedding_vec_size, self.world)
-                top = ex["train"].backward(g.contiguous())
-            else:
-                top = ex["train"].backward(g.contiguous())
-            h.backward(top.contiguous())
-            h.update_params()
+        gscale = self.solver.scaler / (max(self.bpg, 1) * self.world)
+        head = (label, gscale) if (train and self._head_layer is not None and
+                                   label.shape[1] == 1) else None
+        logit, loss = self._forward_dense(tensors, train, head)
+        if not train:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
+            return loss, torch.sigmoid(logit)
+        if loss is not None:        # logit layer + loss + their backward already done in one pass
+            loss.backward()
+        elif logit.is_cuda and label.shape == logit.shape:
+            # fused BCE forward + logit gradient (two launches instead of ~20)
+            lg = tensors[self._loss_layer.bottom_names[0]]
+            loss, dlogit = bce_with_logits(lg, label, gscale)
+            lg.backward(dlogit)
+        else:
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
+            (loss * (self.solver.scaler / self.world)).backward()
+        for fin in after:
+            fin()
         for i, rt in enumerate(self._ebc):
             rt["train"].lr = self._lr
             rt["train"].backward_and_update(leaves[("ebc", i)].grad.contiguous())
-        if self._dense_opt is not None and getattr(self, "_dense_frozen", False):
+        self._dense_step()
+        return loss.detach().reshape(()), None
+
+    def _dense_step(self):
+        frozen = getattr(self, "_dense_frozen", False)
+        if self._flat_mlps:
+            if frozen:
+                return
+            for m in self._flat_mlps:  # gradients are shares of the global-batch mean: plain sum
+                if self.world > 1:
+                    _all_reduce(m.flat_g)
+                m.sgd_step(self._lr, 1.0 / self.solver.scaler)
+            return
+        if self._dense_opt is None:
+            return
+        if frozen:
             self._dense_opt.zero_grad(set_to_none=True)
-        elif self._dense_opt is not None:
-            if self.world > 1:
-                for q in self._dense_params:
-                    if q.grad is not None:
-                        _all_reduce(q.grad)
-            if self.solver.scaler != 1.0:  # one multi-tensor launch, not one per parameter
-                grads = [q.grad for q in self._dense_params if q.grad is not None]
-                if grads:
-                    torch._foreach_div_(grads, self.solver.scaler)
-            self._dense_opt.step()
-            self._dense_opt.zero_grad(set_to_none=True)
-            for m in self._mods.values():
-                if isinstance(m, FusedMLP):
-                    m.refresh_shadow()
-        return loss, None
+            return
+        if self.world > 1:
+            for q in self._dense_params:
+                if q.grad is not None:
+                    _all_reduce(q.grad)
+        if self.solver.scaler != 1.0:  # one multi-tensor launch, not one per parameter
+            grads = [q.grad for q in self._dense_params if q.grad is not None]
+            if grads:
+                torch._foreach_div_(grads, self.solver.scaler)
+        self._dense_opt.step()
+        self._dense_opt.zero_grad(set_to_none=True)
+        for m in self._mods.values():
+            if isinstance(m, FusedMLP):
+                m.refresh_shadow()
 
     def check_overflow(self, blocking: bool = True):
+        if blocking:
+            self._drain_prefetch()
+        return self._check_overflow(blocking)
+
+    def _check_overflow(self, blocking: bool = True):
         """Model::check_overflow (R/HugeCTR/src/pybind/model.cpp:1088: called by every train()):
         raises when an embedding saw more distinct keys than max_vocabulary_size_per_gpu.  train()
         uses the non-blocking form (the flag of an earlier iteration, no host sync on the path);
@@ -960,19 +1267,36 @@ class Model:
 
     def train(self) -> bool:
         assert self._compiled
-        batch = self.reader.next_batch(train=True)
+        for st in self._xstate.values():
+            if st["select"] is not None:
+                self._select_exchange(st)
+        batch, self._lookahead = self._lookahead, None
+        if batch is None:
+            batch = self.reader.next_batch(train=True)
         if batch is None:
             return False
+        nxt = None
+        if self._inter and any(st["mode"] != "rows" for st in self._xstate.values()):
+            # inter-iteration overlap: the next batch's keys are needed a step early
+            nxt = self._lookahead = self.reader.next_batch(train=True)
         self.check_overflow(blocking=False)
-        loss, _ = self._run_batch(batch, True)
+        loss, _ = self._run_batch(batch, True, nxt)
         self._loss_t = loss.detach()
         self._iter += 1
         return True
+
+    def _drain_prefetch(self):
+        """an index stage running ahead on a side stream must be through before anything else
+        touches the embedding (evaluation, checkpoints, overflow checks)"""
+        for st in getattr(self, "_xstate", {}).values():
+            if st["ux"] is not None:
+                st["ux"].drain()
 
     def eval(self) -> bool:
         batch = self.reader.next_batch(train=False)
         if batch is None:
             return False
+        self._drain_prefetch()
         if not getattr(self, "_eval_buf", None):
             self.check_overflow()
         with torch.no_grad():
@@ -1103,6 +1427,7 @@ class Model:
 
     # -- checkpoints: directory layout of the reference (SURVEY §5 "Checkpoint / resume") ----------
     def save_params_to_files(self, prefix: str, iteration: int = 0):
+        self._drain_prefetch()
         self.check_overflow()
         for i, (name, (se, p, h, _, localized)) in enumerate(self._emb.items()):
             keys, slot, vec = h.dump_parameters()

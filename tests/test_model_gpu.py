@@ -765,3 +765,128 @@ def test_two_ranks_train_like_one_rank(tmp_path, kind, combiner):
     vv = np.fromfile(ck / "emb_vector", "<f4").reshape(-1, 16)
     assert kk.size == k2.size and (np.sort(kk) == k2[o2]).all()
     assert (vv[np.argsort(kk)] == v2[o2]).all()
+
+
+# ---- the N > 1 training step of the product: solver.train_intra / inter_iteration_overlap and the
+# exchange payload (R/HugeCTR/src/pybind/model_pipeline.cpp:299-346) ------------
+def _overlap_model(hugectr, folder, world, overlap, mixed):
+    solver = hugectr.CreateSolver(batchsize=256, batchsize_eval=256, lr=0.05,
+                                  vvgpu=[list(range(world))], i64_input_key=True,
+                                  max_eval_batches=1, use_mixed_precision=mixed,
+                                  scaler=128.0 if mixed else 1.0,
+                                  train_intra_iteration_overlap=overlap,
+                                  train_inter_iteration_overlap=overlap)
+    reader = hugectr.DataReaderParams(
+        data_reader_type=hugectr.DataReaderType_t.Parquet,
+        source=[os.path.join(folder, "train", "_file_list.txt")],
+        eval_source=os.path.join(folder, "val", "_file_list.txt"), slot_size_array=SIZES,
+        check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.SGD,
+                                  update_type=hugectr.Update_t.Local, atomic_update=False)
+    model = hugectr.Model(solver, reader, opt)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam("data1", 1, True, 26)]))
+    D, T, A = hugectr.DenseLayer, hugectr.Layer_t, hugectr.Activation_t
+    model.add(hugectr.SparseEmbedding(
+        embedding_type=hugectr.Embedding_t.LocalizedSlotSparseEmbeddingHash,
+        slot_size_array=SIZES, embedding_vec_size=32, combiner="sum",
+        sparse_embedding_name="emb", bottom_name="data1", optimizer=opt))
+    model.add(D(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"], num_outputs=[64, 32],
+                act_type=A.Relu))
+    model.add(D(layer_type=T.Interaction, bottom_names=["mlp1", "emb"], top_names=["inter"]))
+    model.add(D(layer_type=T.MLP, bottom_names=["inter"], top_names=["mlp2"],
+                num_outputs=[128, 64, 1], activations=[A.Relu, A.Relu, A.Non]))
+    model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+                top_names=["loss"]))
+    model.compile()
+    model.load_sparse_weights([os.path.join(folder, "init_sparse")])
+    return model
+
+
+def _overlap_worker(rank, world, port, folder, overlap, exchange, mixed, steps, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    if exchange:
+        os.environ["HCTR_EXCHANGE"] = exchange
+    else:
+        os.environ.pop("HCTR_EXCHANGE", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hugectr_amd.hugectr as hugectr
+        torch.manual_seed(5)
+        model = _overlap_model(hugectr, folder, world, overlap, mixed)
+        losses, k, v, dense = _parity_run(model, steps)
+        model._eval_buf = []
+        model.eval()  # (drains an index stage that ran ahead)
+        auc = dict(model.get_eval_metrics())["AUC"]
+        rep = model.exchange_report()["emb"]
+        ret[rank] = ("ok", losses, k, v, dense, rep, auc)
+    except Exception as ex:
+        import traceback
+        ret[rank] = ("".join(traceback.format_exception(type(ex), ex, ex.__traceback__)),)
+    finally:
+        dist.destroy_process_group()
+
+
+def _overlap_run(tmp_path, overlap, exchange, mixed, steps, salt):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + os.getpid() % 2000 + 17 + salt
+    procs = [ctx.Process(target=_overlap_worker,
+                         args=(r, 2, port, str(tmp_path), overlap, exchange, mixed, steps, ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r in range(2):
+        assert ret.get(r) is not None and ret[r][0] == "ok", ret.get(r)
+    return [ret[0], ret[1]]
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_two_ranks_overlap_schedule(tmp_path, mixed):
+    """2 ranks (gloo, this one GPU), the DLRM graph: (a) train_intra/inter_iteration_overlap off =
+    blocking collectives in line; (b) overlap on with the rows payload (asynchronous all-to-all
+    under the bottom MLP, gradient all-to-all from inside backward) must equal (a) BIT FOR BIT;
+    (c) the unique-row payload (distinct rows once per destination, per-row gradient sums, next
+    batch's index stage on a side stream; with 16-bit vectors the Interaction reads the rows
+    through the index table) agrees to fp32 rounding; (d) HCTR_EXCHANGE=auto runs its selection
+    over real training steps, settles on one payload on both ranks and trains the same model."""
+    import hugectr_amd.hugectr as hugectr
+    from numpy.testing import assert_allclose
+    _gen(tmp_path, hugectr, n_train=8192, n_eval=512)
+    rng = np.random.default_rng(3)
+    V = sum(SIZES)
+    d = tmp_path / "init_sparse"
+    d.mkdir()
+    np.arange(V, dtype="<i8").tofile(d / "key")
+    np.repeat(np.arange(26), SIZES).astype("<u8").tofile(d / "slot_id")
+    (rng.standard_normal((V, 32)) * 0.1).astype("<f4").tofile(d / "emb_vector")
+    steps = 20
+    a = _overlap_run(tmp_path, False, None, mixed, steps, 0)
+    b = _overlap_run(tmp_path, True, "rows", mixed, steps, 1)
+    for r in range(2):
+        assert a[r][5]["payload"] == "rows" and not a[r][5]["intra_iteration_overlap"]
+        assert b[r][5]["payload"] == "rows" and b[r][5]["intra_iteration_overlap"]
+        assert a[r][1] == b[r][1], "losses differ between overlap off and on"
+        assert (a[r][2] == b[r][2]).all() and (a[r][3] == b[r][3]).all()
+        assert (a[r][4] == b[r][4]).all()
+    tol = dict(rtol=2e-2, atol=2e-3) if mixed else dict(rtol=2e-4, atol=2e-6)
+    for exchange, salt in (("unique", 2), ("auto", 3)):
+        c = _overlap_run(tmp_path, True, exchange, mixed, steps, salt)
+        assert c[0][5]["payload"] == c[1][5]["payload"]
+        if exchange == "unique":
+            assert c[0][5]["payload"] == "unique" and c[0][5]["distinct_rows_out"] > 0
+        else:
+            assert c[0][5]["payload"] in ("rows", "unique")
+            assert c[0][5]["selection_ms_per_step"] is not None
+        for r in range(2):
+            assert_allclose(c[r][1], a[r][1], rtol=5e-3 if mixed else 2e-5)
+            o1, o2 = np.argsort(a[r][2]), np.argsort(c[r][2])
+            assert (a[r][2][o1] == c[r][2][o2]).all()
+            assert_allclose(c[r][3][o2], a[r][3][o1], **tol)
+            assert_allclose(c[r][4], a[r][4], **tol)
+            assert abs(c[r][6] - a[r][6]) < 2e-2
