@@ -273,11 +273,23 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
 
     # ---- roofline of the gather+pool kernel (DESIGN.md section 5 / SURVEY 8d) -------------------
     nnz_g = B * spr  # one-hot: one key per (sample, slot on this rank)
-    alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz
+    fused = bool(xrep.get("gather_fused_into_interaction"))
     U = sum(uniq) / max(len(uniq), 1)
-    # compulsory = what must cross the HBM interface even with a perfect cache: every key and row
-    # index once, every DISTINCT row once, every output element once
-    comp_bytes = nnz_g * 8 + nnz_g * 8 + U * D * 4 + B * spr * D * esz
+    n_ins = S + 1
+    out_len = D + n_ins * (n_ins - 1) // 2 + 1
+    if fused:
+        # one GPU: the gather rides in the interaction kernel (hctr_emb_forward_interaction).  Per
+        # launch: row index + fp32 row per key, the bottom-MLP row, the pooled vectors written
+        # once, the interaction output -- SURVEY 8(d)'s gather bytes (without the key read, which
+        # is the index stage's) + the interaction's own input / output, minus the pooled re-read
+        io = Bl * D * esz + Bl * out_len * esz
+        alg_bytes = nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz + io
+        comp_bytes = nnz_g * 8 + U * D * 4 + B * spr * D * esz + io
+    else:
+        alg_bytes = nnz_g * 8 + nnz_g * 8 + nnz_g * D * 4 + B * spr * D * esz
+        # compulsory = what must cross the HBM interface even with a perfect cache: every key and
+        # row index once, every DISTINCT row once, every output element once
+        comp_bytes = nnz_g * 8 + nnz_g * 8 + U * D * 4 + B * spr * D * esz
     pool_ms, pool_n = prof["gather_pool"]
     pool_s = pool_ms / max(pool_n, 1) * 1e-3
     achieved = alg_bytes / pool_s / 1e9 if pool_ms > 0 else 0.0
@@ -293,7 +305,8 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
             try:
                 j = json.load(open(pmc_path))
                 if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
-                    pmc = j["kernels"]["pool_vec4_kernel"]["hbm_bytes_per_launch"]
+                    pmc = j["kernels"]["interaction_fwd16_gather_kernel" if fused
+                                       else "pool_vec4_kernel"]["hbm_bytes_per_launch"]
                     pmc_src = os.path.relpath(pmc_path, ROOT) + (
                         f" @ {j['commit']}" if j.get("commit") else "")
                     break
@@ -342,7 +355,11 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                    "new_keys_per_step": new_keys, "distinct_rows_per_batch": U,
                    "final_loss": m.get_current_loss(),
                    "dense_gemm_selection": getattr(m, "_gemm_selection", "off")},
-        "roofline": {"bound": "hbm", "kernel": "pool_vec4_kernel (gather + intra-slot pooling)",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("interaction_fwd16_gather_kernel (gather + pooling fused into the "
+                                "dot interaction: table rows -> LDS tile -> MFMA, pooled vectors "
+                                "written once)" if fused else
+                                "pool_vec4_kernel (gather + intra-slot pooling)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
                      "traffic_source": pmc_src,
@@ -693,6 +710,17 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
         ebc.backward_and_update(grad)
     both_us = timed(train)
     nnz = B * sum(hot)
+    pmc, pmc_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic_ebc.json")
+    if os.path.exists(pmc_path) and B == 65536 and D == 128 and abs(alpha - 1.1) < 1e-9:
+        try:  # the gather kernel of this leg (rocprofv3 --pmc passes, tools/measure_round.sh)
+            j = json.load(open(pmc_path))
+            kern = ("pool_ptrs_vec4_kernel" if dynamic else
+                    "pool_flat_kernel" if kind == "multi_hot" else "pool_vec4_kernel")
+            pmc = j["kernels"][kern]["hbm_bytes_per_launch"]
+            pmc_src = f"{os.path.relpath(pmc_path, ROOT)} [{kern}] @ {j.get('commit', '?')}"
+        except Exception:
+            pmc = None
     # dynamic tables: + the 16-byte hash probe per key in place of the static index arithmetic
     alg = nnz * (8 + 8 + D * 4) + B * 26 * D * 2 + (nnz * 16 if dynamic else 0)
     ach = alg / (fwd_us * 1e-6) / 1e9
@@ -712,7 +740,11 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
         "roofline": {"bound": "hbm", "kernel": "whole forward (key -> row pass + gather/pool): a "
                                                "lower bound on the gather kernel's own rate",
                      "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": pmc_src,
+                     # duplicates counted: power-law keys repeat rows, which L2 /
+                     # Infinity Cache serve -- `traffic` (PMC counters of the gather kernel) over
+                     # the forward's time is what crossed the HBM interface
+                     "hbm_traffic_gbps": (pmc / (fwd_us * 1e-6) / 1e9) if pmc else None,
                      "algorithmic_bytes_per_launch": alg},
     }
 

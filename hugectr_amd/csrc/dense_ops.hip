@@ -293,6 +293,139 @@ __global__ void __launch_bounds__(64, 2)
   }
 }
 
+// ---- gather fused into the interaction (one GPU, one key per bucket, sum combiner) ---------------
+// The pooled vector of a one-hot bucket IS its table row (rounded to the 16-bit type), and the
+// interaction stages each sample's rows in LDS anyway: this kernel reads the fp32 table rows
+// through value_index straight into the tile, writes the pooled [batch][n_emb][W] vectors once (the
+// backward and the top-gradient layout need them) and runs the same MFMA chain and output stage
+// as interaction_fwd16_kernel -- bit-identical to pool_vec4_kernel + interaction_fwd16_kernel,
+// without the pass that re-reads the pooled vectors (B * n_emb * W * 2 bytes).
+// A missing row (kInvalidIndex: evaluation miss / full table) pools as zeros.
+template <int W, int NPRE>
+__device__ __forceinline__ void load_gather_idx(uint64_t (&idx)[NPRE],
+                                                const uint64_t* __restrict__ value_index,
+                                                size_t b, int n_emb, int n_vec, int lane) {
+  constexpr int W8 = W / 8;
+  const uint64_t* vi = value_index + b * (size_t)n_emb;
+#pragma unroll
+  for (int q = 0; q < NPRE; q++) {
+    int i = lane + 64 * q;
+    i = i < n_vec ? i : 0;
+    const int row = i / W8;
+    idx[q] = vi[row > 0 ? row - 1 : 0];
+  }
+}
+
+template <int W, int NPRE>
+__device__ __forceinline__ void load_gather_rows(f32x4 (&lo)[NPRE], f32x4 (&hi)[NPRE],
+                                                 const uint64_t (&idx)[NPRE],
+                                                 const unsigned short* __restrict__ mlp,
+                                                 const float* __restrict__ table, size_t b,
+                                                 int n_vec, int lane) {
+  constexpr int W8 = W / 8;
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(mlp + b * W);  // (16 bytes = 8 halves)
+#pragma unroll
+  for (int q = 0; q < NPRE; q++) {
+    int i = lane + 64 * q;
+    i = i < n_vec ? i : 0;
+    const int row = i / W8, c8 = i % W8;
+    const uint64_t r = idx[q] != kInvalidIndex ? idx[q] : 0ull;  // always a legal read
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(table + r * (uint64_t)W + c8 * 8);
+    lo[q] = (row == 0) ? m4[c8] : t4[0];
+    hi[q] = (row == 0) ? m4[c8] : t4[1];
+  }
+}
+
+template <int W, bool BF>
+__global__ void __launch_bounds__(64, 2)
+    interaction_fwd16_gather_kernel(size_t batch, int n_emb,
+                                    const unsigned short* __restrict__ mlp,
+                                    const float* __restrict__ table,
+                                    const uint64_t* __restrict__ value_index,
+                                    unsigned short* __restrict__ pooled,
+                                    unsigned short* __restrict__ out, int out_len) {
+  using C = InterCfg16<W>;
+  using H = H16<BF>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  const int lane = threadIdx.x;
+  const int n_ins = n_emb + 1;
+  unsigned short* xt = smem16;
+  unsigned short* stage = smem16 + (n_ins + 1) * C::LD;
+  constexpr int W8 = W / 8;
+  constexpr int NPRE = (32 * W8 + 63) / 64;
+  const int n_vec = n_ins * W8;
+  for (int i = lane; i < C::LD; i += 64) xt[n_ins * C::LD + i] = 0;  // zero row
+
+  const int r = lane & 31, h = lane >> 5;
+  const int rr = r < n_ins ? r : n_ins;
+  f32x4 lo[NPRE], hi[NPRE];
+  uint64_t idx[NPRE], idx_nxt[NPRE];
+  size_t b = blockIdx.x;
+  const size_t last = batch - 1;
+  // row indices run one sample ahead of the rows, the rows one sample ahead of the MFMA chain
+  load_gather_idx<W, NPRE>(idx, value_index, b < batch ? b : last, n_emb, n_vec, lane);
+  load_gather_rows<W, NPRE>(lo, hi, idx, mlp, table, b < batch ? b : last, n_vec, lane);
+  {
+    const size_t nb = b + gridDim.x;
+    load_gather_idx<W, NPRE>(idx_nxt, value_index, nb < batch ? nb : last, n_emb, n_vec, lane);
+  }
+  for (; b < batch; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) {
+      const int i = lane + 64 * q;
+      if (i < n_vec) {
+        const int row = i / W8, c8 = i % W8;
+        u32x4 v;
+        if (row == 0) {
+          v = *reinterpret_cast<const u32x4*>(&lo[q]);
+        } else {
+          const bool live = idx[q] != kInvalidIndex;
+          float f[8] = {lo[q][0], lo[q][1], lo[q][2], lo[q][3], hi[q][0], hi[q][1], hi[q][2], hi[q][3]};
+          unsigned short u[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) u[k] = H::from_f32(0.f + (live ? f[k] : 0.f));
+          v[0] = (uint32_t)u[0] | ((uint32_t)u[1] << 16);
+          v[1] = (uint32_t)u[2] | ((uint32_t)u[3] << 16);
+          v[2] = (uint32_t)u[4] | ((uint32_t)u[5] << 16);
+          v[3] = (uint32_t)u[6] | ((uint32_t)u[7] << 16);
+          *reinterpret_cast<u32x4*>(pooled + (b * (size_t)n_emb + (row - 1)) * W + c8 * 8) = v;
+        }
+        *reinterpret_cast<u32x4*>(xt + row * C::LD + c8 * 8) = v;
+      }
+    }
+    __syncthreads();
+    const size_t nb = b + gridDim.x, nb2 = nb + gridDim.x;
+#pragma unroll
+    for (int q = 0; q < NPRE; q++) idx[q] = idx_nxt[q];
+    if (nb < batch) load_gather_rows<W, NPRE>(lo, hi, idx, mlp, table, nb, n_vec, lane);
+    load_gather_idx<W, NPRE>(idx_nxt, value_index, nb2 < batch ? nb2 : last, n_emb, n_vec, lane);
+
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned short* xr = xt + rr * C::LD + h * (W / 2);
+#pragma unroll
+    for (int t = 0; t < W / 16; t++) {
+      const typename H::vec8 f = *reinterpret_cast<const typename H::vec8*>(xr + t * 8);
+      acc = H::mfma(f, f, acc);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row > r && row < n_ins) stage[W + tri_index(row, r)] = H::from_f32(acc[reg]);
+    }
+    for (int i = lane; i < W; i += 64) stage[i] = xt[i];
+    if (lane == 0) stage[out_len - 1] = 0;
+    __syncthreads();
+    unsigned short* o = out + b * (size_t)out_len;
+    if ((out_len & 7) == 0) {
+      for (int i = lane; i < out_len / 8; i += 64)
+        reinterpret_cast<u32x4*>(o)[i] = reinterpret_cast<const u32x4*>(stage)[i];
+    } else {
+      for (int i = lane; i < out_len; i += 64) o[i] = stage[i];
+    }
+    __syncthreads();
+  }
+}
+
 template <int W, bool BF>
 __global__ void __launch_bounds__(64, 2)
     interaction_bwd16_kernel(size_t batch, int n_emb, const unsigned short* __restrict__ mlp,
@@ -1640,6 +1773,51 @@ int hctr_interaction_fwd_indexed(size_t batch, int n_emb, int width, const void*
                                  hctr_stream_t stream) {
   HCTR_REQUIRE(row_of, "null pointer");
   return interaction_fwd_impl(batch, n_emb, width, mlp, rows, row_of, out, dtype, stream);
+}
+
+int hctr_interaction_fwd_gather(size_t batch, int n_emb, int width, const void* mlp,
+                                const float* table, const uint64_t* value_index, void* pooled,
+                                void* out, int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(n_emb >= 1 && n_emb <= 31, "interaction_fwd_gather: 1 .. 31 embeddings");
+  HCTR_REQUIRE(dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16,
+               "interaction_fwd_gather: 16-bit vectors (fp16 / bf16)");
+  HCTR_REQUIRE(width == 128 || width == 64 || width == 32 || width == 16,
+               "interaction_fwd_gather: width 16 / 32 / 64 / 128");
+  if (batch == 0) return HCTR_OK;
+  HCTR_REQUIRE(mlp && table && value_index && pooled && out, "null pointer");
+  HCTR_REQUIRE(reinterpret_cast<uintptr_t>(mlp) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(table) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(pooled) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(out) % 16 == 0,
+               "interaction_fwd_gather: 16-byte aligned buffers");
+  hipStream_t s = as_stream(stream);
+  const int n_ins = n_emb + 1;
+  const int out_len = width + n_ins * (n_ins - 1) / 2 + 1;
+  const int stage_len = (out_len + 7) & ~7;
+  const size_t gmax = (size_t)256 * (size_t)inter_waves_per_cu(0);
+  const int grid1 = (int)(batch < gmax ? batch : gmax);
+  const bool bf = dtype == HCTR_EMB_BF16;
+#define HCTR_IFG16(W_)                                                                          \
+  {                                                                                             \
+    const size_t lds = (size_t)((n_ins + 1) * InterCfg16<W_>::LD + stage_len) * 2;              \
+    if (bf)                                                                                     \
+      hipLaunchKernelGGL((interaction_fwd16_gather_kernel<W_, true>), dim3(grid1), dim3(64),    \
+                         lds, s, batch, n_emb, (const unsigned short*)mlp, table, value_index,  \
+                         (unsigned short*)pooled, (unsigned short*)out, out_len);               \
+    else                                                                                        \
+      hipLaunchKernelGGL((interaction_fwd16_gather_kernel<W_, false>), dim3(grid1), dim3(64),   \
+                         lds, s, batch, n_emb, (const unsigned short*)mlp, table, value_index,  \
+                         (unsigned short*)pooled, (unsigned short*)out, out_len);               \
+  }
+  switch (width) {
+    case 128: HCTR_IFG16(128) break;
+    case 64: HCTR_IFG16(64) break;
+    case 32: HCTR_IFG16(32) break;
+    default: HCTR_IFG16(16) break;
+  }
+#undef HCTR_IFG16
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
 }
 
 static int interaction_bwd_impl(size_t batch, int n_emb, int width, const void* mlp,

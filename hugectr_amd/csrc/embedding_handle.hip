@@ -148,31 +148,6 @@ __global__ void __launch_bounds__(kBlock) fill_kernel(T* p, size_t n, T v) {
     p[i] = v;
 }
 
-// slot id of rows inserted by the last get_insert (store_slot_id_kernel semantics,
-// store_slot_id_functor.cu:26-48, restricted to the rows that are new -- older rows keep theirs)
-template <typename K>
-__global__ void __launch_bounds__(kBlock)
-    store_new_slot_ids_kernel(const uint64_t* __restrict__ d_new_count,
-                              const uint64_t* __restrict__ new_positions,
-                              const uint64_t* __restrict__ value_index,
-                              const K* __restrict__ ro, size_t buckets, int spg, int rank,
-                              int world, int localized, uint64_t* __restrict__ slot_id) {
-  const uint64_t n_new = *d_new_count;
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_new;
-       i += (size_t)gridDim.x * kBlock) {
-    const uint64_t pos = new_positions[i];
-    // bucket u with ro[u] <= pos < ro[u+1]
-    size_t lo = 0, hi = buckets;
-    while (lo < hi) {
-      size_t mid = (lo + hi) >> 1;
-      if ((uint64_t)ro[mid + 1] <= pos) lo = mid + 1;
-      else hi = mid;
-    }
-    const int j = (int)(lo % spg);
-    const int sid = localized ? rank + j * world : j;
-    slot_id[value_index[pos]] = (uint64_t)sid;
-  }
-}
 
 __global__ void gather_rows_kernel(const uint64_t* __restrict__ rows, size_t n, int D,
                                    const float* __restrict__ table, float* __restrict__ out,
@@ -281,13 +256,18 @@ struct hctr_embedding {
   bool nnz_pending = false;
   // host-side upper bound of the rows handed out: the exact counter of a past batch (async copy
   // + event, never waited on) plus the keys of the batches enqueued since
-  uint64_t* h_rows = nullptr;  // pinned
-  hipEvent_t rows_event = nullptr;
-  bool rows_pending = false, rows_valid = false;
-  size_t rows_known = 0, added_since_known = 0, added_since_snapshot = 0;
+  // The index stage's finish kernel POSTS {rows handed out, batch sequence number} and the
+  // hash table's error flags to these pinned words (no copy launch, no event): h_rows[0] = row
+  // counter after batch h_rows[1].  The host reads the sequence number first, so the counter it
+  // pairs with it is never older; cum_keys[seq % kSeqRing] = keys enqueued through batch seq.
+  // NOT thread-safe across streams: one stream order per handle (the index stage running ahead
+  // on a side stream is ordered against the main stream by the caller's events).
+  uint64_t* h_rows = nullptr;  // pinned [2]
+  static constexpr int kSeqRing = 64;
+  uint64_t seq = 0, min_valid_seq = 1, cum_total = 0;
+  uint64_t cum_keys[kSeqRing] = {0};
   uint32_t* h_err = nullptr;  // pinned copy of the hash table's error flags (poll_overflow)
-  hipEvent_t err_event = nullptr;
-  bool err_pending = false;
+  uint32_t flip = 0;          // parity of the training batch's one-hot flag (tb.one_hot[2])
   size_t last_exact_nnz = 0;     // world > 1: exact live nnz of the previous train batch
   // side-stream sort right after the index stage: on by default when world > 1 (it then runs
   // inside the all-to-all wait); on one GPU it would only share the chip with the dense tower --
@@ -323,8 +303,6 @@ int free_all(hctr_embedding* e) {
   if (e->nnz_event) (void)hipEventDestroy(e->nnz_event);
   if (e->h_err) (void)hipHostFree(e->h_err);
   if (e->h_rows) (void)hipHostFree(e->h_rows);
-  if (e->rows_event) (void)hipEventDestroy(e->rows_event);
-  if (e->err_event) (void)hipEventDestroy(e->err_event);
   return HCTR_OK;
 }
 
@@ -367,18 +345,24 @@ int exclusive_scan_lens(hctr_embedding* e, void* ro_dst, size_t n, hipStream_t s
 template <typename K>
 int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, const K* ro_in,
                 const K* keys_in, size_t nnz, const K** ro_out, const K** keys_out,
-                size_t* buckets_out, hipStream_t s) {
+                size_t* buckets_out, hipStream_t s, uint32_t* one_hot, bool fused_train) {
   const int world = e->p.world, rank = e->p.rank, S = (int)e->p.slot_num;
   const bool localized = e->p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH;
   const size_t buckets = batch * e->buckets_per_sample();
   *buckets_out = buckets;
-  HCTR_HIP(hipMemsetAsync(bb.one_hot, 1, sizeof(uint32_t), s));  // non-zero = "one-hot so far"
+  // training batches: the flag of THIS batch was preset by the previous index stage's finish
+  // kernel (two words, alternating); evaluation keeps the memset
+  if (!fused_train)
+    HCTR_HIP(hipMemsetAsync(one_hot, 1, sizeof(uint32_t), s));  // non-zero = "one-hot so far"
   if (world == 1) {
     // nothing to filter: keep a private copy of the row offsets (update_params needs them after
     // the caller's buffers may have been recycled); keys are consumed by the hash stage now.
-    hipLaunchKernelGGL(copy_offsets_check_kernel<K>, dim3(grid_for(buckets + 1, kBlock, 1024)),
-                       dim3(kBlock), 0, s, ro_in, buckets + 1, (K*)bb.ro, bb.one_hot);
-    HCTR_LAUNCH_CHECK();
+    // Training: the copy + one-hot check ride in the probe kernel (IndexExtras), no launch here.
+    if (!fused_train) {
+      hipLaunchKernelGGL(copy_offsets_check_kernel<K>, dim3(grid_for(buckets + 1, kBlock, 1024)),
+                         dim3(kBlock), 0, s, ro_in, buckets + 1, (K*)bb.ro, one_hot);
+      HCTR_LAUNCH_CHECK();
+    }
     *ro_out = (const K*)bb.ro;
     *keys_out = keys_in;
     return HCTR_OK;
@@ -392,7 +376,7 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
   (void)nnz;
   if (localized) {
     hipLaunchKernelGGL(localized_lens_kernel<K>, dim3(grid_for(buckets, kBlock)), dim3(kBlock), 0,
-                       s, ro_in, batch, S, e->spg, rank, world, (K*)e->lens, bb.one_hot);
+                       s, ro_in, batch, S, e->spg, rank, world, (K*)e->lens, one_hot);
     HCTR_LAUNCH_CHECK();
     HCTR_TRY(exclusive_scan_lens<K>(e, bb.ro, buckets, s));
     hipLaunchKernelGGL(localized_copy_keys_kernel<K>, dim3(grid_for(buckets, kBlock)),
@@ -401,7 +385,7 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
     HCTR_LAUNCH_CHECK();
   } else {
     hipLaunchKernelGGL(distributed_lens_kernel<K>, dim3(grid_for(buckets, kBlock)), dim3(kBlock),
-                       0, s, ro_in, keys_in, buckets, rank, world, (K*)e->lens, bb.one_hot);
+                       0, s, ro_in, keys_in, buckets, rank, world, (K*)e->lens, one_hot);
     HCTR_LAUNCH_CHECK();
     HCTR_TRY(exclusive_scan_lens<K>(e, bb.ro, buckets, s));
     hipLaunchKernelGGL(distributed_copy_keys_kernel<K>, dim3(grid_for(buckets, kBlock)),
@@ -422,8 +406,23 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   size_t buckets = 0;
   hctr_embedding::BatchBufs& bb = is_train ? e->tb : e->eb;
   HCTR_REQUIRE(bb.ro != nullptr, "forward: batch size 0 configured for this mode");
-  HCTR_TRY(filter_keys<K>(e, bb, batch, ro_in, keys_in, nnz, &ro, &keys, &buckets, s));
-  if (buckets == 0) return HCTR_OK;
+  // the training index stage is two launches: its probe kernel also copies / checks the row
+  // offsets (world == 1), its finish kernel presets the next batch's one-hot flag and posts the
+  // row counter + error flags to pinned host words
+  const bool fused_train = is_train != 0 && nnz > 0;
+  uint32_t* one_hot = bb.one_hot;
+  uint32_t* one_hot_next = nullptr;
+  if (fused_train) {
+    one_hot = bb.one_hot + (e->flip & 1u);
+    one_hot_next = bb.one_hot + ((e->flip + 1u) & 1u);
+    e->flip++;
+  }
+  HCTR_TRY(filter_keys<K>(e, bb, batch, ro_in, keys_in, nnz, &ro, &keys, &buckets, s, one_hot,
+                          fused_train));
+  if (buckets == 0) {
+    if (fused_train) e->flip--;  // (nothing ran that would preset the other flag)
+    return HCTR_OK;
+  }
   if (bb.ro_full)
     HCTR_HIP(hipMemcpyAsync(bb.ro_full, ro_in, (batch * e->p.slot_num + 1) * sizeof(K),
                             hipMemcpyDeviceToDevice, s));
@@ -447,25 +446,34 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
       sink.rank = e->p.rank;
       sink.world = e->p.world;
       sink.localized = e->p.embedding_type == HCTR_EMB_LOCALIZED_SLOT_HASH ? 1 : 0;
-      HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s, &sink));
-      // row-count bookkeeping for the sort's key width (SparseUpdater::row_bound)
-      if (e->rows_pending && hipEventQuery(e->rows_event) == hipSuccess) {
-        e->rows_known = (size_t)*e->h_rows;
-        e->added_since_known = e->added_since_snapshot;
-        e->rows_pending = false;
-        e->rows_valid = true;
+      IndexExtras x;
+      if (e->p.world == 1) {
+        x.ro_src = ro_in;
+        x.ro_dst = bb.ro;
+        x.n_offsets = buckets + 1;
+        x.one_hot = one_hot;
       }
-      e->added_since_known += nnz;
-      if (!e->rows_pending) {
-        HCTR_HIP(hipMemcpyAsync(e->h_rows, e->ht.d_counter, sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, s));
-        HCTR_HIP(hipEventRecord(e->rows_event, s));
-        e->rows_pending = true;
-        e->added_since_snapshot = 0;
-      } else {
-        e->added_since_snapshot += nnz;
+      x.one_hot_next = one_hot_next;
+      e->seq++;
+      e->cum_total += nnz;
+      e->cum_keys[e->seq % hctr_embedding::kSeqRing] = e->cum_total;
+      x.host_rows = e->h_rows;
+      x.host_seq = e->h_rows + 1;
+      x.seq = e->seq;
+      x.host_error = e->h_err;
+      HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s, &sink, &x));
+      // row-count bound for the sort's key width (SparseUpdater::row_bound): the counter after a
+      // past batch q (posted by its finish kernel) + every key enqueued since
+      {
+        const uint64_t q = *(volatile uint64_t*)(e->h_rows + 1);  // sequence number first ...
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const uint64_t rows = *(volatile uint64_t*)e->h_rows;     // ... rows at least that new
+        if (q >= e->min_valid_seq && e->seq - q < (uint64_t)hctr_embedding::kSeqRing)
+          e->upd.row_bound =
+              rows + (e->cum_total - e->cum_keys[q % hctr_embedding::kSeqRing]);
+        else
+          e->upd.row_bound = 0;  // unknown: the sort takes the full key width
       }
-      e->upd.row_bound = e->rows_valid ? e->rows_known + e->added_since_known : 0;
     } else {
       HCTR_TRY(e->ht.get_mark(keys, nnz, d_n, bb.value_index, s));
     }
@@ -489,7 +497,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   const int pool_combiner = e->scale_after_reduce() ? 0 : e->p.combiner;
   HCTR_TRY(forward_pool_dispatch(buckets, (int)e->p.embedding_vec_size, pool_combiner, ro,
                                  e->p.key_type, bb.value_index, e->table, out, e->p.out_dtype,
-                                 multi_hot, s, bb.one_hot));
+                                 multi_hot, s, one_hot));
   e->prof.end(0, s);
   if (nnz > 0 && is_train && e->presort_enabled &&
       !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
@@ -602,6 +610,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
     HCTR_ALLOC(bb.keys, nn * e->key_bytes);
     HCTR_ALLOC(bb.value_index, nn * sizeof(uint64_t));
     HCTR_ALLOC(bb.one_hot, 64);
+    (void)hipMemset(bb.one_hot, 1, 64);  // both flags of the training batches start "one-hot"
     if (e->scale_after_reduce()) HCTR_ALLOC(bb.ro_full, (bsz * p.slot_num + 1) * e->key_bytes);
   }
   HCTR_ALLOC(e->lens, (e->buckets_max + 1) * e->key_bytes);
@@ -610,13 +619,13 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
 #undef HCTR_ALLOC
   if (hipHostMalloc((void**)&e->h_nnz, 8, hipHostMallocDefault) != hipSuccess ||
       hipHostMalloc((void**)&e->h_err, 8, hipHostMallocDefault) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_rows, 8, hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&e->rows_event, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->err_event, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_rows, 16, hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&e->nnz_event, hipEventDisableTiming) != hipSuccess) {
     set_error("pinned host / event allocation failed");
     return fail(HCTR_ERR_HIP);
   }
+  e->h_rows[0] = e->h_rows[1] = 0;
+  *e->h_err = 0u;
   if ((rc = e->ht.create(V, p.key_type)) != HCTR_OK) return fail(rc);
   if ((rc = e->ht.reserve(e->nnz_max)) != HCTR_OK) return fail(rc);
   if ((rc = e->upd.create(e->nnz_max, V, (int)D)) != HCTR_OK) return fail(rc);
@@ -774,6 +783,24 @@ int hctr_emb_backward(hctr_embedding* e, const void* top_grad, hctr_stream_t str
   return HCTR_OK;
 }
 
+int hctr_emb_forward_interaction(hctr_embedding* e, int is_train, const void* mlp, void* pooled,
+                                 void* out, hctr_stream_t stream) {
+  HCTR_REQUIRE(e && mlp && pooled && out, "null pointer");
+  HCTR_REQUIRE(e->p.world == 1, "forward_interaction: one GPU (the pooled vectors are exchanged "
+                                "before the interaction otherwise)");
+  HCTR_REQUIRE(!is_train || e->has_train_batch, "forward_interaction before the index stage");
+  const size_t batch = is_train ? e->p.train_batch_size : e->p.evaluate_batch_size;
+  hctr_embedding::BatchBufs& bb = is_train ? e->tb : e->eb;
+  HCTR_REQUIRE(bb.value_index != nullptr, "batch size 0 configured for this mode");
+  hipStream_t s = as_stream(stream);
+  e->prof.begin(0, s);
+  const int rc = hctr_interaction_fwd_gather(batch, (int)e->p.slot_num,
+                                             (int)e->p.embedding_vec_size, mlp, e->table,
+                                             bb.value_index, pooled, out, e->p.out_dtype, stream);
+  e->prof.end(0, s);
+  return rc;
+}
+
 int hctr_emb_get_wgrad(hctr_embedding* e, void* wgrad, hctr_stream_t stream) {
   HCTR_REQUIRE(e && wgrad, "null pointer");
   HCTR_REQUIRE(e->top_grad, "get_wgrad() before backward()");
@@ -835,18 +862,11 @@ int hctr_emb_check_overflow(hctr_embedding* e, hctr_stream_t stream) {
 
 int hctr_emb_poll_overflow(hctr_embedding* e, hctr_stream_t stream) {
   HCTR_REQUIRE(e, "null handle");
-  hipStream_t s = as_stream(stream);
-  if (e->err_pending && hipEventQuery(e->err_event) == hipSuccess) {
-    e->err_pending = false;
-    if (*e->h_err != 0u) {
-      set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
-      return HCTR_ERR_OVERFLOW;
-    }
-  }
-  if (!e->err_pending) {
-    HCTR_HIP(hipMemcpyAsync(e->h_err, e->ht.d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HCTR_HIP(hipEventRecord(e->err_event, s));
-    e->err_pending = true;
+  (void)stream;
+  // the flags as the finish kernel of a completed index stage posted them (no copy, no sync)
+  if (*(volatile uint32_t*)e->h_err != 0u) {
+    set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
+    return HCTR_ERR_OVERFLOW;
   }
   return HCTR_OK;
 }
@@ -925,9 +945,10 @@ int hctr_emb_load(hctr_embedding* e, const int64_t* d_keys, const uint64_t* d_sl
     }
   }
   if (rc == HCTR_OK) rc = e->ht.set_value_head(head + count, s);
-  // the next counter snapshot re-establishes the bound (one in flight predates this load)
-  e->rows_valid = e->rows_pending = false;
-  e->added_since_known = e->added_since_snapshot = 0;
+  // a counter posted by a batch enqueued before this load says nothing about the rows now:
+  // only posts of later batches re-establish the bound (hipStreamSynchronize above: nothing of
+  // this stream is still in flight)
+  e->min_valid_seq = e->seq + 1;
   e->upd.row_bound = 0;
   (void)hipFree(rows);
   if (keys_typed) (void)hipFree(keys_typed);
@@ -964,8 +985,9 @@ int hctr_emb_reset(hctr_embedding* e, hctr_stream_t stream) {
   HCTR_REQUIRE(e, "null handle");
   hipStream_t s = as_stream(stream);
   HCTR_TRY(e->ht.clear(s));
-  e->rows_valid = e->rows_pending = false;
-  e->added_since_known = e->added_since_snapshot = 0;
+  HCTR_HIP(hipStreamSynchronize(s));  // (no post of an older batch can land after this)
+  e->min_valid_seq = e->seq + 1;
+  *e->h_err = 0u;
   e->upd.row_bound = 0;
   HCTR_TRY(reset_opt_states(e, s));
   e->has_train_batch = false;

@@ -11,7 +11,29 @@ struct HtEntry {
 };
 
 constexpr uint64_t kPendingBit = 1ull << 63;
+// value of a key that met a full table: it keeps its hash slot but owns no row.  Below
+// kPendingBit, so later batches resolve it on the fast path (it reads as kInvalidIndex) instead
+// of re-entering the insert protocol and raising the overflow flag again
+constexpr uint64_t kNoRow = kPendingBit - 1;
 constexpr int kHtTile = 1024;  // positions per compaction tile
+constexpr int kHtFinishBlocks = 128;  // workgroups of the cooperative finish kernel (co-resident)
+
+// what get_insert can do on the side of its two launches (all optional)
+struct IndexExtras {
+  // world == 1: private copy of the batch's row offsets + "every bucket holds one key" check,
+  // done by the probe kernel's threads (no launch of its own)
+  const void* ro_src = nullptr;
+  void* ro_dst = nullptr;
+  size_t n_offsets = 0;
+  uint32_t* one_hot = nullptr;       // cleared when ro_src[i] != i for some i
+  uint32_t* one_hot_next = nullptr;  // preset to 1 for the NEXT batch by the finish kernel
+  // pinned host words the finish kernel posts to (no copy launch, no event): rows handed out so
+  // far, then `seq` -- the host reads seq first, so the row count it pairs with it is never older
+  uint64_t* host_rows = nullptr;
+  uint64_t* host_seq = nullptr;
+  uint64_t seq = 0;
+  uint32_t* host_error = nullptr;    // the error flags
+};
 
 // where get_insert records the slot id of newly inserted rows (embedding dump needs it)
 struct SlotSink {
@@ -35,8 +57,10 @@ struct HashTable {
   uint64_t* d_new_count = nullptr;  // number of keys inserted by the last get_insert
   // scratch sized for max_n positions
   size_t max_n = 0;
-  uint32_t* tile_sums = nullptr;   // [ceil(max_n / kHtTile) + 1]
+  uint32_t* d_barrier = nullptr;    // {arrived, generation} of the finish kernel's grid barrier
+  uint32_t* tile_sums = nullptr;   // [ceil(max_n / kHtTile) + 1] (+ kHtFinishBlocks block totals)
   uint64_t* new_positions = nullptr;  // [max_n] positions (into keys) of newly inserted keys
+  unsigned long long* fin_masks = nullptr;  // [max_n / 64 + 2] first-occurrence masks (finish)
   uint64_t* d_scratch64 = nullptr;  // 1 element
 
   int create(size_t capacity, int key_type);
@@ -44,7 +68,7 @@ struct HashTable {
   int clear(hipStream_t s);
   int reserve(size_t n);  // scratch for batches up to n keys
   int get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s,
-                 const SlotSink* sink = nullptr);
+                 const SlotSink* sink = nullptr, const IndexExtras* extras = nullptr);
   int get_mark(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out, hipStream_t s);
   int insert(const void* keys, const uint64_t* vals, size_t n, hipStream_t s);
   int count(hipStream_t s, size_t* out);

@@ -8,13 +8,19 @@
 // atomicAdd; here a new key's index is counter + (rank of its FIRST occurrence among the new
 // keys of the batch), i.e. exactly what a sequential insert in array order produces.
 //
-// get_insert is 5 launches; in steady state (no unseen key) launches 2-5 exit on one scalar load:
-//   A probe_insert : find/claim slot (CAS on key); known key -> index; unseen -> atomicMin of
-//                    (PENDING | position) into the slot value, out = PENDING | slot
-//   B flag_count   : flag positions that are the first occurrence of an unseen key, per-tile count
-//   S scan_tiles   : single-workgroup exclusive scan of tile counts, counter bump
-//   D1 assign      : first occurrences get counter_base + rank, written to slot + out
-//   D2 resolve     : remaining occurrences read the now-final slot value
+// get_insert is 2 launches (round 3; five before):
+//   1 probe_insert : find/claim slot (CAS on key); known key -> index; unseen -> atomicMin of
+//                    (PENDING | position) into the slot value, out = PENDING | slot.  Its threads
+//                    also make the caller's private copy of the row offsets (world == 1).
+//   2 finish       : exits on one scalar load when the batch held no unseen key.  Otherwise, in
+//                    kHtFinishBlocks co-resident workgroups with ONE grid barrier between them:
+//                    (A) per 64 positions a mask of the FIRST occurrences of unseen keys + counts
+//                    per workgroup; barrier; (S) every workgroup scans the counts, workgroup 0
+//                    bumps the row counter; (D) every pending position computes its key's row =
+//                    counter + (first occurrences before the key's first position) from the
+//                    masks -- no second pass over the table, no dependency between workgroups.
+//                    Also posts the row counter / error flags to pinned host words and presets
+//                    the caller's one-hot flag of the next batch (no copy / memset launches).
 #include "hashtable.h"
 
 #include "block_prims.h"
@@ -39,6 +45,9 @@ __device__ __forceinline__ size_t live_count(const uint64_t* d_n, size_t n) {
   uint64_t v = *d_n;
   return v < n ? (size_t)v : n;
 }
+
+// a key that met a full table owns no row: it reads as a miss
+__device__ __forceinline__ uint64_t row_of(uint64_t v) { return v == kNoRow ? kInvalidIndex : v; }
 
 __global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < size;
@@ -81,7 +90,7 @@ __device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, u
   }
   unsigned long long v = tab[slot].val;
   if (v < kPendingBit) {
-    out[i] = v;
+    out[i] = row_of(v);
   } else {
     atomicMin(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
     out[i] = kPendingBit | slot;
@@ -99,9 +108,22 @@ template <typename K>
 __global__ void __launch_bounds__(kBlock)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
-                           uint32_t* d_pending, uint32_t* d_error) {
+                           uint32_t* d_pending, uint32_t* d_error, const K* __restrict__ ro_src,
+                           K* __restrict__ ro_dst, size_t n_offsets,
+                           uint32_t* __restrict__ one_hot) {
   const size_t nl = live_count(d_n, n);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
+  if (ro_src != nullptr) {
+    // the caller's private copy of the row offsets; lengths all 1 and ro[0] == 0  <=>
+    // ro[i] == i for every i: otherwise the gather must not take its offset-free one-hot loop
+    bool bad = false;
+    for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n_offsets; i += nthreads) {
+      const K v = ro_src[i];
+      ro_dst[i] = v;
+      bad |= v != (K)i;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
+  }
   for (size_t i0 = blockIdx.x * (size_t)kBlock + threadIdx.x; i0 < nl;
        i0 += nthreads * kHtUnroll) {
     K key[kHtUnroll];
@@ -121,7 +143,7 @@ __global__ void __launch_bounds__(kBlock)
       const size_t i = i0 + (size_t)u * nthreads;
       if (i >= nl) continue;
       if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
-        out[i] = ent[u].y;
+        out[i] = row_of(ent[u].y);
       else
         ht_probe_insert_one<K>(tab, size, key[u], i, out, d_pending, d_error);
     }
@@ -131,25 +153,6 @@ __global__ void __launch_bounds__(kBlock)
 __device__ __forceinline__ bool is_first_occurrence(const HtEntry* tab, uint64_t o, size_t i) {
   if (o < kPendingBit || o == kInvalidIndex) return false;
   return tab[o & ~kPendingBit].val == (kPendingBit | (uint64_t)i);
-}
-
-__global__ void __launch_bounds__(kBlock)
-    ht_flag_count_kernel(const HtEntry* __restrict__ tab, const uint64_t* __restrict__ out,
-                         size_t n, const uint64_t* d_n, const uint32_t* d_pending,
-                         uint32_t* __restrict__ tile_sums, size_t n_tiles) {
-  if (*d_pending == 0u) return;
-  __shared__ uint32_t smem[kBlock / 64 + 1];
-  const size_t nl = live_count(d_n, n);
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int r = 0; r < kHtTile / kBlock; r++) {
-      size_t i = tile * kHtTile + r * kBlock + threadIdx.x;
-      if (i < nl) c += is_first_occurrence(tab, out[i], i) ? 1u : 0u;
-    }
-    uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
-    if (threadIdx.x == 0) tile_sums[tile] = tot;
-  }
 }
 
 // single workgroup: exclusive scan of sums[0..m) in place, total -> *d_total (uint64)
@@ -178,53 +181,6 @@ __global__ void __launch_bounds__(1024)
   if (threadIdx.x == 0) *d_total = carry;
 }
 
-// get_insert step S: scan the per-tile counts of new keys, hand out the index range
-// [counter, counter + new) and latch/reset the "batch has unseen keys" flag so that the next
-// get_insert needs no memset.
-__global__ void __launch_bounds__(1024)
-    ht_scan_bump_kernel(uint32_t* sums, size_t m, uint32_t* d_pending, uint32_t* d_latched,
-                        uint64_t* d_counter, uint64_t* d_base, uint64_t* d_new_count,
-                        uint64_t capacity, uint32_t* d_error) {
-  __shared__ uint32_t smem[1024 / 64 + 1];
-  __shared__ uint64_t carry;
-  const uint32_t pending = *d_pending;
-  if (pending == 0u) {
-    if (threadIdx.x == 0) {
-      *d_latched = 0u;
-      *d_new_count = 0;
-      *d_base = *d_counter;
-    }
-    return;
-  }
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (size_t base = 0; base < m; base += 1024) {
-    size_t i = base + threadIdx.x;
-    uint32_t v = (i < m) ? sums[i] : 0u;
-    uint32_t tot;
-    uint32_t ex = block_exclusive_scan<uint32_t, 1024>(v, smem, &tot);
-    uint64_t c = carry;
-    if (i < m) sums[i] = (uint32_t)(c + ex);
-    __syncthreads();
-    if (threadIdx.x == 0) carry = c + tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const uint64_t c0 = *d_counter;
-    *d_base = c0;
-    *d_new_count = carry;
-    // more unseen keys than free rows: the counter stops at the capacity, ht_assign_kernel gives
-    // the keys beyond it no row (kInvalidIndex -> they pool as zeros and are skipped by the
-    // update, like an eval miss), and error bit 1 makes check_overflow() fail as the reference's
-    // does (localized_slot_sparse_embedding_hash.hpp:552-569) -- nothing is read or written
-    // outside the [capacity] row arrays
-    *d_counter = (c0 + carry > capacity) ? capacity : c0 + carry;
-    if (c0 + carry > capacity) atomicOr(d_error, 2u);
-    *d_latched = 1u;
-    *d_pending = 0u;
-  }
-}
-
 // optional: record the slot id of every newly inserted row (store_slot_id_kernel semantics,
 // R/HugeCTR/src/embeddings/store_slot_id_functor.cu:26-48, restricted to rows that are new)
 struct SlotIdSink {
@@ -237,6 +193,13 @@ struct SlotIdSink {
 
 __device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos, uint64_t row) {
   size_t lo = 0, hi = k.buckets;
+  if (pos < k.buckets) {  // one key per bucket: bucket == position (two reads instead of ~20)
+    const uint64_t a = k.key_is_u32 ? (uint64_t)((const uint32_t*)k.row_offset)[pos]
+                                    : (uint64_t)((const long long*)k.row_offset)[pos];
+    const uint64_t e = k.key_is_u32 ? (uint64_t)((const uint32_t*)k.row_offset)[pos + 1]
+                                    : (uint64_t)((const long long*)k.row_offset)[pos + 1];
+    if (a <= pos && pos < e) lo = hi = (size_t)pos;
+  }
   while (lo < hi) {  // bucket u with ro[u] <= pos < ro[u+1]
     const size_t mid = (lo + hi) >> 1;
     const uint64_t e = k.key_is_u32 ? (uint64_t)((const uint32_t*)k.row_offset)[mid + 1]
@@ -248,49 +211,203 @@ __device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos
   k.slot_id[row] = (uint64_t)(k.localized ? k.rank + j * k.world : j);
 }
 
-__global__ void __launch_bounds__(kBlock)
-    ht_assign_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
-                     const uint64_t* d_n, const uint32_t* d_pending,
-                     const uint32_t* __restrict__ tile_sums, size_t n_tiles,
-                     const uint64_t* d_base, uint64_t* __restrict__ new_positions,
-                     SlotIdSink sink, uint64_t capacity) {
-  if (*d_pending == 0u) return;
-  __shared__ uint32_t smem[kBlock / 64 + 1];
-  const size_t nl = live_count(d_n, n);
-  const uint64_t base = *d_base;
-  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    uint32_t run = tile_sums[tile];
-#pragma unroll
-    for (int r = 0; r < kHtTile / kBlock; r++) {
-      size_t i = tile * kHtTile + r * kBlock + threadIdx.x;
-      uint64_t o = (i < nl) ? out[i] : 0;
-      bool f = (i < nl) && is_first_occurrence(tab, o, i);
-      uint32_t tot;
-      uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
-      if (f) {
-        uint64_t rank = (uint64_t)run + ex;
-        uint64_t fin = base + rank;
-        if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
-        tab[o & ~kPendingBit].val = fin;
-        out[i] = fin;
-        new_positions[rank] = (uint64_t)i;
-        if (sink.slot_id != nullptr && fin != kInvalidIndex)
-          record_slot_id(sink, (uint64_t)i, fin);
-      }
-      run += tot;
-    }
+// ---- get_insert, launch 2 ------------------------------------------------------------------------
+constexpr int kFinBlock = 1024;
+constexpr int kFinUnroll = 4;
+constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises error bit 2^2)
+
+struct FinishCtl {
+  uint32_t *pending, *latched, *error, *barrier;
+  uint64_t *counter, *base, *new_count;
+  uint32_t* block_tot;          // [gridDim.x] first occurrences per workgroup region
+  unsigned long long* masks;    // [ceil(n / 64)] first-occurrence masks
+  uint32_t* gprefix;            // [ceil(n / 64)] firsts of the group's region in front of it
+  uint32_t* one_hot_next;
+  uint64_t *host_rows, *host_seq;
+  uint64_t seq;
+  uint32_t* host_error;
+};
+
+__device__ __forceinline__ void post_to_host(const FinishCtl& c, uint64_t rows) {
+  if (c.one_hot_next != nullptr) *c.one_hot_next = 1u;
+  if (c.host_error != nullptr) *c.host_error = *c.error;
+  if (c.host_rows != nullptr) {
+    *c.host_rows = rows;
+    __threadfence_system();  // rows before seq: whoever sees seq sees rows at least this new
+    *c.host_seq = c.seq;
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
-    ht_resolve_kernel(const HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
-                      const uint64_t* d_n, const uint32_t* d_pending) {
-  if (*d_pending == 0u) return;
+// all workgroups of the grid are resident (grid <= kHtFinishBlocks, far below what 256 CUs hold):
+// sense-reversing barrier on {arrived, generation}
+__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
+  __threadfence();
+  __syncthreads();
+  __shared__ uint32_t ok;
+  if (threadIdx.x == 0) {
+    ok = 1u;
+    const uint32_t gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t old =
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nblocks - 1u) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      uint32_t spins = 0;
+      while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kSpinLimit) {
+          ok = 0u;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  __threadfence();
+  return ok != 0u;
+}
+
+__global__ void __launch_bounds__(kFinBlock)
+    ht_finish_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
+                     const uint64_t* d_n, FinishCtl c, uint64_t* __restrict__ new_positions,
+                     SlotIdSink sink, uint64_t capacity) {
+  if (*c.pending == 0u) {  // steady state: no unseen key in this batch
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const uint64_t cnt = *c.counter;
+      *c.latched = 0u;
+      *c.new_count = 0;
+      *c.base = cnt;
+      post_to_host(c, cnt);
+    }
+    return;
+  }
+  __shared__ uint32_t smem[kFinBlock / 64 + 1];
+  const uint64_t c0 = *c.counter;  // (workgroup 0 moves it only behind the barrier)
   const size_t nl = live_count(d_n, n);
-  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < nl;
-       i += (size_t)gridDim.x * kBlock) {
-    uint64_t o = out[i];
-    if (o >= kPendingBit && o != kInvalidIndex) out[i] = tab[o & ~kPendingBit].val;
+  const uint32_t G = gridDim.x, b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = kFinBlock / 64;
+  // region of this workgroup: `per` consecutive positions (a multiple of the block size), wave w
+  // takes the 64-position groups w, w + NW, ... of it
+  size_t per = (nl + G - 1) / G;
+  per = (per + kFinBlock - 1) / kFinBlock * kFinBlock;
+  const size_t r0 = (size_t)b * per < nl ? (size_t)b * per : nl;
+  const size_t r1 = r0 + per < nl ? r0 + per : nl;
+  // ---- A: masks of first occurrences; per 64-position group the number of first occurrences of
+  //         this region in front of it; count of the region -----------------------------------------
+  // (kFinUnroll groups per wavefront in flight: every load is unconditional on a clamped address,
+  //  so the position -> slot -> value round trips of the groups overlap instead of queueing up)
+  for (size_t g0 = r0 + (size_t)wave * 64; g0 < r1; g0 += (size_t)NW * 64 * kFinUnroll) {
+    uint64_t o[kFinUnroll], v[kFinUnroll];
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const size_t i = g0 + (size_t)u * NW * 64 + lane;
+      o[u] = out[i < r1 ? i : r0];
+    }
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
+      v[u] = tab[pend ? (o[u] & ~kPendingBit) : 0ull].val;
+    }
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const size_t gu = g0 + (size_t)u * NW * 64;
+      const size_t i = gu + lane;
+      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
+      const bool f = i < r1 && pend && v[u] == (kPendingBit | (uint64_t)i);
+      const unsigned long long m = __ballot(f);
+      if (lane == 0 && gu < r1) c.masks[gu >> 6] = m;
+    }
+  }
+  __syncthreads();  // (the masks of this region are this workgroup's own writes)
+  {
+    const size_t gf = r0 >> 6, ng = (r1 - r0 + 63) >> 6;
+    uint32_t run = 0u;
+    for (size_t g0 = 0; g0 < ng; g0 += kFinBlock) {
+      const size_t g = g0 + threadIdx.x;
+      const uint32_t v = g < ng ? (uint32_t)__popcll(c.masks[gf + g]) : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &tot);
+      if (g < ng) c.gprefix[gf + g] = run + ex;
+      run += tot;
+    }
+    if (threadIdx.x == 0) c.block_tot[b] = run;
+  }
+  if (!grid_barrier(c.barrier, G)) {
+    if (threadIdx.x == 0) atomicOr(c.error, 4u);
+    return;
+  }
+  // ---- S: base of every region; workgroup 0 hands out the row range ---------------------------
+  {
+    const uint32_t v = threadIdx.x < G ? c.block_tot[threadIdx.x] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &total);
+    if (threadIdx.x < G) c.block_tot[G + threadIdx.x] = ex;  // every workgroup writes the same
+    if (b == 0 && threadIdx.x == 0) {
+      *c.base = c0;
+      *c.new_count = total;
+      // more unseen keys than free rows: the counter stops at the capacity, the keys beyond it
+      // get no row (they pool as zeros and are skipped by the update, like an eval miss), and
+      // error bit 1 makes check_overflow() fail as the reference's does
+      // (localized_slot_sparse_embedding_hash.hpp:552-569) -- nothing is read or written outside
+      // the [capacity] row arrays
+      const uint64_t head = (c0 + total > capacity) ? capacity : c0 + total;
+      *c.counter = head;
+      if (c0 + total > capacity) atomicOr(c.error, 2u);
+      *c.latched = 1u;
+      *c.pending = 0u;
+      post_to_host(c, head);
+    }
+    __syncthreads();
+  }
+  const uint32_t* base_of = c.block_tot + G;
+  // ---- D: rows.  rank of a first position fp = firsts in the regions before its own + firsts of
+  //         its own region in front of its group + firsts of its group below it ---------------------
+  for (size_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (size_t)kFinBlock * kFinUnroll) {
+    uint64_t o[kFinUnroll], v[kFinUnroll], mk[kFinUnroll];
+    uint32_t gp[kFinUnroll], bs[kFinUnroll];
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const size_t i = i0 + (size_t)u * kFinBlock;
+      o[u] = out[i < r1 ? i : r0];
+    }
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
+      v[u] = tab[pend ? (o[u] & ~kPendingBit) : 0ull].val;
+    }
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
+      const bool need = pend && v[u] >= kPendingBit;  // else: the row is already published
+      const uint64_t fp = need ? (v[u] & ~kPendingBit) : 0ull;
+      gp[u] = c.gprefix[fp >> 6];
+      mk[u] = c.masks[fp >> 6];
+      bs[u] = base_of[(uint32_t)(fp / per)];
+    }
+#pragma unroll
+    for (int u = 0; u < kFinUnroll; u++) {
+      const size_t i = i0 + (size_t)u * kFinBlock;
+      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
+      if (i >= r1 || !pend) continue;
+      if (v[u] < kPendingBit) {  // the key's first occurrence has already published the row
+        out[i] = row_of(v[u]);
+        continue;
+      }
+      const uint64_t fp = v[u] & ~kPendingBit;
+      const uint32_t rank =
+          bs[u] + gp[u] + (uint32_t)__popcll(mk[u] & ((1ull << (fp & 63)) - 1ull));
+      uint64_t fin = c0 + rank;
+      if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
+      out[i] = fin;
+      if (i == fp) {
+        const uint64_t slot = o[u] & ~kPendingBit;
+        tab[slot].val = fin == kInvalidIndex ? kNoRow : fin;
+        new_positions[rank] = (uint64_t)i;
+        if (sink.slot_id != nullptr && fin != kInvalidIndex) record_slot_id(sink, (uint64_t)i, fin);
+      }
+    }
   }
 }
 
@@ -322,13 +439,13 @@ __global__ void __launch_bounds__(kBlock)
       const long long k64 = widen<K>(key[u]);
       uint64_t res = kInvalidIndex;
       if ((long long)ent[u].x == k64) {
-        res = ent[u].y;
+        res = row_of(ent[u].y);
       } else if ((long long)ent[u].x != empty) {  // collision: walk on
         uint64_t sl = (slot[u] + 1 == size) ? 0 : slot[u] + 1;
         for (uint64_t probes = 1; probes <= size; ++probes) {
           const long long cur = tab[sl].key;
           if (cur == k64) {
-            res = tab[sl].val;
+            res = row_of(tab[sl].val);
             break;
           }
           if (cur == empty) break;
@@ -383,7 +500,8 @@ __global__ void __launch_bounds__(kBlock)
     for (int r = 0; r < kHtTile / kBlock; r++) {
       uint64_t i = tile * (uint64_t)kHtTile + r * kBlock + threadIdx.x;
       // erased entries (dynamic tables) keep a tombstone key with an invalid value
-      if (i < size) c += (tab[i].key != empty && tab[i].val != kInvalidIndex) ? 1u : 0u;
+      if (i < size)
+        c += (tab[i].key != empty && tab[i].val != kInvalidIndex && tab[i].val != kNoRow) ? 1u : 0u;
     }
     uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
     if (threadIdx.x == 0) tile_sums[tile] = tot;
@@ -404,7 +522,7 @@ __global__ void __launch_bounds__(kBlock)
       bool f = false;
       if (i < size) {
         e = tab[i];
-        f = e.key != empty && e.val != kInvalidIndex;
+        f = e.key != empty && e.val != kInvalidIndex && e.val != kNoRow;
       }
       uint32_t tot;
       uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
@@ -444,6 +562,7 @@ int HashTable::create(size_t cap, int kt) {
   d_pending = reinterpret_cast<uint32_t*>(scal + 4);
   d_error = reinterpret_cast<uint32_t*>(scal + 4) + 1;
   d_latched = reinterpret_cast<uint32_t*>(scal + 5);
+  d_barrier = reinterpret_cast<uint32_t*>(scal + 6);
   HCTR_HIP(hipMemset(scal, 0, 64));
   return clear(nullptr);
 }
@@ -453,6 +572,8 @@ int HashTable::destroy() {
   if (d_counter) (void)hipFree(d_counter);
   if (tile_sums) (void)hipFree(tile_sums);
   if (new_positions) (void)hipFree(new_positions);
+  if (fin_masks) (void)hipFree(fin_masks);
+  fin_masks = nullptr;
   entries = nullptr;
   d_counter = nullptr;
   tile_sums = nullptr;
@@ -476,14 +597,17 @@ int HashTable::reserve(size_t n) {
   if (n <= max_n && tile_sums != nullptr) return HCTR_OK;
   if (tile_sums) (void)hipFree(tile_sums);
   if (new_positions) (void)hipFree(new_positions);
-  HCTR_HIP(hipMalloc(&tile_sums, need_tiles * sizeof(uint32_t)));
+  if (fin_masks) (void)hipFree(fin_masks);
+  // (+ the finish kernel's per-workgroup counts and their scan)
+  HCTR_HIP(hipMalloc(&tile_sums, (need_tiles + 2 * kHtFinishBlocks) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&new_positions, (n > 0 ? n : 1) * sizeof(uint64_t)));
+  HCTR_HIP(hipMalloc(&fin_masks, (n / 64 + 2) * (sizeof(unsigned long long) + sizeof(uint32_t))));
   max_n = n;
   return HCTR_OK;
 }
 
 int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint64_t* out,
-                          hipStream_t s, const SlotSink* sink_in) {
+                          hipStream_t s, const SlotSink* sink_in, const IndexExtras* ex) {
   if (n == 0) return HCTR_OK;
   HCTR_TRY(reserve(n));
   SlotIdSink sink;
@@ -504,30 +628,42 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
     sink.world = sink_in->world;
     sink.localized = sink_in->localized;
   }
-  const int grid = grid_for(ceil_div<size_t>(n, kHtUnroll), kBlock, 1 << 16);
+  IndexExtras none;
+  const IndexExtras& x = ex ? *ex : none;
+  const size_t work = n > x.n_offsets ? n : x.n_offsets;
+  const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, 1 << 16);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const uint32_t*)keys, n, d_n, out, d_pending, d_error);
+                       size, (const uint32_t*)keys, n, d_n, out, d_pending, d_error,
+                       (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst, x.n_offsets, x.one_hot);
   } else {
     hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const long long*)keys, n, d_n, out, d_pending, d_error);
+                       size, (const long long*)keys, n, d_n, out, d_pending, d_error,
+                       (const long long*)x.ro_src, (long long*)x.ro_dst, x.n_offsets, x.one_hot);
   }
   HCTR_LAUNCH_CHECK();
-  // steps B..D2 exit on one scalar load when the batch holds no unseen key (steady state);
-  // small grids keep those empty launches cheap, grid-stride covers the cold-start case.
-  const size_t n_tiles = ceil_div<size_t>(n, kHtTile);
-  const int tgrid = (int)(n_tiles < (size_t)512 ? n_tiles : (size_t)512);
-  hipLaunchKernelGGL(ht_flag_count_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
-                     d_pending, tile_sums, n_tiles);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ht_scan_bump_kernel, dim3(1), dim3(1024), 0, s, tile_sums, n_tiles, d_pending,
-                     d_latched, d_counter, d_base, d_new_count, capacity, d_error);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ht_assign_kernel, dim3(tgrid), dim3(kBlock), 0, s, entries, out, n, d_n,
-                     d_latched, tile_sums, n_tiles, d_base, new_positions, sink, capacity);
-  HCTR_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ht_resolve_kernel, dim3(grid_for(n, kBlock, 512)), dim3(kBlock), 0, s,
-                     entries, out, n, d_n, d_latched);
+  FinishCtl c;
+  c.pending = d_pending;
+  c.latched = d_latched;
+  c.error = d_error;
+  c.barrier = d_barrier;
+  c.counter = d_counter;
+  c.base = d_base;
+  c.new_count = d_new_count;
+  c.block_tot = tile_sums + ceil_div<size_t>(max_n > size ? max_n : size, kHtTile) + 1;
+  c.masks = fin_masks;
+  c.gprefix = reinterpret_cast<uint32_t*>(fin_masks + (max_n / 64 + 2));
+  c.one_hot_next = x.one_hot_next;
+  c.host_rows = x.host_rows;
+  c.host_seq = x.host_seq;
+  c.seq = x.seq;
+  c.host_error = x.host_error;
+  // few positions: fewer workgroups (every one of them takes part in the barrier)
+  size_t fg = ceil_div<size_t>(n, (size_t)kFinBlock * 4);
+  if (fg > (size_t)kHtFinishBlocks) fg = kHtFinishBlocks;
+  if (fg < 1) fg = 1;
+  hipLaunchKernelGGL(ht_finish_kernel, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n, d_n,
+                     c, new_positions, sink, capacity);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

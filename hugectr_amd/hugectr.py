@@ -30,7 +30,7 @@ from .dense import FusedMLP, bce_with_logits
 from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward_reorder
 from .embedding_collection import (DataParallelCollection, EmbeddingCollection,  # noqa: F401
                                    EmbeddingCollectionConfig, EmbeddingTableConfig)
-from .layers import MultiCrossLayer, interaction, interaction_indexed
+from .layers import MultiCrossLayer, interaction, interaction_gather, interaction_indexed
 from .parallel import DistributedExchange, LocalizedExchange
 from .parallel import all_reduce as _all_reduce
 from . import data as _data
@@ -218,10 +218,13 @@ def _use_gemm_selection(solver) -> str:
         import torch.cuda.tunable as tunable
         if not tunable.is_enabled():
             tunable.enable(True)
-            tunable.set_filename(path)
             tunable.tuning_enable(False)
-            tunable.write_file_on_exit(False)  # the recorded selections are read, never rewritten
             tunable.read_file(path)
+            # the recorded selections are read, never rewritten: whatever TunableOp writes when
+            # the process ends goes to a scratch file
+            import tempfile
+            tunable.set_filename(os.path.join(tempfile.gettempdir(),
+                                              f"hctr_tunableop_{os.getpid()}.csv"))
         return "file"
     except Exception:  # an optimisation only
         return "off"
@@ -492,6 +495,15 @@ class _IndexedEmb:
         self.rows, self.row_of, self.on_grad = rows, row_of, on_grad
 
 
+class _GatherEmb:
+    """embedding output that is not materialised before the Interaction layer: on one GPU with one
+    key per bucket the interaction kernel reads the table rows through the index stage's result
+    itself (hctr_emb_forward_interaction) and writes the pooled vectors once, for the backward"""
+
+    def __init__(self, emb, train, on_grad):
+        self.emb, self.train, self.on_grad = emb, train, on_grad
+
+
 class _Tensors(dict):
     def __getitem__(self, k):
         v = dict.__getitem__(self, k)
@@ -696,8 +708,18 @@ class Model:
             raise RuntimeError("HCTR_EXCHANGE must be rows, unique, unique16 or auto")
         self._xstate = {}
         for name, (se, p, h, ex, localized) in self._emb.items():
-            st = {"mode": "rows", "ux": None, "select": None, "indexed": False, "timing_ms": None}
+            st = {"mode": "rows", "ux": None, "select": None, "indexed": False, "timing_ms": None,
+                  "fused_gather": False}
             one_hot = p.is_fixed_length and p.max_nnz() == 1
+            cons = consumers.get(name, [])
+            to_interaction = (len(cons) == 1 and cons[0][1] == 1 and
+                              self.layers[cons[0][0]].layer_type == Layer_t.Interaction)
+            # one GPU, one key per bucket, the Interaction layer the only reader: the gather rides
+            # in the interaction kernel (no second trip of the pooled vectors through HBM)
+            st["fused_gather"] = (self.world == 1 and one_hot and se.combiner == 0 and
+                                  to_interaction and s.use_mixed_precision and
+                                  se.embedding_vec_size in (16, 32, 64, 128) and p.slot_num <= 31 and
+                                  os.environ.get("HCTR_FUSED_GATHER", "1") != "0")
             if (self.world > 1 and localized and one_hot and se.combiner == 0 and
                     want != "rows" and self._intra and
                     (se.embedding_vec_size * (2 if s.use_mixed_precision else 4)) % 16 == 0):
@@ -708,10 +730,7 @@ class Model:
                     if self.rank == 0:
                         print(f"[HCTR][WARNING] unique-row exchange unavailable for {name}: {e!r}")
                 if st["ux"] is not None:
-                    cons = consumers.get(name, [])
-                    st["indexed"] = (len(cons) == 1 and cons[0][1] == 1 and
-                                     self.layers[cons[0][0]].layer_type == Layer_t.Interaction and
-                                     s.use_mixed_precision)
+                    st["indexed"] = to_interaction and s.use_mixed_precision
                     if want == "auto":
                         st["select"] = {"it": 0, "t0": 0.0, "t": {}}
                     else:
@@ -772,6 +791,7 @@ class Model:
             esz = 2 if self.solver.use_mixed_precision else 4
             D = se.embedding_vec_size
             r = {"payload": st["mode"] if self.world > 1 else "none (1 GPU)",
+                 "gather_fused_into_interaction": st["fused_gather"],
                  "selection_ms_per_step": st["timing_ms"],
                  "intra_iteration_overlap": self._intra, "inter_iteration_overlap": self._inter}
             if self.world > 1 and localized and st["mode"] == "rows":
@@ -1019,6 +1039,8 @@ class Model:
         logit, fused_loss = None, None
         for i, L in enumerate(self.layers):
             t, key = L.layer_type, f"l{i}"
+            if t == Layer_t.BinaryCrossEntropyLoss and fused_loss is not None:
+                continue  # (the logit never existed as a tensor)
             x = [tensors[b] for b in L.bottom_names]
             if t == Layer_t.MLP and head is not None and i == self._head_layer:
                 fused_loss = self._mods[key].forward_bce(x[0].reshape(x[0].shape[0], -1), *head)
@@ -1058,7 +1080,11 @@ class Model:
             elif t == Layer_t.ReduceSum:
                 y = x[0].sum(dim=L.axis, keepdim=True)
             elif t == Layer_t.Interaction:
-                if isinstance(x[1], _IndexedEmb):
+                if isinstance(x[1], _GatherEmb):
+                    e = x[1]
+                    y = interaction_gather(x[0].to(e.emb.out_dtype).contiguous(), e.emb, e.train,
+                                           on_emb_grad=e.on_grad)
+                elif isinstance(x[1], _IndexedEmb):
                     e = x[1]
                     y = interaction_indexed(x[0].to(e.rows.dtype).contiguous(), e.rows, e.row_of,
                                             on_emb_grad=e.on_grad)
@@ -1083,6 +1109,17 @@ class Model:
         bpg = self.bpg if train else self.bpg_eval
         S, D, W = p.slot_num, se.embedding_vec_size, self.world
         ro, keys = batch["sparse"][se.bottom_name]
+        if st["fused_gather"]:
+            h.index(train, ro, keys)
+            got = {}
+            tensors[name] = _GatherEmb(h, train, (lambda g: got.__setitem__("g", g)) if train
+                                       else None)
+            if train:
+                def finish():
+                    h.backward(got.pop("g"))
+                    h.update_params()
+                after.append(finish)
+            return
         if not train or W == 1 or not localized or not self._intra:
             # one GPU, evaluation, the distributed embedding, or no intra-iteration overlap asked
             # for: blocking collectives, in line

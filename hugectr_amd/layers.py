@@ -73,6 +73,49 @@ class _InteractionIndexedFn(torch.autograd.Function):
         return mlp_grad, None, None, None
 
 
+class _InteractionGatherFn(torch.autograd.Function):
+    """gather fused into the interaction (one GPU, one key per bucket): the embedding's table rows
+    are read through its value_index straight into the interaction's LDS tile, the pooled vectors
+    are written once for the backward.  `on_emb_grad(dE)` receives the [B, n_emb, W] gradient of
+    the pooled vectors as soon as it exists (the sparse update consumes it)."""
+
+    @staticmethod
+    def forward(ctx, mlp, emb, is_train, on_emb_grad):
+        mlp = mlp.contiguous()
+        B, W = mlp.shape
+        n_emb = emb.slot_num
+        n_ins = n_emb + 1
+        out = torch.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=mlp.dtype, device=mlp.device)
+        pooled = torch.empty((B, n_emb, W), dtype=mlp.dtype, device=mlp.device)
+        check(lib.hctr_emb_forward_interaction(emb._h, 1 if is_train else 0, ptr(mlp), ptr(pooled),
+                                               ptr(out), stream_ptr()))
+        ctx.save_for_backward(mlp, pooled)
+        ctx.on_emb_grad = on_emb_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        mlp, pooled = ctx.saved_tensors
+        grad = grad.contiguous()
+        B, W = mlp.shape
+        n_emb = pooled.shape[1]
+        mlp_grad = torch.empty_like(mlp)
+        emb_grad = torch.empty_like(pooled)
+        check(lib.hctr_interaction_bwd(B, n_emb, W, ptr(mlp), ptr(pooled), ptr(grad), ptr(mlp_grad),
+                                       ptr(emb_grad), _DT[mlp.dtype], stream_ptr()))
+        if ctx.on_emb_grad is not None:
+            ctx.on_emb_grad(emb_grad)
+        return mlp_grad, None, None, None
+
+
+def interaction_gather(mlp: torch.Tensor, emb, is_train: bool = True, on_emb_grad=None):
+    """mlp [B, W] 16-bit; emb: a SparseEmbeddingHash (world 1, one key per bucket, vector size W,
+    output type = mlp's) whose index stage has run (emb.index) -> interaction output; the pooled
+    vectors never make a second trip through HBM."""
+    assert mlp.dtype == emb.out_dtype and mlp.shape[1] == emb.embedding_vec_size
+    return _InteractionGatherFn.apply(mlp, emb, is_train, on_emb_grad)
+
+
 def interaction_indexed(mlp: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor,
                         on_emb_grad=None) -> torch.Tensor:
     """mlp [B,W], rows [R,W] (same 16-bit dtype), row_of int32 [B,n_emb] -> interaction output"""

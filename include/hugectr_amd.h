@@ -432,6 +432,23 @@ int hctr_interaction_bwd_indexed(size_t batch, int n_emb, int width, const void*
                                  const void* rows, const uint32_t* row_of, const void* top_grad,
                                  void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream);
 
+/* Gather fused into InteractionLayer::fprop (one GPU, ONE key per bucket, sum combiner): the
+ * pooled vector of a one-hot bucket is its table row rounded to the 16-bit type
+ * (forward_sum_kernel, R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:28-75, followed by
+ * InteractionLayer<__half>::fprop, R/HugeCTR/src/layers/interaction_layer.cu:1046-1127).  Rows are
+ * read through value_index ([batch * n_emb] row numbers, ~0 = no row -> zeros) straight into the
+ * interaction's LDS tile; `pooled` [batch][n_emb][width] is written once (the backward needs it);
+ * out as hctr_interaction_fwd.  Bit-identical to hctr_emb_forward + hctr_interaction_fwd.
+ * 16-bit dtypes, width 16/32/64/128, n_emb <= 31. */
+int hctr_interaction_fwd_gather(size_t batch, int n_emb, int width, const void* mlp,
+                                const float* table, const uint64_t* value_index, void* pooled,
+                                void* out, int dtype, hctr_stream_t stream);
+/* the same on an embedding handle whose index stage has run (hctr_emb_index): its table, its
+ * value_index, its vector size and output type; world = 1, sum combiner (or mean: one key), the
+ * batch of `is_train`.  Timed as the handle's gather stage (hctr_emb_profile_get stage 0). */
+int hctr_emb_forward_interaction(hctr_embedding* e, int is_train, const void* mlp, void* pooled,
+                                 void* out, hctr_stream_t stream);
+
 /* MultiCrossLayer<T> v1 (projection_dim = 0): x_{l+1} = x0 * (x_l . w_l) + b_l + x_l
  * (R/HugeCTR/src/layers/multi_cross_layer.cu:582-601,1023-1060).  kernels/biases [layers][w];
  * outputs [layers][B][w] (outputs[layers-1] is the layer output), hiddens [layers][B]. */

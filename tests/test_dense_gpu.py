@@ -224,6 +224,49 @@ def test_interaction_indexed_equals_dense(dtype_name, B, n_emb, W):
     assert torch.equal(e1.grad, got["dE"])
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("B,S,D", [(300, 26, 128), (65, 5, 64), (129, 31, 32), (70, 7, 16)])
+def test_gather_fused_into_interaction_equals_pool_then_interaction(dtype_name, B, S, D):
+    """hctr_emb_forward_interaction (table rows read through value_index into the interaction's
+    tile, pooled vectors written once) == hctr_emb_forward + hctr_interaction_fwd, bit for bit:
+    pooled vectors, interaction output, both gradients; training batch (keys inserted) and an
+    evaluation batch with unseen keys (-> zeros)"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    dt = getattr(torch, dtype_name)
+    vps = 50
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.1, atomic_update=False)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, B, S * vps, D, S, S, 0, opt,
+                                 slot_size_array=[vps] * S, out_dtype=dt)
+    emb.init_params()
+    emb.table().normal_(0, 1)
+    emb.table()[3, :4] = torch.tensor([-0.0, 0.0, 1e-9, -1e-9], device="cuda")  # signed zeros, tiny
+    g = torch.Generator(device="cuda").manual_seed(B + S)
+    ro = torch.arange(B * S + 1, dtype=torch.int64, device="cuda")
+    off = torch.arange(S, device="cuda") * vps
+    for is_train, hi in ((True, vps - 5), (False, vps)):  # the eval batch meets unseen keys
+        keys = (torch.randint(0, hi, (B, S), device="cuda", generator=g) + off).reshape(-1)
+        mlp = torch.randn(B, D, device="cuda", generator=g).to(dt)
+        pooled = emb.forward(is_train, ro, keys).clone()
+        m1 = mlp.clone().requires_grad_()
+        e1 = pooled.clone().requires_grad_()
+        out_d = ha.interaction(m1, e1)
+        emb.index(is_train, ro, keys)
+        m2 = mlp.clone().requires_grad_()
+        got = {}
+        out_f = ha.interaction_gather(m2, emb, is_train, on_emb_grad=lambda d: got.update(dE=d))
+        assert torch.equal(out_f.view(torch.int16), out_d.view(torch.int16))
+        saved = out_f.grad_fn.saved_tensors[1]  # the pooled vectors the fused kernel wrote
+        assert torch.equal(saved.view(torch.int16), pooled.view(torch.int16))
+        top = torch.randn(out_d.shape, device="cuda", generator=g).to(dt)
+        out_d.backward(top)
+        out_f.backward(top)
+        assert torch.equal(m1.grad, m2.grad) and torch.equal(e1.grad, got["dE"])
+        if not is_train:
+            assert (pooled.float().abs().sum(-1) == 0).any(), "no evaluation miss in this batch"
+
+
 def test_fused_mlp_flat_mode_equals_parameter_mode():
     """flatten(): gradients written straight into the flat buffer and the fused SGD + shadow-refresh
     kernel give the same weights as torch.optim.SGD on the unflattened module"""
