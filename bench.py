@@ -550,6 +550,8 @@ def small_config_leg(cfg, steps, warmup, dev):
                                 "BASELINE configs[1]: DeepFM, Criteo-Kaggle slot sizes, "
                                 "DistributedSlotSparseEmbeddingHash, D=16, bs=16384, Adam Global"),
                    "surface": "hugectr_amd.hugectr Model.train()", "batch": B, "slots": 26,
+                   # solver.use_cuda_graph (default on): dense tower replayed from a HIP graph
+                   "hip_graph": getattr(m, "_graph", None) is not None,
                    "emb_dim": D, "table_rows_total": int(sum(slots)),
                    "max_vocabulary_size_per_gpu": h.get_max_vocabulary_size(),
                    "final_loss": m.get_current_loss()},

@@ -170,9 +170,12 @@ class EmbeddingCollection:
         lens = (br[1:] - br[:-1]).view(self.L_user, batch)
         starts = br[:-1].view(self.L_user, batch)
         ks, ls = [], []
+        # key range of every user lookup: ONE host read per step (not two per lookup)
+        bounds = br[0:self.L_user * batch + 1:batch].tolist() \
+            if any(not split for _, _, split in self._virt) else None
         for l, r, split in self._virt:
             if not split:
-                ks.append(keys[int(br[l * batch]):int(br[(l + 1) * batch])])
+                ks.append(keys[bounds[l]:bounds[l + 1]])
                 ls.append(lens[l])
             else:
                 m = lens[l] > r

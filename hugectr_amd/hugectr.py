@@ -467,6 +467,26 @@ class _FmOrder2(torch.nn.Module):
         return 0.5 * (v.sum(1) ** 2 - (v ** 2).sum(1))
 
 
+class _ScaleFn(torch.autograd.Function):
+    """Layer_t.Scale (R/HugeCTR/src/layers/scale_layer.cu:30-66): fprop repeats -- axis 0: every
+    element `factor` times in place ([B, n] -> [B, n * factor], out[j * factor + i] = in[j]);
+    axis 1: the row `factor` times side by side.  bprop is the reference's downscale_kernel: it
+    takes the gradient of the FIRST copy only (it does not sum over the copies)."""
+
+    @staticmethod
+    def forward(ctx, x, axis, factor):
+        ctx.axis, ctx.factor, ctx.n = axis, factor, x.shape[1]
+        if axis == 0:
+            return x.repeat_interleave(factor, dim=1)
+        return x.repeat(1, factor)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.axis == 0:
+            return g[:, ::ctx.factor].contiguous(), None, None
+        return g[:, :ctx.n].contiguous(), None, None
+
+
 class _WeightMultiply(torch.nn.Module):
     def __init__(self, slots, vec):
         super().__init__()
@@ -574,9 +594,15 @@ class Model:
     def compile(self, loss_names=None, loss_weights=None):
         """loss_names / loss_weights: the multi-task form (model_wrapper.hpp compile overload);
         one BinaryCrossEntropyLoss is what this surface trains, so they must name that loss"""
-        if loss_names is not None and len(list(loss_names)) > 1:
-            raise RuntimeError("multi-loss models are outside the hot-path scope of hugectr_amd")
         assert self.input is not None, "Model.add(Input(...)) first"
+        # multi-task models (R/samples/mmoe): one BinaryCrossEntropyLoss per label, the training
+        # loss is their weighted sum (Model::compile(loss_names, loss_weights), model.cpp)
+        self._loss_weights = {}
+        if loss_names is not None:
+            ws = list(loss_weights) if loss_weights is not None else [1.0] * len(list(loss_names))
+            if len(ws) != len(list(loss_names)):
+                raise RuntimeError("compile: loss_names and loss_weights differ in length")
+            self._loss_weights = {str(n): float(w) for n, w in zip(loss_names, ws)}
         s = self.solver
         B, Be = s.batchsize, s.batchsize_eval
         self.bpg, self.bpg_eval = B // self.world, Be // self.world
@@ -584,8 +610,9 @@ class Model:
         self.emb_dtype = torch.float16 if s.use_mixed_precision else torch.float32
         sp = {p.top_name: p for p in self.input.sparse_params}
         self._emb = {}
-        self._shapes: Dict[str, tuple] = {self.input.dense_name: (self.input.dense_dim,),
-                                          self.input.label_name: (self.input.label_dim,)}
+        self._shapes: Dict[str, tuple] = {self.input.dense_name: (self.input.dense_dim,)}
+        for n, d in zip(self.input.label_names, self.input.label_dims):
+            self._shapes[n] = (int(d),)
         for se in self.embeddings:
             p = sp[se.bottom_name]
             opt = self._emb_opt(se)
@@ -632,10 +659,20 @@ class Model:
         # dense modules
         self._mods = torch.nn.ModuleDict()
         self._loss_layer = None
+        self._loss_layers = []
         for i, L in enumerate(self.layers):
             self._build_layer(i, L)
         self._mods.to(self.device)
         self._dense_params = [p for p in self._mods.parameters()]
+        # solver.use_cuda_graph (graph_wrapper.cpp:30-41, default on): small batches are bound by
+        # launch latency, not by kernels -- the dense tower's forward, loss, backward and optimizer
+        # step are captured once into a HIP graph and replayed (one GPU, legacy embeddings, one loss;
+        # HCTR_HIP_GRAPH=0 keeps eager launches, =1 captures whatever the batch size)
+        env = os.environ.get("HCTR_HIP_GRAPH", "auto")
+        self._graph_ok = (bool(s.use_cuda_graph) and env != "0" and self.world == 1 and
+                          not self.ebc_configs and len(self._loss_layers) == 1 and
+                          (self.bpg <= 16384 or env == "1"))
+        self._graph, self._graph_wait = None, 0
         self._dense_opt = self._make_dense_opt()
         # Model.reader_override: anything with next_batch(train) / has_eval() handing out batches
         # in the readers' layout (data.py) -- bench.py serves batches resident in HBM this way
@@ -1009,8 +1046,12 @@ class Model:
             n_emb, W = self._shapes[L.bottom_names[1]]
             n_ins = n_emb + 1
             self._shapes[L.top_names[0]] = (W + n_ins * (n_ins - 1) // 2 + 1,)
+        elif t == Layer_t.Scale:
+            n = self._in_width(b0)
+            self._shapes[L.top_names[0]] = (n * int(L.factor),)
         elif t == Layer_t.BinaryCrossEntropyLoss:
             self._loss_layer = L
+            self._loss_layers = getattr(self, "_loss_layers", []) + [L]
         else:
             raise RuntimeError(f"Layer_t.{t.name} is outside the hot-path scope of hugectr_amd")
 
@@ -1020,7 +1061,8 @@ class Model:
         if not self._dense_params:
             return None
         if t == Optimizer_t.Adam:
-            return torch.optim.Adam(self._dense_params, lr=lr, betas=(o.beta1, o.beta2), eps=o.epsilon)
+            return torch.optim.Adam(self._dense_params, lr=lr, betas=(o.beta1, o.beta2), eps=o.epsilon,
+                                    capturable=bool(getattr(self, "_graph_ok", False)))
         if t == Optimizer_t.AdaGrad:
             return torch.optim.Adagrad(self._dense_params, lr=lr,
                                        initial_accumulator_value=o.initial_accu_value, eps=o.epsilon)
@@ -1037,6 +1079,7 @@ class Model:
         only the loss run its logit layer + BinaryCrossEntropyLoss + their backward as one pass;
         returns (logit or None, fused loss or None)"""
         logit, fused_loss = None, None
+        logits = tensors.setdefault("__logits__", [])
         for i, L in enumerate(self.layers):
             t, key = L.layer_type, f"l{i}"
             if t == Layer_t.BinaryCrossEntropyLoss and fused_loss is not None:
@@ -1054,6 +1097,12 @@ class Model:
                 y = torch.relu(x[0])
             elif t == Layer_t.Sigmoid:
                 y = torch.sigmoid(x[0])
+            elif t == Layer_t.Softmax:
+                y = torch.softmax(x[0].float(), dim=-1)
+            elif t == Layer_t.ELU:
+                y = torch.nn.functional.elu(x[0], L.elu_alpha)
+            elif t == Layer_t.Scale:
+                y = _ScaleFn.apply(x[0].reshape(x[0].shape[0], -1), int(L.axis), int(L.factor))
             elif t == Layer_t.Dropout:
                 y = torch.nn.functional.dropout(x[0], L.dropout_rate, training=train)
             elif t == Layer_t.Concat:
@@ -1094,6 +1143,7 @@ class Model:
             elif t == Layer_t.BinaryCrossEntropyLoss:
                 if fused_loss is None:
                     logit = x[0].float()
+                    logits.append((L, x[0], x[1]))
                 continue
             else:
                 raise RuntimeError(t)
@@ -1197,8 +1247,12 @@ class Model:
         after.append(finish)
 
     def _run_batch(self, batch, train: bool, nxt=None):
-        tensors = _Tensors({self.input.dense_name: batch["dense"],
-                            self.input.label_name: batch["label"]})
+        tensors = _Tensors({self.input.dense_name: batch["dense"]})
+        off = 0
+        for n, d in zip(self.input.label_names, self.input.label_dims):
+            tensors[n] = batch["label"] if len(self.input.label_names) == 1 else \
+                batch["label"][:, off:off + d]
+            off += d
         leaves, after = {}, []
         for name in self._emb:
             self._emb_forward(name, batch, nxt, train, tensors, leaves, after)
@@ -1238,11 +1292,26 @@ class Model:
         gscale = self.solver.scaler / (max(self.bpg, 1) * self.world)
         head = (label, gscale) if (train and self._head_layer is not None and
                                    label.shape[1] == 1) else None
+        multi = len(self._loss_layers) > 1
+        if multi:
+            head = None
         logit, loss = self._forward_dense(tensors, train, head)
-        if not train:
+        if multi:
+            # weighted sum of the tasks' losses; evaluation scores = every task's, side by side
+            total, probs = None, []
+            for L, lg, lab in tensors["__logits__"]:
+                w = self._loss_weights.get(L.bottom_names[1], 1.0)
+                li = torch.nn.functional.binary_cross_entropy_with_logits(lg.float(), lab.float())
+                total = li * w if total is None else total + li * w
+                probs.append(torch.sigmoid(lg.float()))
+            if not train:
+                return total, torch.cat(probs, dim=1)
+            (total * (self.solver.scaler / self.world)).backward()
+            loss = total
+        elif not train:
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
             return loss, torch.sigmoid(logit)
-        if loss is not None:        # logit layer + loss + their backward already done in one pass
+        elif loss is not None:      # logit layer + loss + their backward already done in one pass
             loss.backward()
         elif logit.is_cuda and label.shape == logit.shape:
             # fused BCE forward + logit gradient (two launches instead of ~20)
@@ -1260,8 +1329,94 @@ class Model:
         self._dense_step()
         return loss.detach().reshape(()), None
 
-    def _dense_step(self):
-        frozen = getattr(self, "_dense_frozen", False)
+    # -- HIP-graph replay of the dense tower (solver.use_cuda_graph) ---------------------------------
+    def _graph_dense(self, G, skip_step: bool):
+        """forward of the dense layers on the graph's static inputs, loss, backward, optimizer step"""
+        tensors = _Tensors({self.input.dense_name: G["dense"]})
+        tensors[self.input.label_names[0]] = G["label"]
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            if self._xstate[name]["fused_gather"]:
+                tensors[name] = _GatherEmb(h, True, lambda g, n=name: G["grads"].__setitem__(n, g))
+            else:
+                tensors[name] = G["leaf"][name]
+        gscale = self.solver.scaler / max(self.bpg, 1)
+        head = (G["label"], gscale) if (self._head_layer is not None and
+                                        G["label"].shape[1] == 1) else None
+        logit, loss = self._forward_dense(tensors, True, head)
+        if loss is not None:
+            loss.backward()
+        else:
+            lg = tensors[self._loss_layer.bottom_names[0]]
+            loss, dlogit = bce_with_logits(lg, G["label"], gscale)
+            lg.backward(dlogit)
+        for name, leaf in G["leaf"].items():
+            G["grads"][name] = leaf.grad
+        self._dense_step(skip=skip_step)
+        return loss.detach().reshape(())
+
+    def _graph_capture(self, batch):
+        B = self.bpg
+        G = {"lr": self._lr, "leaf": {}, "pooled": {}, "grads": {},
+             "dense": torch.empty_like(batch["dense"]),
+             "label": torch.empty_like(batch["label"].float())}
+        G["dense"].copy_(batch["dense"])
+        G["label"].copy_(batch["label"].float())
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            ro, keys = batch["sparse"][se.bottom_name]
+            if self._xstate[name]["fused_gather"]:
+                h.index(True, ro, keys)
+                continue
+            S = h.slots_on_rank if localized else p.slot_num
+            G["pooled"][name] = torch.empty((self.solver.batchsize, S, se.embedding_vec_size),
+                                            dtype=self.emb_dtype, device=self.device)
+            h.forward(True, ro, keys, out=G["pooled"][name])
+            G["leaf"][name] = G["pooled"][name].view(B, p.slot_num, se.embedding_vec_size) \
+                .requires_grad_(True)
+        # the kernels of this graph have all run eagerly in earlier iterations; two more passes on
+        # a side stream settle the allocator, without optimizer steps
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._graph_dense(G, skip_step=True)
+        torch.cuda.current_stream().wait_stream(side)
+        for leaf in G["leaf"].values():
+            leaf.grad = None
+        for q in self._dense_params:
+            q.grad = None
+        G["graph"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(G["graph"]):
+            G["loss"] = self._graph_dense(G, skip_step=False)
+        return G
+
+    def _graph_step(self, batch):
+        """one training step with the dense tower replayed from its HIP graph: the embedding's index
+        stage / gather in front of it and its backward + sparse update behind it stay eager launches
+        on the same stream (their sizes follow the data)"""
+        G = self._graph
+        fresh = G is None or G["lr"] != self._lr
+        if fresh:
+            G = self._graph = self._graph_capture(batch)
+        else:
+            for name, (se, p, h, ex, localized) in self._emb.items():
+                ro, keys = batch["sparse"][se.bottom_name]
+                if self._xstate[name]["fused_gather"]:
+                    h.index(True, ro, keys)
+                else:
+                    h.forward(True, ro, keys, out=G["pooled"][name])
+            G["dense"].copy_(batch["dense"])
+            G["label"].copy_(batch["label"])
+        G["graph"].replay()
+        for name, (se, p, h, ex, localized) in self._emb.items():
+            g = G["grads"][name]
+            if not self._xstate[name]["fused_gather"]:
+                g = ex["train"].backward(g.contiguous())  # (one GPU: a view)
+            h.backward(g.contiguous())
+            h.update_params()
+        return G["loss"]
+
+    def _dense_step(self, skip: bool = False):
+        frozen = getattr(self, "_dense_frozen", False) or skip
         if self._flat_mlps:
             if frozen:
                 return
@@ -1317,7 +1472,26 @@ class Model:
             # inter-iteration overlap: the next batch's keys are needed a step early
             nxt = self._lookahead = self.reader.next_batch(train=True)
         self.check_overflow(blocking=False)
-        loss, _ = self._run_batch(batch, True, nxt)
+        loss = None
+        if self._graph_ok and not getattr(self, "_dense_frozen", False):
+            # three eager steps first (and after every change of the learning rate): lazy
+            # initialisations -- optimizer state, GEMM selections, kernel modules -- happen there
+            if getattr(self, "_graph_lr", None) != self._lr:
+                self._graph_lr, self._graph_wait, self._graph = self._lr, 3, None
+            if self._graph_wait > 0:
+                self._graph_wait -= 1
+            else:
+                try:
+                    loss = self._graph_step(batch)
+                except Exception as e:  # capture is an optimisation: eager launches from here on
+                    if self._graph is not None:
+                        raise
+                    print(f"[HCTR][WARNING] HIP-graph capture failed ({e!r}); eager launches")
+                    self._graph_ok = False
+                    for q in self._dense_params:
+                        q.grad = None
+        if loss is None:
+            loss, _ = self._run_batch(batch, True, nxt)
         self._loss_t = loss.detach()
         self._iter += 1
         return True

@@ -28,6 +28,9 @@ SCRIPTS = {
     "dcn_parquet": ("samples/dcn/dcn_parquet.py", []),
     "deepfm_parquet": ("samples/deepfm/deepfm_parquet.py", []),
     "wdl_1gpu": ("samples/wdl/wdl_1gpu.py", []),
+    # BASELINE configs[4] names MMoE: two labels, two BinaryCrossEntropyLoss layers,
+    # compile(loss_names, loss_weights), Softmax gates, Scale / ElementwiseMultiply expert mixing
+    "mmoe_parquet": ("samples/mmoe/mmoe_parquet.py", []),
     "dgx_a100_one_hot": ("test/embedding_collection_test/dgx_a100_one_hot.py",
                          ["--num_gpus_per_node", "1", "--batchsize", "8192", "--batchsize_eval",
                           "8192", "--max_iter", "24", "--eval_interval", "12",

@@ -16,7 +16,7 @@ import pytest
 REF = "/root/reference"
 # dense layers of model families outside SURVEY 8 (DIN / BST / MMoE attention and sequence blocks)
 OUT_OF_SCOPE_LAYERS = {"FusedReshapeConcat", "LayerNorm", "MatrixMultiply", "MultiHeadAttention",
-                       "PReLU_Dice", "ReduceMean", "Scale", "SequenceMask"}
+                       "PReLU_Dice", "ReduceMean", "SequenceMask"}
 
 
 def _chain(node):

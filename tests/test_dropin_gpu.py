@@ -1,6 +1,7 @@
 """Drop-in boundary on the GPU: the exact calls the reference's own UNMODIFIED training scripts make
 (tests/golden/script_traces.json, recorded from R/samples/dcn/dcn_parquet.py,
 R/samples/deepfm/deepfm_parquet.py, R/samples/wdl/wdl_1gpu.py,
+R/samples/mmoe/mmoe_parquet.py (two tasks, two losses),
 R/test/embedding_collection_test/dgx_a100_one_hot.py and the MLPerf DLRM-DCNv2 sample
 R/samples/dlrm/train.py by tests/golden/make_script_traces.py) are
 executed against `import hugectr` -- this repo's module of the reference's name -- on an MI355X,
@@ -34,8 +35,11 @@ def _make_data(hugectr, calls, tmp_path):
     sizes = reader["slot_size_array"]
     fmt = reader["data_reader_type"]["name"]
     if fmt == "DataReaderType_t.Parquet":
+        inp = _find(calls, "Input")["kwargs"]
+        label_dim = sum(inp["label_dims"]) if "label_dims" in inp else inp.get("label_dim", 1)
         hugectr.tools.DataGenerator(hugectr.tools.DataGeneratorParams(
-            format=hugectr.DataReaderType_t.Parquet, label_dim=1, dense_dim=13,
+            format=hugectr.DataReaderType_t.Parquet, label_dim=label_dim,
+            dense_dim=inp.get("dense_dim", 13),
             num_slot=len(sizes), i64_input_key=bool(solver.get("i64_input_key", False)),
             source=reader["source"][0], eval_source=reader["eval_source"], slot_size_array=sizes,
             dist_type=hugectr.Distribution_t.PowerLaw, power_law_type=hugectr.PowerLaw_t.Short,
