@@ -269,6 +269,20 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     emb.profiling(False)
     m.check_overflow()
     new_keys = (emb.get_vocabulary_size() - rows_before) / max(steps, 1)
+    # the same stages with NO unseen key (batches the tables have met): the index stage's floor
+    steady_us = None
+    if world == 1:
+        m.reader = _CycleReader(batches[-4:])
+        m._lookahead = None
+        for _ in range(4):
+            m.train()
+        sync()
+        emb.profiling(True)
+        for _ in range(8):
+            m.train()
+        sync()
+        steady_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in emb.profile().items()}
+        emb.profiling(False)
     xrep = m.exchange_report()["sparse_embedding1"]
 
     # ---- roofline of the gather+pool kernel (DESIGN.md section 5 / SURVEY 8d) -------------------
@@ -385,6 +399,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                            "frac": (idx_bytes / idx_s / 1e9 / HBM_PEAK_GBPS) if idx_s > 0 else None,
                            "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6},
         "stage_us_per_step": stage_us,
+        "stage_us_per_step_no_new_keys": steady_us,
         "embedding_ms_per_step": sum(stage_us.values()) * 1e-3,
     }
     if per_rank is not None:

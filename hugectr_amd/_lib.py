@@ -165,6 +165,7 @@ _SIGNATURES = {
     "hctr_uniq_gather_rows": (c_int, [c_size_t, c_int, _P, _P, _P, c_int, _P]),
     "hctr_uniq_expand": (c_int, [c_size_t, c_int, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "hctr_interaction_fwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "hctr_ebc_scale_average": (c_int, [c_size_t, c_int, c_int, _P, _P, c_int, _P, c_int, c_int, _P]),
     "hctr_interaction_fwd_gather": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P]),
     "hctr_emb_forward_interaction": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "hctr_interaction_bwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int,

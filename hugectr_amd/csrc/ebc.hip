@@ -269,6 +269,35 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// One GPU, Average lookups: network_forward's receiver arithmetic applied IN PLACE to the pooled
+// sums the gather stored straight into the output (and network_backward's to the output's gradient):
+// the sum already rounded to the vector type, times 1 / (keys of the bucket), rounded again
+// (R/HugeCTR/embedding/operators/network_forward.cu:272-292, network_backward.cu).  Only the
+// vectors of Average lookups with more than one key are touched; the same bits as
+// ebc_network_vec_kernel leaves (which moves a vector of a single shard with scale 1 untouched).
+template <typename T, bool FWD>
+__global__ void __launch_bounds__(kBlock)
+    ebc_scale_average_kernel(size_t bpg, int num_lookup, int ev, const int* __restrict__ combiner,
+                             const long long* __restrict__ bucket_counts, int batch_major,
+                             T* __restrict__ data) {
+  const size_t total = (size_t)num_lookup * bpg * ev;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const int e = (int)(i % ev);
+    const size_t lb = i / ev;
+    const size_t b = lb % bpg;
+    const int l = (int)(lb / bpg);
+    if (combiner[l] != 1) continue;
+    const long long c = bucket_counts[(size_t)l * bpg + b];
+    if (c <= 1) continue;  // scale 1: the vector moves as it is
+    const float scale = 1.0f / (float)c;
+    T* p = data + (batch_major ? (b * (size_t)num_lookup + l) * ev + e
+                               : ((size_t)l * bpg + b) * ev + e);
+    const float v = ld_as_f32<T>(p);
+    st_from_f32<T>(p, FWD ? (0.f + v) * scale : v * scale);
+  }
+}
+
 // 16-byte vector form (ev * sizeof(T) % 16 == 0, 16-byte aligned buffers): one thread moves
 // 16 B of one (lookup, sample) vector; arithmetic only where a scale or a shard sum is needed
 template <typename T>
@@ -683,6 +712,38 @@ static int ebc_network(bool fwd, size_t bpg, int num_lookup, int ev, int max_sha
     HCTR_REQUIRE(false, "dtype");
   }
 #undef HCTR_NET
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_ebc_scale_average(size_t batch_per_gpu, int num_lookup, int ev_size,
+                           const int32_t* d_combiner, const int64_t* d_bucket_counts,
+                           int batch_major, void* data, int dtype, int forward,
+                           hctr_stream_t stream) {
+  const size_t total = (size_t)num_lookup * batch_per_gpu * ev_size;
+  if (total == 0) return HCTR_OK;
+  HCTR_REQUIRE(d_combiner && d_bucket_counts && data, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const int grid = grid_for(total, kBlock, 8192);
+#define HCTR_SCALE(T)                                                                          \
+  if (forward)                                                                                 \
+    hipLaunchKernelGGL((ebc_scale_average_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s,    \
+                       batch_per_gpu, num_lookup, ev_size, d_combiner,                         \
+                       (const long long*)d_bucket_counts, batch_major, (T*)data);              \
+  else                                                                                         \
+    hipLaunchKernelGGL((ebc_scale_average_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s,   \
+                       batch_per_gpu, num_lookup, ev_size, d_combiner,                         \
+                       (const long long*)d_bucket_counts, batch_major, (T*)data);
+  if (dtype == HCTR_EMB_F32) {
+    HCTR_SCALE(float)
+  } else if (dtype == HCTR_EMB_F16) {
+    HCTR_SCALE(__half)
+  } else if (dtype == HCTR_EMB_BF16) {
+    HCTR_SCALE(__hip_bfloat16)
+  } else {
+    HCTR_REQUIRE(false, "dtype");
+  }
+#undef HCTR_SCALE
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -51,7 +51,7 @@ struct HashTable {
   // device scalars
   uint64_t* d_counter = nullptr;    // value head (next row index)
   uint64_t* d_base = nullptr;       // counter snapshot used by the current get_insert
-  uint32_t* d_pending = nullptr;    // != 0 when the current batch holds unseen keys
+  uint32_t* d_pending = nullptr;    // positions of the current batch that hold an unseen key
   uint32_t* d_latched = nullptr;    // d_pending as seen by the scan step of this get_insert
   uint32_t* d_error = nullptr;      // bit0: probe overflow (table full) bit1: counter > capacity
   uint64_t* d_new_count = nullptr;  // number of keys inserted by the last get_insert
@@ -60,7 +60,11 @@ struct HashTable {
   uint32_t* d_barrier = nullptr;    // {arrived, generation} of the finish kernel's grid barrier
   uint32_t* tile_sums = nullptr;   // [ceil(max_n / kHtTile) + 1] (+ kHtFinishBlocks block totals)
   uint64_t* new_positions = nullptr;  // [max_n] positions (into keys) of newly inserted keys
-  unsigned long long* fin_masks = nullptr;  // [max_n / 64 + 2] first-occurrence masks (finish)
+  unsigned long long* fin_masks = nullptr;  // 2 x [mask_words] first-occurrence masks + prefixes
+  size_t mask_words = 0;
+  uint32_t* region_cnt = nullptr;   // [2048] first occurrences per region of positions (finish)
+  uint32_t* pend_list = nullptr;    // [max_n] positions of the batch whose key was not in the table
+  uint32_t* d_parity = nullptr;     // which mask buffer the next inserting batch takes
   uint64_t* d_scratch64 = nullptr;  // 1 element
 
   int create(size_t capacity, int key_type);

@@ -58,15 +58,17 @@ __global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
 }
 
 // one key, the full protocol: probe (linear), claim an empty slot for an unseen key, hand back the
-// row or the pending marker (see the header of this file)
+// row or the pending marker (see the header of this file).  A position left pending is appended to
+// the workgroup's LDS list (the finish kernel works on the list of pending positions only).
 template <typename K>
 __device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
                                                     K key, size_t i, uint64_t* __restrict__ out,
-                                                    uint32_t* d_pending, uint32_t* d_error) {
+                                                    uint32_t* d_error, uint32_t* s_cnt,
+                                                    uint32_t* s_pos) {
   const long long empty = KeyTraits<K>::empty;
   const long long k64 = widen<K>(key);
   uint64_t slot = (uint64_t)murmur3_key(key) % size;
-  bool ok = false;
+  bool ok = false, claimed = false;
   for (uint64_t probes = 0; probes < size; ++probes) {
     long long cur = tab[slot].key;
     if (cur == k64) {
@@ -78,6 +80,7 @@ __device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, u
                                          (unsigned long long)empty, (unsigned long long)k64);
       if (old == (unsigned long long)empty || old == (unsigned long long)k64) {
         ok = true;
+        claimed = old == (unsigned long long)empty;
         break;
       }
     }
@@ -88,14 +91,18 @@ __device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, u
     out[i] = kInvalidIndex;
     return;
   }
-  unsigned long long v = tab[slot].val;
-  if (v < kPendingBit) {
-    out[i] = row_of(v);
-  } else {
-    atomicMin(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
-    out[i] = kPendingBit | slot;
-    *d_pending = 1u;  // benign race: all writers store 1
+  if (!claimed) {  // (a slot this thread has just claimed holds no row yet: no read needed)
+    const unsigned long long v = tab[slot].val;
+    if (v < kPendingBit) {
+      out[i] = row_of(v);
+      return;
+    }
   }
+  // no-return atomic: nothing waits for it
+  (void)__hip_atomic_fetch_min(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  out[i] = kPendingBit | slot;
+  s_pos[atomicAdd(s_cnt, 1u)] = (uint32_t)i;
 }
 
 // Steady state = every key is in the table and sits in its home slot or close to it, so the
@@ -108,31 +115,38 @@ template <typename K>
 __global__ void __launch_bounds__(kBlock)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
-                           uint32_t* d_pending, uint32_t* d_error, const K* __restrict__ ro_src,
+                           uint32_t* d_list_count, uint32_t* __restrict__ d_list,
+                           uint32_t* d_error, const K* __restrict__ ro_src,
                            K* __restrict__ ro_dst, size_t n_offsets,
                            uint32_t* __restrict__ one_hot) {
+  __shared__ uint32_t s_cnt, s_base;
+  __shared__ uint32_t s_pos[kBlock * kHtUnroll];
   const size_t nl = live_count(d_n, n);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
+  const size_t gtid = blockIdx.x * (size_t)kBlock + threadIdx.x;
   if (ro_src != nullptr) {
     // the caller's private copy of the row offsets; lengths all 1 and ro[0] == 0  <=>
     // ro[i] == i for every i: otherwise the gather must not take its offset-free one-hot loop
     bool bad = false;
-    for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n_offsets; i += nthreads) {
+    for (size_t i = gtid; i < n_offsets; i += nthreads) {
       const K v = ro_src[i];
       ro_dst[i] = v;
       bad |= v != (K)i;
     }
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
   }
-  for (size_t i0 = blockIdx.x * (size_t)kBlock + threadIdx.x; i0 < nl;
-       i0 += nthreads * kHtUnroll) {
+  // (trip count uniform over the workgroup: it meets at barriers inside the loop)
+  for (size_t base = 0; base < nl; base += nthreads * kHtUnroll) {
+    const size_t i0 = base + gtid;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
     K key[kHtUnroll];
     uint64_t slot[kHtUnroll];
     ulonglong2 ent[kHtUnroll];
 #pragma unroll
     for (int u = 0; u < kHtUnroll; u++) {
       const size_t i = i0 + (size_t)u * nthreads;
-      key[u] = keys[i < nl ? i : i0];
+      key[u] = keys[i < nl ? i : 0];
       slot[u] = (uint64_t)murmur3_key(key[u]) % size;
     }
 #pragma unroll
@@ -144,15 +158,19 @@ __global__ void __launch_bounds__(kBlock)
       if (i >= nl) continue;
       if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
         out[i] = row_of(ent[u].y);
-      else
-        ht_probe_insert_one<K>(tab, size, key[u], i, out, d_pending, d_error);
+      else  // (issuing the four keys' claims together was measured: no gain with 4 % unseen keys,
+            //  and the steady state lost 5 us to the extra registers)
+        ht_probe_insert_one<K>(tab, size, key[u], i, out, d_error, &s_cnt, s_pos);
     }
+    __syncthreads();
+    const uint32_t cnt = s_cnt;
+    if (cnt != 0u) {  // this workgroup's pending positions -> the batch's list (one atomic)
+      if (threadIdx.x == 0) s_base = atomicAdd(d_list_count, cnt);
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) d_list[s_base + k] = s_pos[k];
+    }
+    __syncthreads();
   }
-}
-
-__device__ __forceinline__ bool is_first_occurrence(const HtEntry* tab, uint64_t o, size_t i) {
-  if (o < kPendingBit || o == kInvalidIndex) return false;
-  return tab[o & ~kPendingBit].val == (kPendingBit | (uint64_t)i);
 }
 
 // single workgroup: exclusive scan of sums[0..m) in place, total -> *d_total (uint64)
@@ -213,15 +231,19 @@ __device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos
 
 // ---- get_insert, launch 2 ------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
-constexpr int kFinUnroll = 4;
+constexpr int kFinRegions = 2048;  // (their bases live in LDS: 8 KB)
 constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises error bit 2^2)
 
 struct FinishCtl {
-  uint32_t *pending, *latched, *error, *barrier;
+  uint32_t *list_count, *latched, *error, *barrier;
   uint64_t *counter, *base, *new_count;
-  uint32_t* block_tot;          // [gridDim.x] first occurrences per workgroup region
-  unsigned long long* masks;    // [ceil(n / 64)] first-occurrence masks
-  uint32_t* gprefix;            // [ceil(n / 64)] firsts of the group's region in front of it
+  const uint32_t* list;         // positions whose key was not in the table (unordered)
+  uint32_t* region_cnt;         // 2 x [kFinRegions] first occurrences per region (as masks2)
+  // two buffers of [mask_words] first-occurrence masks: buffer *parity is all zero on entry and
+  // takes this batch's bits, the other one is zeroed here for the next batch that inserts
+  unsigned long long* masks2;
+  uint32_t* parity;
+  size_t mask_words;
   uint32_t* one_hot_next;
   uint64_t *host_rows, *host_seq;
   uint64_t seq;
@@ -238,24 +260,40 @@ __device__ __forceinline__ void post_to_host(const FinishCtl& c, uint64_t rows) 
   }
 }
 
+// Data that crosses workgroups inside the finish kernel (masks, group prefixes, region counts)
+// moves through agent-scope atomic loads / stores: they are coherent at the memory side, so the
+// barrier itself needs no cache write-back / invalidate (an agent-scope release fence writes the
+// XCD's whole L2 back -- measured ~20 us per barrier with the probe kernel's 14 MB of fresh
+// stores sitting there).
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // all workgroups of the grid are resident (grid <= kHtFinishBlocks, far below what 256 CUs hold):
-// sense-reversing barrier on {arrived, generation}
+// sense-reversing barrier on {arrived, generation}.  __syncthreads: every wave has waited for
+// its (write-through) stores before thread 0 arrives.
 __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
-  __threadfence();
   __syncthreads();
   __shared__ uint32_t ok;
   if (threadIdx.x == 0) {
     ok = 1u;
-    const uint32_t gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t gen = ld_agent(bar + 1);
+    __builtin_amdgcn_s_waitcnt(0);  // (the generation is read before this workgroup arrives)
     const uint32_t old =
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == nblocks - 1u) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      st_agent(bar, 0u);
+      __builtin_amdgcn_s_waitcnt(0);  // (the count is back at zero before anybody is released)
+      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       uint32_t spins = 0;
-      while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(2);
+      while (ld_agent(bar + 1) == gen) {
+        __builtin_amdgcn_s_sleep(1);
         if (++spins > kSpinLimit) {
           ok = 0u;
           break;
@@ -264,7 +302,6 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
     }
   }
   __syncthreads();
-  __threadfence();
   return ok != 0u;
 }
 
@@ -272,7 +309,8 @@ __global__ void __launch_bounds__(kFinBlock)
     ht_finish_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
                      const uint64_t* d_n, FinishCtl c, uint64_t* __restrict__ new_positions,
                      SlotIdSink sink, uint64_t capacity) {
-  if (*c.pending == 0u) {  // steady state: no unseen key in this batch
+  const uint32_t P = *c.list_count;  // (workgroup 0 resets it only behind the first barrier)
+  if (P == 0u) {  // steady state: no unseen key in this batch
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const uint64_t cnt = *c.counter;
       *c.latched = 0u;
@@ -283,130 +321,101 @@ __global__ void __launch_bounds__(kFinBlock)
     return;
   }
   __shared__ uint32_t smem[kFinBlock / 64 + 1];
-  const uint64_t c0 = *c.counter;  // (workgroup 0 moves it only behind the barrier)
+  const uint64_t c0 = *c.counter;  // (workgroup 0 moves it only behind the barriers)
   const size_t nl = live_count(d_n, n);
   const uint32_t G = gridDim.x, b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = kFinBlock / 64;
-  // region of this workgroup: `per` consecutive positions (a multiple of the block size), wave w
-  // takes the 64-position groups w, w + NW, ... of it
-  size_t per = (nl + G - 1) / G;
-  per = (per + kFinBlock - 1) / kFinBlock * kFinBlock;
-  const size_t r0 = (size_t)b * per < nl ? (size_t)b * per : nl;
-  const size_t r1 = r0 + per < nl ? r0 + per : nl;
-  // ---- A: masks of first occurrences; per 64-position group the number of first occurrences of
-  //         this region in front of it; count of the region -----------------------------------------
-  // (kFinUnroll groups per wavefront in flight: every load is unconditional on a clamped address,
-  //  so the position -> slot -> value round trips of the groups overlap instead of queueing up)
-  for (size_t g0 = r0 + (size_t)wave * 64; g0 < r1; g0 += (size_t)NW * 64 * kFinUnroll) {
-    uint64_t o[kFinUnroll], v[kFinUnroll];
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const size_t i = g0 + (size_t)u * NW * 64 + lane;
-      o[u] = out[i < r1 ? i : r0];
-    }
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
-      v[u] = tab[pend ? (o[u] & ~kPendingBit) : 0ull].val;
-    }
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const size_t gu = g0 + (size_t)u * NW * 64;
-      const size_t i = gu + lane;
-      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
-      const bool f = i < r1 && pend && v[u] == (kPendingBit | (uint64_t)i);
-      const unsigned long long m = __ballot(f);
-      if (lane == 0 && gu < r1) c.masks[gu >> 6] = m;
-    }
+  const size_t gtid = (size_t)b * kFinBlock + threadIdx.x, gthreads = (size_t)G * kFinBlock;
+  const uint32_t par = *c.parity & 1u;  // (workgroup 0 flips it only behind the barriers)
+  unsigned long long* const masks = c.masks2 + (size_t)par * c.mask_words;
+  {  // the other mask buffer is nobody's at the moment: all zero for the next inserting batch
+    unsigned long long* const other = c.masks2 + (size_t)(1u - par) * c.mask_words;
+    for (size_t w = gtid; w < c.mask_words; w += gthreads) other[w] = 0ull;
+    if (gtid < (size_t)kFinRegions) c.region_cnt[(1u - par) * kFinRegions + gtid] = 0u;
   }
-  __syncthreads();  // (the masks of this region are this workgroup's own writes)
-  {
-    const size_t gf = r0 >> 6, ng = (r1 - r0 + 63) >> 6;
-    uint32_t run = 0u;
-    for (size_t g0 = 0; g0 < ng; g0 += kFinBlock) {
-      const size_t g = g0 + threadIdx.x;
-      const uint32_t v = g < ng ? (uint32_t)__popcll(c.masks[gf + g]) : 0u;
-      uint32_t tot;
-      const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &tot);
-      if (g < ng) c.gprefix[gf + g] = run + ex;
-      run += tot;
+  uint32_t* const region_cnt = c.region_cnt + par * kFinRegions;  // (zero on entry, like masks)
+  // regions of `per` consecutive positions (a multiple of 64, at most kFinRegions of them)
+  size_t per = (nl + kFinRegions - 1) / kFinRegions;
+  per = (per + 63) / 64 * 64;
+  const uint32_t R = (uint32_t)((nl + per - 1) / per);
+  // ---- A: the pending positions that hold the FIRST occurrence of their key set their bit and
+  //         count themselves into their region --------------------------------------------------
+  for (size_t k = gtid; k < P; k += gthreads) {
+    const uint64_t i = c.list[k];
+    const uint64_t slot = out[i] & ~kPendingBit;
+    if (tab[slot].val == (kPendingBit | i)) {
+      atomicOr(&masks[i >> 6], 1ull << (i & 63));
+      atomicAdd(&region_cnt[i / per], 1u);
     }
-    if (threadIdx.x == 0) c.block_tot[b] = run;
   }
   if (!grid_barrier(c.barrier, G)) {
     if (threadIdx.x == 0) atomicOr(c.error, 4u);
     return;
   }
-  // ---- S: base of every region; workgroup 0 hands out the row range ---------------------------
+  // ---- S: every workgroup scans the region counts (into LDS); workgroup 0 hands out the row
+  //         range ------------------------------------------------------------------------------------
+  __shared__ uint32_t region_base[kFinRegions];
   {
-    const uint32_t v = threadIdx.x < G ? c.block_tot[threadIdx.x] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &total);
-    if (threadIdx.x < G) c.block_tot[G + threadIdx.x] = ex;  // every workgroup writes the same
-    if (b == 0 && threadIdx.x == 0) {
-      *c.base = c0;
-      *c.new_count = total;
-      // more unseen keys than free rows: the counter stops at the capacity, the keys beyond it
-      // get no row (they pool as zeros and are skipped by the update, like an eval miss), and
-      // error bit 1 makes check_overflow() fail as the reference's does
-      // (localized_slot_sparse_embedding_hash.hpp:552-569) -- nothing is read or written outside
-      // the [capacity] row arrays
-      const uint64_t head = (c0 + total > capacity) ? capacity : c0 + total;
-      *c.counter = head;
-      if (c0 + total > capacity) atomicOr(c.error, 2u);
-      *c.latched = 1u;
-      *c.pending = 0u;
-      post_to_host(c, head);
+    uint32_t run = 0u;
+    for (uint32_t r0 = 0; r0 < R; r0 += kFinBlock) {
+      const uint32_t r = r0 + threadIdx.x;
+      const uint32_t v = r < R ? ld_agent(&region_cnt[r]) : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &tot);
+      if (r < R) region_base[r] = run + ex;
+      run += tot;
     }
+    const uint32_t total = run;
     __syncthreads();
+    if (b == 0) {
+      if (threadIdx.x == 0) {
+        *c.base = c0;
+        *c.new_count = total;
+        // more unseen keys than free rows: the counter stops at the capacity, the keys beyond it
+        // get no row (they pool as zeros and are skipped by the update, like an eval miss), and
+        // error bit 1 makes check_overflow() fail as the reference's does
+        // (localized_slot_sparse_embedding_hash.hpp:552-569) -- nothing is read or written
+        // outside the [capacity] row arrays
+        const uint64_t head = (c0 + total > capacity) ? capacity : c0 + total;
+        *c.counter = head;
+        if (c0 + total > capacity) atomicOr(c.error, 2u);
+        *c.latched = 1u;
+        *c.list_count = 0u;
+        *c.parity = 1u - par;
+        post_to_host(c, head);
+      }
+    }
   }
-  const uint32_t* base_of = c.block_tot + G;
   // ---- D: rows.  rank of a first position fp = firsts in the regions before its own + firsts of
-  //         its own region in front of its group + firsts of its group below it ---------------------
-  for (size_t i0 = r0 + threadIdx.x; i0 < r1; i0 += (size_t)kFinBlock * kFinUnroll) {
-    uint64_t o[kFinUnroll], v[kFinUnroll], mk[kFinUnroll];
-    uint32_t gp[kFinUnroll], bs[kFinUnroll];
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const size_t i = i0 + (size_t)u * kFinBlock;
-      o[u] = out[i < r1 ? i : r0];
+  //         its own region in front of it (mask words, a few tens at most) -------------------------
+  for (size_t k = gtid; k < P; k += gthreads) {
+    const uint64_t i = c.list[k];
+    const uint64_t slot = out[i] & ~kPendingBit;
+    const uint64_t v = tab[slot].val;
+    if (v < kPendingBit) {  // the key's first occurrence has already published the row
+      out[i] = row_of(v);
+      continue;
     }
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
-      v[u] = tab[pend ? (o[u] & ~kPendingBit) : 0ull].val;
+    const uint64_t fp = v & ~kPendingBit;
+    const uint32_t r = (uint32_t)(fp / per);
+    const size_t w0 = ((size_t)r * per) >> 6, wf = fp >> 6;
+    uint32_t rank = region_base[r] +
+                    (uint32_t)__popcll(ld_agent(&masks[wf]) & ((1ull << (fp & 63)) - 1ull));
+    for (size_t w = w0; w < wf; w += 4) {  // (independent loads, clamped: four in flight)
+      const unsigned long long m0 = ld_agent(&masks[w]);
+      const unsigned long long m1 = ld_agent(&masks[w + 1 < wf ? w + 1 : w]);
+      const unsigned long long m2 = ld_agent(&masks[w + 2 < wf ? w + 2 : w]);
+      const unsigned long long m3 = ld_agent(&masks[w + 3 < wf ? w + 3 : w]);
+      rank += (uint32_t)__popcll(m0) + (w + 1 < wf ? (uint32_t)__popcll(m1) : 0u) +
+              (w + 2 < wf ? (uint32_t)__popcll(m2) : 0u) +
+              (w + 3 < wf ? (uint32_t)__popcll(m3) : 0u);
     }
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
-      const bool need = pend && v[u] >= kPendingBit;  // else: the row is already published
-      const uint64_t fp = need ? (v[u] & ~kPendingBit) : 0ull;
-      gp[u] = c.gprefix[fp >> 6];
-      mk[u] = c.masks[fp >> 6];
-      bs[u] = base_of[(uint32_t)(fp / per)];
-    }
-#pragma unroll
-    for (int u = 0; u < kFinUnroll; u++) {
-      const size_t i = i0 + (size_t)u * kFinBlock;
-      const bool pend = o[u] >= kPendingBit && o[u] != kInvalidIndex;
-      if (i >= r1 || !pend) continue;
-      if (v[u] < kPendingBit) {  // the key's first occurrence has already published the row
-        out[i] = row_of(v[u]);
-        continue;
-      }
-      const uint64_t fp = v[u] & ~kPendingBit;
-      const uint32_t rank =
-          bs[u] + gp[u] + (uint32_t)__popcll(mk[u] & ((1ull << (fp & 63)) - 1ull));
-      uint64_t fin = c0 + rank;
-      if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
-      out[i] = fin;
-      if (i == fp) {
-        const uint64_t slot = o[u] & ~kPendingBit;
-        tab[slot].val = fin == kInvalidIndex ? kNoRow : fin;
-        new_positions[rank] = (uint64_t)i;
-        if (sink.slot_id != nullptr && fin != kInvalidIndex) record_slot_id(sink, (uint64_t)i, fin);
-      }
+    uint64_t fin = c0 + rank;
+    if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
+    out[i] = fin;
+    if (i == fp) {
+      tab[slot].val = fin == kInvalidIndex ? kNoRow : fin;
+      new_positions[rank] = i;
+      if (sink.slot_id != nullptr && fin != kInvalidIndex) record_slot_id(sink, i, fin);
     }
   }
 }
@@ -563,6 +572,7 @@ int HashTable::create(size_t cap, int kt) {
   d_error = reinterpret_cast<uint32_t*>(scal + 4) + 1;
   d_latched = reinterpret_cast<uint32_t*>(scal + 5);
   d_barrier = reinterpret_cast<uint32_t*>(scal + 6);
+  d_parity = reinterpret_cast<uint32_t*>(scal + 7);
   HCTR_HIP(hipMemset(scal, 0, 64));
   return clear(nullptr);
 }
@@ -573,7 +583,9 @@ int HashTable::destroy() {
   if (tile_sums) (void)hipFree(tile_sums);
   if (new_positions) (void)hipFree(new_positions);
   if (fin_masks) (void)hipFree(fin_masks);
+  if (pend_list) (void)hipFree(pend_list);
   fin_masks = nullptr;
+  pend_list = nullptr;
   entries = nullptr;
   d_counter = nullptr;
   tile_sums = nullptr;
@@ -588,6 +600,8 @@ int HashTable::clear(hipStream_t s) {
                      size, empty);
   HCTR_LAUNCH_CHECK();
   HCTR_HIP(hipMemsetAsync(d_counter, 0, 64, s));
+  if (fin_masks)
+    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4, s));
   return HCTR_OK;
 }
 
@@ -598,10 +612,16 @@ int HashTable::reserve(size_t n) {
   if (tile_sums) (void)hipFree(tile_sums);
   if (new_positions) (void)hipFree(new_positions);
   if (fin_masks) (void)hipFree(fin_masks);
+  if (pend_list) (void)hipFree(pend_list);
   // (+ the finish kernel's per-workgroup counts and their scan)
   HCTR_HIP(hipMalloc(&tile_sums, (need_tiles + 2 * kHtFinishBlocks) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&new_positions, (n > 0 ? n : 1) * sizeof(uint64_t)));
-  HCTR_HIP(hipMalloc(&fin_masks, (n / 64 + 2) * (sizeof(unsigned long long) + sizeof(uint32_t))));
+  mask_words = n / 64 + 2;
+  HCTR_HIP(hipMalloc(&fin_masks, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
+  HCTR_HIP(hipMemset(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
+  region_cnt = reinterpret_cast<uint32_t*>(fin_masks + 2 * mask_words);
+  HCTR_HIP(hipMemset(d_parity, 0, sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&pend_list, (n > 0 ? n : 1) * sizeof(uint32_t)));
   max_n = n;
   return HCTR_OK;
 }
@@ -634,31 +654,34 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, 1 << 16);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const uint32_t*)keys, n, d_n, out, d_pending, d_error,
+                       size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, d_error,
                        (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst, x.n_offsets, x.one_hot);
   } else {
     hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const long long*)keys, n, d_n, out, d_pending, d_error,
+                       size, (const long long*)keys, n, d_n, out, d_pending, pend_list, d_error,
                        (const long long*)x.ro_src, (long long*)x.ro_dst, x.n_offsets, x.one_hot);
   }
   HCTR_LAUNCH_CHECK();
   FinishCtl c;
-  c.pending = d_pending;
+  c.list_count = d_pending;
+  c.list = pend_list;
   c.latched = d_latched;
   c.error = d_error;
   c.barrier = d_barrier;
   c.counter = d_counter;
   c.base = d_base;
   c.new_count = d_new_count;
-  c.block_tot = tile_sums + ceil_div<size_t>(max_n > size ? max_n : size, kHtTile) + 1;
-  c.masks = fin_masks;
-  c.gprefix = reinterpret_cast<uint32_t*>(fin_masks + (max_n / 64 + 2));
+  c.region_cnt = region_cnt;
+  c.masks2 = fin_masks;
+  c.parity = d_parity;
+  c.mask_words = mask_words;
   c.one_hot_next = x.one_hot_next;
   c.host_rows = x.host_rows;
   c.host_seq = x.host_seq;
   c.seq = x.seq;
   c.host_error = x.host_error;
-  // few positions: fewer workgroups (every one of them takes part in the barrier)
+  HCTR_REQUIRE(n < 0xFFFFFFFFull, "get_insert: more than 2^32 - 1 keys in one call");
+  // few positions: fewer workgroups (every one of them takes part in the barriers)
   size_t fg = ceil_div<size_t>(n, (size_t)kFinBlock * 4);
   if (fg > (size_t)kHtFinishBlocks) fg = kHtFinishBlocks;
   if (fg < 1) fg = 1;

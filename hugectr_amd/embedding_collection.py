@@ -345,8 +345,11 @@ class EmbeddingCollection:
         # staged path (tests compare the two).
         self._multi_hot = max_hotness > 1
         self._direct = (self.world == 1 and self.n_local == self.L
-                        and all(c == 0 for c in self.combiner)
                         and os.environ.get("HCTR_EBC_DIRECT", "1") != "0")
+        # Average lookups on the direct path: the gather stores SUMS, the receiver arithmetic of
+        # network_forward / network_backward is applied in place to the Average
+        # lookups' vectors (hctr_ebc_scale_average)
+        self._direct_avg = self._direct and any(c == 1 for c in self.combiner)
         self._map_on = False
         self.d_one_hot = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
@@ -407,7 +410,7 @@ class EmbeddingCollection:
         if self._virt is not None and gbucket_range.numel() == self.L_user * self.B + 1:
             gkeys, gbucket_range = self._expand_csr(gkeys, gbucket_range, self.B)
         kt = _lib.KEY_I64 if gkeys.dtype == torch.int64 else _lib.KEY_U32
-        if not direct:  # bucket lengths of my samples: the Average divisor of network_*
+        if not direct or self._direct_avg:  # bucket lengths of my samples: the Average divisor
             check(lib.hctr_ebc_bucket_counts(self.B, self.world, self.rank, self.L,
                                              ptr(gbucket_range), kt, ptr(self.counts),
                                              stream_ptr()))
@@ -426,7 +429,7 @@ class EmbeddingCollection:
                                            ptr(self.indices), ptr(self.d_nnz), ptr(self.d_one_hot),
                                            int(gkeys.numel()), stream_ptr()))
             if self.dynamic:  # (row_start < 0: the pass kept the raw keys)
-                return self._dynamic_pool(send, True)
+                return self._scale_average(self._dynamic_pool(send, True), True)
             self._nnz_host = int(gkeys.numel())
             bm = self.batch_major
             check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
@@ -435,7 +438,7 @@ class EmbeddingCollection:
                                                1 if self._multi_hot else 0, self.bpg if bm else 0,
                                                self.L if bm else 0, ptr(self.d_one_hot),
                                                stream_ptr()))
-            return send
+            return self._scale_average(send, True)
         check(lib.hctr_ebc_route_keys(self.B, self.world, self.n_local, ptr(self.d_desc),
                                       ptr(self.d_row_start), ptr(gkeys), ptr(gbucket_range), kt,
                                       ptr(self.out_range), ptr(self.indices), ptr(self.d_nnz),
@@ -447,6 +450,14 @@ class EmbeddingCollection:
                                     ptr(self.indices), ptr(self.table), ptr(send),
                                     _DT[self.out_dtype], stream_ptr()))
         return send
+
+    def _scale_average(self, data: torch.Tensor, forward: bool) -> torch.Tensor:
+        if self._direct_avg and data.numel():
+            check(lib.hctr_ebc_scale_average(self.bpg, self.L, self.ev, ptr(self.d_combiner),
+                                             ptr(self.counts), 1 if self.batch_major else 0,
+                                             ptr(data), _DT[self.out_dtype], 1 if forward else 0,
+                                             stream_ptr()))
+        return data
 
     def forward_global(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor) -> torch.Tensor:
         """replicated global feature-major CSR -> this rank's output rows"""
@@ -618,6 +629,8 @@ class EmbeddingCollection:
 
     def backward_and_update(self, grad: torch.Tensor):
         if self._direct:  # the gradient of the output is the gradient of my buckets
+            if self._direct_avg:  # (in place when the caller's tensor is contiguous: it is ours)
+                grad = self._scale_average(grad.contiguous(), False)
             return self.apply_gradients(grad, True)
         send = self.network_backward(grad)
         top = self._a2a(send, self.recv_counts, self.send_counts)

@@ -307,6 +307,15 @@ int hctr_ebc_route_whole(size_t batch, int num_lookups, const int64_t* row_start
 int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,
                            const void* bucket_range, int key_type, int64_t* counts,
                            hctr_stream_t stream);
+/* One GPU (nothing to exchange): the Average arithmetic of NetworkForward (forward != 0: the
+ * pooled sum, already rounded to the vector type, times 1 / bucket key count, rounded again --
+ * network_forward.cu:272-292) or of NetworkBackward (forward == 0) applied in place to the
+ * [lookup][b][ev] / [b][lookup][ev] output (its gradient); vectors of Sum lookups and of buckets
+ * with at most one key are not touched. */
+int hctr_ebc_scale_average(size_t batch_per_gpu, int num_lookup, int ev_size,
+                           const int32_t* d_combiner, const int64_t* d_bucket_counts,
+                           int batch_major, void* data, int dtype, int forward,
+                           hctr_stream_t stream);
 /* NetworkForward / NetworkBackward: blocks of [batch_per_gpu][ev] vectors, one per (source rank,
  * its local lookup); d_src_blocks[l * max_shards + s] = block of shard s of lookup l or -1.
  * out / grad layout: feature-major [lookup][b][ev] or batch-major [b][lookup][ev]. */

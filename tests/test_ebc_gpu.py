@@ -464,13 +464,17 @@ def test_multi_hot_concat_combiner(oracle, world):
 
 @pytest.mark.parametrize("batch_major", [False, True])
 @pytest.mark.parametrize("max_hot", [1, 5])
+@pytest.mark.parametrize("combiners", [["sum"] * 5, ["sum", "mean", "mean", "sum", "mean"]])
 @pytest.mark.parametrize("opt_name,dtype", [("sgd", "float32"), ("adagrad", "bfloat16"),
                                             ("ftrl", "float16")])
-def test_one_gpu_direct_path_equals_staged(monkeypatch, batch_major, max_hot, opt_name, dtype):
-    """One GPU, sum lookups: pooling straight into the output (transposed store for batch-major) and
+def test_one_gpu_direct_path_equals_staged(monkeypatch, batch_major, max_hot, opt_name, dtype,
+                                           combiners):
+    """One GPU: pooling straight into the output (transposed store for batch-major) and
     the update reading the output's gradient in place must reproduce, bit for bit, the staged
     route -> pool -> network_forward / network_backward -> update path the reference runs
-    (R/HugeCTR/embedding/model_parallel_embedding.cpp forward_per_gpu / backward_per_gpu)."""
+    (R/HugeCTR/embedding/model_parallel_embedding.cpp forward_per_gpu / backward_per_gpu) --
+    Average lookups included: their receiver-side division (network_forward.cu:272-292)
+    is applied in place to the pooled sums, its mirror to the gradient."""
     import torch
     import hugectr_amd as ha
     from hugectr_amd import _lib
@@ -481,7 +485,7 @@ def test_one_gpu_direct_path_equals_staged(monkeypatch, batch_major, max_hot, op
     tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
     cfg = ha.EmbeddingCollectionConfig()
     for l, t in enumerate(lookup_table):
-        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", "sum")
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", combiners[l])
     opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "ftrl": _lib.OPT_FTRL}[opt_name]
     kw = dict(lr=0.1, optimizer=opt, scaler=4.0, epsilon=1e-6, batch_major=batch_major,
               max_hotness=max_hot, ftrl=(0.02, 0.05, 0.3), out_dtype=getattr(torch, dtype), seed=3)
@@ -506,10 +510,7 @@ def test_one_gpu_direct_path_equals_staged(monkeypatch, batch_major, max_hot, op
         assert torch.equal(staged.table, direct.table), step
         if staged.accum is not None:
             assert torch.equal(staged.accum, direct.accum), step
-    # an Average lookup keeps the staged path (its divisor lives in network_forward)
-    cfg2 = ha.EmbeddingCollectionConfig()
-    cfg2.embedding_lookup(tcfg[0], "i", "o", "mean")
-    assert not ha.EmbeddingCollection.for_rank(0, 1, cfg2, B, **kw)._direct
+    assert direct._direct_avg == ("mean" in combiners)
 
 
 def test_forward_pool_mapped_rejects_bad_shapes():

@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-anchor = sys.argv[2] if len(sys.argv) > 2 else "pool_vec4"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "ht_probe_insert"
 idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 a, b = idx[-2], idx[-1]
 t0 = int(rows[a]["Start_Timestamp"])
