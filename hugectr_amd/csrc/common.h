@@ -22,6 +22,7 @@ constexpr uint64_t kInvalidIndex = ~0ull;  // std::numeric_limits<size_t>::max()
     if (e__ != hipSuccess) {                                                             \
       ::hctr::set_error(std::string(#call) + ": " + hipGetErrorString(e__) + " at " +    \
                         __FILE__ + ":" + std::to_string(__LINE__));                      \
+      (void)hipGetLastError(); /* reported: a later launch check must not see it again */ \
       return HCTR_ERR_HIP;                                                               \
     }                                                                                    \
   } while (0)

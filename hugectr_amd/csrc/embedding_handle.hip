@@ -590,6 +590,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
     hipError_t er = hipMalloc((void**)&(ptr), (bytes));                                \
     if (er != hipSuccess) {                                                            \
       set_error(std::string("hipMalloc(" #ptr "): ") + hipGetErrorString(er));         \
+      (void)hipGetLastError();                                                         \
       return fail(HCTR_ERR_HIP);                                                       \
     }                                                                                  \
   } while (0)

@@ -14,10 +14,10 @@ from collections import defaultdict
 
 
 def short(name):
-    """hctr::(anonymous namespace)::pool_vec4_kernel<32, 4, long long, __half>(...) -> pool_vec4_kernel"""
-    n = name.split("(anonymous namespace)::")[-1]
-    n = n.split("hctr::")[-1]
-    return re.split(r"[<(\s]", n, maxsplit=1)[0]
+    """void hctr::(anonymous namespace)::pool_vec4_kernel<32, 4, long long, __half>(...) ->
+    pool_vec4_kernel (the FIRST qualified name: parameter types carry the namespace too)"""
+    m = re.match(r"\s*(?:void\s+)?(?:hctr::)?(?:\(anonymous namespace\)::)?([A-Za-z_]\w*)", name)
+    return m.group(1) if m else name
 
 
 def collect(path, counter):
