@@ -1794,7 +1794,15 @@ int hctr_interaction_fwd_gather(size_t batch, int n_emb, int width, const void* 
   const int n_ins = n_emb + 1;
   const int out_len = width + n_ins * (n_ins - 1) / 2 + 1;
   const int stage_len = (out_len + 7) & ~7;
-  const size_t gmax = (size_t)256 * (size_t)inter_waves_per_cu(0);
+  // resident wavefronts per CU: every one keeps a sample's rows (14 x 16 B per lane) in flight,
+  // and with random rows an iteration lasts as long as that round trip -- more waves, more of
+  // them overlapped (HCTR_GATHER_WAVES overrides)
+  static const int waves = [] {
+    const char* e = getenv("HCTR_GATHER_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 8;
+  }();
+  const size_t gmax = (size_t)256 * (size_t)waves;
   const int grid1 = (int)(batch < gmax ? batch : gmax);
   const bool bf = dtype == HCTR_EMB_BF16;
 #define HCTR_IFG16(W_)                                                                          \

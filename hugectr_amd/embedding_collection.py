@@ -393,6 +393,40 @@ class EmbeddingCollection:
         torch.cumsum(glens, 0, out=gbr[1:])
         return torch.cat(out), gbr
 
+    def _a2a_async(self, buf, send_counts, recv_counts):
+        """-> (receive buffer, work or None): the collective runs on the communicator's stream while
+        the caller keeps launching; work.wait() orders the current stream behind it"""
+        if self.world == 1 or not dist.is_initialized():
+            return buf, None
+        out = torch.empty(sum(recv_counts), dtype=buf.dtype, device=self.dev)
+        from .parallel import all_to_all_single
+        work = all_to_all_single(out, buf.reshape(-1), recv_counts, send_counts, group=self.group,
+                                 async_op=True)
+        return out, work
+
+    # -- the model-parallel exchange in two halves (hugectr.Model, train_intra_iteration_overlap:
+    #    ebc_mp_model_forward / ebc_mp_network_forward on their own stream while the bottom MLP
+    #    runs, R/HugeCTR/src/pybind/model_pipeline.cpp:299-346) -----------------------------------
+    def forward_global_begin(self, gkeys: torch.Tensor, gbucket_range: torch.Tensor):
+        send = self.route_and_pool(gkeys, gbucket_range, False)
+        recv, work = self._a2a_async(send, self.send_counts, self.recv_counts)
+        return recv, work, send  # (send stays alive until the collective has read it)
+
+    def forward_global_finish(self, recv: torch.Tensor, work) -> torch.Tensor:
+        if work is not None:
+            work.wait()
+        return self.network_forward(recv)
+
+    def backward_begin(self, grad: torch.Tensor):
+        send = self.network_backward(grad)
+        top, work = self._a2a_async(send, self.recv_counts, self.send_counts)
+        return top, work, send
+
+    def backward_finish(self, top: torch.Tensor, work):
+        if work is not None:
+            work.wait()
+        self.apply_gradients(top)
+
     def _a2a(self, buf, send_counts, recv_counts):
         if self.world == 1 or not dist.is_initialized():
             return buf

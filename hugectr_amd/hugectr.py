@@ -990,6 +990,46 @@ class Model:
             return e.forward(gk, gbr)
         return e.forward_global(gk, gbr)
 
+    def _ebc_begin(self, rt, batch, train: bool, after):
+        """starts the forward of one collection; returns a (memoising) function that hands out its
+        output [batch/world, lookups, ev] -- for training a leaf whose gradient `after` consumes.
+        N > 1 GPUs + train_intra_iteration_overlap: the all-to-all of the pooled vectors is
+        asynchronous and waited for by the first dense layer that reads the output, the gradient
+        all-to-all starts from inside backward."""
+        e = rt["train"] if train else rt["eval"]
+        box = {}
+        use_async = (train and self._intra and isinstance(e, EmbeddingCollection) and
+                     not e._direct and batch.get("ebc") is not None)
+        if not use_async:
+            E = self._ebc_forward(rt, batch, train)
+            if train:
+                E = E.detach().requires_grad_(True)
+
+                def finish(E=E):
+                    rt["train"].lr = self._lr
+                    rt["train"].backward_and_update(E.grad.contiguous())
+                after.append(finish)
+            return lambda: E
+        gk, gbr = batch["ebc"][rt["index"]]
+        recv, work, keep = e.forward_global_begin(gk, gbr)
+
+        def on_grad(g):
+            box["back"] = e.backward_begin(g.contiguous())
+
+        def get_E():
+            if "E" not in box:
+                box["E"] = e.forward_global_finish(recv, work).detach().requires_grad_(True)
+                box["E"].register_hook(on_grad)
+                box["keep"] = keep
+            return box["E"]
+
+        def finish():
+            e.lr = self._lr
+            top, w, _ = box.pop("back")
+            e.backward_finish(top, w)
+        after.append(finish)
+        return get_E
+
     def _in_width(self, name):
         shp = self._shapes[name]
         n = 1
@@ -1258,33 +1298,35 @@ class Model:
         for name in self._emb:
             self._emb_forward(name, batch, nxt, train, tensors, leaves, after)
         for i, rt in enumerate(self._ebc):
-            E = self._ebc_forward(rt, batch, train)
-            if train:
-                E = E.detach().requires_grad_(True)
-                leaves[("ebc", i)] = E
+            get_E = self._ebc_begin(rt, batch, train, after)
             cfg = rt["parent"]
+            span = getattr(rt["train"], "virt_span", None)
+
+            def piece(v0, reps, get_E=get_E, as_float=False):
+                def resolve():
+                    E = get_E()
+                    x = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
+                    return x.float() if as_float else x
+                return _Pending(resolve)
             if rt["whole"]:
                 if cfg.top_name:
-                    tensors[cfg.top_name] = E
+                    tensors[cfg.top_name] = _Pending(get_E)
                 else:
-                    span = getattr(rt["train"], "virt_span", None)
                     for l, (_, _, top, _) in enumerate(cfg.lookups):
                         v0, reps = span[l] if span else (l, 1)
-                        tensors[top] = E[:, v0, :] if reps == 1 else \
-                            E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
+                        tensors[top] = piece(v0, reps)
             else:  # one of several collections of a mixed-size config
-                span = getattr(rt["train"], "virt_span", None)
                 for j, l in enumerate(rt["ids"]):
                     v0, reps = span[j] if span else (j, 1)
-                    Ej = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
                     if cfg.top_name:
-                        tensors[(id(cfg), l)] = Ej.float()
+                        tensors[(id(cfg), l)] = piece(v0, reps, as_float=True)
                     else:
-                        tensors[cfg.lookups[l][2]] = Ej
+                        tensors[cfg.lookups[l][2]] = piece(v0, reps)
         for cfg in self.ebc_configs:
-            if cfg.top_name and (id(cfg), 0) in tensors:
-                tensors[cfg.top_name] = torch.cat(
-                    [tensors.pop((id(cfg), l)) for l in range(len(cfg.lookups))], dim=1)
+            if cfg.top_name and dict.__contains__(tensors, (id(cfg), 0)):
+                n = len(cfg.lookups)
+                tensors[cfg.top_name] = _Pending(
+                    lambda cfg=cfg, n=n: torch.cat([tensors[(id(cfg), l)] for l in range(n)], dim=1))
         label = batch["label"].float()
         # the logit gradient is (sigmoid - y) * scaler / batch_per_gpu / total_gpu_count
         # (BinaryCrossEntropy_Kernel, R/HugeCTR/src/loss.cu:242-249): every gradient below --
@@ -1324,9 +1366,6 @@ class Model:
             (loss * (self.solver.scaler / self.world)).backward()
         for fin in after:
             fin()
-        for i, rt in enumerate(self._ebc):
-            rt["train"].lr = self._lr
-            rt["train"].backward_and_update(leaves[("ebc", i)].grad.contiguous())
         self._dense_step()
         return loss.detach().reshape(()), None
 
