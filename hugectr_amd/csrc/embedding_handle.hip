@@ -341,6 +341,20 @@ int exclusive_scan_lens(hctr_embedding* e, void* ro_dst, size_t n, hipStream_t s
   return exclusive_scan_to_offsets<K>((const K*)e->lens, n, e->tile_sums, e->d_nnz, (K*)ro_dst, s);
 }
 
+// row-count bound for the sort's key width (SparseUpdater::row_bound): the counter after a past
+// batch q (posted by its index stage's finish kernel) + every key enqueued since.  Called when the
+// index stage is enqueued (a side-stream presort needs a bound then) and again by update_params,
+// when this batch's own post has usually landed and the bound is exact.
+void refresh_row_bound(hctr_embedding* e) {
+  const uint64_t q = *(volatile uint64_t*)(e->h_rows + 1);  // sequence number first ...
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const uint64_t rows = *(volatile uint64_t*)e->h_rows;     // ... rows at least that new
+  if (q >= e->min_valid_seq && q <= e->seq && e->seq - q < (uint64_t)hctr_embedding::kSeqRing)
+    e->upd.row_bound = rows + (e->cum_total - e->cum_keys[q % hctr_embedding::kSeqRing]);
+  else
+    e->upd.row_bound = 0;  // unknown: the sort takes the full key width
+}
+
 // returns (via *ro_out / *keys_out) the CSR this rank resolves
 template <typename K>
 int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, const K* ro_in,
@@ -462,18 +476,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
       x.seq = e->seq;
       x.host_error = e->h_err;
       HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s, &sink, &x));
-      // row-count bound for the sort's key width (SparseUpdater::row_bound): the counter after a
-      // past batch q (posted by its finish kernel) + every key enqueued since
-      {
-        const uint64_t q = *(volatile uint64_t*)(e->h_rows + 1);  // sequence number first ...
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        const uint64_t rows = *(volatile uint64_t*)e->h_rows;     // ... rows at least that new
-        if (q >= e->min_valid_seq && e->seq - q < (uint64_t)hctr_embedding::kSeqRing)
-          e->upd.row_bound =
-              rows + (e->cum_total - e->cum_keys[q % hctr_embedding::kSeqRing]);
-        else
-          e->upd.row_bound = 0;  // unknown: the sort takes the full key width
-      }
+      refresh_row_bound(e);
     } else {
       HCTR_TRY(e->ht.get_mark(keys, nnz, d_n, bb.value_index, s));
     }
@@ -822,6 +825,7 @@ int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
     e->nnz_pending = false;
   }
   e->opt.times++;  // update_params(): adam.times++ before the update (…hash.hpp:346-347)
+  if (e->seq > 0) refresh_row_bound(e);
   e->upd.scale_row_offset = e->tb.ro_full;  // NULL unless distributed + mean + N > 1
   const int rc = e->upd.update(e->cur_buckets, nnz, e->p.combiner, e->ro, e->p.key_type,
                                e->value_index, e->top_grad, e->p.out_dtype, e->opt, e->table,

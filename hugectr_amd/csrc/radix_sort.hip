@@ -29,16 +29,19 @@ constexpr int kRsWaves = kRsBlock / 64;
 constexpr int kRsRounds = 16;                       // keys per lane
 constexpr int kRsWaveKeys = 64 * kRsRounds;         // 1024 consecutive keys per wavefront
 constexpr int kRsTile = kRsWaveKeys * kRsWaves;     // 4096
-constexpr int kRsBits = 10;
-constexpr int kRsBins = 1 << kRsBits;
+// digit width: 10 bits, or 11 when that saves a whole pass (keys of 21-22 bits: a table that has
+// handed out fewer than 4 M rows -- two passes instead of three)
+constexpr int kRsMaxBits = 11;
+constexpr int kRsMaxBins = 1 << kRsMaxBits;
 constexpr int kRsScanBlock = 1024;                  // colscan: 32 tile chunks x 32 digit values
 constexpr int kRsScanBins = 32;
 
 // lanes of this wavefront that hold the same digit as mine (valid lanes only): ten ballots
+template <int BITS>
 __device__ __forceinline__ unsigned long long rs_match(uint32_t d, bool valid) {
   unsigned long long m = __ballot(valid);
 #pragma unroll
-  for (int bit = 0; bit < kRsBits; bit++) {
+  for (int bit = 0; bit < BITS; bit++) {
     const bool one = ((d >> bit) & 1u) != 0u;
     const unsigned long long bal = __ballot(one);
     m &= one ? bal : ~bal;
@@ -46,9 +49,11 @@ __device__ __forceinline__ unsigned long long rs_match(uint32_t d, bool valid) {
   return m;
 }
 
+template <int BITS>
 __global__ void __launch_bounds__(kRsBlock)
     rs_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
                    uint32_t* __restrict__ hist) {
+  constexpr int kRsBins = 1 << BITS;
   __shared__ uint32_t h[kRsBins];
   for (int b = threadIdx.x; b < kRsBins; b += kRsBlock) h[b] = 0u;
   __syncthreads();
@@ -79,8 +84,10 @@ __global__ void __launch_bounds__(kRsBlock)
 }
 
 // hist[t][b] <- sum of hist[t'][b] over t' < t, for the 32 digit values of this workgroup
+template <int BITS>
 __global__ void __launch_bounds__(kRsScanBlock)
     rs_colscan_kernel(uint32_t* __restrict__ hist, size_t tiles, uint32_t* __restrict__ total) {
+  constexpr int kRsBins = 1 << BITS;
   constexpr int kChunks = kRsScanBlock / kRsScanBins;
   __shared__ uint32_t part[kChunks][kRsScanBins];
   const int c = threadIdx.x % kRsScanBins, q = threadIdx.x / kRsScanBins;
@@ -104,31 +111,37 @@ __global__ void __launch_bounds__(kRsScanBlock)
   if (q == kChunks - 1) total[b] = run;  // keys of this digit value in all tiles
 }
 
+// MASK: the lanes of a round that share a digit are found through a per-wavefront LDS lane mask
+// per digit value (10-bit digits: 32 KB of masks fit beside the tile); otherwise with BITS ballots
+// (11-bit digits: the masks would halve the resident workgroups)
+template <int BITS, bool MASK>
 __global__ void __launch_bounds__(kRsBlock)
     rs_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                       uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, size_t n,
                       int shift, const uint32_t* __restrict__ tile_offs,
                       const uint32_t* __restrict__ total) {
+  constexpr int kRsBins = 1 << BITS;
+  constexpr int kPerThread = kRsBins / kRsBlock;  // digit values per thread in the offset step
   // The tile is first sorted INSIDE LDS (stable, by this digit), then streamed out: consecutive
   // threads write consecutive sorted elements, and elements of one digit value are consecutive
   // in the output too, so the stores of a digit run coalesce.  (Storing each key straight from
   // the ranking loop -- one 4-byte store per lane to 64 unrelated lines -- cost 19 of the 33 us.)
   __shared__ uint32_t wh[kRsWaves][kRsBins];  // per-wavefront digit counters, then local cursors
   __shared__ int32_t delta[kRsBins];          // global position - local position, per digit value
-  // 32 KB used twice: while ranking, per wavefront one 64-bit lane mask per digit value (the
+  // used twice: while ranking (MASK), per wavefront one 64-bit lane mask per digit value (the
   // lanes of a round that hold it: built with ds_or, read back, cleared by the group's first
   // lane -- three LDS operations instead of ten ballots and ~80 vector instructions per round);
   // afterwards the tile's sorted keys and values
-  constexpr int kStage = kRsTile > kRsWaves * kRsBins ? kRsTile : kRsWaves * kRsBins;
+  constexpr int kStage = (MASK && kRsWaves * kRsBins > kRsTile) ? kRsWaves * kRsBins : kRsTile;
   __shared__ unsigned long long stage[kStage];
   uint32_t* lkey = reinterpret_cast<uint32_t*>(stage);
   uint32_t* lval = lkey + kRsTile;
-  volatile unsigned long long* mm = stage + (size_t)(threadIdx.x >> 6) * kRsBins;
+  volatile unsigned long long* mm = stage + (size_t)(threadIdx.x >> 6) * (MASK ? kRsBins : 0);
   __shared__ uint32_t scan_smem[kRsBlock / 64 + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < kRsWaves * kRsBins; i += kRsBlock) {
     (&wh[0][0])[i] = 0u;
-    stage[i] = 0ull;
+    if (MASK) stage[i] = 0ull;
   }
   const size_t tile_base = (size_t)blockIdx.x * kRsTile;
   const size_t base = tile_base + (size_t)wave * kRsWaveKeys + lane;
@@ -147,27 +160,33 @@ __global__ void __launch_bounds__(kRsBlock)
     const bool valid = base + (size_t)r * 64 < n;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
     unsigned long long m = 0ull;
-    // LDS operations of one wavefront complete in issue order; the wave barriers keep the
-    // COMPILER from moving the OR, the read-back and the clear across each other (they sit in
-    // divergent branches it could otherwise reschedule)
-    if (valid) atomicOr(const_cast<unsigned long long*>(&mm[d]), 1ull << lane);
-    __builtin_amdgcn_wave_barrier();
-    if (valid) m = mm[d];
-    __builtin_amdgcn_wave_barrier();
+    if (MASK) {
+      // LDS operations of one wavefront complete in issue order; the wave barriers keep the
+      // COMPILER from moving the OR, the read-back and the clear across each other (they sit in
+      // divergent branches it could otherwise reschedule)
+      if (valid) atomicOr(const_cast<unsigned long long*>(&mm[d]), 1ull << lane);
+      __builtin_amdgcn_wave_barrier();
+      if (valid) m = mm[d];
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      m = rs_match<BITS>(d, valid);
+      if (!valid) m = 0ull;
+    }
     const uint32_t rank = (uint32_t)__popcll(m & lt), cnt = (uint32_t)__popcll(m);
     info[r] = rank | (cnt << 8);
     if (valid && rank == 0u) {
-      mm[d] = 0ull;
+      if (MASK) mm[d] = 0ull;
       atomicAdd(&wh[wave][d], cnt);
     }
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();  // (the masks are all zero again: stage becomes the sorted tile)
-  // per digit value (4 per thread): keys of this tile, global first position, local first position
-  uint32_t c4[4], t4[4], cs = 0u, ts = 0u;
+  // per digit value (kPerThread per thread): keys of this tile, global first position, local
+  // first position
+  uint32_t c4[kPerThread], t4[kPerThread], cs = 0u, ts = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int b = threadIdx.x * 4 + j;
+  for (int j = 0; j < kPerThread; j++) {
+    const int b = threadIdx.x * kPerThread + j;
     c4[j] = 0u;
 #pragma unroll
     for (int w = 0; w < kRsWaves; w++) c4[j] += wh[w][b];
@@ -179,8 +198,8 @@ __global__ void __launch_bounds__(kRsBlock)
   uint32_t lex = block_exclusive_scan<uint32_t, kRsBlock>(cs, scan_smem, &all);  // local
   uint32_t gex = block_exclusive_scan<uint32_t, kRsBlock>(ts, scan_smem, &all);  // global
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int b = threadIdx.x * 4 + j;
+  for (int j = 0; j < kPerThread; j++) {
+    const int b = threadIdx.x * kPerThread + j;
     delta[b] = (int32_t)(gex + tile_offs[(size_t)blockIdx.x * kRsBins + b]) - (int32_t)lex;
     uint32_t run = lex;
     lex += c4[j];
@@ -226,15 +245,49 @@ __global__ void __launch_bounds__(kRsBlock)
 
 }  // namespace
 
+// digit width of a sort of end_bit-bit keys: 11 bits where that saves a pass over 10-bit digits
+static int radix_sort_bits(int end_bit) {
+  const int p10 = (end_bit + 9) / 10, p11 = (end_bit + 10) / 11;
+  return p11 < p10 ? 11 : 10;
+}
+
 int radix_sort_passes(int end_bit) {
-  int p = (end_bit + kRsBits - 1) / kRsBits;
+  const int bits = radix_sort_bits(end_bit);
+  int p = (end_bit + bits - 1) / bits;
   return p < 1 ? 1 : p;
 }
 
 size_t radix_sort_temp_bytes(size_t n) {
   const size_t tiles = ceil_div<size_t>(n > 0 ? n : 1, (size_t)kRsTile);
-  return 2 * n * sizeof(uint32_t) + tiles * kRsBins * sizeof(uint32_t) +
-         4 * kRsBins * sizeof(uint32_t) + 256;
+  return 2 * n * sizeof(uint32_t) + tiles * kRsMaxBins * sizeof(uint32_t) +
+         4 * kRsMaxBins * sizeof(uint32_t) + 256;
+}
+
+template <int BITS, bool MASK>
+static int radix_sort_run(uint32_t* ktmp, uint32_t* vtmp, uint32_t* hist, uint32_t* total,
+                          const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                          size_t n, size_t tiles, int passes, hipStream_t s) {
+  constexpr int kRsBins = 1 << BITS;
+  const uint32_t* sk = kin;
+  const uint32_t* sv = vin;
+  for (int p = 0; p < passes; p++) {
+    const bool to_out = ((passes - 1 - p) % 2) == 0;  // the last pass lands in the caller's buffers
+    uint32_t* dk = to_out ? kout : ktmp;
+    uint32_t* dv = to_out ? vout : vtmp;
+    const int shift = p * BITS;
+    hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3((unsigned)tiles), dim3(kRsBlock), 0, s, sk, n,
+                       shift, hist);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rs_colscan_kernel<BITS>, dim3(kRsBins / kRsScanBins), dim3(kRsScanBlock), 0,
+                       s, hist, tiles, total);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((rs_scatter_kernel<BITS, MASK>), dim3((unsigned)tiles), dim3(kRsBlock), 0, s,
+                       sk, sv, dk, dv, n, shift, hist, total);
+    HCTR_LAUNCH_CHECK();
+    sk = dk;
+    sv = dv;
+  }
+  return HCTR_OK;
 }
 
 int radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
@@ -254,28 +307,12 @@ int radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uin
   uint32_t* ktmp = (uint32_t*)temp;
   uint32_t* vtmp = ktmp + n;
   uint32_t* hist = vtmp + n;
-  uint32_t* total = hist + tiles * kRsBins;
-  const uint32_t* sk = kin;
-  const uint32_t* sv = vin;
-  for (int p = 0; p < passes; p++) {
-    const bool to_out = ((passes - 1 - p) % 2) == 0;  // the last pass lands in the caller's buffers
-    uint32_t* dk = to_out ? kout : ktmp;
-    uint32_t* dv = to_out ? vout : vtmp;
-    const int shift = p * kRsBits;
-    uint32_t* tot = total;
-    hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(kRsBlock), 0, s, sk, n, shift,
-                       hist);
-    HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rs_colscan_kernel, dim3(kRsBins / kRsScanBins), dim3(kRsScanBlock), 0, s,
-                       hist, tiles, tot);
-    HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(kRsBlock), 0, s, sk, sv, dk,
-                       dv, n, shift, hist, tot);
-    HCTR_LAUNCH_CHECK();
-    sk = dk;
-    sv = dv;
-  }
-  return HCTR_OK;
+  uint32_t* total = hist + tiles * kRsMaxBins;
+  if (radix_sort_bits(end_bit) == 11)
+    return radix_sort_run<11, false>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, tiles,
+                                     passes, s);
+  return radix_sort_run<10, true>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, tiles, passes,
+                                  s);
 }
 
 }  // namespace hctr

@@ -27,7 +27,10 @@ def _sort(keys, vals, end_bit):
 @pytest.mark.parametrize("n,end_bit,dist", [
     (0, 10, "u"), (1, 5, "u"), (63, 10, "u"), (64, 11, "u"), (4095, 20, "u"), (4096, 20, "u"),
     (4097, 21, "u"), (100_003, 29, "u"), (100_003, 32, "u"), (50_000, 9, "u"), (50_000, 30, "few"),
-    (1_703_936, 29, "pow"), (1_703_936, 29, "pad"), (300_000, 19, "pow")])
+    (1_703_936, 29, "pow"), (1_703_936, 29, "pad"), (300_000, 19, "pow"),
+    # 21-22 and 31-32 bits: two / three passes of 11-bit digits (ballot matching)
+    (1_703_936, 22, "pow"), (1_703_936, 22, "pad"), (1_703_936, 21, "u"), (200_000, 31, "u"),
+    (70_000, 22, "few")])
 def test_radix_sort_is_the_stable_sort(n, end_bit, dist):
     rng = np.random.default_rng(n + end_bit)
     hi = (1 << end_bit) - 1
