@@ -68,6 +68,38 @@ def test_forward_bit_exact(oracle, D, combiner, one_hot, key_bytes):
     assert emb.get_vocabulary_size() == ht.size()
 
 
+@pytest.mark.parametrize("D,combiner", [(128, 0), (16, 1)])
+def test_one_hot_and_multi_hot_batches_alternate_on_one_handle(oracle, D, combiner):
+    """The index stage keeps TWO one-hot flags and presets the next batch's from its finish kernel
+    (no memset launch): a handle that meets one-hot, ragged multi-hot, one-hot, an evaluation batch
+    and one-hot again must take the right gather loop every time -- rows and pooled vectors
+    bit-equal to the oracle at every step, new keys arriving at every step."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(5 + D)
+    B, S, hot, vps = 96, 7, 4, 300
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, B, S * vps, D, S * hot, S, combiner,
+                                 ha.OptParams())
+    emb.init_params()
+    table = emb.table().cpu().numpy().copy()
+    ht = oracle.HashTable(S * vps, 8)
+    for step, (train, one_hot) in enumerate([(True, True), (True, False), (True, True),
+                                             (False, False), (True, True), (True, False),
+                                             (True, False), (False, True), (True, True)]):
+        ro, keys = make_csr(rng, B, S, hot, vps, one_hot=one_hot)
+        out = emb.forward(train, _t(torch, ro, torch.int64), _t(torch, keys, torch.int64))
+        vi = ht.get_insert(keys) if train else ht.get_mark(keys)
+        if train:
+            got_vi = emb.value_index(keys.size).cpu().numpy().view(np.uint64)
+            assert (got_vi == vi).all(), (step, "row indices differ from the sequential oracle")
+        want = oracle.forward(ro, vi, table, D, combiner)
+        got = out.cpu().numpy().reshape(-1, D)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), (step, train, one_hot)
+    assert emb.get_vocabulary_size() == ht.size()
+    emb.poll_overflow()
+
+
 def test_forward_empty_batch_of_keys(oracle):
     import torch
     import hugectr_amd as ha
