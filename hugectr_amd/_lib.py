@@ -170,6 +170,8 @@ _SIGNATURES = {
     "hctr_emb_forward_interaction": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "hctr_interaction_bwd_indexed": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int,
                                              _P]),
+    "hctr_interaction_bwd_indexed_scatter": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P,
+                                                     c_int, _P]),
     "hctr_updater_set_ftrl": (c_int, [_P, c_float, c_float, c_float]),
     "hctr_updater_set_grad_map": (c_int, [_P, c_size_t, c_size_t]),
     "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,

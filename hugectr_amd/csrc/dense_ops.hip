@@ -433,7 +433,10 @@ __global__ void __launch_bounds__(64, 2)
                              const uint32_t* __restrict__ row_of,
                              const unsigned short* __restrict__ top_grad,
                              unsigned short* __restrict__ mlp_grad,
-                             unsigned short* __restrict__ emb_grad, int out_len) {
+                             unsigned short* __restrict__ emb_grad, int out_len,
+                             const uint32_t* __restrict__ grad_map) {
+  // grad_map != nullptr: the gradient of embedding s of sample b goes to row
+  // grad_map[b * n_emb + s] of emb_grad (the all-to-all send layout: no reorder pass behind it)
   using C = InterCfg16<W>;
   using H = H16<BF>;
   constexpr int GS = 40;  // G row stride (16-bit elements): 80 B -> 16 distinct 16-B slots
@@ -555,8 +558,11 @@ __global__ void __launch_bounds__(64, 2)
             o4[e] = (unsigned)H::from_f32(a0) | ((unsigned)H::from_f32(a1) << 16);
           }
           mg4[c8] = o4;
-        } else {
+        } else if (grad_map == nullptr) {
           eg4[i - W8] = v;
+        } else {
+          const uint32_t dst = grad_map[b * (size_t)n_emb + (row - 1)];
+          reinterpret_cast<u32x4*>(emb_grad + (size_t)dst * W)[c8] = v;
         }
       }
     }
@@ -1830,7 +1836,8 @@ int hctr_interaction_fwd_gather(size_t batch, int n_emb, int width, const void* 
 
 static int interaction_bwd_impl(size_t batch, int n_emb, int width, const void* mlp,
                                 const void* emb, const uint32_t* row_of, const void* top_grad,
-                                void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream) {
+                                void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream,
+                                const uint32_t* grad_map = nullptr) {
   HCTR_REQUIRE(n_emb >= 1 && width >= 1, "shape");
   {
     const int n_ins_ = n_emb + 1;
@@ -1890,12 +1897,12 @@ static int interaction_bwd_impl(size_t batch, int n_emb, int width, const void* 
       hipLaunchKernelGGL((interaction_bwd16_kernel<W_, true>), dim3(grid1), dim3(64), lds, s,    \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
                          row_of, (const unsigned short*)top_grad, (unsigned short*)mlp_grad,     \
-                         (unsigned short*)emb_grad, out_len);                                    \
+                         (unsigned short*)emb_grad, out_len, grad_map);                          \
     else                                                                                         \
       hipLaunchKernelGGL((interaction_bwd16_kernel<W_, false>), dim3(grid1), dim3(64), lds, s,   \
                          batch, n_emb, (const unsigned short*)mlp, (const unsigned short*)emb,   \
                          row_of, (const unsigned short*)top_grad, (unsigned short*)mlp_grad,     \
-                         (unsigned short*)emb_grad, out_len);                                    \
+                         (unsigned short*)emb_grad, out_len, grad_map);                          \
   }
     switch (width) {
       case 128: HCTR_IBWD16(128) break;
@@ -1939,6 +1946,15 @@ int hctr_interaction_bwd_indexed(size_t batch, int n_emb, int width, const void*
   HCTR_REQUIRE(row_of, "null pointer");
   return interaction_bwd_impl(batch, n_emb, width, mlp, rows, row_of, top_grad, mlp_grad, emb_grad,
                               dtype, stream);
+}
+
+int hctr_interaction_bwd_indexed_scatter(size_t batch, int n_emb, int width, const void* mlp,
+                                         const void* rows, const uint32_t* row_of,
+                                         const void* top_grad, void* mlp_grad, void* grad_rows,
+                                         int dtype, hctr_stream_t stream) {
+  HCTR_REQUIRE(row_of, "null pointer");
+  return interaction_bwd_impl(batch, n_emb, width, mlp, rows, row_of, top_grad, mlp_grad, grad_rows,
+                              dtype, stream, row_of);
 }
 
 #define HCTR_CROSS_DISPATCH(MACRO)       \

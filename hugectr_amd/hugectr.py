@@ -511,8 +511,10 @@ class _IndexedEmb:
     """embedding output of the unique-row exchange kept as (distinct rows, (sample, slot) -> row):
     the Interaction layer reads the rows through the table, the [B, S, D] tensor is never written"""
 
-    def __init__(self, rows, row_of, on_grad):
-        self.rows, self.row_of, self.on_grad = rows, row_of, on_grad
+    def __init__(self, rows, row_of, on_grad, scatter=False):
+        # scatter: row_of is a bijection (the reorder map of an all-to-all receive buffer) and
+        # on_grad takes the gradient in the rows' layout
+        self.rows, self.row_of, self.on_grad, self.scatter = rows, row_of, on_grad, scatter
 
 
 class _GatherEmb:
@@ -747,13 +749,33 @@ class Model:
         self._xstate = {}
         for name, (se, p, h, ex, localized) in self._emb.items():
             st = {"mode": "rows", "ux": None, "select": None, "indexed": False, "timing_ms": None,
-                  "fused_gather": False}
+                  "fused_gather": False, "rows_indexed": False}
             one_hot = p.is_fixed_length and p.max_nnz() == 1
             cons = consumers.get(name, [])
             to_interaction = (len(cons) == 1 and cons[0][1] == 1 and
                               self.layers[cons[0][0]].layer_type == Layer_t.Interaction)
             # one GPU, one key per bucket, the Interaction layer the only reader: the gather rides
             # in the interaction kernel (no second trip of the pooled vectors through HBM)
+            # N > 1, rows payload, Interaction the only reader: the interaction reads the
+            # all-to-all receive buffer [peer][b][slot in peer][D] through the reorder map and
+            # writes the embedding gradients straight in the send layout -- forward_reorder /
+            # backward_reorder (a read + a write of the whole [B/N, S, D] tensor each) disappear
+            n_ins = p.slot_num + 1
+            st["rows_indexed"] = (self.world > 1 and localized and to_interaction and
+                                  s.use_mixed_precision and self._intra and
+                                  se.embedding_vec_size in (32, 64, 128) and n_ins <= 32 and
+                                  (se.embedding_vec_size + n_ins * (n_ins - 1) // 2 + 1) % 8 == 0 and
+                                  os.environ.get("HCTR_ROWS_INDEXED", "1") != "0")
+            if st["rows_indexed"]:
+                W_, S_ = self.world, p.slot_num
+                s_of = [S_ // W_ + (1 if g < S_ % W_ else 0) for g in range(W_)]
+                base = [self.bpg * sum(s_of[:g]) for g in range(W_)]
+                b_ = torch.arange(self.bpg, dtype=torch.int64).view(-1, 1)
+                sl = torch.arange(S_, dtype=torch.int64).view(1, -1)
+                g_, j_ = sl % W_, sl // W_
+                row = torch.tensor(base, dtype=torch.int64)[g_] + b_ * torch.tensor(
+                    s_of, dtype=torch.int64)[g_] + j_
+                st["row_map"] = row.to(torch.int32).to(self.device).contiguous()
             st["fused_gather"] = (self.world == 1 and one_hot and se.combiner == 0 and
                                   to_interaction and s.use_mixed_precision and
                                   se.embedding_vec_size in (16, 32, 64, 128) and p.slot_num <= 31 and
@@ -1177,7 +1199,7 @@ class Model:
                 elif isinstance(x[1], _IndexedEmb):
                     e = x[1]
                     y = interaction_indexed(x[0].to(e.rows.dtype).contiguous(), e.rows, e.row_of,
-                                            on_emb_grad=e.on_grad)
+                                            on_emb_grad=e.on_grad, scatter_grad=e.scatter)
                 else:
                     dt = x[1].dtype
                     y = interaction(x[0].to(dt).contiguous(), x[1].contiguous())
@@ -1271,9 +1293,15 @@ class Model:
             sent["work"] = e.backward_async(gsend, top_grad.view(-1))
             sent["buf"] = gsend  # stays alive until the collective has read it
 
+        def on_rows_grad(gsend):  # already in the send layout (scatter through the reorder map)
+            sent["work"] = e.backward_async(gsend.view(-1), top_grad.view(-1))
+            sent["buf"] = gsend
+
         def resolve():
             if work is not None:
                 work.wait()
+            if st["rows_indexed"]:
+                return _IndexedEmb(recv.view(-1, D), st["row_map"], on_rows_grad, scatter=True)
             E = forward_reorder(recv, bpg, S, D, W).requires_grad_(True)
             E.register_hook(on_grad)
             return E

@@ -45,8 +45,9 @@ class _InteractionIndexedFn(torch.autograd.Function):
     soon as it exists (the exchange reduces it per row); rows itself gets no gradient here."""
 
     @staticmethod
-    def forward(ctx, mlp, rows, row_of, on_emb_grad):
+    def forward(ctx, mlp, rows, row_of, on_emb_grad, scatter_grad=False):
         mlp = mlp.contiguous()
+        ctx.scatter_grad = scatter_grad
         B, W = mlp.shape
         n_emb = row_of.shape[1]
         n_ins = n_emb + 1
@@ -65,12 +66,13 @@ class _InteractionIndexedFn(torch.autograd.Function):
         n_emb = row_of.shape[1]
         mlp_grad = torch.empty_like(mlp)
         emb_grad = torch.empty((B, n_emb, W), dtype=mlp.dtype, device=mlp.device)
-        check(lib.hctr_interaction_bwd_indexed(B, n_emb, W, ptr(mlp), ptr(rows), ptr(row_of),
-                                               ptr(grad), ptr(mlp_grad), ptr(emb_grad),
-                                               _DT[mlp.dtype], stream_ptr()))
+        fn = lib.hctr_interaction_bwd_indexed_scatter if ctx.scatter_grad else \
+            lib.hctr_interaction_bwd_indexed
+        check(fn(B, n_emb, W, ptr(mlp), ptr(rows), ptr(row_of), ptr(grad), ptr(mlp_grad),
+                 ptr(emb_grad), _DT[mlp.dtype], stream_ptr()))
         if ctx.on_emb_grad is not None:
             ctx.on_emb_grad(emb_grad)
-        return mlp_grad, None, None, None
+        return mlp_grad, None, None, None, None
 
 
 class _InteractionGatherFn(torch.autograd.Function):
@@ -117,10 +119,14 @@ def interaction_gather(mlp: torch.Tensor, emb, is_train: bool = True, on_emb_gra
 
 
 def interaction_indexed(mlp: torch.Tensor, rows: torch.Tensor, row_of: torch.Tensor,
-                        on_emb_grad=None) -> torch.Tensor:
-    """mlp [B,W], rows [R,W] (same 16-bit dtype), row_of int32 [B,n_emb] -> interaction output"""
+                        on_emb_grad=None, scatter_grad: bool = False) -> torch.Tensor:
+    """mlp [B,W], rows [R,W] (same 16-bit dtype), row_of int32 [B,n_emb] -> interaction output.
+    scatter_grad (row_of must be a bijection onto the B * n_emb rows, e.g. the reorder map of an
+    all-to-all receive buffer): on_emb_grad receives the embedding gradient in the ROWS' layout
+    (row row_of[b, s] = gradient of embedding s of sample b) instead of [B, n_emb, W]"""
     assert rows.dtype == mlp.dtype and row_of.dtype == torch.int32 and rows.is_contiguous()
-    return _InteractionIndexedFn.apply(mlp, rows, row_of.contiguous(), on_emb_grad)
+    assert not scatter_grad or rows.shape[0] == row_of.numel()
+    return _InteractionIndexedFn.apply(mlp, rows, row_of.contiguous(), on_emb_grad, scatter_grad)
 
 
 def interaction(mlp: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:

@@ -440,6 +440,14 @@ int hctr_interaction_fwd_indexed(size_t batch, int n_emb, int width, const void*
 int hctr_interaction_bwd_indexed(size_t batch, int n_emb, int width, const void* mlp,
                                  const void* rows, const uint32_t* row_of, const void* top_grad,
                                  void* mlp_grad, void* emb_grad, int dtype, hctr_stream_t stream);
+/* the same when row_of is a BIJECTION onto the rows (the reorder map of the localized embedding's
+ * all-to-all receive buffer, forward_reorder_functor.cu:43-57): the embedding gradient of (b, s) is
+ * written to row row_of[b * n_emb + s] of grad_rows [batch * n_emb][width] -- the all-to-all send
+ * layout of backward_reorder -- so neither reorder pass exists as a kernel */
+int hctr_interaction_bwd_indexed_scatter(size_t batch, int n_emb, int width, const void* mlp,
+                                         const void* rows, const uint32_t* row_of,
+                                         const void* top_grad, void* mlp_grad, void* grad_rows,
+                                         int dtype, hctr_stream_t stream);
 
 /* Gather fused into InteractionLayer::fprop (one GPU, ONE key per bucket, sum combiner): the
  * pooled vector of a one-hot bucket is its table row rounded to the 16-bit type

@@ -224,6 +224,43 @@ def test_interaction_indexed_equals_dense(dtype_name, B, n_emb, W):
     assert torch.equal(e1.grad, got["dE"])
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,n_emb,W,world", [(96, 26, 128, 4), (64, 26, 32, 2), (40, 10, 64, 8)])
+def test_interaction_through_the_reorder_map_needs_no_reorder_pass(dtype_name, B, n_emb, W, world):
+    """N > 1 rows payload: the interaction reads the all-to-all receive buffer
+    [peer][b][slot in peer][D] through the reorder map (forward_reorder_functor.cu:43-57) and writes
+    the embedding gradients straight in backward_reorder's send layout
+    (hctr_interaction_bwd_indexed_scatter): output and gradients bit-equal to forward_reorder ->
+    interaction -> backward_reorder"""
+    import torch
+    import hugectr_amd as ha
+    dt = getattr(torch, dtype_name)
+    g = torch.Generator(device="cuda").manual_seed(B + n_emb + world)
+    recv = torch.randn(B * n_emb * W, device="cuda", generator=g).to(dt)
+    mlp = torch.randn(B, W, device="cuda", generator=g).to(dt)
+    s_of = [n_emb // world + (1 if r < n_emb % world else 0) for r in range(world)]
+    base = [B * sum(s_of[:r]) for r in range(world)]
+    row = torch.empty((B, n_emb), dtype=torch.int32)
+    for b in range(B):
+        for s in range(n_emb):
+            r, j = s % world, s // world
+            row[b, s] = base[r] + b * s_of[r] + j
+    row = row.cuda()
+    E = ha.forward_reorder(recv, B, n_emb, W, world).requires_grad_()
+    m1, m2 = mlp.clone().requires_grad_(), mlp.clone().requires_grad_()
+    out_d = ha.interaction(m1, E)
+    got = {}
+    out_i = ha.interaction_indexed(m2, recv.view(-1, W), row, on_emb_grad=lambda d: got.update(g=d),
+                                   scatter_grad=True)
+    assert torch.equal(out_i, out_d)
+    top = torch.randn(out_d.shape, device="cuda", generator=g).to(dt)
+    out_d.backward(top)
+    out_i.backward(top)
+    assert torch.equal(m1.grad, m2.grad)
+    want = ha.backward_reorder(E.grad.contiguous(), B, n_emb, W, world)
+    assert torch.equal(got["g"].reshape(-1), want.reshape(-1))
+
+
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("B,S,D", [(300, 26, 128), (65, 5, 64), (129, 31, 32), (70, 7, 16)])
 def test_gather_fused_into_interaction_equals_pool_then_interaction(dtype_name, B, S, D):
