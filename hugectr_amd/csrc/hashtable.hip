@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(kBlock)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
                            uint32_t* d_list_count, uint32_t* __restrict__ d_list,
-                           uint32_t* d_error, const K* __restrict__ ro_src,
+                           uint32_t list_cap, uint32_t* d_error, const K* __restrict__ ro_src,
                            K* __restrict__ ro_dst, size_t n_offsets,
                            uint32_t* __restrict__ one_hot) {
   __shared__ uint32_t s_cnt, s_base;
@@ -167,7 +167,11 @@ __global__ void __launch_bounds__(kBlock)
     if (cnt != 0u) {  // this workgroup's pending positions -> the batch's list (one atomic)
       if (threadIdx.x == 0) s_base = atomicAdd(d_list_count, cnt);
       __syncthreads();
-      for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) d_list[s_base + k] = s_pos[k];
+      // (the count is reset by every finish kernel; should one have given up at its barrier,
+      //  the list must still never be written past its end)
+      for (uint32_t k = threadIdx.x; k < cnt; k += kBlock)
+        if (s_base + k < list_cap) d_list[s_base + k] = s_pos[k];
+      if (threadIdx.x == 0 && s_base + cnt > list_cap) atomicOr(d_error, 4u);
     }
     __syncthreads();
   }
@@ -238,6 +242,7 @@ struct FinishCtl {
   uint32_t *list_count, *latched, *error, *barrier;
   uint64_t *counter, *base, *new_count;
   const uint32_t* list;         // positions whose key was not in the table (unordered)
+  uint32_t list_cap;
   uint32_t* region_cnt;         // 2 x [kFinRegions] first occurrences per region (as masks2)
   // two buffers of [mask_words] first-occurrence masks: buffer *parity is all zero on entry and
   // takes this batch's bits, the other one is zeroed here for the next batch that inserts
@@ -309,7 +314,8 @@ __global__ void __launch_bounds__(kFinBlock)
     ht_finish_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
                      const uint64_t* d_n, FinishCtl c, uint64_t* __restrict__ new_positions,
                      SlotIdSink sink, uint64_t capacity) {
-  const uint32_t P = *c.list_count;  // (workgroup 0 resets it only behind the first barrier)
+  uint32_t P = *c.list_count;  // (workgroup 0 resets it only behind the barrier)
+  if (P > c.list_cap) P = c.list_cap;
   if (P == 0u) {  // steady state: no unseen key in this batch
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const uint64_t cnt = *c.counter;
@@ -654,17 +660,18 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, 1 << 16);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, d_error,
+                       size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, (uint32_t)max_n, d_error,
                        (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst, x.n_offsets, x.one_hot);
   } else {
     hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const long long*)keys, n, d_n, out, d_pending, pend_list, d_error,
+                       size, (const long long*)keys, n, d_n, out, d_pending, pend_list, (uint32_t)max_n, d_error,
                        (const long long*)x.ro_src, (long long*)x.ro_dst, x.n_offsets, x.one_hot);
   }
   HCTR_LAUNCH_CHECK();
   FinishCtl c;
   c.list_count = d_pending;
   c.list = pend_list;
+  c.list_cap = (uint32_t)max_n;
   c.latched = d_latched;
   c.error = d_error;
   c.barrier = d_barrier;

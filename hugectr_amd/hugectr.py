@@ -1392,9 +1392,12 @@ class Model:
         else:
             loss = torch.nn.functional.binary_cross_entropy_with_logits(logit, label)
             (loss * (self.solver.scaler / self.world)).backward()
+        # the dense gradients' all-reduce (N > 1) runs on the communicator's stream under the
+        # embeddings' backward + sparse update
+        works = self._dense_reduce_begin()
         for fin in after:
             fin()
-        self._dense_step()
+        self._dense_step(reduced=works)
         return loss.detach().reshape(()), None
 
     # -- HIP-graph replay of the dense tower (solver.use_cuda_graph) ---------------------------------
@@ -1483,13 +1486,27 @@ class Model:
             h.update_params()
         return G["loss"]
 
-    def _dense_step(self, skip: bool = False):
+    def _dense_reduce_begin(self):
+        """N > 1: starts the data-parallel all-reduce of the dense gradients (shares of the
+        global-batch mean: a plain sum) and returns the handles _dense_step waits on; None when
+        there is nothing to reduce asynchronously (one GPU, frozen dense part, host-staged gloo)"""
+        if self.world == 1 or getattr(self, "_dense_frozen", False) or not self._intra or \
+                dist.get_backend() == "gloo":
+            return None
+        ts = [m.flat_g for m in self._flat_mlps] if self._flat_mlps else \
+            [q.grad for q in self._dense_params if q.grad is not None]
+        return [dist.all_reduce(t, async_op=True) for t in ts]
+
+    def _dense_step(self, skip: bool = False, reduced=None):
         frozen = getattr(self, "_dense_frozen", False) or skip
+        if reduced is not None:
+            for w in reduced:
+                w.wait()
         if self._flat_mlps:
             if frozen:
                 return
             for m in self._flat_mlps:  # gradients are shares of the global-batch mean: plain sum
-                if self.world > 1:
+                if self.world > 1 and reduced is None:
                     _all_reduce(m.flat_g)
                 m.sgd_step(self._lr, 1.0 / self.solver.scaler)
             return
@@ -1498,7 +1515,7 @@ class Model:
         if frozen:
             self._dense_opt.zero_grad(set_to_none=True)
             return
-        if self.world > 1:
+        if self.world > 1 and reduced is None:
             for q in self._dense_params:
                 if q.grad is not None:
                     _all_reduce(q.grad)
