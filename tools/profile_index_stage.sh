@@ -1,4 +1,6 @@
 #!/bin/bash
+# per-launch medians of the index-stage kernels (steps that insert / steps that do not) from a
+# rocprofv3 kernel trace of the main bench leg
 cd /tmp && export TMPDIR=/tmp
 W="--extra none --no-cpu-baseline --steps 30 --warmup 8"
 rm -rf /tmp/ks
