@@ -336,7 +336,8 @@ __global__ void __launch_bounds__(kFinBlock)
   {  // the other mask buffer is nobody's at the moment: all zero for the next inserting batch
     unsigned long long* const other = c.masks2 + (size_t)(1u - par) * c.mask_words;
     for (size_t w = gtid; w < c.mask_words; w += gthreads) other[w] = 0ull;
-    if (gtid < (size_t)kFinRegions) c.region_cnt[(1u - par) * kFinRegions + gtid] = 0u;
+    for (size_t r = gtid; r < (size_t)kFinRegions; r += gthreads)
+      c.region_cnt[(1u - par) * kFinRegions + r] = 0u;
   }
   uint32_t* const region_cnt = c.region_cnt + par * kFinRegions;  // (zero on entry, like masks)
   // regions of `per` consecutive positions (a multiple of 64, at most kFinRegions of them)

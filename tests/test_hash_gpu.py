@@ -209,3 +209,73 @@ def test_overflow_keys_get_no_row_and_nothing_is_touched_out_of_bounds(D):
     # eval on the same keys: get_mark of a key that holds no row is a miss
     out = emb.forward(False, ro, keys).float().cpu().numpy().reshape(B * S, D)
     assert (out == 0.0).all()  # live rows were stepped to 1 - lr * 1 = 0, the rest are misses
+
+
+@pytest.mark.parametrize("key_bytes", [4, 8])
+def test_get_insert_many_batches_of_every_shape(oracle, key_bytes):
+    """The two-launch index stage over a long, irregular sequence on ONE table: batches of 1 to
+    300 000 keys (one workgroup / the full cooperative grid of the finish kernel), none / a few /
+    all keys unseen (the finish kernel's early exit alternating with its barrier path, so its
+    double-buffered masks and region counts change hands at every possible moment), keys repeated
+    hundreds of times inside a batch, get_mark in between, the live-count form (d_n < n) -- rows
+    bit-equal to the sequential oracle after every call."""
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(17 + key_bytes)
+    cap = 1_500_000
+    ktype = _lib.KEY_U32 if key_bytes == 4 else _lib.KEY_I64
+    tdt = torch.int32 if key_bytes == 4 else torch.int64
+    g, ref = GpuHT(cap, ktype), oracle.HashTable(cap, key_bytes)
+    universe = rng.permutation(6_000_000)[:2_500_000].astype(np.int64) * (3 if key_bytes == 8 else 1)
+    seen = 0
+    sizes = [1, 63, 64, 65, 4095, 4096, 4097, 300_000, 5, 131_072, 200_000, 1000, 257, 65_536,
+             250_000, 31, 100_000, 8191, 3, 150_000]
+    for it, n in enumerate(sizes * 2):
+        kind = it % 4
+        if kind == 0:      # all unseen
+            new = n
+        elif kind == 1:    # none unseen (steady state: the finish kernel exits at once)
+            new = 0
+        elif kind == 2:    # a few per cent unseen
+            new = max(1, n // 25)
+        else:              # half unseen, heavy repetition inside the batch
+            new = n // 2
+        new = min(new, universe.size - seen) if seen < universe.size else 0
+        if seen == 0 and new == 0:
+            new = n
+        fresh = universe[seen:seen + new]
+        seen += new
+        old = universe[rng.integers(0, max(seen - new, 1), size=n - new)] if seen - new > 0 \
+            else np.repeat(fresh[:1], n - new)
+        keys = np.concatenate([fresh, old])
+        if kind == 3 and n > 8:  # hundreds of copies of a handful of keys, new ones included
+            hot = keys[rng.integers(0, keys.size, size=6)]
+            keys[rng.integers(0, n, size=n // 3)] = hot[rng.integers(0, 6, size=n // 3)]
+        rng.shuffle(keys)
+        kt = _mk(torch, keys if key_bytes == 8 else keys.astype(np.uint32).view(np.int32), tdt)
+        got = g.get_insert(kt)
+        want = ref.get_insert(keys)
+        if not (got == want).all():
+            bad = np.nonzero(got != want)[0]
+            first_seen = {int(k): j for j, k in enumerate(universe[:seen])}
+            raise AssertionError((it, n, kind, bad.size, [
+                (int(keys[b]), int(got[b]), int(want[b]), first_seen.get(int(keys[b])))
+                for b in bad[:6]]))
+        if it % 5 == 4:  # eval in between: misses read as invalid, nothing is inserted
+            probe = np.concatenate([universe[:min(seen, 1000)], universe[-500:]])
+            pt = _mk(torch, probe if key_bytes == 8 else probe.astype(np.uint32).view(np.int32), tdt)
+            assert (g.get_mark(pt) == ref.get_mark(probe)).all()
+            assert g.value_head() == ref.size()
+    # live count on the device smaller than the host bound: positions beyond it are not touched
+    n, live = 50_000, 31_337
+    keys = universe[rng.integers(0, universe.size, size=n)]
+    kt = _mk(torch, keys if key_bytes == 8 else keys.astype(np.uint32).view(np.int32), tdt)
+    d_n = torch.tensor([live], dtype=torch.int64, device="cuda")
+    out = torch.full((n,), -7, dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib.hctr_ht_get_insert(g.h, _lib.ptr(kt), n, _lib.ptr(d_n), _lib.ptr(out),
+                                           _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    assert (res[:live].view(np.uint64) == ref.get_insert(keys[:live])).all()
+    assert (res[live:] == -7).all()
+    assert g.size() == ref.size()
