@@ -31,7 +31,7 @@ from .embedding import OptParams, SparseEmbeddingHash, backward_reorder, forward
 from .embedding_collection import (DataParallelCollection, EmbeddingCollection,  # noqa: F401
                                    EmbeddingCollectionConfig, EmbeddingTableConfig)
 from .layers import MultiCrossLayer, interaction, interaction_gather, interaction_indexed
-from .parallel import DistributedExchange, LocalizedExchange
+from .parallel import DistributedExchange, LocalizedExchange, reorder_row_map
 from .parallel import all_reduce as _all_reduce
 from . import data as _data
 
@@ -767,15 +767,8 @@ class Model:
                                   (se.embedding_vec_size + n_ins * (n_ins - 1) // 2 + 1) % 8 == 0 and
                                   os.environ.get("HCTR_ROWS_INDEXED", "1") != "0")
             if st["rows_indexed"]:
-                W_, S_ = self.world, p.slot_num
-                s_of = [S_ // W_ + (1 if g < S_ % W_ else 0) for g in range(W_)]
-                base = [self.bpg * sum(s_of[:g]) for g in range(W_)]
-                b_ = torch.arange(self.bpg, dtype=torch.int64).view(-1, 1)
-                sl = torch.arange(S_, dtype=torch.int64).view(1, -1)
-                g_, j_ = sl % W_, sl // W_
-                row = torch.tensor(base, dtype=torch.int64)[g_] + b_ * torch.tensor(
-                    s_of, dtype=torch.int64)[g_] + j_
-                st["row_map"] = row.to(torch.int32).to(self.device).contiguous()
+                st["row_map"] = reorder_row_map(self.bpg, p.slot_num, self.world).to(
+                    self.device).contiguous()
             st["fused_gather"] = (self.world == 1 and one_hot and se.combiner == 0 and
                                   to_interaction and s.use_mixed_precision and
                                   se.embedding_vec_size in (16, 32, 64, 128) and p.slot_num <= 31 and

@@ -58,6 +58,21 @@ def localized_split_sizes(batch: int, slot_num: int, vec: int, rank: int, world:
     return send, recv
 
 
+def reorder_row_map(batch_per_gpu: int, slot_num: int, world: int) -> torch.Tensor:
+    """int32 [batch_per_gpu, slot_num]: row of (local sample b, global slot s) in the all-to-all
+    receive buffer [peer g][b][slot in g][D] of the localized embedding, i.e. the index form of
+    forward_reorder (R/HugeCTR/src/embeddings/forward_reorder_functor.cu:43-57: slot s lives on GPU
+    s % N as its (s / N)-th slot).  A bijection onto the batch_per_gpu * slot_num rows: the same
+    map is the scatter of backward_reorder."""
+    s_of = [slots_on_rank(slot_num, g, world) for g in range(world)]
+    base = [batch_per_gpu * sum(s_of[:g]) for g in range(world)]
+    b = torch.arange(batch_per_gpu, dtype=torch.int64).view(-1, 1)
+    sl = torch.arange(slot_num, dtype=torch.int64).view(1, -1)
+    g, j = sl % world, sl // world
+    row = torch.tensor(base, dtype=torch.int64)[g] + b * torch.tensor(s_of, dtype=torch.int64)[g] + j
+    return row.to(torch.int32)
+
+
 class LocalizedExchange:
     """all-to-all of pooled vectors (forward) and of top gradients (backward)."""
 

@@ -140,3 +140,27 @@ def test_chunked_async_exchange_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_worker_chunked, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret.get(r) == "ok" for r in range(world)), dict(ret)
+
+
+def test_reorder_row_map_is_the_index_form_of_forward_and_backward_reorder():
+    """hugectr.Model reads the all-to-all receive buffer through parallel.reorder_row_map (the
+    interaction's indexed kernels) instead of running forward_reorder / backward_reorder: the map
+    must gather exactly what the oracle's forward_reorder produces and scatter exactly what its
+    backward_reorder produces, uneven slot counts included."""
+    import numpy as np
+    import torch
+    from oracle import pyoracle as orc
+    from hugectr_amd.parallel import reorder_row_map
+    orc.build()
+    rng = np.random.default_rng(0)
+    for bpg, S, D, world in ((5, 26, 4, 8), (7, 26, 8, 4), (3, 7, 2, 2), (4, 3, 2, 3), (6, 5, 4, 1)):
+        recv = rng.standard_normal(bpg * S * D).astype(np.float32)
+        row = reorder_row_map(bpg, S, world).numpy()
+        assert sorted(row.reshape(-1).tolist()) == list(range(bpg * S))  # a bijection
+        want = orc.forward_reorder(recv, bpg, S, D, world).reshape(bpg, S, D)
+        got = recv.reshape(-1, D)[row]
+        assert (got == want).all()
+        g = rng.standard_normal((bpg, S, D)).astype(np.float32)
+        back = np.zeros((bpg * S, D), np.float32)
+        back[row.reshape(-1)] = g.reshape(-1, D)
+        assert (back.reshape(-1) == orc.backward_reorder(g.reshape(-1), bpg, S, D, world)).all()
