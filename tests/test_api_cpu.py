@@ -300,3 +300,25 @@ def test_readers_hand_an_embedding_collection_its_global_csr(tmp_path):
             for (gk, gbr), names, o in zip(b["ebc"], groups, goffs):
                 wk, wbr = _ebc_csr_from_inputs(b, names, o, 32)
                 assert gk.dtype == torch.int64 and torch.equal(gk, wk) and torch.equal(gbr, wbr)
+
+
+def test_scale_layer_follows_the_reference_upscale_and_first_copy_downscale():
+    """Layer_t.Scale (R/HugeCTR/src/layers/scale_layer.cu:30-66, the MMoE sample's gate mixing):
+    fprop axis 0: out[b, j * factor + i] = in[b, j]; axis 1: out[b, i * n + j] = in[b, j]; bprop is
+    the reference's downscale_kernel -- the gradient of the FIRST copy only, not the sum."""
+    import numpy as np
+    import torch
+    from hugectr_amd.hugectr import _ScaleFn
+    rng = np.random.default_rng(1)
+    x = torch.from_numpy(rng.standard_normal((5, 3)).astype(np.float32)).requires_grad_()
+    for axis, factor in ((0, 4), (1, 4), (0, 1)):
+        x.grad = None
+        y = _ScaleFn.apply(x, axis, factor)
+        xn = x.detach().numpy()
+        want = np.repeat(xn, factor, axis=1) if axis == 0 else np.tile(xn, (1, factor))
+        assert y.shape == (5, 3 * factor) and (y.detach().numpy() == want).all()
+        g = torch.from_numpy(rng.standard_normal((5, 3 * factor)).astype(np.float32))
+        y.backward(g)
+        gn = g.numpy()
+        first = gn[:, ::factor] if axis == 0 else gn[:, :3]
+        assert (x.grad.numpy() == first).all()
