@@ -376,6 +376,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                    "table_rows_this_rank": my_rows,
                    "parallelism": f"slot-sharded x{world} + dp{world}",
                    "new_keys_per_step": new_keys, "distinct_rows_per_batch": U,
+                   "gather_fused_into_interaction": fused,
                    "final_loss": m.get_current_loss(),
                    "dense_gemm_selection": getattr(m, "_gemm_selection", "off")},
         "roofline": {"bound": "hbm",
