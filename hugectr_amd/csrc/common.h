@@ -43,6 +43,14 @@ constexpr uint64_t kInvalidIndex = ~0ull;  // std::numeric_limits<size_t>::max()
     if (rc__ != HCTR_OK) return rc__; \
   } while (0)
 
+// dynamically sized LDS of a kernel (the launch's shared-memory bytes).  Spelled through a macro so
+// that the host interpreter of tests/emu (test infrastructure; it cannot express an unsized extern
+// array) can supply its own definition -- for hipcc this IS the plain declaration.
+#ifndef HCTR_DYN_LDS
+#define HCTR_DYN_LDS(T, name) extern __shared__ T name[]
+#define HCTR_DYN_LDS16(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#endif
+
 template <typename T>
 static inline T ceil_div(T a, T b) {
   return (a + b - 1) / b;

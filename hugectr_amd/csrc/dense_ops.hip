@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64, 2)
                                 const float* __restrict__ emb, float* __restrict__ out,
                                 int out_len) {
   using C = InterCfg<W>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HCTR_DYN_LDS16(float, smem);
   const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
   float* xt = smem;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(64, 2)
                              unsigned short* __restrict__ out, int out_len) {
   using C = InterCfg16<W>;
   using H = H16<BF>;
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  HCTR_DYN_LDS16(unsigned short, smem16);
   const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
   unsigned short* xt = smem16;
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(64, 2)
                                     unsigned short* __restrict__ out, int out_len) {
   using C = InterCfg16<W>;
   using H = H16<BF>;
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  HCTR_DYN_LDS16(unsigned short, smem16);
   const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
   unsigned short* xt = smem16;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(64, 2)
   using C = InterCfg16<W>;
   using H = H16<BF>;
   constexpr int GS = 40;  // G row stride (16-bit elements): 80 B -> 16 distinct 16-B slots
-  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  HCTR_DYN_LDS16(unsigned short, smem16);
   const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
   unsigned short* xt = smem16;            // [32][LD] X, reused for dX
@@ -597,7 +597,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
     interaction_fwd_generic_kernel(size_t batch, int n_emb, int W, const T* __restrict__ mlp,
                                    const T* __restrict__ emb, T* __restrict__ out, int out_len) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HCTR_DYN_LDS16(float, smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ins = n_emb + 1;
   float* xt = smem + wave * (n_ins * (W + 1));
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(64, 2)
                                 int out_len) {
   using C = InterCfg<W>;
   constexpr int GS = 36;  // G row stride (floats): 16 lanes of a ds_read_b128 group -> 16 slots
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HCTR_DYN_LDS16(float, smem);
   const int lane = threadIdx.x;
   const int n_ins = n_emb + 1;
   float* xt = smem;                 // [32][LD]  X, later reused for dX
@@ -782,7 +782,7 @@ __global__ void __launch_bounds__(kBlock)
                                    const T* __restrict__ emb, const T* __restrict__ top_grad,
                                    T* __restrict__ mlp_grad, T* __restrict__ emb_grad,
                                    int out_len) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HCTR_DYN_LDS16(float, smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_ins = n_emb + 1;
   float* xt = smem + wave * (n_ins * (W + 1) + n_ins * n_ins);
@@ -887,7 +887,7 @@ __global__ void __launch_bounds__(kBlock)
                         const float* __restrict__ kernels, const float* __restrict__ outputs,
                         const float* __restrict__ hiddens, const float* __restrict__ out_grad,
                         float* __restrict__ in_grad, float* __restrict__ partials) {
-  extern __shared__ float cross_lds[];
+  HCTR_DYN_LDS(float, cross_lds);
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -1210,7 +1210,7 @@ __global__ void __launch_bounds__(kBlock)
     logit_head_kernel(size_t batch, int K, const T* __restrict__ x, const T* __restrict__ w,
                       const T* __restrict__ bias, const float* __restrict__ label,
                       float grad_scale, T* __restrict__ dx, float* __restrict__ partial) {
-  extern __shared__ float lds[];  // [waves][K + 2]
+  HCTR_DYN_LDS(float, lds);  // [waves][K + 2]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 wr[NSEG], acc[NSEG];
@@ -1385,7 +1385,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock)
     skinny_fc_fwd_kernel(size_t batch, int K, int N, int R, const float* __restrict__ x,
                          const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ y) {
-  extern __shared__ float xs[];  // [R][kSkinnyK]
+  HCTR_DYN_LDS(float, xs);  // [R][kSkinnyK]
   const int col = threadIdx.x % kSkinnyLanes;
   const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kSkinnyLanes);
   const bool live = col * 4 < N;
@@ -1447,7 +1447,7 @@ __global__ void __launch_bounds__(kSkinnyBwdBlock)
     skinny_fc_bwd_kernel(size_t batch, int K, int N, const float* __restrict__ x,
                          const T* __restrict__ dy, const T* __restrict__ y,
                          float* __restrict__ partial) {
-  extern __shared__ float lds[];  // [N * (kSkinnyK + 1)]
+  HCTR_DYN_LDS(float, lds);  // [N * (kSkinnyK + 1)]
   const int lane = threadIdx.x & 63;
   const int col = threadIdx.x % kSkinnyLanes;
   const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / kSkinnyLanes);
@@ -1547,7 +1547,7 @@ __global__ void __launch_bounds__(kSkinnyBwdBlock)
     skinny_fc_bwd_mfma_kernel(size_t batch, int K, int N, const float* __restrict__ x,
                               const T* __restrict__ dy, const T* __restrict__ y,
                               float* __restrict__ partial) {
-  extern __shared__ float lds[];  // [N * (kSkinnyK + 1)]
+  HCTR_DYN_LDS(float, lds);  // [N * (kSkinnyK + 1)]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int kWaves = kSkinnyBwdBlock / 64;

@@ -1,0 +1,213 @@
+"""The kernels' OWN SOURCE stepped through on the CPU (tests/emu: a lane-by-lane interpreter of the
+HIP execution model -- test infrastructure, never part of the product) and checked against the
+oracle: kernel logic (indexing, ranks, scans, barriers where data crosses lanes, the MFMA operand
+layout) is verified here before GPU time is spent; the `-m gpu` tests remain the parity tests on
+the hardware.  Sizes are small: the interpreter runs ~10^6 lane-steps a second."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import assert_close, make_csr
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+import emu  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="no host clang++ / make")
+
+
+@pytest.fixture(scope="module")
+def elib():
+    lib = emu.load()
+    emu.bind(lib)
+    return lib
+
+
+def test_hash_rows_match_the_sequential_oracle_over_an_irregular_sequence(oracle, elib):
+    """tests/test_hash_gpu.py::test_get_insert_many_batches_of_every_shape at a tenth of the size,
+    plus the sequence that exposed the stale region counters of round 3 (a one-workgroup finish
+    kernel between two batches of > 1024 regions)."""
+    for key_bytes in (8, 4):
+        rng = np.random.default_rng(17 + key_bytes)
+        cap = 450_000
+        g = emu.HashTable(elib, cap, 0 if key_bytes == 4 else 1)
+        ref = oracle.HashTable(cap, key_bytes)
+        universe = rng.permutation(1_000_000)[:700_000].astype(np.int64) * (3 if key_bytes == 8 else 1)
+        seen = 0
+        sizes = [100_000, 5, 100_000, 1, 63, 64, 65, 4095, 4096, 4097, 13_107, 1000, 257, 31, 8191, 3]
+        for it, n in enumerate(sizes + sizes[3:]):
+            kind = 0 if it < 3 else it % 4
+            new = [n, 0, max(1, n // 25), n // 2][kind]
+            new = min(new, universe.size - seen)
+            fresh = universe[seen:seen + new]
+            seen += new
+            old = universe[rng.integers(0, seen - new, size=n - new)] if n > new else fresh[:0]
+            keys = np.concatenate([fresh, old])
+            if kind == 3 and n > 8:  # hundreds of copies of a handful of keys, new ones included
+                hot = keys[rng.integers(0, keys.size, size=6)]
+                keys[rng.integers(0, n, size=n // 3)] = hot[rng.integers(0, 6, size=n // 3)]
+            rng.shuffle(keys)
+            kk = np.ascontiguousarray(keys if key_bytes == 8 else keys.astype(np.uint32))
+            got, want = g.get_insert(kk), ref.get_insert(keys)
+            assert (got == want).all(), (key_bytes, it, n, kind, int((got != want).sum()))
+            if it % 5 == 4:
+                probe = np.concatenate([universe[:min(seen, 500)], universe[-300:]])
+                pk = np.ascontiguousarray(probe if key_bytes == 8 else probe.astype(np.uint32))
+                assert (g.get_mark(pk) == ref.get_mark(probe)).all()
+                assert g.value_head() == ref.size()
+        k1, v1 = g.dump()
+        k2, v2 = ref.dump()
+        o1, o2 = np.argsort(k1), np.argsort(k2)
+        assert (k1[o1] == k2[o2]).all() and (v1[o1] == v2[o2]).all()
+
+
+@pytest.mark.parametrize("end_bit", [10, 20, 22, 24, 31, 32])
+def test_radix_sort_is_a_stable_sort(elib, end_bit):
+    rng = np.random.default_rng(end_bit)
+    for n in (1, 64, 4095, 4097, 20_000):
+        hi = (1 << end_bit) - 1
+        keys = rng.integers(0, hi, size=n, endpoint=True).astype(np.uint32)
+        keys[rng.integers(0, n, size=n // 3)] = keys[0]  # long runs of one key
+        vals = np.arange(n, dtype=np.uint32)
+        ko, vo = emu.radix_sort_pairs(elib, keys, vals, end_bit)
+        order = np.argsort(keys, kind="stable")
+        assert (ko == keys[order]).all() and (vo == vals[order]).all()
+
+
+OPTS = [
+    ("sgd", dict(optimizer=6, atomic_update=0)),
+    ("adam_local", dict(optimizer=1, update_type=0)),
+    ("adam_lazy", dict(optimizer=1, update_type=2)),
+    ("adagrad", dict(optimizer=3)),
+    ("momentum_global", dict(optimizer=5, update_type=1, momentum_factor=0.9)),
+    ("nesterov_local", dict(optimizer=4, update_type=0, momentum_factor=0.9)),
+]
+
+
+@pytest.mark.parametrize("name,kw", OPTS, ids=[o[0] for o in OPTS])
+@pytest.mark.parametrize("D,combiner", [(16, 1), (128, 0)])
+def test_train_steps_match_oracle(oracle, elib, name, kw, D, combiner):
+    """tests/test_embedding_gpu.py::test_train_steps_match_oracle, kernel source on the CPU: index
+    stage, gather / pooling, backward and the sorted sparse update of several batches."""
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(7)
+    B, S, hot, vps = 64, 6, 4, 40
+    V = S * vps + 16
+    opt = dict(lr=0.05, scaler=4.0, beta1=0.9, beta2=0.999, epsilon=1e-7, **kw)
+    emb = emu.Embedding(elib, _lib.EMB_LOCALIZED, B, V, D, S * hot, S, combiner, opt)
+    table = emb.table().copy()
+    ns = {1: 2, 3: 1, 5: 1, 4: 1, 6: 0}[kw["optimizer"]]
+    s0 = np.zeros_like(table) if ns >= 1 else None
+    s1 = np.zeros_like(table) if ns >= 2 else None
+    pt = np.ones(table.shape, dtype=np.uint64) if name == "adam_lazy" else None
+    ht = oracle.HashTable(V, 8)
+    m = {1: oracle.OPT_ADAM, 3: oracle.OPT_ADAGRAD, 5: oracle.OPT_MOMENTUM, 4: oracle.OPT_NESTEROV,
+         6: oracle.OPT_SGD}
+    for it in range(3):
+        ro, keys = make_csr(rng, B, S, hot, vps, one_hot=(combiner == 0 and it % 2 == 0))
+        out = emb.forward(True, ro, keys)
+        vi = ht.get_insert(keys)
+        assert (emb.value_index(keys.size) == vi).all()
+        want = oracle.forward(ro, vi, table, D, combiner)
+        assert (out.reshape(-1, D).view(np.uint32) == want.view(np.uint32)).all(), "forward"
+        g = rng.standard_normal((B * S, D)).astype(np.float32)
+        emb.backward(g.reshape(B, S, D))
+        emb.update_params()
+        o = oracle.OptParamsC()
+        o.optimizer, o.update_type, o.lr = m[kw["optimizer"]], kw.get("update_type", 0), 0.05
+        o.beta1, o.beta2, o.epsilon = 0.9, 0.999, 1e-7
+        o.momentum_factor, o.scaler, o.times = kw.get("momentum_factor", 0.0), 4.0, it + 1
+        oracle.update_params(ro, vi, oracle.backward(ro, g, D, combiner), o, table, s0, s1, pt)
+        assert_close(emb.table(), table, 1e-5, 1e-6, f"{name} table it{it}")
+        if s0 is not None:
+            assert_close(emb.opt_state(0), s0, 1e-5, 1e-6, f"{name} state0 it{it}")
+        if s1 is not None:
+            assert_close(emb.opt_state(1), s1, 1e-5, 1e-7, f"{name} state1 it{it}")
+
+
+def test_power_law_update_walks_long_runs(oracle, elib):
+    """rows with thousands of gradients (the long-run lists of seg_reduce, seg_combine and the
+    chunked combine of the largest runs) next to rows with one: the table after SGD equals the
+    oracle's within the fp32 re-association of the long runs"""
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(3)
+    B, S, D = 4096, 4, 32
+    vps = 3000
+    V = S * vps
+    # slot 0: three rows share all samples; slot 1: power law; slots 2, 3: nearly unique
+    k = np.empty((B, S), dtype=np.int64)
+    k[:, 0] = rng.integers(0, 3, size=B)
+    k[:, 1] = np.minimum((rng.pareto(1.1, size=B) * 2).astype(np.int64), vps - 1) + vps
+    k[:, 2] = rng.integers(0, vps, size=B) + 2 * vps
+    k[:, 3] = rng.integers(0, vps, size=B) + 3 * vps
+    keys = k.reshape(-1)
+    ro = np.arange(B * S + 1, dtype=np.int64)
+    emb = emu.Embedding(elib, _lib.EMB_LOCALIZED, B, V, D, S, S, 0,
+                        dict(optimizer=6, lr=0.1, scaler=1.0, atomic_update=0))
+    table = emb.table().copy()
+    ht = oracle.HashTable(V, 8)
+    for it in range(2):
+        emb.forward(True, ro, keys)
+        vi = ht.get_insert(keys)
+        g = rng.standard_normal((B * S, D)).astype(np.float32)
+        emb.backward(g.reshape(B, S, D))
+        emb.update_params()
+        o = oracle.OptParamsC()
+        o.optimizer, o.update_type, o.lr, o.scaler, o.times = oracle.OPT_SGD, 0, 0.1, 1.0, it + 1
+        oracle.update_params(ro, vi, g, o, table)
+        assert_close(emb.table(), table, 2e-4, 2e-4, f"table it{it}")
+
+
+@pytest.mark.parametrize("dtype,npd,tol", [(0, np.float32, 2e-3), (1, np.float16, 4e-2)])
+@pytest.mark.parametrize("B,n_emb,W", [(64, 26, 128), (37, 3, 32), (70, 7, 64)])
+def test_interaction_kernels(oracle, elib, dtype, npd, tol, B, n_emb, W):
+    """the MFMA interaction kernels with the matrix instruction modelled lane for lane (operand
+    layout of the CDNA3/4 ISA): forward and both gradients against the fp32 oracle"""
+    rng = np.random.default_rng(B)
+    mlp = rng.standard_normal((B, W)).astype(npd)
+    emb = rng.standard_normal((B, n_emb, W)).astype(npd)
+    n_ins = n_emb + 1
+    out = np.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=npd)
+    emu.check(elib, elib.hctr_interaction_fwd(B, n_emb, W, emu.ptr(mlp), emu.ptr(emb),
+                                              emu.ptr(out), dtype, None))
+    want = oracle.interaction_fwd(mlp.astype(np.float32), emb.astype(np.float32))
+    assert_close(out.astype(np.float32), want, tol, tol, "forward")
+    g = rng.standard_normal(out.shape).astype(npd)
+    mg, eg = np.empty_like(mlp), np.empty_like(emb)
+    emu.check(elib, elib.hctr_interaction_bwd(B, n_emb, W, emu.ptr(mlp), emu.ptr(emb), emu.ptr(g),
+                                              emu.ptr(mg), emu.ptr(eg), dtype, None))
+    wmg, weg = oracle.interaction_bwd(mlp.astype(np.float32), emb.astype(np.float32),
+                                      g.astype(np.float32))
+    assert_close(mg.astype(np.float32), wmg, tol, tol, "mlp grad")
+    assert_close(eg.astype(np.float32), weg, tol, tol, "emb grad")
+
+
+@pytest.mark.parametrize("W", [32, 128])
+def test_gather_fused_into_interaction_equals_pool_then_interaction(oracle, elib, W):
+    """hctr_interaction_fwd_gather (table rows read through value_index straight into the
+    interaction's tile) is bit-identical to the pooled vectors + hctr_interaction_fwd"""
+    rng = np.random.default_rng(W)
+    B, n_emb, V = 70, 9, 500
+    table = rng.standard_normal((V, W)).astype(np.float32)
+    vi = rng.integers(0, V, size=B * n_emb).astype(np.uint64)
+    mlp = rng.standard_normal((B, W)).astype(np.float16)
+    n_ins = n_emb + 1
+    out = np.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=np.float16)
+    pooled = np.empty((B, n_emb, W), dtype=np.float16)
+    emu.check(elib, elib.hctr_interaction_fwd_gather(B, n_emb, W, emu.ptr(mlp), emu.ptr(table),
+                                                     emu.ptr(vi), emu.ptr(pooled), emu.ptr(out), 1,
+                                                     None))
+    want_pooled = table[vi.astype(np.int64)].astype(np.float16).reshape(B, n_emb, W)
+    assert (pooled.view(np.uint16) == want_pooled.view(np.uint16)).all()
+    out2 = np.empty_like(out)
+    emu.check(elib, elib.hctr_interaction_fwd(B, n_emb, W, emu.ptr(mlp), emu.ptr(want_pooled),
+                                              emu.ptr(out2), 1, None))
+    assert (out.view(np.uint16) == out2.view(np.uint16)).all()
+
+
+def test_no_collective_met_an_idle_lane(elib):
+    """(runs last in this file) no shuffle of the kernels exercised above read a lane that was not
+    taking part in it -- on the hardware such a read returns a stale register"""
+    s = emu.stats(elib)
+    assert s["launches"] > 100 and s["shfl_from_inactive"] == 0, s
