@@ -43,12 +43,12 @@ class GpuCache:
         return mi[:m], mk[:m]
 
     def Replace(self, keys: torch.Tensor, values: torch.Tensor):
-        check(lib.hctr_cache_replace(self._h, ptr(keys), keys.numel(), ptr(values.contiguous()),
-                                     stream_ptr()))
+        values = values.contiguous()  # (a named tensor: the pointer must outlive this line)
+        check(lib.hctr_cache_replace(self._h, ptr(keys), keys.numel(), ptr(values), stream_ptr()))
 
     def Update(self, keys: torch.Tensor, values: torch.Tensor):
-        check(lib.hctr_cache_update(self._h, ptr(keys), keys.numel(), ptr(values.contiguous()),
-                                    stream_ptr()))
+        values = values.contiguous()
+        check(lib.hctr_cache_update(self._h, ptr(keys), keys.numel(), ptr(values), stream_ptr()))
 
     def Dump(self, start_set_index: int = 0, end_set_index: int = None) -> torch.Tensor:
         end = self.capacity_in_set if end_set_index is None else end_set_index
@@ -132,8 +132,9 @@ class TieredEmbedding:
         n = self._keys.numel()
         nu = ctypes.c_size_t()
         dt = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[grad.dtype]
+        grad = grad.contiguous()
         check(lib.hctr_ebc_local_reduce(self._upd, n, n, ptr(self._ro), ptr(self._keys),
-                                        self.table.rows, None, ptr(grad.contiguous()), dt,
+                                        self.table.rows, None, ptr(grad), dt,
                                         ctypes.byref(nu), ptr(self._urow), None, ptr(self._wgrad),
                                         stream_ptr()))
         self.table.scatter_add(self._urow[:nu.value], self._wgrad[:nu.value], alpha=-self.lr)

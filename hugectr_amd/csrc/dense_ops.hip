@@ -894,6 +894,9 @@ __global__ void __launch_bounds__(kBlock)
   float* gmy = partials + wave * (size_t)layers * 2 * w;
   float* my = LDS ? cross_lds : gmy;
   for (int i = lane; i < layers * 2 * w; i += 64) my[i] = 0.f;
+  // (entry i is cleared / copied out by lane i % 64 but accumulated by the lane that owns its
+  //  COLUMN: the partial rows cross lanes at both ends of the row loop)
+  __builtin_amdgcn_wave_barrier();
   for (size_t row = wave; row < batch; row += nwaves) {
     float a0[NPL], dy[NPL], dx0[NPL];
 #pragma unroll
@@ -932,6 +935,7 @@ __global__ void __launch_bounds__(kBlock)
       if (i < w) in_grad[row * w + i] = dx0[t] + dy[t];
     }
   }
+  __builtin_amdgcn_wave_barrier();
   if (LDS)
     for (int i = lane; i < layers * 2 * w; i += 64) gmy[i] = my[i];
 }

@@ -172,7 +172,8 @@ class _LogitHeadFn(torch.autograd.Function):
         db = gb if gb is not None else torch.empty(1, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.hctr_logit_head_workspace_bytes(K) // 4, dtype=torch.float32, device=dev)
-        check(lib.hctr_logit_head(B, K, ptr(x), ptr(w16), ptr(b16), ptr(label.contiguous()),
+        label = label.contiguous()
+        check(lib.hctr_logit_head(B, K, ptr(x), ptr(w16), ptr(b16), ptr(label),
                                   float(grad_scale), ptr(dx), ptr(dw), ptr(db), ptr(loss), ptr(ws),
                                   _DT16[x.dtype], stream_ptr()))
         ctx.flat = gw is not None

@@ -619,10 +619,11 @@ class EmbeddingCollection:
         # every (lookup, shard) block is written exactly once by the kernel: no zero fill needed
         send = torch.empty((max(self.total_blocks, 1) * self.bpg, self.ev), dtype=self.out_dtype,
                            device=self.dev)
+        grad = grad.contiguous()  # (named: the pointer must outlive the argument list)
         check(lib.hctr_ebc_network_backward(self.bpg, self.L, self.ev, self.max_shards,
                                             ptr(self.d_src_blocks), ptr(self.d_combiner),
                                             ptr(self.counts), 1 if self.batch_major else 0,
-                                            ptr(grad.contiguous()), ptr(send), _DT[self.out_dtype],
+                                            ptr(grad), ptr(send), _DT[self.out_dtype],
                                             stream_ptr()))
         return send
 
@@ -637,10 +638,11 @@ class EmbeddingCollection:
             check(lib.hctr_updater_set_grad_map(self._upd, self.bpg if mapped else 0,
                                                 self.L if mapped else 0))
             self._map_on = mapped
+        top_grad = top_grad.contiguous()
         if self.dynamic:
-            return self._dynamic_apply(top_grad.contiguous())
+            return self._dynamic_apply(top_grad)
         check(lib.hctr_updater_update(self._upd, self.nb, self._nnz_host, ptr(self.out_range),
-                                      ptr(self.indices), ptr(top_grad.contiguous()),
+                                      ptr(self.indices), ptr(top_grad),
                                       _DT[self.out_dtype], self.optimizer, _lib.UPDATE_LOCAL,
                                       self.lr, 0.9, 0.999, self.epsilon, 0.0, self.scaler,
                                       self._times, ptr(self.table), ptr(self.accum),
@@ -804,7 +806,8 @@ class DataParallelCollection:
         if n == 0:
             return
         ro = torch.arange(n + 1, dtype=torch.int64, device=self.dev)
-        check(lib.hctr_updater_update(self._apply, n, n, ptr(ro), ptr(rows), ptr(dense[rows]), _lib.F32,
+        picked = dense[rows]  # (named: a temporary would be released before the launch reads it)
+        check(lib.hctr_updater_update(self._apply, n, n, ptr(ro), ptr(rows), ptr(picked), _lib.F32,
                                       self.optimizer, _lib.UPDATE_LOCAL, self.lr, 0.9, 0.999,
                                       self.epsilon, 0.0, self.scaler, self._times, ptr(self.table),
                                       ptr(self.accum), ptr(self.ftrl_z), stream_ptr()))

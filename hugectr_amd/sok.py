@@ -518,8 +518,9 @@ class OptimizerWrapper:
         wg = torch.empty((n, D), dtype=torch.float32, device=kg.device)
         nu = ctypes.c_size_t()
         k64 = keys if keys.dtype == torch.int64 else keys.to(torch.int64)
+        kg = kg.contiguous()
         check(lib.hctr_ebc_local_reduce(var._updater[0], n, n, ptr(ro), ptr(rows), base[-1],
-                                        ptr(k64), ptr(kg.contiguous()), _lib.F32, ctypes.byref(nu),
+                                        ptr(k64), ptr(kg), _lib.F32, ctypes.byref(nu),
                                         ptr(urow), ptr(ukey), ptr(wg), stream_ptr()))
         uniq = ukey[:nu.value].to(keys.dtype)
         sums = wg[:nu.value]

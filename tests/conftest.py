@@ -17,6 +17,16 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+    # HCTR_EMU=1: the `-m gpu` tests on a machine without a GPU, the kernels' own source run by the
+    # host interpreter of tests/emu (a logic pre-flight; see tests/emu/fakecuda.py)
+    if os.environ.get("HCTR_EMU") == "1":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import fakecuda
+        fakecuda.install(os.environ.get("HCTR_EMU_VARIANT"))
+        site = os.path.join(ROOT, "tests", "emu", "site")  # (worker processes: sitecustomize)
+        os.environ["PYTHONPATH"] = site + os.pathsep + os.environ.get("PYTHONPATH", "")
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch

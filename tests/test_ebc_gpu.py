@@ -28,9 +28,10 @@ def test_keys_to_indices_bit_exact(oracle):
     rng = np.random.default_rng(0)
     keys = rng.integers(0, 10**9, size=10000).astype(np.int64)
     out = torch.empty(keys.size, dtype=torch.int64, device="cuda")
+    kd = torch.from_numpy(keys).cuda()
     for start, ns in ((0, 1), (12345, 8), (7, 3)):
-        _lib.check(_lib.lib.hctr_ebc_keys_to_indices(_lib.ptr(torch.from_numpy(keys).cuda()), _lib.KEY_I64,
-                                                     keys.size, start, ns, _lib.ptr(out), _lib.stream_ptr()))
+        _lib.check(_lib.lib.hctr_ebc_keys_to_indices(_lib.ptr(kd), _lib.KEY_I64, keys.size, start, ns,
+                                                     _lib.ptr(out), _lib.stream_ptr()))
         want = np.empty(keys.size, np.int64)
         oracle.lib().hco_keys_to_indices(keys.size, oracle._p(keys), start, ns, oracle._p(want))
         assert (out.cpu().numpy() == want).all()

@@ -19,7 +19,10 @@ pytestmark = pytest.mark.skipif(not emu.available(), reason="no host clang++ / m
 
 @pytest.fixture(scope="module")
 def elib():
-    lib = emu.load()
+    # HCTR_EMU_VARIANT=<dir>: the files of <dir> laid over hugectr_amd/csrc (a kernel variant is
+    # run through this whole file before it replaces anything)
+    var = os.environ.get("HCTR_EMU_VARIANT")
+    lib = emu.load(var, os.path.basename(os.path.normpath(var))) if var else emu.load()
     emu.bind(lib)
     return lib
 
