@@ -16,7 +16,11 @@ from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_siz
                     c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhugectr_amd.so")
+# HCTR_LIB_VARIANT=<name>: a kernel variant built next to the product (csrc/Makefile, VARIANT= /
+# TAG=) and measured against it; unset = the product library.  A name that was not built fails
+# like a missing product library does.
+_VARIANT = os.environ.get("HCTR_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, f"libhugectr_amd{'_' + _VARIANT if _VARIANT else ''}.so")
 
 # enums (include/hugectr_amd.h)
 OPT_FTRL, OPT_ADAM, OPT_RMSPROP, OPT_ADAGRAD, OPT_NESTEROV, OPT_MOMENTUM_SGD, OPT_SGD = range(7)
