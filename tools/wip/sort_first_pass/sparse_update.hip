@@ -1,0 +1,1609 @@
+// sparse_update.hip -- fused embedding backward + sparse optimizer update on gfx950.
+//
+// Replaces backward_sum/backward_mean (R/HugeCTR/src/embeddings/backward_functor.cu:26-104) and
+// EmbeddingOptimizer::update (R/HugeCTR/src/optimizers/sparse_optimizer.cu:622-864).
+// Reference pipeline: wgrad copy -> sample-id expand -> radix sort (row index -> bucket id) ->
+// run flags -> scan -> BLOCKING D2H of the run count -> one block per unique row.
+// Here: no wgrad tensor (the top gradient is read in place, the mean scale 1/n is applied while
+// accumulating), the run count stays on the device (persistent grid-stride over runs), and a
+// "group" of D/4 lanes owns a row with 16-byte accesses.  Gradient accumulation per row is in
+// ascending bucket id, exactly the reference's order (stable sort), then / scaler.
+#include "sparse_update.h"
+#include "radix_sort.h"
+
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "block_prims.h"
+
+namespace hctr {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTile = 1024;
+
+template <typename GradT>
+struct Load4;
+template <>
+struct Load4<float> {
+  typedef float4 raw;  // 4 elements as they sit in memory
+  __device__ __forceinline__ static raw ld_raw(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw r) { return r; }
+  __device__ __forceinline__ static float4 ld(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+  }
+  __device__ __forceinline__ static float ld1(const float* p) { return *p; }
+  __device__ __forceinline__ static float rnd(float v) { return v; }
+};
+template <>
+struct Load4<__half> {
+  typedef uint2 raw;
+  __device__ __forceinline__ static raw ld_raw(const __half* p) {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw u) {
+    __half2 a = *reinterpret_cast<__half2*>(&u.x), b = *reinterpret_cast<__half2*>(&u.y);
+    float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+  }
+  __device__ __forceinline__ static float4 ld(const __half* p) { return cvt(ld_raw(p)); }
+  __device__ __forceinline__ static float ld1(const __half* p) { return __half2float(*p); }
+  __device__ __forceinline__ static float rnd(float v) { return __half2float(__float2half_rn(v)); }
+};
+template <>
+struct Load4<__hip_bfloat16> {
+  typedef uint2 raw;
+  __device__ __forceinline__ static raw ld_raw(const __hip_bfloat16* p) {
+    return *reinterpret_cast<const uint2*>(p);
+  }
+  __device__ __forceinline__ static float4 cvt(raw u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+  }
+  __device__ __forceinline__ static float4 ld(const __hip_bfloat16* p) { return cvt(ld_raw(p)); }
+  __device__ __forceinline__ static float ld1(const __hip_bfloat16* p) {
+    return __bfloat162float(*p);
+  }
+  __device__ __forceinline__ static float rnd(float v) {
+    return __bfloat162float(__float2bfloat16(v));
+  }
+};
+
+// ---- step 1: (row index, bucket id) pairs (sample_id_expand_kernel :189-200) ------------------
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    expand_pairs_kernel(size_t buckets, size_t n_sort, const OffT* __restrict__ row_offset,
+                        const uint64_t* __restrict__ value_index, SortK* __restrict__ keys,
+                        uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count,
+                        uint32_t map_inner, uint32_t map_outer,
+                        const uint32_t* __restrict__ skip_flag) {
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (tid == 0 && blockIdx.y == 0)  // long-run lists of seg_reduce / seg_combine
+    span_count[0] = span_count[1] = span_count[2] = span_count[3] = 0u;
+  // one-hot batch: the sort's first pass takes rows and payloads from where they lie (RsFirst)
+  if (skip_flag != nullptr && *skip_flag != 0u) return;
+  const size_t nthreads = (size_t)gridDim.x * kBlock;
+  // key-parallel (block_prims.h): the payload is the gradient row of the key's bucket
+  // (SparseUpdater::map_inner)
+  for_each_key_wave(buckets, row_offset, [&](size_t u, size_t j) {
+    if (j >= n_sort) return;
+    keys[j] = (SortK)value_index[j];
+    vals[j] = map_inner ? ((uint32_t)u % map_inner) * map_outer + (uint32_t)u / map_inner
+                        : (uint32_t)u;
+  });
+  // padding (host upper bound > live nnz): sorts to the end, never forms a counted run
+  if (blockIdx.y != 0) return;
+  for (size_t j = nnz + tid; j < n_sort; j += nthreads) {
+    keys[j] = (SortK)~(SortK)0;
+    vals[j] = 0xFFFFFFFFu;
+  }
+}
+
+// ---- step 2: run starts ------------------------------------------------------------------------
+template <typename SortK>
+__device__ __forceinline__ bool is_run_start(const SortK* k, size_t i, size_t nnz) {
+  if (i >= nnz) return false;
+  return i == 0 || k[i] != k[i - 1];
+}
+
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    run_count_kernel(const SortK* __restrict__ keys, const OffT* __restrict__ row_offset,
+                     size_t buckets, size_t n_tiles, uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nnz = (size_t)row_offset[buckets];
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < kTile / kBlock; r++) {
+      size_t i = tile * kTile + r * kBlock + threadIdx.x;
+      c += is_run_start(keys, i, nnz) ? 1u : 0u;
+    }
+    uint32_t tot = block_reduce_sum<uint32_t, kBlock>(c, smem);
+    if (threadIdx.x == 0) tile_sums[tile] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+    scan_tiles_u32_kernel(uint32_t* sums, size_t m, uint64_t* d_total) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (size_t base = 0; base < m; base += 1024) {
+    size_t i = base + threadIdx.x;
+    uint32_t v = (i < m) ? sums[i] : 0u;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<uint32_t, 1024>(v, smem, &tot);
+    uint64_t c = carry;
+    if (i < m) sums[i] = (uint32_t)(c + ex);
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = carry;
+}
+
+template <typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    run_write_kernel(const SortK* __restrict__ keys, const OffT* __restrict__ row_offset,
+                     size_t buckets, size_t n_tiles, const uint32_t* __restrict__ tile_sums,
+                     const uint64_t* __restrict__ d_num_runs, uint32_t* __restrict__ run_start) {
+  __shared__ uint32_t smem[kBlock / 64 + 1];
+  const size_t nnz = (size_t)row_offset[buckets];
+  if (blockIdx.x == 0 && threadIdx.x == 0) run_start[*d_num_runs] = (uint32_t)nnz;
+  for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint32_t run = tile_sums[tile];
+#pragma unroll
+    for (int r = 0; r < kTile / kBlock; r++) {
+      size_t i = tile * kTile + r * kBlock + threadIdx.x;
+      bool f = is_run_start(keys, i, nnz);
+      uint32_t tot;
+      uint32_t ex = block_exclusive_scan<uint32_t, kBlock>(f ? 1u : 0u, smem, &tot);
+      if (f) run_start[run + ex] = (uint32_t)i;
+      run += tot;
+    }
+  }
+}
+
+// ---- step 3: per-row ordered reduce + optimizer -------------------------------------------------
+struct OptConst {
+  int optimizer, update_type;
+  float lr, beta1, beta2, epsilon, mf, scaler;
+  float alpha_t;         // lr * adam.bias()
+  float alpha_t_common;  // lr / (1 - beta1) (lazy adam)
+  float ftrl_l1, ftrl_l2b;  // lambda1, lambda2 + beta / lr
+  unsigned long long times;
+  int state_half;  // optimizer state carries fp16 values
+};
+
+// OptimizerTensor<TypeEmbeddingComp> (R/HugeCTR/include/optimizer.hpp:284-296): with fp16 embeddings
+// the reference keeps m / v / accumulators in fp16 -- every kernel converts the stored value to
+// float, computes in float and converts the result back on the store; the weight update of the
+// same step uses the unrounded float.  Here the state arrays stay fp32 and hold fp16-representable
+// values: same numbers, the footprint saving is not taken.
+__device__ __forceinline__ float state_store(int state_half, float x) {
+  if (!state_half) return x;
+  // the fp32 result first, THEN the conversion (two roundings, as the reference's float math +
+  // TypeConvertFunc does): without the barrier the compiler folds a preceding multiply into one
+  // mixed-precision instruction that rounds the exact product straight to fp16
+  asm volatile("" : "+v"(x));
+  return __half2float(__float2half_rn(x));
+}
+
+// internal pseudo-optimizer of hctr_updater_reduce_presorted: table[row] = gradient sum (no read)
+constexpr int kOptStoreSum = 1000;
+
+// one element of one row; formulas cite sparse_optimizer.cu
+__device__ __forceinline__ void apply_opt(const OptConst& o, float gi, float& w, float* s0p,
+                                          float* s1p, unsigned long long* ptp) {
+  switch (o.optimizer) {
+    case HCTR_OPT_SGD:  // opt_sgd_kernel :497-518
+      w += -o.lr * gi;
+      break;
+    case kOptStoreSum:
+      w = gi;
+      break;
+    case HCTR_OPT_FTRL: {  // FtrlOptimizer::update, ragged_static_embedding.cu:159-290 (s0 = n, s1 = z)
+      float ni = *s0p;
+      const float sq = sqrtf(ni + 1.1920929e-07f);
+      ni = ni + gi * gi;
+      const float sqn = sqrtf(ni + 1.1920929e-07f);
+      const float sigma = (sqn - sq) / o.lr;
+      const float zi = *s1p + gi - sigma * w;
+      const float p = (1.f - 2.f * (float)signbit(zi)) * o.ftrl_l1 - zi;
+      const float q = sqn / o.lr + o.ftrl_l2b;
+      w = p / q * (float)signbit(o.ftrl_l1 - fabsf(zi));
+      *s0p = state_store(o.state_half, ni);
+      *s1p = state_store(o.state_half, zi);
+    } break;
+    case HCTR_OPT_ADAGRAD: {  // opt_adagrad_kernel :410-437 (Global == Local)
+      float accum = *s0p + gi * gi;
+      *s0p = state_store(o.state_half, accum);
+      w += -o.lr * gi / (sqrtf(accum) + o.epsilon);
+    } break;
+    case HCTR_OPT_ADAM:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_adam_kernel :379-408
+        float mi = o.beta1 * *s0p + (1.0f - o.beta1) * gi;
+        float vi = o.beta2 * *s1p + (1.0f - o.beta2) * gi * gi;
+        *s0p = state_store(o.state_half, mi);
+        *s1p = state_store(o.state_half, vi);
+        w += -o.alpha_t * mi / (sqrtf(vi) + o.epsilon);
+      } else if (o.update_type == HCTR_UPDATE_GLOBAL) {  // opt_adam_kernel_global :241-265
+        *s0p = state_store(o.state_half, *s0p + (1.0f - o.beta1) * gi / o.beta1);
+        *s1p = state_store(o.state_half, *s1p + (1.0f - o.beta2) * gi * gi / o.beta2);
+      } else {  // opt_adam_kernel_lazy :524-561
+        unsigned long long pt = *ptp;
+        *ptp = o.times;
+        unsigned long long skipped = o.times - pt;
+        float b1ps = powf(o.beta1, (float)skipped);
+        float a = o.alpha_t_common * sqrtf(1.0f - powf(o.beta2, (float)pt)) /
+                  (1.0f - powf(o.beta1, (float)pt)) * (1.0f - b1ps);
+        float mi = *s0p, vi = *s1p;
+        w += -a * mi / (sqrtf(vi) + o.epsilon);
+        mi = b1ps * mi + (1.0f - o.beta1) * gi;
+        vi = powf(o.beta2, (float)skipped) * vi + (1.0f - o.beta2) * gi * gi;
+        *s0p = state_store(o.state_half, mi);
+        *s1p = state_store(o.state_half, vi);
+      }
+      break;
+    case HCTR_OPT_MOMENTUM_SGD:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_momentum_sgd_kernel :440-465
+        float mo = o.mf * *s0p - o.lr * gi;
+        *s0p = state_store(o.state_half, mo);
+        w += mo;
+      } else {  // opt_momentum_sgd_kernel_global :292-312
+        *s0p = state_store(o.state_half, *s0p - o.lr * gi / o.mf);
+      }
+      break;
+    case HCTR_OPT_NESTEROV:
+      if (o.update_type == HCTR_UPDATE_LOCAL) {  // opt_nesterov_kernel :468-494
+        float accm_old = *s0p;
+        float accm_new = o.mf * accm_old - o.lr * gi;
+        *s0p = state_store(o.state_half, accm_new);
+        w += -o.mf * accm_old + (1.0f + o.mf) * accm_new;
+      } else {  // nesterov_local_update_kernel_global :352-375
+        float accm = *s0p;
+        accm -= o.lr * gi;
+        *s0p = state_store(o.state_half, accm);
+        w -= (1.0f + o.mf) * (o.lr * gi);
+      }
+      break;
+    default: break;
+  }
+}
+
+__device__ __forceinline__ bool needs_s0(const OptConst& o) {
+  return o.optimizer != HCTR_OPT_SGD && o.optimizer != kOptStoreSum;
+}
+__device__ __forceinline__ bool needs_s1(const OptConst& o) {
+  return o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_FTRL;
+}
+__device__ __forceinline__ bool needs_pt(const OptConst& o) {
+  return o.optimizer == HCTR_OPT_ADAM && o.update_type == HCTR_UPDATE_LAZY_GLOBAL;
+}
+
+// Row update shared by seg_apply_kernel and seg_combine_kernel, split in load / compute / store so
+// that callers can keep several rows in flight: gi = acc / scaler, then the optimizer on the 4
+// elements this lane owns.
+struct RowRegs {
+  float4 w, s0, s1;
+  unsigned long long pt[4];
+};
+
+template <int LPR>
+__device__ __forceinline__ void row_load(const OptConst& o, uint64_t row, int l, RowRegs& r,
+                                         const float* __restrict__ table,
+                                         const float* __restrict__ state0,
+                                         const float* __restrict__ state1,
+                                         const unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  const size_t f = row * (uint64_t)D + l * 4;
+  r.s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  r.w = r.s0;
+  if (o.optimizer != kOptStoreSum) r.w = *reinterpret_cast<const float4*>(table + f);
+  r.s1 = r.s0;
+  r.pt[0] = r.pt[1] = r.pt[2] = r.pt[3] = 1ull;
+  if (needs_s0(o)) r.s0 = *reinterpret_cast<const float4*>(state0 + f);
+  if (needs_s1(o)) r.s1 = *reinterpret_cast<const float4*>(state1 + f);
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) r.pt[t] = prev_time[f + t];
+  }
+}
+
+__device__ __forceinline__ void row_compute(const OptConst& o, float4 gi, RowRegs& r) {
+  gi.x /= o.scaler;
+  gi.y /= o.scaler;
+  gi.z /= o.scaler;
+  gi.w /= o.scaler;
+  apply_opt(o, gi.x, r.w.x, &r.s0.x, &r.s1.x, &r.pt[0]);
+  apply_opt(o, gi.y, r.w.y, &r.s0.y, &r.s1.y, &r.pt[1]);
+  apply_opt(o, gi.z, r.w.z, &r.s0.z, &r.s1.z, &r.pt[2]);
+  apply_opt(o, gi.w, r.w.w, &r.s0.w, &r.s1.w, &r.pt[3]);
+}
+
+template <int LPR>
+__device__ __forceinline__ void row_store(const OptConst& o, uint64_t row, int l, const RowRegs& r,
+                                          float* __restrict__ table, float* __restrict__ state0,
+                                          float* __restrict__ state1,
+                                          unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  const size_t f = row * (uint64_t)D + l * 4;
+  const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
+                           o.update_type == HCTR_UPDATE_GLOBAL);
+  if (w_written) *reinterpret_cast<float4*>(table + f) = r.w;
+  if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = r.s0;
+  if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = r.s1;
+  if (needs_pt(o)) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) prev_time[f + t] = r.pt[t];
+  }
+}
+
+// A key that found no row (hash table overflow, or an unseen key of an index-only call) carries
+// kInvalidIndex; as a 32-bit sort key that is 0xFFFFFFFF, which create() keeps out of the legal row
+// range.  Such positions sort behind every live row and their run is dropped by every writer.
+constexpr uint64_t kNoRow = 0xFFFFFFFFull;
+
+template <int LPR>
+__device__ __forceinline__ void apply_row_vec4(const OptConst& o, uint64_t row, int l, float4 gi,
+                                               float* __restrict__ table,
+                                               float* __restrict__ state0,
+                                               float* __restrict__ state1,
+                                               unsigned long long* __restrict__ prev_time) {
+  if (row == kNoRow) return;
+  RowRegs r;
+  row_load<LPR>(o, row, l, r, table, state0, state1, prev_time);
+  row_compute(o, gi, r);
+  row_store<LPR>(o, row, l, r, table, state0, state1, prev_time);
+}
+
+// Tile-based segmented reduce + optimizer.  The sorted (row, bucket) list is cut into tiles of
+// kSegTile positions; a group of LPR lanes walks one tile in order, so every group performs about
+// the same number of gradient-row reads no matter how skewed the key distribution is (the
+// reference gives one block to each unique row, sparse_optimizer.cu:223-237 -- a power-law head
+// row with 20k duplicates is then one serial 20k-iteration loop).
+//   * A run (= all gradients of one row) that starts in tile t is OWNED by tile t's group.  The
+//     owner follows it up to one tile past its own tile end; the next tile's group skips those
+//     leading positions.  So every run that ends before the end of tile t+1 is reduced by one group
+//     in ascending bucket order (the reference's order, stable sort) and applied at once.
+//   * A run that reaches beyond tile t+1 is "long": the owner stores the sum of its own part in
+//     tail[t] and appends t to span_list; every later tile the run touches stores its part in
+//     head[t'].  seg_combine_kernel adds tail + heads in a fixed order (deterministic).
+constexpr int kSegTile = 32;
+
+// number of keys in bucket b (the mean combiner's divisor)
+__device__ __forceinline__ int bucket_len(const void* row_offset_v, bool off_is_u32, uint32_t b) {
+  if (off_is_u32) {
+    const uint32_t* ro = (const uint32_t*)row_offset_v;
+    return (int)(ro[b + 1] - ro[b]);
+  }
+  const long long* ro = (const long long*)row_offset_v;
+  return (int)(ro[b + 1] - ro[b]);
+}
+
+template <typename GradT>
+__device__ __forceinline__ float4 scaled_grad(typename Load4<GradT>::raw r, int combiner, int n) {
+  float4 v = Load4<GradT>::cvt(r);
+  if (combiner == 1) {
+    // backward_mean_align2_kernel (backward_functor.cu:83-104): the scaler is rounded to the
+    // gradient type before the multiply; fp32 gradients: rnd() is the identity
+    const float sc = Load4<GradT>::rnd(n > 1 ? 1.0f / (float)n : 1.0f);
+    v.x = Load4<GradT>::rnd(v.x * sc);
+    v.y = Load4<GradT>::rnd(v.y * sc);
+    v.z = Load4<GradT>::rnd(v.z * sc);
+    v.w = Load4<GradT>::rnd(v.w * sc);
+  }
+  return v;
+}
+
+// Phase A: segmented sums.  Pure load/accumulate/store -- no read-modify-write of table rows
+// inside the walk.  The kernel is bound by DEPENDENT memory round trips per tile, not by bytes, so
+// everything a tile may need is fetched in as few trips as possible:
+//   trip 1: the tile's 32 (row, bucket) pairs, one per lane (coalesced), the NEXT tile's pairs
+//           (for the run that overhangs the tile end) and the four neighbour rows that decide
+//           ownership -- run starts / overhang length become 32-bit ballot masks;
+//   trips 2..: the 32 gradient rows of the tile plus the first kSegAhead rows of the overhang,
+//           issued back to back in batches of QB raw (unconverted) fragments, clamped to a row the
+//           batch reads anyway where a position is not needed.
+// The only sequential part is the fp32 add chain, which is what fixes the summation order.
+// The sum of a run its owner finishes goes to gsum[start position]; seg_apply_kernel picks it up.
+constexpr int kSegAhead = 8;
+
+// row id of tile position q (0..31): the metadata lane that holds it broadcasts it to the group
+template <int NPL, int ML>
+__device__ __forceinline__ uint32_t seg_row_at(const uint32_t (&mrow)[NPL], int q, int gshift) {
+  uint32_t src = mrow[0];
+#pragma unroll
+  for (int j = 1; j < NPL; j++) src = (q / ML == j) ? mrow[j] : src;
+  return (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
+}
+
+constexpr int kFuseNone = 0, kFuseSgd = 1, kFuseAdaGrad = 2;
+
+template <int LPR, typename OffT, typename SortK, typename GradT, int kFuse>
+__global__ void __launch_bounds__(kBlock)
+    seg_reduce_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                      const SortK* __restrict__ sorted_rows,
+                      const uint32_t* __restrict__ sorted_buckets, int combiner,
+                      const GradT* __restrict__ grad, float* __restrict__ gsum,
+                      float* __restrict__ head, float* __restrict__ tail,
+                      uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
+                      float* __restrict__ direct_out, const OffT* __restrict__ scale_ro,
+                      OptConst fuse_o, float* __restrict__ fuse_state0) {
+  // kFuse (kFuseSgd / kFuseAdaGrad): the optimizer applied where a run's sum is complete --
+  // e.g. table[row] += -lr * (sum / scaler) -- right here (direct_out = the table) instead of
+  // parking the sum in gsum for seg_apply.  Every row is one run owned by one lane group, so
+  // nobody else touches it; the arithmetic is seg_apply's (apply_opt), bit for bit, without the
+  // gsum round trip (2 x D x 4 bytes per unique row).  Optimizers with two state vectors or
+  // time stamps keep the two-pass form (their row registers would cost the gather its occupancy).
+  // Measured (MI355X): one-hot Criteo-1TB update 231 -> 209 us, embedding_collection one-hot
+  // backward+update 365 -> 295 us, multi-hot MLPerf shape 2.15 -> 1.84 ms.  (No-return fp32
+  // atomic adds in place of the read-modify-write were 2x SLOWER: 496 us / 4.2 ms.)
+  // scale_ro: the CSR whose bucket lengths divide a mean gradient.  The distributed embedding
+  // divides by the bucket's key count over ALL GPUs (backward() with the all-reduced row offsets,
+  // distributed_slot_sparse_embedding_hash.hpp:216-221), not by this rank's filtered count.
+  // direct_out != nullptr (hctr_updater_reduce_presorted): the sum of a finished run goes to
+  // direct_out[row] instead of gsum[run start] -- no apply pass is needed afterwards
+  typedef typename Load4<GradT>::raw Raw;
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int T = kSegTile;
+  constexpr int LA = kSegAhead;
+  constexpr int ML = LPR < T ? LPR : T;  // lanes of a group that carry tile metadata
+  constexpr int NPL = T / ML;            // metadata entries per such lane
+  constexpr int QB = sizeof(Raw) == 8 ? 20 : 10;  // fragments in flight per lane: 40 VGPRs
+  constexpr bool kOff32 = sizeof(OffT) == 4;
+  static_assert(T == 32 && (T + LA) % QB == 0, "masks are 32-bit; batches tile T + LA");
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const int gshift = ((threadIdx.x & 63) / LPR) * LPR;  // first lane of my group in the wave
+  constexpr unsigned long long kGroupMask = ML >= 64 ? ~0ull : ((1ull << ML) - 1ull);
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t n_tiles = (nnz + T - 1) / T;
+  // kFuse: the row update of a finished run is completed when the NEXT run finishes -- its row
+  // (and accumulator) read travels while the next run's gradients are added, instead of stalling
+  // the lane group (one-hot update 205 -> 195 us, multi-hot backward + update 1.73 -> 1.59 ms)
+  uint32_t pend_row = 0xFFFFFFFFu;
+  float4 pend_w = make_float4(0.f, 0.f, 0.f, 0.f), pend_d = pend_w;
+  RowRegs pend_rr;  // kFuseAdaGrad: row + accumulator in flight, pend_d = the run's gradient sum
+  auto pend_flush = [&]() {
+    if (pend_row != 0xFFFFFFFFu) {
+      if constexpr (kFuse == kFuseAdaGrad) {
+        OptConst oo = fuse_o;
+        oo.optimizer = HCTR_OPT_ADAGRAD;  // (compile-time: the state loads / stores fold)
+        row_compute(oo, pend_d, pend_rr);
+        row_store<LPR>(oo, (uint64_t)pend_row, l, pend_rr, direct_out, fuse_state0, nullptr, nullptr);
+      } else {
+        pend_w.x += pend_d.x;
+        pend_w.y += pend_d.y;
+        pend_w.z += pend_d.z;
+        pend_w.w += pend_d.w;
+        *reinterpret_cast<float4*>(direct_out + (size_t)pend_row * D + l * 4) = pend_w;
+      }
+    }
+  };
+  for (size_t tile = (size_t)blockIdx.x * GPB + g; tile < n_tiles;
+       tile += (size_t)gridDim.x * GPB) {
+    const size_t base = tile * T;
+    const size_t end = (base + T < nnz) ? base + T : nnz;
+    const size_t limit = (end + T < nnz) ? end + T : nnz;
+    const int nvalid = (int)(end - base);
+    // ---- trip 1: all metadata --------------------------------------------------------------
+    uint32_t mrow[NPL], mbkt[NPL], prow[NPL], nrow[NPL], nbkt[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const size_t pos = base + (size_t)j * ML + l;
+      const bool valid = l < ML && pos < end;
+      mrow[j] = valid ? (uint32_t)sorted_rows[pos] : 0xFFFFFFFFu;
+      mbkt[j] = valid ? sorted_buckets[pos] : 0u;
+      prow[j] = (valid && pos > 0) ? (uint32_t)sorted_rows[pos - 1] : 0xFFFFFFFFu;
+      const size_t np = end + (size_t)j * ML + l;
+      const bool nval = l < ML && np < limit;
+      nrow[j] = nval ? (uint32_t)sorted_rows[np] : 0xFFFFFFFFu;
+      nbkt[j] = nval ? sorted_buckets[np] : 0u;
+    }
+    // rows at base-T, base-T-1 (who owns a run that enters this tile) and at limit (does the
+    // overhanging run reach beyond tile+1); 0xFFFFFFFF never equals a live row
+    const uint32_t row_pt = base >= (size_t)T ? (uint32_t)sorted_rows[base - T] : 0xFFFFFFFFu;
+    const uint32_t row_pt1 = base > (size_t)T ? (uint32_t)sorted_rows[base - T - 1] : 0xFFFFFFFFu;
+    const uint32_t row_lim = limit < nnz ? (uint32_t)sorted_rows[limit] : 0xFFFFFFFFu;
+
+    uint32_t startmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const size_t pos = base + (size_t)j * ML + l;
+      const bool valid = l < ML && pos < end;
+      const bool is_start = valid && (pos == 0 || prow[j] != mrow[j]);
+      const unsigned long long bal = __ballot(is_start);
+      startmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
+    }
+    const uint32_t row0 = (uint32_t)__shfl((int)mrow[0], gshift, 64);
+    const uint32_t cur_row =
+        (uint32_t)__shfl((int)mrow[(nvalid - 1) / ML], gshift + ((nvalid - 1) % ML), 64);
+    const uint32_t next_row0 = (uint32_t)__shfl((int)nrow[0], gshift, 64);
+#define HCTR_RUN_DST(q_)                                                                        \
+  ((direct_out != nullptr && seg_row_at<NPL, ML>(mrow, (q_), gshift) != 0xFFFFFFFFu)             \
+       ? direct_out + (size_t)seg_row_at<NPL, ML>(mrow, (q_), gshift) * D                       \
+       : gsum + (base + (size_t)(q_)) * D) /* a run of keys without a row has no output row */
+    auto emit_run = [&](int q_run, const float4& a) {
+      if constexpr (kFuse == kFuseSgd) {
+        const uint32_t r = seg_row_at<NPL, ML>(mrow, q_run, gshift);
+        if (r != 0xFFFFFFFFu) {
+          pend_flush();
+          pend_d.x = -fuse_o.lr * (a.x / fuse_o.scaler);
+          pend_d.y = -fuse_o.lr * (a.y / fuse_o.scaler);
+          pend_d.z = -fuse_o.lr * (a.z / fuse_o.scaler);
+          pend_d.w = -fuse_o.lr * (a.w / fuse_o.scaler);
+          pend_row = r;
+          pend_w = *reinterpret_cast<const float4*>(direct_out + (size_t)r * D + l * 4);
+        }
+      } else if constexpr (kFuse == kFuseAdaGrad) {
+        const uint32_t r = seg_row_at<NPL, ML>(mrow, q_run, gshift);
+        if (r != 0xFFFFFFFFu) {
+          pend_flush();
+          OptConst oo = fuse_o;
+          oo.optimizer = HCTR_OPT_ADAGRAD;
+          pend_d = a;
+          pend_row = r;
+          row_load<LPR>(oo, (uint64_t)r, l, pend_rr, direct_out, fuse_state0, nullptr, nullptr);
+        }
+      } else {
+        *reinterpret_cast<float4*>(HCTR_RUN_DST(q_run) + l * 4) = a;
+      }
+    };
+    const bool ends_at_tile_end = end == nnz || next_row0 != cur_row;
+    int q0 = 0;
+    bool head_mode = false;
+    if (base > 0 && (startmask & 1u) == 0u) {
+      // the tile starts inside a run begun earlier: owned by the previous tile AND ending inside
+      // this tile -> its owner reduces it, skip it; otherwise it is (part of) a long run.
+      const bool owner_prev = row_pt != row0 || base == (size_t)T || row_pt1 != row0;
+      const bool whole_tile = startmask == 0u;
+      const bool ends_inside = !whole_tile || ends_at_tile_end;
+      if (owner_prev && ends_inside) q0 = whole_tile ? nvalid : __ffs((int)startmask) - 1;
+      else head_mode = true;
+    }
+    if (q0 >= nvalid) continue;  // the whole tile belonged to the previous tile's run
+    // overhang: leading positions of the next tile that continue this tile's last run
+    uint32_t matchmask = 0u;
+#pragma unroll
+    for (int j = 0; j < NPL; j++) {
+      const unsigned long long bal = __ballot(nrow[j] == cur_row);
+      matchmask |= (uint32_t)((bal >> gshift) & kGroupMask) << (j * ML);
+    }
+    const bool whole_head = head_mode && startmask == 0u;  // one earlier run covers the tile
+    int cnt = (~matchmask == 0u) ? T : __ffs((int)~matchmask) - 1;  // leading ones
+    if (ends_at_tile_end || whole_head) cnt = 0;
+    const int cnt_la = cnt < LA ? cnt : LA;
+
+    // ---- trips 2..: gradient rows, QB fragments in flight ---------------------------------
+    int run_start = q0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 own_part = acc;
+    const uint32_t b_q0 = (uint32_t)__shfl((int)mbkt[q0 / ML], gshift + (q0 % ML), 64);
+#pragma unroll
+    for (int qb = 0; qb < T + LA; qb += QB) {
+      Raw v[QB];
+      int nb[QB];
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const int q = qb + k;
+        uint32_t bsel;
+        if (q < T) {
+          const uint32_t bq = (uint32_t)__shfl((int)mbkt[q / ML], gshift + (q % ML), 64);
+          bsel = (q >= q0 && q < nvalid) ? bq : b_q0;
+        } else {
+          const uint32_t bq =
+              (uint32_t)__shfl((int)nbkt[(q - T) / ML], gshift + ((q - T) % ML), 64);
+          bsel = (q - T) < cnt_la ? bq : b_q0;
+        }
+        v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
+        nb[k] = combiner == 1 ? bucket_len(scale_ro, kOff32, bsel) : 1;
+      }
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const int q = qb + k;
+        if (q == T) own_part = acc;
+        if (q < T) {
+          if (q >= q0 && q < nvalid) {
+            if (((startmask >> q) & 1u) != 0u && q != q0) {
+              if (head_mode) *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
+              else emit_run(run_start, acc);
+              acc = make_float4(0.f, 0.f, 0.f, 0.f);
+              run_start = q;
+              head_mode = false;
+            }
+            const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+            acc.x += f.x;
+            acc.y += f.y;
+            acc.z += f.z;
+            acc.w += f.w;
+          }
+        } else if ((q - T) < cnt_la) {
+          const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+          acc.x += f.x;
+          acc.y += f.y;
+          acc.z += f.z;
+          acc.w += f.w;
+        }
+      }
+    }
+    if (head_mode) {  // one run covers the whole tile
+      *reinterpret_cast<float4*>(head + tile * D + l * 4) = acc;
+      continue;
+    }
+    if (cnt == 0) {  // the last run ends with the tile
+      emit_run(run_start, acc);
+      continue;
+    }
+    // the last run of this tile continues: this group owns it and follows it through tile+1
+    if (cnt > LA) {
+      constexpr int QC = 8;
+#pragma unroll 1
+      for (int qb = LA; qb < cnt; qb += QC) {
+        Raw v[QC];
+        int nb[QC];
+#pragma unroll
+        for (int k = 0; k < QC; k++) {
+          const int q = (qb + k) < cnt ? qb + k : cnt - 1;
+          // NPL > 1: the register index is dynamic here -> select with a small unrolled scan
+          uint32_t src = nbkt[0];
+#pragma unroll
+          for (int j = 1; j < NPL; j++) src = (q / ML == j) ? nbkt[j] : src;
+          const uint32_t bsel = (uint32_t)__shfl((int)src, gshift + (q % ML), 64);
+          v[k] = Load4<GradT>::ld_raw(grad + (size_t)bsel * D + l * 4);
+          nb[k] = combiner == 1 ? bucket_len(scale_ro, kOff32, bsel) : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < QC; k++) {
+          if (qb + k < cnt) {
+            const float4 f = scaled_grad<GradT>(v[k], combiner, nb[k]);
+            acc.x += f.x;
+            acc.y += f.y;
+            acc.z += f.z;
+            acc.w += f.w;
+          }
+        }
+      }
+    }
+    // long <=> the run reaches beyond the end of tile+1
+    const bool runs_on = cnt == T && limit < nnz && row_lim == cur_row;
+    if (!runs_on) {
+      emit_run(run_start, acc);
+    } else {
+      *reinterpret_cast<float4*>(tail + tile * D + l * 4) = own_part;
+      if (l == 0) span_list[atomicAdd(span_count, 1u)] = (uint32_t)tile;
+    }
+  }
+  if constexpr (kFuse != kFuseNone) pend_flush();
+}
+#undef HCTR_RUN_DST
+
+// Phase B: one lane inspects one sorted position; run starts of runs that are not "long" are
+// compacted with a wave ballot and handed to lane groups, which read the run's gradient sum from
+// gsum[position] and apply the optimizer to the row (one coalesced D*4-byte RMW per row).
+// kSgd: plain SGD known at compile time -- one float4 of state per row instead of the generic
+// RowRegs (w, two state vectors, four time stamps: 148 VGPRs, 3 waves per SIMD), 8 rows per lane
+// group in flight instead of 4 (93 VGPRs).  Same arithmetic, same bits; seg_apply 98 -> 70 us at
+// the bench shape.
+template <int LPR, typename OffT, typename SortK, bool kSgd>
+__global__ void __launch_bounds__(kBlock)
+    seg_apply_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                     const SortK* __restrict__ sorted_rows, const float* __restrict__ gsum,
+                     OptConst o, float* __restrict__ table, float* __restrict__ state0,
+                     float* __restrict__ state1, unsigned long long* __restrict__ prev_time) {
+  constexpr int D = LPR * 4;
+  constexpr int G = 64 / LPR;  // groups per wavefront
+  constexpr int T = kSegTile;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t c0 = wave * 64; c0 < nnz; c0 += nwaves * 64) {
+    const size_t p = c0 + lane;
+    SortK row = 0;
+    bool active = false;
+    if (p < nnz) {
+      row = sorted_rows[p];
+      const bool is_start = p == 0 || sorted_rows[p - 1] != row;
+      if (is_start) {
+        const size_t e2 = (p / T + 2) * T;  // first position after the tile following p's tile
+        const bool is_long = e2 < nnz && sorted_rows[e2] == row;
+        active = !is_long && (uint64_t)row != kNoRow;
+      }
+    }
+    unsigned long long mask = __ballot(active);
+    // R rows per group per step: all gsum / table / state reads of a step are issued before the
+    // first optimizer evaluation
+    constexpr int R = kSgd ? 8 : 4;
+    while (mask != 0ull) {
+      int src[R];
+#pragma unroll
+      for (int k = 0; k < R; k++) {
+        src[k] = -1;
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+          if (mask != 0ull) {
+            const int bit = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            if (q == g) src[k] = bit;
+          }
+        }
+      }
+      uint32_t r2[R];
+      float4 gi[R];
+      if constexpr (kSgd) {
+        float4 w[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
+          if (src[k] >= 0) {
+            gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
+            w[k] = *reinterpret_cast<const float4*>(table + (uint64_t)r2[k] * D + l * 4);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          if (src[k] >= 0) {  // row_compute + apply_opt(HCTR_OPT_SGD): w += -lr * (g / scaler)
+            w[k].x += -o.lr * (gi[k].x / o.scaler);
+            w[k].y += -o.lr * (gi[k].y / o.scaler);
+            w[k].z += -o.lr * (gi[k].z / o.scaler);
+            w[k].w += -o.lr * (gi[k].w / o.scaler);
+            *reinterpret_cast<float4*>(table + (uint64_t)r2[k] * D + l * 4) = w[k];
+          }
+        }
+      } else {
+        RowRegs rr[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          r2[k] = (uint32_t)__shfl((int)row, src[k] < 0 ? 0 : src[k], 64);
+          if (src[k] >= 0) {
+            gi[k] = *reinterpret_cast<const float4*>(gsum + (c0 + src[k]) * D + l * 4);
+            row_load<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+          if (src[k] >= 0) {
+            row_compute(o, gi[k], rr[k]);
+            row_store<LPR>(o, (uint64_t)r2[k], l, rr[k], table, state0, state1, prev_time);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Long runs (listed in span_list by the tile they start in): tail[t0] + head[t0+1] + head[t0+2] ...
+// With power-law keys most long runs are a few tiles long while a handful (the rows of 3- or
+// 10-row tables) span hundreds of tiles.  seg_combine_kernel gives one lane group to each run: it
+// measures the run (how many following tiles begin with the same row) and adds the head partials
+// in order, 8 reads in flight; runs of more than kCombBigTiles tiles are parked in big_list and
+// taken by seg_combine_big_kernel, one 1024-thread workgroup per run: group q adds heads q,
+// q+GPB, ...; the GPB sums are added in the fixed order q = 0..GPB-1.  Both orders are fixed, so
+// the result does not depend on scheduling.
+constexpr int kCombBigTiles = 64;
+constexpr int kCombBlock = 1024;
+constexpr int kCombBigChunk = 2048;  // tile partials one workgroup of the big kernel adds
+
+template <int LPR, typename OffT, typename SortK>
+__global__ void __launch_bounds__(kBlock)
+    seg_combine_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                       const SortK* __restrict__ sorted_rows, OptConst o,
+                       float* __restrict__ table, float* __restrict__ state0,
+                       float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                       const float* __restrict__ head, const float* __restrict__ tail,
+                       const uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
+                       uint32_t* __restrict__ big_list, size_t big_stride) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int CU = 8;
+  constexpr unsigned long long kGroupMask = LPR >= 64 ? ~0ull : ((1ull << LPR) - 1ull);
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
+  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
+  const uint32_t n_span = span_count[0];
+  for (size_t si = (size_t)blockIdx.x * GPB + g; si < n_span; si += (size_t)gridDim.x * GPB) {
+    const size_t t0 = span_list[si];
+    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    float4 acc = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+    size_t n_heads = 0;
+    bool parked = false;
+    for (;;) {
+      const size_t tt = t0 + 1 + n_heads + l;
+      const bool match = tt < n_tiles && sorted_rows[tt * kSegTile] == row;
+      const unsigned long long gm = (__ballot(match) >> gshift) & kGroupMask;
+      const int ld = gm == kGroupMask ? LPR : __ffsll((long long)~gm) - 1;
+      n_heads += (size_t)ld;
+      if (ld < LPR) break;
+      if (n_heads > (size_t)kCombBigTiles) {
+        parked = true;
+        break;
+      }
+    }
+    if (parked) {
+      // a big run: measure it to the end (LPR evenly spaced probes per round; tiles < lo begin
+      // with `row`, tile hi does not) and register its chunks of kCombBigChunk tile partials --
+      // seg_combine_big_kernel gives every chunk a workgroup of its own
+      size_t lo = t0 + 1 + n_heads, hi = n_tiles;
+      while (lo < hi) {
+        const size_t step = (hi - lo + LPR - 1) / LPR;
+        const size_t probe = lo + (size_t)l * step;
+        const bool match = probe < hi && sorted_rows[probe * kSegTile] == row;
+        const unsigned long long gm = (__ballot(match) >> gshift) & kGroupMask;
+        const int m = gm == kGroupMask ? LPR : __ffsll((long long)~gm) - 1;
+        if (m == 0) {
+          hi = lo;
+        } else {
+          const size_t first_miss = lo + (size_t)m * step;
+          lo = lo + (size_t)(m - 1) * step + 1;
+          if (first_miss < hi) hi = first_miss;
+        }
+      }
+      if (l == 0) {
+        const size_t n = lo - (t0 + 1);
+        const unsigned long long nch = (n + kCombBigChunk - 1) / kCombBigChunk;
+        // one 64-bit counter: runs in the upper half, chunks in the lower -- the chunk bases
+        // then ascend with the slot numbers (binary search in the big kernel)
+        const unsigned long long old = atomicAdd(
+            reinterpret_cast<unsigned long long*>(span_count + 2), (1ull << 32) | nch);
+        const size_t slot = (size_t)(old >> 32);
+        big_list[slot] = (uint32_t)t0;
+        big_list[big_stride + slot] = (uint32_t)n;
+        big_list[2 * big_stride + slot] = (uint32_t)(old & 0xFFFFFFFFull);
+      }
+      continue;
+    }
+    for (size_t i = 0; i < n_heads; i += CU) {
+      float4 h[CU];
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        const size_t tt = t0 + 1 + (i + c < n_heads ? i + c : i);  // clamp: always a legal read
+        h[c] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
+      }
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        if (i + c < n_heads) {
+          acc.x += h[c].x;
+          acc.y += h[c].y;
+          acc.z += h[c].z;
+          acc.w += h[c].w;
+        }
+      }
+    }
+    apply_row_vec4<LPR>(o, (uint64_t)row, l, acc, table, state0, state1, prev_time);
+  }
+}
+
+template <int LPR, typename OffT, typename SortK>
+__global__ void __launch_bounds__(kCombBlock)
+    seg_combine_big_kernel(size_t buckets, const OffT* __restrict__ row_offset,
+                           const SortK* __restrict__ sorted_rows, OptConst o,
+                           float* __restrict__ table, float* __restrict__ state0,
+                           float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                           float* head, const float* __restrict__ tail, uint32_t* big_list,
+                           size_t big_stride, const uint32_t* __restrict__ span_count) {
+  // Work item = one chunk (kCombBigChunk tile partials) of one big run.  A row with a million
+  // gradients is 30 000 partials: one workgroup adding them all was the tail of the whole update
+  // (a single CU's bandwidth); now its chunks run side by side.  Every chunk sum has a fixed order
+  // (group q adds partials q, q + GPB, ...; the GPB group sums are added q = 0..GPB-1), a chunk's
+  // sum is parked in the slot of its own first partial, and the workgroup that finishes LAST (a
+  // counter per run) adds tail + chunk sums in chunk order and applies the optimizer: the result
+  // does not depend on which workgroup that is.
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kCombBlock / LPR;
+  constexpr int CU = 8;
+  __shared__ float4 part[kCombBlock];
+  __shared__ int is_last;
+  const int g = threadIdx.x / LPR;
+  const int l = threadIdx.x % LPR;
+  const unsigned long long ctr = *reinterpret_cast<const unsigned long long*>(span_count + 2);
+  const uint32_t n_big = (uint32_t)(ctr >> 32);
+  const uint32_t total = (uint32_t)(ctr & 0xFFFFFFFFull);
+  const uint32_t* big_t0 = big_list;
+  const uint32_t* big_len = big_list + big_stride;
+  const uint32_t* big_base = big_list + 2 * big_stride;
+  uint32_t* big_done = big_list + 3 * big_stride;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    uint32_t lo = 0, hi = n_big;  // the run whose chunks include w: last slot with base <= w
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (big_base[mid] <= w) lo = mid;
+      else hi = mid;
+    }
+    const uint32_t slot = lo;
+    const size_t t0 = big_t0[slot];
+    const size_t n_heads = big_len[slot];
+    const uint32_t c = w - big_base[slot];
+    const uint32_t nch = (uint32_t)((n_heads + kCombBigChunk - 1) / kCombBigChunk);
+    const SortK row = sorted_rows[(t0 + 1) * kSegTile - 1];
+    const size_t h0 = (size_t)c * kCombBigChunk;
+    const size_t h1 = h0 + kCombBigChunk < n_heads ? h0 + kCombBigChunk : n_heads;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = h0 + (size_t)g; i < h1; i += (size_t)GPB * CU) {
+      float4 h[CU];
+#pragma unroll
+      for (int k = 0; k < CU; k++) {
+        const size_t ii = i + (size_t)k * GPB;
+        const size_t tt = t0 + 1 + (ii < h1 ? ii : i);
+        h[k] = *reinterpret_cast<const float4*>(head + tt * D + l * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < CU; k++) {
+        if (i + (size_t)k * GPB < h1) {
+          acc.x += h[k].x;
+          acc.y += h[k].y;
+          acc.z += h[k].z;
+          acc.w += h[k].w;
+        }
+      }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0) {
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nch == 1u) tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+#pragma unroll 8
+      for (int q = 0; q < GPB; q++) {
+        const float4 pq = part[q * LPR + l];
+        tot.x += pq.x;
+        tot.y += pq.y;
+        tot.z += pq.z;
+        tot.w += pq.w;
+      }
+      if (nch == 1u) {
+        apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+      } else {  // every partial of this chunk has been read (the barrier above): reuse slot h0
+        *reinterpret_cast<float4*>(head + (t0 + 1 + h0) * D + l * 4) = tot;
+        __threadfence();
+      }
+    }
+    __syncthreads();
+    if (nch > 1u) {
+      if (threadIdx.x == 0) is_last = atomicAdd(big_done + slot, 1u) == nch - 1u ? 1 : 0;
+      __syncthreads();
+      if (is_last != 0) {
+        if (g == 0) {
+          __threadfence();
+          float4 tot = *reinterpret_cast<const float4*>(tail + t0 * D + l * 4);
+          for (uint32_t c2 = 0; c2 < nch; c2++) {
+            float* p = head + (t0 + 1 + (size_t)c2 * kCombBigChunk) * D + l * 4;
+            // (sums other workgroups parked: read past this CU's vector cache)
+            tot.x += __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.y += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.z += __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tot.w += __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+        }
+        if (threadIdx.x == 0) big_done[slot] = 0u;  // clean for the next update
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// any D: one wavefront per run, lanes stride over the vector
+template <typename OffT, typename SortK, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    update_rows_generic_kernel(const uint64_t* __restrict__ d_num_runs,
+                               const uint32_t* __restrict__ run_start,
+                               const SortK* __restrict__ sorted_rows,
+                               const uint32_t* __restrict__ sorted_buckets,
+                               const OffT* __restrict__ scale_ro, int combiner, int D,
+                               const GradT* __restrict__ grad, OptConst o,
+                               float* __restrict__ table, float* __restrict__ state0,
+                               float* __restrict__ state1,
+                               unsigned long long* __restrict__ prev_time) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  const size_t num_runs = (size_t)*d_num_runs;
+  for (size_t r = wave; r < num_runs; r += nwaves) {
+    const uint32_t off = run_start[r];
+    const uint32_t cnt = run_start[r + 1] - off;
+    const uint64_t row = (uint64_t)sorted_rows[off];
+    if (row == kNoRow) continue;
+    for (int v = lane; v < D; v += 64) {
+      float gi = 0.0f;
+      for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t b = sorted_buckets[off + k];
+        float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
+        if (combiner == 1) {
+          long long n = (long long)scale_ro[b + 1] - (long long)scale_ro[b];
+          if (n > 1) {
+            const float sc = 1.0f / (float)n;  // even sizes: align2 rule (16-bit scaler)
+            gv = Load4<GradT>::rnd(gv * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc));
+          }
+        }
+        gi += gv;
+      }
+      gi /= o.scaler;
+      const size_t f = row * (uint64_t)D + v;
+      float w = table[f];
+      float s0 = needs_s0(o) ? state0[f] : 0.f;
+      float s1 = needs_s1(o) ? state1[f] : 0.f;
+      unsigned long long pt = needs_pt(o) ? prev_time[f] : 1ull;
+      apply_opt(o, gi, w, &s0, &s1, &pt);
+      table[f] = w;
+      if (needs_s0(o)) state0[f] = s0;
+      if (needs_s1(o)) state1[f] = s1;
+      if (needs_pt(o)) prev_time[f] = pt;
+    }
+  }
+}
+
+// SGD with atomic_update (opt_sgd_atomic_kernel :564-582): w[idx] += -(lr/scaler) * wgrad[bucket]
+template <typename OffT, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    sgd_atomic_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
+                      const uint64_t* __restrict__ value_index, const GradT* __restrict__ grad,
+                      float lr_scale, float* __restrict__ table,
+                      const OffT* __restrict__ scale_ro) {
+  const int lane = threadIdx.x & 63;
+  const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
+  for (size_t u = wave; u < buckets; u += nwaves) {
+    const long long off = (long long)row_offset[u];
+    const int n = (int)((long long)row_offset[u + 1] - off);
+    // (the scaling CSR is read for the mean combiner only)
+    const int ns = combiner == 1 ? (int)((long long)scale_ro[u + 1] - (long long)scale_ro[u]) : 1;
+    float sc = (combiner == 1 && ns > 1) ? 1.0f / (float)ns : 1.0f;
+    if (D % 2 == 0) sc = Load4<GradT>::rnd(sc);  // align2 rule (backward_functor.cu:83-104)
+    for (int v = lane; v < D; v += 64) {
+      float gv = Load4<GradT>::ld1(grad + u * (size_t)D + v);
+      if (combiner == 1) gv = Load4<GradT>::rnd(gv * sc);
+      const float dw = -lr_scale * gv;
+      for (int j = 0; j < n; j++) {
+        const uint64_t idx = value_index[off + j];
+        if (idx != kInvalidIndex) unsafeAtomicAdd(table + idx * (uint64_t)D + v, dw);
+      }
+    }
+  }
+}
+
+// ---- global (whole-table) sweeps ----------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    adam_global_sweep_kernel(size_t n, float beta1, float beta2, float eps, float alpha_t,
+                             int state_half, float* __restrict__ m, float* __restrict__ v,
+                             float* __restrict__ w) {
+  // adam_update_kernel_global :269-288
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float mi = beta1 * m[i];
+    float vi = beta2 * v[i];
+    m[i] = state_store(state_half, mi);
+    v[i] = state_store(state_half, vi);
+    w[i] += -alpha_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    momentum_global_sweep_kernel(size_t n, float factor, int state_half, float* __restrict__ mo,
+                                 float* __restrict__ w) {
+  // momentum_sgd_update_kernel_global :316-329
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float m = mo[i];
+    m *= factor;
+    w[i] += m;
+    mo[i] = state_store(state_half, m);
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    nesterov_global_sweep_kernel(size_t n, float mu, int state_half, float* __restrict__ accm,
+                                 float* __restrict__ w) {
+  // nesterov_global_update_kernel_global :333-347
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    float a = accm[i];
+    a *= mu;
+    accm[i] = state_store(state_half, a);
+    w[i] += a * mu;
+  }
+}
+
+// ---- wgrad materialisation (tests / get_wgrad) --------------------------------------------------
+template <typename OffT, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    wgrad_kernel(size_t buckets, int D, int combiner, const OffT* __restrict__ row_offset,
+                 const GradT* __restrict__ top, GradT* __restrict__ wgrad) {
+  const size_t total = buckets * (size_t)D;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * kBlock) {
+    const size_t u = i / D;
+    float g = Load4<GradT>::ld1(top + i);
+    if (combiner == 1) {
+      long long n = (long long)row_offset[u + 1] - (long long)row_offset[u];
+      if (n > 1) {
+        const float sc = 1.0f / (float)n;
+        g = g * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc);
+      }
+    }
+    if constexpr (std::is_same<GradT, float>::value) wgrad[i] = g;
+    else if constexpr (std::is_same<GradT, __half>::value) wgrad[i] = __float2half_rn(g);
+    else wgrad[i] = __float2bfloat16(g);
+  }
+}
+
+// HCTR_SORT=rocprim selects the library's one-sweep sort (A/B measurements); default: radix_sort.hip
+inline bool use_library_sort() {
+  static const bool v = [] {
+    const char* e = getenv("HCTR_SORT");
+    return e != nullptr && e[0] == 'r';
+  }();
+  return v;
+}
+
+template <typename SortK>
+int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, const uint32_t* vin,
+               uint32_t* vout, size_t n, int end_bit, hipStream_t s, const RsFirst* first = nullptr) {
+  static_assert(sizeof(SortK) == 4, "32-bit sort keys");
+  if (temp == nullptr) {  // size query: room for either implementation
+    size_t lib = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, lib, kin, kout, vin, vout, n, 0,
+                                             (unsigned)end_bit, s, false);
+    if (e != hipSuccess) {
+      set_error(std::string("rocprim::radix_sort_pairs: ") + hipGetErrorString(e));
+      return HCTR_ERR_HIP;
+    }
+    const size_t own = radix_sort_temp_bytes(n);
+    temp_bytes = lib > own ? lib : own;
+    return HCTR_OK;
+  }
+  if (!use_library_sort())
+    return radix_sort_pairs_u32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout,
+                                n, end_bit, s, first);
+  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0,
+                                           (unsigned)end_bit, s, false);
+  if (e != hipSuccess) {
+    set_error(std::string("rocprim::radix_sort_pairs: ") + hipGetErrorString(e));
+    return HCTR_ERR_HIP;
+  }
+  return HCTR_OK;
+}
+
+// (row, bucket) pairs -> stable radix sort by row (sparse_optimizer.cu:657-676)
+template <typename OffT, typename SortK>
+int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const uint64_t* vi,
+               hipStream_t s) {
+  SortK* kin = (SortK*)u.sort_keys_in;
+  SortK* kout = (SortK*)u.sort_keys_out;
+  // wavefronts per 64-bucket chunk = the average bucket length (for_each_key_wave): one for
+  // one-hot input, 8 for the MLPerf multi-hot shape whose 100-hot table would otherwise be the tail
+  const size_t avg = buckets > 0 ? (n + buckets - 1) / buckets : 1;
+  const unsigned parts = (unsigned)(avg < 1 ? 1 : (avg > 16 ? 16 : avg));
+  // one key per bucket on the host's count AND on the device's word (the index stage checked the
+  // offsets): rows and payloads are read in place by the sort's first pass
+  RsFirst first;
+  first.keys64 = vi;
+  first.flag = u.one_hot_flag;
+  first.map_inner = u.map_inner;
+  first.map_outer = u.map_outer;
+  const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
+  const bool in_place = u.one_hot_flag != nullptr && n == buckets && !use_library_sort() &&
+                        !(ip_env && ip_env[0] == '0');
+  hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock), parts),
+                     dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count,
+                     u.map_inner, u.map_outer, in_place ? u.one_hot_flag : nullptr);
+  HCTR_LAUNCH_CHECK();
+  // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
+  int end_bit = 1;
+  // (row_bound: the caller may know that only the first row_bound rows of the table exist yet)
+  const size_t top = (u.row_bound > 0 && u.row_bound < u.max_vocab) ? u.row_bound : u.max_vocab;
+  while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= top) end_bit++;
+  end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
+  size_t tb = u.sort_temp_bytes;
+  if (u.prof) u.prof->begin(2, s);
+  HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, n,
+                             end_bit, s, in_place ? &first : nullptr));
+  if (u.prof) u.prof->end(2, s);
+  return HCTR_OK;
+}
+
+template <typename OffT, typename SortK, typename GradT>
+int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                 const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
+                 float* state0, float* state1, uint64_t* prev_time, hipStream_t s) {
+  const int D = u.D;
+  const OffT* sro = u.scale_row_offset ? (const OffT*)u.scale_row_offset : ro;
+  OptConst o;
+  o.optimizer = opt.optimizer;
+  o.update_type = opt.update_type;
+  o.lr = opt.lr;
+  o.beta1 = opt.beta1;
+  o.beta2 = opt.beta2;
+  o.epsilon = opt.epsilon;
+  o.mf = opt.momentum_factor;
+  o.scaler = opt.scaler;
+  o.times = opt.times;
+  // AdamOptHyperParams::bias() (optimizer.hpp:58-60): double pow, rounded to float, times lr
+  const float bias = (float)(std::sqrt(1.0 - std::pow((double)opt.beta2, (double)opt.times)) /
+                             (1.0 - std::pow((double)opt.beta1, (double)opt.times)));
+  o.alpha_t = opt.lr * bias;
+  o.alpha_t_common = opt.lr / (1.0f - opt.beta1);
+  o.ftrl_l1 = opt.ftrl_lambda1;
+  o.ftrl_l2b = opt.ftrl_lambda2 + opt.ftrl_beta / opt.lr;
+  o.state_half = opt.state_half;
+  // Global update types sweep the table (sparse_optimizer.cu:269-347 run over all
+  // max_vocabulary_size_per_gpu rows).  A row that was never handed out has zero state,
+  // and zero state is a fixed point of every sweep (m = v = 0 stay 0, w += -alpha * 0 / (0 + eps)
+  // leaves w's bits alone): sweeping the rows handed out so far -- row_bound, the same upper bound
+  // the sort's key width uses -- gives the identical table for a fraction of the traffic while a
+  // table fills up (DeepFM / Criteo-Kaggle, 33.7 M rows x 16: 12.9 GB per step down to the live rows).
+  const size_t live_rows = (u.row_bound > 0 && u.row_bound < u.max_vocab) ? u.row_bound : u.max_vocab;
+  const size_t table_elems = live_rows * (size_t)D;
+
+  if (u.map_inner != 0u) {
+    if (combiner != 0 || u.ext_rows != nullptr || (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) ||
+        (size_t)u.map_inner * u.map_outer != buckets) {
+      set_error("gradient map: sum combiner, sorted update, samples * lookups == buckets only");
+      return HCTR_ERR_INVALID_ARG;
+    }
+  }
+
+  if (opt.optimizer == HCTR_OPT_SGD && opt.atomic_update) {
+    const float lr_scale = opt.lr / opt.scaler;
+    hipLaunchKernelGGL((sgd_atomic_kernel<OffT, GradT>), dim3(grid_for(buckets * 64, kBlock)),
+                       dim3(kBlock), 0, s, buckets, D, combiner, ro, vi, grad, lr_scale, table, sro);
+    HCTR_LAUNCH_CHECK();
+    return HCTR_OK;
+  }
+
+  if (opt.optimizer == HCTR_OPT_NESTEROV && opt.update_type == HCTR_UPDATE_GLOBAL) {
+    hipLaunchKernelGGL(nesterov_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                       dim3(kBlock), 0, s, table_elems, opt.momentum_factor, opt.state_half, state0,
+                       table);
+    HCTR_LAUNCH_CHECK();
+  }
+
+  if (nnz > 0) {
+    SortK* kout = (SortK*)u.sort_keys_out;
+    const uint32_t* vout = u.sort_vals_out;
+    if (u.ext_rows != nullptr) {
+      // presorted by the caller: only the long-run counters need a reset
+      static_assert(sizeof(SortK) == 4, "presorted lists carry 32-bit rows");
+      kout = (SortK*)const_cast<uint32_t*>(u.ext_rows);
+      vout = u.ext_buckets;
+      HCTR_HIP(hipMemsetAsync(u.span_count, 0, 4 * sizeof(uint32_t), s));
+    } else if (u.early_n >= nnz && u.early_vi == vi && u.early_buckets == buckets) {
+      // (row, bucket) pairs of this batch were sorted on the side stream right after the index
+      // stage (SparseUpdater::presort); padding keys sit behind the live ones
+      HCTR_HIP(hipStreamWaitEvent(s, u.ev_sorted, 0));
+      nnz = u.early_n;
+    } else {
+      HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, s)));
+    }
+    u.early_n = 0;
+    if (u.prof) u.prof->begin(3, s);
+    const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
+    bool done = false;
+    // store-only mode: finished runs are written straight to their output row
+    float* direct = (opt.optimizer == kOptStoreSum && opt.scaler == 1.0f) ? table : nullptr;
+    // plain SGD: the apply pass folds into the reduce (seg_reduce_kernel<.., kFuseSgd>);
+    // HCTR_SGD_FUSED=0 keeps the two-pass form (measurements, the bit-equality test)
+    const char* fuse_env = getenv("HCTR_SGD_FUSED");  // (read per call: tests flip it in-process)
+    int fuse = kFuseNone;
+    if (!(fuse_env && fuse_env[0] == '0') && direct == nullptr) {
+      if (o.optimizer == HCTR_OPT_SGD) fuse = kFuseSgd;
+      if (o.optimizer == HCTR_OPT_ADAGRAD) fuse = kFuseAdaGrad;
+    }
+#define HCTR_SEG_REDUCE(LPR_, FUSE_, OUT_)                                                        \
+  hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT, FUSE_>),                        \
+                     dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,    \
+                     kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail, u.span_list,     \
+                     u.span_count, OUT_, sro, o, state0)
+#define HCTR_SEG_CASE(LPR_)                                                                       \
+  {                                                                                               \
+    constexpr int GPB = kBlock / LPR_;                                                            \
+    const size_t seg_tiles = ceil_div<size_t>(nnz, (size_t)kSegTile);                             \
+    if (fuse == kFuseSgd) HCTR_SEG_REDUCE(LPR_, kFuseSgd, table);                                     \
+    else if (fuse == kFuseAdaGrad) HCTR_SEG_REDUCE(LPR_, kFuseAdaGrad, table);                        \
+    else HCTR_SEG_REDUCE(LPR_, kFuseNone, direct);                                                    \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    if (direct == nullptr && fuse == kFuseNone) {                                                 \
+      if (o.optimizer == HCTR_OPT_SGD)                                                            \
+        hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, true>),                           \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           kout, u.gsum, o, table, state0, state1,                                \
+                           (unsigned long long*)prev_time);                                       \
+      else                                                                                        \
+        hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, false>),                          \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           kout, u.gsum, o, table, state0, state1,                                \
+                           (unsigned long long*)prev_time);                                       \
+      HCTR_LAUNCH_CHECK();                                                                        \
+    }                                                                                             \
+    hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
+                       dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, s, buckets, ro, \
+                       kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
+                       u.seg_tail, u.span_list, u.span_count, u.big_list, u.big_stride);          \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((seg_combine_big_kernel<LPR_, OffT, SortK>), dim3(256), dim3(kCombBlock),  \
+                       0, s, buckets, ro, kout, o, table, state0, state1,                         \
+                       (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.big_list,        \
+                       u.big_stride, u.span_count);                                               \
+  }
+    if (a16 && D % 4 == 0) {
+      done = true;
+      switch (D / 4) {
+        case 1: HCTR_SEG_CASE(1) break;
+        case 2: HCTR_SEG_CASE(2) break;
+        case 4: HCTR_SEG_CASE(4) break;
+        case 8: HCTR_SEG_CASE(8) break;
+        case 16: HCTR_SEG_CASE(16) break;
+        case 32: HCTR_SEG_CASE(32) break;
+        case 64: HCTR_SEG_CASE(64) break;
+        default: done = false;
+      }
+    }
+#undef HCTR_SEG_CASE
+#undef HCTR_SEG_REDUCE
+    if (!done) {
+      // generic embedding_vec_size: run detection + one wavefront per unique row
+      const size_t n_tiles = ceil_div<size_t>(nnz, kTile);
+      const int tgrid = (int)(n_tiles < (size_t)kMaxGrid ? n_tiles : (size_t)kMaxGrid);
+      hipLaunchKernelGGL((run_count_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout,
+                         ro, buckets, n_tiles, u.tile_sums);
+      HCTR_LAUNCH_CHECK();
+      hipLaunchKernelGGL(scan_tiles_u32_kernel, dim3(1), dim3(1024), 0, s, u.tile_sums, n_tiles,
+                         u.d_num_runs);
+      HCTR_LAUNCH_CHECK();
+      hipLaunchKernelGGL((run_write_kernel<OffT, SortK>), dim3(tgrid), dim3(kBlock), 0, s, kout,
+                         ro, buckets, n_tiles, u.tile_sums, u.d_num_runs, u.run_start);
+      HCTR_LAUNCH_CHECK();
+      hipLaunchKernelGGL((update_rows_generic_kernel<OffT, SortK, GradT>),
+                         dim3(grid_for(nnz * 64, kBlock)), dim3(kBlock), 0, s, u.d_num_runs,
+                         u.run_start, kout, vout, sro, combiner, D, grad, o, table,
+                         state0, state1, (unsigned long long*)prev_time);
+    }
+    HCTR_LAUNCH_CHECK();
+    if (u.prof) u.prof->end(3, s);
+  }
+
+  if (opt.update_type == HCTR_UPDATE_GLOBAL) {
+    if (opt.optimizer == HCTR_OPT_ADAM) {
+      hipLaunchKernelGGL(adam_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                         dim3(kBlock), 0, s, table_elems, opt.beta1, opt.beta2, opt.epsilon,
+                         o.alpha_t, opt.state_half, state0, state1, table);
+      HCTR_LAUNCH_CHECK();
+    } else if (opt.optimizer == HCTR_OPT_MOMENTUM_SGD) {
+      hipLaunchKernelGGL(momentum_global_sweep_kernel, dim3(grid_for(table_elems, kBlock)),
+                         dim3(kBlock), 0, s, table_elems, opt.momentum_factor, opt.state_half,
+                         state0, table);
+      HCTR_LAUNCH_CHECK();
+    }
+  }
+  return HCTR_OK;
+}
+
+template <typename OffT, typename GradT>
+int update_sortk(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                 const uint64_t* vi, const GradT* grad, const OptState& opt, float* table,
+                 float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  // row indices are sorted as 32-bit keys; create() rejects tables with >= 2^32 rows per GPU
+  return update_typed<OffT, uint32_t, GradT>(u, buckets, nnz, combiner, ro, vi, grad, opt, table,
+                                             s0, s1, pt, s);
+}
+
+template <typename OffT>
+int update_grad(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const OffT* ro,
+                const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  switch (grad_dtype) {
+    case HCTR_EMB_F32:
+      return update_sortk<OffT, float>(u, buckets, nnz, combiner, ro, vi, (const float*)grad, opt,
+                                       table, s0, s1, pt, s);
+    case HCTR_EMB_F16:
+      return update_sortk<OffT, __half>(u, buckets, nnz, combiner, ro, vi, (const __half*)grad,
+                                        opt, table, s0, s1, pt, s);
+    case HCTR_EMB_BF16:
+      return update_sortk<OffT, __hip_bfloat16>(u, buckets, nnz, combiner, ro, vi,
+                                                (const __hip_bfloat16*)grad, opt, table, s0, s1,
+                                                pt, s);
+  }
+  set_error("grad dtype");
+  return HCTR_ERR_INVALID_ARG;
+}
+
+}  // namespace
+
+// This file is compiled three times (Makefile): HCTR_SU_PART 0 = everything but the segmented
+// update's kernel instantiations, 1 / 2 = those for 32-bit / 64-bit row offsets (63 instances of
+// seg_reduce_kernel each) -- the three objects build side by side instead of one 3-minute TU.
+#ifndef HCTR_SU_PART
+#define HCTR_SU_PART 0
+#endif
+int update_grad_u32(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const uint32_t* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s);
+int update_grad_i64(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const long long* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s);
+#if HCTR_SU_PART == 1
+int update_grad_u32(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const uint32_t* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  return update_grad<uint32_t>(u, buckets, nnz, combiner, ro, vi, grad, grad_dtype, opt, table, s0,
+                               s1, pt, s);
+}
+#elif HCTR_SU_PART == 2
+int update_grad_i64(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, const long long* ro,
+                    const uint64_t* vi, const void* grad, int grad_dtype, const OptState& opt,
+                    float* table, float* s0, float* s1, uint64_t* pt, hipStream_t s) {
+  return update_grad<long long>(u, buckets, nnz, combiner, ro, vi, grad, grad_dtype, opt, table,
+                                s0, s1, pt, s);
+}
+#else
+
+int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
+  max_nnz = max_nnz_ > 0 ? max_nnz_ : 1;
+  max_vocab = max_vocab_;
+  D = D_;
+  key32 = true;
+  if (max_vocab >= 0xFFFFFFF0ull) {
+    set_error("more than 2^32 - 16 rows per GPU are not supported by the sparse update");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  const size_t ksz = 4;
+  HCTR_HIP(hipMalloc(&sort_keys_in, max_nnz * ksz));
+  HCTR_HIP(hipMalloc(&sort_keys_out, max_nnz * ksz));
+  HCTR_HIP(hipMalloc(&sort_vals_in, max_nnz * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&sort_vals_out, max_nnz * sizeof(uint32_t)));
+  size_t tb = 0;
+  HCTR_TRY(sort_pairs<uint32_t>(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, nullptr,
+                                nullptr, max_nnz, 32, nullptr));
+  sort_temp_bytes = tb > 0 ? tb : 16;
+  HCTR_HIP(hipMalloc(&sort_temp, sort_temp_bytes));
+  HCTR_HIP(hipMalloc(&tile_sums, (ceil_div<size_t>(max_nnz, kTile) + 1) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&run_start, (max_nnz + 2) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&d_num_runs, sizeof(uint64_t)));
+  HCTR_HIP(hipMemset(d_num_runs, 0, sizeof(uint64_t)));
+  {
+    int lo = 0, hi = 0;  // hi = numerically lowest = most urgent
+    HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* pr = getenv("HCTR_PRESORT_PRIO");  // "low": fill gaps only (measurements)
+    HCTR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking,
+                                         (pr && pr[0] == 'l') ? lo : hi));
+    HCTR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HCTR_HIP(hipEventCreateWithFlags(&ev_sorted, hipEventDisableTiming));
+  }
+  const size_t seg_tiles = ceil_div<size_t>(max_nnz, (size_t)kSegTile) + 1;
+  HCTR_HIP(hipMalloc(&seg_head, seg_tiles * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&seg_tail, seg_tiles * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&gsum, max_nnz * (size_t)D * sizeof(float)));
+  HCTR_HIP(hipMalloc(&span_list, seg_tiles * sizeof(uint32_t)));
+  // [0] long runs, [1] unused, [2..3] one 64-bit counter: big runs (upper half) / their chunks
+  HCTR_HIP(hipMalloc(&span_count, 4 * sizeof(uint32_t)));
+  HCTR_HIP(hipMemset(span_count, 0, 4 * sizeof(uint32_t)));
+  // per big run: start tile, length in tile partials, first chunk number, finished-chunk counter
+  // (the counters start at zero and every update leaves them at zero)
+  big_stride = seg_tiles;
+  HCTR_HIP(hipMalloc(&big_list, 4 * seg_tiles * sizeof(uint32_t)));
+  HCTR_HIP(hipMemset(big_list, 0, 4 * seg_tiles * sizeof(uint32_t)));
+  return HCTR_OK;
+}
+
+int SparseUpdater::destroy() {
+  void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
+                  run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
+                  gsum,         big_list};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (side) {
+    (void)hipStreamSynchronize(side);
+    (void)hipStreamDestroy(side);
+    (void)hipEventDestroy(ev_fork);
+    (void)hipEventDestroy(ev_sorted);
+    side = nullptr;
+  }
+  early_n = 0;
+  sort_keys_in = sort_keys_out = sort_temp = nullptr;
+  sort_vals_in = sort_vals_out = tile_sums = run_start = nullptr;
+  d_num_runs = nullptr;
+  seg_head = seg_tail = nullptr;
+  span_list = span_count = big_list = nullptr;
+  gsum = nullptr;
+  return HCTR_OK;
+}
+
+int SparseUpdater::presort(size_t buckets, size_t n, const void* row_offset, int key_type,
+                           const uint64_t* value_index, hipStream_t s) {
+  early_n = 0;
+  if (buckets == 0 || n == 0 || n > max_nnz || buckets > 0xFFFFFFF0ull || !side) return HCTR_OK;
+  HCTR_HIP(hipEventRecord(ev_fork, s));
+  HCTR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+  int rc;
+  if (key_type == HCTR_KEY_U32)
+    rc = sort_stage<uint32_t, uint32_t>(*this, buckets, n, (const uint32_t*)row_offset,
+                                        value_index, side);
+  else
+    rc = sort_stage<long long, uint32_t>(*this, buckets, n, (const long long*)row_offset,
+                                         value_index, side);
+  if (rc != HCTR_OK) return rc;
+  HCTR_HIP(hipEventRecord(ev_sorted, side));
+  early_n = n;
+  early_vi = value_index;
+  early_buckets = buckets;
+  return HCTR_OK;
+}
+
+int SparseUpdater::update(size_t buckets, size_t nnz, int combiner, const void* row_offset,
+                          int key_type, const uint64_t* value_index, const void* top_grad,
+                          int grad_dtype, const OptState& opt, float* table, float* state0,
+                          float* state1, uint64_t* prev_time, hipStream_t s) {
+  if (buckets == 0) return HCTR_OK;
+  if (nnz > max_nnz) {
+    set_error("update: nnz exceeds the workspace (batch_size * max_feature_num)");
+    return HCTR_ERR_INVALID_ARG;
+  }
+  if (buckets > 0xFFFFFFF0ull) {
+    set_error("update: more than 2^32 buckets");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  switch (opt.optimizer) {
+    case HCTR_OPT_SGD:
+    case HCTR_OPT_ADAM:
+    case HCTR_OPT_ADAGRAD:
+    case HCTR_OPT_MOMENTUM_SGD:
+    case HCTR_OPT_NESTEROV:
+    case kOptStoreSum: break;
+    case HCTR_OPT_FTRL:
+      if (allow_ftrl) break;
+      [[fallthrough]];
+    default:
+      // Ftrl / RMSProp are not implemented by the reference's GPU update either
+      set_error("sparse optimizer not supported (reference: sparse_optimizer.cu:821-826)");
+      return HCTR_ERR_UNSUPPORTED;
+  }
+  if (opt.update_type == HCTR_UPDATE_LAZY_GLOBAL && opt.optimizer != HCTR_OPT_ADAM) {
+    set_error("lazy global update is only implemented for Adam (sparse_optimizer.cu:829-850)");
+    return HCTR_ERR_UNSUPPORTED;
+  }
+  if (key_type == HCTR_KEY_U32)
+    return update_grad_u32(*this, buckets, nnz, combiner, (const uint32_t*)row_offset, value_index,
+                           top_grad, grad_dtype, opt, table, state0, state1, prev_time, s);
+  if (key_type == HCTR_KEY_I64)
+    return update_grad_i64(*this, buckets, nnz, combiner, (const long long*)row_offset, value_index,
+                           top_grad, grad_dtype, opt, table, state0, state1, prev_time, s);
+  set_error("key_type");
+  return HCTR_ERR_INVALID_ARG;
+}
+
+int materialize_wgrad(size_t buckets, int D, int combiner, const void* ro, int key_type,
+                      const void* top, void* wgrad, int dtype, hipStream_t s) {
+  if (buckets == 0) return HCTR_OK;
+  const int grid = grid_for(buckets * (size_t)D, kBlock);
+#define HCTR_WG(OffT, GradT)                                                                  \
+  hipLaunchKernelGGL((wgrad_kernel<OffT, GradT>), dim3(grid), dim3(kBlock), 0, s, buckets, D, \
+                     combiner, (const OffT*)ro, (const GradT*)top, (GradT*)wgrad)
+  if (key_type == HCTR_KEY_U32) {
+    if (dtype == HCTR_EMB_F32) HCTR_WG(uint32_t, float);
+    else if (dtype == HCTR_EMB_F16) HCTR_WG(uint32_t, __half);
+    else HCTR_WG(uint32_t, __hip_bfloat16);
+  } else {
+    if (dtype == HCTR_EMB_F32) HCTR_WG(long long, float);
+    else if (dtype == HCTR_EMB_F16) HCTR_WG(long long, __half);
+    else HCTR_WG(long long, __hip_bfloat16);
+  }
+#undef HCTR_WG
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+#endif  // HCTR_SU_PART
+
+}  // namespace hctr
