@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace hipemu {
@@ -170,9 +171,25 @@ void run_block(Worker* w, dim3 grid, dim3 block, unsigned linear_block) {
     makecontext(&f.ctx, (void (*)())trampoline, 0);
   }
   size_t live = n;
+  // HIPEMU_SCHED: the order in which the runnable threads of a workgroup are resumed -- 0 lane 0
+  // first (default), 1 last lane first, 2 a new pseudo-random order at every pass.  Results that
+  // change with it point at data crossing threads without a barrier.
+  static const size_t sched = env_size("HIPEMU_SCHED", 0);
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = (uint32_t)(sched == 1 ? n - 1 - i : i);
+  uint64_t rnd = 0x9E3779B97F4A7C15ull * (linear_block + 1);
   while (live > 0) {
     bool ran = false;
-    for (size_t i = 0; i < n; i++) {
+    if (sched == 2) {
+      for (size_t i = n - 1; i > 0; i--) {
+        rnd ^= rnd << 13;
+        rnd ^= rnd >> 7;
+        rnd ^= rnd << 17;
+        std::swap(order[i], order[rnd % (i + 1)]);
+      }
+    }
+    for (size_t oi = 0; oi < n; oi++) {
+      const size_t i = order[oi];
       Fiber& f = w->fibers[i];
       if (f.state != READY) continue;
       w->cur = &f;
