@@ -123,7 +123,7 @@ def one_case(seed):
         want = oracle.ebc_forward(B, lookup_table, ev, comb, keys, br, row_start, dense,
                                   num_gpus=world, batch_major=batch_major)
         for d in range(world):
-            assert_close(outs[d].cpu().numpy().reshape(-1), want[d], 1e-5, 1e-6,
+            assert_close(outs[d].cpu().numpy().reshape(-1), want[d], 1e-5, 2e-5,
                          f"{desc} fwd rank{d} it{it}")
         grads = [rng.standard_normal(tuple(outs[d].shape)).astype(np.float32) for d in range(world)]
         if world == 1:
