@@ -105,7 +105,8 @@ def one_case(lib, _lib, seed):
         #  gradient sum cancels carries the rounding of terms far larger than itself)
         def atol(a):
             return 1e-5 + 1e-4 * float(np.abs(a).max())
-        assert_close(emb.table(), table, 1e-3, atol(table), f"{desc} table it{it}")
+        # (tables: an Adam step is lr * m / (sqrt(v) + eps) whatever the gradient's size)
+        assert_close(emb.table(), table, 1e-3, max(atol(table), 1e-3 * 0.05), f"{desc} table it{it}")
         if s0 is not None:
             assert_close(emb.opt_state(0), s0, 1e-3, atol(s0), f"{desc} state0 it{it}")
         if s1 is not None:
