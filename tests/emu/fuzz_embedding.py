@@ -51,13 +51,32 @@ def one_case(lib, _lib, seed):
     name, kw = OPTS[int(rng.integers(0, len(OPTS)))]
     scaler = float(rng.choice([1.0, 4.0, 1024.0]))
     steps = int(rng.integers(1, 4))
+    # the shard of one rank of N (every rank sees the full-batch CSR and filters its share:
+    # localized = the slots s with s % N == rank, distributed = the keys k with k % N == rank)
+    world = int(rng.choice([1, 1, 2, 3, 4, 8]))
+    rank = int(rng.integers(0, world))
+    localized = bool(rng.integers(0, 2)) or world == 1
+    if world > 1:
+        B = B * world
+        if not localized:
+            combiner = 0  # (mean on a distributed embedding divides after the reduce-scatter:
+                          #  tests/test_embedding_gpu.py::test_distributed_mean_divides_...)
     desc = dict(seed=seed, key_bytes=key_bytes, D=D, combiner=combiner, B=B, S=S, hot=hot, vps=vps,
-                dt=dt, opt=name, scaler=scaler, steps=steps)
+                dt=dt, opt=name, scaler=scaler, steps=steps, world=world, rank=rank,
+                localized=localized)
     V = S * vps + int(rng.integers(0, 20))
     kd = np.int64 if key_bytes == 8 else np.uint32
     opt = dict(lr=0.05, scaler=scaler, beta1=0.9, beta2=0.999, epsilon=1e-7, **kw)
-    emb = emu.Embedding(lib, _lib.EMB_LOCALIZED, B, V, D, S * hot, S, combiner, opt, key_dtype=kd,
-                        out_dtype={"f32": 0, "f16": 1, "bf16": 2}[dt])
+    emb = emu.Embedding(lib, _lib.EMB_LOCALIZED if localized else _lib.EMB_DISTRIBUTED, B, V, D,
+                        S * hot, S, combiner, opt, key_dtype=kd,
+                        out_dtype={"f32": 0, "f16": 1, "bf16": 2}[dt], rank=rank, world=world)
+    s_r = orc.slots_on_gpu(S, rank, world) if localized else S
+
+    def shard(ro, keys):
+        if world == 1:
+            return ro, keys
+        f = orc.localized_filter if localized else orc.distributed_filter
+        return f(ro, keys, B, S, rank, world)
     table = emb.table().copy()
     ns = {1: 2, 3: 1, 5: 1, 4: 1, 6: 0}[kw["optimizer"]]
     s0 = np.zeros_like(table) if ns >= 1 else None
@@ -71,6 +90,7 @@ def one_case(lib, _lib, seed):
                             one_hot=(kind == 0))
         rok, kk = ro.astype(kd), keys.astype(kd)
         out = emb.forward(True, rok, kk)
+        ro, keys = shard(ro, keys)
         vi = ht.get_insert(keys)
         assert (emb.value_index(keys.size) == vi).all(), (desc, it, "rows")
         if dt == "f32":
@@ -84,14 +104,14 @@ def one_case(lib, _lib, seed):
             else:
                 got = (out.reshape(-1, D).astype(np.uint32) << 16).view(np.float32)
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), (desc, it, "forward16")
-        g = (rng.standard_normal((B * S, D)) * 2).astype(np.float32)
+        g = (rng.standard_normal((B * s_r, D)) * 2).astype(np.float32)
         if dt == "f32":
             gg, wg = g, orc.backward(ro, g, D, combiner)
         else:
             wg = orc.backward_mixed(ro, g, D, combiner, dt)
             g16 = orc.round_to(g, dt)
             gg = g16.astype(np.float16) if dt == "f16" else (g16.view(np.uint32) >> 16).astype(np.uint16)
-        emb.backward(gg.reshape(B, S, D))
+        emb.backward(gg.reshape(B, s_r, D))
         emb.update_params()
         if half_state:  # (state rounding has its own GPU test: rows / forward stay checked)
             table[...] = emb.table()
@@ -122,6 +142,7 @@ def one_case(lib, _lib, seed):
     # evaluation batch: unseen keys read as zeros and still count in the mean
     ro, keys = make_csr(rng, B, S, hot, vps * 2 + 1, one_hot=bool(rng.integers(0, 2)))
     out = emb.forward(False, ro.astype(kd), keys.astype(kd))
+    ro, keys = shard(ro, keys)
     vi = ht.get_mark(keys)
     if dt == "f32":
         want = orc.forward(ro, vi, table, D, combiner)

@@ -437,6 +437,14 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
                           fused_train));
   if (buckets == 0) {
     if (fused_train) e->flip--;  // (nothing ran that would preset the other flag)
+    if (is_train) {
+      // a rank that owns no slot (localized, slot_num < GPUs): an empty training batch, so that
+      // backward() / update_params() of the common loop are no-ops instead of errors
+      e->cur_buckets = 0;
+      e->cur_nnz_bound = 0;
+      e->has_train_batch = true;
+      e->nnz_pending = false;
+    }
     return HCTR_OK;
   }
   if (is_train) e->cur_one_hot = (fused_train && e->p.world == 1) ? one_hot : nullptr;
@@ -788,9 +796,11 @@ int hctr_emb_update_rows(hctr_embedding* e, size_t n, const int64_t* row_offset,
 
 int hctr_emb_backward(hctr_embedding* e, const void* top_grad, hctr_stream_t stream) {
   (void)stream;
-  HCTR_REQUIRE(e && top_grad, "null pointer");
+  HCTR_REQUIRE(e, "null pointer");
   HCTR_REQUIRE(e->has_train_batch, "backward() before forward(is_train=1)");
-  e->top_grad = top_grad;
+  // (an empty batch has an empty gradient, whose pointer may be null: never dereferenced)
+  HCTR_REQUIRE(top_grad || e->cur_buckets == 0, "null pointer");
+  e->top_grad = top_grad ? top_grad : (const void*)e;
   return HCTR_OK;
 }
 
