@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE ONLY: randomized differential test of the N > 1 payloads of the localized
+embedding -- the unique-row exchange (hugectr_amd/unique_exchange.py) against the per-sample
+exchange of the reference layout, W ranks over gloo, each rank the kernels' source under the host
+interpreter (tests/emu) -- over random world sizes (2, 3, 4, 8: uneven slot counts, ranks without
+a slot), slot sizes, batch sizes, vector sizes, 16- / 32-bit outputs and sums, plans made ahead or
+in line, the plain and the indexed receive form.  (tests/test_unique_exchange_gpu.py with its
+constants drawn at random.)
+
+    python tests/emu/fuzz_unique.py --seed 0 --cases 10 [--worlds 2,3,4,8]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    S = int(rng.choice([1, 2, 3, 5, 9, 26]))
+    return dict(seed=seed, S=S, Bl=int(rng.choice([1, 2, 8, 33, 96])),
+                D=int(rng.choice([32, 64, 128])),
+                sizes=[int(rng.choice([1, 3, 7, 41, 300, 5000])) for _ in range(S)],
+                dtype=str(rng.choice(["bfloat16", "float16", "float32"])),
+                opt=str(rng.choice(["sgd", "adagrad"])), sum16=bool(rng.integers(0, 2)),
+                steps=int(rng.integers(2, 5)), prefetch=[bool(rng.integers(0, 2)) for _ in range(5)],
+                indexed=[bool(rng.integers(0, 2)) for _ in range(5)], alpha=float(rng.choice([1.1, 1.3, 2.0])))
+
+
+def run_case(c, rank, world):
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    from hugectr_amd.parallel import LocalizedExchange, slots_on_rank
+    from hugectr_amd.unique_exchange import UniqueExchange
+    dt = getattr(torch, c["dtype"])
+    sum16 = c["sum16"] and dt != torch.float32
+    Bl, S, D, sizes = c["Bl"], c["S"], c["D"], c["sizes"]
+    B = Bl * world
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    kw = dict(optimizer=_lib.OPT_SGD, lr=0.05, atomic_update=False) if c["opt"] == "sgd" else \
+        dict(optimizer=_lib.OPT_ADAGRAD, lr=0.05, epsilon=1e-6)
+
+    def mk():
+        return ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, sum(sizes), D, S, S, 0,
+                                      ha.OptParams(**kw), slot_size_array=sizes, out_dtype=dt,
+                                      rank=rank, world=world, seed=5)
+    emb_u, emb_d = mk(), mk()
+    emb_u.init_params()
+    emb_d.init_params()
+    ux = UniqueExchange(emb_u, Bl, S, D, sum_dtype=dt if sum16 else torch.float32)
+    dx = LocalizedExchange(B, S, D)
+    s_r = slots_on_rank(S, rank, world)
+    ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
+    rng = np.random.default_rng(c["seed"] + 1)  # the same keys on every rank (full-batch CSR)
+    steps = c["steps"]
+    batches = [torch.from_numpy(np.stack(
+        [(rng.zipf(c["alpha"], size=B) - 1) % v + o for v, o in zip(sizes, offs)],
+        axis=1).reshape(-1).astype(np.int64)).cuda() for _ in range(steps)]
+    for step in range(steps):
+        kt = batches[step]
+        ux.forward_begin(ro, kt)
+        if c["indexed"][step] and D >= 32:
+            rows_u, row_of = ux.forward_finish(indexed=True)
+            E = rows_u[row_of.long()].contiguous()
+        else:
+            E = ux.forward_finish()
+        if step + 1 < steps and c["prefetch"][step]:
+            ux.prefetch(ro, batches[step + 1])
+        pooled = emb_d.forward(True, ro, kt)
+        recv = dx.forward(pooled.cpu()).cuda()
+        E_ref = ha.forward_reorder(recv, Bl, S, D, world)
+        assert tuple(E.shape) == tuple(E_ref.shape), (step, E.shape, E_ref.shape)
+        if step == 0:
+            assert torch.equal(E, E_ref), "E differs at step 0"
+        else:
+            scale = E_ref.float().abs().max().item() if E_ref.numel() else 0.0
+            err = (E.float() - E_ref.float()).abs().max().item() if E_ref.numel() else 0.0
+            lim = (2e-2 * scale + 8e-3) if (sum16 or dt != torch.float32) else (2e-4 * scale + 1e-5)
+            assert err <= lim, (step, "E", err, lim)
+        g = torch.from_numpy(rng.standard_normal((world, Bl, S, D)).astype(np.float32))[rank]
+        g = g.cuda().to(dt)
+        ux.backward_and_update(g)
+        gsend = ha.backward_reorder(g, Bl, S, D, world)
+        top = dx.backward(gsend.cpu()).cuda().view(B, s_r, D)
+        emb_d.backward(top.contiguous())
+        emb_d.update_params()
+        tu, td = emb_u.table(), emb_d.table()
+        err = (tu - td).abs().max().item()
+        tol = (2e-2, 8e-3) if sum16 else ((2e-3, 1e-4) if dt != torch.float32 else (1e-4, 1e-5))
+        lim = tol[0] * td.abs().max().item() + tol[1]
+        assert err <= lim, (step, "table", err, lim)
+    assert emb_u.get_vocabulary_size() == emb_d.get_vocabulary_size()
+
+
+def worker(rank, world, port, seed, cases, ret):
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("FUZZ_HANG_S", "900")), exit=True)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bad = []
+    try:
+        for i in range(cases):
+            c = draw(seed * 1_000_003 + world * 1000 + i)
+            try:
+                run_case(c, rank, world)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                import traceback
+                ok = 0
+                msg = "".join(traceback.format_exception(type(e), e, e.__traceback__))[-1500:]
+                print(f"rank {rank} of {world} case {c}\n{msg}", flush=True)
+            # every rank must leave a case together: a rank that failed alone would desynchronise
+            # the collectives of the next one
+            import torch
+            flag = torch.tensor([ok])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not ok:
+                bad.append((c, msg))
+            elif flag.item() == 0:
+                pass
+            if flag.item() == 0 and ok:
+                continue
+            if not ok and world > 1:
+                break  # (collectives are out of step after a one-sided failure)
+        ret[rank] = bad
+    finally:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=6)
+    ap.add_argument("--worlds", default="2,3,4,8")
+    a = ap.parse_args()
+    os.environ["HCTR_EMU"] = "1"
+    os.environ["PYTHONPATH"] = os.path.join(HERE, "site") + os.pathsep + ROOT + os.pathsep + \
+        os.environ.get("PYTHONPATH", "")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch.multiprocessing as mp
+    total_bad = 0
+    for world in [int(x) for x in a.worlds.split(",")]:
+        ctx = mp.get_context("spawn")
+        ret = ctx.Manager().dict()
+        port = 24000 + os.getpid() % 3000 + world
+        procs = [ctx.Process(target=worker, args=(r, world, port, a.seed, a.cases, ret))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(3000)
+        nbad = 0
+        for r in range(world):
+            for c, msg in (ret.get(r) or []):
+                nbad += 1
+                print(f"FAIL world {world} rank {r} {c}\n{msg}", flush=True)
+            if ret.get(r) is None:
+                nbad += 1
+                print(f"FAIL world {world} rank {r}: no result", flush=True)
+        print(f"world {world}: {a.cases} cases, {nbad} failures", flush=True)
+        total_bad += nbad
+    sys.exit(1 if total_bad else 0)
+
+
+if __name__ == "__main__":
+    main()

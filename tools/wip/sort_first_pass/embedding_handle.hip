@@ -721,7 +721,8 @@ int hctr_emb_init_params(hctr_embedding* e, hctr_stream_t stream) {
 int hctr_emb_forward(hctr_embedding* e, int is_train, const void* row_offset, const void* keys,
                      size_t nnz, void* out, hctr_stream_t stream) {
   HCTR_REQUIRE(e, "null handle");
-  HCTR_REQUIRE(row_offset && out, "null pointer");
+  // (a rank that owns no slot has an empty output, whose pointer may be null)
+  HCTR_REQUIRE(row_offset && (out || e->buckets_per_sample() == 0), "null pointer");
   HCTR_REQUIRE(nnz == 0 || keys, "keys is null");
   HCTR_REQUIRE(nnz <= (is_train ? e->p.train_batch_size : e->p.evaluate_batch_size) *
                           (e->p.max_feature_num ? e->p.max_feature_num : 1),
