@@ -4,7 +4,8 @@
 // R/gpu_cache/src/nv_gpu_cache.cu:247-1155: Query / Replace / Update / Dump) and the role of
 // gpu_cache::UvmTable (R/gpu_cache/include/uvm_table.hpp:133-174: device table in front of a host
 // table) -- BASELINE config 4, SURVEY 8(f)2.  The reference has neither tests nor callers for these
-// in tree: parity is against our own sequential restatement (oracle/cache_oracle.py), "unpinned".
+// in tree: parity is against a sequential restatement (oracle/cache_oracle.py), which is itself
+// checked against the reference's own kernels stepped through on the host (tests/test_ref_cache_cpu.py).
 //
 // MI355X-first layout: a slab set of the reference is SET_ASSOCIATIVITY (2) slabs x 32 keys; here
 // the whole set is ONE wavefront-wide row of 64 slots, searched with a single 64-lane ballot

@@ -5,7 +5,14 @@ update_kernel, :1080-1153 dump_kernel; constants R/gpu_cache/include/nv_gpu_cach
 sequentially in key-position order -- one of the interleavings the reference's per-set mutexes
 allow, and the one the HIP implementation fixes.  The tiered table on top follows the role of
 gpu_cache::UvmTable (R/gpu_cache/include/uvm_table.hpp:133-174).
-Parity unpinned: the reference has no tests, callers or golden vectors for these classes."""
+The reference has no tests, callers or golden vectors for these classes, so CacheOracle is pinned
+against the reference's OWN kernels instead: oracle/Makefile `ref` compiles nv_gpu_cache.cu from
+the checkout as plain C++ and the host interpreter of tests/emu executes it (threads = fibers,
+32-lane tiles = wavefronts, thread blocks in block order = key-position order) into
+oracle/_ref/libref_cache.so; tests/test_ref_cache_cpu.py compares every Query result, the Dump
+order and the internal state (key, LRU counter and vector of every slot, global counter) after
+each call of random Query / Replace / Update / Dump sequences, u32 and i64 keys.  TieredOracle
+(our tiered table's flow, not UvmTable's internals) has nothing to be pinned against beyond that."""
 import struct
 
 import numpy as np

@@ -18,9 +18,12 @@
  *     stand-in for common.hpp (oracle/ref_shims/) and driven over several training steps from
  *     Norm dataset + sparse model files (tests/test_ref_embedding_cpu.py): sum forward / wgrad
  *     bit-equal, tables within 5e-7.
- * Not pinned that way ("parity unpinned", checked against closed forms, hand-worked cases and the
- * independent numpy fixtures in tests/golden/): the Interaction / Cross references (the
- * reference's are inline in CUDA-bound gtest files), the EBC references, the reorder maps.
+ * The other oracles are pinned by their own reference builds (oracle/Makefile `ref`): Interaction /
+ * Cross (the CPU references inline in the reference's gtest files, tests/test_ref_layers_cpu.py),
+ * embedding_collection (tests/test_ref_ebc_cpu.py), the dynamic table (tests/test_ref_det_cpu.py),
+ * the embedding cache (the reference's CUDA kernels executed by the host interpreter,
+ * tests/test_ref_cache_cpu.py).  Not pinned that way: the reorder maps (closed forms, hand-worked
+ * cases and the numpy fixtures in tests/golden/).
  *
  * All functions are plain C, single-threaded unless `threads > 1` is passed where offered.
  */

@@ -1,0 +1,107 @@
+// <cuda_runtime_api.h> stand-in -- TEST INFRASTRUCTURE ONLY (oracle/_ref/libref_cache.so).
+// The reference's embedding cache (R/gpu_cache/src/nv_gpu_cache.cu) is CUDA source; to pin
+// oracle/cache_oracle.py against the reference's OWN code it is compiled as plain C++ from where it
+// lies and stepped through by the host interpreter of tests/emu (hipemu.h: fibers = threads,
+// 32-lane tiles = wavefronts of width 32).  This header restates the part of the CUDA language and
+// runtime that file uses: declarations and trivial host-memory forwards, no reference code.
+#pragma once
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../../tests/emu/hipemu.h"
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define threadIdx (hipemu::ids()->tid)
+#define blockIdx (hipemu::ids()->bid)
+#define blockDim (hipemu::ids()->bdim)
+#define gridDim (hipemu::ids()->gdim)
+
+typedef struct refemu_stream* cudaStream_t;
+typedef struct refemu_event* cudaEvent_t;
+enum cudaError_t { cudaSuccess = 0, cudaErrorMemoryAllocation = 2 };
+enum cudaMemoryType { cudaMemoryTypeUnregistered = 0, cudaMemoryTypeHost = 1, cudaMemoryTypeDevice = 2 };
+struct cudaPointerAttributes {
+  cudaMemoryType type;
+  int device;
+};
+#define CUDART_VERSION 12000
+
+static inline const char* cudaGetErrorString(cudaError_t e) {
+  return e == cudaSuccess ? "no error" : "error (host interpreter)";
+}
+static inline cudaError_t cudaGetLastError() { return cudaSuccess; }
+static inline cudaError_t cudaGetDevice(int* d) {
+  *d = 0;
+  return cudaSuccess;
+}
+static inline cudaError_t cudaSetDevice(int) { return cudaSuccess; }
+static inline cudaError_t cudaPointerGetAttributes(cudaPointerAttributes* a, const void*) {
+  a->type = cudaMemoryTypeDevice;
+  a->device = 0;
+  return cudaSuccess;
+}
+static inline cudaError_t cudaMalloc(void** p, size_t bytes) {
+  void* q = nullptr;
+  if (posix_memalign(&q, 256, bytes ? (bytes + 255) / 256 * 256 : 256) != 0)
+    return cudaErrorMemoryAllocation;
+  memset(q, 0xA5, bytes);  // fresh device memory holds garbage
+  *p = q;
+  return cudaSuccess;
+}
+static inline cudaError_t cudaFree(void* p) {
+  free(p);
+  return cudaSuccess;
+}
+static inline cudaError_t cudaMemsetAsync(void* p, int v, size_t n, cudaStream_t = nullptr) {
+  memset(p, v, n);
+  return cudaSuccess;
+}
+static inline cudaError_t cudaStreamSynchronize(cudaStream_t) { return cudaSuccess; }
+
+// ---- the CUDA builtins the file uses (its own overloads for long / long long / unsigned long
+// forward to the unsigned long long one, as on the device) ------------------------------------------
+static inline void __syncthreads() { hipemu::syncthreads(); }
+static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+}
+static inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+// a CAS that did not swap is the body of a spin loop (warp_lock_mutex): threads are fibers here,
+// so the spinning one must let the lock's holder run
+static inline int atomicCAS(int* p, int cmp, int v) {
+  const int want = cmp;
+  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  if (cmp != want) hipemu::spin_pause();
+  return cmp;
+}
+
+// kernel<<<grid, block, shmem, stream>>>(args) is rewritten by oracle/ref_launch_rewrite.py (the
+// only edit made to the reference's text, into oracle/_ref/gen/) to this macro
+namespace refemu {
+struct Cfg {
+  dim3 g, b;
+  size_t shmem;
+  template <typename G, typename B>
+  Cfg(G g_, B b_, size_t s_ = 0, cudaStream_t = nullptr)
+      : g((unsigned)g_), b((unsigned)b_), shmem(s_) {}
+};
+}  // namespace refemu
+#define REFEMU_LAUNCH(kernel, cfg, ...)                       \
+  do {                                                         \
+    ::refemu::Cfg refemu_cfg cfg;                              \
+    hipemu::launch(refemu_cfg.g, refemu_cfg.b, refemu_cfg.shmem, \
+                   [&]() { kernel(__VA_ARGS__); });            \
+  } while (0)

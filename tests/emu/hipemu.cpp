@@ -40,6 +40,8 @@ struct Worker {
 thread_local Worker* tl_worker = nullptr;
 
 std::atomic<uint64_t> g_launches{0}, g_blocks{0}, g_divergent{0}, g_inactive{0};
+int g_wave = 64;            // lanes of a wavefront (set_wave_width)
+size_t g_worker_cap = 0;    // OS threads of a launch (set_max_workers; 0 = the default policy)
 
 size_t env_size(const char* name, size_t dflt) {
   const char* v = getenv(name);
@@ -117,7 +119,7 @@ bool resolve_wave(Worker* w, size_t lo, size_t hi) {
       case OP_ANY: f.result = (pred != 0) ? 1 : 0; break;
       case OP_FIRST: f.result = w->fibers[lo + (size_t)first].val; break;
       case OP_SHFL:
-        index = (f.arg + (self & ~(wd - 1))) & 63;
+        index = (f.arg + (self & ~(wd - 1))) & (g_wave - 1);
         is_shfl = true;
         break;
       case OP_SHFL_UP:
@@ -137,7 +139,7 @@ bool resolve_wave(Worker* w, size_t lo, size_t hi) {
         break;
     }
     if (is_shfl) {
-      if (index >= 0 && index < 64 && ((active >> index) & 1ull)) {
+      if (index >= 0 && index < g_wave && ((active >> index) & 1ull)) {
         f.result = w->fibers[lo + (size_t)index].val;
       } else {
         f.result = 0;  // (the hardware hands back whatever the idle lane's register holds)
@@ -199,7 +201,8 @@ void run_block(Worker* w, dim3 grid, dim3 block, unsigned linear_block) {
     }
     if (live == 0) break;
     bool released = false;
-    for (size_t lo = 0; lo < n; lo += 64) released |= resolve_wave(w, lo, lo + 64 < n ? lo + 64 : n);
+    const size_t wv = (size_t)g_wave;
+    for (size_t lo = 0; lo < n; lo += wv) released |= resolve_wave(w, lo, lo + wv < n ? lo + wv : n);
     if (!released) {
       size_t at_bar = 0, ready = 0;
       for (auto& f : w->fibers) {
@@ -246,6 +249,12 @@ void spin_pause() {
 
 void* dyn_shared() { return tl_worker->dyn; }
 
+void set_wave_width(int lanes) {
+  if (lanes != 64 && lanes != 32) die("set_wave_width: 32 or 64 lanes", nullptr);
+  g_wave = lanes;
+}
+void set_max_workers(size_t n) { g_worker_cap = n; }
+
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
   const size_t nthreads = (size_t)block.x * block.y * block.z;
@@ -259,7 +268,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
   // one OS thread per workgroup while the grid is small: every workgroup of a kernel that spins on
   // a grid barrier is alive.  (Larger grids: workgroups queue on `hw` threads -- such a kernel
   // would run into its spin limit, which the kernels under test report as an error.)
-  const size_t nworkers = nblocks <= max_workers ? nblocks : hw;
+  size_t nworkers = nblocks <= max_workers ? nblocks : hw;
+  if (g_worker_cap > 0 && nworkers > g_worker_cap) nworkers = g_worker_cap;
   std::atomic<size_t> next{0};
   auto work = [&]() {
     Worker w;

@@ -48,6 +48,12 @@ void syncthreads();
 uint64_t collective(Op op, uint64_t value, int arg, int width, int site);
 void spin_pause();  // s_sleep inside a spin loop: lets everybody else run
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+// width of a wavefront (64; 32 when the code under the interpreter is written for 32-lane warps,
+// e.g. the reference's CUDA sources behind oracle/_ref/libref_cache.so) and a cap on the OS threads
+// of a launch (0 = one per workgroup while the grid is small; 1 = workgroups strictly one after the
+// other in block order, which makes lock-protected code deterministic)
+void set_wave_width(int lanes);
+void set_max_workers(size_t n);
 void* dyn_shared();
 
 struct Stats {

@@ -1,7 +1,8 @@
 """The cache oracle against hand-worked scenarios of the reference's rules
 (R/gpu_cache/src/nv_gpu_cache.cu:541-697): probing starts in slab key % 2, empty slots first,
 least-recently-used eviction with ties broken in probing order, Query refreshes, Update never
-inserts.  (The reference ships no golden vectors for gpu_cache: parity unpinned.)"""
+inserts.  (The reference ships no golden vectors for gpu_cache; tests/test_ref_cache_cpu.py pins
+the oracle against the reference's own kernels executed by the host interpreter.)"""
 import numpy as np
 
 from oracle.cache_oracle import CacheOracle, TieredOracle, murmur3_32
