@@ -319,7 +319,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     # HBM bytes per launch from the PMC counters (rocprofv3, separate passes, tools/measure_round.sh
     # -> profiles/r3_pmc_hbm_traffic_<label>.json, stamped with the commit it was taken on; a bench
     # process cannot read the counters of its own kernels)
-    pmc, pmc_src = None, None
+    pmc, pmc_src, pmc_upd, pmc_idx = None, None, None, None
     tag = label or ("fp32" if esz == 4 else "fp16")
     for rnd in ("r3", "r2"):
         pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{tag}.json")
@@ -328,10 +328,26 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
             try:
                 j = json.load(open(pmc_path))
                 if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
-                    pmc = j["kernels"]["interaction_fwd16_gather_kernel" if fused
-                                       else "pool_vec4_kernel"]["hbm_bytes_per_launch"]
+                    ks = j["kernels"]
+                    pmc = ks["interaction_fwd16_gather_kernel" if fused
+                             else "pool_vec4_kernel"]["hbm_bytes_per_launch"]
                     pmc_src = os.path.relpath(pmc_path, ROOT) + (
                         f" @ {j['commit']}" if j.get("commit") else "")
+
+                    def per_step(names, once):
+                        # bytes per step of a group of kernels: per-launch average x launches per
+                        # step (= its launch count over that of a kernel launched once a step)
+                        n1 = ks[once]["launches_averaged"][0]
+                        return sum(ks[k]["hbm_bytes_per_launch"] *
+                                   ks[k]["launches_averaged"][0] / n1 for k in names if k in ks)
+                    if "seg_reduce_kernel" in ks:
+                        pmc_upd = per_step(("expand_pairs_kernel", "rs_hist_kernel",
+                                            "rs_colscan_kernel", "rs_scatter_kernel",
+                                            "seg_reduce_kernel", "seg_combine_kernel",
+                                            "seg_combine_big_kernel"), "seg_reduce_kernel")
+                    if "ht_probe_insert_kernel" in ks:
+                        pmc_idx = per_step(("ht_probe_insert_kernel", "ht_finish_kernel"),
+                                           "ht_probe_insert_kernel")
                     break
             except Exception:
                 pmc = None
@@ -402,12 +418,15 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                             "achieved": (upd_bytes / upd_s / 1e9) if upd_s > 0 else None,
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": (upd_bytes / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
-                            "algorithmic_bytes": upd_bytes, "us": upd_s * 1e6, "traffic": None},
+                            "algorithmic_bytes": upd_bytes, "us": upd_s * 1e6,
+                            # HBM bytes per step of these kernels (same PMC passes as above)
+                            "traffic": pmc_upd, "traffic_source": pmc_src if pmc_upd else None},
         "roofline_index": {"bound": "hbm", "kernels": "hash index stage (filter + probe / insert)",
                            "achieved": (idx_bytes / idx_s / 1e9) if idx_s > 0 else None,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (idx_bytes / idx_s / 1e9 / HBM_PEAK_GBPS) if idx_s > 0 else None,
-                           "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6},
+                           "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6,
+                           "traffic": pmc_idx, "traffic_source": pmc_src if pmc_idx else None},
         "stage_us_per_step": stage_us,
         "stage_us_per_step_no_new_keys": steady_us,
         "embedding_ms_per_step": sum(stage_us.values()) * 1e-3,
