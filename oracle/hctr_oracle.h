@@ -18,6 +18,11 @@
  *     stand-in for common.hpp (oracle/ref_shims/) and driven over several training steps from
  *     Norm dataset + sparse model files (tests/test_ref_embedding_cpu.py): sum forward / wgrad
  *     bit-equal, tables within 5e-7.
+ *   - the same functions against the reference's DEVICE code (the CUDA kernels of
+ *     forward_per_gpu_functor.cu / backward_functor.cu / forward_scale_functor.cu and
+ *     EmbeddingOptimizer::update with its kernels, cut out of the checkout and executed by the
+ *     host interpreter of tests/emu): forward / backward bit-equal incl. the fp16 align2 rules,
+ *     ten optimizer variants within 1e-6 (tests/test_ref_gpu_kernels_cpu.py).
  * The other oracles are pinned by their own reference builds (oracle/Makefile `ref`): Interaction /
  * Cross (the CPU references inline in the reference's gtest files, tests/test_ref_layers_cpu.py),
  * embedding_collection (tests/test_ref_ebc_cpu.py), the dynamic table (tests/test_ref_det_cpu.py),

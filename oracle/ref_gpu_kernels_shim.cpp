@@ -1,0 +1,202 @@
+// TEST INFRASTRUCTURE ONLY: C entry points over the REFERENCE's own DEVICE code of the legacy sparse
+// embedding, executed by the host interpreter of tests/emu (CUDA threads = fibers, host memory):
+//   forward_sum / forward_mean   + their launch wrappers (fp32, and the paired-half "align2" forms)
+//                                  R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:22-243
+//   do_forward_scale                R/HugeCTR/src/embeddings/forward_scale_functor.cu:23-101
+//   backward_sum / backward_mean    R/HugeCTR/src/embeddings/backward_functor.cu:23-158
+//   EmbeddingOptimizer::update     R/HugeCTR/src/optimizers/sparse_optimizer.cu:170-612 (kernels),
+//                                  :622-864 (the method: expansion, sort, run counting, optimizer)
+// The blocks are cut out of the checkout by oracle/Makefile (sed by their first / last lines, the
+// <<<>>> launches rewritten by ref_launch_rewrite.py) into _ref/gen/ (generated, never committed).
+// What is written here is declarations only: the class shell whose member NAMES update() refers to
+// (after R/HugeCTR/include/optimizer.hpp:284-340), a pointer-and-size Tensor2, and the C wrappers.
+// cub's sort / scan are the contract-level stand-ins of ref_shims/cuda/cuda_device_extras.h.
+// tests/test_ref_gpu_kernels_cpu.py compares oracle/hctr_oracle.c AND the HIP kernels' source
+// (tests/emu build of hugectr_amd/csrc) with these on the same inputs.
+#include <common.hpp>  // oracle/ref_shims/common.hpp: enums, OptParams, binary16 __half
+
+#include <cmath>
+#include <limits>
+#include <memory>
+
+#include "ref_shims/cuda/cuda_runtime_api.h"
+#include "ref_shims/cuda/cuda_device_extras.h"
+
+#define HCTR_LIB_THROW(expr) \
+  do { if ((expr) != cudaSuccess) throw std::runtime_error("cuda stand-in reported an error"); } while (0)
+
+namespace HugeCTR {
+
+template <typename T>
+class Tensor2 {
+  T* p_ = nullptr;
+  size_t bytes_ = 0;
+
+ public:
+  Tensor2() = default;
+  Tensor2(T* p, size_t bytes) : p_(p), bytes_(bytes) {}
+  T* get_ptr() const { return p_; }
+  size_t get_size_in_bytes() const { return bytes_; }
+};
+
+struct SparseEmbeddingHashParams {
+  OptParams opt_params;
+};
+
+template <typename TypeEmbeddingComp>
+struct OptimizerTensor {
+  Tensor2<TypeEmbeddingComp> opt_z_tensors_, opt_n_tensors_, opt_m_tensors_, opt_v_tensors_;
+  Tensor2<uint64_t> opt_prev_time_tensors_;
+  Tensor2<TypeEmbeddingComp> opt_momentum_tensors_, opt_accm_tensors_;
+};
+
+template <typename TypeHashKey, typename TypeEmbeddingComp>
+class EmbeddingOptimizer {
+ public:
+  Tensor2<void> temp_storage_sort_tensors_, temp_storage_scan_tensors_;
+  Tensor2<TypeHashKey> sample_id_tensors_, sample_id_sort_tensors_;
+  Tensor2<size_t> hash_value_index_sort_tensors_;
+  Tensor2<uint32_t> new_hash_value_flag_tensors_, hash_value_flag_sumed_tensors_,
+      hash_value_index_count_offset_tensors_, hash_value_index_count_counter_tensors_;
+  SparseEmbeddingHashParams& param;
+  OptimizerTensor<TypeEmbeddingComp> opt_tensors_;
+  explicit EmbeddingOptimizer(SparseEmbeddingHashParams& p) : param(p) {}
+  void update(size_t batch_size, size_t slot_num, size_t embedding_vec_size,
+              size_t max_vocabulary_size_per_gpu, size_t nnz, const Tensor2<TypeHashKey>& row_offset,
+              Tensor2<size_t>& hash_value_index, const Tensor2<TypeEmbeddingComp>& wgrad,
+              Tensor2<float>& hash_table_value, size_t sm_count, cudaStream_t stream);
+};
+
+// ---- the reference's text from here ----------------------------------------------------------------
+#include "_ref/gen/gpu_type_convert_func.inc"
+#include "_ref/gen/gpu_forward.inc"
+#include "_ref/gen/gpu_forward_scale.inc"
+#include "_ref/gen/gpu_backward.inc"
+#include "_ref/gen/gpu_opt_kernels.inc"
+#include "_ref/gen/gpu_opt_update.inc"
+// ---- to here -----------------------------------------------------------------------------------------
+
+namespace {
+template <typename K, typename E>
+void run_forward(int combiner, size_t batch, size_t slots, size_t D, const K* ro, const size_t* vi,
+                 const float* table, E* out) {
+  if (combiner == 0)
+    forward_sum(batch, slots, D, ro, vi, table, out, (cudaStream_t) nullptr);
+  else
+    forward_mean(batch, slots, D, ro, vi, table, out, (cudaStream_t) nullptr);
+}
+template <typename K, typename E>
+void run_backward(int combiner, size_t batch, size_t slots, size_t D, const K* ro, const E* top,
+                  E* wgrad) {
+  if (combiner == 0)
+    backward_sum(batch, slots, D, top, wgrad, (cudaStream_t) nullptr);
+  else
+    backward_mean(batch, slots, D, ro, top, wgrad, (cudaStream_t) nullptr);
+}
+template <typename K, typename E>
+void run_update(const OptParams& op, size_t batch, size_t slots, size_t D, size_t vocab, size_t nnz,
+                const K* ro, size_t* vi, const E* wgrad, float* table, E* s0, E* s1,
+                uint64_t* prev_time) {
+  SparseEmbeddingHashParams p;
+  p.opt_params = op;
+  EmbeddingOptimizer<K, E> o(p);
+  const size_t n = nnz > 0 ? nnz : 1;
+  std::vector<K> sid(n), sids(n);
+  std::vector<size_t> vis(n);
+  std::vector<uint32_t> flag(n), sumed(n), off(n + 1), counter(1);
+  std::vector<char> tmp(64);
+  o.temp_storage_sort_tensors_ = Tensor2<void>(tmp.data(), tmp.size());
+  o.temp_storage_scan_tensors_ = Tensor2<void>(tmp.data(), tmp.size());
+  o.sample_id_tensors_ = Tensor2<K>(sid.data(), n * sizeof(K));
+  o.sample_id_sort_tensors_ = Tensor2<K>(sids.data(), n * sizeof(K));
+  o.hash_value_index_sort_tensors_ = Tensor2<size_t>(vis.data(), n * sizeof(size_t));
+  o.new_hash_value_flag_tensors_ = Tensor2<uint32_t>(flag.data(), n * 4);
+  o.hash_value_flag_sumed_tensors_ = Tensor2<uint32_t>(sumed.data(), n * 4);
+  o.hash_value_index_count_offset_tensors_ = Tensor2<uint32_t>(off.data(), (n + 1) * 4);
+  o.hash_value_index_count_counter_tensors_ = Tensor2<uint32_t>(counter.data(), 4);
+  const size_t sb = vocab * D * sizeof(E);
+  switch (op.optimizer) {
+    case Optimizer_t::Adam:
+      o.opt_tensors_.opt_m_tensors_ = Tensor2<E>(s0, sb);
+      o.opt_tensors_.opt_v_tensors_ = Tensor2<E>(s1, sb);
+      o.opt_tensors_.opt_prev_time_tensors_ = Tensor2<uint64_t>(prev_time, vocab * D * 8);
+      break;
+    case Optimizer_t::MomentumSGD:
+      o.opt_tensors_.opt_momentum_tensors_ = Tensor2<E>(s0, sb);
+      break;
+    default:
+      o.opt_tensors_.opt_accm_tensors_ = Tensor2<E>(s0, sb);
+  }
+  Tensor2<K> t_ro(const_cast<K*>(ro), (batch * slots + 1) * sizeof(K));
+  Tensor2<size_t> t_vi(vi, n * sizeof(size_t));
+  Tensor2<E> t_wg(const_cast<E*>(wgrad), batch * slots * D * sizeof(E));
+  Tensor2<float> t_tab(table, vocab * D * 4);
+  o.update(batch, slots, D, vocab, nnz, t_ro, t_vi, t_wg, t_tab, /*sm_count=*/8, nullptr);
+}
+}  // namespace
+}  // namespace HugeCTR
+
+using namespace HugeCTR;
+
+extern "C" {
+// key_bytes 8 | 4, fp16 0 | 1; row_offset is key-typed (as the reference's), value_index size_t
+void refgpu_forward(int key_bytes, int fp16, int combiner, size_t batch, size_t slots, size_t D,
+                    const void* ro, const size_t* vi, const float* table, void* out) {
+  hipemu::set_wave_width(64);
+  hipemu::set_max_workers(0);
+  if (key_bytes == 8 && !fp16) run_forward(combiner, batch, slots, D, (const long long*)ro, vi, table, (float*)out);
+  if (key_bytes == 8 && fp16) run_forward(combiner, batch, slots, D, (const long long*)ro, vi, table, (__half*)out);
+  if (key_bytes == 4 && !fp16) run_forward(combiner, batch, slots, D, (const unsigned*)ro, vi, table, (float*)out);
+  if (key_bytes == 4 && fp16) run_forward(combiner, batch, slots, D, (const unsigned*)ro, vi, table, (__half*)out);
+}
+
+// distributed embedding, mean: the division after the reduce-scatter (in place)
+void refgpu_forward_scale(int key_bytes, int fp16, size_t batch, size_t slots, size_t D,
+                          const void* ro, void* feature) {
+  if (key_bytes == 8 && !fp16) do_forward_scale(batch, slots, D, (const long long*)ro, (float*)feature, (cudaStream_t) nullptr);
+  if (key_bytes == 8 && fp16) do_forward_scale(batch, slots, D, (const long long*)ro, (__half*)feature, (cudaStream_t) nullptr);
+  if (key_bytes == 4 && !fp16) do_forward_scale(batch, slots, D, (const unsigned*)ro, (float*)feature, (cudaStream_t) nullptr);
+  if (key_bytes == 4 && fp16) do_forward_scale(batch, slots, D, (const unsigned*)ro, (__half*)feature, (cudaStream_t) nullptr);
+}
+
+void refgpu_backward(int key_bytes, int fp16, int combiner, size_t batch, size_t slots, size_t D,
+                     const void* ro, const void* top, void* wgrad) {
+  if (key_bytes == 8 && !fp16) run_backward(combiner, batch, slots, D, (const long long*)ro, (const float*)top, (float*)wgrad);
+  if (key_bytes == 8 && fp16) run_backward(combiner, batch, slots, D, (const long long*)ro, (const __half*)top, (__half*)wgrad);
+  if (key_bytes == 4 && !fp16) run_backward(combiner, batch, slots, D, (const unsigned*)ro, (const float*)top, (float*)wgrad);
+  if (key_bytes == 4 && fp16) run_backward(combiner, batch, slots, D, (const unsigned*)ro, (const __half*)top, (__half*)wgrad);
+}
+
+// one EmbeddingOptimizer::update; optimizer / update_type = the reference's enum values
+// (common.hpp:82-94); `times` = adam.times AFTER the increment the embedding does before update.
+// Optimizer state has the embedding's output type (fp32 or fp16), as in the reference.
+int refgpu_update(int key_bytes, int fp16, int optimizer, int update_type, int atomic_sgd, float lr,
+                  float scaler, float beta1, float beta2, float epsilon, float momentum_or_mu,
+                  unsigned long long times, size_t batch, size_t slots, size_t D, size_t vocab,
+                  size_t nnz, const void* ro, size_t* vi, const void* wgrad, float* table, void* s0,
+                  void* s1, uint64_t* prev_time) {
+  OptParams op;
+  op.optimizer = static_cast<Optimizer_t>(optimizer);
+  op.update_type = static_cast<Update_t>(update_type);
+  op.lr = lr;
+  op.scaler = scaler;
+  op.hyperparams.adam.beta1 = beta1;
+  op.hyperparams.adam.beta2 = beta2;
+  op.hyperparams.adam.epsilon = epsilon;
+  op.hyperparams.adam.times = times;
+  op.hyperparams.adagrad.epsilon = epsilon;
+  op.hyperparams.momentum.factor = momentum_or_mu;
+  op.hyperparams.nesterov.mu = momentum_or_mu;
+  op.hyperparams.sgd.atomic_update = atomic_sgd != 0;
+  try {
+    if (key_bytes == 8 && !fp16) run_update(op, batch, slots, D, vocab, nnz, (const long long*)ro, vi, (const float*)wgrad, table, (float*)s0, (float*)s1, prev_time);
+    if (key_bytes == 8 && fp16) run_update(op, batch, slots, D, vocab, nnz, (const long long*)ro, vi, (const __half*)wgrad, table, (__half*)s0, (__half*)s1, prev_time);
+    if (key_bytes == 4 && !fp16) run_update(op, batch, slots, D, vocab, nnz, (const unsigned*)ro, vi, (const float*)wgrad, table, (float*)s0, (float*)s1, prev_time);
+    if (key_bytes == 4 && fp16) run_update(op, batch, slots, D, vocab, nnz, (const unsigned*)ro, vi, (const __half*)wgrad, table, (__half*)s0, (__half*)s1, prev_time);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "refgpu_update: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+}

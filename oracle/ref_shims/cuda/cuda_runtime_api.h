@@ -64,6 +64,18 @@ static inline cudaError_t cudaMemsetAsync(void* p, int v, size_t n, cudaStream_t
   return cudaSuccess;
 }
 static inline cudaError_t cudaStreamSynchronize(cudaStream_t) { return cudaSuccess; }
+enum cudaMemcpyKind {
+  cudaMemcpyHostToHost,
+  cudaMemcpyHostToDevice,
+  cudaMemcpyDeviceToHost,
+  cudaMemcpyDeviceToDevice,
+  cudaMemcpyDefault
+};
+static inline cudaError_t cudaMemcpyAsync(void* d, const void* s, size_t n, cudaMemcpyKind,
+                                          cudaStream_t = nullptr) {
+  memmove(d, s, n);
+  return cudaSuccess;
+}
 
 // ---- the CUDA builtins the file uses (its own overloads for long / long long / unsigned long
 // forward to the unsigned long long one, as on the device) ------------------------------------------
@@ -78,6 +90,21 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
 }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline float atomicAdd(float* p, float v) {
+  unsigned* u = reinterpret_cast<unsigned*>(p);
+  unsigned old = __atomic_load_n(u, __ATOMIC_RELAXED);
+  for (;;) {
+    float f;
+    memcpy(&f, &old, 4);
+    f += v;
+    unsigned nu;
+    memcpy(&nu, &f, 4);
+    if (__atomic_compare_exchange_n(u, &old, nu, true, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) {
+      memcpy(&f, &old, 4);
+      return f;
+    }
+  }
+}
 static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 // a CAS that did not swap is the body of a spin loop (warp_lock_mutex): threads are fibers here,
 // so the spinning one must let the lock's holder run
