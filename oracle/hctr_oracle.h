@@ -27,8 +27,8 @@
  * Cross (the CPU references inline in the reference's gtest files, tests/test_ref_layers_cpu.py),
  * embedding_collection (tests/test_ref_ebc_cpu.py), the dynamic table (tests/test_ref_det_cpu.py),
  * the embedding cache (the reference's CUDA kernels executed by the host interpreter,
- * tests/test_ref_cache_cpu.py).  Not pinned that way: the reorder maps (closed forms, hand-worked
- * cases and the numpy fixtures in tests/golden/).
+ * tests/test_ref_cache_cpu.py).  The reorder maps: the reference's reorder kernels, executed
+ * (tests/test_ref_gpu_kernels_cpu.py).
  *
  * All functions are plain C, single-threaded unless `threads > 1` is passed where offered.
  */

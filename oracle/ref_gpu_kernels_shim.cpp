@@ -4,6 +4,9 @@
 //                                  R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:22-243
 //   do_forward_scale                R/HugeCTR/src/embeddings/forward_scale_functor.cu:23-101
 //   backward_sum / backward_mean    R/HugeCTR/src/embeddings/backward_functor.cu:23-158
+//   do_forward_reorder / do_backward_reorder (the layout change around the localized embedding's
+//                                  all-to-all)  R/HugeCTR/src/embeddings/forward_reorder_functor.cu:22-120,
+//                                  backward_reorder_functor.cu:22-123
 //   EmbeddingOptimizer::update     R/HugeCTR/src/optimizers/sparse_optimizer.cu:170-612 (kernels),
 //                                  :622-864 (the method: expansion, sort, run counting, optimizer)
 // The blocks are cut out of the checkout by oracle/Makefile (sed by their first / last lines, the
@@ -72,6 +75,8 @@ class EmbeddingOptimizer {
 #include "_ref/gen/gpu_forward.inc"
 #include "_ref/gen/gpu_forward_scale.inc"
 #include "_ref/gen/gpu_backward.inc"
+#include "_ref/gen/gpu_forward_reorder.inc"
+#include "_ref/gen/gpu_backward_reorder.inc"
 #include "_ref/gen/gpu_opt_kernels.inc"
 #include "_ref/gen/gpu_opt_update.inc"
 // ---- to here -----------------------------------------------------------------------------------------
@@ -165,6 +170,18 @@ void refgpu_backward(int key_bytes, int fp16, int combiner, size_t batch, size_t
   if (key_bytes == 8 && fp16) run_backward(combiner, batch, slots, D, (const long long*)ro, (const __half*)top, (__half*)wgrad);
   if (key_bytes == 4 && !fp16) run_backward(combiner, batch, slots, D, (const unsigned*)ro, (const float*)top, (float*)wgrad);
   if (key_bytes == 4 && fp16) run_backward(combiner, batch, slots, D, (const unsigned*)ro, (const __half*)top, (__half*)wgrad);
+}
+
+// forward: all-to-all receive buffer [peer][b][slot in peer][D] -> [b][slot][D]; backward: the inverse
+void refgpu_reorder(int fp16, int backward, size_t bpg, size_t slots, size_t D, size_t gpus,
+                    const void* in, void* out) {
+  if (!backward) {
+    if (fp16) do_forward_reorder(bpg, slots, D, gpus, (const __half*)in, (__half*)out, (cudaStream_t) nullptr);
+    else do_forward_reorder(bpg, slots, D, gpus, (const float*)in, (float*)out, (cudaStream_t) nullptr);
+  } else {
+    if (fp16) do_backward_reorder(bpg, slots, D, gpus, (const __half*)in, (__half*)out, (cudaStream_t) nullptr);
+    else do_backward_reorder(bpg, slots, D, gpus, (const float*)in, (float*)out, (cudaStream_t) nullptr);
+  }
 }
 
 // one EmbeddingOptimizer::update; optimizer / update_type = the reference's enum values

@@ -277,3 +277,46 @@ def test_forward_scale_of_the_reference_is_the_oracle_mean_of_a_sum(oracle, ref,
         assert np.array_equal(got16.view(np.uint16), want16.view(np.uint16))
     else:  # odd D: forward_mean rounds sum * (1/n) once, forward_scale rounds the sum first
         assert_close(got16.astype(np.float32), want16.astype(np.float32), 2e-3, 1e-4, "fp16 odd D")
+
+
+@pytest.mark.parametrize("fp16", [0, 1])
+@pytest.mark.parametrize("bpg,S,D,gpus", [(5, 26, 16, 8), (4, 7, 11, 3), (3, 5, 128, 1), (6, 3, 8, 4),
+                                          (2, 26, 4, 2)])
+def test_reorder_maps_equal_the_reference_reorder_kernels(oracle, ref, elib, bpg, S, D, gpus, fp16):
+    """the layout change around the localized embedding's all-to-all: the reference's
+    forward_reorder / backward_reorder kernels (slot s lives on GPU s % N as its (s / N)-th slot;
+    slot counts that do not divide by the GPU count, more GPUs than slots) against the oracle's
+    maps, the HIP kernels' source, and the index form the Model uses (parallel.reorder_row_map)"""
+    import torch
+    from hugectr_amd import _lib
+    from hugectr_amd.parallel import reorder_row_map
+    L = ref.L
+    L.refgpu_reorder.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_size_t] * 4 + \
+        [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(bpg * S + D + gpus)
+    dt = np.float16 if fp16 else np.float32
+    n = bpg * S * D
+    x = rng.standard_normal(n).astype(dt)
+    for backward in (0, 1):
+        want = np.full(n, np.nan, dt)
+        L.refgpu_reorder(fp16, backward, bpg, S, D, gpus, _p(x), _p(want))
+        assert not np.isnan(want.astype(np.float32)).any()  # a bijection: every element written
+        fo = oracle.backward_reorder if backward else oracle.forward_reorder
+        got = np.asarray(fo(x.astype(np.float32), bpg, S, D, gpus)).reshape(-1).astype(dt)
+        assert np.array_equal(got, want), ("oracle", backward)
+        hip = np.full(n, np.nan, dt)
+        fn = elib.hctr_backward_reorder if backward else elib.hctr_forward_reorder
+        emu.check(elib, fn(bpg, S, D, gpus, _p(x), _p(hip), _lib.F16 if fp16 else _lib.F32, None))
+        assert np.array_equal(hip, want), ("hip", backward)
+    # index form: row of (local sample b, slot s) in the receive buffer
+    rows = reorder_row_map(bpg, S, gpus).numpy().reshape(-1)
+    fwd = np.full(n, np.nan, dt)
+    L.refgpu_reorder(fp16, 0, bpg, S, D, gpus, _p(x), _p(fwd))
+    assert np.array_equal(x.reshape(-1, D)[rows].reshape(-1), fwd)
+    bwd = np.full(n, np.nan, dt)
+    L.refgpu_reorder(fp16, 1, bpg, S, D, gpus, _p(x), _p(bwd))
+    scat = np.empty((bpg * S, D), dt)
+    scat[rows] = x.reshape(-1, D)
+    assert np.array_equal(scat.reshape(-1), bwd)
+    assert torch.equal(torch.sort(torch.from_numpy(rows.astype(np.int64)))[0],
+                       torch.arange(bpg * S))
