@@ -1,11 +1,14 @@
 """TEST INFRASTRUCTURE ONLY.  `kernel<T...><<<grid, block, shmem, stream>>>(args);` is CUDA syntax,
 not C++: to compile a reference .cu file as plain C++ for the host interpreter (tests/emu), every
 launch statement is rewritten to `REFEMU_LAUNCH((kernel<T...>), (grid, block, shmem, stream), args);`
-(macro in ref_shims/cuda/cuda_runtime_api.h).  Nothing else in the text changes.  The output goes to
+(macro in ref_shims/cuda/cuda_runtime_api.h), and a declaration of dynamically sized shared memory
+`extern __shared__ T name[];` (an unsized extern array cannot be expressed on the host) to
+`T* name = (T*)hipemu::dyn_shared();`.  Nothing else in the text changes.  The output goes to
 oracle/_ref/gen/ (generated at build time from the checkout, never committed).
 
     python ref_launch_rewrite.py <in.cu> <out.cpp>
 """
+import re
 import sys
 
 
@@ -73,5 +76,7 @@ def rewrite(src: str) -> str:
 if __name__ == "__main__":
     text = open(sys.argv[1]).read()
     res = rewrite(text)
+    res = re.sub(r"extern\s+__shared__\s+([A-Za-z_][\w ]*?)\s+(\w+)\[\];",
+                 r"\1* \2 = (\1*)hipemu::dyn_shared();", res)
     assert "<<<" not in res
     open(sys.argv[2], "w").write(res)

@@ -26,7 +26,12 @@
 typedef struct refemu_stream* cudaStream_t;
 typedef struct refemu_event* cudaEvent_t;
 enum cudaError_t { cudaSuccess = 0, cudaErrorMemoryAllocation = 2 };
-enum cudaMemoryType { cudaMemoryTypeUnregistered = 0, cudaMemoryTypeHost = 1, cudaMemoryTypeDevice = 2 };
+enum cudaMemoryType {
+  cudaMemoryTypeUnregistered = 0,
+  cudaMemoryTypeHost = 1,
+  cudaMemoryTypeDevice = 2,
+  cudaMemoryTypeManaged = 3
+};
 struct cudaPointerAttributes {
   cudaMemoryType type;
   int device;
@@ -55,6 +60,16 @@ static inline cudaError_t cudaMalloc(void** p, size_t bytes) {
   *p = q;
   return cudaSuccess;
 }
+template <typename T>
+static inline cudaError_t cudaMallocManaged(T** p, size_t bytes) {
+  void* q = nullptr;
+  const cudaError_t rc = cudaMalloc(&q, bytes);
+  *p = (T*)q;
+  return rc;
+}
+static inline cudaError_t cudaMemPrefetchAsync(const void*, size_t, int, cudaStream_t = nullptr) {
+  return cudaSuccess;
+}
 static inline cudaError_t cudaFree(void* p) {
   free(p);
   return cudaSuccess;
@@ -71,6 +86,10 @@ enum cudaMemcpyKind {
   cudaMemcpyDeviceToDevice,
   cudaMemcpyDefault
 };
+static inline cudaError_t cudaMemcpy(void* d, const void* s, size_t n, cudaMemcpyKind) {
+  memmove(d, s, n);
+  return cudaSuccess;
+}
 static inline cudaError_t cudaMemcpyAsync(void* d, const void* s, size_t n, cudaMemcpyKind,
                                           cudaStream_t = nullptr) {
   memmove(d, s, n);
@@ -104,6 +123,41 @@ static inline float atomicAdd(float* p, float v) {
       return f;
     }
   }
+}
+struct alignas(8) uint2 {
+  unsigned x, y;
+};
+struct alignas(16) uint4 {
+  unsigned x, y, z, w;
+};
+static inline double __longlong_as_double(long long v) {
+  double d;
+  memcpy(&d, &v, 8);
+  return d;
+}
+static inline long long __double_as_longlong(double v) {
+  long long d;
+  memcpy(&d, &v, 8);
+  return d;
+}
+static inline float __int_as_float(int v) {
+  float d;
+  memcpy(&d, &v, 4);
+  return d;
+}
+static inline int __float_as_int(float v) {
+  int d;
+  memcpy(&d, &v, 4);
+  return d;
+}
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp,
+                                           unsigned long long v) {
+  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
+}
+static inline unsigned atomicCAS(unsigned* p, unsigned cmp, unsigned v) {
+  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return cmp;
 }
 static inline int atomicExch(int* p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 // a CAS that did not swap is the body of a spin loop (warp_lock_mutex): threads are fibers here,
