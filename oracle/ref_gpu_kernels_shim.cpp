@@ -7,6 +7,11 @@
 //   do_forward_reorder / do_backward_reorder (the layout change around the localized embedding's
 //                                  all-to-all)  R/HugeCTR/src/embeddings/forward_reorder_functor.cu:22-120,
 //                                  backward_reorder_functor.cu:22-123
+//   select_value_and_rowoffset_by_slot_id_kernel / select_rowoffset + HashOp (filter_keys_per_gpu of the
+//                                  localized / distributed embedding; the three library calls
+//                                  around them follow localized_slot_sparse_embedding_hash.cu:
+//                                  113-146 and distributed_slot_sparse_embedding_hash.cu:107-147)
+//   store_slot_id_kernel           R/HugeCTR/src/embeddings/store_slot_id_functor.cu:22-50
 //   EmbeddingOptimizer::update     R/HugeCTR/src/optimizers/sparse_optimizer.cu:170-612 (kernels),
 //                                  :622-864 (the method: expansion, sort, run counting, optimizer)
 // The blocks are cut out of the checkout by oracle/Makefile (sed by their first / last lines, the
@@ -77,6 +82,9 @@ class EmbeddingOptimizer {
 #include "_ref/gen/gpu_backward.inc"
 #include "_ref/gen/gpu_forward_reorder.inc"
 #include "_ref/gen/gpu_backward_reorder.inc"
+#include "_ref/gen/gpu_filter_localized.inc"
+#include "_ref/gen/gpu_filter_distributed.inc"
+#include "_ref/gen/gpu_store_slot_id.inc"
 #include "_ref/gen/gpu_opt_kernels.inc"
 #include "_ref/gen/gpu_opt_update.inc"
 // ---- to here -----------------------------------------------------------------------------------------
@@ -138,6 +146,33 @@ void run_update(const OptParams& op, size_t batch, size_t slots, size_t D, size_
   Tensor2<float> t_tab(table, vocab * D * 4);
   o.update(batch, slots, D, vocab, nnz, t_ro, t_vi, t_wg, t_tab, /*sm_count=*/8, nullptr);
 }
+// filter_keys_per_gpu: the reference's kernels between the library calls its host code makes
+// (cudaMemset of the flags, the kernel, DeviceSelect, InclusiveSum), in its order
+template <typename K>
+size_t run_filter(int distributed, size_t batch, size_t slots, size_t gid, size_t gnum, const K* ro,
+                  const K* keys, size_t nnz, K* ro_out, K* keys_out) {
+  std::vector<char> tmp(64);
+  size_t tb = tmp.size(), picked = 0;
+  const size_t num = batch * slots;
+  if (!distributed) {
+    const size_t spg = slots / gnum + (gid < slots % gnum ? 1 : 0);
+    std::vector<char> flag(nnz + 1, 0);
+    std::vector<K> sel(batch * spg + 1, 0);
+    REFEMU_LAUNCH((localized_filter_keys_kernel::select_value_and_rowoffset_by_slot_id_kernel),
+                  ((num - 1) / 256 + 1, 256), ro, num, flag.data(), sel.data(), spg, slots, gid,
+                  gnum);
+    cub::DeviceSelect::Flagged(tmp.data(), tb, keys, flag.data(), keys_out, &picked, nnz);
+    cub::DeviceScan::InclusiveSum(tmp.data(), tb, sel.data(), ro_out, batch * spg + 1);
+  } else {
+    distributed_embedding_kernels::HashOp<K> op{gid, gnum};
+    cub::DeviceSelect::If(tmp.data(), tb, keys, keys_out, &picked, nnz, op);
+    std::vector<K> sel(num + 1, 0);
+    REFEMU_LAUNCH((distributed_embedding_kernels::select_rowoffset), ((num - 1) / 512 + 1, 512), ro,
+                  num, keys, sel.data(), gid, gnum);
+    cub::DeviceScan::InclusiveSum(tmp.data(), tb, sel.data(), ro_out, num + 1);
+  }
+  return picked;
+}
 }  // namespace
 }  // namespace HugeCTR
 
@@ -182,6 +217,31 @@ void refgpu_reorder(int fp16, int backward, size_t bpg, size_t slots, size_t D, 
     if (fp16) do_backward_reorder(bpg, slots, D, gpus, (const __half*)in, (__half*)out, (cudaStream_t) nullptr);
     else do_backward_reorder(bpg, slots, D, gpus, (const float*)in, (float*)out, (cudaStream_t) nullptr);
   }
+}
+
+// keys of the full-batch CSR that GPU `gid` of `gnum` resolves: localized = its slots (slot % gnum ==
+// gid), distributed = its keys (key % gnum == gid); returns the key count
+size_t refgpu_filter_keys(int key_bytes, int distributed, size_t batch, size_t slots, size_t gid,
+                          size_t gnum, const void* ro, const void* keys, size_t nnz, void* ro_out,
+                          void* keys_out) {
+  if (key_bytes == 8)
+    return run_filter(distributed, batch, slots, gid, gnum, (const long long*)ro,
+                      (const long long*)keys, nnz, (long long*)ro_out, (long long*)keys_out);
+  return run_filter(distributed, batch, slots, gid, gnum, (const unsigned*)ro,
+                    (const unsigned*)keys, nnz, (unsigned*)ro_out, (unsigned*)keys_out);
+}
+
+// slot id of every row met by this batch (the localized embedding's dump needs it)
+void refgpu_store_slot_id(int key_bytes, size_t batch, int slots, int slots_per_gpu, int gnum,
+                          int gid, const void* ro, const size_t* vi, size_t* slot_id) {
+  const size_t n = batch * (size_t)slots_per_gpu;
+  if (n == 0) return;
+  if (key_bytes == 8)
+    REFEMU_LAUNCH((store_slot_id_kernel), ((n - 1) / 64 + 1, 64), batch, slots, slots_per_gpu, gnum,
+                  gid, (const long long*)ro, vi, slot_id);
+  else
+    REFEMU_LAUNCH((store_slot_id_kernel), ((n - 1) / 64 + 1, 64), batch, slots, slots_per_gpu, gnum,
+                  gid, (const unsigned*)ro, vi, slot_id);
 }
 
 // one EmbeddingOptimizer::update; optimizer / update_type = the reference's enum values

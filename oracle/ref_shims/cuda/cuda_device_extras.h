@@ -87,6 +87,35 @@ struct DeviceRadixSort {
     return cudaSuccess;
   }
 };
+// cub::DeviceSelect::Flagged / If: the flagged (or accepted) items in their input order, their count
+struct DeviceSelect {
+  template <typename T, typename F, typename C, typename N>
+  static cudaError_t Flagged(void* temp, size_t& temp_bytes, const T* in, const F* flags, T* out,
+                             C* num_selected, N n, cudaStream_t = nullptr) {
+    if (temp == nullptr) {
+      temp_bytes = 16;
+      return cudaSuccess;
+    }
+    size_t m = 0;
+    for (size_t i = 0; i < (size_t)n; i++)
+      if (flags[i]) out[m++] = in[i];
+    *num_selected = (C)m;
+    return cudaSuccess;
+  }
+  template <typename T, typename C, typename N, typename Op>
+  static cudaError_t If(void* temp, size_t& temp_bytes, const T* in, T* out, C* num_selected, N n,
+                        Op op, cudaStream_t = nullptr) {
+    if (temp == nullptr) {
+      temp_bytes = 16;
+      return cudaSuccess;
+    }
+    size_t m = 0;
+    for (size_t i = 0; i < (size_t)n; i++)
+      if (op(in[i])) out[m++] = in[i];
+    *num_selected = (C)m;
+    return cudaSuccess;
+  }
+};
 struct DeviceScan {
   template <typename T, typename N>
   static cudaError_t InclusiveSum(void* temp, size_t& temp_bytes, const T* in, T* out, N n,

@@ -320,3 +320,82 @@ def test_reorder_maps_equal_the_reference_reorder_kernels(oracle, ref, elib, bpg
     assert np.array_equal(scat.reshape(-1), bwd)
     assert torch.equal(torch.sort(torch.from_numpy(rows.astype(np.int64)))[0],
                        torch.arange(bpg * S))
+
+
+def _ref_filter(ref, kb, distributed, B, S, gid, gnum, ro, keys):
+    L = ref.L
+    L.refgpu_filter_keys.restype = ctypes.c_size_t
+    L.refgpu_filter_keys.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_size_t] * 4 + \
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    kdt = np.int64 if kb == 8 else np.uint32
+    r, k = np.ascontiguousarray(ro, kdt), np.ascontiguousarray(keys, kdt)
+    spg = S if distributed else S // gnum + (1 if gid < S % gnum else 0)
+    ro_out = np.full(B * spg + 1, 77, kdt)
+    k_out = np.zeros(max(k.size, 1), kdt)
+    n = L.refgpu_filter_keys(kb, distributed, B, S, gid, gnum, _p(r), _p(k), k.size, _p(ro_out),
+                             _p(k_out))
+    return ro_out.astype(np.int64), k_out[:n].astype(np.int64)
+
+
+@pytest.mark.parametrize("kb", [8, 4])
+@pytest.mark.parametrize("B,S,hot,gnum", [(6, 26, 3, 8), (5, 7, 4, 3), (4, 3, 5, 4), (7, 5, 2, 1)])
+def test_oracle_key_filters_equal_the_reference_kernels(oracle, ref, B, S, hot, gnum, kb):
+    """filter_keys_per_gpu of both legacy embeddings: the reference's kernels between the library
+    calls its host code makes (localized: slots with slot % N == rank, more GPUs than slots
+    included; distributed: keys with key % N == rank)"""
+    rng = np.random.default_rng(B * S + gnum)
+    ro, keys = make_csr(rng, B, S, hot, 50)
+    for gid in range(gnum):
+        want_ro, want_k = oracle.localized_filter(ro, keys, B, S, gid, gnum)
+        got_ro, got_k = _ref_filter(ref, kb, 0, B, S, gid, gnum, ro, keys)
+        assert np.array_equal(got_ro, want_ro) and np.array_equal(got_k, want_k), ("localized", gid)
+        want_ro, want_k = oracle.distributed_filter(ro, keys, B, S, gid, gnum)
+        got_ro, got_k = _ref_filter(ref, kb, 1, B, S, gid, gnum, ro, keys)
+        assert np.array_equal(got_ro, want_ro) and np.array_equal(got_k, want_k), ("distributed", gid)
+
+
+@pytest.mark.parametrize("etype,world", [("localized", 4), ("localized", 3), ("distributed", 4)])
+def test_hip_rank_shard_equals_the_reference_kernel_chain(ref, elib, etype, world):
+    """one rank of N through hctr_emb_forward (HIP source: filter + index + pool) against the
+    reference's device code chained the same way: its filter kernels, its forward kernel on the
+    rows the HIP index stage handed out, its store_slot_id kernel against the slot ids the HIP
+    embedding dumps"""
+    from hugectr_amd import _lib
+    L = ref.L
+    L.refgpu_store_slot_id.argtypes = [ctypes.c_int, ctypes.c_size_t] + [ctypes.c_int] * 4 + \
+        [ctypes.c_void_p] * 3
+    rng = np.random.default_rng(world + len(etype))
+    B, S, hot, vps, D = 4 * world, 7, 3, 40, 8
+    V = S * vps + 8
+    dist = etype == "distributed"
+    for rank in range(world):
+        emb = emu.Embedding(elib, _lib.EMB_DISTRIBUTED if dist else _lib.EMB_LOCALIZED, B, V, D,
+                            S * hot, S, 0, dict(lr=0.1, scaler=1.0, optimizer=6), rank=rank,
+                            world=world)
+        table = emb.table().copy()
+        ro, keys = make_csr(rng, B, S, hot, vps)
+        out = emb.forward(True, ro, keys)
+        fro, fkeys = _ref_filter(ref, 8, 1 if dist else 0, B, S, rank, world, ro, keys)
+        spr = S if dist else emb.slots_on_rank
+        assert out.shape == (B, spr, D)
+        if fkeys.size == 0:
+            assert not out.any()
+            continue
+        vi = emb.value_index(fkeys.size).copy()
+        want = ref.forward(8, 0, 0, B, spr, D, fro, vi, table)
+        assert np.array_equal(out.reshape(-1, D).view(np.uint32), want.view(np.uint32)), rank
+        if not dist:  # slot ids (localized only: the dump carries them)
+            slot_ref = np.full(V, 999, np.uint64)
+            fr = np.ascontiguousarray(fro, np.int64)
+            L.refgpu_store_slot_id(8, B, S, spr, world, rank, _p(fr), _p(vi), _p(slot_ref))
+            n = int(vi.max()) + 1
+            dk = np.zeros(V, np.int64)
+            ds = np.zeros(V, np.uint64)
+            dv = np.zeros((V, D), np.float32)
+            cnt = ctypes.c_size_t()
+            emu.check(elib, elib.hctr_emb_dump(emb.h, _p(dk), _p(ds), _p(dv), ctypes.byref(cnt),
+                                               None))
+            assert cnt.value == n
+            row_of = dict(zip(fkeys.tolist(), vi.tolist()))
+            for k, s in zip(dk[:n].tolist(), ds[:n].tolist()):
+                assert slot_ref[row_of[k]] == s, (rank, k)
