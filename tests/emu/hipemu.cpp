@@ -40,6 +40,7 @@ struct Worker {
 thread_local Worker* tl_worker = nullptr;
 
 std::atomic<uint64_t> g_launches{0}, g_blocks{0}, g_divergent{0}, g_inactive{0};
+std::atomic<int> g_launch_error{0};
 int g_wave = 64;            // lanes of a wavefront (set_wave_width)
 size_t g_worker_cap = 0;    // OS threads of a launch (set_max_workers; 0 = the default policy)
 
@@ -249,6 +250,8 @@ void spin_pause() {
 
 void* dyn_shared() { return tl_worker->dyn; }
 
+bool take_launch_error() { return g_launch_error.exchange(0) != 0; }
+
 void set_wave_width(int lanes) {
   if (lanes != 64 && lanes != 32) die("set_wave_width: 32 or 64 lanes", nullptr);
   g_wave = lanes;
@@ -258,7 +261,10 @@ void set_max_workers(size_t n) { g_worker_cap = n; }
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
   const size_t nthreads = (size_t)block.x * block.y * block.z;
-  if (nblocks == 0 || nthreads == 0) return;
+  if (nblocks == 0 || nthreads == 0 || nthreads > 1024) {
+    g_launch_error.store(1);  // hipErrorInvalidConfiguration on the device: nothing runs
+    return;
+  }
   g_launches.fetch_add(1, std::memory_order_relaxed);
   g_blocks.fetch_add(nblocks, std::memory_order_relaxed);
   static const size_t max_workers = env_size("HIPEMU_MAX_WORKERS", 128);

@@ -52,6 +52,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 // e.g. the reference's CUDA sources behind oracle/_ref/libref_cache.so) and a cap on the OS threads
 // of a launch (0 = one per workgroup while the grid is small; 1 = workgroups strictly one after the
 // other in block order, which makes lock-protected code deterministic)
+// a launch the device would refuse (a grid or block dimension of zero, more than 1024 threads per
+// block: hipErrorInvalidConfiguration) runs nothing and is remembered; take_launch_error() hands
+// the flag to the next hipGetLastError() of the calling thread's process and clears it
+bool take_launch_error();
 void set_wave_width(int lanes);
 void set_max_workers(size_t n);
 void* dyn_shared();

@@ -70,9 +70,13 @@ constexpr unsigned hipHostMallocMapped = 2, hipHostMallocPortable = 1;
 constexpr unsigned hipHostMallocDefault = 0, hipEventDisableTiming = 2, hipEventDefault = 0;
 
 static inline const char* hipGetErrorString(hipError_t e) {
-  return e == hipSuccess ? "no error" : "error (host interpreter)";
+  return e == hipSuccess ? "no error"
+                         : "error (host interpreter; after a launch: invalid configuration, e.g. a "
+                           "zero-sized grid)";
 }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetLastError() {
+  return hipemu::take_launch_error() ? hipErrorInvalidValue : hipSuccess;
+}
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 template <typename T>
 static inline hipError_t hipMalloc(T** p, size_t bytes) {
