@@ -100,7 +100,11 @@ struct OptParams {
 /* IEEE binary16 with round-to-nearest-even conversions (what __float2half / __half2float do) */
 struct __half {  // with the implicit float conversions cuda_fp16.h gives host code
   unsigned short bits;
+#ifdef REFSHIM_TRIVIAL_HALF  // (a member of unions in the reference's device code, as cuda_fp16's is)
+  __half() = default;
+#else
   __half() : bits(0) {}
+#endif
   __half(float v) : bits(_cvtss_sh(v, _MM_FROUND_TO_NEAREST_INT)) {}
   __half(int v) : bits(_cvtss_sh((float)v, _MM_FROUND_TO_NEAREST_INT)) {}
   operator float() const { return _cvtsh_ss(bits); }

@@ -47,6 +47,29 @@ static inline __half2 __hadd2(__half2 a, __half2 b) {
   return r;
 }
 
+static inline unsigned short __half_as_ushort(__half h) { return h.bits; }
+static inline __half __ushort_as_half(unsigned short u) {
+  __half h;
+  h.bits = u;
+  return h;
+}
+struct alignas(16) float4 {
+  float x, y, z, w;
+};
+// __shfl_sync on a 32-lane warp (the interpreter runs such code with set_wave_width(32)); the call
+// site is the caller's source line
+template <typename T>
+static inline T __shfl_sync(unsigned, T v, int src, int width = 32, int site = __builtin_LINE()) {
+  uint64_t b = 0;
+  static_assert(sizeof(T) <= 8, "shuffles move at most 64 bits");
+  memcpy(&b, &v, sizeof(T));
+  b = hipemu::collective(hipemu::OP_SHFL, b, src, width, site);
+  T r;
+  memcpy(&r, &b, sizeof(T));
+  return r;
+}
+#define warpSize 32
+
 // CUDA's global min / max take mixed integer types (max(1, uint32_t), min(size_t, size_t) ...)
 template <typename A, typename B>
 static inline typename std::common_type<A, B>::type max(A a, B b) {
