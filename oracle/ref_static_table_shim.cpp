@@ -3,7 +3,8 @@
 // (R/HugeCTR/embedding_storage/ragged_static_embedding.cu:29-355: the lookup kernel, the key -> row
 // functor, the SGD / AdaGrad / Ftrl optimizer functors and update_kernel / update4_kernel), with the
 // 4-wide vector type those functors load and store through (R/HugeCTR/embedding/operators/
-// generic_lookup.cuh:29-291) and the binary search of R/HugeCTR/embedding/view.hpp:25-39, cut out
+// generic_lookup.cuh:29-291), the binary search of R/HugeCTR/embedding/view.hpp:25-39 and
+// keys_to_indices_kernel (R/HugeCTR/embedding/operators/keys_to_indices.cu:23-43), cut out
 // of the checkout into _ref/gen/ by oracle/Makefile and executed by the host interpreter of
 // tests/emu (32-lane warps: the update kernels hand a key's row from lane to lane with
 // __shfl_sync).  The launch lines below follow RaggedStaticEmbeddingTable::lookup / update
@@ -33,6 +34,7 @@ namespace embedding {
 #include "_ref/gen/static_view_bsearch.inc"
 #include "_ref/gen/static_vec4.inc"
 #include "_ref/gen/static_table_kernels.inc"
+#include "_ref/gen/static_keys_to_indices.inc"
 
 namespace {
 template <typename Opt>
@@ -76,6 +78,20 @@ void refstatic_update(int optimizer, size_t num_keys, const long long* keys, con
     run_update(vec4, keys, &num_keys, key_table, wgrad, wgrad_start, f, emb_table,
                FtrlOptimizer<float, float>{state1, state0, beta, lambda1, lambda2}, lr, scaler);
   }
+  hipemu::set_wave_width(64);
+}
+
+// KeysToIndicesConverter::convert: keys of `num_lookups` lookups back to back (lookup_offset), in
+// place: index = first row of the lookup's table on this GPU + key / num_shards[table]
+void refstatic_keys_to_indices(long long* keys, size_t num_keys, const uint64_t* lookup_offset,
+                               int num_lookups, const int* table_of_lookup, const int* local_tables,
+                               int num_local_tables, const uint64_t* table_row_offset,
+                               const int* num_shards) {
+  hipemu::set_wave_width(32);
+  if (num_keys == 0) return;
+  REFEMU_LAUNCH((keys_to_indices_kernel), ((num_keys - 1) / 256 + 1, 256), keys, num_keys,
+                lookup_offset, num_lookups, table_of_lookup, local_tables, num_local_tables,
+                table_row_offset, num_shards);
   hipemu::set_wave_width(64);
 }
 

@@ -138,3 +138,44 @@ def test_static_lookup_addresses_equal_the_reference_kernel():
     start = np.concatenate([[0], np.cumsum(rows)])[:-1]
     want = np.concatenate([base + (start[t] + per[t]) * ev * 4 for t in range(len(rows))])
     assert np.array_equal(got, want.astype(np.uint64))
+
+
+def test_keys_to_indices_equals_the_reference_kernel(oracle):
+    """keys_to_indices_kernel (keys_to_indices.cu:23-43) over several lookups that share tables,
+    row-sharded tables included (index = table's first local row + key / num_shards): the oracle's
+    map and hctr_ebc_keys_to_indices (HIP source), lookup by lookup"""
+    from hugectr_amd import _lib
+    L = ctypes.CDLL(LIB)
+    L.refstatic_keys_to_indices.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int] + [ctypes.c_void_p] * 2
+    rng = np.random.default_rng(5)
+    local_tables = np.array([0, 2, 3, 6], np.int32)            # the tables this GPU holds
+    rows = np.array([100, 40, 900, 7], np.uint64)
+    row_off = np.concatenate([[0], np.cumsum(rows)]).astype(np.uint64)
+    num_shards = np.array([1, 1, 2, 4, 1, 1, 1], np.int32)     # by table id
+    table_of_lookup = np.array([0, 2, 2, 3, 6, 0], np.int32)
+    counts = [17, 0, 33, 64, 5, 300]
+    per = [rng.integers(0, 2**31, size=c).astype(np.int64) for c in counts]
+    keys = np.concatenate(per)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    got = keys.copy()
+    L.refstatic_keys_to_indices(_p(got), got.size, _p(off), len(counts), _p(table_of_lookup),
+                                _p(local_tables), len(local_tables), _p(row_off), _p(num_shards))
+    lib = None
+    if emu.available():
+        lib = emu.load()
+        emu.bind(lib)
+    for l, k in enumerate(per):
+        t = int(table_of_lookup[l])
+        start = int(row_off[list(local_tables).index(t)])
+        ns = int(num_shards[t])
+        want = np.empty(k.size, np.int64)
+        oracle.lib().hco_keys_to_indices(k.size, oracle._p(k), start, ns, oracle._p(want))
+        seg = got[int(off[l]):int(off[l + 1])]
+        assert np.array_equal(seg, want), ("oracle", l)
+        if lib is not None and k.size:
+            out = np.zeros(k.size, np.uint64)
+            emu.check(lib, lib.hctr_ebc_keys_to_indices(_p(k), _lib.KEY_I64, k.size, start, ns,
+                                                        _p(out), None))
+            assert np.array_equal(out.astype(np.int64), seg), ("hip", l)
