@@ -41,6 +41,15 @@ def load(csrc=None, tag=None):
     return _libs[key]
 
 
+def load_under_test():
+    """the product's kernel source, or -- HCTR_EMU_VARIANT=<dir> -- the variant laid over it (a
+    kernel variant goes through the same tests before it replaces anything)"""
+    var = os.environ.get("HCTR_EMU_VARIANT")
+    lib = load(var, os.path.basename(os.path.normpath(var))) if var else load()
+    bind(lib)
+    return lib
+
+
 def ptr(a):
     return ctypes.c_void_p(a.ctypes.data) if a is not None else None
 

@@ -123,8 +123,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cases", type=int, default=100)
     a = ap.parse_args()
-    lib = emu.load()
-    emu.bind(lib)
+    lib = emu.load_under_test()
     ref = T.RefGpu()
     bad = 0
     for i in range(a.cases):

@@ -197,9 +197,7 @@ def test_oracle_update_equals_the_reference_optimizer(oracle, ref, name, kw, ns,
 def elib():
     if not emu.available():
         pytest.skip("no host clang++ / make")
-    lib = emu.load()
-    emu.bind(lib)
-    return lib
+    return emu.load_under_test()
 
 
 HIP_OPTS = [

@@ -129,8 +129,7 @@ def test_hip_index_stage_source_equals_the_reference_gpu_table(kb, capacity, cal
     if not emu.available():
         pytest.skip("no host clang++ / make")
     from hugectr_amd import _lib
-    lib = emu.load()
-    emu.bind(lib)
+    lib = emu.load_under_test()
     rng = np.random.default_rng(seed * 10 + kb)
     ref = RefTable(capacity, kb)
     hip = emu.HashTable(lib, capacity, _lib.KEY_I64 if kb == 8 else _lib.KEY_U32)

@@ -88,8 +88,7 @@ def test_static_table_optimizers_equal_the_reference_device_code(oracle, opt, na
     r0, r1, o0, o1, h0, h1 = mk(), mk(), mk(), mk(), mk(), mk()
     lib = None
     if emu.available():
-        lib = emu.load()
-        emu.bind(lib)
+        lib = emu.load_under_test()
         upd = ctypes.c_void_p()
         emu.check(lib, lib.hctr_updater_create(T * B, total, ev, ctypes.byref(upd)))
         emu.check(lib, lib.hctr_updater_set_ftrl(upd, FTRL[0], FTRL[1], FTRL[2]))
@@ -164,8 +163,7 @@ def test_keys_to_indices_equals_the_reference_kernel(oracle):
                                 _p(local_tables), len(local_tables), _p(row_off), _p(num_shards))
     lib = None
     if emu.available():
-        lib = emu.load()
-        emu.bind(lib)
+        lib = emu.load_under_test()
     for l, k in enumerate(per):
         t = int(table_of_lookup[l])
         start = int(row_off[list(local_tables).index(t)])

@@ -14,7 +14,8 @@ FILES="tests/test_hash_gpu.py tests/test_embedding_gpu.py tests/test_golden_gpu.
 case "$1" in
 check)
   D=$(realpath "$2"); N=$(basename "$D")
-  HCTR_EMU_VARIANT=$D python -m pytest tests/test_emu_cpu.py -x -q
+  HCTR_EMU_VARIANT=$D python -m pytest tests/test_emu_cpu.py tests/test_ref_gpu_kernels_cpu.py tests/test_ref_hashtable_cpu.py tests/test_ref_static_table_cpu.py -x -q
+  HCTR_EMU_VARIANT=$D python tests/emu/fuzz_ref_kernels.py --seed 7 --cases 150
   HCTR_EMU=1 HCTR_EMU_VARIANT=$D python -m pytest $FILES -x -q -m gpu -n 4 --timeout 900 -p no:cacheprovider
   make -C hugectr_amd/csrc -j 8 VARIANT=$D TAG=$N > /tmp/variant_build.log 2>&1 || { tail -30 /tmp/variant_build.log; exit 1; }
   echo "built hugectr_amd/libhugectr_amd_$N.so; next: gpurun --timeout 900 -- 'bash tools/variant.sh gpu $N'"
