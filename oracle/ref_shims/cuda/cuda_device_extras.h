@@ -47,6 +47,19 @@ static inline __half2 __hadd2(__half2 a, __half2 b) {
   return r;
 }
 
+#ifdef REFSHIM_HALF_ARITH
+// binary16 arithmetic of device code (cuda_fp16.hpp: operators on two __half values round once to
+// binary16; a sum / product of two binary16 values is exact in binary32)
+static inline __half operator+(const __half& a, const __half& b) {
+  return __float2half(__half2float(a) + __half2float(b));
+}
+static inline __half operator-(const __half& a, const __half& b) {
+  return __float2half(__half2float(a) - __half2float(b));
+}
+static inline __half operator*(const __half& a, const __half& b) {
+  return __float2half(__half2float(a) * __half2float(b));
+}
+#endif
 static inline unsigned short __half_as_ushort(__half h) { return h.bits; }
 static inline __half __ushort_as_half(unsigned short u) {
   __half h;

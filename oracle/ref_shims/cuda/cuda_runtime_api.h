@@ -172,12 +172,17 @@ static inline int atomicCAS(int* p, int cmp, int v) {
 // kernel<<<grid, block, shmem, stream>>>(args) is rewritten by oracle/ref_launch_rewrite.py (the
 // only edit made to the reference's text, into oracle/_ref/gen/) to this macro
 namespace refemu {
+static inline dim3 to_dim3(dim3 d) { return d; }
+template <typename T>
+static inline dim3 to_dim3(T v) {
+  return dim3((unsigned)v);
+}
 struct Cfg {
   dim3 g, b;
   size_t shmem;
   template <typename G, typename B>
   Cfg(G g_, B b_, size_t s_ = 0, cudaStream_t = nullptr)
-      : g((unsigned)g_), b((unsigned)b_), shmem(s_) {}
+      : g(to_dim3(g_)), b(to_dim3(b_)), shmem(s_) {}
 };
 }  // namespace refemu
 #define REFEMU_LAUNCH(kernel, cfg, ...)                       \
