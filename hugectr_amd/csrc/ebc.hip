@@ -238,6 +238,9 @@ __global__ void __launch_bounds__(kBlock)
                        const T* __restrict__ in, T* __restrict__ out) {
   // FWD: out[l][b][:] = (sum_s recv[block(l,s)][b][:]) / count   (count only for Average)
   // BWD: send[block(l,s)][b][:] = grad[l][b][:] / count            for every shard s of l
+  // A DIVISION by the count, as the reference's kernels (accum /= average_pooling_factor,
+  // generic_lookup.cuh:336-341, 733-738) and its CPU code (v /= (end - start)) do it: a product
+  // with the reciprocal differs in the last bit for most counts
   const size_t total = (size_t)num_lookup * bpg * ev;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < total;
        i += (size_t)gridDim.x * kBlock) {
@@ -245,10 +248,10 @@ __global__ void __launch_bounds__(kBlock)
     const size_t lb = i / ev;
     const size_t b = lb % bpg;
     const int l = (int)(lb / bpg);
-    float scale = 1.0f;
+    float div = 1.0f;
     if (combiner[l] == 1) {
       const long long c = bucket_counts[(size_t)l * bpg + b];
-      if (c > 0) scale = 1.0f / (float)c;
+      if (c > 0) div = (float)c;
     }
     const size_t dense_idx = batch_major ? (b * (size_t)num_lookup + l) * ev + e
                                          : ((size_t)l * bpg + b) * ev + e;
@@ -258,9 +261,9 @@ __global__ void __launch_bounds__(kBlock)
         const int blk = src_blocks[l * max_shards + s];
         if (blk >= 0) acc += ld_as_f32<T>(in + ((size_t)blk * bpg + b) * ev + e);
       }
-      st_from_f32<T>(out + dense_idx, acc * scale);
+      st_from_f32<T>(out + dense_idx, acc / div);
     } else {
-      const float g = ld_as_f32<T>(in + dense_idx) * scale;
+      const float g = ld_as_f32<T>(in + dense_idx) / div;
       for (int s = 0; s < max_shards; s++) {
         const int blk = src_blocks[l * max_shards + s];
         if (blk >= 0) st_from_f32<T>(out + ((size_t)blk * bpg + b) * ev + e, g);
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(kBlock)
 
 // One GPU, Average lookups: network_forward's receiver arithmetic applied IN PLACE to the pooled
 // sums the gather stored straight into the output (and network_backward's to the output's gradient):
-// the sum already rounded to the vector type, times 1 / (keys of the bucket), rounded again
+// the sum already rounded to the vector type, divided by the keys of the bucket, rounded again
 // (R/HugeCTR/embedding/operators/network_forward.cu:272-292, network_backward.cu).  Only the
 // vectors of Average lookups with more than one key are touched; the same bits as
 // ebc_network_vec_kernel leaves (which moves a vector of a single shard with scale 1 untouched).
@@ -290,11 +293,11 @@ __global__ void __launch_bounds__(kBlock)
     if (combiner[l] != 1) continue;
     const long long c = bucket_counts[(size_t)l * bpg + b];
     if (c <= 1) continue;  // scale 1: the vector moves as it is
-    const float scale = 1.0f / (float)c;
+    const float div = (float)c;
     T* p = data + (batch_major ? (b * (size_t)num_lookup + l) * ev + e
                                : ((size_t)l * bpg + b) * ev + e);
     const float v = ld_as_f32<T>(p);
-    st_from_f32<T>(p, FWD ? (0.f + v) * scale : v * scale);
+    st_from_f32<T>(p, FWD ? (0.f + v) / div : v / div);
   }
 }
 
@@ -319,10 +322,10 @@ __global__ void __launch_bounds__(kBlock)
     const uint32_t c = (uint32_t)(i - lb * (uint32_t)row16);
     const uint32_t l = (uint32_t)(lb / bpg);
     const size_t b = lb - (size_t)l * bpg;
-    float scale = 1.0f;
+    float div = 1.0f;
     if (combiner[l] == 1) {
       const long long cnt = bucket_counts[(size_t)l * bpg + b];
-      if (cnt > 0) scale = 1.0f / (float)cnt;
+      if (cnt > 0) div = (float)cnt;
     }
     const size_t dense_idx =
         (batch_major ? (b * (size_t)num_lookup + l) : ((size_t)l * bpg + b)) * row16 + c;
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(kBlock)
           n++;
         }
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (n == 1 && scale == 1.0f) {
+      if (n == 1 && div == 1.0f) {
         v = in[((size_t)first * bpg + b) * row16 + c];  // plain move
       } else if (n >= 1) {
         float acc[N];
@@ -350,15 +353,15 @@ __global__ void __launch_bounds__(kBlock)
         }
         T* vt = reinterpret_cast<T*>(&v);
 #pragma unroll
-        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, acc[k] * scale);
+        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, acc[k] / div);
       }
       out[dense_idx] = v;
     } else {
       uint4 v = in[dense_idx];
-      if (scale != 1.0f) {
+      if (div != 1.0f) {
         T* vt = reinterpret_cast<T*>(&v);
 #pragma unroll
-        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, ld_as_f32<T>(vt + k) * scale);
+        for (int k = 0; k < N; k++) st_from_f32<T>(vt + k, ld_as_f32<T>(vt + k) / div);
       }
       for (int s = 0; s < max_shards; s++)
         if (blocks[s] >= 0) out[((size_t)blocks[s] * bpg + b) * row16 + c] = v;

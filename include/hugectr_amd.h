@@ -308,7 +308,7 @@ int hctr_ebc_bucket_counts(size_t batch, int world, int rank, int num_lookup,
                            const void* bucket_range, int key_type, int64_t* counts,
                            hctr_stream_t stream);
 /* One GPU (nothing to exchange): the Average arithmetic of NetworkForward (forward != 0: the
- * pooled sum, already rounded to the vector type, times 1 / bucket key count, rounded again --
+ * pooled sum, already rounded to the vector type, divided by the bucket's key count, rounded again --
  * network_forward.cu:272-292) or of NetworkBackward (forward == 0) applied in place to the
  * [lookup][b][ev] / [b][lookup][ev] output (its gradient); vectors of Sum lookups and of buckets
  * with at most one key are not touched. */
