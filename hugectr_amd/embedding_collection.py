@@ -762,23 +762,32 @@ class DataParallelCollection:
         n = self.L * self.bpg
         # buckets are ordered [peer][lookup][b_local]: my own samples are the segment peer == rank
         self._seg = self.out_range[self.rank * n:(self.rank + 1) * n + 1]
-        pooled = torch.empty((n, self.ev), dtype=self.out_dtype, device=self.dev)
+        # Average divides the fp32 sum by the bucket's key count when > 0 and rounds ONCE to the
+        # output type (multi_to_one_*_kernel, generic_lookup.cuh:336-348): with a 16-bit output and
+        # an Average lookup the sums are pooled in fp32 (a Sum lookup's vector is the same either
+        # way: the rounded fp32 sum)
+        wide = bool(self.mean_ids) and self.out_dtype != torch.float32
+        pdt = torch.float32 if wide else self.out_dtype
+        pooled = torch.empty((n, self.ev), dtype=pdt, device=self.dev)
         check(lib.hctr_forward_pool(n, self.ev, 0, ptr(self._seg), _lib.KEY_I64, ptr(self.indices),
-                                    ptr(self.table), ptr(pooled), _DT[self.out_dtype], stream_ptr()))
+                                    ptr(self.table), ptr(pooled), _DT[pdt], stream_ptr()))
         pooled = pooled.view(self.L, self.bpg, self.ev)
         self._cnt = None
-        if self.mean_ids:  # Average divides by the bucket's key count when > 0 (generic_lookup.cuh:343-348)
+        if self.mean_ids:
             cnt = (self._seg[1:] - self._seg[:-1]).view(self.L, self.bpg).clamp(min=1)
             self._cnt = cnt[self.mean_ids].unsqueeze(-1).to(torch.float32)
-            pooled[self.mean_ids] = (pooled[self.mean_ids].float() / self._cnt).to(self.out_dtype)
-        return pooled.permute(1, 0, 2).contiguous()
+            pooled[self.mean_ids] = pooled[self.mean_ids].float() / self._cnt
+        return pooled.permute(1, 0, 2).contiguous().to(self.out_dtype)
 
     def backward_local(self, grad: torch.Tensor):
         """grad [batch/world, lookups, ev] -> (dense per-row gradient sums [rows, ev] fp32 of MY
         samples, touched-row flags [rows]) -- the operands of the all-reduce"""
         g = grad.permute(1, 0, 2).contiguous()
         if self.mean_ids:
-            g[self.mean_ids] = (g[self.mean_ids].float() / self._cnt).to(g.dtype)
+            # AverageCombiner (data_parallel_embedding.cpp:226-243): the divided gradient stays
+            # fp32 (float_emb_vec_) on its way into the local reduce -- it is not rounded back
+            g = g.float()
+            g[self.mean_ids] = g[self.mean_ids] / self._cnt
         n = self.L * self.bpg
         seg0 = int(self._seg[0])  # host sync: where my segment starts in the routed key list
         nnz = int(self._seg[-1]) - seg0

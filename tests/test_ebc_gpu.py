@@ -303,6 +303,44 @@ def test_data_parallel_tables(oracle, world, opt_name):
         assert_close(ranks[0].table.cpu().numpy(), dense, 1e-5, 1e-6, f"dp tables it{it}")
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_data_parallel_average_with_16_bit_vectors_rounds_once(dtype):
+    """replicated tables, Average lookups, 16-bit output: the fp32 sum is divided by the bucket's key
+    count and rounded ONCE (multi_to_one_*_kernel through DPForward...MultiToOneDesc,
+    model_forward.cu:29-66, generic_lookup.cuh:336-348), and the divided gradient stays fp32 on its
+    way into the local reduce (AverageCombiner, data_parallel_embedding.cpp:226-243) -- i.e. the
+    16-bit collection is the fp32 collection with its output rounded, and both take the same
+    step from the same 16-bit gradient"""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    from hugectr_amd.embedding_collection import DataParallelCollection
+    rng = np.random.default_rng(77)
+    B, ev = 24, 16
+    vocabs = [40, 9]
+    lookup_table = [0, 1, 0]
+    combiners = ["mean", "sum", "mean"]
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", v, ev) for i, v in enumerate(vocabs)]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l, t in enumerate(lookup_table):
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", combiners[l])
+    tdt = getattr(torch, dtype)
+    kw = dict(lr=0.1, optimizer=_lib.OPT_SGD, scaler=1.0, max_hotness=5, rank=0, world=1, seed=9)
+    wide = DataParallelCollection(cfg, B, out_dtype=torch.float32, **kw)
+    narrow = DataParallelCollection(cfg, B, out_dtype=tdt, **kw)
+    assert torch.equal(wide.table, narrow.table)
+    for it in range(2):
+        keys, br = _make_inputs(rng, B, vocabs, lookup_table, 5)
+        gk, gbr = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        a, b = wide.forward(gk, gbr), narrow.forward(gk, gbr)
+        assert b.dtype == tdt and torch.equal(a.to(tdt), b), f"forward it{it}"
+        g = torch.randn(b.shape, device="cuda").to(tdt)
+        for e, gg in ((wide, g.float()), (narrow, g)):
+            d, t = e.backward_local(gg)
+            e.apply_reduced(d, t)
+        assert torch.equal(wide.table, narrow.table), f"tables it{it}"
+
+
 def test_static_table_ilookup_returns_vector_addresses():
     """ILookup::lookup(keys, num_keys, num_keys_per_table_offset, num_table_offset, table_id_list,
     float** embedding_vec) on a static table shard (ragged_static_embedding.cu:33-51): tables of
