@@ -268,6 +268,8 @@ struct hctr_embedding {
   uint64_t cum_keys[kSeqRing] = {0};
   uint32_t* h_err = nullptr;  // pinned copy of the hash table's error flags (poll_overflow)
   uint32_t flip = 0;          // parity of the training batch's one-hot flag (tb.one_hot[2])
+  const uint32_t* cur_one_hot = nullptr;  // the flag word of the batch update_params will take
+                                          // (world == 1 only: the sort reads the rows in place)
   size_t last_exact_nnz = 0;     // world > 1: exact live nnz of the previous train batch
   // side-stream sort right after the index stage: on by default when world > 1 (it then runs
   // inside the all-to-all wait); on one GPU it would only share the chip with the dense tower --
@@ -445,6 +447,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     }
     return HCTR_OK;
   }
+  if (is_train) e->cur_one_hot = (fused_train && e->p.world == 1) ? one_hot : nullptr;
   if (bb.ro_full)
     HCTR_HIP(hipMemcpyAsync(bb.ro_full, ro_in, (batch * e->p.slot_num + 1) * sizeof(K),
                             hipMemcpyDeviceToDevice, s));
@@ -522,8 +525,12 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
       n_sort = e->last_exact_nnz ? e->last_exact_nnz + e->last_exact_nnz / 8 + 1024 : 0;
       if (n_sort > nnz) n_sort = nnz;
     }
-    if (n_sort > 0)
-      HCTR_TRY(e->upd.presort(buckets, n_sort, ro, e->p.key_type, bb.value_index, s));
+    if (n_sort > 0) {
+      e->upd.one_hot_flag = e->cur_one_hot;
+      const int prc = e->upd.presort(buckets, n_sort, ro, e->p.key_type, bb.value_index, s);
+      e->upd.one_hot_flag = nullptr;
+      HCTR_TRY(prc);
+    }
   }
   if (is_train) {
     e->cur_buckets = buckets;
@@ -641,6 +648,9 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   if ((rc = e->ht.create(V, p.key_type)) != HCTR_OK) return fail(rc);
   if ((rc = e->ht.reserve(e->nnz_max)) != HCTR_OK) return fail(rc);
   if ((rc = e->upd.create(e->nnz_max, V, (int)D)) != HCTR_OK) return fail(rc);
+  // sample-major batches: bucket b * S + s -- the positions with the same p % S come from one table
+  // (the sparse update's hot-row streams)
+  e->upd.hot_streams = (uint32_t)e->buckets_per_sample();
   e->presort_enabled = p.world > 1;
   if (const char* ps = getenv("HCTR_PRESORT")) e->presort_enabled = ps[0] != '0';
   e->upd.prof = &e->prof;
@@ -838,11 +848,13 @@ int hctr_emb_update_params(hctr_embedding* e, hctr_stream_t stream) {
   e->opt.times++;  // update_params(): adam.times++ before the update (…hash.hpp:346-347)
   if (e->seq > 0) refresh_row_bound(e);
   e->upd.scale_row_offset = e->tb.ro_full;  // NULL unless distributed + mean + N > 1
+  e->upd.one_hot_flag = e->cur_one_hot;
   const int rc = e->upd.update(e->cur_buckets, nnz, e->p.combiner, e->ro, e->p.key_type,
                                e->value_index, e->top_grad, e->p.out_dtype, e->opt, e->table,
                                e->state0, e->state1, e->prev_time, s);
   // key-typed, batch-sized: never left behind for update_rows (int64 offsets of another length)
   e->upd.scale_row_offset = nullptr;
+  e->upd.one_hot_flag = nullptr;
   return rc;
 }
 

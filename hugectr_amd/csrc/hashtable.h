@@ -63,7 +63,9 @@ struct HashTable {
   unsigned long long* fin_masks = nullptr;  // 2 x [mask_words] first-occurrence masks + prefixes
   size_t mask_words = 0;
   uint32_t* region_cnt = nullptr;   // [2048] first occurrences per region of positions (finish)
-  uint32_t* pend_list = nullptr;    // [max_n] positions of the batch whose key was not in the table
+  uint32_t* pend_list = nullptr;    // positions of the batch whose key was not in the table, one
+                                    // segment per workgroup of the probe kernel
+  uint32_t* block_cnt = nullptr;    // entries of every segment (behind the list)
   uint32_t* d_parity = nullptr;     // which mask buffer the next inserting batch takes
   uint64_t* d_scratch64 = nullptr;  // 1 element
 

@@ -1,3 +1,17 @@
+// (v2: see the finish kernel -- each finish workgroup owns the list segments of its share of the
+// probe workgroups, and keeps its first entries in registers between the two phases)
+// NOT BUILT, NOT THE PRODUCT PATH -- a variant of hugectr_amd/csrc/hashtable.hip measured at the end
+// of round 3 and kept for the next round (together with hashtable_segment_lists.h.txt):
+//   probe kernel: positions left pending go to a per-workgroup SEGMENT of the batch's list (LDS
+//   counter, wave-aggregated appends, counts published per workgroup) -- no global list counter;
+//   the finish kernel scans the segment counts into LDS and finds entry k by binary search.
+// Measured on MI355X (C3, 72 k unseen keys per step): probe 48 -> 36 us (steady 28.3 -> 26.7),
+// finish 36.5 -> 39.8 us.  Passed test_hash_gpu (incl. the many-batches stress test),
+// test_embedding_gpu, test_det_gpu, test_ebc_dynamic_gpu, test_golden_gpu in that form; NOT run:
+// the full `-m gpu` suite and batches of more than 4 M keys per call (several passes per
+// workgroup).  This file is the reconstruction of that state on top of the committed source
+// (compiles for gfx950); to try it: copy both files over csrc/hashtable.{hip,h}, make, run the
+// GPU tests.
 // hashtable.hip -- deterministic open-addressing hash map on gfx950.
 //
 // Semantics follow R/HugeCTR/src/hashtable/nv_hashtable.cu:169-303 +
@@ -58,13 +72,12 @@ __global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
 }
 
 // one key, the full protocol: probe (linear), claim an empty slot for an unseen key, hand back the
-// row or the pending marker (see the header of this file).  A position left pending is appended to
-// the workgroup's LDS list (the finish kernel works on the list of pending positions only).
+// row or the pending marker (see the header of this file).  Returns true when the position is left
+// pending (the caller appends it to the batch's list: the finish kernel works on that list only).
 template <typename K>
-__device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
+__device__ __forceinline__ bool ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
                                                     K key, size_t i, uint64_t* __restrict__ out,
-                                                    uint32_t* d_error, uint32_t* s_cnt,
-                                                    uint32_t* s_pos) {
+                                                    uint32_t* d_error) {
   const long long empty = KeyTraits<K>::empty;
   const long long k64 = widen<K>(key);
   uint64_t slot = (uint64_t)murmur3_key(key) % size;
@@ -89,20 +102,20 @@ __device__ __forceinline__ void ht_probe_insert_one(HtEntry* __restrict__ tab, u
   if (!ok) {
     atomicOr(d_error, 1u);
     out[i] = kInvalidIndex;
-    return;
+    return false;
   }
   if (!claimed) {  // (a slot this thread has just claimed holds no row yet: no read needed)
     const unsigned long long v = tab[slot].val;
     if (v < kPendingBit) {
       out[i] = row_of(v);
-      return;
+      return false;
     }
   }
   // no-return atomic: nothing waits for it
   (void)__hip_atomic_fetch_min(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   out[i] = kPendingBit | slot;
-  s_pos[atomicAdd(s_cnt, 1u)] = (uint32_t)i;
+  return true;
 }
 
 // Steady state = every key is in the table and sits in its home slot or close to it, so the
@@ -115,15 +128,22 @@ template <typename K>
 __global__ void __launch_bounds__(kBlock)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
-                           uint32_t* d_list_count, uint32_t* __restrict__ d_list,
-                           uint32_t list_cap, uint32_t* d_error, const K* __restrict__ ro_src,
-                           K* __restrict__ ro_dst, size_t n_offsets,
+                           uint32_t* d_pending, uint32_t* __restrict__ d_list,
+                           uint32_t* __restrict__ block_cnt, uint32_t seg_cap, uint32_t* d_error,
+                           const K* __restrict__ ro_src, K* __restrict__ ro_dst, size_t n_offsets,
                            uint32_t* __restrict__ one_hot) {
-  __shared__ uint32_t s_cnt, s_base;
-  __shared__ uint32_t s_pos[kBlock * kHtUnroll];
+  // Positions left pending go to THIS workgroup's segment of the batch's list, d_list[blockIdx *
+  // seg_cap ...), counted in LDS; the count is published once at the end.  No global counter: a
+  // single address takes ~10 ns per atomic whoever issues it (26 k wave-level appends to one
+  // counter were measured at 250 us).
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
   const size_t nl = live_count(d_n, n);
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   const size_t gtid = blockIdx.x * (size_t)kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t* const my_list = d_list + (size_t)blockIdx.x * seg_cap;
   if (ro_src != nullptr) {
     // the caller's private copy of the row offsets; lengths all 1 and ro[0] == 0  <=>
     // ro[i] == i for every i: otherwise the gather must not take its offset-free one-hot loop
@@ -133,20 +153,16 @@ __global__ void __launch_bounds__(kBlock)
       ro_dst[i] = v;
       bad |= v != (K)i;
     }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) *one_hot = 0u;
+    if (__ballot(bad) != 0ull && lane == 0) *one_hot = 0u;
   }
-  // (trip count uniform over the workgroup: it meets at barriers inside the loop)
-  for (size_t base = 0; base < nl; base += nthreads * kHtUnroll) {
-    const size_t i0 = base + gtid;
-    if (threadIdx.x == 0) s_cnt = 0u;
-    __syncthreads();
+  for (size_t i0 = gtid; i0 < nl; i0 += nthreads * kHtUnroll) {
     K key[kHtUnroll];
     uint64_t slot[kHtUnroll];
     ulonglong2 ent[kHtUnroll];
 #pragma unroll
     for (int u = 0; u < kHtUnroll; u++) {
       const size_t i = i0 + (size_t)u * nthreads;
-      key[u] = keys[i < nl ? i : 0];
+      key[u] = keys[i < nl ? i : i0];
       slot[u] = (uint64_t)murmur3_key(key[u]) % size;
     }
 #pragma unroll
@@ -155,25 +171,32 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int u = 0; u < kHtUnroll; u++) {
       const size_t i = i0 + (size_t)u * nthreads;
-      if (i >= nl) continue;
-      if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
-        out[i] = row_of(ent[u].y);
-      else  // (issuing the four keys' claims together was measured: no gain with 4 % unseen keys,
-            //  and the steady state lost 5 us to the extra registers)
-        ht_probe_insert_one<K>(tab, size, key[u], i, out, d_error, &s_cnt, s_pos);
+      bool pend = false;
+      if (i < nl) {
+        if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
+          out[i] = row_of(ent[u].y);
+        else  // (issuing the four keys' claims together was measured: no gain with 4 % unseen
+              //  keys, and the steady state lost 5 us to the extra registers)
+          pend = ht_probe_insert_one<K>(tab, size, key[u], i, out, d_error);
+      }
+      const unsigned long long m = __ballot(pend);
+      if (m != 0ull) {  // one LDS atomic per wavefront and unroll step that has any
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (pend) {
+          const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (k < seg_cap) my_list[k] = (uint32_t)i;  // (seg_cap = every key of this workgroup)
+        }
+      }
     }
-    __syncthreads();
-    const uint32_t cnt = s_cnt;
-    if (cnt != 0u) {  // this workgroup's pending positions -> the batch's list (one atomic)
-      if (threadIdx.x == 0) s_base = atomicAdd(d_list_count, cnt);
-      __syncthreads();
-      // (the count is reset by every finish kernel; should one have given up at its barrier,
-      //  the list must still never be written past its end)
-      for (uint32_t k = threadIdx.x; k < cnt; k += kBlock)
-        if (s_base + k < list_cap) d_list[s_base + k] = s_pos[k];
-      if (threadIdx.x == 0 && s_base + cnt > list_cap) atomicOr(d_error, 4u);
-    }
-    __syncthreads();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t c = s_cnt < seg_cap ? s_cnt : seg_cap;
+    block_cnt[blockIdx.x] = c;
+    if (c != 0u) *d_pending = 1u;  // (benign race: every writer stores 1)
   }
 }
 
@@ -236,13 +259,18 @@ __device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos
 // ---- get_insert, launch 2 ------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 constexpr int kFinRegions = 2048;  // (their bases live in LDS: 8 KB)
+constexpr int kProbeMaxBlocks = 4096;  // workgroups of the probe kernel (their list segments'
+                                       // first entries live in the finish kernel's LDS: 16 KB)
 constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises error bit 2^2)
 
 struct FinishCtl {
-  uint32_t *list_count, *latched, *error, *barrier;
+  uint32_t *pending, *latched, *error, *barrier;
   uint64_t *counter, *base, *new_count;
-  const uint32_t* list;         // positions whose key was not in the table (unordered)
-  uint32_t list_cap;
+  // positions whose key was not in the table: segment b of the list = [b * seg_cap, ... +
+  // block_cnt[b]), written by workgroup b of the probe kernel
+  const uint32_t* list;
+  const uint32_t* block_cnt;
+  uint32_t probe_blocks, seg_cap;
   uint32_t* region_cnt;         // 2 x [kFinRegions] first occurrences per region (as masks2)
   // two buffers of [mask_words] first-occurrence masks: buffer *parity is all zero on entry and
   // takes this batch's bits, the other one is zeroed here for the next batch that inserts
@@ -314,9 +342,7 @@ __global__ void __launch_bounds__(kFinBlock)
     ht_finish_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
                      const uint64_t* d_n, FinishCtl c, uint64_t* __restrict__ new_positions,
                      SlotIdSink sink, uint64_t capacity) {
-  uint32_t P = *c.list_count;  // (workgroup 0 resets it only behind the barrier)
-  if (P > c.list_cap) P = c.list_cap;
-  if (P == 0u) {  // steady state: no unseen key in this batch
+  if (*c.pending == 0u) {  // steady state: no unseen key in this batch
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const uint64_t cnt = *c.counter;
       *c.latched = 0u;
@@ -327,9 +353,41 @@ __global__ void __launch_bounds__(kFinBlock)
     return;
   }
   __shared__ uint32_t smem[kFinBlock / 64 + 1];
+  // v2: a finish workgroup takes the list segments of ITS share of the probe workgroups (a few
+  // tens of counts to scan instead of all of them, a search over those only, and no total of the
+  // whole list is needed); positions are spread evenly over the probe workgroups, so the unseen
+  // keys of a batch are spread over the finish workgroups as they are over the batch
+  __shared__ uint32_t seg_first[kProbeMaxBlocks + 1];
+  const uint32_t G = gridDim.x, b = blockIdx.x;
+  const uint32_t own = (c.probe_blocks + G - 1u) / G;
+  const uint32_t q0 = b * own < c.probe_blocks ? b * own : c.probe_blocks;
+  const uint32_t q1 = q0 + own < c.probe_blocks ? q0 + own : c.probe_blocks;
+  const uint32_t nq = q1 - q0;
+  {
+    uint32_t run = 0u;
+    for (uint32_t b0 = 0; b0 < nq; b0 += kFinBlock) {
+      const uint32_t pb = b0 + threadIdx.x;
+      const uint32_t v = pb < nq ? c.block_cnt[q0 + pb] : 0u;
+      uint32_t tot;
+      const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &tot);
+      if (pb < nq) seg_first[pb] = run + ex;
+      run += tot;
+    }
+    if (threadIdx.x == 0) seg_first[nq] = run;
+    __syncthreads();
+  }
+  const uint32_t P = seg_first[nq];  // entries of this workgroup
+  auto entry = [&](size_t k) -> uint64_t {
+    uint32_t lo = 0u, hi = nq;  // largest b with seg_first[b] <= k
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (seg_first[mid] <= (uint32_t)k) lo = mid;
+      else hi = mid;
+    }
+    return (uint64_t)c.list[(size_t)(q0 + lo) * c.seg_cap + ((uint32_t)k - seg_first[lo])];
+  };
   const uint64_t c0 = *c.counter;  // (workgroup 0 moves it only behind the barriers)
   const size_t nl = live_count(d_n, n);
-  const uint32_t G = gridDim.x, b = blockIdx.x;
   const size_t gtid = (size_t)b * kFinBlock + threadIdx.x, gthreads = (size_t)G * kFinBlock;
   const uint32_t par = *c.parity & 1u;  // (workgroup 0 flips it only behind the barriers)
   unsigned long long* const masks = c.masks2 + (size_t)par * c.mask_words;
@@ -346,8 +404,27 @@ __global__ void __launch_bounds__(kFinBlock)
   const uint32_t R = (uint32_t)((nl + per - 1) / per);
   // ---- A: the pending positions that hold the FIRST occurrence of their key set their bit and
   //         count themselves into their region --------------------------------------------------
-  for (size_t k = gtid; k < P; k += gthreads) {
-    const uint64_t i = c.list[k];
+  // (the first kKeep entries of a thread stay in registers for phase D: two dependent loads less)
+  constexpr int kKeep = 4;
+  uint64_t keep_i[kKeep], keep_slot[kKeep];
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
+    keep_i[j] = 0;
+    keep_slot[j] = 0;
+    if (k < P) {
+      const uint64_t i = entry(k);
+      const uint64_t slot = out[i] & ~kPendingBit;
+      keep_i[j] = i;
+      keep_slot[j] = slot;
+      if (tab[slot].val == (kPendingBit | i)) {
+        atomicOr(&masks[i >> 6], 1ull << (i & 63));
+        atomicAdd(&region_cnt[i / per], 1u);
+      }
+    }
+  }
+  for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
+    const uint64_t i = entry(k);
     const uint64_t slot = out[i] & ~kPendingBit;
     if (tab[slot].val == (kPendingBit | i)) {
       atomicOr(&masks[i >> 6], 1ull << (i & 63));
@@ -386,7 +463,7 @@ __global__ void __launch_bounds__(kFinBlock)
         *c.counter = head;
         if (c0 + total > capacity) atomicOr(c.error, 2u);
         *c.latched = 1u;
-        *c.list_count = 0u;
+        *c.pending = 0u;
         *c.parity = 1u - par;
         post_to_host(c, head);
       }
@@ -394,13 +471,11 @@ __global__ void __launch_bounds__(kFinBlock)
   }
   // ---- D: rows.  rank of a first position fp = firsts in the regions before its own + firsts of
   //         its own region in front of it (mask words, a few tens at most) -------------------------
-  for (size_t k = gtid; k < P; k += gthreads) {
-    const uint64_t i = c.list[k];
-    const uint64_t slot = out[i] & ~kPendingBit;
+  auto resolve = [&](uint64_t i, uint64_t slot) {
     const uint64_t v = tab[slot].val;
     if (v < kPendingBit) {  // the key's first occurrence has already published the row
       out[i] = row_of(v);
-      continue;
+      return;
     }
     const uint64_t fp = v & ~kPendingBit;
     const uint32_t r = (uint32_t)(fp / per);
@@ -424,6 +499,15 @@ __global__ void __launch_bounds__(kFinBlock)
       new_positions[rank] = i;
       if (sink.slot_id != nullptr && fin != kInvalidIndex) record_slot_id(sink, i, fin);
     }
+  };
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
+    if (k < P) resolve(keep_i[j], keep_slot[j]);
+  }
+  for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
+    const uint64_t i = entry(k);
+    resolve(i, out[i] & ~kPendingBit);
   }
 }
 
@@ -628,7 +712,13 @@ int HashTable::reserve(size_t n) {
   HCTR_HIP(hipMemset(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
   region_cnt = reinterpret_cast<uint32_t*>(fin_masks + 2 * mask_words);
   HCTR_HIP(hipMemset(d_parity, 0, sizeof(uint32_t)));
-  HCTR_HIP(hipMalloc(&pend_list, (n > 0 ? n : 1) * sizeof(uint32_t)));
+  {  // list segments: every probe workgroup's share of n, rounded up to whole passes
+    const size_t blocks = ceil_div<size_t>(n > 0 ? n : 1, (size_t)kBlock * kHtUnroll);
+    const size_t g = blocks < (size_t)kProbeMaxBlocks ? blocks : (size_t)kProbeMaxBlocks;
+    const size_t entries_ = (n > 0 ? n : 1) + (g + 1) * kBlock * kHtUnroll;
+    HCTR_HIP(hipMalloc(&pend_list, (entries_ + kProbeMaxBlocks) * sizeof(uint32_t)));
+    block_cnt = pend_list + entries_;
+  }
   max_n = n;
   return HCTR_OK;
 }
@@ -657,22 +747,30 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   }
   IndexExtras none;
   const IndexExtras& x = ex ? *ex : none;
+  HCTR_REQUIRE(n < 0xFFFFFFFFull, "get_insert: more than 2^32 - 1 keys in one call");
   const size_t work = n > x.n_offsets ? n : x.n_offsets;
-  const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, 1 << 16);
+  const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, kProbeMaxBlocks);
+  // every key a workgroup may leave pending has a place in its segment of the list
+  const size_t per_pass = (size_t)grid * kBlock * kHtUnroll;
+  const uint32_t seg_cap = (uint32_t)(ceil_div<size_t>(n, per_pass) * kBlock * kHtUnroll);
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, (uint32_t)max_n, d_error,
-                       (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst, x.n_offsets, x.one_hot);
+                       size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, block_cnt,
+                       seg_cap, d_error, (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst,
+                       x.n_offsets, x.one_hot);
   } else {
     hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
-                       size, (const long long*)keys, n, d_n, out, d_pending, pend_list, (uint32_t)max_n, d_error,
-                       (const long long*)x.ro_src, (long long*)x.ro_dst, x.n_offsets, x.one_hot);
+                       size, (const long long*)keys, n, d_n, out, d_pending, pend_list, block_cnt,
+                       seg_cap, d_error, (const long long*)x.ro_src, (long long*)x.ro_dst,
+                       x.n_offsets, x.one_hot);
   }
   HCTR_LAUNCH_CHECK();
   FinishCtl c;
-  c.list_count = d_pending;
+  c.pending = d_pending;
   c.list = pend_list;
-  c.list_cap = (uint32_t)max_n;
+  c.block_cnt = block_cnt;
+  c.probe_blocks = (uint32_t)grid;
+  c.seg_cap = seg_cap;
   c.latched = d_latched;
   c.error = d_error;
   c.barrier = d_barrier;
@@ -688,8 +786,7 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   c.host_seq = x.host_seq;
   c.seq = x.seq;
   c.host_error = x.host_error;
-  HCTR_REQUIRE(n < 0xFFFFFFFFull, "get_insert: more than 2^32 - 1 keys in one call");
-  // few positions: fewer workgroups (every one of them takes part in the barriers)
+  // few positions: fewer workgroups (every one of them takes part in the barrier)
   size_t fg = ceil_div<size_t>(n, (size_t)kFinBlock * 4);
   if (fg > (size_t)kHtFinishBlocks) fg = kHtFinishBlocks;
   if (fg < 1) fg = 1;

@@ -17,7 +17,15 @@
 // ballots; their rank is the running per-wavefront counter of that digit (LDS) plus the number of
 // lower lanes in the match mask.  Three launches of a few microseconds per digit instead of one
 // 46-us launch; keys of b bits take ceil(b / 10) digits.
+// The first digit pass can read its keys straight from the index stage's 64-bit rows and make up
+// the payload (position, or its gradient-map image) itself -- the sparse update's pair expansion
+// drops out for one-hot batches -- and can leave out the keys below a bound (RsFirst).  Measured
+// and dropped (round 4, MI355X, 1.7 M pairs): tiles of 2048 / 1024 keys and a 128- / 64-workgroup
+// column scan -- every combination slower than 4096-key tiles with a 32-workgroup scan (sort
+// 104 us -> 107 .. 137 us).
 #include "radix_sort.h"
+
+#include <cstdlib>
 
 #include "block_prims.h"
 
@@ -36,6 +44,29 @@ constexpr int kRsMaxBins = 1 << kRsMaxBits;
 constexpr int kRsScanBlock = 1024;                  // colscan: 32 tile chunks x 32 digit values
 constexpr int kRsScanBins = 32;
 
+// key / payload of position i in the first pass (see RsFirst)
+struct RsSrc {
+  const uint64_t* k64;
+  const uint32_t* flag;
+  uint32_t map_inner, map_outer;
+  // first pass of a one-hot batch: keys below skip_below are left out of the sort altogether (the
+  // sparse update's hot rows, summed by hot_chunk_kernel); the pass that filters posts the number
+  // of keys it kept to *n_kept, and the later passes take their length from *n_live
+  uint32_t skip_below;
+  uint32_t* n_kept;
+  const uint32_t* n_live;
+};
+__device__ __forceinline__ bool rs_first64(const RsSrc& f) {
+  return f.k64 != nullptr && *f.flag != 0u;
+}
+__device__ __forceinline__ size_t rs_len(const RsSrc& f, size_t n) {
+  return f.n_live != nullptr ? (size_t)*f.n_live : n;
+}
+__device__ __forceinline__ uint32_t rs_payload(const RsSrc& f, size_t i) {
+  const uint32_t u = (uint32_t)i;
+  return f.map_inner ? (u % f.map_inner) * f.map_outer + u / f.map_inner : u;
+}
+
 // lanes of this wavefront that hold the same digit as mine (valid lanes only): ten ballots
 template <int BITS>
 __device__ __forceinline__ unsigned long long rs_match(uint32_t d, bool valid) {
@@ -52,8 +83,12 @@ __device__ __forceinline__ unsigned long long rs_match(uint32_t d, bool valid) {
 template <int BITS>
 __global__ void __launch_bounds__(kRsBlock)
     rs_hist_kernel(const uint32_t* __restrict__ keys, size_t n, int shift,
-                   uint32_t* __restrict__ hist) {
+                   uint32_t* __restrict__ hist, RsSrc src) {
   constexpr int kRsBins = 1 << BITS;
+  n = rs_len(src, n);
+  if ((size_t)blockIdx.x * kRsTile >= n) return;  // (a tile past the live length: colscan skips it)
+  const bool f64 = rs_first64(src);
+  const uint32_t skip = f64 ? src.skip_below : 0u;
   __shared__ uint32_t h[kRsBins];
   for (int b = threadIdx.x; b < kRsBins; b += kRsBlock) h[b] = 0u;
   __syncthreads();
@@ -63,14 +98,14 @@ __global__ void __launch_bounds__(kRsBlock)
 #pragma unroll
   for (int r = 0; r < kRsRounds; r++) {
     const size_t i = base + (size_t)r * 64;
-    key[r] = i < n ? keys[i] : 0xFFFFFFFFu;
+    key[r] = i < n ? (f64 ? (uint32_t)src.k64[i] : keys[i]) : 0xFFFFFFFFu;
   }
   // Row ids of a power-law batch are small numbers: in the upper digits most lanes of a wavefront
   // hold the SAME value, and 64 LDS atomics on one address serialise.  The lanes that agree with
   // lane 0 are counted with one ballot and added once; the rest take the plain atomic.
 #pragma unroll
   for (int r = 0; r < kRsRounds; r++) {
-    const bool valid = base + (size_t)r * 64 < n;
+    const bool valid = base + (size_t)r * 64 < n && key[r] >= skip;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
     const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
     const unsigned long long same = __ballot(valid && d == d0);
@@ -86,8 +121,10 @@ __global__ void __launch_bounds__(kRsBlock)
 // hist[t][b] <- sum of hist[t'][b] over t' < t, for the 32 digit values of this workgroup
 template <int BITS>
 __global__ void __launch_bounds__(kRsScanBlock)
-    rs_colscan_kernel(uint32_t* __restrict__ hist, size_t tiles, uint32_t* __restrict__ total) {
+    rs_colscan_kernel(uint32_t* __restrict__ hist, size_t tiles, uint32_t* __restrict__ total,
+                      const uint32_t* __restrict__ n_live, uint32_t tile_keys) {
   constexpr int kRsBins = 1 << BITS;
+  if (n_live != nullptr) tiles = ((size_t)*n_live + tile_keys - 1) / tile_keys;
   constexpr int kChunks = kRsScanBlock / kRsScanBins;
   __shared__ uint32_t part[kChunks][kRsScanBins];
   const int c = threadIdx.x % kRsScanBins, q = threadIdx.x / kRsScanBins;
@@ -119,8 +156,12 @@ __global__ void __launch_bounds__(kRsBlock)
     rs_scatter_kernel(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                       uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, size_t n,
                       int shift, const uint32_t* __restrict__ tile_offs,
-                      const uint32_t* __restrict__ total) {
+                      const uint32_t* __restrict__ total, RsSrc src) {
   constexpr int kRsBins = 1 << BITS;
+  n = rs_len(src, n);
+  if ((size_t)blockIdx.x * kRsTile >= n) return;
+  const bool f64 = rs_first64(src);
+  const uint32_t skip = f64 ? src.skip_below : 0u;
   constexpr int kPerThread = kRsBins / kRsBlock;  // digit values per thread in the offset step
   // The tile is first sorted INSIDE LDS (stable, by this digit), then streamed out: consecutive
   // threads write consecutive sorted elements, and elements of one digit value are consecutive
@@ -145,19 +186,18 @@ __global__ void __launch_bounds__(kRsBlock)
   }
   const size_t tile_base = (size_t)blockIdx.x * kRsTile;
   const size_t base = tile_base + (size_t)wave * kRsWaveKeys + lane;
-  const int tile_n = (int)((n - tile_base) < (size_t)kRsTile ? (n - tile_base) : (size_t)kRsTile);
   uint32_t key[kRsRounds];
 #pragma unroll
   for (int r = 0; r < kRsRounds; r++) {
     const size_t i = base + (size_t)r * 64;
-    key[r] = i < n ? kin[i] : 0xFFFFFFFFu;
+    key[r] = i < n ? (f64 ? (uint32_t)src.k64[i] : kin[i]) : 0xFFFFFFFFu;
   }
   __syncthreads();
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t info[kRsRounds];  // rank inside the match group | group size << 8
 #pragma unroll
   for (int r = 0; r < kRsRounds; r++) {
-    const bool valid = base + (size_t)r * 64 < n;
+    const bool valid = base + (size_t)r * 64 < n && key[r] >= skip;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
     unsigned long long m = 0ull;
     if (MASK) {
@@ -194,9 +234,11 @@ __global__ void __launch_bounds__(kRsBlock)
     cs += c4[j];
     ts += t4[j];
   }
-  uint32_t all;
-  uint32_t lex = block_exclusive_scan<uint32_t, kRsBlock>(cs, scan_smem, &all);  // local
-  uint32_t gex = block_exclusive_scan<uint32_t, kRsBlock>(ts, scan_smem, &all);  // global
+  uint32_t all, tile_kept;  // keys of this tile that take part / of all tiles
+  uint32_t lex = block_exclusive_scan<uint32_t, kRsBlock>(cs, scan_smem, &tile_kept);  // local
+  uint32_t gex = block_exclusive_scan<uint32_t, kRsBlock>(ts, scan_smem, &all);        // global
+  if (src.n_kept != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *src.n_kept = all;
+  const int tile_n = (int)tile_kept;
 #pragma unroll
   for (int j = 0; j < kPerThread; j++) {
     const int b = threadIdx.x * kPerThread + j;
@@ -216,9 +258,9 @@ __global__ void __launch_bounds__(kRsBlock)
 #pragma unroll
   for (int r = 0; r < kRsRounds; r++) {
     const size_t i = base + (size_t)r * 64;
-    const bool valid = i < n;
+    const bool valid = i < n && key[r] >= skip;
     const uint32_t d = (key[r] >> shift) & (kRsBins - 1);
-    const uint32_t v = valid ? vin[i] : 0u;
+    const uint32_t v = valid ? (f64 ? rs_payload(src, i) : vin[i]) : 0u;
     uint32_t first = 0u;
     if (valid) first = cur[d];                       // every lane of the match group reads ...
     __builtin_amdgcn_wave_barrier();
@@ -266,8 +308,9 @@ size_t radix_sort_temp_bytes(size_t n) {
 template <int BITS, bool MASK>
 static int radix_sort_run(uint32_t* ktmp, uint32_t* vtmp, uint32_t* hist, uint32_t* total,
                           const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                          size_t n, size_t tiles, int passes, hipStream_t s) {
+                          size_t n, int passes, hipStream_t s, const RsFirst* first) {
   constexpr int kRsBins = 1 << BITS;
+  const size_t tiles = ceil_div<size_t>(n, (size_t)kRsTile);
   const uint32_t* sk = kin;
   const uint32_t* sv = vin;
   for (int p = 0; p < passes; p++) {
@@ -275,14 +318,26 @@ static int radix_sort_run(uint32_t* ktmp, uint32_t* vtmp, uint32_t* hist, uint32
     uint32_t* dk = to_out ? kout : ktmp;
     uint32_t* dv = to_out ? vout : vtmp;
     const int shift = p * BITS;
-    hipLaunchKernelGGL(rs_hist_kernel<BITS>, dim3((unsigned)tiles), dim3(kRsBlock), 0, s, sk, n,
-                       shift, hist);
+    RsSrc src;
+    src.k64 = (p == 0 && first) ? first->keys64 : nullptr;
+    src.flag = (p == 0 && first) ? first->flag : nullptr;
+    src.map_inner = first ? first->map_inner : 0u;
+    src.map_outer = first ? first->map_outer : 0u;
+    // a filtering first pass posts how many keys it kept; the later passes (and the caller's
+    // kernels) work on that many -- their grids are launched for n, tiles past the end exit
+    const bool filtered = first != nullptr && first->skip_below != 0u && first->n_kept != nullptr;
+    src.skip_below = (p == 0 && filtered) ? first->skip_below : 0u;
+    src.n_kept = (p == 0 && filtered) ? first->n_kept : nullptr;
+    src.n_live = (p > 0 && filtered) ? first->n_kept : nullptr;
+    hipLaunchKernelGGL((rs_hist_kernel<BITS>), dim3((unsigned)tiles), dim3(kRsBlock), 0, s,
+                       sk, n, shift, hist, src);
     HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rs_colscan_kernel<BITS>, dim3(kRsBins / kRsScanBins), dim3(kRsScanBlock), 0,
-                       s, hist, tiles, total);
+    hipLaunchKernelGGL((rs_colscan_kernel<BITS>), dim3(kRsBins / kRsScanBins),
+                       dim3(kRsScanBlock), 0, s, hist, tiles, total, src.n_live,
+                       (uint32_t)kRsTile);
     HCTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL((rs_scatter_kernel<BITS, MASK>), dim3((unsigned)tiles), dim3(kRsBlock), 0, s,
-                       sk, sv, dk, dv, n, shift, hist, total);
+    hipLaunchKernelGGL((rs_scatter_kernel<BITS, MASK>), dim3((unsigned)tiles),
+                       dim3(kRsBlock), 0, s, sk, sv, dk, dv, n, shift, hist, total, src);
     HCTR_LAUNCH_CHECK();
     sk = dk;
     sv = dv;
@@ -292,7 +347,7 @@ static int radix_sort_run(uint32_t* ktmp, uint32_t* vtmp, uint32_t* hist, uint32
 
 int radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uint32_t* kout,
                          const uint32_t* vin, uint32_t* vout, size_t n, int end_bit,
-                         hipStream_t s) {
+                         hipStream_t s, const RsFirst* first) {
   if (n == 0) return HCTR_OK;
   if (temp == nullptr || temp_bytes < radix_sort_temp_bytes(n)) {
     set_error("radix_sort_pairs_u32: workspace too small");
@@ -302,17 +357,16 @@ int radix_sort_pairs_u32(void* temp, size_t temp_bytes, const uint32_t* kin, uin
     set_error("radix_sort_pairs_u32: n / end_bit out of range");
     return HCTR_ERR_INVALID_ARG;
   }
-  const size_t tiles = ceil_div<size_t>(n, (size_t)kRsTile);
   const int passes = radix_sort_passes(end_bit);
   uint32_t* ktmp = (uint32_t*)temp;
   uint32_t* vtmp = ktmp + n;
   uint32_t* hist = vtmp + n;
-  uint32_t* total = hist + tiles * kRsMaxBins;
+  uint32_t* total = hist + ceil_div<size_t>(n, (size_t)kRsTile) * kRsMaxBins;
   if (radix_sort_bits(end_bit) == 11)
-    return radix_sort_run<11, false>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, tiles,
-                                     passes, s);
-  return radix_sort_run<10, true>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, tiles, passes,
-                                  s);
+    return radix_sort_run<11, false>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, passes, s,
+                                     first);
+  return radix_sort_run<10, true>(ktmp, vtmp, hist, total, kin, kout, vin, vout, n, passes, s,
+                                  first);
 }
 
 }  // namespace hctr

@@ -62,6 +62,29 @@ struct SparseUpdater {
   // (u % map_inner) * map_outer + u / map_inner of `grad` -- the [sample][lookup] gradient read in
   // place instead of being transposed into bucket order first.  0 = identity.  Sum combiner only.
   uint32_t map_inner = 0, map_outer = 0;
+  // device word, non-zero <=> every bucket of the batch holds exactly one key (the index stage's
+  // one-hot flag; world == 1): the sort then reads the rows where they lie and the pair expansion
+  // is skipped (RsFirst).  nullptr = unknown: the pairs are expanded.
+  const uint32_t* one_hot_flag = nullptr;
+  // hot rows of one-hot batches (sparse_update.hip, "hot rows of a one-hot batch"): positions whose
+  // row is < hot_rows are summed per (stream, chunk) by hot_chunk_kernel and never sorted.
+  // hot_streams: 0 = layout unknown (no hot path); S = the batch is sample-major with S buckets
+  // per sample (all positions p with the same p % S come from one table); 1 = positions as they lie
+  uint32_t hot_streams = 0;
+  uint32_t hot_rows = 0;        // H; 0 = off (HCTR_HOT_ROWS, default 8192, at most 16384)
+  hipStream_t hot_side = nullptr;  // the cold pairs' chain (default priority)
+  bool hot_serial = false;         // HCTR_HOT_SERIAL=1: no side stream (measurements)
+  size_t hot_min_n = 0;         // batches with fewer positions keep the plain path (HCTR_HOT_MIN)
+  uint32_t hot_chunks_max = 0;  // chunks the tables below have room for
+  uint16_t* hot_loc = nullptr;        // [hot_rows][hot_chunks_max] partial number of (row, chunk)
+  uint32_t* hot_S = nullptr;           // [hot_chunks_max][4096] a chunk's hot entries, sorted
+  uint32_t* hot_meta = nullptr;        // [hot_chunks_max][2] entries, first pool slot
+  uint32_t* hot_tpref = nullptr;       // [hot_chunks_max][129] run starts in front of a tile
+  uint32_t* hot_items = nullptr;       // tiles with entries (work list of hot_reduce_kernel)
+  uint32_t* hot_joins = nullptr;       // [.][3] runs that cross tile borders (hot_join_kernel)
+  uint32_t* hot_counts = nullptr;      // [0] pool slots, [1] pairs the sort kept, [2] items, [3] joins
+  float* hot_head = nullptr;           // [hot_chunks_max * 128][D] tile partials of runs that
+  float* hot_tail = nullptr;           //   cross tile borders inside a chunk
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;

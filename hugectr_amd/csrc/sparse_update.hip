@@ -15,6 +15,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -81,11 +82,14 @@ __global__ void __launch_bounds__(kBlock)
     expand_pairs_kernel(size_t buckets, size_t n_sort, const OffT* __restrict__ row_offset,
                         const uint64_t* __restrict__ value_index, SortK* __restrict__ keys,
                         uint32_t* __restrict__ vals, uint32_t* __restrict__ span_count,
-                        uint32_t map_inner, uint32_t map_outer) {
+                        uint32_t map_inner, uint32_t map_outer,
+                        const uint32_t* __restrict__ skip_flag) {
   const size_t nnz = (size_t)row_offset[buckets];
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
   if (tid == 0 && blockIdx.y == 0)  // long-run lists of seg_reduce / seg_combine
     span_count[0] = span_count[1] = span_count[2] = span_count[3] = 0u;
+  // one-hot batch: the sort's first pass takes rows and payloads from where they lie (RsFirst)
+  if (skip_flag != nullptr && *skip_flag != 0u) return;
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   // key-parallel (block_prims.h): the payload is the gradient row of the key's bucket
   // (SparseUpdater::map_inner)
@@ -435,7 +439,8 @@ __global__ void __launch_bounds__(kBlock)
                       float* __restrict__ head, float* __restrict__ tail,
                       uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
                       float* __restrict__ direct_out, const OffT* __restrict__ scale_ro,
-                      OptConst fuse_o, float* __restrict__ fuse_state0) {
+                      OptConst fuse_o, float* __restrict__ fuse_state0,
+                      const uint32_t* __restrict__ n_live) {
   // kFuse (kFuseSgd / kFuseAdaGrad): the optimizer applied where a run's sum is complete --
   // e.g. table[row] += -lr * (sum / scaler) -- right here (direct_out = the table) instead of
   // parking the sum in gsum for seg_apply.  Every row is one run owned by one lane group, so
@@ -464,7 +469,9 @@ __global__ void __launch_bounds__(kBlock)
   const int l = threadIdx.x % LPR;
   const int gshift = ((threadIdx.x & 63) / LPR) * LPR;  // first lane of my group in the wave
   constexpr unsigned long long kGroupMask = ML >= 64 ? ~0ull : ((1ull << ML) - 1ull);
-  const size_t nnz = (size_t)row_offset[buckets];
+  // (n_live: the sorted list holds the cold rows' positions only -- the sort's first pass left the
+  //  hot rows to hot_chunk_kernel and posted how many pairs it kept)
+  const size_t nnz = n_live != nullptr ? (size_t)*n_live : (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + T - 1) / T;
   // kFuse: the row update of a finished run is completed when the NEXT run finishes -- its row
   // (and accumulator) read travels while the next run's gradients are added, instead of stalling
@@ -697,14 +704,15 @@ __global__ void __launch_bounds__(kBlock)
     seg_apply_kernel(size_t buckets, const OffT* __restrict__ row_offset,
                      const SortK* __restrict__ sorted_rows, const float* __restrict__ gsum,
                      OptConst o, float* __restrict__ table, float* __restrict__ state0,
-                     float* __restrict__ state1, unsigned long long* __restrict__ prev_time) {
+                     float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                     const uint32_t* __restrict__ n_live) {
   constexpr int D = LPR * 4;
   constexpr int G = 64 / LPR;  // groups per wavefront
   constexpr int T = kSegTile;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR;
   const int l = lane % LPR;
-  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t nnz = n_live != nullptr ? (size_t)*n_live : (size_t)row_offset[buckets];
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
   const size_t nwaves = ((size_t)gridDim.x * kBlock) >> 6;
   for (size_t c0 = wave * 64; c0 < nnz; c0 += nwaves * 64) {
@@ -802,7 +810,8 @@ __global__ void __launch_bounds__(kBlock)
                        float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
                        const float* __restrict__ head, const float* __restrict__ tail,
                        const uint32_t* __restrict__ span_list, uint32_t* __restrict__ span_count,
-                       uint32_t* __restrict__ big_list, size_t big_stride) {
+                       uint32_t* __restrict__ big_list, size_t big_stride,
+                       const uint32_t* __restrict__ n_live) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   constexpr int CU = 8;
@@ -810,7 +819,7 @@ __global__ void __launch_bounds__(kBlock)
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
   const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
-  const size_t nnz = (size_t)row_offset[buckets];
+  const size_t nnz = n_live != nullptr ? (size_t)*n_live : (size_t)row_offset[buckets];
   const size_t n_tiles = (nnz + kSegTile - 1) / kSegTile;
   const uint32_t n_span = span_count[0];
   for (size_t si = (size_t)blockIdx.x * GPB + g; si < n_span; si += (size_t)gridDim.x * GPB) {
@@ -993,6 +1002,439 @@ __global__ void __launch_bounds__(kCombBlock)
   }
 }
 
+// ---- hot rows of a one-hot batch ----------------------------------------------------------------
+// Power-law batches are bimodal: a few thousand rows -- the rows of the tiny tables and the heads
+// of the big ones, which the table handed out first and which therefore carry the LOWEST row
+// numbers -- take two thirds of a batch's positions (Criteo-1TB shape, alpha 1.1: rows < 8192 take
+// 71 % of the 1.7 M positions).  Sending those positions through a global radix sort only to cut
+// the result into tiles again is what made the update latency-bound.  For a batch with one key per
+// bucket (device flag of the index stage) the hot positions never enter the sort:
+//   * position p belongs to stream p % G (G = slots per sample of a sample-major batch: all
+//     positions of a stream come from ONE table, so its hot rows recur inside the stream; G = 1:
+//     the positions as they lie) and a chunk is kHotChunk consecutive positions of one stream;
+//   * hot_sort_kernel, one workgroup per chunk: the chunk's positions whose row is < H are sorted
+//     by row inside LDS (two stable 7-bit passes, ascending position inside a row) and cut into
+//     tiles of 32 like the global list is;
+//   * hot_reduce_kernel, one lane group per tile (all chunks' tiles in one flat list): every run
+//     (= one row's gradients inside the chunk) is summed in ascending position order; the pieces
+//     of runs that cross tile borders are added in tile order by hot_join_kernel.  A chunk's
+//     partial sums land in a pool (the far end of gsum, which the sorted list cannot reach: cold
+//     pairs + hot partials <= nnz) and loc[row][chunk] says where;
+//   * hot_apply_kernel, one lane group per hot row: partials in ascending chunk order, then the
+//     optimizer -- a fixed association, so the result does not depend on scheduling;
+//   * the sort's first pass leaves out keys < H (RsFirst::skip_below); sort and segmented reduce
+//     of the cold pairs (n_live) run on a side stream next to the hot rows' kernels.
+// A batch that is not one-hot (flag 0) makes these kernels exit and the sort keeps every pair.
+// Measured (MI355X, Criteo-1TB shape, round 4): one workgroup doing sort AND reduce of its chunk
+// (8 tiles per lane group, one after the other) took 132 us for 310 MB -- a latency chain on 3
+// waves per SIMD; hence the flat tile list.
+constexpr int kHotChunk = 4096;
+constexpr int kHotBlock = 512;
+constexpr int kHotWaves = kHotBlock / 64;
+constexpr int kHotRounds = kHotChunk / kHotBlock;  // entries per thread
+constexpr int kHotBits = 7;                        // digit of one LDS pass; two passes
+constexpr int kHotBins = 1 << kHotBits;
+constexpr int kHotMaxRows = 1 << (2 * kHotBits);   // 16384
+constexpr int kHotTile = 32;
+constexpr int kHotTiles = kHotChunk / kHotTile;    // 128
+constexpr int kHotPosBits = 12;                    // entry = row << 12 | position inside the chunk
+static_assert((1 << kHotPosBits) == kHotChunk, "entry layout");
+constexpr uint32_t kHotNone = 0xFFFFu;             // loc[][]: the row has no partial in this chunk
+constexpr uint32_t kHotMaxStreams = 64;            // more slots per sample: the plain path
+
+struct HotGeom {
+  uint32_t n;          // positions (= buckets: one key each)
+  uint32_t G;          // streams
+  uint32_t cpg;        // chunks per stream
+  uint32_t rows;       // H
+  uint32_t map_inner, map_outer;  // gradient row of bucket u (SparseUpdater::map_inner)
+  uint32_t loc_stride;  // chunks the loc table has room for, per row
+};
+
+// lanes of this wavefront whose digit equals mine (valid lanes only)
+__device__ __forceinline__ unsigned long long hot_match(uint32_t d, bool valid) {
+  unsigned long long m = __ballot(valid);
+#pragma unroll
+  for (int bit = 0; bit < kHotBits; bit++) {
+    const bool one = ((d >> bit) & 1u) != 0u;
+    const unsigned long long bal = __ballot(one);
+    m &= one ? bal : ~bal;
+  }
+  return valid ? m : 0ull;
+}
+
+// One stable LDS split of the workgroup's entries by the digit (e >> shift) & 127.  "Wavefront,
+// then round, then lane" is the input order (wavefront w holds entries [w * 512, (w + 1) * 512) of
+// it), and ranks are handed out in that nesting.  Returns the number of valid entries.
+__device__ __forceinline__ uint32_t hot_lds_pass(const uint32_t (&e)[kHotRounds], uint32_t vmask,
+                                                 int shift, uint32_t* __restrict__ dst,
+                                                 uint32_t (*wh)[kHotBins], uint32_t* scan_smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < kHotWaves * kHotBins; i += kHotBlock) (&wh[0][0])[i] = 0u;
+  __syncthreads();
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t info[kHotRounds];  // rank inside the match group | group size << 8
+#pragma unroll
+  for (int r = 0; r < kHotRounds; r++) {
+    const bool valid = ((vmask >> r) & 1u) != 0u;
+    const uint32_t d = (e[r] >> shift) & (kHotBins - 1);
+    const unsigned long long m = hot_match(d, valid);
+    const uint32_t rank = (uint32_t)__popcll(m & lt), cnt = (uint32_t)__popcll(m);
+    info[r] = rank | (cnt << 8);
+    if (valid && rank == 0u) atomicAdd(&wh[wave][d], cnt);
+  }
+  __syncthreads();
+  uint32_t c = 0u;
+  if (threadIdx.x < kHotBins) {
+#pragma unroll
+    for (int w = 0; w < kHotWaves; w++) c += wh[w][threadIdx.x];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<uint32_t, kHotBlock>(c, scan_smem, &total);
+  if (threadIdx.x < kHotBins) {
+#pragma unroll
+    for (int w = 0; w < kHotWaves; w++) {
+      const uint32_t cw = wh[w][threadIdx.x];
+      wh[w][threadIdx.x] = run;
+      run += cw;
+    }
+  }
+  __syncthreads();
+  volatile uint32_t* cur = wh[wave];
+#pragma unroll
+  for (int r = 0; r < kHotRounds; r++) {
+    const bool valid = ((vmask >> r) & 1u) != 0u;
+    const uint32_t d = (e[r] >> shift) & (kHotBins - 1);
+    uint32_t first = 0u;
+    if (valid) first = cur[d];                        // every lane of the match group reads ...
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const uint32_t rank = info[r] & 0xFFu;
+      if (rank == 0u) cur[d] = first + (info[r] >> 8);  // ... before its leader advances
+      dst[first + rank] = e[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  return total;
+}
+
+// per-chunk results of hot_sort_kernel
+struct HotBufs {
+  uint32_t* S;       // [chunks][kHotChunk] the chunk's hot entries, sorted by row
+  uint32_t* meta;    // [chunks][2] entries, first pool slot
+  uint32_t* tpref;   // [chunks][kHotTiles + 1] run starts in front of a tile
+  uint32_t* items;   // tiles that hold entries: chunk * kHotTiles + tile (any order)
+  uint32_t* joins;   // [.][3] runs that cross tile borders: chunk << 14 | first tile << 7 | last
+                     //        tile, partial number, row
+  uint32_t* counts;  // [0] pool slots taken, [1] pairs the sort kept, [2] items, [3] joins
+  uint16_t* loc;     // [hot rows][loc_stride] partial number of (row, chunk), kHotNone = none
+  float* head;       // [chunks * kHotTiles][D] partial of the run that enters a tile
+  float* tail;       // [chunks * kHotTiles][D] partial of the run that leaves a tile (its owner's)
+};
+
+// one workgroup per chunk: the chunk's hot entries sorted by row (LDS), run starts per tile, a
+// block of pool slots for its partials, the work lists of hot_reduce_kernel / hot_join_kernel
+__global__ void __launch_bounds__(kHotBlock)
+    hot_sort_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot,
+                    const uint64_t* __restrict__ value_index, HotBufs hb) {
+  if (*one_hot == 0u) return;
+  __shared__ uint32_t list[2][kHotChunk];
+  __shared__ uint32_t wh[kHotWaves][kHotBins];
+  __shared__ uint32_t scan_smem[kHotWaves + 1];
+  __shared__ uint32_t tile_pref[kHotTiles + 2];  // run starts in front of a tile
+  __shared__ uint32_t sh_ibase, sh_jbase;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t chunk = blockIdx.x;
+  const uint32_t g = chunk / hg.cpg, c = chunk % hg.cpg;
+  const uint32_t len_g = hg.n > g ? (hg.n - g + hg.G - 1u) / hg.G : 0u;  // positions of my stream
+  const uint32_t c0 = c * (uint32_t)kHotChunk;
+  // ---- the chunk's hot entries, sorted by row (stable: ascending position inside a row) -------
+  uint32_t e[kHotRounds], vmask = 0u;
+#pragma unroll
+  for (int r = 0; r < kHotRounds; r++) {
+    const uint32_t i = (uint32_t)(wave * (64 * kHotRounds) + r * 64 + lane);
+    e[r] = 0u;
+    if (c0 + i < len_g) {
+      const uint64_t row = value_index[(size_t)(c0 + i) * hg.G + g];
+      if (row < (uint64_t)hg.rows) {
+        e[r] = ((uint32_t)row << kHotPosBits) | i;
+        vmask |= 1u << r;
+      }
+    }
+  }
+  const uint32_t nh = hot_lds_pass(e, vmask, kHotPosBits, list[0], wh, scan_smem);
+  if (threadIdx.x == 0) hb.meta[2 * chunk] = nh;
+  if (nh == 0u) return;  // (uniform: every thread holds the block total)
+  vmask = 0u;
+#pragma unroll
+  for (int r = 0; r < kHotRounds; r++) {
+    const uint32_t j = (uint32_t)(wave * (64 * kHotRounds) + r * 64 + lane);
+    e[r] = j < nh ? list[0][j] : 0u;
+    if (j < nh) vmask |= 1u << r;
+  }
+  hot_lds_pass(e, vmask, kHotPosBits + kHotBits, list[1], wh, scan_smem);
+  const uint32_t* S = list[1];
+  const uint32_t nt = (nh + kHotTile - 1) / kHotTile;
+  // ---- run starts per tile -> the run number of every tile's first entry ----------------------
+#pragma unroll
+  for (int r = 0; r < kHotRounds; r++) {
+    const uint32_t j = (uint32_t)(wave * (64 * kHotRounds) + r * 64 + lane);
+    const bool st = j < nh && (j == 0u || (S[j] >> kHotPosBits) != (S[j - 1] >> kHotPosBits));
+    const unsigned long long bal = __ballot(st);
+    if (lane == 0) {
+      tile_pref[j / kHotTile] = (uint32_t)__popcll(bal & 0xFFFFFFFFull);
+      tile_pref[j / kHotTile + 1] = (uint32_t)__popcll(bal >> 32);
+    }
+    if (j < nh) hb.S[(size_t)chunk * kHotChunk + j] = S[j];
+  }
+  __syncthreads();
+  // a run that leaves tile t and began in it (or exactly at its start) is pieced together by
+  // hot_join_kernel: tail of t + the heads of the tiles after it, through the last one it reaches
+  uint32_t t2 = 0u, jrow = 0u;
+  bool owner = false;
+  if (threadIdx.x + 1u < nt) {
+    const uint32_t t = threadIdx.x, base = t * kHotTile;
+    jrow = S[base + kHotTile - 1u] >> kHotPosBits;
+    owner = (S[base + kHotTile] >> kHotPosBits) == jrow &&
+            !((S[base] >> kHotPosBits) == jrow && t > 0u && (S[base - 1u] >> kHotPosBits) == jrow);
+    if (owner) {
+      t2 = t + 1u;
+      while (t2 + 1u < nt && (S[(t2 + 1u) * kHotTile] >> kHotPosBits) == jrow) t2++;
+    }
+  }
+  {
+    const uint32_t cnt = threadIdx.x < kHotTiles ? tile_pref[threadIdx.x] : 0u;
+    uint32_t nr, nj;
+    const uint32_t ex = block_exclusive_scan<uint32_t, kHotBlock>(cnt, scan_smem, &nr);
+    const uint32_t jx = block_exclusive_scan<uint32_t, kHotBlock>(owner ? 1u : 0u, scan_smem, &nj);
+    if (threadIdx.x == 0) {
+      // (which block of slots / list entries the chunk gets does not matter)
+      hb.meta[2 * chunk + 1] = atomicAdd(hb.counts + 0, nr);
+      sh_ibase = atomicAdd(hb.counts + 2, nt);
+      sh_jbase = nj > 0u ? atomicAdd(hb.counts + 3, nj) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < kHotTiles) {
+      hb.tpref[(size_t)chunk * (kHotTiles + 1) + threadIdx.x] = ex;
+      if (threadIdx.x < nt) hb.items[sh_ibase + threadIdx.x] = chunk * kHotTiles + threadIdx.x;
+      if (owner) {
+        uint32_t* jp = hb.joins + 3 * (size_t)(sh_jbase + jx);
+        jp[0] = (chunk << 14) | (threadIdx.x << 7) | t2;
+        // number of the last run that starts at or before the end of the tile
+        jp[1] = ex + cnt - 1u;
+        jp[2] = jrow;
+      }
+    }
+    if (threadIdx.x == 0) hb.tpref[(size_t)chunk * (kHotTiles + 1) + kHotTiles] = nr;
+  }
+}
+
+// one lane group per tile of 32 sorted entries (any chunk): runs summed in ascending position order;
+// a run inside the tile is a finished partial of its (row, chunk), the piece of a run that enters
+// / leaves the tile goes to head / tail
+template <int LPR, typename GradT>
+__global__ void __launch_bounds__(kBlock)
+    hot_reduce_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot,
+                      const GradT* __restrict__ grad, float* __restrict__ pool_end, HotBufs hb) {
+  typedef typename Load4<GradT>::raw Raw;
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int QB = sizeof(Raw) == 8 ? 16 : 8;  // raw fragments in flight per lane: 32 VGPRs
+  static_assert(kHotTile % QB == 0, "batches tile the tile");
+  if (*one_hot == 0u) return;
+  // the tile's entries + the one in front + the one behind, per lane group
+  __shared__ uint32_t ent[GPB][kHotTile + 2];
+  const int gq = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t n_items = hb.counts[2];
+  constexpr uint32_t kNoneRow = 0xFFFFFFFFu;
+  for (uint32_t it = blockIdx.x * GPB + gq; it < n_items; it += gridDim.x * GPB) {
+    const uint32_t item = hb.items[it];
+    const uint32_t chunk = item / kHotTiles, t = item % kHotTiles;
+    const uint32_t nh = hb.meta[2 * chunk], pbase = hb.meta[2 * chunk + 1];
+    const uint32_t g = chunk / hg.cpg, c0 = (chunk % hg.cpg) * (uint32_t)kHotChunk;
+    const uint32_t base = t * kHotTile;
+    const uint32_t cnt = nh - base < (uint32_t)kHotTile ? nh - base : (uint32_t)kHotTile;
+    const uint32_t* Sg = hb.S + (size_t)chunk * kHotChunk;
+    __builtin_amdgcn_wave_barrier();  // (the previous item's reads of ent are done)
+    for (int q = l; q < kHotTile + 2; q += LPR) {
+      // ent[q] = entry base - 1 + q; outside the chunk's list: no row
+      const bool in = (q > 0 || base > 0u) && base + (uint32_t)q < nh + 1u;
+      ent[gq][q] = in ? Sg[base + (uint32_t)q - 1u] : kNoneRow;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t* E = ent[gq] + 1;  // E[q]: entry q of the tile
+    const uint32_t prev_row = base > 0u ? E[-1] >> kHotPosBits : kNoneRow;
+    const uint32_t next_row = base + cnt < nh ? E[cnt] >> kHotPosBits : kNoneRow;
+    uint32_t cur = E[0] >> kHotPosBits;
+    bool from_prev = cur == prev_row;
+    uint32_t ri = hb.tpref[(size_t)chunk * (kHotTiles + 1) + t] - (from_prev ? 1u : 0u);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t slot = (size_t)chunk * kHotTiles + t;
+    auto emit_partial = [&](uint32_t row, uint32_t rix, const float4& a) {
+      *reinterpret_cast<float4*>(pool_end - ((size_t)(pbase + rix) + 1u) * D + l * 4) = a;
+      if (l == 0) hb.loc[(size_t)row * hg.loc_stride + chunk] = (uint16_t)rix;
+    };
+#pragma unroll
+    for (int qb = 0; qb < kHotTile; qb += QB) {
+      if ((uint32_t)qb >= cnt) break;
+      Raw v[QB];
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const uint32_t q = (uint32_t)(qb + k) < cnt ? (uint32_t)(qb + k) : cnt - 1u;
+        const uint32_t u = (c0 + (E[q] & (uint32_t)(kHotChunk - 1))) * hg.G + g;
+        const uint32_t b = hg.map_inner ? (u % hg.map_inner) * hg.map_outer + u / hg.map_inner : u;
+        v[k] = Load4<GradT>::ld_raw(grad + (size_t)b * D + l * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < QB; k++) {
+        const uint32_t q = (uint32_t)(qb + k);
+        if (q < cnt) {
+          const uint32_t row = E[q] >> kHotPosBits;
+          if (row != cur) {  // the run in hand ends here (it may have begun in an earlier tile)
+            if (from_prev) *reinterpret_cast<float4*>(hb.head + slot * D + l * 4) = acc;
+            else emit_partial(cur, ri, acc);
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            cur = row;
+            from_prev = false;
+            ri++;
+          }
+          const float4 f = Load4<GradT>::cvt(v[k]);
+          acc.x += f.x;
+          acc.y += f.y;
+          acc.z += f.z;
+          acc.w += f.w;
+        }
+      }
+    }
+    const bool to_next = cur == next_row;
+    if (from_prev) *reinterpret_cast<float4*>(hb.head + slot * D + l * 4) = acc;
+    else if (to_next) *reinterpret_cast<float4*>(hb.tail + slot * D + l * 4) = acc;
+    else emit_partial(cur, ri, acc);
+  }
+}
+
+// runs that cross tile borders inside a chunk: tail of the tile they start in + the heads after it
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    hot_join_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot, float* __restrict__ pool_end,
+                    HotBufs hb) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int CU = 8;
+  if (*one_hot == 0u) return;
+  const int gq = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const uint32_t n_joins = hb.counts[3];
+  for (uint32_t it = blockIdx.x * GPB + gq; it < n_joins; it += gridDim.x * GPB) {
+    const uint32_t w = hb.joins[3 * (size_t)it], ri = hb.joins[3 * (size_t)it + 1];
+    const uint32_t row = hb.joins[3 * (size_t)it + 2];
+    const uint32_t chunk = w >> 14, t = (w >> 7) & 127u, t2 = w & 127u;
+    const size_t slot0 = (size_t)chunk * kHotTiles;
+    float4 acc = *reinterpret_cast<const float4*>(hb.tail + (slot0 + t) * D + l * 4);
+    for (uint32_t i = t + 1u; i <= t2; i += CU) {
+      float4 h[CU];
+#pragma unroll
+      for (int k = 0; k < CU; k++) {
+        const uint32_t tt = i + (uint32_t)k <= t2 ? i + (uint32_t)k : i;
+        h[k] = *reinterpret_cast<const float4*>(hb.head + (slot0 + tt) * D + l * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < CU; k++) {
+        if (i + (uint32_t)k <= t2) {
+          acc.x += h[k].x;
+          acc.y += h[k].y;
+          acc.z += h[k].z;
+          acc.w += h[k].w;
+        }
+      }
+    }
+    const uint32_t pbase = hb.meta[2 * chunk + 1];
+    *reinterpret_cast<float4*>(pool_end - ((size_t)(pbase + ri) + 1u) * D + l * 4) = acc;
+    if (l == 0) hb.loc[(size_t)row * hg.loc_stride + chunk] = (uint16_t)ri;
+  }
+}
+
+// one lane group per hot row: its partials in ascending chunk order, then the optimizer
+constexpr int kHotApplyChunks = 1024;  // first pool slots of the chunks, staged in LDS
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+    hot_apply_kernel(HotGeom hg, uint32_t n_chunks, const uint32_t* __restrict__ one_hot,
+                     OptConst o, float* __restrict__ table, float* __restrict__ state0,
+                     float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                     const float* __restrict__ pool_end, HotBufs hb) {
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int CU = 8;
+  constexpr int LU = 4;  // loc words per lane per trip
+  constexpr unsigned long long kGroupMask = LPR >= 64 ? ~0ull : ((1ull << LPR) - 1ull);
+  if (*one_hot == 0u) return;
+  __shared__ uint32_t cbase[kHotApplyChunks];
+  for (uint32_t i = threadIdx.x; i < n_chunks; i += kBlock) cbase[i] = hb.meta[2 * i + 1];
+  __syncthreads();
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
+  for (uint32_t row = blockIdx.x * GPB + g; row < hg.rows; row += gridDim.x * GPB) {
+    uint16_t* lrow = hb.loc + (size_t)row * hg.loc_stride;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    for (uint32_t cb = 0; cb < n_chunks; cb += LPR * LU) {
+      uint32_t v[LU];
+#pragma unroll
+      for (int u = 0; u < LU; u++) {
+        const uint32_t cc = cb + (uint32_t)(u * LPR + l);
+        v[u] = cc < n_chunks ? (uint32_t)lrow[cc] : kHotNone;
+      }
+#pragma unroll
+      for (int u = 0; u < LU; u++) {
+        const uint32_t cc = cb + (uint32_t)(u * LPR + l);
+        unsigned long long m = (__ballot(v[u] != kHotNone) >> gshift) & kGroupMask;
+        uint32_t myslot = 0u;
+        if (v[u] != kHotNone) {
+          lrow[cc] = (uint16_t)kHotNone;  // clean for the next update
+          myslot = cbase[cc] + v[u];
+        }
+        while (m != 0ull) {
+          uint32_t slot[CU];
+          int nk = 0;
+#pragma unroll
+          for (int k = 0; k < CU; k++) {
+            int bit = 0;
+            if (m != 0ull) {
+              bit = __ffsll((long long)m) - 1;
+              m &= m - 1ull;
+              nk = k + 1;
+            }
+            slot[k] = (uint32_t)__shfl((int)myslot, gshift + bit, 64);
+          }
+          float4 h[CU];
+#pragma unroll
+          for (int k = 0; k < CU; k++) {
+            if (k < nk)
+              h[k] = *reinterpret_cast<const float4*>(pool_end - ((size_t)slot[k] + 1u) * D + l * 4);
+          }
+#pragma unroll
+          for (int k = 0; k < CU; k++) {
+            if (k < nk) {
+              acc.x += h[k].x;
+              acc.y += h[k].y;
+              acc.z += h[k].z;
+              acc.w += h[k].w;
+            }
+          }
+          any = true;
+        }
+      }
+    }
+    if (any) apply_row_vec4<LPR>(o, (uint64_t)row, l, acc, table, state0, state1, prev_time);
+  }
+}
+
+// the lists are consumed: clean counters for the next update (after every reader, stream order)
+__global__ void hot_reset_kernel(const uint32_t* __restrict__ one_hot, uint32_t* counts) {
+  if (*one_hot == 0u) return;
+  counts[0] = counts[2] = counts[3] = 0u;
+}
+
 // any D: one wavefront per run, lanes stride over the vector
 template <typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
@@ -1148,7 +1590,7 @@ inline bool use_library_sort() {
 
 template <typename SortK>
 int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, const uint32_t* vin,
-               uint32_t* vout, size_t n, int end_bit, hipStream_t s) {
+               uint32_t* vout, size_t n, int end_bit, hipStream_t s, const RsFirst* first = nullptr) {
   static_assert(sizeof(SortK) == 4, "32-bit sort keys");
   if (temp == nullptr) {  // size query: room for either implementation
     size_t lib = 0;
@@ -1164,7 +1606,7 @@ int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, co
   }
   if (!use_library_sort())
     return radix_sort_pairs_u32(temp, temp_bytes, (const uint32_t*)kin, (uint32_t*)kout, vin, vout,
-                                n, end_bit, s);
+                                n, end_bit, s, first);
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0,
                                            (unsigned)end_bit, s, false);
   if (e != hipSuccess) {
@@ -1175,30 +1617,46 @@ int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, co
 }
 
 // (row, bucket) pairs -> stable radix sort by row (sparse_optimizer.cu:657-676)
+// skip_below / n_kept: the hot path's filter (RsFirst); `timed`: stage 2 of the profiler brackets
+// the sort here (the hot path brackets the fork .. join on the caller's stream instead)
 template <typename OffT, typename SortK>
 int sort_stage(SparseUpdater& u, size_t buckets, size_t n, const OffT* ro, const uint64_t* vi,
-               hipStream_t s) {
+               hipStream_t s, uint32_t skip_below = 0u, uint32_t* n_kept = nullptr,
+               bool timed = true) {
   SortK* kin = (SortK*)u.sort_keys_in;
   SortK* kout = (SortK*)u.sort_keys_out;
   // wavefronts per 64-bucket chunk = the average bucket length (for_each_key_wave): one for
   // one-hot input, 8 for the MLPerf multi-hot shape whose 100-hot table would otherwise be the tail
   const size_t avg = buckets > 0 ? (n + buckets - 1) / buckets : 1;
   const unsigned parts = (unsigned)(avg < 1 ? 1 : (avg > 16 ? 16 : avg));
+  // one key per bucket on the host's count AND on the device's word (the index stage checked the
+  // offsets): rows and payloads are read in place by the sort's first pass
+  RsFirst first;
+  first.keys64 = vi;
+  first.flag = u.one_hot_flag;
+  first.map_inner = u.map_inner;
+  first.map_outer = u.map_outer;
+  first.skip_below = skip_below;
+  first.n_kept = n_kept;
+  const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
+  const bool in_place = u.one_hot_flag != nullptr && n == buckets && !use_library_sort() &&
+                        !(ip_env && ip_env[0] == '0');
   hipLaunchKernelGGL((expand_pairs_kernel<OffT, SortK>), dim3(grid_for(buckets, kBlock), parts),
                      dim3(kBlock), 0, s, buckets, n, ro, vi, kin, u.sort_vals_in, u.span_count,
-                     u.map_inner, u.map_outer);
+                     u.map_inner, u.map_outer, in_place ? u.one_hot_flag : nullptr);
   HCTR_LAUNCH_CHECK();
-  // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663); +1 bit so the padding key sorts last
+  // end_bit = log2(max_vocab)+1 (sparse_optimizer.cu:663).  The padding key and the key of a
+  // position without a row are all ones: inside end_bit bits they are 2^end_bit - 1, above every
+  // live row (rows < top <= 2^end_bit - 1), so they sort last without a bit of their own
   int end_bit = 1;
   // (row_bound: the caller may know that only the first row_bound rows of the table exist yet)
   const size_t top = (u.row_bound > 0 && u.row_bound < u.max_vocab) ? u.row_bound : u.max_vocab;
   while (end_bit < (int)sizeof(SortK) * 8 && ((size_t)1 << end_bit) <= top) end_bit++;
-  end_bit = (end_bit + 1 < (int)sizeof(SortK) * 8) ? end_bit + 1 : (int)sizeof(SortK) * 8;
   size_t tb = u.sort_temp_bytes;
-  if (u.prof) u.prof->begin(2, s);
+  if (u.prof && timed) u.prof->begin(2, s);
   HCTR_TRY(sort_pairs<SortK>(u.sort_temp, tb, kin, kout, u.sort_vals_in, u.sort_vals_out, n,
-                             end_bit, s));
-  if (u.prof) u.prof->end(2, s);
+                             end_bit, s, in_place ? &first : nullptr));
+  if (u.prof && timed) u.prof->end(2, s);
   return HCTR_OK;
 }
 
@@ -1261,6 +1719,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
   if (nnz > 0) {
     SortK* kout = (SortK*)u.sort_keys_out;
     const uint32_t* vout = u.sort_vals_out;
+    bool need_sort = false;
     if (u.ext_rows != nullptr) {
       // presorted by the caller: only the long-run counters need a reset
       static_assert(sizeof(SortK) == 4, "presorted lists carry 32-bit rows");
@@ -1273,14 +1732,109 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       HCTR_HIP(hipStreamWaitEvent(s, u.ev_sorted, 0));
       nnz = u.early_n;
     } else {
-      HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, s)));
+      need_sort = true;
     }
     u.early_n = 0;
-    if (u.prof) u.prof->begin(3, s);
     const bool a16 = reinterpret_cast<uintptr_t>(grad) % 16 == 0;
     bool done = false;
     // store-only mode: finished runs are written straight to their output row
     float* direct = (opt.optimizer == kOptStoreSum && opt.scaler == 1.0f) ? table : nullptr;
+    // ---- hot rows (one key per bucket, device flag): see hot_sort_kernel ------------------------
+    const uint32_t* n_live = nullptr;
+    hipStream_t ss = s;  // stream of the segmented reduce
+    bool hot_taken = false;
+    int seg_grid_cap = 1 << 20;
+    {
+      const int lpr = D / 4;
+      const bool lpr_ok = a16 && D % 4 == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+      const uint32_t G = u.hot_streams;
+      const size_t per_g = G > 0 ? ceil_div<size_t>(nnz, (size_t)G) : 0;
+      const size_t cpg = ceil_div<size_t>(per_g, (size_t)kHotChunk);
+      const size_t n_chunks = (size_t)G * cpg;
+      const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
+      const bool hot = need_sort && u.hot_loc != nullptr && u.one_hot_flag != nullptr && G > 0 &&
+                       G <= kHotMaxStreams &&
+                       nnz == buckets && nnz >= u.hot_min_n && nnz < 0xFFFFFFF0ull && lpr_ok &&
+                       u.scale_row_offset == nullptr && direct == nullptr &&
+                       n_chunks <= (size_t)u.hot_chunks_max && n_chunks <= (size_t)kHotApplyChunks &&
+                       !use_library_sort() &&
+                       !(ip_env && ip_env[0] == '0');
+      if (hot) {
+        HotGeom hg;
+        hg.n = (uint32_t)nnz;
+        hg.G = G;
+        hg.cpg = (uint32_t)cpg;
+        hg.rows = u.hot_rows;
+        hg.map_inner = u.map_inner;
+        hg.map_outer = u.map_outer;
+        hg.loc_stride = u.hot_chunks_max;
+        HotBufs hb;
+        hb.S = u.hot_S;
+        hb.meta = u.hot_meta;
+        hb.tpref = u.hot_tpref;
+        hb.items = u.hot_items;
+        hb.joins = u.hot_joins;
+        hb.counts = u.hot_counts;
+        hb.loc = u.hot_loc;
+        hb.head = u.hot_head;
+        hb.tail = u.hot_tail;
+        // Two chains side by side: the cold pairs (filtering sort, then the segmented reduce over
+        // what it kept) on the side stream, the hot rows on the caller's; they touch disjoint
+        // rows.  Stage 2 of the profiler = fork .. join, all of the update.
+        hipStream_t cs = u.hot_serial ? s : u.hot_side;  // the cold chain's stream
+        if (u.prof) u.prof->begin(2, s);
+        if (cs != s) {
+          HCTR_HIP(hipEventRecord(u.ev_fork, s));
+          HCTR_HIP(hipStreamWaitEvent(cs, u.ev_fork, 0));
+        }
+        HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, cs, u.hot_rows,
+                                          u.hot_counts + 1, false)));
+        float* pool_end = u.gsum + u.max_nnz * (size_t)D;
+        const size_t items_max = nnz / kHotTile + n_chunks;
+        // both chains are grid-stride loops over a bounded number of workgroups: a kernel that
+        // queues one workgroup per tile fills every wave slot of the device and the other
+        // stream's kernels only trickle in (measured: the sort's scatter 21 -> 96 us)
+        const char* hg_env = getenv("HCTR_HOT_GRID");
+        const char* sg_env = getenv("HCTR_SEG_GRID");
+        const int hot_grid = hg_env ? atoi(hg_env) : 768;
+        seg_grid_cap = sg_env ? atoi(sg_env) : 1024;
+        hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)n_chunks), dim3(kHotBlock), 0, s, hg,
+                           u.one_hot_flag, vi, hb);
+        HCTR_LAUNCH_CHECK();
+#define HCTR_HOT_CASE(LPR_)                                                                       \
+  {                                                                                               \
+    constexpr int GPB = kBlock / LPR_;                                                            \
+    hipLaunchKernelGGL((hot_reduce_kernel<LPR_, GradT>), dim3(grid_for(items_max, GPB, hot_grid)), \
+                       dim3(kBlock), 0, s, hg, u.one_hot_flag, grad, pool_end, hb);               \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((hot_join_kernel<LPR_>), dim3(grid_for(items_max / 8 + 1, GPB, 2048)),     \
+                       dim3(kBlock), 0, s, hg, u.one_hot_flag, pool_end, hb);                     \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((hot_apply_kernel<LPR_>), dim3(grid_for(u.hot_rows, GPB)), dim3(kBlock),   \
+                       0, s, hg, (uint32_t)n_chunks, u.one_hot_flag, o, table, state0, state1,    \
+                       (unsigned long long*)prev_time, (const float*)pool_end, hb);               \
+    HCTR_LAUNCH_CHECK();                                                                          \
+  }
+        switch (lpr) {
+          case 1: HCTR_HOT_CASE(1) break;
+          case 2: HCTR_HOT_CASE(2) break;
+          case 4: HCTR_HOT_CASE(4) break;
+          case 8: HCTR_HOT_CASE(8) break;
+          case 16: HCTR_HOT_CASE(16) break;
+          case 32: HCTR_HOT_CASE(32) break;
+          default: HCTR_HOT_CASE(64) break;
+        }
+#undef HCTR_HOT_CASE
+        hipLaunchKernelGGL(hot_reset_kernel, dim3(1), dim3(1), 0, s, u.one_hot_flag, u.hot_counts);
+        HCTR_LAUNCH_CHECK();
+        n_live = u.hot_counts + 1;
+        ss = cs;  // the segmented reduce follows the sort on the side stream
+        hot_taken = true;
+      } else if (need_sort) {
+        HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, s)));
+      }
+    }
+    if (u.prof && !hot_taken) u.prof->begin(3, s);
     // plain SGD: the apply pass folds into the reduce (seg_reduce_kernel<.., kFuseSgd>);
     // HCTR_SGD_FUSED=0 keeps the two-pass form (measurements, the bit-equality test)
     const char* fuse_env = getenv("HCTR_SGD_FUSED");  // (read per call: tests flip it in-process)
@@ -1291,9 +1845,10 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     }
 #define HCTR_SEG_REDUCE(LPR_, FUSE_, OUT_)                                                        \
   hipLaunchKernelGGL((seg_reduce_kernel<LPR_, OffT, SortK, GradT, FUSE_>),                        \
-                     dim3(grid_for(seg_tiles, GPB, 1 << 20)), dim3(kBlock), 0, s, buckets, ro,    \
+                     dim3(grid_for(seg_tiles, GPB, seg_grid_cap)), dim3(kBlock), 0, ss, buckets,   \
+                     ro,                                                                          \
                      kout, vout, combiner, grad, u.gsum, u.seg_head, u.seg_tail, u.span_list,     \
-                     u.span_count, OUT_, sro, o, state0)
+                     u.span_count, OUT_, sro, o, state0, n_live)
 #define HCTR_SEG_CASE(LPR_)                                                                       \
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
@@ -1305,23 +1860,23 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     if (direct == nullptr && fuse == kFuseNone) {                                                 \
       if (o.optimizer == HCTR_OPT_SGD)                                                            \
         hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, true>),                           \
-                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, ss, buckets, ro, \
                            kout, u.gsum, o, table, state0, state1,                                \
-                           (unsigned long long*)prev_time);                                       \
+                           (unsigned long long*)prev_time, n_live);                               \
       else                                                                                        \
         hipLaunchKernelGGL((seg_apply_kernel<LPR_, OffT, SortK, false>),                          \
-                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, s, buckets, ro, \
+                           dim3(grid_for(nnz, kBlock, 256 * 8)), dim3(kBlock), 0, ss, buckets, ro, \
                            kout, u.gsum, o, table, state0, state1,                                \
-                           (unsigned long long*)prev_time);                                       \
+                           (unsigned long long*)prev_time, n_live);                               \
       HCTR_LAUNCH_CHECK();                                                                        \
     }                                                                                             \
     hipLaunchKernelGGL((seg_combine_kernel<LPR_, OffT, SortK>),                                   \
-                       dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, s, buckets, ro, \
+                       dim3(grid_for(seg_tiles, GPB * 4, 1024)), dim3(kBlock), 0, ss, buckets, ro, \
                        kout, o, table, state0, state1, (unsigned long long*)prev_time, u.seg_head, \
-                       u.seg_tail, u.span_list, u.span_count, u.big_list, u.big_stride);          \
+                       u.seg_tail, u.span_list, u.span_count, u.big_list, u.big_stride, n_live);  \
     HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((seg_combine_big_kernel<LPR_, OffT, SortK>), dim3(256), dim3(kCombBlock),  \
-                       0, s, buckets, ro, kout, o, table, state0, state1,                         \
+                       0, ss, buckets, ro, kout, o, table, state0, state1,                         \
                        (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.big_list,        \
                        u.big_stride, u.span_count);                                               \
   }
@@ -1359,7 +1914,15 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                          state0, state1, (unsigned long long*)prev_time);
     }
     HCTR_LAUNCH_CHECK();
-    if (u.prof) u.prof->end(3, s);
+    if (hot_taken) {  // join: the cold chain's end is ordered before whatever follows on s
+      if (ss != s) {
+        HCTR_HIP(hipEventRecord(u.ev_sorted, ss));
+        HCTR_HIP(hipStreamWaitEvent(s, u.ev_sorted, 0));
+      }
+      if (u.prof) u.prof->end(2, s);
+    } else if (u.prof) {
+      u.prof->end(3, s);
+    }
   }
 
   if (opt.update_type == HCTR_UPDATE_GLOBAL) {
@@ -1482,15 +2045,60 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
   big_stride = seg_tiles;
   HCTR_HIP(hipMalloc(&big_list, 4 * seg_tiles * sizeof(uint32_t)));
   HCTR_HIP(hipMemset(big_list, 0, 4 * seg_tiles * sizeof(uint32_t)));
+  // hot rows of one-hot batches.  HCTR_HOT_ROWS: rows below it are hot (0 = off);
+  // HCTR_HOT_MIN: batches with fewer positions keep the plain path (a small batch is launch-bound:
+  // two more kernels and a stream fork cost more than its sort)
+  {
+    const char* hr = getenv("HCTR_HOT_ROWS");
+    long rows = hr ? atol(hr) : 8192;
+    if (rows < 0) rows = 0;
+    if (rows > kHotMaxRows) rows = kHotMaxRows;
+    const char* hm = getenv("HCTR_HOT_MIN");
+    hot_min_n = hm ? (size_t)atoll(hm) : (size_t)262144;
+    hot_rows = 0;
+    if (rows > 0 && max_nnz >= hot_min_n && D % 4 == 0 && D / 4 <= 64 && ((D / 4) & (D / 4 - 1)) == 0) {
+      hot_rows = (uint32_t)rows;
+      const char* hs = getenv("HCTR_HOT_SERIAL");  // "1": both chains on the caller's stream (measurements)
+      hot_serial = hs != nullptr && hs[0] == '1';
+      {
+        int lo = 0, hi = 0;
+        HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const char* hp = getenv("HCTR_HOT_PRIO");  // "high" / "low": priority of the cold chain
+        const int pr = (hp && hp[0] == 'h') ? hi : ((hp && hp[0] == 'l') ? lo : 0);
+        HCTR_HIP(hipStreamCreateWithPriority(&hot_side, hipStreamNonBlocking, pr));
+      }
+      hot_chunks_max = (uint32_t)(ceil_div<size_t>(max_nnz, (size_t)kHotChunk) + kHotMaxStreams);
+      const size_t loc_bytes = (size_t)hot_rows * hot_chunks_max * sizeof(uint16_t);
+      HCTR_HIP(hipMalloc(&hot_loc, loc_bytes));
+      HCTR_HIP(hipMemset(hot_loc, 0xFF, loc_bytes));  // kHotNone everywhere; hot_apply keeps it so
+      const size_t C = hot_chunks_max;
+      HCTR_HIP(hipMalloc(&hot_S, C * kHotChunk * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_meta, C * 2 * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_tpref, C * (kHotTiles + 1) * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_items, (max_nnz / kHotTile + C + 1) * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_joins, 3 * C * kHotTiles * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_counts, 4 * sizeof(uint32_t)));
+      HCTR_HIP(hipMemset(hot_counts, 0, 4 * sizeof(uint32_t)));
+      const size_t part = (size_t)hot_chunks_max * kHotTiles * (size_t)D * sizeof(float);
+      HCTR_HIP(hipMalloc(&hot_head, part));
+      HCTR_HIP(hipMalloc(&hot_tail, part));
+    }
+  }
   return HCTR_OK;
 }
 
 int SparseUpdater::destroy() {
   void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
                   run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
-                  gsum,         big_list};
+                  gsum,         big_list,      hot_loc,      hot_counts,    hot_head,  hot_tail,
+                  hot_S,        hot_meta,      hot_tpref,    hot_items,     hot_joins};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (hot_side) {
+    (void)hipStreamSynchronize(hot_side);
+    (void)hipStreamDestroy(hot_side);
+    hot_side = nullptr;
+  }
   if (side) {
     (void)hipStreamSynchronize(side);
     (void)hipStreamDestroy(side);
@@ -1505,6 +2113,10 @@ int SparseUpdater::destroy() {
   seg_head = seg_tail = nullptr;
   span_list = span_count = big_list = nullptr;
   gsum = nullptr;
+  hot_loc = nullptr;
+  hot_counts = hot_S = hot_meta = hot_tpref = hot_items = hot_joins = nullptr;
+  hot_head = hot_tail = nullptr;
+  hot_rows = hot_chunks_max = 0;
   return HCTR_OK;
 }
 

@@ -684,3 +684,72 @@ def test_row_with_a_quarter_million_gradients(D):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     err = np.abs(outs[0].cpu().numpy().astype(np.float64) - want).max()
     assert err < 2e-3, err  # row 0 moved by ~ sqrt(250k) * 0.01 * 0.25: fp32 partial sums
+
+
+@pytest.mark.parametrize("opt_kw", [dict(optimizer=6, atomic_update=False), dict(optimizer=3),
+                                    dict(optimizer=1, update_type=0)],
+                         ids=["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("B,D,dt,hot_rows", [(16384, 128, "f16", 8192), (12000, 16, "f32", 500),
+                                             (4100, 64, "bf16", 16384)])
+def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, opt_kw, B, D, dt, hot_rows):
+    """the hot-row path of the sparse update (hot_chunk_kernel + hot_apply_kernel, the cold pairs
+    sorted on the side stream by a first pass that leaves the hot rows out) at sizes where it is on
+    by default in the bench: Criteo-like skew (tables of 3 / 4 / 10 rows whose rows fill whole
+    streams and cross chunk borders, power-law tables, a nearly unique one), rows on both sides of
+    the bound, a ragged batch in between (both kernels exit on the device flag).  Table and state
+    against the oracle within the re-association of long sums; the same bits on a second handle;
+    next to the plain path (HCTR_HOT_ROWS=0)."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    sizes = [3, 4, 10, 36, 1000, 50000, 200000, 97]
+    S = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    V = int(sum(sizes))
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    opt = ha.OptParams(lr=0.01, scaler=2.0, **opt_kw)
+    ns = {1: 2, 3: 1, 6: 0}[opt.optimizer]
+
+    def run(rows_env):
+        monkeypatch.setenv("HCTR_HOT_MIN", "0")
+        monkeypatch.setenv("HCTR_HOT_ROWS", str(rows_env))
+        rng = np.random.default_rng(B + D)
+        emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, 2 * S, S, 0, opt, out_dtype=tdt)
+        emb.init_params()
+        torch.cuda.synchronize()
+        table = emb.table().cpu().numpy().copy()
+        s0 = np.zeros_like(table) if ns >= 1 else None
+        s1 = np.zeros_like(table) if ns >= 2 else None
+        ht = oracle.HashTable(V, 8)
+        for it in range(4):
+            if it == 2:
+                lens = rng.integers(0, 3, size=B * S)
+                ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+                keys = (np.minimum(rng.pareto(1.1, size=slot_of.size).astype(np.int64),
+                                   np.array(sizes)[slot_of] - 1) + offs[slot_of]).astype(np.int64)
+            else:
+                ro = np.arange(B * S + 1, dtype=np.int64)
+                keys = np.stack([np.minimum((rng.pareto(1.1, size=B)).astype(np.int64), v - 1) + o
+                                 for v, o in zip(sizes, offs)], axis=1).reshape(-1)
+            emb.forward(True, _t(torch, ro), _t(torch, keys))
+            vi = ht.get_insert(keys)
+            g = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+            gt = _t(torch, g).to(tdt).view(B, S, D).contiguous()
+            emb.backward(gt)
+            emb.update_params()
+            torch.cuda.synchronize()
+            wg = oracle.backward(ro, gt.float().cpu().numpy().reshape(-1, D), D, 0)
+            oo = _oracle_opt(oracle, opt, it + 1)
+            oo.state_half = 1 if dt == "f16" else 0
+            oracle.update_params(ro, vi, wg, oo, table, s0, s1, None)
+            assert_close(emb.table().cpu().numpy(), table, 1e-3, 1e-4, f"table it{it} H={rows_env}")
+            if s0 is not None:
+                assert_close(emb.opt_state(0).cpu().numpy(), s0, 2e-3, 1e-4, f"state0 it{it}")
+        return emb.table().clone()
+
+    a = run(hot_rows)
+    b = run(hot_rows)
+    assert torch.equal(a, b), "the hot path is not deterministic"
+    c = run(0)
+    assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-3, 1e-4, "hot path vs plain path")

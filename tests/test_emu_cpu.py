@@ -214,3 +214,72 @@ def test_no_collective_met_an_idle_lane(elib):
     taking part in it -- on the hardware such a read returns a stale register"""
     s = emu.stats(elib)
     assert s["launches"] > 100 and s["shfl_from_inactive"] == 0, s
+
+
+HOT_OPTS = [("sgd", dict(optimizer=6, atomic_update=0)), ("adagrad", dict(optimizer=3)),
+            ("adam", dict(optimizer=1, update_type=0))]
+
+
+@pytest.mark.parametrize("name,kw", HOT_OPTS, ids=[o[0] for o in HOT_OPTS])
+@pytest.mark.parametrize("B,S,D,odt,hot_rows", [(9000, 3, 8, 0, 64), (5000, 5, 16, 1, 8192),
+                                                (4097, 2, 4, 0, 300)])
+def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, D, odt, hot_rows):
+    """the update's hot-row path (hot_chunk_kernel / hot_apply_kernel + the sort's filtering first
+    pass) forced on at a small size: streams of one slot each, more than one chunk per stream, runs
+    that cross tiles and chunks (a 3-row table), rows on both sides of the hot bound, a batch that
+    is NOT one-hot in between (both kernels exit, the sort keeps every pair).  Against the oracle
+    within the re-association of the sums, the same bits on a second handle, and next to the plain
+    path (HCTR_HOT_ROWS=0)."""
+    from hugectr_amd import _lib
+    vps = 2500
+    V = S * vps
+    opt = dict(lr=0.05, scaler=2.0, beta1=0.9, beta2=0.999, epsilon=1e-7, **kw)
+    npd = np.float16 if odt == 1 else np.float32
+
+    def run(rows_env):
+        monkeypatch.setenv("HCTR_HOT_MIN", "0")
+        monkeypatch.setenv("HCTR_HOT_ROWS", str(rows_env))
+        rng = np.random.default_rng(B + D)
+        emb = emu.Embedding(elib, _lib.EMB_LOCALIZED, B, V, D, 2 * S, S, 0, opt, out_dtype=odt)
+        table = emb.table().copy()
+        ns = {1: 2, 3: 1, 6: 0}[kw["optimizer"]]
+        s0 = np.zeros_like(table) if ns >= 1 else None
+        s1 = np.zeros_like(table) if ns >= 2 else None
+        ht = oracle.HashTable(V, 8)
+        m = {1: oracle.OPT_ADAM, 3: oracle.OPT_ADAGRAD, 6: oracle.OPT_SGD}
+        for it in range(4):
+            k = np.empty((B, S), dtype=np.int64)
+            k[:, 0] = rng.integers(0, 3, size=B)  # three rows take a whole stream
+            for s in range(1, S):
+                k[:, s] = np.minimum((rng.pareto(0.9, size=B) * 3).astype(np.int64), vps - 1) + s * vps
+            if it == 2:  # ragged: 0..2 keys per bucket -> the plain path on the same handle
+                lens = rng.integers(0, 3, size=B * S)
+                ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+                keys = (rng.integers(0, 40, size=slot_of.size) + slot_of * vps).astype(np.int64)
+            else:
+                ro = np.arange(B * S + 1, dtype=np.int64)
+                keys = k.reshape(-1)
+            emb.forward(True, ro, keys)
+            vi = ht.get_insert(keys)
+            assert (emb.value_index(keys.size) == vi).all()
+            g = (rng.standard_normal((B * S, D)) * 0.1).astype(npd)
+            emb.backward(g.reshape(B, S, D))
+            emb.update_params()
+            o = oracle.OptParamsC()
+            o.optimizer, o.update_type, o.lr = m[kw["optimizer"]], kw.get("update_type", 0), 0.05
+            o.beta1, o.beta2, o.epsilon = 0.9, 0.999, 1e-7
+            o.momentum_factor, o.scaler, o.times = 0.0, 2.0, it + 1
+            o.state_half = 1 if odt == 1 else 0  # fp16 embeddings keep fp16-valued state (q6)
+            oracle.update_params(ro, vi, oracle.backward(ro, g.astype(np.float32), D, 0), o, table,
+                                 s0, s1, None)
+            assert_close(emb.table(), table, 3e-4, 3e-5, f"{name} table it{it} hot={rows_env}")
+            if s0 is not None:
+                assert_close(emb.opt_state(0), s0, 3e-4, 3e-5, f"{name} state0 it{it}")
+        return emb.table().copy()
+
+    a = run(hot_rows)
+    b = run(hot_rows)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all(), "the hot path is not deterministic"
+    c = run(0)
+    assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
