@@ -215,7 +215,9 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     sel = 0
     if world > 1 and os.environ.get("HCTR_EXCHANGE", "auto") == "auto" and not a.no_overlap:
         sel = m._SEL_WARM + 2 * m._SEL_TIMED + m._SEL_SWITCH + 1  # the exchange selection's steps
-    nb = a.nbatches if a.nbatches > 0 else sel + warmup + steps + 1
+    inline = 8 if world == 1 else 0  # unseen batches for the in-line stage times (see below)
+    ov_prev = os.environ.get("HCTR_UPDATE_OVERLAP")
+    nb = a.nbatches if a.nbatches > 0 else sel + warmup + steps + inline + 1
     gk = torch.Generator(device=dev)
     gk.manual_seed(1234)                     # the same full-batch CSR on every rank
     gd = torch.Generator(device=dev)
@@ -272,10 +274,23 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
             t = t.to(dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = emb.profile()
+    prof_timed = emb.profile()
     emb.profiling(False)
     m.check_overflow()
     new_keys = (emb.get_vocabulary_size() - rows_before) / max(steps, 1)
+    # The timed region runs the product's schedule: on one GPU the sparse update starts from the
+    # gradient hook on a side stream, under the bottom MLP's backward (hugectr.py), so its events
+    # there bracket shared-chip time.  The stage times the rooflines are computed from are taken
+    # right after, on `inline` further unseen batches with the update in line (its own time).
+    prof = prof_timed
+    if world == 1 and inline > 0:
+        os.environ["HCTR_UPDATE_OVERLAP"] = "0"
+        emb.profiling(True)
+        for _ in range(inline):
+            m.train()
+        sync()
+        prof = emb.profile()
+        emb.profiling(False)
     # the same stages with NO unseen key (batches the tables have met): the index stage's floor
     steady_us = None
     if world == 1:
@@ -290,6 +305,10 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
         sync()
         steady_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in emb.profile().items()}
         emb.profiling(False)
+        if ov_prev is None:
+            os.environ.pop("HCTR_UPDATE_OVERLAP", None)
+        else:
+            os.environ["HCTR_UPDATE_OVERLAP"] = ov_prev
     xrep = m.exchange_report()["sparse_embedding1"]
 
     # ---- roofline of the gather+pool kernel (DESIGN.md section 5 / SURVEY 8d) -------------------
@@ -428,6 +447,13 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                            "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6,
                            "traffic": pmc_idx, "traffic_source": pmc_src if pmc_idx else None},
         "stage_us_per_step": stage_us,
+        # the same stages as the timed region saw them (one GPU: the update overlapped with the
+        # bottom MLP's backward -- shared-chip time, not the kernels' own)
+        "stage_us_per_step_timed_region": {k: (v[0] / max(v[1], 1)) * 1e3
+                                           for k, v in prof_timed.items()},
+        "update_overlapped_with_dense_backward": bool(
+            world == 1 and (ov_prev or "1") != "0" and
+            not a.no_overlap and xrep.get("gather_fused_into_interaction")),
         "stage_us_per_step_no_new_keys": steady_us,
         "embedding_ms_per_step": sum(stage_us.values()) * 1e-3,
     }

@@ -82,7 +82,8 @@ struct SparseUpdater {
   uint32_t* hot_tpref = nullptr;       // [hot_chunks_max][129] run starts in front of a tile
   uint32_t* hot_items = nullptr;       // tiles with entries (work list of hot_reduce_kernel)
   uint32_t* hot_joins = nullptr;       // [.][3] runs that cross tile borders (hot_join_kernel)
-  uint32_t* hot_counts = nullptr;      // [0] pool slots, [1] pairs the sort kept, [2] items, [3] joins
+  uint32_t* hot_counts = nullptr;      // two alternating sets {pool slots, items, joins, -} + [8] pairs the sort kept
+  uint32_t hot_parity = 0;             // set the next update takes
   float* hot_head = nullptr;           // [hot_chunks_max * 128][D] tile partials of runs that
   float* hot_tail = nullptr;           //   cross tile borders inside a chunk
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)

@@ -1127,7 +1127,8 @@ struct HotBufs {
   uint32_t* items;   // tiles that hold entries: chunk * kHotTiles + tile (any order)
   uint32_t* joins;   // [.][3] runs that cross tile borders: chunk << 14 | first tile << 7 | last
                      //        tile, partial number, row
-  uint32_t* counts;  // [0] pool slots taken, [1] pairs the sort kept, [2] items, [3] joins
+  uint32_t* counts;  // this update's counters: [0] pool slots taken, [1] items, [2] joins
+  uint32_t* counts_next;  // the next update's (the other parity): zeroed by hot_sort_kernel
   uint16_t* loc;     // [hot rows][loc_stride] partial number of (row, chunk), kHotNone = none
   float* head;       // [chunks * kHotTiles][D] partial of the run that enters a tile
   float* tail;       // [chunks * kHotTiles][D] partial of the run that leaves a tile (its owner's)
@@ -1138,6 +1139,10 @@ struct HotBufs {
 __global__ void __launch_bounds__(kHotBlock)
     hot_sort_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot,
                     const uint64_t* __restrict__ value_index, HotBufs hb) {
+  // (before the flag is looked at: the counters alternate between two sets, and a batch that is not
+  //  one-hot must leave the next one a clean set too)
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    hb.counts_next[0] = hb.counts_next[1] = hb.counts_next[2] = 0u;
   if (*one_hot == 0u) return;
   __shared__ uint32_t list[2][kHotChunk];
   __shared__ uint32_t wh[kHotWaves][kHotBins];
@@ -1198,9 +1203,14 @@ __global__ void __launch_bounds__(kHotBlock)
     jrow = S[base + kHotTile - 1u] >> kHotPosBits;
     owner = (S[base + kHotTile] >> kHotPosBits) == jrow &&
             !((S[base] >> kHotPosBits) == jrow && t > 0u && (S[base - 1u] >> kHotPosBits) == jrow);
-    if (owner) {
-      t2 = t + 1u;
-      while (t2 + 1u < nt && (S[(t2 + 1u) * kHotTile] >> kHotPosBits) == jrow) t2++;
+    if (owner) {  // last entry of the run: the list is sorted by row
+      uint32_t lo = base + kHotTile, hi = nh;  // S[lo] belongs to the run, S[hi] (if any) does not
+      while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((S[mid] >> kHotPosBits) == jrow) lo = mid;
+        else hi = mid;
+      }
+      t2 = lo / kHotTile;
     }
   }
   {
@@ -1209,10 +1219,14 @@ __global__ void __launch_bounds__(kHotBlock)
     const uint32_t ex = block_exclusive_scan<uint32_t, kHotBlock>(cnt, scan_smem, &nr);
     const uint32_t jx = block_exclusive_scan<uint32_t, kHotBlock>(owner ? 1u : 0u, scan_smem, &nj);
     if (threadIdx.x == 0) {
-      // (which block of slots / list entries the chunk gets does not matter)
-      hb.meta[2 * chunk + 1] = atomicAdd(hb.counts + 0, nr);
-      sh_ibase = atomicAdd(hb.counts + 2, nt);
-      sh_jbase = nj > 0u ? atomicAdd(hb.counts + 3, nj) : 0u;
+      // (which block of slots / list entries the chunk gets does not matter)  One 64-bit add
+      // takes both: pool slots in the low word, work items in the high word
+      const unsigned long long old =
+          atomicAdd(reinterpret_cast<unsigned long long*>(hb.counts),
+                    ((unsigned long long)nt << 32) | (unsigned long long)nr);
+      hb.meta[2 * chunk + 1] = (uint32_t)old;
+      sh_ibase = (uint32_t)(old >> 32);
+      sh_jbase = nj > 0u ? atomicAdd(hb.counts + 2, nj) : 0u;
     }
     __syncthreads();
     if (threadIdx.x < kHotTiles) {
@@ -1234,7 +1248,7 @@ __global__ void __launch_bounds__(kHotBlock)
 // a run inside the tile is a finished partial of its (row, chunk), the piece of a run that enters
 // / leaves the tile goes to head / tail
 template <int LPR, typename GradT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 5)  // (<= 102 VGPRs: leaves room for the other chain)
     hot_reduce_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot,
                       const GradT* __restrict__ grad, float* __restrict__ pool_end, HotBufs hb) {
   typedef typename Load4<GradT>::raw Raw;
@@ -1246,7 +1260,7 @@ __global__ void __launch_bounds__(kBlock)
   // the tile's entries + the one in front + the one behind, per lane group
   __shared__ uint32_t ent[GPB][kHotTile + 2];
   const int gq = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  const uint32_t n_items = hb.counts[2];
+  const uint32_t n_items = hb.counts[1];
   constexpr uint32_t kNoneRow = 0xFFFFFFFFu;
   for (uint32_t it = blockIdx.x * GPB + gq; it < n_items; it += gridDim.x * GPB) {
     const uint32_t item = hb.items[it];
@@ -1321,10 +1335,10 @@ __global__ void __launch_bounds__(kBlock)
                     HotBufs hb) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
-  constexpr int CU = 8;
+  constexpr int CU = 16;
   if (*one_hot == 0u) return;
   const int gq = threadIdx.x / LPR, l = threadIdx.x % LPR;
-  const uint32_t n_joins = hb.counts[3];
+  const uint32_t n_joins = hb.counts[2];
   for (uint32_t it = blockIdx.x * GPB + gq; it < n_joins; it += gridDim.x * GPB) {
     const uint32_t w = hb.joins[3 * (size_t)it], ri = hb.joins[3 * (size_t)it + 1];
     const uint32_t row = hb.joins[3 * (size_t)it + 2];
@@ -1427,12 +1441,6 @@ __global__ void __launch_bounds__(kBlock)
     }
     if (any) apply_row_vec4<LPR>(o, (uint64_t)row, l, acc, table, state0, state1, prev_time);
   }
-}
-
-// the lists are consumed: clean counters for the next update (after every reader, stream order)
-__global__ void hot_reset_kernel(const uint32_t* __restrict__ one_hot, uint32_t* counts) {
-  if (*one_hot == 0u) return;
-  counts[0] = counts[2] = counts[3] = 0u;
 }
 
 // any D: one wavefront per run, lanes stride over the vector
@@ -1774,7 +1782,10 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
         hb.tpref = u.hot_tpref;
         hb.items = u.hot_items;
         hb.joins = u.hot_joins;
-        hb.counts = u.hot_counts;
+        // counter sets alternate: [0..3] / [4..7]; [8] = pairs the sort kept
+        hb.counts = u.hot_counts + 4 * (u.hot_parity & 1u);
+        hb.counts_next = u.hot_counts + 4 * ((u.hot_parity + 1u) & 1u);
+        u.hot_parity++;
         hb.loc = u.hot_loc;
         hb.head = u.hot_head;
         hb.tail = u.hot_tail;
@@ -1788,7 +1799,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
           HCTR_HIP(hipStreamWaitEvent(cs, u.ev_fork, 0));
         }
         HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, cs, u.hot_rows,
-                                          u.hot_counts + 1, false)));
+                                          u.hot_counts + 8, false)));
         float* pool_end = u.gsum + u.max_nnz * (size_t)D;
         const size_t items_max = nnz / kHotTile + n_chunks;
         // both chains are grid-stride loops over a bounded number of workgroups: a kernel that
@@ -1825,9 +1836,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
           default: HCTR_HOT_CASE(64) break;
         }
 #undef HCTR_HOT_CASE
-        hipLaunchKernelGGL(hot_reset_kernel, dim3(1), dim3(1), 0, s, u.one_hot_flag, u.hot_counts);
-        HCTR_LAUNCH_CHECK();
-        n_live = u.hot_counts + 1;
+        n_live = u.hot_counts + 8;
         ss = cs;  // the segmented reduce follows the sort on the side stream
         hot_taken = true;
       } else if (need_sort) {
@@ -2077,8 +2086,8 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
       HCTR_HIP(hipMalloc(&hot_tpref, C * (kHotTiles + 1) * sizeof(uint32_t)));
       HCTR_HIP(hipMalloc(&hot_items, (max_nnz / kHotTile + C + 1) * sizeof(uint32_t)));
       HCTR_HIP(hipMalloc(&hot_joins, 3 * C * kHotTiles * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_counts, 4 * sizeof(uint32_t)));
-      HCTR_HIP(hipMemset(hot_counts, 0, 4 * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_counts, 12 * sizeof(uint32_t)));
+      HCTR_HIP(hipMemset(hot_counts, 0, 12 * sizeof(uint32_t)));
       const size_t part = (size_t)hot_chunks_max * kHotTiles * (size_t)D * sizeof(float);
       HCTR_HIP(hipMalloc(&hot_head, part));
       HCTR_HIP(hipMalloc(&hot_tail, part));

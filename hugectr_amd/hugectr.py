@@ -743,6 +743,8 @@ class Model:
         # -- exchange of the localized embeddings on N > 1 GPUs -----------------------------------
         self._intra = bool(s.train_intra_iteration_overlap) and self.world > 1
         self._inter = bool(s.train_inter_iteration_overlap) and self.world > 1
+        # one GPU: what the flag still overlaps is the sparse update under the bottom MLP's backward
+        self._upd_overlap = bool(s.train_intra_iteration_overlap) and self.world == 1
         want = os.environ.get("HCTR_EXCHANGE", "auto" if (self._intra and self._inter) else "rows")
         if want not in ("rows", "unique", "unique16", "auto"):
             raise RuntimeError("HCTR_EXCHANGE must be rows, unique, unique16 or auto")
@@ -790,6 +792,7 @@ class Model:
                         self._set_exchange(st, want)
             self._xstate[name] = st
         self._lookahead = None     # (batch i + 1) fetched early for the inter-iteration prefetch
+        self._upd_stream = None    # one GPU: the sparse update under the bottom MLP's backward
 
     def _set_exchange(self, st, mode: str):
         st["mode"] = mode
@@ -1218,6 +1221,30 @@ class Model:
         if st["fused_gather"]:
             h.index(train, ro, keys)
             got = {}
+            if train and self._upd_overlap and os.environ.get("HCTR_UPDATE_OVERLAP", "1") != "0":
+                # The sparse update needs the embedding's top gradient only, and the Interaction
+                # layer's backward hands that over BEFORE the bottom MLP's backward runs -- a chain
+                # of small kernels that leaves most of the chip idle.  The update starts from the
+                # gradient hook on a side stream (ordered behind the kernel that produced the
+                # gradient) and the step joins it before the dense optimizer step
+                # (solver.train_intra_iteration_overlap; HCTR_UPDATE_OVERLAP=0: in line).
+                if self._upd_stream is None:
+                    self._upd_stream = torch.cuda.Stream()
+                side = self._upd_stream
+
+                def on_grad(g):
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        h.backward(g)
+                        h.update_params()
+                    got["g"] = g  # (alive until the join: the allocator cannot hand it out before)
+
+                def finish():
+                    got.clear()
+                    torch.cuda.current_stream().wait_stream(side)
+                tensors[name] = _GatherEmb(h, train, on_grad)
+                after.append(finish)
+                return
             tensors[name] = _GatherEmb(h, train, (lambda g: got.__setitem__("g", g)) if train
                                        else None)
             if train:
