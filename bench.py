@@ -32,6 +32,19 @@ TOP = [1024, 1024, 512, 256, 1]   # top MLP
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy)
 
 
+def _csrc_hash():
+    """tools/csrc_hash.py: sha256 over the kernel sources, the stamp of the counter files"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hugectr_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) +
+                    glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def powerlaw(rng, n, vocab, alpha):
     """IntPowerLawDataSimulator (R/HugeCTR/include/data_generator.hpp:108-129), vectorised."""
     if alpha <= 0:
@@ -336,22 +349,25 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     pool_s = pool_ms / max(pool_n, 1) * 1e-3
     achieved = alg_bytes / pool_s / 1e9 if pool_ms > 0 else 0.0
     # HBM bytes per launch from the PMC counters (rocprofv3, separate passes, tools/measure_round.sh
-    # -> profiles/r3_pmc_hbm_traffic_<label>.json, stamped with the commit it was taken on; a bench
+    # -> profiles/r4_pmc_hbm_traffic_<label>.json, stamped with the kernel sources' hash; a bench
     # process cannot read the counters of its own kernels)
-    pmc, pmc_src, pmc_upd, pmc_idx = None, None, None, None
+    pmc, pmc_src, pmc_upd, pmc_idx, pmc_stale, mfma_busy = None, None, None, None, None, None
     tag = label or ("fp32" if esz == 4 else "fp16")
-    for rnd in ("r3", "r2"):
-        pmc_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic_{tag}.json")
-        if (world == 1 and D == 128 and a.batch == 65536 and a.table_scale == 1.0 and
-                os.path.exists(pmc_path)):
-            try:
-                j = json.load(open(pmc_path))
-                if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
+    here = _csrc_hash()
+    if world == 1 and D == 128 and a.batch == 65536 and a.table_scale == 1.0:
+        pmc_path = os.path.join(ROOT, "profiles", f"r4_pmc_hbm_traffic_{tag}.json")
+        try:
+            j = json.load(open(pmc_path))
+            if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
+                pmc_src = os.path.relpath(pmc_path, ROOT) + (
+                    f" @ {j['commit']}" if j.get("commit") else "")
+                # counters are quoted only while the kernel sources are the ones they were taken
+                # on (tools/csrc_hash.py; tools/measure_round.sh regenerates the files)
+                pmc_stale = j.get("csrc_hash") != here
+                if not pmc_stale:
                     ks = j["kernels"]
                     pmc = ks["interaction_fwd16_gather_kernel" if fused
                              else "pool_vec4_kernel"]["hbm_bytes_per_launch"]
-                    pmc_src = os.path.relpath(pmc_path, ROOT) + (
-                        f" @ {j['commit']}" if j.get("commit") else "")
 
                     def per_step(names, once):
                         # bytes per step of a group of kernels: per-launch average x launches per
@@ -362,14 +378,26 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                     if "seg_reduce_kernel" in ks:
                         pmc_upd = per_step(("expand_pairs_kernel", "rs_hist_kernel",
                                             "rs_colscan_kernel", "rs_scatter_kernel",
+                                            "hot_sort_kernel", "hot_reduce_kernel",
+                                            "hot_join_kernel", "hot_apply_kernel",
                                             "seg_reduce_kernel", "seg_combine_kernel",
                                             "seg_combine_big_kernel"), "seg_reduce_kernel")
                     if "ht_probe_insert_kernel" in ks:
                         pmc_idx = per_step(("ht_probe_insert_kernel", "ht_finish_kernel"),
                                            "ht_probe_insert_kernel")
-                    break
-            except Exception:
-                pmc = None
+        except Exception:
+            pmc = None
+        # matrix-pipe utilisation of the interaction kernels (SQ pass of tools/measure_round.sh)
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_sq_counters.json")))
+            if j.get("csrc_hash") == here and tag == "fp16":
+                mfma_busy = {k: {"mfma_util_of_1024_simds": v.get("mfma_util_of_1024_simds"),
+                                 "wave_cycles_split": v.get("wave_cycles_split")}
+                             for k, v in j["kernels"].items() if k.startswith("interaction_")}
+                mfma_busy["source"] = "profiles/r4_pmc_sq_counters.json" + (
+                    f" @ {j['commit']}" if j.get("commit") else "")
+        except Exception:
+            mfma_busy = None
     stage_us = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}
     # update (a12): SURVEY 8(d) bytes = nnz (8 + K) + B S_g D E (gradients read) + U D 4 x 2 (rows)
     upd_bytes = nnz_g * 16 + B * spr * D * esz + U * D * 4 * 2
@@ -421,7 +449,11 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                                 "pool_vec4_kernel (gather + intra-slot pooling)"),
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc,
-                     "traffic_source": pmc_src,
+                     "traffic_source": pmc_src, "traffic_stale": pmc_stale,
+                     # SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs' cycles, and where the waves'
+                     # cycles go, for the interaction kernels (north_star: "MFMA utilisation on the
+                     # interaction"); null when the counter file is not of these sources
+                     "mfma_busy": mfma_busy,
                      "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
                      "avg_launch_us": pool_s * 1e6,
                      # SURVEY 8(d) counts duplicate rows; power-law keys repeat hot rows, which L2
@@ -432,8 +464,10 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                      "frac_compulsory": (comp_bytes / pool_s / 1e9 / HBM_PEAK_GBPS)
                      if pool_ms > 0 else None,
                      "hbm_traffic_gbps": (pmc / pool_s / 1e9) if pmc and pool_ms > 0 else None},
-        "roofline_update": {"bound": "hbm", "kernels": "radix sort of (row, bucket) pairs + "
-                            "segmented reduce with the optimizer folded in + long-run combine",
+        "roofline_update": {"bound": "hbm", "kernels": "hot rows (per-chunk LDS sort, tile reduce, "
+                            "chunk-ordered apply) beside the cold pairs' radix sort + segmented "
+                            "reduce with the optimizer folded in; `us` = fork .. join of the two "
+                            "chains with the update in line (stage_us_per_step)",
                             "achieved": (upd_bytes / upd_s / 1e9) if upd_s > 0 else None,
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": (upd_bytes / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
@@ -782,15 +816,17 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
         ebc.backward_and_update(grad)
     both_us = timed(train)
     nnz = B * sum(hot)
-    pmc, pmc_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic_ebc.json")
+    pmc, pmc_src, pmc_stale = None, None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r4_pmc_hbm_traffic_ebc.json")
     if os.path.exists(pmc_path) and B == 65536 and D == 128 and abs(alpha - 1.1) < 1e-9:
         try:  # the gather kernel of this leg (rocprofv3 --pmc passes, tools/measure_round.sh)
             j = json.load(open(pmc_path))
             kern = ("pool_ptrs_vec4_kernel" if dynamic else
                     "pool_flat_kernel" if kind == "multi_hot" else "pool_vec4_kernel")
-            pmc = j["kernels"][kern]["hbm_bytes_per_launch"]
             pmc_src = f"{os.path.relpath(pmc_path, ROOT)} [{kern}] @ {j.get('commit', '?')}"
+            pmc_stale = j.get("csrc_hash") != _csrc_hash()  # (quoted for these sources only)
+            if not pmc_stale:
+                pmc = j["kernels"][kern]["hbm_bytes_per_launch"]
         except Exception:
             pmc = None
     # dynamic tables: + the 16-byte hash probe per key in place of the static index arithmetic
@@ -813,6 +849,7 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
                                                "lower bound on the gather kernel's own rate",
                      "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBPS, "traffic": pmc, "traffic_source": pmc_src,
+                     "traffic_stale": pmc_stale,
                      # duplicates counted: power-law keys repeat rows, which L2 /
                      # Infinity Cache serve -- `traffic` (PMC counters of the gather kernel) over
                      # the forward's time is what crossed the HBM interface
@@ -1041,6 +1078,13 @@ def main():
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha, dynamic=True))
         run("tiered", ("auto", "all", "next"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
         out["extra"] = extra
+        # the discriminating figures as top-level keys (a driver that keeps the head of the line
+        # sees them): the gather on uniform keys over big tables -- nothing cache-resident, no
+        # repeated row -- and the fp32 leg
+        if isinstance(extra.get("uniform_big_tables"), dict) and "roofline" in extra["uniform_big_tables"]:
+            out["roofline_uniform"] = extra["uniform_big_tables"]["roofline"]
+        if isinstance(extra.get("fp32"), dict) and "roofline" in extra["fp32"]:
+            out["roofline_fp32"] = extra["fp32"]["roofline"]
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             try:

@@ -277,6 +277,7 @@ struct hctr_embedding {
   bool presort_enabled = true;
   size_t cur_buckets = 0;
   size_t cur_nnz_bound = 0;
+  size_t eval_nnz = 0;  // keys of the last evaluation batch (host count)
   const void* top_grad = nullptr;
   bool has_train_batch = false;
 
@@ -493,6 +494,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     }
     e->prof.end(1, s);
   }
+  if (!is_train) e->eval_nnz = nnz;
   if (out == nullptr) {  // hctr_emb_index: resolve rows only (unique-row exchange)
     if (is_train) {
       e->cur_buckets = buckets;
@@ -815,6 +817,9 @@ int hctr_emb_forward_interaction(hctr_embedding* e, int is_train, const void* ml
                                 "before the interaction otherwise)");
   HCTR_REQUIRE(!is_train || e->has_train_batch, "forward_interaction before the index stage");
   const size_t batch = is_train ? e->p.train_batch_size : e->p.evaluate_batch_size;
+  // the kernel reads value_index as [sample][slot]: the indexed batch must hold one key per bucket
+  HCTR_REQUIRE((is_train ? e->cur_nnz_bound : e->eval_nnz) == batch * e->p.slot_num,
+               "forward_interaction: the indexed batch does not hold one key per bucket");
   hctr_embedding::BatchBufs& bb = is_train ? e->tb : e->eb;
   HCTR_REQUIRE(bb.value_index != nullptr, "batch size 0 configured for this mode");
   hipStream_t s = as_stream(stream);
@@ -876,11 +881,15 @@ size_t hctr_emb_get_max_vocabulary_size(const hctr_embedding* e) {
 
 size_t hctr_emb_slots_on_rank(const hctr_embedding* e) { return e ? e->buckets_per_sample() : 0; }
 
-int hctr_emb_check_overflow(hctr_embedding* e, hctr_stream_t stream) {
-  HCTR_REQUIRE(e, "null handle");
-  uint32_t f = 0;
-  HCTR_TRY(e->ht.error_flags(as_stream(stream), &f));
-  if (f != 0) {
+// error flags of the hash table: bit 4 = the index stage's grid barrier never opened (its workgroups
+// were not resident together); anything else = more distinct keys than rows
+static int report_ht_flags(uint32_t f) {
+  if ((f & 4u) != 0u) {
+    set_error("index stage: the cooperative finish kernel timed out at its grid barrier (device "
+              "partitioned or CU-masked below the kernel's grid?); the batch's unseen keys got no row");
+    return HCTR_ERR_HIP;
+  }
+  if (f != 0u) {
     // check_overflow, localized_slot_sparse_embedding_hash.hpp:552-569
     set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
     return HCTR_ERR_OVERFLOW;
@@ -888,15 +897,18 @@ int hctr_emb_check_overflow(hctr_embedding* e, hctr_stream_t stream) {
   return HCTR_OK;
 }
 
+int hctr_emb_check_overflow(hctr_embedding* e, hctr_stream_t stream) {
+  HCTR_REQUIRE(e, "null handle");
+  uint32_t f = 0;
+  HCTR_TRY(e->ht.error_flags(as_stream(stream), &f));
+  return report_ht_flags(f);
+}
+
 int hctr_emb_poll_overflow(hctr_embedding* e, hctr_stream_t stream) {
   HCTR_REQUIRE(e, "null handle");
   (void)stream;
   // the flags as the finish kernel of a completed index stage posted them (no copy, no sync)
-  if (*(volatile uint32_t*)e->h_err != 0u) {
-    set_error("embedding hash table overflow: more distinct keys than max_vocabulary_size_per_gpu");
-    return HCTR_ERR_OVERFLOW;
-  }
-  return HCTR_OK;
+  return report_ht_flags(*(volatile uint32_t*)e->h_err);
 }
 
 int hctr_emb_dump(hctr_embedding* e, int64_t* d_keys, uint64_t* d_slot_id, float* d_vectors,

@@ -311,6 +311,10 @@ __device__ __forceinline__ void st_agent(T* p, T v) {
 // sense-reversing barrier on {arrived, generation}.  __syncthreads: every wave has waited for
 // its (write-through) stores before thread 0 arrives.
 __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
+  // every thread waits for ITS OWN outstanding memory operations first (the no-return atomics on
+  // masks / region counts of phase A included): the workgroup barrier alone orders the waves, not
+  // the arrival of their atomics at the memory side -- a per-wave wait, no cache write-back
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   __shared__ uint32_t ok;
   if (threadIdx.x == 0) {
@@ -432,7 +436,16 @@ __global__ void __launch_bounds__(kFinBlock)
     }
   }
   if (!grid_barrier(c.barrier, G)) {
-    if (threadIdx.x == 0) atomicOr(c.error, 4u);
+    // the barrier never opened (the grid was not resident as a whole: a partitioned or masked
+    // device): no row can be handed out.  The pending positions of this workgroup's share get "no
+    // row" (they pool as zeros and the update skips them) instead of keeping PENDING | slot, the
+    // barrier words are put back so that the next batch starts clean, error bit 4 tells the host
+    for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) out[entry(k)] = kInvalidIndex;
+    if (threadIdx.x == 0) {
+      atomicOr(c.error, 4u);
+      st_agent(c.barrier, 0u);
+      if (c.host_error != nullptr) *c.host_error = *c.error;
+    }
     return;
   }
   // ---- S: every workgroup scans the region counts (into LDS); workgroup 0 hands out the row
@@ -786,9 +799,24 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   c.host_seq = x.host_seq;
   c.seq = x.seq;
   c.host_error = x.host_error;
-  // few positions: fewer workgroups (every one of them takes part in the barrier)
+  // few positions: fewer workgroups (every one of them takes part in the barrier), and never more
+  // than the device can hold at once (a CPX partition or a CU-masked device has far fewer than
+  // 256 CUs: a grid that is not resident as a whole could only time out at its barrier)
+  static const size_t resident = [] {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_finish_kernel, kFinBlock, 0) !=
+            hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        per_cu < 1 || cus < 1) {
+      (void)hipGetLastError();
+      return (size_t)kHtFinishBlocks;
+    }
+    return (size_t)per_cu * (size_t)cus;
+  }();
   size_t fg = ceil_div<size_t>(n, (size_t)kFinBlock * 4);
   if (fg > (size_t)kHtFinishBlocks) fg = kHtFinishBlocks;
+  if (fg > resident) fg = resident;
   if (fg < 1) fg = 1;
   hipLaunchKernelGGL(ht_finish_kernel, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n, d_n,
                      c, new_positions, sink, capacity);

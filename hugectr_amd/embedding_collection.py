@@ -665,8 +665,8 @@ class EmbeddingCollection:
 
     def backward_and_update(self, grad: torch.Tensor):
         if self._direct:  # the gradient of the output is the gradient of my buckets
-            if self._direct_avg:  # (in place when the caller's tensor is contiguous: it is ours)
-                grad = self._scale_average(grad.contiguous(), False)
+            if self._direct_avg:  # scaled in a copy: the caller's gradient tensor stays as it was
+                grad = self._scale_average(grad.contiguous().clone(), False)
             return self.apply_gradients(grad, True)
         send = self.network_backward(grad)
         top = self._a2a(send, self.recv_counts, self.send_counts)

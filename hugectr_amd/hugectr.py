@@ -336,6 +336,11 @@ class Input:
         self.label_name = self.label_names[0]
         self.dense_dim, self.dense_name = int(dense_dim), dense_name
         self.sparse_params: List[DataReaderSparseParam] = list(data_reader_sparse_param_array)
+        # label_weights_ of the reference (model_compile.cpp:748-765): the tasks' default weights
+        if label_weights is not None and len(list(label_weights)) != len(self.label_names):
+            raise RuntimeError("Input: label_weights and label_names differ in length")
+        self.label_weights = [float(w) for w in label_weights] if label_weights is not None \
+            else [1.0] * len(self.label_names)
 
 
 class LearningRateScheduler:
@@ -599,12 +604,19 @@ class Model:
         assert self.input is not None, "Model.add(Input(...)) first"
         # multi-task models (R/samples/mmoe): one BinaryCrossEntropyLoss per label, the training
         # loss is their weighted sum (Model::compile(loss_names, loss_weights), model.cpp)
-        self._loss_weights = {}
+        # Input(label_weights=...) seeds the weights, compile(loss_names, loss_weights) replaces
+        # the named ones and an unknown label name is an error (update_label_weights,
+        # R/HugeCTR/src/pybind/model_compile.cpp:748-765)
+        self._loss_weights = dict(zip(self.input.label_names, self.input.label_weights))
         if loss_names is not None:
             ws = list(loss_weights) if loss_weights is not None else [1.0] * len(list(loss_names))
             if len(ws) != len(list(loss_names)):
                 raise RuntimeError("compile: loss_names and loss_weights differ in length")
-            self._loss_weights = {str(n): float(w) for n, w in zip(loss_names, ws)}
+            for n, w in zip(loss_names, ws):
+                if str(n) not in self.input.label_names:
+                    raise RuntimeError(f"compile: '{n}' is not a label of this model "
+                                       f"(labels: {self.input.label_names})")
+                self._loss_weights[str(n)] = float(w)
         s = self.solver
         B, Be = s.batchsize, s.batchsize_eval
         self.bpg, self.bpg_eval = B // self.world, Be // self.world
@@ -1043,6 +1055,9 @@ class Model:
 
         def finish():
             e.lr = self._lr
+            if "back" not in box:  # the gradient hook never fired (output unused by the loss)
+                box.clear()
+                return
             top, w, _ = box.pop("back")
             e.backward_finish(top, w)
         after.append(finish)
@@ -1219,6 +1234,12 @@ class Model:
         S, D, W = p.slot_num, se.embedding_vec_size, self.world
         ro, keys = batch["sparse"][se.bottom_name]
         if st["fused_gather"]:
+            # (the fused kernel indexes value_index as [sample][slot]: one key per bucket, which the
+            #  reader's static parameters promise -- a batch of another size is refused here)
+            if keys.numel() != bpg * S or ro.numel() != bpg * S + 1:
+                raise RuntimeError(
+                    f"{name}: fixed-length one-hot input declared (is_fixed_length, max_nnz 1) but the "
+                    f"batch holds {keys.numel()} keys for {bpg * S} buckets")
             h.index(train, ro, keys)
             got = {}
             if train and self._upd_overlap and os.environ.get("HCTR_UPDATE_OVERLAP", "1") != "0":
@@ -1327,6 +1348,8 @@ class Model:
             return E
 
         def finish():
+            if "work" not in sent:  # no gradient arrived (the output does not reach the loss):
+                return              # nothing to exchange, nothing to update
             if sent.get("work") is not None:
                 sent["work"].wait()
             sent.clear()

@@ -142,6 +142,21 @@ static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, i
   *s = nullptr;
   return hipSuccess;
 }
+// (the interpreter runs every workgroup of a small grid on its own OS thread: "all resident")
+template <typename F>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) {
+  *n = 2;
+  return hipSuccess;
+}
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+static inline hipError_t hipGetDevice(int* d) {
+  *d = 0;
+  return hipSuccess;
+}
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+  *v = 256;
+  return hipSuccess;
+}
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) {
   return hipSuccess;
 }

@@ -209,13 +209,6 @@ def test_gather_fused_into_interaction_equals_pool_then_interaction(oracle, elib
     assert (out.view(np.uint16) == out2.view(np.uint16)).all()
 
 
-def test_no_collective_met_an_idle_lane(elib):
-    """(runs last in this file) no shuffle of the kernels exercised above read a lane that was not
-    taking part in it -- on the hardware such a read returns a stale register"""
-    s = emu.stats(elib)
-    assert s["launches"] > 100 and s["shfl_from_inactive"] == 0, s
-
-
 HOT_OPTS = [("sgd", dict(optimizer=6, atomic_update=0)), ("adagrad", dict(optimizer=3)),
             ("adam", dict(optimizer=1, update_type=0))]
 
@@ -283,3 +276,10 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
     assert (a.view(np.uint32) == b.view(np.uint32)).all(), "the hot path is not deterministic"
     c = run(0)
     assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
+
+
+def test_no_collective_met_an_idle_lane(elib):
+    """(runs last in this file) no shuffle of the kernels exercised above read a lane that was not
+    taking part in it -- on the hardware such a read returns a stale register"""
+    s = emu.stats(elib)
+    assert s["launches"] > 100 and s["shfl_from_inactive"] == 0, s

@@ -41,10 +41,12 @@ def main():
     ap.add_argument("--workload", default="")
     ap.add_argument("--alpha", type=float, default=1.1)
     ap.add_argument("--commit", default="")
+    ap.add_argument("--csrc-hash", default="")
     ap.add_argument("--skip-frac", type=float, default=0.4,
                     help="leading share of every kernel's launches left out (warm-up / cold inserts)")
     a = ap.parse_args()
     res = {"precision": a.precision, "workload": a.workload, "alpha": a.alpha, "commit": a.commit,
+           "csrc_hash": a.csrc_hash,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (with "
                      "--kernel-trace only), counter x 1024 B, gfx950 FETCH_SIZE x2 correction for "
                      "16-B/lane coalesced reads (MI355X_MICROARCH.md, section HBM); averages over the "
