@@ -750,6 +750,214 @@ def dlrm_ebc_model_leg(steps, warmup, dev, B=65536, alpha=1.1):
             "direct_one_gpu_path": bool(m._ebc[0]["train"]._direct)}
 
 
+def _timed_us(fn, it=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it * 1e3
+
+
+MFMA_PEAK_16 = 2500.0   # TFLOP/s dense, fp16 / bf16 (MI355X_MICROARCH.md)
+MFMA_PEAK_F32 = 157.3   # TFLOP/s, f32-input matrix instructions
+
+
+def interaction_leg(dev):
+    """the dot-interaction layer alone (a19) -- B in {8192, 65536}, 26 embeddings +
+    the bottom-MLP row, W = 128, N(0, 1) inputs (R/test/utest/layers/interaction_layer_test.cpp:96),
+    fp16 and fp32, forward and backward.  HBM-bound at these shapes (27 x 128 inputs, 8 MFMAs per
+    sample): bytes = B (n_ins W + W + n_ins (n_ins - 1) / 2 + 1) E forward, ~2x backward."""
+    from hugectr_amd import _lib
+    from hugectr_amd.layers import _DT
+    lib, ptr, check, sp = _lib.lib, _lib.ptr, _lib.check, _lib.stream_ptr
+    res = {}
+    n, W = 26, 128
+    n_ins = n + 1
+    for B in (8192, 65536):
+        for name, dt, E in (("fp16", torch.float16, 2), ("fp32", torch.float32, 4)):
+            # the C ABI directly, launches back to back (through autograd the host's ~100 us per
+            # call would be what is timed at B = 8192)
+            mlp = torch.randn(B, W, device=dev).to(dt)
+            emb = torch.randn(B, n, W, device=dev).to(dt)
+            out = torch.empty((B, W + n_ins * (n_ins - 1) // 2 + 1), dtype=dt, device=dev)
+            g = torch.randn(out.shape, device=dev).to(dt)
+            mg, eg = torch.empty_like(mlp), torch.empty_like(emb)
+            fwd = _timed_us(lambda: check(lib.hctr_interaction_fwd(
+                B, n, W, ptr(mlp), ptr(emb), ptr(out), _DT[dt], sp())), it=50)
+            bwd = _timed_us(lambda: check(lib.hctr_interaction_bwd(
+                B, n, W, ptr(mlp), ptr(emb), ptr(g), ptr(mg), ptr(eg), _DT[dt], sp())), it=50)
+            out_len = W + n_ins * (n_ins - 1) // 2 + 1
+            fb_bytes = B * (n_ins * W + out_len) * E
+            bw_bytes = B * (2 * n_ins * W + out_len) * E  # inputs + their gradients + dOut
+            flops = B * 2 * n_ins * n_ins * W
+            res[f"B{B}_{name}"] = {
+                "forward_us": fwd, "backward_us": bwd,
+                "roofline": {"bound": "hbm", "achieved": fb_bytes / fwd / 1e3, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": fb_bytes / fwd / 1e3 / HBM_PEAK_GBPS,
+                             "algorithmic_bytes": fb_bytes},
+                "roofline_backward": {"bound": "hbm", "achieved": bw_bytes / bwd / 1e3,
+                                      "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": bw_bytes / bwd / 1e3 / HBM_PEAK_GBPS,
+                                      "algorithmic_bytes": bw_bytes},
+                "mfma_tflops_forward": flops / fwd / 1e6,
+                "mfma_frac_of_peak": flops / fwd / 1e6 / (MFMA_PEAK_16 if E == 2 else MFMA_PEAK_F32)}
+            del mlp, emb, out, g, mg, eg
+    return {"workload": "SURVEY I1: InteractionLayer alone, n_emb=26, W=128, N(0,1) inputs",
+            "kernels": "interaction_fwd16 / bwd16 (v_mfma_f32_32x32x16_f16), fp32: 3x bf16-split MFMA",
+            "cases": res}
+
+
+def cross_leg(dev):
+    """MultiCrossLayer alone (a20).  v1 (projection_dim 0): B=1024, w=429, 6 layers
+    (the README DCN shape; B=16384 beside it, where the launch is no longer the cost) -- HBM-bound,
+    B w E 4 bytes per layer against the fused kernel's own B w 4 (1 + L).  v2: B=8192,
+    w=3456, p=512, 3 layers (the MLPerf DCNv2 tower, R/samples/dlrm/train.py:425-441) -- MFMA-bound,
+    4 B w p flops per layer forward, twice that backward."""
+    from hugectr_amd.layers import MultiCrossLayer
+    res = {}
+    for B in (1024, 16384):
+        w, L = 429, 6
+        layer = MultiCrossLayer(w, L, 0).to(dev)
+        x = torch.randn(B, w, device=dev, requires_grad=True)
+        out = layer(x)
+        g = torch.randn_like(out)
+        fwd = _timed_us(lambda: layer(x), it=50)
+
+        def both():
+            o = layer(x)
+            o.backward(g)
+            x.grad = None
+            layer.zero_grad(set_to_none=True)
+        fb = _timed_us(both, it=50)
+        alg = L * B * w * 4 * 4
+        own = B * w * 4 * (1 + L)
+        # (the fraction is quoted on the fused kernel's own bytes -- x0 read once, L outputs
+        #  written -- not on SURVEY's 4 arrays per layer, which a kernel that keeps the row in
+        #  registers never moves: that figure exceeds 1 at B = 16384)
+        res[f"v1_B{B}"] = {"forward_us": fwd, "forward_backward_us": fb,
+                           "roofline": {"bound": "hbm", "achieved": own / fwd / 1e3,
+                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": own / fwd / 1e3 / HBM_PEAK_GBPS,
+                                        "kernel_bytes": own, "survey_bytes_4_arrays_per_layer": alg}}
+    B, w, pdim, L = 8192, 3456, 512, 3
+    for name, dt, peak in (("fp16", torch.float16, MFMA_PEAK_16), ("fp32", torch.float32, MFMA_PEAK_F32)):
+        layer = MultiCrossLayer(w, L, pdim).to(dev)
+        x = torch.randn(B, w, device=dev).to(dt).requires_grad_(True)
+        out = layer(x)
+        g = torch.randn_like(out)
+        fwd = _timed_us(lambda: layer(x), it=10)
+
+        def both2():
+            o = layer(x)
+            o.backward(g)
+            x.grad = None
+            layer.zero_grad(set_to_none=True)
+        fb = _timed_us(both2, it=10)
+        flops = L * 4 * B * w * pdim
+        res[f"v2_B{B}_{name}"] = {
+            "forward_us": fwd, "forward_backward_us": fb, "activation_dtype": name,
+            "roofline": {"bound": "mfma", "achieved": flops / fwd / 1e6, "peak": peak,
+                         "unit": "TFLOP/s", "frac": flops / fwd / 1e6 / peak, "flops": flops},
+            "roofline_forward_backward": {"bound": "mfma", "achieved": 3 * flops / fb / 1e6,
+                                          "peak": peak, "unit": "TFLOP/s",
+                                          "frac": 3 * flops / fb / 1e6 / peak, "flops": 3 * flops}}
+        del layer, x, out, g
+    return {"workload": "SURVEY X1: MultiCrossLayer alone", "cases": res}
+
+
+def dcnv2_model_leg(steps, warmup, dev, B=65536, alpha=1.1):
+    """The model the reference ships for MLPerf (R/samples/dlrm/train.py:406-470): one multi-hot
+    input per table (214 keys per sample), an embedding_collection over the 26 MLPerf tables
+    (sum), bottom MLP, concat, MultiCross with projection_dim 512 x 3 layers, top MLP, BCE --
+    through hugectr.Model.train(), mixed precision, SGD.  One step = Model.train()."""
+    import shutil
+    import tempfile
+    import hugectr_amd.hugectr as hugectr
+    nb = 3
+    hot, sizes = MLPERF_HOTNESS, MLPERF_TABLES
+    tmp = tempfile.mkdtemp(prefix="hctr_bench_dcnv2_")
+    try:
+        rng = np.random.default_rng(78)
+        nk = sum(hot)
+        a = np.zeros((B * nb, 1 + 13 + nk), dtype="<u4")
+        col = 14
+        for v, h in zip(sizes, hot):
+            a[:, col:col + h] = powerlaw(rng, B * nb * h, v, alpha).reshape(B * nb, h).astype("<u4")
+            col += h
+        a[:, 0] = (a[:, 16] % 2).astype("<i4").view("<u4")
+        a[:, 1:14] = rng.random((B * nb, 13), dtype=np.float32).view("<u4")
+        f = os.path.join(tmp, "train_data.bin")
+        a.tofile(f)
+        del a
+        solver = hugectr.CreateSolver(max_eval_batches=1, batchsize_eval=B, batchsize=B, lr=0.005,
+                                      vvgpu=[[0]], repeat_dataset=True, i64_input_key=False,
+                                      use_mixed_precision=True, scaler=1024.0,
+                                      use_embedding_collection=True)
+        optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.SGD,
+                                            update_type=hugectr.Update_t.Local, atomic_update=True)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.RawAsync, source=[f], eval_source="",
+            check_type=hugectr.Check_t.Non, num_samples=B * nb, eval_num_samples=0,
+            slot_size_array=sizes,
+            async_param=hugectr.AsyncParam(1, 4, 512000, 4, 512, True, hugectr.Alignment_t.Non,
+                                           multi_hot_reader=True, is_dense_float=True))
+        m = hugectr.Model(solver, reader, optimizer)
+        m.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                                for i in range(26)]))
+        tables = [hugectr.EmbeddingTableConfig(name=str(i), max_vocabulary_size=v, ev_size=128)
+                  for i, v in enumerate(sizes)]
+        ebc = hugectr.EmbeddingCollectionConfig(use_exclusive_keys=True)
+        ebc.embedding_lookup(table_config=tables, bottom_name=[f"data{i}" for i in range(26)],
+                             top_name="sparse_embedding", combiner=["sum"] * 26)
+        names = [str(i) for i in range(26)]
+        ebc.shard(shard_matrix=[names], shard_strategy=[("mp", names)])
+        m.add(ebc)
+        L, T, A = hugectr.DenseLayer, hugectr.Layer_t, hugectr.Activation_t
+        m.add(L(layer_type=T.MLP, bottom_names=["dense"], top_names=["mlp1"],
+                num_outputs=BOTTOM, act_type=A.Relu))
+        m.add(L(layer_type=T.Concat, bottom_names=["sparse_embedding", "mlp1"],
+                top_names=["concat1"]))
+        m.add(L(layer_type=T.MultiCross, bottom_names=["concat1"], top_names=["interaction1"],
+                projection_dim=512, num_layers=3))
+        m.add(L(layer_type=T.MLP, bottom_names=["interaction1"], top_names=["mlp2"],
+                num_outputs=TOP, activations=[A.Relu] * 4 + [A.Non]))
+        m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["mlp2", "label"],
+                top_names=["loss"]))
+        m.compile()
+        batches = [m.reader.next_batch(True) for _ in range(nb)]
+        m.reader = _CycleReader(batches)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for _ in range(warmup):
+        m.train()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m.check_overflow()
+    w = 26 * 128 + 128
+    cross_flops = 3 * 3 * 4 * B * w * 512  # forward + backward of the three cross layers
+    return {"workload": "MLPerf DLRM-DCNv2 as R/samples/dlrm/train.py:406-470 builds it, through "
+                        f"hugectr.Model.train(): B={B}, 26 tables ({sum(sizes)} rows), 214 keys / "
+                        "sample (multi-hot, sum), D=128, bottom MLP 512-256-128, MultiCross "
+                        "projection 512 x 3 layers over 3456 columns, top MLP 1024-1024-512-256-1, "
+                        "SGD, use_mixed_precision (scaler 1024), batches resident in HBM",
+            "surface": "hugectr_amd.hugectr Model.train() + EmbeddingCollectionConfig + MultiCross",
+            "value": B * steps / el, "unit": "samples/s", "ms_per_step": el / steps * 1e3,
+            "steps": steps, "warmup": warmup, "final_loss": m.get_current_loss(),
+            "keys_per_batch": B * sum(hot), "cross_flops_per_step": cross_flops,
+            "direct_one_gpu_path": bool(m._ebc[0]["train"]._direct)}
+
+
 # R/samples/dlrm/train.py:29-83 (MLPerf DLRM-DCNv2): tables capped at 40 M rows, keys per sample
 MLPERF_TABLES = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282,
                  10, 2209, 11938, 155, 4, 976, 14, 40000000, 40000000, 40000000, 590152, 12973,
@@ -959,7 +1167,7 @@ def main():
                          "the reference), fp32 = the reference's default (everything fp32).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in both.")
     ap.add_argument("--extra", default="auto",
-                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next"],
+                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other precision on the same workload, `uniform_big_tables` (no key "
                          "repeats: the discriminating roofline), BASELINE configs[0] / [1] (DCN "
@@ -1070,6 +1278,10 @@ def main():
         run("c2", ("auto", "all"), lambda: small_config_leg("c2", 50, 20, dev))
         run("dlrm_ebc_model", ("auto", "all", "model"),
             lambda: dlrm_ebc_model_leg(a.extra_steps, 4, dev, alpha=a.alpha))
+        run("interaction", ("auto", "all", "dense"), lambda: interaction_leg(dev))
+        run("cross", ("auto", "all", "dense"), lambda: cross_leg(dev))
+        run("dcnv2_model", ("auto", "all", "model", "dcnv2"),
+            lambda: dcnv2_model_leg(a.extra_steps, 3, dev, alpha=a.alpha))
         run("ebc_one_hot", ("auto", "all", "ebc"),
             lambda: ebc_leg("one_hot", a.extra_steps, 3, dev, a.alpha))
         run("ebc_multi_hot", ("auto", "all", "ebc"),

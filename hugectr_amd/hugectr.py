@@ -1162,7 +1162,11 @@ class Model:
             if t == Layer_t.MLP and head is not None and i == self._head_layer:
                 fused_loss = self._mods[key].forward_bce(x[0].reshape(x[0].shape[0], -1), *head)
                 continue
-            if t in (Layer_t.InnerProduct, Layer_t.MLP, Layer_t.MultiCross, Layer_t.FmOrder2):
+            if t == Layer_t.MultiCross and self._mods[key].projection_dim > 0:
+                # v2 in the activations' own type: under use_mixed_precision the reference's
+                # MultiCrossLayer<__half> runs its GEMMs in fp16 (multi_cross_layer.cu:1023-1114)
+                y = self._mods[key](x[0].reshape(x[0].shape[0], -1))
+            elif t in (Layer_t.InnerProduct, Layer_t.MLP, Layer_t.MultiCross, Layer_t.FmOrder2):
                 y = self._mods[key](x[0].reshape(x[0].shape[0], -1).float()
                                     if t != Layer_t.MLP else x[0].reshape(x[0].shape[0], -1))
             elif t == Layer_t.WeightMultiply:
@@ -1180,7 +1184,11 @@ class Model:
             elif t == Layer_t.Dropout:
                 y = torch.nn.functional.dropout(x[0], L.dropout_rate, training=train)
             elif t == Layer_t.Concat:
-                y = torch.cat([v.reshape(v.shape[0], -1).float() for v in x], dim=1)
+                # (inputs of one type keep it -- under use_mixed_precision the tower stays fp16
+                #  between layers as the reference's __half layers do; mixed inputs: fp32)
+                same = all(v.dtype == x[0].dtype for v in x)
+                y = torch.cat([v.reshape(v.shape[0], -1) if same else
+                               v.reshape(v.shape[0], -1).float() for v in x], dim=1)
             elif t == Layer_t.Reshape:
                 if L.selected_slots:
                     y = x[0][:, list(L.selected_slots), :].reshape(x[0].shape[0], -1)

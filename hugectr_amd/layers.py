@@ -170,10 +170,74 @@ class _CrossV1Fn(torch.autograd.Function):
         return in_grad, kg, bg
 
 
+def _mm_f32(a, b):
+    """a @ b of 16-bit operands with an fp32 result (weight gradients: a sum over the whole batch
+    does not fit fp16's range at loss scale 1024)"""
+    if a.dtype in (torch.float16, torch.bfloat16):
+        try:
+            return torch.mm(a, b, out_dtype=torch.float32)
+        except (TypeError, NotImplementedError, RuntimeError):  # (no out_dtype on this backend)
+            return torch.mm(a.float(), b.float())
+    return torch.mm(a, b)
+
+
+class _CrossV2Fn(torch.autograd.Function):
+    """DCN-v2 cross layers, x_{l+1} = x0 * (x_l U_l V_l + b_l) + x_l, in the activations' own type
+    T (fp16 / bf16 under use_mixed_precision: the GEMMs run on the matrix cores; fp32 otherwise)
+    with fp32 master weights -- MultiCrossForwardFunctorv2 / MultiCrossBackwardFunctorv2
+    (R/HugeCTR/src/layers/multi_cross_layer.cu:582-700,732-812): per layer two GEMMs forward (the
+    bias rides in the second one's epilogue) and four backward (S1 = S0 V^T, dV = (XU)^T S0,
+    dU = X^T S1, dY_{l-1} = S1 U^T + dY_l with the residual in the GEMM's epilogue); S0 = dY .* x0
+    and the x0 gradient dY .* H accumulate in T as the reference's fused_mul_fma3 does.  Weight
+    and bias gradients leave as fp32."""
+
+    @staticmethod
+    def forward(ctx, x0, U, V, b):
+        T = x0.dtype
+        L = U.shape[0]
+        Ut, Vt, bt = U.to(T), V.to(T), b.to(T)
+        xs, ps, hs = [x0], [], []
+        xl = x0
+        for l in range(L):
+            pl = xl @ Ut[l]
+            h = torch.addmm(bt[l], pl, Vt[l])
+            xl = torch.addcmul(xl, x0, h)
+            ps.append(pl)
+            hs.append(h)
+            xs.append(xl)
+        ctx.save_for_backward(Ut, Vt, *xs[:-1], *ps, *hs)
+        ctx.L = L
+        return xl
+
+    @staticmethod
+    def backward(ctx, grad):
+        L = ctx.L
+        sv = ctx.saved_tensors
+        Ut, Vt = sv[0], sv[1]
+        xs, ps, hs = sv[2:2 + L], sv[2 + L:2 + 2 * L], sv[2 + 2 * L:2 + 3 * L]
+        x0 = xs[0]
+        dy = grad.contiguous()
+        acc = torch.zeros_like(x0)
+        wdt = torch.float32 if x0.dtype in (torch.float16, torch.bfloat16) else x0.dtype
+        dU = torch.empty(Ut.shape, dtype=wdt, device=x0.device)
+        dV = torch.empty(Vt.shape, dtype=wdt, device=x0.device)
+        db = torch.empty((L, x0.shape[1]), dtype=wdt, device=x0.device)
+        for l in range(L - 1, -1, -1):
+            s0 = dy * x0
+            acc.addcmul_(dy, hs[l])
+            s1 = s0 @ Vt[l].t()
+            dV[l] = _mm_f32(ps[l].t(), s0)
+            db[l] = s0.sum(0, dtype=wdt)
+            dU[l] = _mm_f32(xs[l].t(), s1)
+            dy = torch.addmm(dy, s1, Ut[l].t())
+        return acc + dy, dU, dV, db
+
+
 class MultiCrossLayer(torch.nn.Module):
     """DCN cross layers.  projection_dim == 0: v1 (x_{l+1} = x0 * (x_l . w_l) + b_l + x_l), all
     layers fused in one HIP launch.  projection_dim > 0: v2 (x_{l+1} = x0 * (x_l U_l V_l + b_l)
-    + x_l): the two GEMMs go to hipBLASLt through torch, the epilogue is fused in HIP."""
+    + x_l): the GEMMs go to hipBLASLt through torch in the activations' type (16-bit inputs: on the
+    matrix cores), bias and residual ride in GEMM epilogues (_CrossV2Fn)."""
 
     def __init__(self, width: int, num_layers: int, projection_dim: int = 0):
         super().__init__()
@@ -192,8 +256,4 @@ class MultiCrossLayer(torch.nn.Module):
     def forward(self, x0):
         if self.projection_dim == 0:
             return _CrossV1Fn.apply(x0, self.kernels, self.biases)
-        xl = x0
-        for l in range(self.num_layers):
-            h = (xl @ self.U[l]) @ self.V[l] + self.biases[l]
-            xl = x0 * h + xl
-        return xl
+        return _CrossV2Fn.apply(x0.contiguous(), self.U, self.V, self.biases)

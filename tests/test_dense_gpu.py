@@ -75,18 +75,40 @@ def test_cross_v1_fwd_bwd(oracle, B, w, L):
     assert_close(layer.biases.grad.cpu().numpy(), bg, 2e-4, 1e-4, "cross db")
 
 
-def test_cross_v2_matches_oracle(oracle):
+@pytest.mark.parametrize("dtype_name,rt,at", [("float32", 1e-3, 1e-4), ("float16", 2e-2, 2e-3),
+                                              ("bfloat16", 8e-2, 1e-2)])
+def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
+    """MultiCross v2 forward AND backward in the activations' type (fp32; fp16 / bf16 = the
+    reference's mixed-precision MultiCrossLayer<__half>: GEMMs in the 16-bit type, fp32 master
+    weights and weight gradients) against the fp32 oracle (CPU restatement of
+    multi_cross_layer_test.cpp's reference); 16-bit tolerances follow the type's rounding of the
+    [B, w] intermediates"""
     import torch
     import hugectr_amd as ha
+    dt = getattr(torch, dtype_name)
     rng = np.random.default_rng(11)
     B, w, p, L = 64, 96, 16, 3
-    x0 = (rng.standard_normal((B, w)) * 0.1).astype(np.float32)
+    x0 = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
     layer = ha.MultiCrossLayer(w, L, p).cuda()
+    with torch.no_grad():
+        layer.biases.normal_(0, 0.1)
     U = layer.U.detach().cpu().numpy(); V = layer.V.detach().cpu().numpy()
     b = layer.biases.detach().cpu().numpy()
-    out = layer(torch.from_numpy(x0).cuda())
-    outs, _, _ = oracle.cross_v2_fwd(x0, U, V, b)
-    assert_close(out.detach().cpu().numpy(), outs[-1], 1e-3, 1e-4, "cross v2 fwd")
+    xt = torch.from_numpy(x0).cuda().to(dt).requires_grad_(True)
+    x0r = xt.detach().float().cpu().numpy()  # (the oracle sees the rounded input)
+    out = layer(xt)
+    assert out.dtype == dt
+    outs, hid, xus = oracle.cross_v2_fwd(x0r, U, V, b)
+    assert_close(out.detach().float().cpu().numpy(), outs[-1], rt, at, "cross v2 fwd")
+    og = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
+    ogt = torch.from_numpy(og).cuda().to(dt)
+    out.backward(ogt)
+    ig, dU, dV, db = oracle.cross_v2_bwd(x0r, U, V, outs, hid, xus, ogt.float().cpu().numpy())
+    assert layer.U.grad.dtype == torch.float32 and layer.biases.grad.dtype == torch.float32
+    assert_close(xt.grad.float().cpu().numpy(), ig, rt, 4 * at, "cross v2 dx")
+    assert_close(layer.U.grad.cpu().numpy(), dU, rt, 8 * at, "cross v2 dU")
+    assert_close(layer.V.grad.cpu().numpy(), dV, rt, 8 * at, "cross v2 dV")
+    assert_close(layer.biases.grad.cpu().numpy(), db, rt, 8 * at, "cross v2 db")
 
 
 @pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
