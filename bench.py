@@ -289,6 +289,8 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
         elapsed = float(t.item())
     prof_timed = emb.profile()
     emb.profiling(False)
+    upd_overlapped = bool(getattr(m, "_upd_overlap", False) and getattr(m, "_upd_overlap_on", False)
+                          and (ov_prev or "auto") != "0")
     m.check_overflow()
     new_keys = (emb.get_vocabulary_size() - rows_before) / max(steps, 1)
     # The timed region runs the product's schedule: on one GPU the sparse update starts from the
@@ -485,9 +487,10 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
         # bottom MLP's backward -- shared-chip time, not the kernels' own)
         "stage_us_per_step_timed_region": {k: (v[0] / max(v[1], 1)) * 1e3
                                            for k, v in prof_timed.items()},
+        # (auto: the product switches it off when the update is a long bandwidth-bound kernel --
+        #  hugectr.py _overlap_update_now; this is the mode the timed region ended in)
         "update_overlapped_with_dense_backward": bool(
-            world == 1 and (ov_prev or "1") != "0" and
-            not a.no_overlap and xrep.get("gather_fused_into_interaction")),
+            upd_overlapped and xrep.get("gather_fused_into_interaction")),
         "stage_us_per_step_no_new_keys": steady_us,
         "embedding_ms_per_step": sum(stage_us.values()) * 1e-3,
     }

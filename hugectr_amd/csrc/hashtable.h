@@ -17,6 +17,7 @@ constexpr uint64_t kPendingBit = 1ull << 63;
 constexpr uint64_t kNoRow = kPendingBit - 1;
 constexpr int kHtTile = 1024;  // positions per compaction tile
 constexpr int kHtFinishBlocks = 128;  // workgroups of the cooperative finish kernel (co-resident)
+constexpr int kHtFinishBlocksMax = 512;  // upper bound of HCTR_HT_FINISH_BLOCKS
 
 // what get_insert can do on the side of its two launches (all optional)
 struct IndexExtras {

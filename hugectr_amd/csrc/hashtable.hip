@@ -1,17 +1,3 @@
-// (v2: see the finish kernel -- each finish workgroup owns the list segments of its share of the
-// probe workgroups, and keeps its first entries in registers between the two phases)
-// NOT BUILT, NOT THE PRODUCT PATH -- a variant of hugectr_amd/csrc/hashtable.hip measured at the end
-// of round 3 and kept for the next round (together with hashtable_segment_lists.h.txt):
-//   probe kernel: positions left pending go to a per-workgroup SEGMENT of the batch's list (LDS
-//   counter, wave-aggregated appends, counts published per workgroup) -- no global list counter;
-//   the finish kernel scans the segment counts into LDS and finds entry k by binary search.
-// Measured on MI355X (C3, 72 k unseen keys per step): probe 48 -> 36 us (steady 28.3 -> 26.7),
-// finish 36.5 -> 39.8 us.  Passed test_hash_gpu (incl. the many-batches stress test),
-// test_embedding_gpu, test_det_gpu, test_ebc_dynamic_gpu, test_golden_gpu in that form; NOT run:
-// the full `-m gpu` suite and batches of more than 4 M keys per call (several passes per
-// workgroup).  This file is the reconstruction of that state on top of the committed source
-// (compiles for gfx950); to try it: copy both files over csrc/hashtable.{hip,h}, make, run the
-// GPU tests.
 // hashtable.hip -- deterministic open-addressing hash map on gfx950.
 //
 // Semantics follow R/HugeCTR/src/hashtable/nv_hashtable.cu:169-303 +
@@ -36,6 +22,8 @@
 //                    Also posts the row counter / error flags to pinned host words and presets
 //                    the caller's one-hot flag of the next batch (no copy / memset launches).
 #include "hashtable.h"
+
+#include <cstdlib>
 
 #include "block_prims.h"
 
@@ -718,7 +706,7 @@ int HashTable::reserve(size_t n) {
   if (fin_masks) (void)hipFree(fin_masks);
   if (pend_list) (void)hipFree(pend_list);
   // (+ the finish kernel's per-workgroup counts and their scan)
-  HCTR_HIP(hipMalloc(&tile_sums, (need_tiles + 2 * kHtFinishBlocks) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&tile_sums, (need_tiles + 2 * kHtFinishBlocksMax) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&new_positions, (n > 0 ? n : 1) * sizeof(uint64_t)));
   mask_words = n / 64 + 2;
   HCTR_HIP(hipMalloc(&fin_masks, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
@@ -814,8 +802,16 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
     }
     return (size_t)per_cu * (size_t)cus;
   }();
+  // (HCTR_HT_FINISH_BLOCKS: the cap, for measurements; at most kHtFinishBlocksMax)
+  static const size_t cap = [] {
+    const char* e = getenv("HCTR_HT_FINISH_BLOCKS");
+    long v = e ? atol(e) : kHtFinishBlocks;
+    if (v < 1) v = 1;
+    if (v > kHtFinishBlocksMax) v = kHtFinishBlocksMax;
+    return (size_t)v;
+  }();
   size_t fg = ceil_div<size_t>(n, (size_t)kFinBlock * 4);
-  if (fg > (size_t)kHtFinishBlocks) fg = kHtFinishBlocks;
+  if (fg > cap) fg = cap;
   if (fg > resident) fg = resident;
   if (fg < 1) fg = 1;
   hipLaunchKernelGGL(ht_finish_kernel, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n, d_n,

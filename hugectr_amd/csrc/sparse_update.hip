@@ -1802,13 +1802,16 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                                           u.hot_counts + 8, false)));
         float* pool_end = u.gsum + u.max_nnz * (size_t)D;
         const size_t items_max = nnz / kHotTile + n_chunks;
-        // both chains are grid-stride loops over a bounded number of workgroups: a kernel that
-        // queues one workgroup per tile fills every wave slot of the device and the other
-        // stream's kernels only trickle in (measured: the sort's scatter 21 -> 96 us)
+        // the hot rows' reduce is a grid-stride loop over a bounded number of workgroups: a kernel
+        // that queues one workgroup per tile fills every wave slot of the device and the other
+        // chain's sort only trickles in (measured: its scatter 21 -> 96 us; 768 workgroups: 60 us).
+        // The cold chain's reduce keeps one workgroup per 8 tiles: with uniform keys it IS the
+        // update (2 GB), and a bounded grid sharing the chip with the dense tower's GEMMs was
+        // measured at + 1.6 ms per step (HCTR_SEG_GRID bounds it for measurements)
         const char* hg_env = getenv("HCTR_HOT_GRID");
         const char* sg_env = getenv("HCTR_SEG_GRID");
         const int hot_grid = hg_env ? atoi(hg_env) : 768;
-        seg_grid_cap = sg_env ? atoi(sg_env) : 1024;
+        if (sg_env) seg_grid_cap = atoi(sg_env);
         hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)n_chunks), dim3(kHotBlock), 0, s, hg,
                            u.one_hot_flag, vi, hb);
         HCTR_LAUNCH_CHECK();

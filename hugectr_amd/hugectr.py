@@ -805,6 +805,8 @@ class Model:
             self._xstate[name] = st
         self._lookahead = None     # (batch i + 1) fetched early for the inter-iteration prefetch
         self._upd_stream = None    # one GPU: the sparse update under the bottom MLP's backward
+        self._upd_timing = []      # (overlapped?, (start, end) events) of recent updates
+        self._upd_overlap_on = True
 
     def _set_exchange(self, st, mode: str):
         st["mode"] = mode
@@ -1232,6 +1234,32 @@ class Model:
             tensors[L.top_names[0]] = y
         return logit, fused_loss
 
+    def _overlap_update_now(self) -> bool:
+        """one GPU: should this step's sparse update run under the bottom MLP's backward?  The two
+        share the chip, which pays while the update is about as long as that backward (power-law
+        keys: 0.27 ms next to 0.22 ms, - 65 us per step) and costs dearly when it is a long
+        bandwidth-bound kernel (uniform keys over big tables: 2 GB of row read-modify-writes --
+        the dense kernels beside it were measured at 10-16 x their own time, + 1.6 ms per step).
+        auto: the update's own duration, taken with events two or more steps back (never waited
+        for), switches the mode with hysteresis -- above 0.6 ms overlapped -> in line, below
+        0.35 ms in line -> overlapped."""
+        mode = os.environ.get("HCTR_UPDATE_OVERLAP", "auto")
+        if mode == "0":
+            return False
+        if mode == "1":
+            return True
+        q = self._upd_timing
+        while len(q) > 1 or (q and q[0][1][1].query()):
+            was_overlapped, (e0, e1) = q.pop(0)
+            if not e1.query():  # (older than the newest and still running: cannot be; skip)
+                continue
+            ms = e0.elapsed_time(e1)
+            if was_overlapped and ms > 0.6:
+                self._upd_overlap_on = False
+            elif not was_overlapped and ms < 0.35:
+                self._upd_overlap_on = True
+        return self._upd_overlap_on
+
     def _emb_forward(self, name, batch, nxt, train: bool, tensors, leaves, after):
         """forward of one legacy embedding into `tensors[name]`; `after` collects what has to run
         once backward is through (wait for the gradient exchange, backward + sparse update)"""
@@ -1250,28 +1278,45 @@ class Model:
                     f"batch holds {keys.numel()} keys for {bpg * S} buckets")
             h.index(train, ro, keys)
             got = {}
-            if train and self._upd_overlap and os.environ.get("HCTR_UPDATE_OVERLAP", "1") != "0":
+            if train and self._upd_overlap and self._overlap_update_now():
                 # The sparse update needs the embedding's top gradient only, and the Interaction
                 # layer's backward hands that over BEFORE the bottom MLP's backward runs -- a chain
                 # of small kernels that leaves most of the chip idle.  The update starts from the
                 # gradient hook on a side stream (ordered behind the kernel that produced the
                 # gradient) and the step joins it before the dense optimizer step
-                # (solver.train_intra_iteration_overlap; HCTR_UPDATE_OVERLAP=0: in line).
+                # (solver.train_intra_iteration_overlap; HCTR_UPDATE_OVERLAP=0: in line, 1: always,
+                # auto: see _overlap_update_now).
                 if self._upd_stream is None:
                     self._upd_stream = torch.cuda.Stream()
                 side = self._upd_stream
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
                 def on_grad(g):
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
+                        ev[0].record()
                         h.backward(g)
                         h.update_params()
+                        ev[1].record()
                     got["g"] = g  # (alive until the join: the allocator cannot hand it out before)
 
                 def finish():
                     got.clear()
                     torch.cuda.current_stream().wait_stream(side)
+                    self._upd_timing.append((True, ev))
                 tensors[name] = _GatherEmb(h, train, on_grad)
+                after.append(finish)
+                return
+            if train and self._upd_overlap:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+                def finish():
+                    ev[0].record()
+                    h.backward(got.pop("g"))
+                    h.update_params()
+                    ev[1].record()
+                    self._upd_timing.append((False, ev))
+                tensors[name] = _GatherEmb(h, train, lambda g: got.__setitem__("g", g))
                 after.append(finish)
                 return
             tensors[name] = _GatherEmb(h, train, (lambda g: got.__setitem__("g", g)) if train
