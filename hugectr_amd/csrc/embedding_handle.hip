@@ -323,13 +323,20 @@ int reset_opt_states(hctr_embedding* e, hipStream_t s) {
   const size_t elems = e->p.max_vocabulary_size_per_gpu * e->p.embedding_vec_size;
   // EmbeddingOptimizer::initialize, sparse_optimizer.cu:111-168.  AdaGrad: the reference memsets
   // BYTES with initial_accu_value (only right for 0); we fill the float value.
+  // (fp16 embeddings: the state arrays are __half arrays, optimizer.hpp:284-296)
+  const bool half = e->opt.state_half != 0;
   if (e->state0) {
     const float v0 = e->p.optimizer == HCTR_OPT_ADAGRAD ? e->p.initial_accu_value : 0.0f;
-    hipLaunchKernelGGL(fill_kernel<float>, dim3(grid_for(elems, 256, 8192)), dim3(256), 0, s,
-                       e->state0, elems, v0);
+    if (half)
+      hipLaunchKernelGGL(fill_kernel<__half>, dim3(grid_for(elems, 256, 8192)), dim3(256), 0, s,
+                         reinterpret_cast<__half*>(e->state0), elems, __float2half_rn(v0));
+    else
+      hipLaunchKernelGGL(fill_kernel<float>, dim3(grid_for(elems, 256, 8192)), dim3(256), 0, s,
+                         e->state0, elems, v0);
     HCTR_LAUNCH_CHECK();
   }
-  if (e->state1) HCTR_HIP(hipMemsetAsync(e->state1, 0, elems * sizeof(float), s));
+  if (e->state1)
+    HCTR_HIP(hipMemsetAsync(e->state1, 0, elems * (half ? sizeof(__half) : sizeof(float)), s));
   if (e->prev_time) {
     hipLaunchKernelGGL(fill_kernel<uint64_t>, dim3(grid_for(elems, 256, 8192)), dim3(256), 0, s,
                        e->prev_time, elems, (uint64_t)1);
@@ -616,8 +623,10 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   } while (0)
   HCTR_ALLOC(e->table, V * D * sizeof(float));
   const int ns = num_states(p.optimizer);
-  if (ns >= 1) HCTR_ALLOC(e->state0, V * D * sizeof(float));
-  if (ns >= 2) HCTR_ALLOC(e->state1, V * D * sizeof(float));
+  // the state of fp16 embeddings is stored in fp16 (OptimizerTensor<__half>, optimizer.hpp:284-296)
+  const size_t state_elem = p.out_dtype == HCTR_EMB_F16 ? sizeof(__half) : sizeof(float);
+  if (ns >= 1) HCTR_ALLOC(e->state0, V * D * state_elem);
+  if (ns >= 2) HCTR_ALLOC(e->state1, V * D * state_elem);
   if (p.optimizer == HCTR_OPT_ADAM && p.update_type == HCTR_UPDATE_LAZY_GLOBAL)
     HCTR_ALLOC(e->prev_time, V * D * sizeof(uint64_t));
   HCTR_ALLOC(e->slot_id, V * sizeof(uint64_t));

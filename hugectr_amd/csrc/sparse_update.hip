@@ -188,8 +188,9 @@ struct OptConst {
 // OptimizerTensor<TypeEmbeddingComp> (R/HugeCTR/include/optimizer.hpp:284-296): with fp16 embeddings
 // the reference keeps m / v / accumulators in fp16 -- every kernel converts the stored value to
 // float, computes in float and converts the result back on the store; the weight update of the
-// same step uses the unrounded float.  Here the state arrays stay fp32 and hold fp16-representable
-// values: same numbers, the footprint saving is not taken.
+// same step uses the unrounded float.  Here too (round 4): with state_half the state arrays ARE
+// __half arrays (half the footprint and the traffic of the fp32 arrays rounds 1-3 kept); the
+// pointers travel as float* and are re-typed where they are dereferenced (ld_state / st_state).
 __device__ __forceinline__ float state_store(int state_half, float x) {
   if (!state_half) return x;
   // the fp32 result first, THEN the conversion (two roundings, as the reference's float math +
@@ -197,6 +198,32 @@ __device__ __forceinline__ float state_store(int state_half, float x) {
   // mixed-precision instruction that rounds the exact product straight to fp16
   asm volatile("" : "+v"(x));
   return __half2float(__float2half_rn(x));
+}
+
+// element f of a state array / the four elements from f on (f a multiple of 4)
+__device__ __forceinline__ float ld_state1(const float* base, size_t f, int half) {
+  return half ? __half2float(reinterpret_cast<const __half*>(base)[f]) : base[f];
+}
+__device__ __forceinline__ void st_state1(float* base, size_t f, int half, float v) {
+  if (half) reinterpret_cast<__half*>(base)[f] = __float2half_rn(v);  // (v is fp16-valued: exact)
+  else base[f] = v;
+}
+__device__ __forceinline__ float4 ld_state4(const float* base, size_t f, int half) {
+  if (half)
+    return Load4<__half>::cvt(
+        *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(base) + f));
+  return *reinterpret_cast<const float4*>(base + f);
+}
+__device__ __forceinline__ void st_state4(float* base, size_t f, int half, const float4& v) {
+  if (half) {
+    const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<const uint32_t*>(&a);
+    u.y = *reinterpret_cast<const uint32_t*>(&b);
+    *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(base) + f) = u;
+  } else {
+    *reinterpret_cast<float4*>(base + f) = v;
+  }
 }
 
 // internal pseudo-optimizer of hctr_updater_reduce_presorted: table[row] = gradient sum (no read)
@@ -312,8 +339,8 @@ __device__ __forceinline__ void row_load(const OptConst& o, uint64_t row, int l,
   if (o.optimizer != kOptStoreSum) r.w = *reinterpret_cast<const float4*>(table + f);
   r.s1 = r.s0;
   r.pt[0] = r.pt[1] = r.pt[2] = r.pt[3] = 1ull;
-  if (needs_s0(o)) r.s0 = *reinterpret_cast<const float4*>(state0 + f);
-  if (needs_s1(o)) r.s1 = *reinterpret_cast<const float4*>(state1 + f);
+  if (needs_s0(o)) r.s0 = ld_state4(state0, f, o.state_half);
+  if (needs_s1(o)) r.s1 = ld_state4(state1, f, o.state_half);
   if (needs_pt(o)) {
 #pragma unroll
     for (int t = 0; t < 4; t++) r.pt[t] = prev_time[f + t];
@@ -341,8 +368,8 @@ __device__ __forceinline__ void row_store(const OptConst& o, uint64_t row, int l
   const bool w_written = !((o.optimizer == HCTR_OPT_ADAM || o.optimizer == HCTR_OPT_MOMENTUM_SGD) &&
                            o.update_type == HCTR_UPDATE_GLOBAL);
   if (w_written) *reinterpret_cast<float4*>(table + f) = r.w;
-  if (needs_s0(o)) *reinterpret_cast<float4*>(state0 + f) = r.s0;
-  if (needs_s1(o)) *reinterpret_cast<float4*>(state1 + f) = r.s1;
+  if (needs_s0(o)) st_state4(state0, f, o.state_half, r.s0);
+  if (needs_s1(o)) st_state4(state1, f, o.state_half, r.s1);
   if (needs_pt(o)) {
 #pragma unroll
     for (int t = 0; t < 4; t++) prev_time[f + t] = r.pt[t];
@@ -1481,13 +1508,13 @@ __global__ void __launch_bounds__(kBlock)
       gi /= o.scaler;
       const size_t f = row * (uint64_t)D + v;
       float w = table[f];
-      float s0 = needs_s0(o) ? state0[f] : 0.f;
-      float s1 = needs_s1(o) ? state1[f] : 0.f;
+      float s0 = needs_s0(o) ? ld_state1(state0, f, o.state_half) : 0.f;
+      float s1 = needs_s1(o) ? ld_state1(state1, f, o.state_half) : 0.f;
       unsigned long long pt = needs_pt(o) ? prev_time[f] : 1ull;
       apply_opt(o, gi, w, &s0, &s1, &pt);
       table[f] = w;
-      if (needs_s0(o)) state0[f] = s0;
-      if (needs_s1(o)) state1[f] = s1;
+      if (needs_s0(o)) st_state1(state0, f, o.state_half, s0);
+      if (needs_s1(o)) st_state1(state1, f, o.state_half, s1);
       if (needs_pt(o)) prev_time[f] = pt;
     }
   }
@@ -1530,10 +1557,10 @@ __global__ void __launch_bounds__(kBlock)
   // adam_update_kernel_global :269-288
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
-    float mi = beta1 * m[i];
-    float vi = beta2 * v[i];
-    m[i] = state_store(state_half, mi);
-    v[i] = state_store(state_half, vi);
+    float mi = beta1 * ld_state1(m, i, state_half);
+    float vi = beta2 * ld_state1(v, i, state_half);
+    st_state1(m, i, state_half, state_store(state_half, mi));
+    st_state1(v, i, state_half, state_store(state_half, vi));
     w[i] += -alpha_t * mi / (sqrtf(vi) + eps);
   }
 }
@@ -1544,10 +1571,10 @@ __global__ void __launch_bounds__(kBlock)
   // momentum_sgd_update_kernel_global :316-329
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
-    float m = mo[i];
+    float m = ld_state1(mo, i, state_half);
     m *= factor;
     w[i] += m;
-    mo[i] = state_store(state_half, m);
+    st_state1(mo, i, state_half, state_store(state_half, m));
   }
 }
 
@@ -1557,9 +1584,9 @@ __global__ void __launch_bounds__(kBlock)
   // nesterov_global_update_kernel_global :333-347
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
-    float a = accm[i];
+    float a = ld_state1(accm, i, state_half);
     a *= mu;
-    accm[i] = state_store(state_half, a);
+    st_state1(accm, i, state_half, state_store(state_half, a));
     w[i] += a * mu;
   }
 }

@@ -335,11 +335,13 @@ class SparseEmbeddingHash:
                           torch.float32)
 
     def opt_state(self, k: int) -> Optional[torch.Tensor]:
+        """[max_vocab, D] view of optimizer state k (no copy): fp32, or fp16 with fp16 embeddings
+        (OptimizerTensor<TypeEmbeddingComp>, R/HugeCTR/include/optimizer.hpp:284-296)"""
         addr = lib.hctr_emb_opt_state_ptr(self._h, k)
         if not addr:
             return None
         return self._view(addr, (self.max_vocabulary_size_per_gpu, self.embedding_vec_size),
-                          torch.float32)
+                          torch.float16 if self.out_dtype == torch.float16 else torch.float32)
 
     def value_index(self, nnz: int) -> torch.Tensor:
         addr = lib.hctr_emb_value_index_ptr(self._h)

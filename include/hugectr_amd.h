@@ -225,7 +225,9 @@ int hctr_emb_dump(hctr_embedding* emb, int64_t* d_keys, uint64_t* d_slot_id, flo
                   size_t* count, hctr_stream_t stream);
 int hctr_emb_load(hctr_embedding* emb, const int64_t* d_keys, const uint64_t* d_slot_id,
                   const float* d_vectors, size_t count, hctr_stream_t stream);
-/* raw device views (owned by the handle): table [max_vocab][D] fp32, optimizer state k */
+/* raw device views (owned by the handle): table [max_vocab][D] fp32, optimizer state k
+ * [max_vocab][D] -- fp32, or __half when out_dtype is HCTR_EMB_F16: the reference's
+ * OptimizerTensor<TypeEmbeddingComp> (R/HugeCTR/include/optimizer.hpp:284-296) */
 float* hctr_emb_table_ptr(hctr_embedding* emb);
 float* hctr_emb_opt_state_ptr(hctr_embedding* emb, int k);
 const uint64_t* hctr_emb_value_index_ptr(hctr_embedding* emb);

@@ -30,6 +30,9 @@ _libs = {}
 
 
 def load(csrc=None, tag=None):
+    # (the interpreter keeps at most 128 workgroups alive at once -- HIPEMU_MAX_WORKERS: the index
+    #  stage's cooperative finish kernel must not ask for more)
+    os.environ.setdefault("HCTR_HT_FINISH_BLOCKS", "128")
     key = tag or ""
     if key not in _libs:
         lib = ctypes.CDLL(build(csrc, tag))
@@ -180,7 +183,11 @@ class Embedding:
 
     def opt_state(self, k):
         a = self.lib.hctr_emb_opt_state_ptr(self.h, k)
-        return self._view(a, (self.vocab, self.D), np.float32) if a else None
+        if not a:
+            return None
+        if self.out_dtype == 1:  # fp16 embeddings keep their optimizer state in fp16
+            return self._view(a, (self.vocab, self.D), np.float16).astype(np.float32)
+        return self._view(a, (self.vocab, self.D), np.float32)
 
     def value_index(self, nnz):
         return self._view(self.lib.hctr_emb_value_index_ptr(self.h), (nnz,), np.uint64)

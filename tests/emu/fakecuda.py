@@ -158,6 +158,9 @@ def _install(variant=None):
     tc.is_current_stream_capturing = lambda: False
     tc.graphs.is_current_stream_capturing = lambda: False
     os.environ.setdefault("HCTR_HIP_GRAPH", "0")  # (no capture here: the eager schedule runs)
+    # (the interpreter keeps at most 128 workgroups alive at once: the index stage's cooperative
+    #  finish kernel must not ask for more)
+    os.environ.setdefault("HCTR_HT_FINISH_BLOCKS", "128")
     tc.manual_seed = lambda s: None
     tc.manual_seed_all = lambda s: None
     torch.Tensor.is_cuda = property(lambda self: True)

@@ -640,8 +640,8 @@ def test_fp16_embedding_keeps_fp16_valued_optimizer_state(oracle, name, kw):
         for k, want in ((0, s0), (1, s1)):
             if want is None:
                 continue
-            got = emb.opt_state(k).cpu().numpy()
-            assert (got == got.astype(np.float16).astype(np.float32)).all(), "state not fp16-valued"
+            assert emb.opt_state(k).dtype == torch.float16, "the state of fp16 embeddings is stored in fp16"
+            got = emb.opt_state(k).float().cpu().numpy()
             if name == "adam_lazy":  # powf is not correctly rounded: allow an fp16 ulp
                 assert_close(got, want, 1e-3, 1e-7, f"{name} state{k} it{it}")
             else:  # float multiply / add, then ONE conversion: the same bits as the oracle
