@@ -8,7 +8,6 @@ TAG=${1:-v1}
 cd /root/repo
 COMMIT=$(git rev-parse --short HEAD 2>/dev/null || cat tools/.commit 2>/dev/null || echo unknown)
 HASH=$(python tools/csrc_hash.py)
-python bench.py > gpurun_out/r4_bench_n1_$TAG.json 2> gpurun_out/r4_bench_n1_$TAG.err
 cd /tmp && export TMPDIR=/tmp
 W="--extra none --no-cpu-baseline --steps 30 --warmup 8"
 rm -rf /tmp/ks
@@ -33,3 +32,9 @@ if [ "$2" = "all" ]; then
   pmc uniform_big_tables 0.0 --extra uniform --steps 2 --warmup 2 --extra-steps 10 --no-cpu-baseline
   pmc ebc 1.1 --extra ebc --steps 2 --warmup 2 --extra-steps 6 --no-cpu-baseline
 fi
+# the bench line last: it quotes the counter files of THIS run (same sources, same box)
+cd /root/repo
+cp gpurun_out/r4_pmc_hbm_traffic_fp16.json profiles/ 2>/dev/null
+cp gpurun_out/r4_pmc_hbm_traffic_uniform_big_tables.json gpurun_out/r4_pmc_hbm_traffic_ebc.json profiles/ 2>/dev/null
+cp gpurun_out/r4_pmc_sq_counters_$TAG.json profiles/r4_pmc_sq_counters.json
+python bench.py > gpurun_out/r4_bench_n1_$TAG.json 2> gpurun_out/r4_bench_n1_$TAG.err
