@@ -181,6 +181,8 @@ _SIGNATURES = {
     "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,
                                               c_size_t, _P, _P]),
     "hctr_emb_index": (c_int, [_P, c_int, _P, _P, c_size_t, _P]),
+    "hctr_emb_index_ahead": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "hctr_emb_index_adopt": (c_int, [_P]),
     "hctr_emb_update_rows": (c_int, [_P, c_size_t, _P, _P, _P, c_int, _P]),
     "hctr_relu_bwd_bias_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_relu_bwd_bias": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, c_int, _P]),

@@ -10,6 +10,7 @@
 #include <hip/hip_fp16.h>
 
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "block_prims.h"
@@ -246,6 +247,12 @@ struct hctr_embedding {
     uint32_t* one_hot = nullptr;  // device flag: every bucket of the filtered CSR holds one key
   };
   BatchBufs tb, eb;
+  // a second set of training buffers: hctr_emb_index_ahead resolves the NEXT batch into it while
+  // the current batch's update still reads tb (hctr_emb_index_adopt swaps the two)
+  BatchBufs tb_spare;
+  bool ahead_valid = false;
+  size_t ahead_buckets = 0, ahead_nnz = 0;
+  const uint32_t* ahead_one_hot = nullptr;
   void*& ro = tb.ro;
   uint64_t*& value_index = tb.value_index;
   void* lens = nullptr;  // key-typed [buckets_max] scratch
@@ -267,7 +274,9 @@ struct hctr_embedding {
   uint64_t seq = 0, min_valid_seq = 1, cum_total = 0;
   uint64_t cum_keys[kSeqRing] = {0};
   uint32_t* h_err = nullptr;  // pinned copy of the hash table's error flags (poll_overflow)
-  uint32_t flip = 0;          // parity of the training batch's one-hot flag (tb.one_hot[2])
+  uint32_t flip = 0;          // the training batch's one-hot flag is word flip % 4 of tb.one_hot
+                              // (two batches can be in flight: the word of batch i is preset
+                              //  again by the finish kernel of batch i + 3 at the earliest)
   const uint32_t* cur_one_hot = nullptr;  // the flag word of the batch update_params will take
                                           // (world == 1 only: the sort reads the rows in place)
   size_t last_exact_nnz = 0;     // world > 1: exact live nnz of the previous train batch
@@ -299,7 +308,8 @@ int free_all(hctr_embedding* e) {
   void* ptrs[] = {e->table,  e->state0,  e->state1,         e->prev_time, e->slot_id,
                   e->tb.ro,  e->tb.keys, e->tb.value_index, e->eb.ro,     e->eb.keys,
                   e->eb.value_index,     e->lens,           e->tile_sums, e->d_nnz,
-                  e->tb.ro_full,         e->eb.ro_full,     e->tb.one_hot, e->eb.one_hot};
+                  e->tb.ro_full,         e->eb.ro_full,     e->tb.one_hot, e->eb.one_hot,
+                  e->tb_spare.ro,        e->tb_spare.value_index};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (e->h_nnz) (void)hipHostFree(e->h_nnz);
@@ -422,14 +432,17 @@ int filter_keys(hctr_embedding* e, hctr_embedding::BatchBufs& bb, size_t batch, 
   return HCTR_OK;
 }
 
+// ahead: index-only call for the batch AFTER the current one (hctr_emb_index_ahead): resolved into
+// tb_spare, the handle's current training batch stays what it is
 template <typename K>
 int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys_in, size_t nnz,
-                  void* out, hipStream_t s) {
+                  void* out, hipStream_t s, bool ahead = false) {
   const size_t batch = is_train ? e->p.train_batch_size : e->p.evaluate_batch_size;
   const K *ro = nullptr, *keys = nullptr;
   size_t buckets = 0;
-  hctr_embedding::BatchBufs& bb = is_train ? e->tb : e->eb;
+  hctr_embedding::BatchBufs& bb = ahead ? e->tb_spare : (is_train ? e->tb : e->eb);
   HCTR_REQUIRE(bb.ro != nullptr, "forward: batch size 0 configured for this mode");
+  if (is_train && !ahead) e->ahead_valid = false;  // (a batch indexed ahead is stale now)
   // the training index stage is two launches: its probe kernel also copies / checks the row
   // offsets (world == 1), its finish kernel presets the next batch's one-hot flag and posts the
   // row counter + error flags to pinned host words
@@ -437,8 +450,8 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   uint32_t* one_hot = bb.one_hot;
   uint32_t* one_hot_next = nullptr;
   if (fused_train) {
-    one_hot = bb.one_hot + (e->flip & 1u);
-    one_hot_next = bb.one_hot + ((e->flip + 1u) & 1u);
+    one_hot = e->tb.one_hot + (e->flip & 3u);
+    one_hot_next = e->tb.one_hot + ((e->flip + 1u) & 3u);
     e->flip++;
   }
   HCTR_TRY(filter_keys<K>(e, bb, batch, ro_in, keys_in, nnz, &ro, &keys, &buckets, s, one_hot,
@@ -455,7 +468,8 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     }
     return HCTR_OK;
   }
-  if (is_train) e->cur_one_hot = (fused_train && e->p.world == 1) ? one_hot : nullptr;
+  const uint32_t* batch_one_hot = (fused_train && e->p.world == 1) ? one_hot : nullptr;
+  if (is_train && !ahead) e->cur_one_hot = batch_one_hot;
   if (bb.ro_full)
     HCTR_HIP(hipMemcpyAsync(bb.ro_full, ro_in, (batch * e->p.slot_num + 1) * sizeof(K),
                             hipMemcpyDeviceToDevice, s));
@@ -494,6 +508,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
       x.host_seq = e->h_rows + 1;
       x.seq = e->seq;
       x.host_error = e->h_err;
+      x.two_launches = ahead;  // (beside the dense tower's GEMMs: no grid barrier)
       HCTR_TRY(e->ht.get_insert(keys, nnz, d_n, bb.value_index, s, &sink, &x));
       refresh_row_bound(e);
     } else {
@@ -502,6 +517,13 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     e->prof.end(1, s);
   }
   if (!is_train) e->eval_nnz = nnz;
+  if (ahead) {
+    e->ahead_buckets = buckets;
+    e->ahead_nnz = nnz;
+    e->ahead_one_hot = batch_one_hot;
+    e->ahead_valid = true;
+    return HCTR_OK;
+  }
   if (out == nullptr) {  // hctr_emb_index: resolve rows only (unique-row exchange)
     if (is_train) {
       e->cur_buckets = buckets;
@@ -642,6 +664,10 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
     HCTR_ALLOC(bb.one_hot, 64);
     (void)hipMemset(bb.one_hot, 1, 64);  // both flags of the training batches start "one-hot"
     if (e->scale_after_reduce()) HCTR_ALLOC(bb.ro_full, (bsz * p.slot_num + 1) * e->key_bytes);
+    if (mode == 0 && p.world == 1) {  // (index-ahead is a one-GPU schedule)
+      HCTR_ALLOC(e->tb_spare.ro, (bsz * e->buckets_per_sample() + 1) * e->key_bytes);
+      HCTR_ALLOC(e->tb_spare.value_index, nn * sizeof(uint64_t));
+    }
   }
   HCTR_ALLOC(e->lens, (e->buckets_max + 1) * e->key_bytes);
   HCTR_ALLOC(e->tile_sums, (ceil_div<size_t>(e->buckets_max + 1, kTile) + 1) * 8);
@@ -793,6 +819,38 @@ int hctr_emb_index(hctr_embedding* e, int is_train, const void* row_offset, cons
                                    (const uint32_t*)keys, nnz, nullptr, s);
   return forward_typed<long long>(e, is_train, (const long long*)row_offset,
                                   (const long long*)keys, nnz, nullptr, s);
+}
+
+int hctr_emb_index_ahead(hctr_embedding* e, const void* row_offset, const void* keys, size_t nnz,
+                         hctr_stream_t stream) {
+  HCTR_REQUIRE(e, "null handle");
+  HCTR_REQUIRE(row_offset && keys && nnz > 0, "null pointer / empty batch");
+  HCTR_REQUIRE(e->p.world == 1 && e->tb_spare.ro != nullptr, "index_ahead: one GPU, training mode");
+  HCTR_REQUIRE(nnz <= e->p.train_batch_size * (e->p.max_feature_num ? e->p.max_feature_num : 1),
+               "nnz exceeds batch_size * max_feature_num");
+  HCTR_REQUIRE(!e->ahead_valid, "index_ahead: the batch indexed ahead has not been adopted yet");
+  hipStream_t s = as_stream(stream);
+  if (e->p.key_type == HCTR_KEY_U32)
+    return forward_typed<uint32_t>(e, 1, (const uint32_t*)row_offset, (const uint32_t*)keys, nnz,
+                                   nullptr, s, true);
+  return forward_typed<long long>(e, 1, (const long long*)row_offset, (const long long*)keys, nnz,
+                                  nullptr, s, true);
+}
+
+int hctr_emb_index_adopt(hctr_embedding* e) {
+  HCTR_REQUIRE(e, "null handle");
+  HCTR_REQUIRE(e->ahead_valid, "index_adopt: no batch has been indexed ahead");
+  // (pointers only: kernels of the previous batch's update that are still queued hold the old ones)
+  std::swap(e->tb.ro, e->tb_spare.ro);
+  std::swap(e->tb.value_index, e->tb_spare.value_index);
+  e->cur_buckets = e->ahead_buckets;
+  e->cur_nnz_bound = e->ahead_nnz;
+  e->cur_one_hot = e->ahead_one_hot;
+  e->has_train_batch = true;
+  e->nnz_pending = false;
+  e->top_grad = nullptr;
+  e->ahead_valid = false;
+  return HCTR_OK;
 }
 
 int hctr_emb_update_rows(hctr_embedding* e, size_t n, const int64_t* row_offset,

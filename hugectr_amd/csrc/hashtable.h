@@ -37,6 +37,9 @@ struct IndexExtras {
   uint64_t* host_seq = nullptr;
   uint64_t seq = 0;
   uint32_t* host_error = nullptr;    // the error flags
+  // the finish kernel as two launches instead of one with a grid barrier: for an index stage that
+  // runs beside other work (its workgroups cannot count on being resident together)
+  bool two_launches = false;
 };
 
 // where get_insert records the slot id of newly inserted rows (embedding dump needs it)
@@ -71,6 +74,7 @@ struct HashTable {
                                     // segment per workgroup of the probe kernel
   uint32_t* block_cnt = nullptr;    // entries of every segment (behind the list)
   uint32_t* d_parity = nullptr;     // which mask buffer the next inserting batch takes
+  uint32_t* d_snap = nullptr;       // two-launch finish: what its first half saw (FinishCtl::snap)
   uint64_t* d_scratch64 = nullptr;  // 1 element
 
   int create(size_t capacity, int key_type);

@@ -253,6 +253,7 @@ constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises
 
 struct FinishCtl {
   uint32_t *pending, *latched, *error, *barrier;
+  uint32_t* snap;  // two-launch form: {unseen keys?, mask parity, row counter lo, hi} of the first half
   uint64_t *counter, *base, *new_count;
   // positions whose key was not in the table: segment b of the list = [b * seg_cap, ... +
   // block_cnt[b]), written by workgroup b of the probe kernel
@@ -330,19 +331,31 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
   return ok != 0u;
 }
 
+// PHASE 0: the whole kernel, one grid barrier between its halves (every workgroup resident: the
+// in-line index stage).  PHASE 1 / 2: the same two halves as two launches, no barrier -- for an
+// index stage that runs beside other work (hctr_emb_index_ahead under the dense tower's GEMMs: a
+// grid that waits for workgroups the GEMMs keep off the chip was measured at + 1 ms per step).
+// The second launch takes the row counter / mask parity the first one saw from c.snap (workgroup
+// 0 of the second half moves the live words).
+template <int PHASE>
 __global__ void __launch_bounds__(kFinBlock)
     ht_finish_kernel(HtEntry* __restrict__ tab, uint64_t* __restrict__ out, size_t n,
                      const uint64_t* d_n, FinishCtl c, uint64_t* __restrict__ new_positions,
                      SlotIdSink sink, uint64_t capacity) {
-  if (*c.pending == 0u) {  // steady state: no unseen key in this batch
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const uint64_t cnt = *c.counter;
-      *c.latched = 0u;
-      *c.new_count = 0;
-      *c.base = cnt;
-      post_to_host(c, cnt);
+  if constexpr (PHASE == 2) {
+    if (c.snap[0] == 0u) return;
+  } else {
+    if (*c.pending == 0u) {  // steady state: no unseen key in this batch
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t cnt = *c.counter;
+        *c.latched = 0u;
+        *c.new_count = 0;
+        *c.base = cnt;
+        if constexpr (PHASE == 1) c.snap[0] = 0u;
+        post_to_host(c, cnt);
+      }
+      return;
     }
-    return;
   }
   __shared__ uint32_t smem[kFinBlock / 64 + 1];
   // v2: a finish workgroup takes the list segments of ITS share of the probe workgroups (a few
@@ -378,12 +391,22 @@ __global__ void __launch_bounds__(kFinBlock)
     }
     return (uint64_t)c.list[(size_t)(q0 + lo) * c.seg_cap + ((uint32_t)k - seg_first[lo])];
   };
-  const uint64_t c0 = *c.counter;  // (workgroup 0 moves it only behind the barriers)
+  // (workgroup 0 moves the counter and flips the parity only behind the barrier / in the second
+  //  launch, which reads the first launch's snapshot)
+  const uint64_t c0 = PHASE == 2 ? ((uint64_t)c.snap[3] << 32 | c.snap[2]) : *c.counter;
   const size_t nl = live_count(d_n, n);
   const size_t gtid = (size_t)b * kFinBlock + threadIdx.x, gthreads = (size_t)G * kFinBlock;
-  const uint32_t par = *c.parity & 1u;  // (workgroup 0 flips it only behind the barriers)
+  const uint32_t par = PHASE == 2 ? c.snap[1] : (*c.parity & 1u);
+  if constexpr (PHASE == 1) {
+    if (b == 0 && threadIdx.x == 0) {
+      c.snap[0] = 1u;
+      c.snap[1] = par;
+      c.snap[2] = (uint32_t)c0;
+      c.snap[3] = (uint32_t)(c0 >> 32);
+    }
+  }
   unsigned long long* const masks = c.masks2 + (size_t)par * c.mask_words;
-  {  // the other mask buffer is nobody's at the moment: all zero for the next inserting batch
+  if constexpr (PHASE != 2) {  // the other mask buffer is nobody's at the moment: all zero for the next inserting batch
     unsigned long long* const other = c.masks2 + (size_t)(1u - par) * c.mask_words;
     for (size_t w = gtid; w < c.mask_words; w += gthreads) other[w] = 0ull;
     for (size_t r = gtid; r < (size_t)kFinRegions; r += gthreads)
@@ -397,44 +420,50 @@ __global__ void __launch_bounds__(kFinBlock)
   // ---- A: the pending positions that hold the FIRST occurrence of their key set their bit and
   //         count themselves into their region --------------------------------------------------
   // (the first kKeep entries of a thread stay in registers for phase D: two dependent loads less)
-  constexpr int kKeep = 4;
-  uint64_t keep_i[kKeep], keep_slot[kKeep];
+  constexpr int kKeep = PHASE == 0 ? 4 : 0;  // (two launches: nothing survives in registers)
+  uint64_t keep_i[kKeep > 0 ? kKeep : 1], keep_slot[kKeep > 0 ? kKeep : 1];
+  if constexpr (PHASE != 2) {
 #pragma unroll
-  for (int j = 0; j < kKeep; j++) {
-    const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
-    keep_i[j] = 0;
-    keep_slot[j] = 0;
-    if (k < P) {
+    for (int j = 0; j < kKeep; j++) {
+      const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
+      keep_i[j] = 0;
+      keep_slot[j] = 0;
+      if (k < P) {
+        const uint64_t i = entry(k);
+        const uint64_t slot = out[i] & ~kPendingBit;
+        keep_i[j] = i;
+        keep_slot[j] = slot;
+        if (tab[slot].val == (kPendingBit | i)) {
+          atomicOr(&masks[i >> 6], 1ull << (i & 63));
+          atomicAdd(&region_cnt[i / per], 1u);
+        }
+      }
+    }
+    for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
       const uint64_t i = entry(k);
       const uint64_t slot = out[i] & ~kPendingBit;
-      keep_i[j] = i;
-      keep_slot[j] = slot;
       if (tab[slot].val == (kPendingBit | i)) {
         atomicOr(&masks[i >> 6], 1ull << (i & 63));
         atomicAdd(&region_cnt[i / per], 1u);
       }
     }
   }
-  for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
-    const uint64_t i = entry(k);
-    const uint64_t slot = out[i] & ~kPendingBit;
-    if (tab[slot].val == (kPendingBit | i)) {
-      atomicOr(&masks[i >> 6], 1ull << (i & 63));
-      atomicAdd(&region_cnt[i / per], 1u);
+  if constexpr (PHASE == 1) return;  // (the launch boundary is the barrier)
+  if constexpr (PHASE == 0) {
+    if (!grid_barrier(c.barrier, G)) {
+      // the barrier never opened (the grid was not resident as a whole: a partitioned or masked
+      // device): no row can be handed out.  The pending positions of this workgroup's share get
+      // "no row" (they pool as zeros and the update skips them) instead of keeping PENDING | slot,
+      // the barrier words are put back so that the next batch starts clean, error bit 4 tells the
+      // host
+      for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) out[entry(k)] = kInvalidIndex;
+      if (threadIdx.x == 0) {
+        atomicOr(c.error, 4u);
+        st_agent(c.barrier, 0u);
+        if (c.host_error != nullptr) *c.host_error = *c.error;
+      }
+      return;
     }
-  }
-  if (!grid_barrier(c.barrier, G)) {
-    // the barrier never opened (the grid was not resident as a whole: a partitioned or masked
-    // device): no row can be handed out.  The pending positions of this workgroup's share get "no
-    // row" (they pool as zeros and the update skips them) instead of keeping PENDING | slot, the
-    // barrier words are put back so that the next batch starts clean, error bit 4 tells the host
-    for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) out[entry(k)] = kInvalidIndex;
-    if (threadIdx.x == 0) {
-      atomicOr(c.error, 4u);
-      st_agent(c.barrier, 0u);
-      if (c.host_error != nullptr) *c.host_error = *c.error;
-    }
-    return;
   }
   // ---- S: every workgroup scans the region counts (into LDS); workgroup 0 hands out the row
   //         range ------------------------------------------------------------------------------------
@@ -655,7 +684,7 @@ int HashTable::create(size_t cap, int kt) {
   if (size == 0) size = 1;
   HCTR_HIP(hipMalloc(&entries, size * sizeof(HtEntry)));
   uint64_t* scal = nullptr;
-  HCTR_HIP(hipMalloc(&scal, 64));
+  HCTR_HIP(hipMalloc(&scal, 96));
   d_counter = scal;
   d_base = scal + 1;
   d_new_count = scal + 2;
@@ -665,7 +694,8 @@ int HashTable::create(size_t cap, int kt) {
   d_latched = reinterpret_cast<uint32_t*>(scal + 5);
   d_barrier = reinterpret_cast<uint32_t*>(scal + 6);
   d_parity = reinterpret_cast<uint32_t*>(scal + 7);
-  HCTR_HIP(hipMemset(scal, 0, 64));
+  d_snap = reinterpret_cast<uint32_t*>(scal + 8);
+  HCTR_HIP(hipMemset(scal, 0, 96));
   return clear(nullptr);
 }
 
@@ -792,7 +822,7 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   // 256 CUs: a grid that is not resident as a whole could only time out at its barrier)
   static const size_t resident = [] {
     int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_finish_kernel, kFinBlock, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_finish_kernel<0>, kFinBlock, 0) !=
             hipSuccess ||
         hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -814,8 +844,17 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   if (fg > cap) fg = cap;
   if (fg > resident) fg = resident;
   if (fg < 1) fg = 1;
-  hipLaunchKernelGGL(ht_finish_kernel, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n, d_n,
-                     c, new_positions, sink, capacity);
+  c.snap = d_snap;
+  if (x.two_launches) {
+    hipLaunchKernelGGL(ht_finish_kernel<1>, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n,
+                       d_n, c, new_positions, sink, capacity);
+    HCTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ht_finish_kernel<2>, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n,
+                       d_n, c, new_positions, sink, capacity);
+  } else {
+    hipLaunchKernelGGL(ht_finish_kernel<0>, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n,
+                       d_n, c, new_positions, sink, capacity);
+  }
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -155,6 +155,18 @@ class SparseEmbeddingHash:
         check(lib.hctr_emb_index(self._h, 1 if is_train else 0, ptr(row_offset), ptr(keys), nnz,
                                  stream_ptr()))
 
+    def index_ahead(self, row_offset: torch.Tensor, keys: torch.Tensor):
+        """index stage of the training batch AFTER the current one, on the current torch stream
+        (one GPU): the current batch -- its rows, its pending update -- stays what it is until
+        index_adopt().  The stream must be ordered behind the previous index stage."""
+        self._check_key_types(row_offset, keys)
+        check(lib.hctr_emb_index_ahead(self._h, ptr(row_offset), ptr(keys), int(keys.numel()),
+                                       stream_ptr()))
+
+    def index_adopt(self):
+        """the batch indexed ahead becomes the current training batch (no launch)"""
+        check(lib.hctr_emb_index_adopt(self._h))
+
     def update_rows(self, rows: torch.Tensor, grads: torch.Tensor, row_offset: torch.Tensor):
         """sparse optimizer on (row, gradient) entries: entry i updates rows[i] with grads[i]
         (entries naming the same row are summed in entry order); row_offset = arange(n + 1)"""

@@ -527,8 +527,9 @@ class _GatherEmb:
     key per bucket the interaction kernel reads the table rows through the index stage's result
     itself (hctr_emb_forward_interaction) and writes the pooled vectors once, for the backward"""
 
-    def __init__(self, emb, train, on_grad):
+    def __init__(self, emb, train, on_grad, after_forward=None):
         self.emb, self.train, self.on_grad = emb, train, on_grad
+        self.after_forward = after_forward  # called once the interaction's forward is enqueued
 
 
 class _Tensors(dict):
@@ -757,6 +758,16 @@ class Model:
         self._inter = bool(s.train_inter_iteration_overlap) and self.world > 1
         # one GPU: what the flag still overlaps is the sparse update under the bottom MLP's backward
         self._upd_overlap = bool(s.train_intra_iteration_overlap) and self.world == 1
+        # one GPU: the NEXT batch's index stage on a side stream (solver.train_inter_iteration_overlap)
+        # HCTR_INDEX_AHEAD (default "0": the index stage stays at the step's start).  Measured on
+        # MI355X, DLRM Criteo-1TB shape, round 4 (profiles/r4_index_ahead_ab.txt): "mlp" = under
+        # this batch's top MLP: + 1 ms per step -- the probe kernel's waves keep the GEMMs' big
+        # workgroups from being placed (the index stage itself 70 -> 260 us); "tail" = behind the
+        # sparse update on its side stream, joined by the next step before its gather: 2.215 ->
+        # 2.209 ms, inside the noise -- the side stream's chain ends when the next step needs it.
+        self._idx_mode = os.environ.get("HCTR_INDEX_AHEAD", "0")
+        self._idx_overlap = (bool(s.train_inter_iteration_overlap) and self.world == 1 and
+                             self._idx_mode != "0")
         want = os.environ.get("HCTR_EXCHANGE", "auto" if (self._intra and self._inter) else "rows")
         if want not in ("rows", "unique", "unique16", "auto"):
             raise RuntimeError("HCTR_EXCHANGE must be rows, unique, unique16 or auto")
@@ -805,6 +816,8 @@ class Model:
             self._xstate[name] = st
         self._lookahead = None     # (batch i + 1) fetched early for the inter-iteration prefetch
         self._upd_stream = None    # one GPU: the sparse update under the bottom MLP's backward
+        self._idx_stream = None    # one GPU: the next batch's index stage (inter-iteration overlap)
+        self._idx_ahead = {}       # embedding name -> (the batch indexed ahead, its event)
         self._upd_timing = []      # (overlapped?, (start, end) events) of recent updates
         self._upd_overlap_on = True
 
@@ -1217,6 +1230,8 @@ class Model:
                     e = x[1]
                     y = interaction_gather(x[0].to(e.emb.out_dtype).contiguous(), e.emb, e.train,
                                            on_emb_grad=e.on_grad)
+                    if e.after_forward is not None:
+                        e.after_forward()
                 elif isinstance(x[1], _IndexedEmb):
                     e = x[1]
                     y = interaction_indexed(x[0].to(e.rows.dtype).contiguous(), e.rows, e.row_of,
@@ -1276,7 +1291,31 @@ class Model:
                 raise RuntimeError(
                     f"{name}: fixed-length one-hot input declared (is_fixed_length, max_nnz 1) but the "
                     f"batch holds {keys.numel()} keys for {bpg * S} buckets")
-            h.index(train, ro, keys)
+            ahead = self._idx_ahead.pop(name, None) if train else None
+            if ahead is not None and ahead[0] is batch:
+                # this batch's rows were resolved under the previous step's top MLP
+                h.index_adopt()
+                torch.cuda.current_stream().wait_event(ahead[1])
+            else:
+                if ahead is not None:  # (another batch than the one indexed ahead: drop that)
+                    torch.cuda.current_stream().wait_event(ahead[1])
+                h.index(train, ro, keys)
+            launch_ahead = None
+            if (train and self._idx_overlap and nxt is not None and
+                    nxt["sparse"][se.bottom_name][1].numel() == bpg * S):
+                def launch_ahead(nxt=nxt):
+                    # behind this batch's index stage AND its gather (both memory-bound), under
+                    # the top MLP's GEMMs; the hash table is the only state the two batches share
+                    if self._idx_stream is None:
+                        self._idx_stream = torch.cuda.Stream()
+                    side = self._idx_stream
+                    side.wait_stream(torch.cuda.current_stream())
+                    nro, nkeys = nxt["sparse"][se.bottom_name]
+                    with torch.cuda.stream(side):
+                        h.index_ahead(nro, nkeys)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    self._idx_ahead[name] = (nxt, ev)
             got = {}
             if train and self._upd_overlap and self._overlap_update_now():
                 # The sparse update needs the embedding's top gradient only, and the Interaction
@@ -1291,6 +1330,8 @@ class Model:
                 side = self._upd_stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
+                tail = launch_ahead is not None and self._idx_mode == "tail"
+
                 def on_grad(g):
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
@@ -1298,13 +1339,27 @@ class Model:
                         h.backward(g)
                         h.update_params()
                         ev[1].record()
+                        if tail:
+                            # the next batch's index stage right behind the update: the step no
+                            # longer joins the side stream at its end -- the next step waits for
+                            # this event before it reads rows or table (adoption, _drain_prefetch)
+                            nro, nkeys = nxt["sparse"][se.bottom_name]
+                            h.index_ahead(nro, nkeys)
+                            eva = torch.cuda.Event()
+                            eva.record()
+                            self._idx_ahead[name] = (nxt, eva)
                     got["g"] = g  # (alive until the join: the allocator cannot hand it out before)
 
                 def finish():
-                    got.clear()
-                    torch.cuda.current_stream().wait_stream(side)
+                    if tail and name in self._idx_ahead:
+                        got["keep"] = got.pop("g", None)  # (until the next step has joined)
+                        self._upd_keep = got
+                    else:
+                        got.clear()
+                        torch.cuda.current_stream().wait_stream(side)
                     self._upd_timing.append((True, ev))
-                tensors[name] = _GatherEmb(h, train, on_grad)
+                tensors[name] = _GatherEmb(h, train, on_grad,
+                                           None if tail else launch_ahead)
                 after.append(finish)
                 return
             if train and self._upd_overlap:
@@ -1316,11 +1371,12 @@ class Model:
                     h.update_params()
                     ev[1].record()
                     self._upd_timing.append((False, ev))
-                tensors[name] = _GatherEmb(h, train, lambda g: got.__setitem__("g", g))
+                tensors[name] = _GatherEmb(h, train, lambda g: got.__setitem__("g", g),
+                                           launch_ahead if self._idx_mode == "mlp" else None)
                 after.append(finish)
                 return
             tensors[name] = _GatherEmb(h, train, (lambda g: got.__setitem__("g", g)) if train
-                                       else None)
+                                       else None, launch_ahead if self._idx_mode == "mlp" else None)
             if train:
                 def finish():
                     h.backward(got.pop("g"))
@@ -1649,7 +1705,8 @@ class Model:
         if batch is None:
             return False
         nxt = None
-        if self._inter and any(st["mode"] != "rows" for st in self._xstate.values()):
+        if (self._inter and any(st["mode"] != "rows" for st in self._xstate.values())) or \
+                (self._idx_overlap and any(st["fused_gather"] for st in self._xstate.values())):
             # inter-iteration overlap: the next batch's keys are needed a step early
             nxt = self._lookahead = self.reader.next_batch(train=True)
         self.check_overflow(blocking=False)
@@ -1683,6 +1740,8 @@ class Model:
         for st in getattr(self, "_xstate", {}).values():
             if st["ux"] is not None:
                 st["ux"].drain()
+        for _, ev in getattr(self, "_idx_ahead", {}).values():
+            torch.cuda.current_stream().wait_event(ev)
 
     def eval(self) -> bool:
         batch = self.reader.next_batch(train=False)

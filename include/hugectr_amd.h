@@ -417,6 +417,16 @@ int hctr_updater_reduce_presorted(hctr_updater* u, size_t positions, size_t buck
  * (row, gradient) entries: entry i updates rows[i] with grad[i][:] (row_offset = arange(n + 1)) */
 int hctr_emb_index(hctr_embedding* emb, int is_train, const void* row_offset, const void* keys,
                    size_t nnz, hctr_stream_t stream);
+/* One GPU, inter-iteration overlap (solver.train_inter_iteration_overlap; the reference resolves the
+ * next batch's keys while the current iteration computes, R/HugeCTR/src/pybind/model_pipeline.cpp:
+ * 299-346): the index stage of the batch AFTER the current training batch, into a second set of
+ * buffers -- the current batch (its rows, its pending backward / update_params) stays what it is.
+ * `stream` must be ordered behind the previous index stage (the hash table is shared state).
+ * hctr_emb_index_adopt makes that batch the current one (host-side pointer swap, no launch); the
+ * caller orders its stream behind index_ahead's before reading the rows. */
+int hctr_emb_index_ahead(hctr_embedding* emb, const void* row_offset, const void* keys, size_t nnz,
+                         hctr_stream_t stream);
+int hctr_emb_index_adopt(hctr_embedding* emb);
 int hctr_emb_update_rows(hctr_embedding* emb, size_t n, const int64_t* row_offset,
                          const uint64_t* rows, const void* grad, int grad_dtype,
                          hctr_stream_t stream);

@@ -753,3 +753,51 @@ def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, opt_kw, B, D, d
     assert torch.equal(a, b), "the hot path is not deterministic"
     c = run(0)
     assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-3, 1e-4, "hot path vs plain path")
+
+
+@pytest.mark.parametrize("ahead", [False, True], ids=["cooperative_finish", "index_ahead_two_launches"])
+def test_index_stage_beside_a_device_full_of_gemms(oracle, ahead):
+    """the index stage with unseen keys on a side stream while the default stream keeps the device
+    full of GEMMs -- the inter-iteration-overlap situation.  In-line form: the cooperative finish
+    kernel's grid barrier must open (no timeout flag, error bit 4) however its workgroups are
+    scheduled between GEMM workgroups; index_ahead form: the two-launch finish kernel.  Rows
+    bit-exact against the sequential oracle in both."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(31)
+    B, S, D, vps = 32768, 8, 16, 60000
+    V = S * vps
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.1, atomic_update=False)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S, S, 0, opt)
+    emb.init_params()
+    ht = oracle.HashTable(V, 8)
+    ro = torch.arange(B * S + 1, dtype=torch.int64, device="cuda")
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.float16)
+    side = torch.cuda.Stream()
+
+    def keys_of():
+        k = np.stack([rng.integers(0, vps, size=B) + s * vps for s in range(S)], 1).reshape(-1)
+        return k.astype(np.int64)
+    k0 = keys_of()
+    emb.index(True, ro, _t(torch, k0))
+    assert (emb.value_index(k0.size).cpu().numpy().view(np.uint64) == ht.get_insert(k0)).all()
+    for it in range(3):
+        k = keys_of()  # ~ 40 % unseen keys: the finish kernel has real work
+        kt = _t(torch, k)
+        torch.cuda.synchronize()
+        for _ in range(12):  # ~ 10 ms of GEMMs queued on the default stream
+            a @ a
+        with torch.cuda.stream(side):
+            if ahead:
+                emb.index_ahead(ro, kt)
+            else:
+                emb.index(True, ro, kt)
+        for _ in range(12):
+            a @ a
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if ahead:
+            emb.index_adopt()
+        emb.check_overflow()  # (a barrier that never opened raises here: error bit 4)
+        assert (emb.value_index(k.size).cpu().numpy().view(np.uint64) == ht.get_insert(k)).all()

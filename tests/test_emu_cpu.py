@@ -278,6 +278,47 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
     assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
 
 
+def test_index_ahead_equals_the_sequential_oracle(oracle, elib):
+    """hctr_emb_index_ahead / hctr_emb_index_adopt (the next batch's index stage into the spare
+    buffers, finish kernel as two launches without its grid barrier): the rows of a sequence of
+    batches -- first one indexed in line, the others ahead while the previous batch is still the
+    current one -- equal the sequential oracle's, the current batch's rows stay untouched until the
+    adoption, and an update in between takes the right batch"""
+    import ctypes
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(21)
+    B, S, D, vps = 600, 5, 8, 400
+    V = S * vps
+    emb = emu.Embedding(elib, _lib.EMB_LOCALIZED, B, V, D, S, S, 0,
+                        dict(optimizer=6, lr=0.1, scaler=1.0, atomic_update=0))
+    table = emb.table().copy()
+    ht = oracle.HashTable(V, 8)
+    ro = np.arange(B * S + 1, dtype=np.int64)
+
+    def batch():
+        return (np.stack([np.minimum((rng.pareto(1.0, size=B) * 4).astype(np.int64), vps - 1) + s * vps
+                          for s in range(S)], 1).reshape(-1)).astype(np.int64)
+    keys = batch()
+    emu.check(elib, elib.hctr_emb_index(emb.h, 1, emu.ptr(ro), emu.ptr(keys), keys.size, None))
+    for it in range(4):
+        vi = ht.get_insert(keys)
+        assert (emb.value_index(keys.size) == vi).all(), f"rows of batch {it}"
+        nxt = batch()
+        emu.check(elib, elib.hctr_emb_index_ahead(emb.h, emu.ptr(ro), emu.ptr(nxt), nxt.size, None))
+        assert (emb.value_index(keys.size) == vi).all(), "index_ahead touched the current batch"
+        g = rng.standard_normal((B * S, D)).astype(np.float32)
+        emb.backward(g.reshape(B, S, D))
+        emb.update_params()
+        o = oracle.OptParamsC()
+        o.optimizer, o.update_type, o.lr, o.scaler, o.times = oracle.OPT_SGD, 0, 0.1, 1.0, it + 1
+        oracle.update_params(ro, vi, g, o, table)
+        assert_close(emb.table(), table, 1e-5, 1e-6, f"table after the update of batch {it}")
+        emu.check(elib, elib.hctr_emb_index_adopt(emb.h))
+        keys = nxt
+    assert (emb.value_index(keys.size) == ht.get_insert(keys)).all()
+    emb.check_overflow()
+
+
 def test_no_collective_met_an_idle_lane(elib):
     """(runs last in this file) no shuffle of the kernels exercised above read a lane that was not
     taking part in it -- on the hardware such a read returns a stale register"""
