@@ -81,6 +81,7 @@ struct SparseUpdater {
   uint32_t* hot_meta = nullptr;        // [hot_chunks_max][2] entries, first pool slot
   uint32_t* hot_tpref = nullptr;       // [hot_chunks_max][129] run starts in front of a tile
   uint32_t* hot_items = nullptr;       // tiles with entries (work list of hot_reduce_kernel)
+  uint32_t* hot_loc_blk = nullptr;     // [hot_rows] blocks of 32 chunks that hold a partial of the row
   uint32_t* hot_joins = nullptr;       // [.][3] runs that cross tile borders (hot_join_kernel)
   uint32_t* hot_counts = nullptr;      // two alternating sets {pool slots, items, joins, -} + [8] pairs the sort kept
   uint32_t hot_parity = 0;             // set the next update takes

@@ -1152,6 +1152,7 @@ struct HotBufs {
   uint32_t* meta;    // [chunks][2] entries, first pool slot
   uint32_t* tpref;   // [chunks][kHotTiles + 1] run starts in front of a tile
   uint32_t* items;   // tiles that hold entries: chunk * kHotTiles + tile (any order)
+  uint32_t* loc_blk;  // [hot rows] bit b: some chunk in [32 b, 32 b + 32) holds a partial
   uint32_t* joins;   // [.][3] runs that cross tile borders: chunk << 14 | first tile << 7 | last
                      //        tile, partial number, row
   uint32_t* counts;  // this update's counters: [0] pool slots taken, [1] items, [2] joins
@@ -1213,6 +1214,9 @@ __global__ void __launch_bounds__(kHotBlock)
   for (int r = 0; r < kHotRounds; r++) {
     const uint32_t j = (uint32_t)(wave * (64 * kHotRounds) + r * 64 + lane);
     const bool st = j < nh && (j == 0u || (S[j] >> kHotPosBits) != (S[j - 1] >> kHotPosBits));
+    // (every run of the chunk becomes one partial of its row: hot_apply_kernel looks at the
+    //  blocks of 32 chunks marked here only)
+    if (st) atomicOr(hb.loc_blk + (S[j] >> kHotPosBits), 1u << (chunk >> 5));
     const unsigned long long bal = __ballot(st);
     if (lane == 0) {
       tile_pref[j / kHotTile] = (uint32_t)__popcll(bal & 0xFFFFFFFFull);
@@ -1281,7 +1285,10 @@ __global__ void __launch_bounds__(kBlock, 5)  // (<= 102 VGPRs: leaves room for 
   typedef typename Load4<GradT>::raw Raw;
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
-  constexpr int QB = sizeof(Raw) == 8 ? 16 : 8;  // raw fragments in flight per lane: 32 VGPRs
+  // raw fragments in flight per lane: half a tile, 32 VGPRs.  Measured and dropped (round 4): the
+  // whole tile in one batch at 4 waves per SIMD, and one 40-word record per tile written by
+  // hot_sort_kernel (one fetch instead of item -> entries / counts): both 79 -> 90 us
+  constexpr int QB = sizeof(Raw) == 8 ? 16 : 8;
   static_assert(kHotTile % QB == 0, "batches tile the tile");
   if (*one_hot == 0u) return;
   // the tile's entries + the one in front + the one behind, per lane group
@@ -1415,54 +1422,63 @@ __global__ void __launch_bounds__(kBlock)
   const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
   const int gshift = ((threadIdx.x & 63) / LPR) * LPR;
   for (uint32_t row = blockIdx.x * GPB + g; row < hg.rows; row += gridDim.x * GPB) {
+    // blocks of 32 chunks that hold a partial of this row (a row of one stream: one or two)
+    uint32_t blk = hb.loc_blk[row];
+    __builtin_amdgcn_wave_barrier();  // (every lane of the group has read the word ...)
+    if (blk == 0u) continue;
+    if (l == 0) hb.loc_blk[row] = 0u;  // (... before it is cleaned for the next update)
     uint16_t* lrow = hb.loc + (size_t)row * hg.loc_stride;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     bool any = false;
-    for (uint32_t cb = 0; cb < n_chunks; cb += LPR * LU) {
-      uint32_t v[LU];
+    while (blk != 0u) {
+      const uint32_t b32 = (uint32_t)__ffs((int)blk) - 1u;
+      blk &= blk - 1u;
+      for (uint32_t cb = b32 * 32u; cb < b32 * 32u + 32u && cb < n_chunks; cb += LPR * LU) {
+        uint32_t v[LU];
 #pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const uint32_t cc = cb + (uint32_t)(u * LPR + l);
-        v[u] = cc < n_chunks ? (uint32_t)lrow[cc] : kHotNone;
-      }
-#pragma unroll
-      for (int u = 0; u < LU; u++) {
-        const uint32_t cc = cb + (uint32_t)(u * LPR + l);
-        unsigned long long m = (__ballot(v[u] != kHotNone) >> gshift) & kGroupMask;
-        uint32_t myslot = 0u;
-        if (v[u] != kHotNone) {
-          lrow[cc] = (uint16_t)kHotNone;  // clean for the next update
-          myslot = cbase[cc] + v[u];
+        for (int u = 0; u < LU; u++) {
+          const uint32_t cc = cb + (uint32_t)(u * LPR + l);
+          v[u] = (cc < n_chunks && cc < b32 * 32u + 32u) ? (uint32_t)lrow[cc] : kHotNone;
         }
-        while (m != 0ull) {
-          uint32_t slot[CU];
-          int nk = 0;
 #pragma unroll
-          for (int k = 0; k < CU; k++) {
-            int bit = 0;
-            if (m != 0ull) {
-              bit = __ffsll((long long)m) - 1;
-              m &= m - 1ull;
-              nk = k + 1;
+        for (int u = 0; u < LU; u++) {
+          const uint32_t cc = cb + (uint32_t)(u * LPR + l);
+          unsigned long long m = (__ballot(v[u] != kHotNone) >> gshift) & kGroupMask;
+          uint32_t myslot = 0u;
+          if (v[u] != kHotNone) {
+            lrow[cc] = (uint16_t)kHotNone;  // clean for the next update
+            myslot = cbase[cc] + v[u];
+          }
+          while (m != 0ull) {
+            uint32_t slot[CU];
+            int nk = 0;
+#pragma unroll
+            for (int k = 0; k < CU; k++) {
+              int bit = 0;
+              if (m != 0ull) {
+                bit = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                nk = k + 1;
+              }
+              slot[k] = (uint32_t)__shfl((int)myslot, gshift + bit, 64);
             }
-            slot[k] = (uint32_t)__shfl((int)myslot, gshift + bit, 64);
-          }
-          float4 h[CU];
+            float4 h[CU];
 #pragma unroll
-          for (int k = 0; k < CU; k++) {
-            if (k < nk)
-              h[k] = *reinterpret_cast<const float4*>(pool_end - ((size_t)slot[k] + 1u) * D + l * 4);
-          }
-#pragma unroll
-          for (int k = 0; k < CU; k++) {
-            if (k < nk) {
-              acc.x += h[k].x;
-              acc.y += h[k].y;
-              acc.z += h[k].z;
-              acc.w += h[k].w;
+            for (int k = 0; k < CU; k++) {
+              if (k < nk)
+                h[k] = *reinterpret_cast<const float4*>(pool_end - ((size_t)slot[k] + 1u) * D + l * 4);
             }
+#pragma unroll
+            for (int k = 0; k < CU; k++) {
+              if (k < nk) {
+                acc.x += h[k].x;
+                acc.y += h[k].y;
+                acc.z += h[k].z;
+                acc.w += h[k].w;
+              }
+            }
+            any = true;
           }
-          any = true;
         }
       }
     }
@@ -1808,6 +1824,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
         hb.meta = u.hot_meta;
         hb.tpref = u.hot_tpref;
         hb.items = u.hot_items;
+        hb.loc_blk = u.hot_loc_blk;
         hb.joins = u.hot_joins;
         // counter sets alternate: [0..3] / [4..7]; [8] = pairs the sort kept
         hb.counts = u.hot_counts + 4 * (u.hot_parity & 1u);
@@ -2112,6 +2129,8 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
       HCTR_HIP(hipMemset(hot_loc, 0xFF, loc_bytes));  // kHotNone everywhere; hot_apply keeps it so
       const size_t C = hot_chunks_max;
       HCTR_HIP(hipMalloc(&hot_S, C * kHotChunk * sizeof(uint32_t)));
+      HCTR_HIP(hipMalloc(&hot_loc_blk, (size_t)hot_rows * sizeof(uint32_t)));
+      HCTR_HIP(hipMemset(hot_loc_blk, 0, (size_t)hot_rows * sizeof(uint32_t)));
       HCTR_HIP(hipMalloc(&hot_meta, C * 2 * sizeof(uint32_t)));
       HCTR_HIP(hipMalloc(&hot_tpref, C * (kHotTiles + 1) * sizeof(uint32_t)));
       HCTR_HIP(hipMalloc(&hot_items, (max_nnz / kHotTile + C + 1) * sizeof(uint32_t)));
@@ -2130,7 +2149,8 @@ int SparseUpdater::destroy() {
   void* ptrs[] = {sort_keys_in, sort_keys_out, sort_vals_in, sort_vals_out, sort_temp, tile_sums,
                   run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
                   gsum,         big_list,      hot_loc,      hot_counts,    hot_head,  hot_tail,
-                  hot_S,        hot_meta,      hot_tpref,    hot_items,     hot_joins};
+                  hot_S,        hot_meta,      hot_tpref,    hot_items,     hot_joins,
+                  hot_loc_blk};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (hot_side) {
@@ -2153,7 +2173,7 @@ int SparseUpdater::destroy() {
   span_list = span_count = big_list = nullptr;
   gsum = nullptr;
   hot_loc = nullptr;
-  hot_counts = hot_S = hot_meta = hot_tpref = hot_items = hot_joins = nullptr;
+  hot_counts = hot_S = hot_meta = hot_tpref = hot_items = hot_joins = hot_loc_blk = nullptr;
   hot_head = hot_tail = nullptr;
   hot_rows = hot_chunks_max = 0;
   return HCTR_OK;
