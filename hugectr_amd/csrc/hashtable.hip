@@ -423,29 +423,68 @@ __global__ void __launch_bounds__(kFinBlock)
   constexpr int kKeep = PHASE == 0 ? 4 : 0;  // (two launches: nothing survives in registers)
   uint64_t keep_i[kKeep > 0 ? kKeep : 1], keep_slot[kKeep > 0 ? kKeep : 1];
   if constexpr (PHASE != 2) {
+    // A DENSE list (most keys of the batch unseen: a first epoch): the 64 entries of a wavefront
+    // are consecutive positions of one probe workgroup, i.e. one or two mask words, and 64 atomics
+    // on one address serialise at the memory side.  The lanes that share a word then OR their bits
+    // across the wavefront and one of them issues the two atomics (all positions of a word lie in
+    // one region: `per` is a multiple of 64).  For sparse lists that form was measured slower
+    // (round 3), hence the threshold: two entries per thread.
+    const bool dense = P >= 2u * (uint32_t)kFinBlock;
+    const int lane = threadIdx.x & 63;
+    auto mark = [&](bool first, uint64_t i) {  // (called by every lane of the workgroup)
+      if (!dense) {
+        if (first) {
+          atomicOr(&masks[i >> 6], 1ull << (i & 63));
+          atomicAdd(&region_cnt[i / per], 1u);
+        }
+        return;
+      }
+      const uint32_t word = (uint32_t)(i >> 6);
+      unsigned long long todo = __ballot(first);
+      while (todo != 0ull) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t w0 = (uint32_t)__shfl((int)word, leader, 64);
+        const bool mine = first && word == w0;
+        const unsigned long long same = __ballot(mine);
+        unsigned long long bits = mine ? (1ull << (i & 63)) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bits, d, 64);
+          const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bits >> 32), d, 64);
+          bits |= ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == leader) {
+          atomicOr(&masks[w0], bits);
+          atomicAdd(&region_cnt[((size_t)w0 << 6) / per], (uint32_t)__popcll(bits));
+        }
+        todo &= ~same;
+      }
+    };
 #pragma unroll
     for (int j = 0; j < kKeep; j++) {
       const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
       keep_i[j] = 0;
       keep_slot[j] = 0;
+      bool first = false;
       if (k < P) {
         const uint64_t i = entry(k);
         const uint64_t slot = out[i] & ~kPendingBit;
         keep_i[j] = i;
         keep_slot[j] = slot;
-        if (tab[slot].val == (kPendingBit | i)) {
-          atomicOr(&masks[i >> 6], 1ull << (i & 63));
-          atomicAdd(&region_cnt[i / per], 1u);
-        }
+        first = tab[slot].val == (kPendingBit | i);
       }
+      mark(first, keep_i[j]);
     }
-    for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
-      const uint64_t i = entry(k);
-      const uint64_t slot = out[i] & ~kPendingBit;
-      if (tab[slot].val == (kPendingBit | i)) {
-        atomicOr(&masks[i >> 6], 1ull << (i & 63));
-        atomicAdd(&region_cnt[i / per], 1u);
+    for (size_t k0 = (size_t)kKeep * kFinBlock; k0 < P; k0 += kFinBlock) {  // (uniform trips)
+      const size_t k = k0 + threadIdx.x;
+      bool first = false;
+      uint64_t i = 0;
+      if (k < P) {
+        i = entry(k);
+        const uint64_t slot = out[i] & ~kPendingBit;
+        first = tab[slot].val == (kPendingBit | i);
       }
+      mark(first, i);
     }
   }
   if constexpr (PHASE == 1) return;  // (the launch boundary is the barrier)

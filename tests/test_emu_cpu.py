@@ -278,6 +278,21 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
     assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
 
 
+def test_hash_rows_of_batches_full_of_unseen_keys(oracle, elib):
+    """a first epoch: nearly every key of a batch is unseen, the finish kernel's list is DENSE (two
+    or more entries per thread: the wave-aggregated form of its mask / region atomics) -- 30 000 and
+    50 000 keys with duplicates, then a batch that mixes seen and unseen; rows equal the sequential
+    oracle's"""
+    rng = np.random.default_rng(44)
+    cap = 200000
+    o = oracle.HashTable(cap, 8)
+    g = emu.HashTable(elib, cap, 1)
+    for n, hi in ((30000, 10**7), (50000, 10**7), (20000, 60000)):
+        keys = rng.integers(0, hi, size=n).astype(np.int64)
+        keys[rng.integers(0, n, size=n // 10)] = keys[rng.integers(0, n, size=n // 10)]  # duplicates
+        assert (g.get_insert(keys) == o.get_insert(keys)).all(), n
+
+
 def test_index_ahead_equals_the_sequential_oracle(oracle, elib):
     """hctr_emb_index_ahead / hctr_emb_index_adopt (the next batch's index stage into the spare
     buffers, finish kernel as two launches without its grid barrier): the rows of a sequence of
