@@ -9,6 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
+from .dense import split_k_wgrad
 
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 
@@ -226,9 +227,15 @@ class _CrossV2Fn(torch.autograd.Function):
             s0 = dy * x0
             acc.addcmul_(dy, hs[l])
             s1 = s0 @ Vt[l].t()
-            dV[l] = _mm_f32(ps[l].t(), s0)
+            # weight gradients reduce over K = batch into a small tile set (512 x 3456: 27 tiles of
+            # 256 x 256 on 256 CUs): split-K through batched GEMMs, as the MLP's are (dense.py)
+            if x0.is_cuda and x0.dtype in (torch.float16, torch.bfloat16):
+                split_k_wgrad(ps[l], s0, out=dV[l])
+                split_k_wgrad(xs[l], s1, out=dU[l])
+            else:
+                dV[l] = _mm_f32(ps[l].t(), s0)
+                dU[l] = _mm_f32(xs[l].t(), s1)
             db[l] = s0.sum(0, dtype=wdt)
-            dU[l] = _mm_f32(xs[l].t(), s1)
             dy = torch.addmm(dy, s1, Ut[l].t())
         return acc + dy, dU, dV, db
 
