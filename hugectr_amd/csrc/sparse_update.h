@@ -92,6 +92,7 @@ struct SparseUpdater {
   size_t early_buckets = 0;
 
   int create(size_t max_nnz, size_t max_vocab, int D);
+  int hot_buffers(hipStream_t s);  // the hot-row path's tables and side stream, on first use
   int destroy();
   // optional: start sorting n >= live nnz (row, bucket) pairs now, concurrently with stream s
   int presort(size_t buckets, size_t n, const void* row_offset, int key_type,

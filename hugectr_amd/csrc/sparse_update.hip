@@ -1803,13 +1803,14 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       const size_t cpg = ceil_div<size_t>(per_g, (size_t)kHotChunk);
       const size_t n_chunks = (size_t)G * cpg;
       const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
-      const bool hot = need_sort && u.hot_loc != nullptr && u.one_hot_flag != nullptr && G > 0 &&
+      const bool hot = need_sort && u.hot_rows > 0 && u.one_hot_flag != nullptr && G > 0 &&
                        G <= kHotMaxStreams &&
                        nnz == buckets && nnz >= u.hot_min_n && nnz < 0xFFFFFFF0ull && lpr_ok &&
                        u.scale_row_offset == nullptr && direct == nullptr &&
                        n_chunks <= (size_t)u.hot_chunks_max && n_chunks <= (size_t)kHotApplyChunks &&
                        !use_library_sort() &&
                        !(ip_env && ip_env[0] == '0');
+      if (hot) HCTR_TRY(u.hot_buffers(s));
       if (hot) {
         HotGeom hg;
         hg.n = (uint32_t)nnz;
@@ -2112,36 +2113,46 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
     const char* hm = getenv("HCTR_HOT_MIN");
     hot_min_n = hm ? (size_t)atoll(hm) : (size_t)262144;
     hot_rows = 0;
+    // (the tables themselves are allocated by the first update that can take the path --
+    //  hot_buffers(): an updater that never sees a one-hot batch never pays for them)
     if (rows > 0 && max_nnz >= hot_min_n && D % 4 == 0 && D / 4 <= 64 && ((D / 4) & (D / 4 - 1)) == 0) {
       hot_rows = (uint32_t)rows;
       const char* hs = getenv("HCTR_HOT_SERIAL");  // "1": both chains on the caller's stream (measurements)
       hot_serial = hs != nullptr && hs[0] == '1';
-      {
-        int lo = 0, hi = 0;
-        HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char* hp = getenv("HCTR_HOT_PRIO");  // "high" / "low": priority of the cold chain
-        const int pr = (hp && hp[0] == 'h') ? hi : ((hp && hp[0] == 'l') ? lo : 0);
-        HCTR_HIP(hipStreamCreateWithPriority(&hot_side, hipStreamNonBlocking, pr));
-      }
       hot_chunks_max = (uint32_t)(ceil_div<size_t>(max_nnz, (size_t)kHotChunk) + kHotMaxStreams);
-      const size_t loc_bytes = (size_t)hot_rows * hot_chunks_max * sizeof(uint16_t);
-      HCTR_HIP(hipMalloc(&hot_loc, loc_bytes));
-      HCTR_HIP(hipMemset(hot_loc, 0xFF, loc_bytes));  // kHotNone everywhere; hot_apply keeps it so
-      const size_t C = hot_chunks_max;
-      HCTR_HIP(hipMalloc(&hot_S, C * kHotChunk * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_loc_blk, (size_t)hot_rows * sizeof(uint32_t)));
-      HCTR_HIP(hipMemset(hot_loc_blk, 0, (size_t)hot_rows * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_meta, C * 2 * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_tpref, C * (kHotTiles + 1) * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_items, (max_nnz / kHotTile + C + 1) * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_joins, 3 * C * kHotTiles * sizeof(uint32_t)));
-      HCTR_HIP(hipMalloc(&hot_counts, 12 * sizeof(uint32_t)));
-      HCTR_HIP(hipMemset(hot_counts, 0, 12 * sizeof(uint32_t)));
-      const size_t part = (size_t)hot_chunks_max * kHotTiles * (size_t)D * sizeof(float);
-      HCTR_HIP(hipMalloc(&hot_head, part));
-      HCTR_HIP(hipMalloc(&hot_tail, part));
     }
   }
+  return HCTR_OK;
+}
+
+int SparseUpdater::hot_buffers(hipStream_t s) {
+  if (hot_loc != nullptr) return HCTR_OK;
+  {
+    int lo = 0, hi = 0;
+    HCTR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* hp = getenv("HCTR_HOT_PRIO");  // "high" / "low": priority of the cold chain
+    const int pr = (hp && hp[0] == 'h') ? hi : ((hp && hp[0] == 'l') ? lo : 0);
+    HCTR_HIP(hipStreamCreateWithPriority(&hot_side, hipStreamNonBlocking, pr));
+  }
+  const size_t C = hot_chunks_max;
+  HCTR_HIP(hipMalloc(&hot_S, C * kHotChunk * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&hot_loc_blk, (size_t)hot_rows * sizeof(uint32_t)));
+  HCTR_HIP(hipMemsetAsync(hot_loc_blk, 0, (size_t)hot_rows * sizeof(uint32_t), s));
+  HCTR_HIP(hipMalloc(&hot_meta, C * 2 * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&hot_tpref, C * (kHotTiles + 1) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&hot_items, (max_nnz / kHotTile + C + 1) * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&hot_joins, 3 * C * kHotTiles * sizeof(uint32_t)));
+  HCTR_HIP(hipMalloc(&hot_counts, 12 * sizeof(uint32_t)));
+  HCTR_HIP(hipMemsetAsync(hot_counts, 0, 12 * sizeof(uint32_t), s));
+  const size_t part = C * kHotTiles * (size_t)D * sizeof(float);
+  HCTR_HIP(hipMalloc(&hot_head, part));
+  HCTR_HIP(hipMalloc(&hot_tail, part));
+  // (last: its presence is what marks the set complete)
+  const size_t loc_bytes = (size_t)hot_rows * hot_chunks_max * sizeof(uint16_t);
+  HCTR_HIP(hipMalloc(&hot_loc, loc_bytes));
+  // kHotNone everywhere; hot_apply keeps it so.  (On the caller's stream: the kernels that follow
+  // on it, and on the side stream behind its fork event, see the tables initialised)
+  HCTR_HIP(hipMemsetAsync(hot_loc, 0xFF, loc_bytes, s));
   return HCTR_OK;
 }
 
