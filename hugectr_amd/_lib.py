@@ -132,6 +132,7 @@ _SIGNATURES = {
     "hctr_det_export": (c_int, [_P, c_size_t, _P, _P, c_size_t, _SZP, _P]),
     "hctr_det_lookup_index": (c_int, [_P, c_size_t, _P, c_size_t, c_int, _P, _P]),
     "hctr_det_rows": (c_int, [_P, c_size_t, POINTER(_P), _SZP]),
+    "hctr_det_row_store": (c_int, [_P, POINTER(_P), POINTER(ctypes.c_uint64)]),
     "hctr_det_lookup_rows": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, c_int, _P, _P,
                                      POINTER(c_uint64), _P]),
     "hctr_radix_sort_temp_bytes": (c_size_t, [c_size_t]),
@@ -178,6 +179,7 @@ _SIGNATURES = {
                                                      c_int, _P]),
     "hctr_updater_set_ftrl": (c_int, [_P, c_float, c_float, c_float]),
     "hctr_updater_set_grad_map": (c_int, [_P, c_size_t, c_size_t]),
+    "hctr_updater_set_row_bound": (c_int, [_P, ctypes.c_uint64]),
     "hctr_updater_reduce_presorted": (c_int, [_P, c_size_t, c_size_t, _P, _P, _P, _P, c_int,
                                               c_size_t, _P, _P]),
     "hctr_emb_index": (c_int, [_P, c_int, _P, _P, c_size_t, _P]),

@@ -324,7 +324,8 @@ __global__ void __launch_bounds__(kBlock)
 
 struct DetClass {
   HashTable ht;
-  float* rows = nullptr;
+  float* rows = nullptr;  // (inside hctr_det::arena when the table keeps one row store)
+  bool owns_rows = true;
   size_t cap = 0;         // rows allocated == ht.capacity
   int dim = 0;
   size_t head_bound = 0;  // host upper bound of the row counter (value head)
@@ -343,6 +344,13 @@ struct hctr_det {
   float init_val = 0.f;
   uint64_t seed = 0;
   uint64_t adam_times = 0;
+  // Classes of ONE dimension (an embedding_collection group always: one ev_size) keep their rows in
+  // one allocation, class c at row sum(cap of the classes before it): the table-wide row numbers
+  // that hctr_det_lookup_rows hands out are then rows of one flat [arena_rows][dim] table, and the
+  // static tables' gather and sparse-update kernels run on a dynamic table as they are
+  // (hctr_det_row_store).  A class that grows re-lays the arena out (doubling: amortised).
+  float* arena = nullptr;
+  size_t arena_rows = 0;
   uint64_t* idx = nullptr;  // scratch row indices
   uint64_t* idx2 = nullptr;
   size_t idx_cap = 0;
@@ -372,11 +380,12 @@ int det_scratch(hctr_det* h, size_t n) {
   return HCTR_OK;
 }
 
-int class_create(DetClass& c, size_t cap, int dim, int key_type) {
+int class_create(DetClass& c, size_t cap, int dim, int key_type, bool owns_rows) {
   c.dim = dim;
   c.cap = cap;
+  c.owns_rows = owns_rows;
   HCTR_TRY(c.ht.create(cap, key_type));
-  HCTR_HIP(hipMalloc(&c.rows, cap * (size_t)dim * sizeof(float)));
+  if (owns_rows) HCTR_HIP(hipMalloc(&c.rows, cap * (size_t)dim * sizeof(float)));
   HCTR_HIP(hipMalloc(&c.d_erased, sizeof(unsigned long long)));
   HCTR_HIP(hipMemset(c.d_erased, 0, sizeof(unsigned long long)));
   c.head_bound = 0;
@@ -385,7 +394,7 @@ int class_create(DetClass& c, size_t cap, int dim, int key_type) {
 
 void class_destroy(DetClass& c) {
   c.ht.destroy();
-  if (c.rows) (void)hipFree(c.rows);
+  if (c.rows && c.owns_rows) (void)hipFree(c.rows);
   if (c.d_erased) (void)hipFree(c.d_erased);
   c.rows = nullptr;
   c.d_erased = nullptr;
@@ -393,7 +402,37 @@ void class_destroy(DetClass& c) {
 
 // make room for n more rows (cuco::dynamic_map::reserve): doubling re-allocation of the row store
 // and a re-index of the live keys into a table of the new capacity (tombstones are dropped)
-int class_reserve(DetClass& c, size_t n, int key_type, hipStream_t s) {
+// one allocation for the row stores of all classes, class ci at row sum(cap[0..ci)); rows
+// [0, keep[ci]) of every class travel to their new place
+int arena_layout(hctr_det* h, const std::vector<size_t>& cap, const std::vector<size_t>& keep,
+                 hipStream_t s) {
+  const size_t dim = (size_t)h->cls[0].dim;
+  size_t total = 0;
+  for (size_t v : cap) total += v;
+  float* na = nullptr;
+  HCTR_HIP(hipMalloc(&na, total * dim * sizeof(float)));
+  size_t base = 0;
+  for (size_t ci = 0; ci < h->cls.size(); ci++) {
+    DetClass& c = h->cls[ci];
+    if (c.rows != nullptr && keep[ci] > 0)
+      HCTR_HIP(hipMemcpyAsync(na + base * dim, c.rows, keep[ci] * dim * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
+    base += cap[ci];
+  }
+  HCTR_HIP(hipStreamSynchronize(s));
+  if (h->arena) (void)hipFree(h->arena);
+  h->arena = na;
+  h->arena_rows = total;
+  base = 0;
+  for (size_t ci = 0; ci < h->cls.size(); ci++) {
+    h->cls[ci].rows = na + base * dim;
+    h->cls[ci].cap = cap[ci];
+    base += cap[ci];
+  }
+  return HCTR_OK;
+}
+
+int class_reserve(hctr_det* h, DetClass& c, size_t n, int key_type, hipStream_t s) {
   if (c.head_bound + n <= c.cap) return HCTR_OK;
   size_t head = 0;
   HCTR_TRY(c.ht.value_head(s, &head));  // synchronises: the exact row counter
@@ -423,18 +462,30 @@ int class_reserve(DetClass& c, size_t n, int key_type, hipStream_t s) {
     HCTR_TRY(nht.insert(d_keys, d_vals, live, s));
   }
   HCTR_TRY(nht.set_value_head(head, s));
-  float* nrows = nullptr;
-  HCTR_HIP(hipMalloc(&nrows, ncap * (size_t)c.dim * sizeof(float)));
-  HCTR_HIP(hipMemcpyAsync(nrows, c.rows, head * (size_t)c.dim * sizeof(float),
-                          hipMemcpyDeviceToDevice, s));
-  HCTR_HIP(hipStreamSynchronize(s));
+  if (h->arena != nullptr) {
+    // (head_bound: the host's upper bound of a class's row counter -- what lies above it was
+    //  never handed out)
+    std::vector<size_t> cap(h->cls.size()), keep(h->cls.size());
+    for (size_t ci = 0; ci < h->cls.size(); ci++) {
+      const DetClass& o = h->cls[ci];
+      cap[ci] = &o == &c ? ncap : o.cap;
+      keep[ci] = &o == &c ? head : (o.head_bound < o.cap ? o.head_bound : o.cap);
+    }
+    HCTR_TRY(arena_layout(h, cap, keep, s));
+  } else {
+    float* nrows = nullptr;
+    HCTR_HIP(hipMalloc(&nrows, ncap * (size_t)c.dim * sizeof(float)));
+    HCTR_HIP(hipMemcpyAsync(nrows, c.rows, head * (size_t)c.dim * sizeof(float),
+                            hipMemcpyDeviceToDevice, s));
+    HCTR_HIP(hipStreamSynchronize(s));
+    (void)hipFree(c.rows);
+    c.rows = nrows;
+    c.cap = ncap;
+  }
   (void)hipFree(d_keys);
   (void)hipFree(d_vals);
-  (void)hipFree(c.rows);
   c.ht.destroy();
   c.ht = nht;
-  c.rows = nrows;
-  c.cap = ncap;
   // rows of erased keys stay allocated (indices are never reused); only the index forgets them
   return HCTR_OK;
 }
@@ -463,7 +514,7 @@ inline const void* key_at(const hctr_det* h, const void* keys, size_t off) {
 // lookup with insertion of unseen keys; leaves row indices in h->idx[0..n)
 int class_lookup_insert(hctr_det* h, DetClass& c, size_t cls_index, const void* keys, size_t n,
                         uint64_t* idx, hipStream_t s) {
-  HCTR_TRY(class_reserve(c, n, h->key_type, s));
+  HCTR_TRY(class_reserve(h, c, n, h->key_type, s));
   HCTR_TRY(c.ht.get_insert(keys, n, nullptr, idx, s));
   c.head_bound += n;
   hipLaunchKernelGGL(det_init_rows_kernel, dim3(grid_for(n * (size_t)c.dim, kBlock, 2048)),
@@ -504,6 +555,8 @@ int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const
   }
   const size_t cap = initial_capacity_per_class ? initial_capacity_per_class : 1048576;
   h->cls.resize(num_classes);
+  bool flat = true;  // one dimension: one row store (hctr_det::arena)
+  for (size_t i = 1; i < num_classes; i++) flat = flat && dimension_per_class[i] == dimension_per_class[0];
   for (size_t i = 0; i < num_classes; i++) {
     if (dimension_per_class[i] == 0 || dimension_per_class[i] > (1u << 20)) {
       set_error("dimension_per_class out of range");
@@ -511,9 +564,18 @@ int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const
       delete h;
       return HCTR_ERR_INVALID_ARG;
     }
-    const int rc = class_create(h->cls[i], cap, (int)dimension_per_class[i], key_type);
+    const int rc = class_create(h->cls[i], cap, (int)dimension_per_class[i], key_type, !flat);
     if (rc != HCTR_OK) {
       for (size_t j = 0; j <= i; j++) class_destroy(h->cls[j]);
+      delete h;
+      return rc;
+    }
+  }
+  if (flat) {
+    const std::vector<size_t> caps(num_classes, cap), none(num_classes, 0);
+    const int rc = arena_layout(h, caps, none, nullptr);
+    if (rc != HCTR_OK) {
+      for (auto& c : h->cls) class_destroy(c);
       delete h;
       return rc;
     }
@@ -527,6 +589,7 @@ int hctr_det_destroy(hctr_det* h) {
   if (!h) return HCTR_OK;
   (void)hipDeviceSynchronize();
   for (auto& c : h->cls) class_destroy(c);
+  if (h->arena) (void)hipFree(h->arena);
   if (h->idx) (void)hipFree(h->idx);
   if (h->idx2) (void)hipFree(h->idx2);
   if (h->ptr_w) (void)hipFree(h->ptr_w);
@@ -576,7 +639,7 @@ int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size
   std::vector<size_t> need(h->cls.size(), 0);
   for (const Range& r : rs) need[r.cls] += r.n;
   for (size_t ci = 0; ci < need.size(); ci++)
-    if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
+    if (need[ci]) HCTR_TRY(class_reserve(h, h->cls[ci], need[ci], h->key_type, s));
   for (const Range& r : rs) {
     DetClass& c = h->cls[r.cls];
     if (r.n == 0) continue;
@@ -683,7 +746,7 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
         }
       if (any) {
         for (size_t ci = 0; ci < ncls; ci++)
-          if (need[ci]) HCTR_TRY(class_reserve(h->cls[ci], need[ci], h->key_type, s));
+          if (need[ci]) HCTR_TRY(class_reserve(h, h->cls[ci], need[ci], h->key_type, s));
         for (const Range& r : rs)
           if (miss[r.cls])
             HCTR_TRY(class_lookup_insert(h, h->cls[r.cls], r.cls, key_at(h, keys, r.off), r.n,
@@ -818,6 +881,13 @@ int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacit
   HCTR_REQUIRE(h && class_index < h->cls.size() && rows, "class_index");
   *rows = h->cls[class_index].rows;
   if (capacity) *capacity = h->cls[class_index].cap;
+  return HCTR_OK;
+}
+
+int hctr_det_row_store(hctr_det* h, float** rows, uint64_t* total_rows) {
+  HCTR_REQUIRE(h && rows, "null pointer");
+  *rows = h->arena;
+  if (total_rows) *total_rows = h->arena ? (uint64_t)h->arena_rows : 0;
   return HCTR_OK;
 }
 

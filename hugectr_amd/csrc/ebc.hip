@@ -801,6 +801,12 @@ int hctr_updater_set_grad_map(hctr_updater* u, size_t samples, size_t lookups) {
   return HCTR_OK;
 }
 
+int hctr_updater_set_row_bound(hctr_updater* u, uint64_t rows) {
+  HCTR_REQUIRE(u, "null handle");
+  u->impl.row_bound = (size_t)rows;
+  return HCTR_OK;
+}
+
 int hctr_updater_destroy(hctr_updater* u) {
   if (!u) return HCTR_OK;
   (void)hipDeviceSynchronize();

@@ -87,6 +87,13 @@ class DynamicEmbeddingTable:
                                        ptr(ptrs), ptr(rows), base, stream_ptr()))
         return ptrs, rows, list(base)
 
+    def row_store(self):
+        """(address, rows) of the one flat fp32 table that the row numbers of lookup_rows index when
+        all classes share a dimension, else (None, 0).  Valid until the next inserting call."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        check(lib.hctr_det_row_store(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return (p.value, int(n.value)) if p.value else (None, 0)
+
     def scatter_add(self, keys, elements, id_spaces=None, id_space_offsets=None):
         sp, so, ns = self._ranges(keys.numel(), id_spaces, id_space_offsets)
         elements = elements.contiguous().float()

@@ -330,9 +330,13 @@ class EmbeddingCollection:
         self.d_nnz = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.counts = torch.zeros(self.L * self.bpg, dtype=torch.int64, device=self.dev)
         self._upd = ctypes.c_void_p()
-        # (dynamic: the updater only sums gradients per unique row, rows are numbered < max_nnz)
-        check(lib.hctr_updater_create(self.max_nnz, self.max_nnz if self.dynamic else self.local_rows,
+        # (dynamic: the table grows -- every update names the rows handed out so far,
+        #  hctr_updater_set_row_bound; the unique-row reduce numbers its rows < max_nnz)
+        check(lib.hctr_updater_create(self.max_nnz, 0xFFFFFFEF if self.dynamic else self.local_rows,
                                       self.ev, ctypes.byref(self._upd)))
+        # HCTR_DYNAMIC_FLAT=0: the pointer-per-key lookup and the unique-key optimizer step for
+        # every optimizer (what optimizers with a state table take in any case)
+        self._dyn_flat = self.dynamic and os.environ.get("HCTR_DYNAMIC_FLAT", "1") != "0"
         if optimizer == _lib.OPT_FTRL and not self.dynamic:
             check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
@@ -576,9 +580,26 @@ class EmbeddingCollection:
         if nnz == 0:
             return send.zero_()
         keys = self.indices[:nnz]
-        ptrs, rows, base = self.det.lookup_rows(keys, self.seg_class, seg, insert=self.training)
+        # one ev_size per group: the classes' rows are ONE flat table and the row numbers index it
+        # (hctr_det_row_store) -- the static tables' gather runs on them, no pointer per key
+        flat = self._dyn_flat
+        ptrs, rows, base = self.det.lookup_rows(keys, self.seg_class, seg, insert=self.training,
+                                                want_ptrs=not flat)
         self._dyn_rows, self._dyn_base = rows, base
         bm = direct and self.batch_major  # one GPU: pooled straight into the batch-major output
+        if flat:
+            store, _ = self.det.row_store()  # (after the inserts: growing moves it)
+            if direct:
+                check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
+                                                   _lib.KEY_I64, ptr(rows), store, ptr(send),
+                                                   _DT[self.out_dtype], 1 if self._multi_hot else 0,
+                                                   self.bpg if bm else 0, self.L if bm else 0,
+                                                   ptr(self.d_one_hot), stream_ptr()))
+            else:
+                check(lib.hctr_forward_pool(self.nb, self.ev, 0, ptr(self.out_range), _lib.KEY_I64,
+                                            ptr(rows), store, ptr(send), _DT[self.out_dtype],
+                                            stream_ptr()))
+            return send
         check(lib.hctr_forward_pool_ptrs_mapped(self.nb, self.ev, 0, ptr(self.out_range), ptr(ptrs),
                                                 ptr(send), _DT[self.out_dtype],
                                                 self.bpg if bm else 0, self.L if bm else 0,
@@ -588,6 +609,19 @@ class EmbeddingCollection:
     def _dynamic_apply(self, top_grad: torch.Tensor):
         nnz = self._nnz_host
         if nnz == 0:
+            return
+        if self._dyn_flat and self.optimizer == _lib.OPT_SGD:
+            # SGD keeps no state table: sort by row, sum per row in bucket order and apply --
+            # sgd_update_grad_kernel + scatter_add (dynamic_embedding.cu:300-330, optimizers.cuh:
+            # 29-45) in the segmented reduce of the static tables' update, on the flat row store:
+            # no unique-key list, no wgrad buffer, no second probe of the keys
+            store, total = self.det.row_store()
+            check(lib.hctr_updater_set_row_bound(self._upd, total))
+            check(lib.hctr_updater_update(self._upd, self.nb, nnz, ptr(self.out_range),
+                                          ptr(self._dyn_rows), ptr(top_grad), _DT[self.out_dtype],
+                                          _lib.OPT_SGD, _lib.UPDATE_LOCAL, self.lr, 0.9, 0.999,
+                                          self.epsilon, 0.0, self.scaler, self._times, store,
+                                          None, None, stream_ptr()))
             return
         urow = torch.empty(nnz, dtype=torch.int64, device=self.dev)
         ukey = torch.empty(nnz, dtype=torch.int64, device=self.dev)

@@ -347,6 +347,9 @@ int hctr_updater_set_ftrl(hctr_updater* u, float lambda1, float lambda2, float b
  * transpose is an address computation of the update (and of hctr_forward_pool_mapped).  Sum
  * combiner only; (0, 0) switches the map off. */
 int hctr_updater_set_grad_map(hctr_updater* u, size_t samples, size_t lookups);
+/* rows handed out so far are < rows (0 = unknown: max_rows of hctr_updater_create): the row sort
+ * of the next updates covers log2(rows) bits only.  For a table that grows (hctr_det_row_store). */
+int hctr_updater_set_row_bound(hctr_updater* u, uint64_t rows);
 int hctr_updater_update(hctr_updater* u, size_t buckets, size_t nnz, const int64_t* bucket_range,
                         const uint64_t* indices, const void* grad, int grad_dtype, int optimizer,
                         int update_type, float lr, float beta1, float beta2, float epsilon,
@@ -532,6 +535,16 @@ int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, 
 int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, size_t num_keys,
                           int insert, uint64_t* row_index, hctr_stream_t stream);
 int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacity);
+/* A table whose classes share ONE dimension (an embedding_collection group: one ev_size) keeps all
+ * rows in one allocation, class c from row class_row_base[c] on, so the table-wide row numbers of
+ * hctr_det_lookup_rows index one flat [total_rows][dim] fp32 table: the static tables' gather
+ * (hctr_forward_pool*) and sparse update (hctr_updater_update) then run on a dynamic table as they
+ * are -- embedding::DynamicEmbeddingTable::lookup + update
+ * (R/HugeCTR/embedding_storage/dynamic_embedding.cu:130-330) without the pointer list, the unique
+ * list and the wgrad buffer in between.  *rows = NULL when the classes differ in dimension.  The
+ * pointer (and every class's hctr_det_rows pointer) changes when ANY class grows, i.e. only
+ * inside a call that inserts. */
+int hctr_det_row_store(hctr_det* h, float** rows, uint64_t* total_rows);
 /* embedding::DynamicEmbeddingTable::lookup (R/HugeCTR/embedding_storage/dynamic_embedding.cu:
  * 130-160): keys grouped by id space (HOST id_spaces / id_space_offsets as in hctr_det_lookup) ->
  * per key the address of its vector (elements, may be NULL) and / or a row number that is unique

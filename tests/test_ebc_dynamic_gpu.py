@@ -309,3 +309,62 @@ def test_one_gpu_direct_path_on_dynamic_tables_equals_staged(monkeypatch, batch_
         staged.backward_and_update(g)
         direct.backward_and_update(g)
     assert staged.det.size() == direct.det.size() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_flat_row_store_gives_the_bits_of_the_pointer_and_unique_key_path(monkeypatch, direct, dtype):
+    """One ev_size per group: the classes' rows are one flat table (hctr_det_row_store), so the
+    static tables' gather runs on the row numbers and -- SGD -- their sort + segmented reduce
+    applies the step in place.  Same pooled vectors and the same table, bit for bit, as the
+    pointer-per-key gather and the unique keys -> wgrad -> optimizer kernel -> scatter_add flow of
+    the reference (dynamic_embedding.cu:130-330) that HCTR_DYNAMIC_FLAT=0 keeps; the classes grow
+    (and the store moves) several times on the way."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(77)
+    B, ev = 96, 32
+    vocabs = [3000, 9, 400, 50000]
+    lookup_table = [0, 1, 2, 2, 3, 0]
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", -1, ev) for i in range(len(vocabs))]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l, t in enumerate(lookup_table):
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", "sum")
+    kw = dict(lr=0.05, optimizer=_lib.OPT_SGD, scaler=8.0, batch_major=True, max_hotness=6,
+              out_dtype=getattr(torch, dtype), seed=5, storage="dynamic", initializer="",
+              init_capacity=16)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", direct)
+    monkeypatch.setenv("HCTR_DYNAMIC_FLAT", "0")
+    ptrs = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    monkeypatch.setenv("HCTR_DYNAMIC_FLAT", "1")
+    flat = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    assert flat._dyn_flat and not ptrs._dyn_flat and flat.det.row_store()[0]
+    L = len(lookup_table)
+    caps = [flat.det.capacity_per_class()]
+    for step in range(6):
+        lens = rng.integers(0, 7, size=L * B).astype(np.int64)
+        br = np.zeros(L * B + 1, np.int64)
+        np.cumsum(lens, out=br[1:])
+        keys = np.concatenate([rng.integers(0, vocabs[lookup_table[l]], size=int(lens[l * B:(l + 1) * B].sum()))
+                               for l in range(L)]).astype(np.int64)
+        kt, brt = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        a, b = ptrs.forward(kt, brt), flat.forward(kt, brt)
+        assert torch.equal(a, b), step
+        g = torch.randn(a.shape, device="cuda").to(a.dtype)
+        ptrs.backward_and_update(g)
+        flat.backward_and_update(g)
+        caps.append(flat.det.capacity_per_class())
+    assert caps[-1] != caps[0], "the test is meant to cross several growth steps"
+    assert ptrs.det.size() == flat.det.size() > 0
+    for c in range(len(flat.det.dims)):
+        (ka, va), (kb, vb) = ptrs.det.export(c), flat.det.export(c)
+        oa, ob = torch.argsort(ka), torch.argsort(kb)
+        assert torch.equal(ka[oa], kb[ob]) and torch.equal(va[oa], vb[ob]), c
+    # eval: unseen keys are not inserted and pool as zeros on both paths
+    ptrs.training = flat.training = False
+    keys = torch.arange(10 ** 9, 10 ** 9 + L * B, dtype=torch.int64).cuda()
+    br = torch.arange(L * B + 1, dtype=torch.int64).cuda()
+    a, b = ptrs.forward(keys, br), flat.forward(keys, br)
+    assert torch.equal(a, b) and float(b.abs().max()) == 0.0
