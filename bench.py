@@ -1034,7 +1034,8 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
     if os.path.exists(pmc_path) and B == 65536 and D == 128 and abs(alpha - 1.1) < 1e-9:
         try:  # the gather kernel of this leg (rocprofv3 --pmc passes, tools/measure_round.sh)
             j = json.load(open(pmc_path))
-            kern = ("pool_ptrs_vec4_kernel" if dynamic else
+            # (dynamic tables of one dimension are one flat row store: the static gather runs on them)
+            kern = ("pool_ptrs_vec4_kernel" if dynamic and not ebc._dyn_flat else
                     "pool_flat_kernel" if kind == "multi_hot" else "pool_vec4_kernel")
             pmc_src = f"{os.path.relpath(pmc_path, ROOT)} [{kern}] @ {j.get('commit', '?')}"
             pmc_stale = j.get("csrc_hash") != _csrc_hash()  # (quoted for these sources only)

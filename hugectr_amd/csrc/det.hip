@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(kBlock)
     det_find_multi_kernel(const DetClassDesc* __restrict__ cls, const uint32_t* __restrict__ seg_class,
                           const uint64_t* __restrict__ seg_off, int n_seg,
                           const K* __restrict__ keys, size_t n, uint64_t* __restrict__ idx,
-                          uint32_t* __restrict__ miss) {
+                          uint32_t* __restrict__ miss, uint64_t* __restrict__ out_row) {
   const long long empty = KeyTraits<K>::empty;
   for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
        i += (size_t)gridDim.x * kBlock) {
@@ -155,6 +155,8 @@ __global__ void __launch_bounds__(kBlock)
     }
     idx[i] = res;
     if (res == kInvalidIndex) miss[c] = 1u;
+    // (the table-wide row number right away: final unless a class has to insert and may grow)
+    if (out_row) out_row[i] = res != kInvalidIndex ? cls[c].row_base + res : kInvalidIndex;
   }
 }
 
@@ -363,6 +365,10 @@ struct hctr_det {
   uint64_t* d_seg_off = nullptr;
   uint32_t* d_miss = nullptr;
   size_t seg_cap = 0;
+  // host copies of what d_desc / d_seg_class / d_seg_off hold (det_upload_spaces)
+  std::vector<unsigned char> up_desc;
+  std::vector<uint32_t> up_seg_class;
+  std::vector<uint64_t> up_seg_off;
 };
 
 namespace {
@@ -669,11 +675,18 @@ static int det_upload_spaces(hctr_det* h, const std::vector<Range>& rs,
     HCTR_HIP(hipMalloc(&h->d_seg_class, c * sizeof(uint32_t)));
     HCTR_HIP(hipMalloc(&h->d_seg_off, c * sizeof(uint64_t)));
     h->seg_cap = c;
+    h->up_seg_class.clear();
+    h->up_seg_off.clear();
   }
   std::vector<DetClassDesc> desc(ncls);
+  memset((void*)desc.data(), 0, ncls * sizeof(DetClassDesc));
   for (size_t ci = 0; ci < ncls; ci++) {
     const DetClass& c = h->cls[ci];
-    desc[ci] = {c.ht.entries, c.ht.size, c.rows, base[ci], c.dim};
+    desc[ci].tab = c.ht.entries;
+    desc[ci].size = c.ht.size;
+    desc[ci].rows = c.rows;
+    desc[ci].row_base = base[ci];
+    desc[ci].dim = c.dim;
   }
   std::vector<uint32_t> sc(rs.size());
   std::vector<uint64_t> so(rs.size());
@@ -681,13 +694,29 @@ static int det_upload_spaces(hctr_det* h, const std::vector<Range>& rs,
     sc[i] = (uint32_t)rs[i].cls;
     so[i] = rs[i].off;
   }
+  // what the device holds already stays (a training loop repeats the same id spaces over tables
+  // that stopped growing: three small copies less in front of every lookup)
+  auto same = [](const auto& a, const auto& b) {
+    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+  };
+  std::vector<unsigned char> dbytes(ncls * sizeof(DetClassDesc));
+  memcpy(dbytes.data(), desc.data(), dbytes.size());  // (padding bytes of the struct: value-initialised above)
   // (pageable sources: the runtime has consumed them when these calls return)
-  HCTR_HIP(hipMemcpyAsync(h->d_desc, desc.data(), ncls * sizeof(DetClassDesc),
-                          hipMemcpyHostToDevice, s));
-  HCTR_HIP(hipMemcpyAsync(h->d_seg_class, sc.data(), sc.size() * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, s));
-  HCTR_HIP(hipMemcpyAsync(h->d_seg_off, so.data(), so.size() * sizeof(uint64_t),
-                          hipMemcpyHostToDevice, s));
+  if (!same(dbytes, h->up_desc)) {
+    HCTR_HIP(hipMemcpyAsync(h->d_desc, desc.data(), ncls * sizeof(DetClassDesc),
+                            hipMemcpyHostToDevice, s));
+    h->up_desc = dbytes;
+  }
+  if (!same(sc, h->up_seg_class)) {
+    HCTR_HIP(hipMemcpyAsync(h->d_seg_class, sc.data(), sc.size() * sizeof(uint32_t),
+                            hipMemcpyHostToDevice, s));
+    h->up_seg_class = sc;
+  }
+  if (!same(so, h->up_seg_off)) {
+    HCTR_HIP(hipMemcpyAsync(h->d_seg_off, so.data(), so.size() * sizeof(uint64_t),
+                            hipMemcpyHostToDevice, s));
+    h->up_seg_off = so;
+  }
   return HCTR_OK;
 }
 
@@ -721,14 +750,19 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
     HCTR_TRY(det_upload_spaces(h, rs, base, s));
     HCTR_HIP(hipMemsetAsync(h->d_miss, 0, ncls * sizeof(uint32_t), s));
     const int grid = grid_for(num_keys, kBlock, 8192);
+    // row numbers only (the flat row store's callers): the probe writes them itself, and the
+    // address / row pass below runs only when a class inserted (its rows, and after a growth every
+    // class's base, are then different ones)
+    uint64_t* early_rows = elements == nullptr ? row_index : nullptr;
+    bool rows_done = early_rows != nullptr;
     if (h->key_type == HCTR_KEY_U32)
       hipLaunchKernelGGL(det_find_multi_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, h->d_desc,
                          h->d_seg_class, h->d_seg_off, (int)rs.size(), (const uint32_t*)keys,
-                         num_keys, h->idx, h->d_miss);
+                         num_keys, h->idx, h->d_miss, early_rows);
     else
       hipLaunchKernelGGL(det_find_multi_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, h->d_desc,
                          h->d_seg_class, h->d_seg_off, (int)rs.size(), (const long long*)keys,
-                         num_keys, h->idx, h->d_miss);
+                         num_keys, h->idx, h->d_miss, early_rows);
     HCTR_LAUNCH_CHECK();
     if (insert) {
       // 2. only those classes take the inserting path (and may grow: every insertion happens
@@ -753,13 +787,16 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
                                          h->idx + r.off, s));
         rebase();
         HCTR_TRY(det_upload_spaces(h, rs, base, s));
+        rows_done = false;
       }
     }
     // 3. addresses / table-wide row numbers of all keys
-    hipLaunchKernelGGL(det_rows_multi_kernel, dim3(grid_for(num_keys, kBlock, 8192)), dim3(kBlock),
-                       0, s, h->d_desc, h->d_seg_class, h->d_seg_off, (int)rs.size(), h->idx,
-                       num_keys, elements, row_index);
-    HCTR_LAUNCH_CHECK();
+    if (!rows_done) {
+      hipLaunchKernelGGL(det_rows_multi_kernel, dim3(grid_for(num_keys, kBlock, 8192)), dim3(kBlock),
+                         0, s, h->d_desc, h->d_seg_class, h->d_seg_off, (int)rs.size(), h->idx,
+                         num_keys, elements, row_index);
+      HCTR_LAUNCH_CHECK();
+    }
   }
   if (class_row_base)
     for (size_t ci = 0; ci <= ncls; ci++) class_row_base[ci] = base[ci];
