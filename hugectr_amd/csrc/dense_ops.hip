@@ -1041,6 +1041,79 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ================================================================================================
+// DCN-v2 cross layer, the elementwise step of one layer's backward in the activations' 16-bit type
+// (MultiCrossBackwardFunctorv2: fused_mul_fma3, R/HugeCTR/src/layers/multi_cross_layer.cu:391-424,
+// 127-165 -- S0 = dY .* X0, dX += dY .* H, one rounding per element as its paired-half kernel
+// rounds -- and the bias gradient db = column sums of S0, which the reference takes in the
+// epilogue of the dV GEMM, :770-776): dY is read once for both products, S0 is summed from
+// registers.  Layout and the two-stage fixed-order column sums are relu_bwd_bias_kernel's.
+// FIRST (the last layer, visited first): dX = dY .* H, the accumulator is not read (nor cleared
+// beforehand).
+// ================================================================================================
+template <bool BF, bool FIRST>
+__global__ void __launch_bounds__(kBlock)
+    cross_v2_bwd_step_kernel(size_t rows, int n, int cw, int rg, const unsigned short* __restrict__ dy,
+                             const unsigned short* __restrict__ x0,
+                             const unsigned short* __restrict__ hm, unsigned short* __restrict__ acc_io,
+                             unsigned short* __restrict__ s0, float* __restrict__ partial) {
+  using H = H16<BF>;
+  __shared__ float red[kBlock * 8];
+  const int n8 = n / 8;
+  const int c8 = threadIdx.x % cw, g = threadIdx.x / cw;
+  const bool live = g < rg;
+  const size_t r0 = (size_t)blockIdx.x * kRbRows;
+  const size_t r1 = r0 + kRbRows < rows ? r0 + kRbRows : rows;
+  for (int cc = c8; cc - c8 < n8; cc += cw) {  // uniform trip count: every thread reaches the barriers
+    float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live && cc < n8) {
+#pragma unroll 2
+      for (size_t r = r0 + g; r < r1; r += rg) {
+        const size_t at = r * n + cc * 8;
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + at);
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x0 + at);
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(hm + at);
+        u32x4 av = {0u, 0u, 0u, 0u};
+        if (!FIRST) av = *reinterpret_cast<const u32x4*>(acc_io + at);
+        u32x4 so, ao;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float g0 = H::to_f32((unsigned short)(gv[e] & 0xFFFFu));
+          const float g1 = H::to_f32((unsigned short)(gv[e] >> 16));
+          // (the product of two 16-bit values is exact in fp32: one rounding, to the 16-bit type)
+          const unsigned short p0 = H::from_f32(g0 * H::to_f32((unsigned short)(xv[e] & 0xFFFFu)));
+          const unsigned short p1 = H::from_f32(g1 * H::to_f32((unsigned short)(xv[e] >> 16)));
+          sum[2 * e] += H::to_f32(p0);
+          sum[2 * e + 1] += H::to_f32(p1);
+          so[e] = (unsigned)p0 | ((unsigned)p1 << 16);
+          float a0 = g0 * H::to_f32((unsigned short)(hv[e] & 0xFFFFu));
+          float a1 = g1 * H::to_f32((unsigned short)(hv[e] >> 16));
+          if (!FIRST) {
+            a0 += H::to_f32((unsigned short)(av[e] & 0xFFFFu));
+            a1 += H::to_f32((unsigned short)(av[e] >> 16));
+          }
+          ao[e] = (unsigned)H::from_f32(a0) | ((unsigned)H::from_f32(a1) << 16);
+        }
+        *reinterpret_cast<u32x4*>(s0 + at) = so;
+        *reinterpret_cast<u32x4*>(acc_io + at) = ao;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[e * kBlock + threadIdx.x] = sum[e];
+    __syncthreads();
+    if (g == 0 && cc < n8) {
+      float* p = partial + (size_t)blockIdx.x * n + cc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float t = 0.f;
+        for (int k = 0; k < rg; k++) t += red[e * kBlock + k * cw + c8];
+        p[e] = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // db[c..c+3] = sum over tiles of partial[tile][c..c+3]: a workgroup owns 8 float4 column groups x 32
 // tile groups; the 32 group sums are added in fixed order through LDS.
 __global__ void __launch_bounds__(kBlock)
@@ -2054,6 +2127,37 @@ int hctr_relu_bwd_bias(size_t rows, int n, const void* dy, const void* y, void* 
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div<int>(n, 32)), dim3(kBlock), 0, s,
                      tiles, n, workspace, db);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+int hctr_cross_v2_bwd_step(size_t batch, int width, const void* dy, const void* x0, const void* h,
+                           void* acc, void* s0, float* db, float* workspace, int first, int dtype,
+                           hctr_stream_t stream) {
+  HCTR_REQUIRE(width > 0 && width % 8 == 0, "width must be a multiple of 8");
+  HCTR_REQUIRE(dtype == HCTR_EMB_BF16 || dtype == HCTR_EMB_F16, "16-bit dtypes only");
+  if (batch == 0) return HCTR_OK;
+  HCTR_REQUIRE(dy && x0 && h && acc && s0 && db && workspace, "null pointer");
+  hipStream_t s = as_stream(stream);
+  const size_t tiles = ceil_div<size_t>(batch, (size_t)kRbRows);
+  const int cw = width / 8 < kBlock ? width / 8 : kBlock;
+  const int rg = kBlock / cw;
+#define HCTR_CROSS_STEP(BF_, FIRST_)                                                              \
+  hipLaunchKernelGGL((cross_v2_bwd_step_kernel<BF_, FIRST_>), dim3((unsigned)tiles), dim3(kBlock), \
+                     0, s, batch, width, cw, rg, (const unsigned short*)dy,                        \
+                     (const unsigned short*)x0, (const unsigned short*)h, (unsigned short*)acc,    \
+                     (unsigned short*)s0, workspace)
+  if (dtype == HCTR_EMB_BF16) {
+    if (first) HCTR_CROSS_STEP(true, true);
+    else HCTR_CROSS_STEP(true, false);
+  } else {
+    if (first) HCTR_CROSS_STEP(false, true);
+    else HCTR_CROSS_STEP(false, false);
+  }
+#undef HCTR_CROSS_STEP
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div<int>(width, 32)), dim3(kBlock), 0, s,
+                     tiles, width, workspace, db);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
-from .dense import split_k_wgrad
+from .dense import _DT16, split_k_wgrad
 
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
 
@@ -218,14 +218,29 @@ class _CrossV2Fn(torch.autograd.Function):
         xs, ps, hs = sv[2:2 + L], sv[2 + L:2 + 2 * L], sv[2 + 2 * L:2 + 3 * L]
         x0 = xs[0]
         dy = grad.contiguous()
-        acc = torch.zeros_like(x0)
+        acc = torch.empty_like(x0)
         wdt = torch.float32 if x0.dtype in (torch.float16, torch.bfloat16) else x0.dtype
         dU = torch.empty(Ut.shape, dtype=wdt, device=x0.device)
         dV = torch.empty(Vt.shape, dtype=wdt, device=x0.device)
         db = torch.empty((L, x0.shape[1]), dtype=wdt, device=x0.device)
+        B, w = x0.shape
+        fused = x0.is_cuda and x0.dtype in _DT16 and w % 8 == 0
+        if fused:
+            # S0 = dY .* X0, dX += dY .* H and db = colsum(S0) in one pass over dY (HIP), as the
+            # reference's fused_mul_fma3 + the dV GEMM's bias-gradient epilogue
+            s0 = torch.empty_like(x0)
+            ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, dtype=torch.float32,
+                             device=x0.device)
+        else:
+            acc.zero_()
         for l in range(L - 1, -1, -1):
-            s0 = dy * x0
-            acc.addcmul_(dy, hs[l])
+            if fused:
+                check(lib.hctr_cross_v2_bwd_step(B, w, ptr(dy), ptr(x0), ptr(hs[l]), ptr(acc), ptr(s0),
+                                                 ptr(db[l]), ptr(ws), 1 if l == L - 1 else 0,
+                                                 _DT16[x0.dtype], stream_ptr()))
+            else:
+                s0 = dy * x0
+                acc.addcmul_(dy, hs[l])
             s1 = s0 @ Vt[l].t()
             # weight gradients reduce over K = batch into a small tile set (512 x 3456: 27 tiles of
             # 256 x 256 on 256 CUs): split-K through batched GEMMs, as the MLP's are (dense.py)
@@ -235,7 +250,8 @@ class _CrossV2Fn(torch.autograd.Function):
             else:
                 dV[l] = _mm_f32(ps[l].t(), s0)
                 dU[l] = _mm_f32(xs[l].t(), s1)
-            db[l] = s0.sum(0, dtype=wdt)
+            if not fused:
+                db[l] = s0.sum(0, dtype=wdt)
             dy = torch.addmm(dy, s1, Ut[l].t())
         return acc + dy, dU, dV, db
 

@@ -639,6 +639,15 @@ int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* d
 int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,
                            const float* h, const float* bias, float* hidden_out, float* out,
                            hctr_stream_t stream);
+/* One layer's elementwise step of MultiCrossBackwardFunctorv2 in the activations' 16-bit type
+ * (fused_mul_fma3, R/HugeCTR/src/layers/multi_cross_layer.cu:391-424 / 127-165, + the bias gradient
+ * the reference takes in the dV GEMM's epilogue, :770-776): s0 = dy .* x0, acc = (first ? 0 : acc)
+ * + dy .* h, each rounded once to the 16-bit type; db[c] = sum_b s0[b][c] in fp32 (two-stage, fixed
+ * order).  All arrays [batch][width], width % 8 == 0; workspace: hctr_relu_bwd_bias_workspace_bytes
+ * (batch, width).  first != 0: acc is written without being read (the last layer, visited first). */
+int hctr_cross_v2_bwd_step(size_t batch, int width, const void* dy, const void* x0, const void* h,
+                           void* acc, void* s0, float* db, float* workspace, int first, int dtype,
+                           hctr_stream_t stream);
 
 /* ---- embedding cache in HBM + host<->HBM tiered table (BASELINE config 4) ----------------------
  * gpu_cache::gpu_cache<key, ref_counter, empty_key, SET_ASSOCIATIVITY 2, SLAB_SIZE 32>

@@ -112,6 +112,36 @@ def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
 
 
 @pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("B,w", [(300, 3456), (129, 24), (7, 2056)])
+def test_cross_v2_backward_step_equals_the_three_torch_passes(dtype_name, B, w):
+    """hctr_cross_v2_bwd_step (S0 = dY .* X0, dX (+)= dY .* H, db = column sums of S0, one pass over
+    dY) against the three passes it replaces: the same bits for S0 and dX (products of 16-bit values
+    are exact in fp32, each element is rounded once), db within fp32 summation error"""
+    import torch
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr
+    dt = getattr(torch, dtype_name)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(B + w)
+    dy, x0, h, acc0 = (torch.randn((B, w), device="cuda", generator=g).to(dt) for _ in range(4))
+    ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, dtype=torch.float32, device="cuda")
+    code = _lib.F16 if dt == torch.float16 else _lib.BF16
+    for first in (1, 0):
+        acc = torch.full_like(acc0, float("nan")) if first else acc0.clone()
+        s0 = torch.full_like(dy, float("nan"))
+        db = torch.full((w,), float("nan"), device="cuda")
+        check(lib.hctr_cross_v2_bwd_step(B, w, ptr(dy), ptr(x0), ptr(h), ptr(acc), ptr(s0), ptr(db), ptr(ws),
+                                         first, code, None))
+        torch.cuda.synchronize()
+        want_s0 = dy * x0
+        want_acc = dy * h if first else torch.addcmul(acc0, dy, h)
+        assert torch.equal(s0, want_s0), (first, "s0")
+        assert torch.equal(acc, want_acc), (first, "acc")
+        ref = want_s0.double().sum(0)
+        assert float((db.double() - ref).abs().max()) <= 1e-5 * float(want_s0.double().abs().sum(0).max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
 @pytest.mark.parametrize("B,n_emb,W", [(512, 26, 128), (70, 26, 64), (33, 13, 32)])
 def test_interaction_16bit(oracle, dtype_name, B, n_emb, W):
     """mixed-precision mode (reference: InteractionLayer<__half>, eps 1.0 in its own test,

@@ -169,3 +169,30 @@ def test_v2_binary16_elementwise_kernels_round_as_the_16_bit_cross_layer_does(re
     once = (dy.astype(f64) * h.astype(f64) + acc.astype(f64)).astype(f16)
     twice = (acc.astype(f32) + (dy.astype(f32) * h.astype(f32)).astype(f16).astype(f32)).astype(f16)
     np.testing.assert_array_equal(a, once if aligned else twice)
+
+
+@pytest.mark.parametrize("first", [1, 0])
+@pytest.mark.parametrize("B,w", [(130, 3456), (257, 24), (5, 40), (128, 2056)])
+def test_v2_backward_step_of_the_hip_source_next_to_fused_mul_fma3(ref, elib, B, w, first):
+    """hctr_cross_v2_bwd_step (dense_ops.hip: S0 = dY .* X0, dX += dY .* H, db = column sums of S0 in
+    one pass) next to the reference's fused_mul_fma3 launch (its paired-half kernel: B * w % 8 == 0)"""
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(B * 100 + w + first)
+    x0, h, dy, acc = (rng.standard_normal((B, w)).astype(f16) for _ in range(4))
+    r_s0 = np.zeros((B, w), f16)
+    r_acc = np.zeros((B, w), f16) if first else acc.copy()
+    ref.refcross_v2_mul_fma3(B, w, 1, _p(r_s0), _p(r_acc), _p(dy), _p(x0), _p(h))
+    g_s0 = np.full((B, w), np.nan, f16)
+    g_acc = np.full((B, w), np.nan, f16) if first else acc.copy()  # (first: never read)
+    db = np.full(w, np.nan, f32)
+    ws = np.zeros(elib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, f32)
+    emu.check(elib, elib.hctr_cross_v2_bwd_step(B, w, _p(dy), _p(x0), _p(h), _p(g_acc), _p(g_s0), _p(db),
+                                                _p(ws), first, _lib.F16, None))
+    np.testing.assert_array_equal(g_s0, r_s0)
+    # the accumulator: exact product + addend rounded to fp32, then to binary16 -- the fused
+    # instruction rounds once; the two differ in a rare tie case by one ulp
+    d = np.abs(g_acc.view(np.int16).astype(np.int32) - r_acc.view(np.int16).astype(np.int32))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.999
+    if first:
+        np.testing.assert_array_equal(g_acc, r_acc)  # (no addend: one rounding either way)
+    np.testing.assert_allclose(db, r_s0.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
