@@ -684,7 +684,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   *e->h_err = 0u;
   if ((rc = e->ht.create(V, p.key_type)) != HCTR_OK) return fail(rc);
   if ((rc = e->ht.reserve(e->nnz_max)) != HCTR_OK) return fail(rc);
-  if ((rc = e->upd.create(e->nnz_max, V, (int)D)) != HCTR_OK) return fail(rc);
+  if ((rc = e->upd.create(e->nnz_max, V, (int)D, true)) != HCTR_OK) return fail(rc);
   // sample-major batches: bucket b * S + s -- the positions with the same p % S come from one table
   // (the sparse update's hot-row streams)
   e->upd.hot_streams = (uint32_t)e->buckets_per_sample();

@@ -91,8 +91,14 @@ struct SparseUpdater {
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;
 
-  int create(size_t max_nnz, size_t max_vocab, int D);
-  int hot_buffers(hipStream_t s);  // the hot-row path's tables and side stream, on first use
+  // eager_hot: the owner feeds one-hot batches with a device flag (the legacy embedding): the
+  // hot-row path's tables and stream are set up here.  Others get them on the first update that
+  // takes the path, if any (hot_buffers) -- measured: set up inside a step of the uniform-key leg
+  // (213 GB of tables already resident) every random-access kernel of the step ran 25-90 % slower
+  // from then on (profiles/r4_uniform_leg_lazy_hot_buffers.txt), so the one owner that does take
+  // the path never does it that way.
+  int create(size_t max_nnz, size_t max_vocab, int D, bool eager_hot = false);
+  int hot_buffers(hipStream_t s);
   int destroy();
   // optional: start sorting n >= live nnz (row, bucket) pairs now, concurrently with stream s
   int presort(size_t buckets, size_t n, const void* row_offset, int key_type,

@@ -2057,7 +2057,7 @@ int update_grad_i64(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, 
 }
 #else
 
-int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
+int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_, bool eager_hot) {
   max_nnz = max_nnz_ > 0 ? max_nnz_ : 1;
   max_vocab = max_vocab_;
   D = D_;
@@ -2113,13 +2113,17 @@ int SparseUpdater::create(size_t max_nnz_, size_t max_vocab_, int D_) {
     const char* hm = getenv("HCTR_HOT_MIN");
     hot_min_n = hm ? (size_t)atoll(hm) : (size_t)262144;
     hot_rows = 0;
-    // (the tables themselves are allocated by the first update that can take the path --
-    //  hot_buffers(): an updater that never sees a one-hot batch never pays for them)
+    // (the tables themselves: here for an owner that announces one-hot batches (eager_hot), else by
+    //  the first update that takes the path -- hot_buffers(); see sparse_update.h)
     if (rows > 0 && max_nnz >= hot_min_n && D % 4 == 0 && D / 4 <= 64 && ((D / 4) & (D / 4 - 1)) == 0) {
       hot_rows = (uint32_t)rows;
       const char* hs = getenv("HCTR_HOT_SERIAL");  // "1": both chains on the caller's stream (measurements)
       hot_serial = hs != nullptr && hs[0] == '1';
       hot_chunks_max = (uint32_t)(ceil_div<size_t>(max_nnz, (size_t)kHotChunk) + kHotMaxStreams);
+      if (eager_hot) {
+        HCTR_TRY(hot_buffers(nullptr));
+        HCTR_HIP(hipDeviceSynchronize());  // (the clears above ran on the null stream)
+      }
     }
   }
   return HCTR_OK;
