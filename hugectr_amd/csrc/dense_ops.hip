@@ -988,6 +988,18 @@ __global__ void __launch_bounds__(kBlock)
 // ================================================================================================
 constexpr int kRbRows = 128;  // rows per workgroup
 
+// rows per workgroup of cross_v2_bwd_step_kernel: 128 at most, fewer (a power of two >= 16) while
+// the grid would stay below ~2 k workgroups -- 64 tiles of 128 rows at batch 8192 left three
+// quarters of the CUs idle
+inline int cross_step_rows_per_tile(size_t batch, int width) {
+  const int n8 = width / 8;
+  const int cw = n8 < kBlock ? n8 : kBlock;
+  const size_t col_blocks = (size_t)((n8 + cw - 1) / cw);
+  int rpt = 128;
+  while (rpt > 16 && ((batch + rpt - 1) / rpt) * col_blocks < 2048) rpt >>= 1;
+  return rpt;
+}
+
 // thread t of a workgroup owns 16-byte column vector (t % cw) and walks rows (t / cw), +rg, ...;
 // cw = min(n/8, 256), rg = 256 / cw row groups; the rg partial sums meet in LDS in fixed order.
 template <bool BF>
@@ -1047,13 +1059,14 @@ __global__ void __launch_bounds__(kBlock)
 // 127-165 -- S0 = dY .* X0, dX += dY .* H, one rounding per element as its paired-half kernel
 // rounds -- and the bias gradient db = column sums of S0, which the reference takes in the
 // epilogue of the dV GEMM, :770-776): dY is read once for both products, S0 is summed from
-// registers.  Layout and the two-stage fixed-order column sums are relu_bwd_bias_kernel's.
+// registers.  Thread layout and the two-stage fixed-order column sums are relu_bwd_bias_kernel's.
 // FIRST (the last layer, visited first): dX = dY .* H, the accumulator is not read (nor cleared
 // beforehand).
 // ================================================================================================
 template <bool BF, bool FIRST>
 __global__ void __launch_bounds__(kBlock)
-    cross_v2_bwd_step_kernel(size_t rows, int n, int cw, int rg, const unsigned short* __restrict__ dy,
+    cross_v2_bwd_step_kernel(size_t rows, int n, int cw, int rg, int rpt,
+                             const unsigned short* __restrict__ dy,
                              const unsigned short* __restrict__ x0,
                              const unsigned short* __restrict__ hm, unsigned short* __restrict__ acc_io,
                              unsigned short* __restrict__ s0, float* __restrict__ partial) {
@@ -1062,12 +1075,15 @@ __global__ void __launch_bounds__(kBlock)
   const int n8 = n / 8;
   const int c8 = threadIdx.x % cw, g = threadIdx.x / cw;
   const bool live = g < rg;
-  const size_t r0 = (size_t)blockIdx.x * kRbRows;
-  const size_t r1 = r0 + kRbRows < rows ? r0 + kRbRows : rows;
-  for (int cc = c8; cc - c8 < n8; cc += cw) {  // uniform trip count: every thread reaches the barriers
+  // a workgroup = rpt rows x cw 16-byte column vectors (blockIdx.y picks the column block): the
+  // grid is (row tiles, column blocks), sized by the host for >= ~1 k workgroups at any batch
+  const size_t r0 = (size_t)blockIdx.x * (size_t)rpt;
+  const size_t r1 = r0 + (size_t)rpt < rows ? r0 + (size_t)rpt : rows;
+  const int cc = (int)blockIdx.y * cw + c8;
+  {
     float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live && cc < n8) {
-#pragma unroll 2
+#pragma unroll 4
       for (size_t r = r0 + g; r < r1; r += rg) {
         const size_t at = r * n + cc * 8;
         const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + at);
@@ -2131,6 +2147,12 @@ int hctr_relu_bwd_bias(size_t rows, int n, const void* dy, const void* y, void* 
   return HCTR_OK;
 }
 
+size_t hctr_cross_v2_bwd_step_workspace_bytes(size_t batch, int width) {
+  if (batch == 0 || width <= 0) return 0;
+  return ceil_div<size_t>(batch, (size_t)cross_step_rows_per_tile(batch, width)) * (size_t)width *
+         sizeof(float);
+}
+
 int hctr_cross_v2_bwd_step(size_t batch, int width, const void* dy, const void* x0, const void* h,
                            void* acc, void* s0, float* db, float* workspace, int first, int dtype,
                            hctr_stream_t stream) {
@@ -2139,12 +2161,14 @@ int hctr_cross_v2_bwd_step(size_t batch, int width, const void* dy, const void* 
   if (batch == 0) return HCTR_OK;
   HCTR_REQUIRE(dy && x0 && h && acc && s0 && db && workspace, "null pointer");
   hipStream_t s = as_stream(stream);
-  const size_t tiles = ceil_div<size_t>(batch, (size_t)kRbRows);
   const int cw = width / 8 < kBlock ? width / 8 : kBlock;
   const int rg = kBlock / cw;
+  const int rpt = cross_step_rows_per_tile(batch, width);
+  const size_t tiles = ceil_div<size_t>(batch, (size_t)rpt);
+  const unsigned col_blocks = (unsigned)ceil_div<int>(width / 8, cw);
 #define HCTR_CROSS_STEP(BF_, FIRST_)                                                              \
-  hipLaunchKernelGGL((cross_v2_bwd_step_kernel<BF_, FIRST_>), dim3((unsigned)tiles), dim3(kBlock), \
-                     0, s, batch, width, cw, rg, (const unsigned short*)dy,                        \
+  hipLaunchKernelGGL((cross_v2_bwd_step_kernel<BF_, FIRST_>), dim3((unsigned)tiles, col_blocks),   \
+                     dim3(kBlock), 0, s, batch, width, cw, rg, rpt, (const unsigned short*)dy,     \
                      (const unsigned short*)x0, (const unsigned short*)h, (unsigned short*)acc,    \
                      (unsigned short*)s0, workspace)
   if (dtype == HCTR_EMB_BF16) {

@@ -229,8 +229,8 @@ class _CrossV2Fn(torch.autograd.Function):
             # S0 = dY .* X0, dX += dY .* H and db = colsum(S0) in one pass over dY (HIP), as the
             # reference's fused_mul_fma3 + the dV GEMM's bias-gradient epilogue
             s0 = torch.empty_like(x0)
-            ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, dtype=torch.float32,
-                             device=x0.device)
+            ws = torch.empty(lib.hctr_cross_v2_bwd_step_workspace_bytes(B, w) // 4,
+                             dtype=torch.float32, device=x0.device)
         else:
             acc.zero_()
         for l in range(L - 1, -1, -1):

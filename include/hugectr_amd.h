@@ -643,8 +643,9 @@ int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float
  * (fused_mul_fma3, R/HugeCTR/src/layers/multi_cross_layer.cu:391-424 / 127-165, + the bias gradient
  * the reference takes in the dV GEMM's epilogue, :770-776): s0 = dy .* x0, acc = (first ? 0 : acc)
  * + dy .* h, each rounded once to the 16-bit type; db[c] = sum_b s0[b][c] in fp32 (two-stage, fixed
- * order).  All arrays [batch][width], width % 8 == 0; workspace: hctr_relu_bwd_bias_workspace_bytes
+ * order).  All arrays [batch][width], width % 8 == 0; workspace: hctr_cross_v2_bwd_step_workspace_bytes
  * (batch, width).  first != 0: acc is written without being read (the last layer, visited first). */
+size_t hctr_cross_v2_bwd_step_workspace_bytes(size_t batch, int width);
 int hctr_cross_v2_bwd_step(size_t batch, int width, const void* dy, const void* x0, const void* h,
                            void* acc, void* s0, float* db, float* workspace, int first, int dtype,
                            hctr_stream_t stream);

@@ -124,7 +124,7 @@ def test_cross_v2_backward_step_equals_the_three_torch_passes(dtype_name, B, w):
     g = torch.Generator(device="cuda")
     g.manual_seed(B + w)
     dy, x0, h, acc0 = (torch.randn((B, w), device="cuda", generator=g).to(dt) for _ in range(4))
-    ws = torch.empty(lib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.hctr_cross_v2_bwd_step_workspace_bytes(B, w) // 4, dtype=torch.float32, device="cuda")
     code = _lib.F16 if dt == torch.float16 else _lib.BF16
     for first in (1, 0):
         acc = torch.full_like(acc0, float("nan")) if first else acc0.clone()

@@ -185,7 +185,7 @@ def test_v2_backward_step_of_the_hip_source_next_to_fused_mul_fma3(ref, elib, B,
     g_s0 = np.full((B, w), np.nan, f16)
     g_acc = np.full((B, w), np.nan, f16) if first else acc.copy()  # (first: never read)
     db = np.full(w, np.nan, f32)
-    ws = np.zeros(elib.hctr_relu_bwd_bias_workspace_bytes(B, w) // 4, f32)
+    ws = np.zeros(elib.hctr_cross_v2_bwd_step_workspace_bytes(B, w) // 4, f32)
     emu.check(elib, elib.hctr_cross_v2_bwd_step(B, w, _p(dy), _p(x0), _p(h), _p(g_acc), _p(g_s0), _p(db),
                                                 _p(ws), first, _lib.F16, None))
     np.testing.assert_array_equal(g_s0, r_s0)
