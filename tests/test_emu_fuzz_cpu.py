@@ -9,13 +9,15 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-pytestmark = pytest.mark.skipif(
-    not os.path.exists(os.path.join(HERE, "emu", "_build", "libhctr_emu.so")),
-    reason="tests/emu not built")
+sys.path.insert(0, os.path.join(HERE, "emu"))
+import emu  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="no host clang++ / make")
 
 
 @pytest.mark.parametrize("script,seed,cases", [("fuzz_ebc_dynamic.py", 0, 10), ("fuzz_det.py", 0, 10)])
 def test_fuzzer_seeds_agree(script, seed, cases):
+    emu.build()  # (the child would build it as well; here a failure reads better)
     env = dict(os.environ)
     for k in ("HCTR_EBC_DIRECT", "HCTR_DYNAMIC_FLAT"):
         env.pop(k, None)
