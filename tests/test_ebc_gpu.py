@@ -576,3 +576,62 @@ def test_forward_pool_mapped_rejects_bad_shapes():
                                       _lib.ptr(tab), None, None, _lib.stream_ptr())
     assert rc != 0  # 4 * 2 != 6 buckets
     _lib.lib.hctr_updater_destroy(u)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_network_buffer_layout_is_the_reference_network_indices(seed):
+    """Where NetworkForward finds the partial vectors of a lookup: the reference's own host code
+    (NetworkIndices::init, R/HugeCTR/embedding/operators/network_forward.cu:23-62, compiled from the
+    checkout into oracle/_ref/libref_network_indices.so) run on the local lookup lists of a random
+    sharding, next to the block table this package builds (d_src_blocks: per lookup, per shard, the
+    block of the received buffer = the source rank's first block + the lookup's index among that
+    rank's local lookups).  Same sources for every lookup; their order inside a lookup is the
+    owners' order here and whatever std::sort leaves in the reference (ties are not ordered there)."""
+    import ctypes
+    import hugectr_amd as ha
+    path = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libref_network_indices.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (needs the reference checkout)")
+    R = ctypes.CDLL(path)
+    P = ctypes.c_void_p
+    R.refnet_indices.argtypes = [ctypes.c_int, P, P, P, P, P, P]
+    rng = np.random.default_rng(seed)
+    world = int(rng.choice([2, 3, 4, 8]))
+    T = int(rng.integers(1, 7))
+    L = int(rng.integers(T, T + 4))
+    lookup_table = list(range(T))
+    for _ in range(L - T):
+        t = int(rng.integers(0, T))
+        lookup_table.insert(int(rng.integers(lookup_table.index(t) + 1, len(lookup_table) + 1)), t)
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", 50 + i, 8) for i in range(T)]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l in range(L):
+        cfg.embedding_lookup(tcfg[lookup_table[l]], f"in{l}", f"out{l}", "sum")
+    sm = [[0] * T for _ in range(world)]
+    for t in range(T):  # every table on a random non-empty set of ranks
+        owners = np.flatnonzero(rng.random(world) < 0.4)
+        if owners.size == 0:
+            owners = np.array([int(rng.integers(0, world))])
+        for g in owners:
+            sm[int(g)][t] = 1
+    cfg.shard(sm)
+    e = ha.EmbeddingCollection.for_rank(0, world, cfg, world * 2, lr=0.1, max_hotness=2)
+    # the ranks' local lookups in the order the package numbers them (= ascending lookup id)
+    local = [[l for l in range(L) if r in e.owners[e.lookup_table[l]]] for r in range(world)]
+    assert [len(x) for x in local] == list(e.n_local_of)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in local])]).astype(np.int32)
+    flat = np.array([l for x in local for l in x] + [0], dtype=np.int32)
+    total = int(offs[-1])
+    ids, gpus = np.full(total, -1, np.int32), np.full(total, -1, np.int32)
+    noff, dst = np.full(L + 1, -1, np.int32), np.full(L, -1, np.int32)
+    p = lambda a: a.ctypes.data_as(P)  # noqa: E731
+    n_dst = R.refnet_indices(world, p(offs), p(flat), p(ids), p(gpus), p(noff), p(dst))
+    assert n_dst == L and list(dst[:L]) == list(range(L))  # every lookup has at least one owner
+    src = e.d_src_blocks.cpu().numpy().reshape(L, e.max_shards)
+    base = np.concatenate([[0], np.cumsum(e.n_local_of)])
+    for l in range(L):
+        ref = sorted(int(base[gpus[i]] + ids[i]) for i in range(noff[l], noff[l + 1]))
+        mine = sorted(int(b) for b in src[l] if b >= 0)
+        assert mine == ref, (l, mine, ref)
+        # ... and in this package the shards are added in ascending rank order
+        assert [int(b) for b in src[l] if b >= 0] == sorted(mine)
