@@ -64,6 +64,17 @@ def one_case(lib, _lib, seed):
     desc = dict(seed=seed, key_bytes=key_bytes, D=D, combiner=combiner, B=B, S=S, hot=hot, vps=vps,
                 dt=dt, opt=name, scaler=scaler, steps=steps, world=world, rank=rank,
                 localized=localized)
+    # the hot-row path of one-hot batches (rows below HCTR_HOT_ROWS leave the sort; read when the
+    # handle is created): forced on for a share of the cases, with few enough hot rows that a
+    # batch has both kinds
+    hot_min = str(rng.choice(["", "", "1"]))
+    hot_rows = str(rng.choice(["8192", "2", "16", "300"]))
+    for k, v in (("HCTR_HOT_MIN", hot_min), ("HCTR_HOT_ROWS", hot_rows)):
+        if v and hot_min:
+            os.environ[k] = v
+        else:
+            os.environ.pop(k, None)
+    desc.update(hot_min=hot_min, hot_rows=hot_rows if hot_min else "")
     V = S * vps + int(rng.integers(0, 20))
     kd = np.int64 if key_bytes == 8 else np.uint32
     opt = dict(lr=0.05, scaler=scaler, beta1=0.9, beta2=0.999, epsilon=1e-7, **kw)
