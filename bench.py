@@ -32,6 +32,130 @@ TOP = [1024, 1024, 512, 256, 1]   # top MLP
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy)
 
 
+LINE_CAP = 4096  # bytes; round 4's 21 KB line outgrew the driver's channel
+
+
+def _r(x, sig=5):
+    """numbers to `sig` significant digits (the line is a summary; the file keeps full precision)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def _pick(d, keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _roof_short(r, extra=()):
+    if not isinstance(r, dict):
+        return None
+    o = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_compulsory",
+                  "frac_traffic", "us", "avg_launch_us") + tuple(extra))
+    o.setdefault("traffic", None)
+    return o
+
+
+def compact_line(full, extra_file):
+    """the ONE stdout line of the contract, <= LINE_CAP bytes: the contract's keys, the roofline
+    objects as numbers and the cpu baseline; everything else lives in `extra_file` (the full
+    record, also printed to stderr).  tests/test_bench_line_cpu.py holds the cap."""
+    cfg = full.get("config", {}) if isinstance(full.get("config"), dict) else {}
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                        "higher_is_better", "scaling"))
+    line["vs_baseline"] = full.get("vs_baseline")
+    line["dtype"] = full.get("precision") or str(full.get("dtype", ""))[:16]
+    line["data"] = "synthetic"
+    line["config"] = _pick(cfg, ("workload", "batch_per_gpu", "global_batch", "slots", "emb_dim",
+                                 "table_rows_total", "parallelism", "exchange", "new_keys_per_step",
+                                 "distinct_rows_per_batch", "gather_fused_into_interaction",
+                                 "final_loss", "key_distribution"))
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:200]
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        ro = _roof_short(r, ("algorithmic_bytes_per_launch", "launches_timed_region",
+                             "launches_inline", "avg_launch_us_timed_region", "traffic_stale"))
+        ro["kernel"] = str(r.get("kernel", "")).split(" ")[0]
+        line["roofline"] = ro
+    for k in ("roofline_update", "roofline_index", "roofline_uniform", "roofline_fp32"):
+        if isinstance(full.get(k), dict):
+            line[k] = _roof_short(full[k], ("algorithmic_bytes", "algorithmic_bytes_per_launch",
+                                            "traffic_ratio"))
+            line[k].pop("peak", None)
+            line[k].pop("unit", None)
+            line[k].pop("bound", None)
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "error"))
+        if "sample" in cb:
+            c["sample"] = str(cb["sample"]).split(";")[0][:300]
+        if isinstance(cb.get("port"), dict):
+            c["port"] = _pick(cb["port"], ("value", "cores"))
+        line["cpu_baseline"] = c
+    st = full.get("strong")
+    if isinstance(st, dict):
+        line["strong"] = _pick(st, ("value", "ms_per_step", "scaling", "error"))
+        if isinstance(st.get("config"), dict):
+            line["strong"]["global_batch"] = st["config"].get("global_batch")
+    # one number per extra leg (the legs themselves: extra_file)
+    ex = full.get("extra")
+    if isinstance(ex, dict):
+        summ = {}
+        for name, leg in ex.items():
+            if not isinstance(leg, dict):
+                continue
+            if "error" in leg:
+                summ[name] = "error"
+            elif "ms_per_step" in leg:
+                summ[name] = {"ms_per_step": _r(leg["ms_per_step"], 4)}
+            elif "forward_backward_update_us" in leg:
+                summ[name] = {"fwd_bwd_upd_us": _r(leg["forward_backward_update_us"], 4)}
+            elif "lookup_us" in leg:
+                summ[name] = {"lookup_us": _r(leg["lookup_us"], 4), "update_us": _r(leg.get("update_us"), 4)}
+            elif "summary" in leg:
+                summ[name] = leg["summary"]
+        line["extra_summary"] = summ
+    line["extra_file"] = extra_file
+    s = json.dumps(line, separators=(",", ":"))
+    # never exceed the cap: shed the optional parts in order of (un)importance
+    for k in ("extra_summary", "strong", "roofline_fp32", "roofline_uniform"):
+        if len(s) <= LINE_CAP:
+            break
+        line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_CAP:
+        line["config"] = {"workload": str(cfg.get("workload", ""))[:120]}
+        if isinstance(line.get("cpu_baseline"), dict):
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"].get("sample", "")[:80]
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= LINE_CAP and "\n" not in s, len(s)
+    return s
+
+
+def emit(full, extra_file):
+    """full record -> extra_file (and stderr under HCTR_BENCH_VERBOSE=1); the compact line ->
+    stdout, last, flushed"""
+    path = extra_file
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+    except OSError as e:
+        path = f"(not written: {e})"
+    if os.environ.get("HCTR_BENCH_VERBOSE"):
+        sys.stderr.write(json.dumps(full, indent=1) + "\n")
+    sys.stderr.write(f"[bench] full record: {path}\n")
+    sys.stderr.flush()
+    sys.stdout.write(compact_line(full, path) + "\n")
+    sys.stdout.flush()
+
+
 def _csrc_hash():
     """tools/csrc_hash.py: sha256 over the kernel sources, the stamp of the counter files"""
     import glob
@@ -456,8 +580,17 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                      # cycles go, for the interaction kernels (north_star: "MFMA utilisation on the
                      # interaction"); null when the counter file is not of these sources
                      "mfma_busy": mfma_busy,
-                     "algorithmic_bytes_per_launch": alg_bytes, "launches": pool_n,
-                     "avg_launch_us": pool_s * 1e6,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     # `achieved` / `avg_launch_us` are of the in-line launches (the update in line,
+                     # the kernel alone on the chip); the timed region's launches share the chip
+                     # with the overlapped update on one GPU -- both averages are given
+                     "launches_inline": pool_n, "avg_launch_us": pool_s * 1e6,
+                     "launches_timed_region": prof_timed.get("gather_pool", (0.0, 0))[1],
+                     "avg_launch_us_timed_region":
+                         (prof_timed["gather_pool"][0] / max(prof_timed["gather_pool"][1], 1) * 1e3)
+                         if prof_timed.get("gather_pool", (0, 0))[1] else None,
+                     "frac_traffic": (pmc / pool_s / 1e9 / HBM_PEAK_GBPS)
+                     if pmc and pool_ms > 0 else None,
                      # SURVEY 8(d) counts duplicate rows; power-law keys repeat hot rows, which L2
                      # / Infinity Cache serve, so `frac` can reach 1 without saying much about the
                      # kernel.  compulsory_bytes counts every DISTINCT row once: the bytes no cache
@@ -475,13 +608,15 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                             "frac": (upd_bytes / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,
                             "algorithmic_bytes": upd_bytes, "us": upd_s * 1e6,
                             # HBM bytes per step of these kernels (same PMC passes as above)
-                            "traffic": pmc_upd, "traffic_source": pmc_src if pmc_upd else None},
+                            "traffic": pmc_upd, "traffic_source": pmc_src if pmc_upd else None,
+                            "traffic_ratio": (pmc_upd / upd_bytes) if pmc_upd else None},
         "roofline_index": {"bound": "hbm", "kernels": "hash index stage (filter + probe / insert)",
                            "achieved": (idx_bytes / idx_s / 1e9) if idx_s > 0 else None,
                            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (idx_bytes / idx_s / 1e9 / HBM_PEAK_GBPS) if idx_s > 0 else None,
                            "algorithmic_bytes": idx_bytes, "us": idx_s * 1e6,
-                           "traffic": pmc_idx, "traffic_source": pmc_src if pmc_idx else None},
+                           "traffic": pmc_idx, "traffic_source": pmc_src if pmc_idx else None,
+                           "traffic_ratio": (pmc_idx / idx_bytes) if pmc_idx else None},
         "stage_us_per_step": stage_us,
         # the same stages as the timed region saw them (one GPU: the update overlapped with the
         # bottom MLP's backward -- shared-chip time, not the kernels' own)
@@ -1185,6 +1320,9 @@ def main():
                     help="c3 = BASELINE configs[2], DLRM Criteo-1TB (the metric's configuration); "
                          "c1 / c2 = configs[0] / [1] as the main line")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--extra-file", default=os.path.join(ROOT, "bench_extra.json"),
+                    help="the full record (every leg, stage tables, prose); the stdout line is its "
+                         "<= 4 KB summary and names this file under `extra_file`")
     ap.add_argument("--tunable", default="auto", choices=["auto", "off"],
                     help="dense-tower GEMM solution selection: auto = hugectr.Model reads the "
                          "committed hugectr_amd/tuning/tunableop_gfx950.csv (solver."
@@ -1219,7 +1357,7 @@ def main():
     if a.config != "c3":
         out = small_config_leg(a.config, a.steps, a.warmup, dev)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out, a.extra_file)
         return
 
     import gc
@@ -1309,7 +1447,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(CRITEO_1TB, a.alpha, a.dim, 4321)
             except Exception as e:  # the oracle is a reported baseline, never the product path
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        emit(out, a.extra_file)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
