@@ -87,6 +87,19 @@ struct SparseUpdater {
   uint32_t hot_parity = 0;             // set the next update takes
   float* hot_head = nullptr;           // [hot_chunks_max * 128][D] tile partials of runs that
   float* hot_tail = nullptr;           //   cross tile borders inside a chunk
+  // cold rows of the same batches (sparse_update.hip, "cold rows of a one-key-per-position batch"):
+  // counted per row instead of sorted.  HCTR_COLD_COUNT=0 keeps the filtering radix sort + segmented
+  // reduce of round 4 (measurements, the bit-equality tests).
+  bool cold_count = true;
+  uint32_t* cold_cnt = nullptr;     // [max_vocab] per-row counter / base word, zero between updates
+  uint32_t* cold_rank = nullptr;    // [max_nnz]
+  uint32_t* cold_plist = nullptr;   // [max_nnz]
+  uint32_t* cold_bkt = nullptr;     // [max_nnz]
+  void* cold_dlist = nullptr;       // [max_nnz] uint2
+  void* cold_singles = nullptr;     // [max_nnz] uint2
+  void* cold_segs = nullptr;        // [max_nnz / 2 + 1] uint4
+  void* cold_longs = nullptr;       // [max_nnz / 2 + 1] uint4 (runs longer than short_max >= 8)
+  uint32_t* cold_counts = nullptr;  // two alternating sets of 8 words
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;

@@ -1486,6 +1486,501 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// ---- cold rows of a one-key-per-position batch: counted per row, never sorted ---------------------
+// The positions the hot-row kernels leave (rows >= H; all of them when the batch's flag says the
+// offsets were ragged) used to go through a global radix sort whose only job was to put the
+// gradients of a row side by side: 70 us of latency-bound passes for 490 k pairs of which a third
+// are alone in their row (Criteo-1TB shape, alpha 1.1: 221 k cold rows, 167 k of them met once,
+// 53 k met 2 .. 32 times, 1.2 k more often).  Here the rows are COUNTED instead:
+//   * cold_count_kernel, one thread per position: rank = atomicAdd(cnt[row], 1) -- the order of
+//     arrival, whatever it is; the position that arrives first announces the row (dlist);
+//   * cold_base_kernel, one thread per announced row: a row met once goes to the list of singles
+//     with its position; a row met c > 1 times gets c consecutive entries of plist (handed out in
+//     any order) and cnt[row] = base | kColdBased; runs of more than short_max go to their own list;
+//   * cold_scatter_kernel, one thread per position: plist[base + rank] = position;
+//   * cold_reduce_kernel: singles -- gradient row and table row of several rows in flight per lane
+//     group, no list at all; short runs -- a lane group sorts the run's positions ASCENDING (LDS
+//     rank count: the arrival order never reaches the arithmetic) and adds the gradients in that
+//     order, the reference's order (stable sort by row, sparse_optimizer.cu:657-676); long runs -- a
+//     workgroup sorts the positions (LDS bitonic up to kColdLds; beyond that it re-derives them in
+//     order by scanning the batch's rows), lane groups sum pieces of 32 consecutive entries, the
+//     pieces are added in order.  Every association is a function of the run alone, so the result
+//     does not depend on scheduling.  The kernel leaves cnt[] zero again.
+// The gradient row of position p: the bucket p itself (through the gradient map) when the batch's
+// flag says one key per bucket, else the bucket found by a search of the offsets (bkt[]).
+constexpr uint32_t kColdBased = 0x80000000u;
+constexpr uint32_t kColdNone = 0xFFFFFFFFu;
+constexpr int kColdPer = 8;      // positions per thread (count / scatter)
+constexpr int kColdLds = 2048;   // longest run sorted inside LDS
+constexpr int kColdPiece = 32;   // entries of a long run summed by one lane group at a time
+
+struct ColdGeom {
+  uint32_t n;          // positions
+  uint32_t hot_rows;   // H (rows below it belong to the hot kernels while the flag is set)
+  uint32_t max_vocab;
+  uint32_t map_inner, map_outer;
+  uint32_t short_max;  // longest run a lane group sorts (cold_reduce_kernel<LPR>: kShortMax)
+  int off_is_u32, combiner;
+  size_t buckets;
+};
+
+struct ColdBufs {
+  uint32_t* cnt;      // [max_vocab] zero between updates
+  uint32_t* rank;     // [max_nnz] order of arrival of a position inside its row
+  uint32_t* plist;    // [max_nnz] positions of the rows met more than once, row by row
+  uint32_t* bkt;      // [max_nnz] bucket of a position (ragged batches only)
+  uint2* dlist;       // [max_nnz] (row, first position to arrive)
+  uint2* singles;     // [max_nnz] (row, position)
+  uint4* segs;        // [max_nnz / 2] short runs: row, base, length
+  uint4* longs;       // long runs: row, base, length
+  // this update's counters, 128 bytes apart (same-word device-scope atomics cost ~11 ns each and
+  // words of one line share that queue): [kCcRows] rows announced; [kCcPl] 64 bits: plist entries
+  // handed out | long runs << 32; [kCcSs] 64 bits: short runs | singles << 32
+  uint32_t* counts;
+  uint32_t* counts_next;
+};
+constexpr int kCcRows = 0, kCcPl = 32, kCcSs = 64, kCcWords = 96;
+constexpr int kColdBlock = 1024;  // count / base / scatter: few, large workgroups = few counter atomics
+constexpr int kColdBasePer = 4;   // announced rows per thread of cold_base_kernel
+
+// bucket of key position j: the last u with offset[u] <= j (empty buckets skipped)
+__device__ __forceinline__ uint32_t cold_bucket_of(const void* ro_v, bool u32, size_t buckets,
+                                                   uint32_t j) {
+  size_t lo = 0, hi = buckets;  // offset[lo] <= j < offset[hi]
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) >> 1;
+    const unsigned long long v = u32 ? (unsigned long long)((const uint32_t*)ro_v)[mid]
+                                     : (unsigned long long)((const long long*)ro_v)[mid];
+    if (v <= (unsigned long long)j) lo = mid;
+    else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+__global__ void __launch_bounds__(kColdBlock)
+    cold_count_kernel(ColdGeom cg, const uint32_t* __restrict__ one_hot,
+                      const void* __restrict__ row_offset, const uint64_t* __restrict__ value_index,
+                      ColdBufs cb) {
+  __shared__ uint32_t smem[kColdBlock / 64 + 1];
+  __shared__ uint32_t sh_base;
+  if (blockIdx.x == 0 && threadIdx.x < kCcWords) cb.counts_next[threadIdx.x] = 0u;
+  const bool oh = *one_hot != 0u;
+  const uint64_t H = oh ? (uint64_t)cg.hot_rows : 0ull;
+  const uint32_t p0 = blockIdx.x * (uint32_t)(kColdBlock * kColdPer) + threadIdx.x;
+  uint32_t row[kColdPer], rk[kColdPer];
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    const uint32_t p = p0 + (uint32_t)(r * kColdBlock);
+    row[r] = kColdNone;
+    if (p < cg.n) {
+      const uint64_t v = value_index[p];
+      if (v >= H && v < (uint64_t)cg.max_vocab) row[r] = (uint32_t)v;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++)
+    rk[r] = row[r] != kColdNone ? atomicAdd(cb.cnt + row[r], 1u) : 1u;
+  uint32_t nlead = 0u;
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    const uint32_t p = p0 + (uint32_t)(r * kColdBlock);
+    if (row[r] != kColdNone) {
+      cb.rank[p] = rk[r];
+      if (!oh) cb.bkt[p] = cold_bucket_of(row_offset, cg.off_is_u32 != 0, cg.buckets, p);
+      nlead += rk[r] == 0u ? 1u : 0u;
+    }
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan<uint32_t, kColdBlock>(nlead, smem, &tot);
+  if (threadIdx.x == 0) sh_base = tot > 0u ? atomicAdd(cb.counts + kCcRows, tot) : 0u;
+  __syncthreads();
+  ex += sh_base;
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    if (row[r] != kColdNone && rk[r] == 0u)
+      cb.dlist[ex++] = make_uint2(row[r], p0 + (uint32_t)(r * kColdBlock));
+  }
+}
+
+__global__ void __launch_bounds__(kColdBlock) cold_base_kernel(ColdGeom cg, ColdBufs cb) {
+  __shared__ unsigned long long smem64[kColdBlock / 64 + 1];
+  __shared__ unsigned long long smem64b[kColdBlock / 64 + 1];
+  __shared__ unsigned long long sh[2];
+  constexpr uint32_t kTrip = (uint32_t)(kColdBlock * kColdBasePer);
+  const uint32_t nd = cb.counts[kCcRows];
+  for (uint32_t i0 = blockIdx.x * kTrip; i0 < nd; i0 += gridDim.x * kTrip) {
+    // thread t takes kColdBasePer CONSECUTIVE rows of the trip (one scan covers them)
+    uint2 e[kColdBasePer];
+    uint32_t c[kColdBasePer];
+#pragma unroll
+    for (int k = 0; k < kColdBasePer; k++) {
+      const uint32_t i = i0 + threadIdx.x * (uint32_t)kColdBasePer + (uint32_t)k;
+      e[k] = make_uint2(0u, 0u);
+      if (i < nd) e[k] = cb.dlist[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kColdBasePer; k++) {
+      const uint32_t i = i0 + threadIdx.x * (uint32_t)kColdBasePer + (uint32_t)k;
+      c[k] = i < nd ? cb.cnt[e[k].x] : 0u;
+    }
+    // two 64-bit scans: plist entries | long runs << 32, and short runs | singles << 32
+    unsigned long long a = 0ull, b = 0ull;
+#pragma unroll
+    for (int k = 0; k < kColdBasePer; k++) {
+      if (c[k] > cg.short_max) a += (unsigned long long)c[k] | (1ull << 32);
+      else if (c[k] > 1u) {
+        a += (unsigned long long)c[k];
+        b += 1ull;
+      } else if (c[k] == 1u) b += 1ull << 32;
+    }
+    unsigned long long ta, tb;
+    unsigned long long xa = block_exclusive_scan<unsigned long long, kColdBlock>(a, smem64, &ta);
+    unsigned long long xb = block_exclusive_scan<unsigned long long, kColdBlock>(b, smem64b, &tb);
+    if (threadIdx.x == 0) {
+      sh[0] = ta != 0ull ? atomicAdd(reinterpret_cast<unsigned long long*>(cb.counts + kCcPl), ta) : 0ull;
+      sh[1] = tb != 0ull ? atomicAdd(reinterpret_cast<unsigned long long*>(cb.counts + kCcSs), tb) : 0ull;
+    }
+    __syncthreads();
+    xa += sh[0];
+    xb += sh[1];
+#pragma unroll
+    for (int k = 0; k < kColdBasePer; k++) {
+      if (c[k] == 1u) {
+        cb.singles[(uint32_t)(xb >> 32)] = e[k];
+        xb += 1ull << 32;
+      } else if (c[k] > 1u) {
+        const uint32_t base = (uint32_t)xa;
+        cb.cnt[e[k].x] = base | kColdBased;
+        const uint4 seg = make_uint4(e[k].x, base, c[k], 0u);
+        if (c[k] > cg.short_max) {
+          cb.longs[(uint32_t)(xa >> 32)] = seg;
+          xa += (unsigned long long)c[k] | (1ull << 32);
+        } else {
+          cb.segs[(uint32_t)xb] = seg;
+          xa += (unsigned long long)c[k];
+          xb += 1ull;
+        }
+      }
+    }
+    __syncthreads();  // (sh is rewritten by the next trip)
+  }
+}
+
+__global__ void __launch_bounds__(kColdBlock)
+    cold_scatter_kernel(ColdGeom cg, const uint32_t* __restrict__ one_hot,
+                        const uint64_t* __restrict__ value_index, ColdBufs cb) {
+  const uint64_t H = *one_hot != 0u ? (uint64_t)cg.hot_rows : 0ull;
+  const uint32_t p0 = blockIdx.x * (uint32_t)(kColdBlock * kColdPer) + threadIdx.x;
+  uint32_t row[kColdPer], w[kColdPer], rk[kColdPer];
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    const uint32_t p = p0 + (uint32_t)(r * kColdBlock);
+    row[r] = kColdNone;
+    if (p < cg.n) {
+      const uint64_t v = value_index[p];
+      if (v >= H && v < (uint64_t)cg.max_vocab) row[r] = (uint32_t)v;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    w[r] = row[r] != kColdNone ? cb.cnt[row[r]] : 0u;
+    rk[r] = row[r] != kColdNone ? cb.rank[p0 + (uint32_t)(r * kColdBlock)] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kColdPer; r++) {
+    if ((w[r] & kColdBased) != 0u)
+      cb.plist[(w[r] & ~kColdBased) + rk[r]] = p0 + (uint32_t)(r * kColdBlock);
+  }
+}
+
+template <int LPR>
+struct ColdShape {
+  // LDS per workgroup: three arrays of GPB x kEMax words = 24 KB whatever LPR is
+  static constexpr int kEMax = 8 * LPR < 256 ? 8 * LPR : 256;   // entries of a slab of short runs
+  static constexpr int kShortMax = kEMax < 32 ? kEMax : 32;     // longest short run
+  static constexpr int kNS = kEMax / 32 > 0 ? kEMax / 32 : 1;   // short runs per slab
+};
+
+template <int LPR, typename GradT, bool kSgd>
+__global__ void __launch_bounds__(kBlock)
+    cold_reduce_kernel(ColdGeom cg, const uint32_t* __restrict__ one_hot,
+                       const void* __restrict__ row_offset,
+                       const uint64_t* __restrict__ value_index, const GradT* __restrict__ grad,
+                       OptConst o, float* __restrict__ table, float* __restrict__ state0,
+                       float* __restrict__ state1, unsigned long long* __restrict__ prev_time,
+                       float* __restrict__ gsum, ColdBufs cb, uint32_t parts) {
+  typedef typename Load4<GradT>::raw Raw;
+  constexpr int D = LPR * 4;
+  constexpr int GPB = kBlock / LPR;
+  constexpr int EMAX = ColdShape<LPR>::kEMax;
+  constexpr int NSS = ColdShape<LPR>::kNS;
+  constexpr int QB = sizeof(Raw) == 8 ? 16 : 8;
+  constexpr int NS1 = kSgd ? 8 : 4;  // singles in flight per lane group
+  static_assert(GPB * EMAX * 3 <= 6144 && kColdLds <= 6144, "LDS budget");
+  __shared__ uint32_t lds[6144];
+  __shared__ uint32_t scan_smem[kBlock / 64 + 1];
+  const bool oh = *one_hot != 0u;
+  const bool mean = cg.combiner == 1 && !oh;  // (one key per bucket: the mean is the sum)
+  const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+  auto grad_row = [&](uint32_t p) -> uint32_t {
+    if (!oh) return cb.bkt[p];
+    return cg.map_inner ? (p % cg.map_inner) * cg.map_outer + p / cg.map_inner : p;
+  };
+  auto cvt = [&](const Raw& r, uint32_t b) -> float4 {
+    return scaled_grad<GradT>(r, mean ? 1 : 0,
+                              mean ? bucket_len(row_offset, cg.off_is_u32 != 0, b) : 1);
+  };
+  auto add = [](float4& a, const float4& f) {
+    a.x += f.x;
+    a.y += f.y;
+    a.z += f.z;
+    a.w += f.w;
+  };
+  // plain SGD: the row of a finished run is completed when the next one finishes (its read
+  // travels meanwhile), as in seg_reduce_kernel
+  uint32_t pend_row = kColdNone;
+  float4 pend_w = make_float4(0.f, 0.f, 0.f, 0.f), pend_d = pend_w;
+  auto pend_flush = [&]() {
+    if (pend_row != kColdNone) {
+      add(pend_w, pend_d);
+      *reinterpret_cast<float4*>(table + (size_t)pend_row * D + l * 4) = pend_w;
+      pend_row = kColdNone;
+    }
+  };
+  auto emit = [&](uint32_t row, const float4& a) {
+    if constexpr (kSgd) {
+      pend_flush();
+      pend_d.x = -o.lr * (a.x / o.scaler);
+      pend_d.y = -o.lr * (a.y / o.scaler);
+      pend_d.z = -o.lr * (a.z / o.scaler);
+      pend_d.w = -o.lr * (a.w / o.scaler);
+      pend_row = row;
+      pend_w = *reinterpret_cast<const float4*>(table + (size_t)row * D + l * 4);
+    } else {
+      apply_row_vec4<LPR>(o, (uint64_t)row, l, a, table, state0, state1, prev_time);
+    }
+    if (l == 0) cb.cnt[row] = 0u;  // clean for the next update
+  };
+
+  // ---- rows met once ---------------------------------------------------------------------------
+  const uint32_t n1 = (parts & 1u) ? cb.counts[kCcSs + 1] : 0u;
+  for (uint32_t i0 = (blockIdx.x * (uint32_t)GPB + (uint32_t)g) * (uint32_t)NS1; i0 < n1;
+       i0 += gridDim.x * (uint32_t)(GPB * NS1)) {
+    uint32_t row[NS1], b[NS1];
+    Raw v[NS1];
+    float4 w[NS1];
+#pragma unroll
+    for (int k = 0; k < NS1; k++) {
+      const uint32_t i = i0 + (uint32_t)k < n1 ? i0 + (uint32_t)k : n1 - 1u;
+      const uint2 e = cb.singles[i];
+      row[k] = e.x;
+      b[k] = grad_row(e.y);
+    }
+#pragma unroll
+    for (int k = 0; k < NS1; k++) {
+      v[k] = Load4<GradT>::ld_raw(grad + (size_t)b[k] * D + l * 4);
+      if constexpr (kSgd) w[k] = *reinterpret_cast<const float4*>(table + (size_t)row[k] * D + l * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NS1; k++) {
+      if (i0 + (uint32_t)k < n1) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        add(a, cvt(v[k], b[k]));
+        if constexpr (kSgd) {
+          w[k].x += -o.lr * (a.x / o.scaler);
+          w[k].y += -o.lr * (a.y / o.scaler);
+          w[k].z += -o.lr * (a.z / o.scaler);
+          w[k].w += -o.lr * (a.w / o.scaler);
+          *reinterpret_cast<float4*>(table + (size_t)row[k] * D + l * 4) = w[k];
+        } else {
+          apply_row_vec4<LPR>(o, (uint64_t)row[k], l, a, table, state0, state1, prev_time);
+        }
+        if (l == 0) cb.cnt[row[k]] = 0u;
+      }
+    }
+  }
+
+  // ---- short runs: NSS of them per lane group and trip ------------------------------------------
+  {
+    uint32_t* raw = lds + (size_t)g * (3 * EMAX);
+    uint32_t* srt = raw + EMAX;
+    uint32_t* erow = srt + EMAX;
+    const uint32_t n2 = (parts & 2u) ? cb.counts[kCcSs] : 0u;
+    for (uint32_t i0 = (blockIdx.x * (uint32_t)GPB + (uint32_t)g) * (uint32_t)NSS; i0 < n2;
+         i0 += gridDim.x * (uint32_t)(GPB * NSS)) {
+      uint32_t srow[NSS], sbase[NSS], soff[NSS + 1];
+      soff[0] = 0u;
+#pragma unroll
+      for (int j = 0; j < NSS; j++) {
+        srow[j] = kColdNone;
+        sbase[j] = 0u;
+        soff[j + 1] = soff[j];
+        if (i0 + (uint32_t)j < n2) {
+          const uint4 e = cb.segs[i0 + (uint32_t)j];
+          srow[j] = e.x;
+          sbase[j] = e.y;
+          soff[j + 1] = soff[j] + e.z;
+        }
+      }
+      const uint32_t E = soff[NSS];
+      __builtin_amdgcn_wave_barrier();  // (the previous trip's reads of the lists are done)
+      for (uint32_t q = (uint32_t)l; q < E; q += (uint32_t)LPR) {
+        uint32_t bs = sbase[0], of = 0u, rw = srow[0];
+#pragma unroll
+        for (int j = 1; j < NSS; j++) {
+          if (q >= soff[j]) {
+            bs = sbase[j];
+            of = soff[j];
+            rw = srow[j];
+          }
+        }
+        raw[q] = cb.plist[bs + (q - of)];
+        erow[q] = rw;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // the run's positions in ascending order: rank = entries of the run below mine
+      for (uint32_t q = (uint32_t)l; q < E; q += (uint32_t)LPR) {
+        uint32_t s0 = 0u, s1 = soff[1];
+#pragma unroll
+        for (int j = 1; j < NSS; j++) {
+          if (q >= soff[j]) {
+            s0 = soff[j];
+            s1 = soff[j + 1];
+          }
+        }
+        const uint32_t mine = raw[q];
+        uint32_t rnk = 0u;
+        for (uint32_t t = s0; t < s1; t++) rnk += raw[t] < mine ? 1u : 0u;
+        srt[s0 + rnk] = mine;
+      }
+      __builtin_amdgcn_wave_barrier();
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t cur = erow[0];
+#pragma unroll 1
+      for (uint32_t qb = 0; qb < E; qb += (uint32_t)QB) {
+        Raw v[QB];
+        uint32_t bb[QB];
+#pragma unroll
+        for (int k = 0; k < QB; k++) {
+          const uint32_t q = qb + (uint32_t)k < E ? qb + (uint32_t)k : E - 1u;
+          bb[k] = grad_row(srt[q]);
+        }
+#pragma unroll
+        for (int k = 0; k < QB; k++) v[k] = Load4<GradT>::ld_raw(grad + (size_t)bb[k] * D + l * 4);
+#pragma unroll
+        for (int k = 0; k < QB; k++) {
+          const uint32_t q = qb + (uint32_t)k;
+          if (q < E) {
+            const uint32_t rw = erow[q];
+            if (rw != cur) {
+              emit(cur, acc);
+              acc = make_float4(0.f, 0.f, 0.f, 0.f);
+              cur = rw;
+            }
+            add(acc, cvt(v[k], bb[k]));
+          }
+        }
+      }
+      emit(cur, acc);
+    }
+    if constexpr (kSgd) pend_flush();
+  }
+
+  // ---- long runs: one workgroup each --------------------------------------------------------------
+  const uint32_t n3 = (parts & 4u) ? cb.counts[kCcPl + 1] : 0u;
+  for (uint32_t ir = blockIdx.x; ir < n3; ir += gridDim.x) {
+    const uint4 e = cb.longs[ir];
+    const uint32_t row = e.x, base = e.y, c = e.z;
+    __syncthreads();  // (LDS of the part above / of the previous run is no longer read)
+    const uint32_t* sp;  // the run's positions, ascending
+    if (c <= (uint32_t)kColdLds) {
+      uint32_t N = 64u;
+      while (N < c) N <<= 1;
+      for (uint32_t q = threadIdx.x; q < N; q += (uint32_t)kBlock)
+        lds[q] = q < c ? cb.plist[base + q] : kColdNone;
+      __syncthreads();
+      for (uint32_t k = 2u; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+          for (uint32_t t = threadIdx.x; t < (N >> 1); t += (uint32_t)kBlock) {
+            const uint32_t lo = ((t / j) * (j << 1)) + (t % j), hi = lo + j;
+            const bool up = (lo & k) == 0u;
+            const uint32_t a = lds[lo], b = lds[hi];
+            if ((a > b) == up) {
+              lds[lo] = b;
+              lds[hi] = a;
+            }
+          }
+          __syncthreads();
+        }
+      }
+      sp = lds;
+    } else {
+      // longer than the LDS list: the batch's rows are walked in order and the positions of this
+      // row written back over the run's (unordered) entries as they come
+      uint32_t filled = 0u;
+      for (uint32_t q0 = 0u; q0 < cg.n; q0 += (uint32_t)(kBlock * 4)) {
+        const uint32_t p = q0 + threadIdx.x * 4u;
+        uint32_t m = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (p + (uint32_t)r < cg.n && value_index[p + (uint32_t)r] == (uint64_t)row) m |= 1u << r;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<uint32_t, kBlock>((uint32_t)__popc(m), scan_smem, &tot);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if ((m >> r) & 1u) cb.plist[base + filled + ex++] = p + (uint32_t)r;
+        filled += tot;
+      }
+      __syncthreads();
+      sp = cb.plist + base;
+    }
+    // pieces of kColdPiece entries, lane group by lane group; the sums wait in gsum[base + first
+    // entry] (rows of gsum the hot rows' pool cannot reach: cold entries + hot partials <= n)
+    const uint32_t np = (c + (uint32_t)kColdPiece - 1u) / (uint32_t)kColdPiece;
+    for (uint32_t k = (uint32_t)g; k < np; k += (uint32_t)GPB) {
+      const uint32_t q0 = k * (uint32_t)kColdPiece;
+      const uint32_t cntp = c - q0 < (uint32_t)kColdPiece ? c - q0 : (uint32_t)kColdPiece;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int qb = 0; qb < kColdPiece; qb += QB) {
+        if ((uint32_t)qb >= cntp) break;
+        Raw v[QB];
+        uint32_t bb[QB];
+#pragma unroll
+        for (int t = 0; t < QB; t++) {
+          const uint32_t q = (uint32_t)(qb + t) < cntp ? (uint32_t)(qb + t) : cntp - 1u;
+          bb[t] = grad_row(sp[q0 + q]);
+        }
+#pragma unroll
+        for (int t = 0; t < QB; t++) v[t] = Load4<GradT>::ld_raw(grad + (size_t)bb[t] * D + l * 4);
+#pragma unroll
+        for (int t = 0; t < QB; t++)
+          if ((uint32_t)(qb + t) < cntp) add(acc, cvt(v[t], bb[t]));
+      }
+      *reinterpret_cast<float4*>(gsum + (size_t)(base + q0) * D + l * 4) = acc;
+    }
+    __syncthreads();
+    if (g == 0) {
+      float4 tot = *reinterpret_cast<const float4*>(gsum + (size_t)base * D + l * 4);
+      constexpr int CU = 8;
+      for (uint32_t k = 1u; k < np; k += (uint32_t)CU) {
+        float4 h[CU];
+#pragma unroll
+        for (int t = 0; t < CU; t++) {
+          const uint32_t kk = k + (uint32_t)t < np ? k + (uint32_t)t : k;
+          h[t] = *reinterpret_cast<const float4*>(
+              gsum + (size_t)(base + kk * (uint32_t)kColdPiece) * D + l * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < CU; t++)
+          if (k + (uint32_t)t < np) add(tot, h[t]);
+      }
+      apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+      if (l == 0) cb.cnt[row] = 0u;
+    }
+  }
+}
+
 // any D: one wavefront per run, lanes stride over the vector
 template <typename OffT, typename SortK, typename GradT>
 __global__ void __launch_bounds__(kBlock)
@@ -1793,7 +2288,7 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     // ---- hot rows (one key per bucket, device flag): see hot_sort_kernel ------------------------
     const uint32_t* n_live = nullptr;
     hipStream_t ss = s;  // stream of the segmented reduce
-    bool hot_taken = false;
+    bool hot_taken = false, cold_taken = false;
     int seg_grid_cap = 1 << 20;
     {
       const int lpr = D / 4;
@@ -1843,8 +2338,77 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
           HCTR_HIP(hipEventRecord(u.ev_fork, s));
           HCTR_HIP(hipStreamWaitEvent(cs, u.ev_fork, 0));
         }
-        HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, cs, u.hot_rows,
-                                          u.hot_counts + 8, false)));
+        const bool cold = u.cold_count && u.cold_cnt != nullptr && nnz < 0x7FFFFFF0ull;
+        if (cold) {
+          // the cold rows' chain: count, bases, scatter, reduce (no sort)
+          ColdGeom cg;
+          cg.n = (uint32_t)nnz;
+          cg.hot_rows = u.hot_rows;
+          cg.max_vocab = (uint32_t)u.max_vocab;
+          cg.map_inner = u.map_inner;
+          cg.map_outer = u.map_outer;
+          cg.off_is_u32 = sizeof(OffT) == 4 ? 1 : 0;
+          cg.combiner = combiner;
+          cg.buckets = buckets;
+          ColdBufs cb;
+          cb.cnt = u.cold_cnt;
+          cb.rank = u.cold_rank;
+          cb.plist = u.cold_plist;
+          cb.bkt = u.cold_bkt;
+          cb.dlist = (uint2*)u.cold_dlist;
+          cb.singles = (uint2*)u.cold_singles;
+          cb.segs = (uint4*)u.cold_segs;
+          cb.longs = (uint4*)u.cold_longs;
+          cb.counts = u.cold_counts + kCcWords * ((u.hot_parity + 1u) & 1u);  // (hot_parity is already
+          cb.counts_next = u.cold_counts + kCcWords * (u.hot_parity & 1u);    //  this update's + 1)
+          const unsigned pgrid = (unsigned)ceil_div<size_t>(nnz, (size_t)(kColdBlock * kColdPer));
+          const unsigned bgrid =
+              (unsigned)grid_for(nnz, kColdBlock * kColdBasePer, 256);
+          // HCTR_COLD_SPLIT=1 (measurements): the three parts of the reduce as three launches
+          const char* sp_env = getenv("HCTR_COLD_SPLIT");
+          const bool split = sp_env != nullptr && sp_env[0] == '1';
+          const char* cg_env = getenv("HCTR_COLD_GRID");
+          const int cold_grid = cg_env ? atoi(cg_env) : 2048;
+          const bool sgd = o.optimizer == HCTR_OPT_SGD;
+#define HCTR_COLD_CASE(LPR_)                                                                      \
+  {                                                                                               \
+    cg.short_max = (uint32_t)ColdShape<LPR_>::kShortMax;                                          \
+    hipLaunchKernelGGL(cold_count_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, cg,               \
+                       u.one_hot_flag, (const void*)ro, vi, cb);                                  \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL(cold_base_kernel, dim3(bgrid), dim3(kColdBlock), 0, cs, cg, cb);           \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL(cold_scatter_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, cg,             \
+                       u.one_hot_flag, vi, cb);                                                   \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    for (uint32_t part = split ? 1u : 7u; part <= 7u; part = split && part < 4u ? part << 1 : 8u) { \
+      if (sgd)                                                                                    \
+        hipLaunchKernelGGL((cold_reduce_kernel<LPR_, GradT, true>), dim3(cold_grid), dim3(kBlock), \
+                           0, cs, cg, u.one_hot_flag, (const void*)ro, vi, grad, o, table, state0, \
+                           state1, (unsigned long long*)prev_time, u.gsum, cb, part);             \
+      else                                                                                        \
+        hipLaunchKernelGGL((cold_reduce_kernel<LPR_, GradT, false>), dim3(cold_grid),             \
+                           dim3(kBlock), 0, cs, cg, u.one_hot_flag, (const void*)ro, vi, grad, o, \
+                           table, state0, state1, (unsigned long long*)prev_time, u.gsum, cb,     \
+                           part);                                                                 \
+      HCTR_LAUNCH_CHECK();                                                                        \
+    }                                                                                             \
+  }
+          switch (lpr) {
+            case 1: HCTR_COLD_CASE(1) break;
+            case 2: HCTR_COLD_CASE(2) break;
+            case 4: HCTR_COLD_CASE(4) break;
+            case 8: HCTR_COLD_CASE(8) break;
+            case 16: HCTR_COLD_CASE(16) break;
+            case 32: HCTR_COLD_CASE(32) break;
+            default: HCTR_COLD_CASE(64) break;
+          }
+#undef HCTR_COLD_CASE
+          cold_taken = true;
+        } else {
+          HCTR_TRY((sort_stage<OffT, SortK>(u, buckets, nnz, ro, vi, cs, u.hot_rows,
+                                            u.hot_counts + 8, false)));
+        }
         float* pool_end = u.gsum + u.max_nnz * (size_t)D;
         const size_t items_max = nnz / kHotTile + n_chunks;
         // the hot rows' reduce is a grid-stride loop over a bounded number of workgroups: a kernel
@@ -1937,7 +2501,9 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
                        (unsigned long long*)prev_time, u.seg_head, u.seg_tail, u.big_list,        \
                        u.big_stride, u.span_count);                                               \
   }
-    if (a16 && D % 4 == 0) {
+    if (cold_taken) {
+      done = true;  // (the cold rows' chain above applied its rows itself)
+    } else if (a16 && D % 4 == 0) {
       done = true;
       switch (D / 4) {
         case 1: HCTR_SEG_CASE(1) break;
@@ -2151,6 +2717,23 @@ int SparseUpdater::hot_buffers(hipStream_t s) {
   const size_t part = C * kHotTiles * (size_t)D * sizeof(float);
   HCTR_HIP(hipMalloc(&hot_head, part));
   HCTR_HIP(hipMalloc(&hot_tail, part));
+  {
+    const char* cc = getenv("HCTR_COLD_COUNT");
+    cold_count = !(cc != nullptr && cc[0] == '0');
+  }
+  if (cold_count) {
+    HCTR_HIP(hipMalloc(&cold_cnt, max_vocab * sizeof(uint32_t)));
+    HCTR_HIP(hipMemsetAsync(cold_cnt, 0, max_vocab * sizeof(uint32_t), s));
+    HCTR_HIP(hipMalloc(&cold_rank, max_nnz * sizeof(uint32_t)));
+    HCTR_HIP(hipMalloc(&cold_plist, max_nnz * sizeof(uint32_t)));
+    HCTR_HIP(hipMalloc(&cold_bkt, max_nnz * sizeof(uint32_t)));
+    HCTR_HIP(hipMalloc(&cold_dlist, max_nnz * sizeof(uint2)));
+    HCTR_HIP(hipMalloc(&cold_singles, max_nnz * sizeof(uint2)));
+    HCTR_HIP(hipMalloc(&cold_segs, (max_nnz / 2 + 1) * sizeof(uint4)));
+    HCTR_HIP(hipMalloc(&cold_longs, (max_nnz / 2 + 1) * sizeof(uint4)));
+    HCTR_HIP(hipMalloc(&cold_counts, 2 * kCcWords * sizeof(uint32_t)));
+    HCTR_HIP(hipMemsetAsync(cold_counts, 0, 2 * kCcWords * sizeof(uint32_t), s));
+  }
   // (last: its presence is what marks the set complete)
   const size_t loc_bytes = (size_t)hot_rows * hot_chunks_max * sizeof(uint16_t);
   HCTR_HIP(hipMalloc(&hot_loc, loc_bytes));
@@ -2165,7 +2748,8 @@ int SparseUpdater::destroy() {
                   run_start,    d_num_runs,    seg_head,     seg_tail,      span_list, span_count,
                   gsum,         big_list,      hot_loc,      hot_counts,    hot_head,  hot_tail,
                   hot_S,        hot_meta,      hot_tpref,    hot_items,     hot_joins,
-                  hot_loc_blk};
+                  hot_loc_blk,  cold_cnt,      cold_rank,    cold_plist,    cold_bkt,
+                  cold_dlist,   cold_singles,  cold_segs,    cold_longs,    cold_counts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (hot_side) {
@@ -2190,6 +2774,8 @@ int SparseUpdater::destroy() {
   hot_loc = nullptr;
   hot_counts = hot_S = hot_meta = hot_tpref = hot_items = hot_joins = hot_loc_blk = nullptr;
   hot_head = hot_tail = nullptr;
+  cold_cnt = cold_rank = cold_plist = cold_bkt = cold_counts = nullptr;
+  cold_dlist = cold_singles = cold_segs = cold_longs = nullptr;
   hot_rows = hot_chunks_max = 0;
   return HCTR_OK;
 }

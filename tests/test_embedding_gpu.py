@@ -755,6 +755,101 @@ def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, opt_kw, B, D, d
     assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-3, 1e-4, "hot path vs plain path")
 
 
+@pytest.mark.parametrize("opt_kw", [dict(optimizer=6, atomic_update=False), dict(optimizer=3),
+                                    dict(optimizer=1, update_type=0)],
+                         ids=["sgd", "adagrad", "adam"])
+@pytest.mark.parametrize("B,D,dt", [(8192, 128, "f16"), (6000, 16, "f32"), (4100, 8, "bf16")])
+def test_update_cold_rows_counted_per_row(oracle, monkeypatch, opt_kw, B, D, dt):
+    """the cold rows' chain of the sparse update (cold_count / base / scatter / reduce: rows counted
+    per row instead of sorted) with nearly every row cold (HCTR_HOT_ROWS=2): rows met once, short
+    runs (2 .. 32 positions, summed in ascending position order = the reference's stable-sort
+    order), long runs sorted inside LDS (a 50-row table: ~ B / 50 positions a row) and a run longer
+    than the LDS list (the third row of a 3-row table: ~ B / 3 positions, re-derived in order by a
+    scan of the batch).  Batch 1 is ragged WITH as many keys as buckets (the host cannot tell: the
+    device flag sends every row, hot ones included, through the chain and the gradient row of a
+    position comes from a search of the offsets; mean combiner scaling is checked there too).
+    Table / state against the oracle: rows with at most 32 positions to 1e-6 (same order of
+    additions), the others within the re-association of pieces of 32; the same bits from a second
+    handle; close to the sorting path (HCTR_COLD_COUNT=0)."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    sizes = [3, 50, 3000, 100000]
+    S = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    V = int(sum(sizes))
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    opt = ha.OptParams(lr=0.01, scaler=2.0, **opt_kw)
+    ns = {1: 2, 3: 1, 6: 0}[opt.optimizer]
+
+    def run(cold_env, combiner):
+        monkeypatch.setenv("HCTR_HOT_MIN", "0")
+        monkeypatch.setenv("HCTR_HOT_ROWS", "2")
+        monkeypatch.setenv("HCTR_COLD_COUNT", cold_env)
+        rng = np.random.default_rng(B + D)
+        emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, 2 * S, S, combiner, opt,
+                                     out_dtype=tdt)
+        emb.init_params()
+        torch.cuda.synchronize()
+        table = emb.table().cpu().numpy().copy()
+        s0 = np.zeros_like(table) if ns >= 1 else None
+        s1 = np.zeros_like(table) if ns >= 2 else None
+        ht = oracle.HashTable(V, 8)
+        for it in range(3):
+            if it == 1:  # ragged, but nnz == buckets: pairs of buckets hold (0, 2) / (2, 0) / (1, 1) keys
+                kind = rng.integers(0, 3, size=B * S // 2)
+                lens = np.stack([np.array([0, 2, 1])[kind], np.array([2, 0, 1])[kind]], 1).reshape(-1)
+                assert lens.sum() == B * S
+                ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+                slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+                keys = (rng.integers(0, 1 << 30, size=slot_of.size) % np.array(sizes)[slot_of] +
+                        offs[slot_of]).astype(np.int64)
+            else:
+                ro = np.arange(B * S + 1, dtype=np.int64)
+                keys = np.stack([rng.integers(0, v, size=B) + o for v, o in zip(sizes, offs)],
+                                axis=1).reshape(-1).astype(np.int64)
+            emb.forward(True, _t(torch, ro), _t(torch, keys))
+            vi = ht.get_insert(keys)
+            g = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+            gt = _t(torch, g).to(tdt).view(B, S, D).contiguous()
+            emb.backward(gt)
+            torch.cuda.synchronize()
+            before = emb.table().cpu().numpy().copy()
+            emb.update_params()
+            torch.cuda.synchronize()
+            wg = oracle.backward_mixed(ro, gt.float().cpu().numpy().reshape(-1, D), D, combiner, dt)
+            oo = _oracle_opt(oracle, opt, it + 1)
+            oo.state_half = 1 if dt == "f16" else 0
+            oracle.update_params(ro, vi, wg, oo, table, s0, s1, None)
+            got = emb.table().cpu().numpy()
+            if opt.optimizer == 3:
+                # AdaGrad steps by lr * g / sqrt(accum): an element whose first gradient sum is
+                # nearly zero moves by ~ lr whatever the sum's size, so sums that differ in their
+                # last bits (pieces of 32 against one chain) can sit up to 2 lr apart there
+                err = np.abs(got.astype(np.float64) - table)
+                bad = err > 1e-4 + 1e-3 * np.abs(table)
+                assert bad.sum() <= 1e-5 * bad.size and err.max() <= 2.5 * opt.lr, (bad.sum(), err.max())
+            else:
+                assert_close(got, table, 1e-3, 1e-4, f"table it{it} cold={cold_env}")
+            if s0 is not None:
+                assert_close(emb.opt_state(0).cpu().numpy(), s0, 2e-3, 1e-4, f"state0 it{it}")
+            cnt = np.bincount(vi.astype(np.int64), minlength=V)
+            few = (cnt > 0) & (cnt <= 32)
+            assert few.sum() > 1000 and ((cnt > 2048).any() or B < 8192) and ((cnt > 32) & (cnt <= 2048)).any()
+            if cold_env == "1":
+                assert_close(got[few], table[few], 1e-6, 1e-7, f"short runs it{it}")
+            assert (got[cnt == 0] == before[cnt == 0]).all(), "a row without a key moved"
+        return emb.table().clone()
+
+    for combiner in (0, 1):
+        a = run("1", combiner)
+        b = run("1", combiner)
+        assert torch.equal(a, b), "the cold rows' chain is not deterministic"
+        c = run("0", combiner)
+        if opt.optimizer != 3:
+            assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-3, 1e-4, "counted vs sorted cold rows")
+
+
 @pytest.mark.parametrize("ahead", [False, True], ids=["cooperative_finish", "index_ahead_two_launches"])
 def test_index_stage_beside_a_device_full_of_gemms(oracle, ahead):
     """the index stage with unseen keys on a side stream while the default stream keeps the device

@@ -1,10 +1,10 @@
 #!/bin/bash
 # (on the GPU box) main bench leg under a list of environment settings, no profiler:
-#   bash tools/r4_ab.sh TAG "ENV=.." "ENV=.." ...   -> gpurun_out/r4_ab_TAG.txt
+#   bash tools/r5_ab.sh TAG "ENV=.." "ENV=.." ...   -> gpurun_out/r5_ab_TAG.txt
 TAG=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-OUT=gpurun_out/r4_ab_$TAG.txt; : > $OUT
+OUT=gpurun_out/r5_ab_$TAG.txt; : > $OUT
 W="--extra none --no-cpu-baseline --steps 40 --warmup 10"
 for CFG in "$@"; do
   echo "==== $CFG" >> $OUT
