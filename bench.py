@@ -86,7 +86,8 @@ def compact_line(full, extra_file):
     for k in ("roofline_update", "roofline_index", "roofline_uniform", "roofline_fp32"):
         if isinstance(full.get(k), dict):
             line[k] = _roof_short(full[k], ("algorithmic_bytes", "algorithmic_bytes_per_launch",
-                                            "traffic_ratio"))
+                                            "traffic_ratio", "us_grouping_ahead",
+                                            "frac_grouping_ahead"))
             line[k].pop("peak", None)
             line[k].pop("unit", None)
             line[k].pop("bound", None)
@@ -422,14 +423,31 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     # there bracket shared-chip time.  The stage times the rooflines are computed from are taken
     # right after, on `inline` further unseen batches with the update in line (its own time).
     prof = prof_timed
+    prof_ahead = None
     if world == 1 and inline > 0:
         os.environ["HCTR_UPDATE_OVERLAP"] = "0"
+        # (a) as the product runs it: the update's grouping kernels (hot rows' chunk sort, cold
+        # rows' count / base / scatter) right behind the index stage on side streams, the update
+        # stage itself = the two reduces + join / apply
         emb.profiling(True)
-        for _ in range(inline):
+        for _ in range(inline // 2):
+            m.train()
+        sync()
+        prof_ahead = emb.profile()
+        # (b) everything of the update inside the update stage (HCTR_PREWORK=0): the stage time
+        # `roofline_update` is computed from
+        pw_prev = os.environ.get("HCTR_PREWORK")
+        os.environ["HCTR_PREWORK"] = "0"
+        emb.profiling(True)
+        for _ in range(inline - inline // 2):
             m.train()
         sync()
         prof = emb.profile()
         emb.profiling(False)
+        if pw_prev is None:
+            os.environ.pop("HCTR_PREWORK", None)
+        else:
+            os.environ["HCTR_PREWORK"] = pw_prev
     # the same stages with NO unseen key (batches the tables have met): the index stage's floor
     steady_us = None
     if world == 1:
@@ -481,7 +499,9 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     tag = label or ("fp32" if esz == 4 else "fp16")
     here = _csrc_hash()
     if world == 1 and D == 128 and a.batch == 65536 and a.table_scale == 1.0:
-        pmc_path = os.path.join(ROOT, "profiles", f"r4_pmc_hbm_traffic_{tag}.json")
+        pmc_path = os.path.join(ROOT, "profiles", f"r5_pmc_hbm_traffic_{tag}.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", f"r4_pmc_hbm_traffic_{tag}.json")
         try:
             j = json.load(open(pmc_path))
             if abs(float(j.get("alpha", 1.1)) - alpha) < 1e-9:
@@ -501,13 +521,17 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                         n1 = ks[once]["launches_averaged"][0]
                         return sum(ks[k]["hbm_bytes_per_launch"] *
                                    ks[k]["launches_averaged"][0] / n1 for k in names if k in ks)
-                    if "seg_reduce_kernel" in ks:
+                    upd_once = ("cold_reduce_kernel" if "cold_reduce_kernel" in ks
+                                else "seg_reduce_kernel")
+                    if upd_once in ks:
                         pmc_upd = per_step(("expand_pairs_kernel", "rs_hist_kernel",
                                             "rs_colscan_kernel", "rs_scatter_kernel",
                                             "hot_sort_kernel", "hot_reduce_kernel",
                                             "hot_join_kernel", "hot_apply_kernel",
+                                            "cold_count_kernel", "cold_base_kernel",
+                                            "cold_scatter_kernel", "cold_reduce_kernel",
                                             "seg_reduce_kernel", "seg_combine_kernel",
-                                            "seg_combine_big_kernel"), "seg_reduce_kernel")
+                                            "seg_combine_big_kernel"), upd_once)
                     if "ht_probe_insert_kernel" in ks:
                         pmc_idx = per_step(("ht_probe_insert_kernel", "ht_finish_kernel"),
                                            "ht_probe_insert_kernel")
@@ -515,12 +539,15 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
             pmc = None
         # matrix-pipe utilisation of the interaction kernels (SQ pass of tools/measure_round.sh)
         try:
-            j = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_sq_counters.json")))
+            sq_path = os.path.join(ROOT, "profiles", "r5_pmc_sq_counters.json")
+            if not os.path.exists(sq_path):
+                sq_path = os.path.join(ROOT, "profiles", "r4_pmc_sq_counters.json")
+            j = json.load(open(sq_path))
             if j.get("csrc_hash") == here and tag == "fp16":
                 mfma_busy = {k: {"mfma_util_of_1024_simds": v.get("mfma_util_of_1024_simds"),
                                  "wave_cycles_split": v.get("wave_cycles_split")}
                              for k, v in j["kernels"].items() if k.startswith("interaction_")}
-                mfma_busy["source"] = "profiles/r4_pmc_sq_counters.json" + (
+                mfma_busy["source"] = os.path.relpath(sq_path, ROOT) + (
                     f" @ {j['commit']}" if j.get("commit") else "")
         except Exception:
             mfma_busy = None
@@ -528,6 +555,10 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     # update (a12): SURVEY 8(d) bytes = nnz (8 + K) + B S_g D E (gradients read) + U D 4 x 2 (rows)
     upd_bytes = nnz_g * 16 + B * spr * D * esz + U * D * 4 * 2
     upd_s = (stage_us.get("sort", 0.0) + stage_us.get("segmented_update", 0.0)) * 1e-6
+    upd_ahead_s = None
+    if prof_ahead is not None:
+        sa = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof_ahead.items()}
+        upd_ahead_s = (sa.get("sort", 0.0) + sa.get("segmented_update", 0.0)) * 1e-6
     idx_bytes = nnz_g * (8 + 16 + 8)
     idx_s = stage_us.get("hash_index", 0.0) * 1e-6
     per_rank = None
@@ -600,9 +631,15 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                      if pool_ms > 0 else None,
                      "hbm_traffic_gbps": (pmc / pool_s / 1e9) if pmc and pool_ms > 0 else None},
         "roofline_update": {"bound": "hbm", "kernels": "hot rows (per-chunk LDS sort, tile reduce, "
-                            "chunk-ordered apply) beside the cold pairs' radix sort + segmented "
-                            "reduce with the optimizer folded in; `us` = fork .. join of the two "
-                            "chains with the update in line (stage_us_per_step)",
+                            "chunk-ordered apply) beside the cold rows' chain (counted per row: "
+                            "count / base / scatter, then singles + sorted short runs + long runs "
+                            "with the optimizer folded in); `us` = fork .. join of the two chains "
+                            "with ALL of it inside the update stage (HCTR_PREWORK=0); "
+                            "`us_grouping_ahead` = the same stage as the product runs it, the "
+                            "grouping kernels started behind the index stage on side streams",
+                            "us_grouping_ahead": (upd_ahead_s * 1e6) if upd_ahead_s else None,
+                            "frac_grouping_ahead": (upd_bytes / upd_ahead_s / 1e9 / HBM_PEAK_GBPS)
+                            if upd_ahead_s else None,
                             "achieved": (upd_bytes / upd_s / 1e9) if upd_s > 0 else None,
                             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": (upd_bytes / upd_s / 1e9 / HBM_PEAK_GBPS) if upd_s > 0 else None,

@@ -284,6 +284,10 @@ struct hctr_embedding {
   // inside the all-to-all wait); on one GPU it would only share the chip with the dense tower --
   // measured: the step is as long as with the sort in line, 100 us (HCTR_PRESORT=1 / 0 overrides)
   bool presort_enabled = true;
+  // one GPU: the grouping work of the update's hot-row path (SparseUpdater::prework) right behind
+  // the index stage, on the updater's side streams, under the gather and the dense tower
+  // (HCTR_PREWORK=0: inside the update)
+  bool prework_enabled = false;
   size_t cur_buckets = 0;
   size_t cur_nnz_bound = 0;
   size_t eval_nnz = 0;  // keys of the last evaluation batch (host count)
@@ -515,6 +519,17 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
       HCTR_TRY(e->ht.get_mark(keys, nnz, d_n, bb.value_index, s));
     }
     e->prof.end(1, s);
+    // (the switch is read per call: bench.py times the update with and without the work ahead)
+    const char* pw_env = getenv("HCTR_PREWORK");
+    if (is_train && !ahead && e->p.world == 1 && (pw_env ? pw_env[0] != '0' : e->prework_enabled) &&
+        !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
+      e->upd.one_hot_flag = batch_one_hot;
+      e->upd.scale_row_offset = nullptr;
+      const int prc = e->upd.prework(buckets, nnz, e->p.combiner, ro, e->p.key_type,
+                                     bb.value_index, s);
+      e->upd.one_hot_flag = nullptr;
+      HCTR_TRY(prc);
+    }
   }
   if (!is_train) e->eval_nnz = nnz;
   if (ahead) {
@@ -690,6 +705,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   e->upd.hot_streams = (uint32_t)e->buckets_per_sample();
   e->presort_enabled = p.world > 1;
   if (const char* ps = getenv("HCTR_PRESORT")) e->presort_enabled = ps[0] != '0';
+  e->prework_enabled = p.world == 1;
   e->upd.prof = &e->prof;
   e->opt.optimizer = p.optimizer;
   e->opt.update_type = p.update_type;

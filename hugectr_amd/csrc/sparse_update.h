@@ -99,7 +99,8 @@ struct SparseUpdater {
   void* cold_singles = nullptr;     // [max_nnz] uint2
   void* cold_segs = nullptr;        // [max_nnz / 2 + 1] uint4
   void* cold_longs = nullptr;       // [max_nnz / 2 + 1] uint4 (runs longer than short_max >= 8)
-  uint32_t* cold_counts = nullptr;  // two alternating sets of 8 words
+  uint32_t* cold_counts = nullptr;  // two alternating sets of counters
+  void* pre_plan = nullptr;         // geometry / buffers / events of the batch in hand (PrePlan)
   size_t early_n = 0;  // > 0: sort_*_out hold the sorted pairs of (early_vi, early_buckets)
   const uint64_t* early_vi = nullptr;
   size_t early_buckets = 0;
@@ -115,6 +116,12 @@ struct SparseUpdater {
   int destroy();
   // optional: start sorting n >= live nnz (row, bucket) pairs now, concurrently with stream s
   int presort(size_t buckets, size_t n, const void* row_offset, int key_type,
+              const uint64_t* value_index, hipStream_t s);
+  // optional: the grouping work of the hot-row path (hot rows' chunk sort; cold rows' count / base
+  // / scatter) needs the rows only -- start it now on the side streams, behind what s holds; the
+  // update of the same (value_index, nnz, buckets) then runs the reduces alone.  A no-op when the
+  // batch would not take that path.  one_hot_flag / map / hot_streams as for update().
+  int prework(size_t buckets, size_t nnz, int combiner, const void* row_offset, int key_type,
               const uint64_t* value_index, hipStream_t s);
   // row_offset/key_type as in the forward; top_grad [buckets][D] of grad_dtype.
   int update(size_t buckets, size_t nnz, int combiner, const void* row_offset, int key_type,

@@ -1762,6 +1762,113 @@ __global__ void __launch_bounds__(kBlock)
     if (l == 0) cb.cnt[row] = 0u;  // clean for the next update
   };
 
+  // ---- long runs: one workgroup each --------------------------------------------------------------
+  const uint32_t n3 = (parts & 4u) ? cb.counts[kCcPl + 1] : 0u;
+  for (uint32_t ir = blockIdx.x; ir < n3; ir += gridDim.x) {
+    const uint4 e = cb.longs[ir];
+    const uint32_t row = e.x, base = e.y, c = e.z;
+    __syncthreads();  // (LDS of the part above / of the previous run is no longer read)
+    const uint32_t* sp;  // the run's positions, ascending
+    if (c <= 512u) {
+      // one pass: an entry's place = the number of entries below it (positions are distinct)
+      for (uint32_t q = threadIdx.x; q < c; q += (uint32_t)kBlock) lds[2048 + q] = cb.plist[base + q];
+      __syncthreads();
+      for (uint32_t q = threadIdx.x; q < c; q += (uint32_t)kBlock) {
+        const uint32_t mine = lds[2048 + q];
+        uint32_t rnk = 0u;
+        for (uint32_t t = 0u; t < c; t++) rnk += lds[2048 + t] < mine ? 1u : 0u;
+        lds[rnk] = mine;
+      }
+      __syncthreads();
+      sp = lds;
+    } else if (c <= (uint32_t)kColdLds) {
+      uint32_t N = 1024u;
+      while (N < c) N <<= 1;
+      for (uint32_t q = threadIdx.x; q < N; q += (uint32_t)kBlock)
+        lds[q] = q < c ? cb.plist[base + q] : kColdNone;
+      __syncthreads();
+      for (uint32_t k = 2u; k <= N; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+          for (uint32_t t = threadIdx.x; t < (N >> 1); t += (uint32_t)kBlock) {
+            const uint32_t lo = ((t / j) * (j << 1)) + (t % j), hi = lo + j;
+            const bool up = (lo & k) == 0u;
+            const uint32_t a = lds[lo], b = lds[hi];
+            if ((a > b) == up) {
+              lds[lo] = b;
+              lds[hi] = a;
+            }
+          }
+          __syncthreads();
+        }
+      }
+      sp = lds;
+    } else {
+      // longer than the LDS list: the batch's rows are walked in order and the positions of this
+      // row written back over the run's (unordered) entries as they come
+      uint32_t filled = 0u;
+      for (uint32_t q0 = 0u; q0 < cg.n; q0 += (uint32_t)(kBlock * 4)) {
+        const uint32_t p = q0 + threadIdx.x * 4u;
+        uint32_t m = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (p + (uint32_t)r < cg.n && value_index[p + (uint32_t)r] == (uint64_t)row) m |= 1u << r;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<uint32_t, kBlock>((uint32_t)__popc(m), scan_smem, &tot);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if ((m >> r) & 1u) cb.plist[base + filled + ex++] = p + (uint32_t)r;
+        filled += tot;
+      }
+      __syncthreads();
+      sp = cb.plist + base;
+    }
+    // pieces of kColdPiece entries, lane group by lane group; the sums wait in gsum[base + first
+    // entry] (rows of gsum the hot rows' pool cannot reach: cold entries + hot partials <= n)
+    const uint32_t np = (c + (uint32_t)kColdPiece - 1u) / (uint32_t)kColdPiece;
+    for (uint32_t k = (uint32_t)g; k < np; k += (uint32_t)GPB) {
+      const uint32_t q0 = k * (uint32_t)kColdPiece;
+      const uint32_t cntp = c - q0 < (uint32_t)kColdPiece ? c - q0 : (uint32_t)kColdPiece;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int qb = 0; qb < kColdPiece; qb += QB) {
+        if ((uint32_t)qb >= cntp) break;
+        Raw v[QB];
+        uint32_t bb[QB];
+#pragma unroll
+        for (int t = 0; t < QB; t++) {
+          const uint32_t q = (uint32_t)(qb + t) < cntp ? (uint32_t)(qb + t) : cntp - 1u;
+          bb[t] = grad_row(sp[q0 + q]);
+        }
+#pragma unroll
+        for (int t = 0; t < QB; t++) v[t] = Load4<GradT>::ld_raw(grad + (size_t)bb[t] * D + l * 4);
+#pragma unroll
+        for (int t = 0; t < QB; t++)
+          if ((uint32_t)(qb + t) < cntp) add(acc, cvt(v[t], bb[t]));
+      }
+      *reinterpret_cast<float4*>(gsum + (size_t)(base + q0) * D + l * 4) = acc;
+    }
+    __syncthreads();
+    if (g == 0) {
+      float4 tot = *reinterpret_cast<const float4*>(gsum + (size_t)base * D + l * 4);
+      constexpr int CU = 8;
+      for (uint32_t k = 1u; k < np; k += (uint32_t)CU) {
+        float4 h[CU];
+#pragma unroll
+        for (int t = 0; t < CU; t++) {
+          const uint32_t kk = k + (uint32_t)t < np ? k + (uint32_t)t : k;
+          h[t] = *reinterpret_cast<const float4*>(
+              gsum + (size_t)(base + kk * (uint32_t)kColdPiece) * D + l * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < CU; t++)
+          if (k + (uint32_t)t < np) add(tot, h[t]);
+      }
+      apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
+      if (l == 0) cb.cnt[row] = 0u;
+    }
+  }
+  __syncthreads();  // (the long runs' LDS lists are no longer read)
+
   // ---- rows met once ---------------------------------------------------------------------------
   const uint32_t n1 = (parts & 1u) ? cb.counts[kCcSs + 1] : 0u;
   for (uint32_t i0 = (blockIdx.x * (uint32_t)GPB + (uint32_t)g) * (uint32_t)NS1; i0 < n1;
@@ -1886,99 +1993,152 @@ __global__ void __launch_bounds__(kBlock)
     if constexpr (kSgd) pend_flush();
   }
 
-  // ---- long runs: one workgroup each --------------------------------------------------------------
-  const uint32_t n3 = (parts & 4u) ? cb.counts[kCcPl + 1] : 0u;
-  for (uint32_t ir = blockIdx.x; ir < n3; ir += gridDim.x) {
-    const uint4 e = cb.longs[ir];
-    const uint32_t row = e.x, base = e.y, c = e.z;
-    __syncthreads();  // (LDS of the part above / of the previous run is no longer read)
-    const uint32_t* sp;  // the run's positions, ascending
-    if (c <= (uint32_t)kColdLds) {
-      uint32_t N = 64u;
-      while (N < c) N <<= 1;
-      for (uint32_t q = threadIdx.x; q < N; q += (uint32_t)kBlock)
-        lds[q] = q < c ? cb.plist[base + q] : kColdNone;
-      __syncthreads();
-      for (uint32_t k = 2u; k <= N; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
-          for (uint32_t t = threadIdx.x; t < (N >> 1); t += (uint32_t)kBlock) {
-            const uint32_t lo = ((t / j) * (j << 1)) + (t % j), hi = lo + j;
-            const bool up = (lo & k) == 0u;
-            const uint32_t a = lds[lo], b = lds[hi];
-            if ((a > b) == up) {
-              lds[lo] = b;
-              lds[hi] = a;
-            }
-          }
-          __syncthreads();
-        }
-      }
-      sp = lds;
-    } else {
-      // longer than the LDS list: the batch's rows are walked in order and the positions of this
-      // row written back over the run's (unordered) entries as they come
-      uint32_t filled = 0u;
-      for (uint32_t q0 = 0u; q0 < cg.n; q0 += (uint32_t)(kBlock * 4)) {
-        const uint32_t p = q0 + threadIdx.x * 4u;
-        uint32_t m = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (p + (uint32_t)r < cg.n && value_index[p + (uint32_t)r] == (uint64_t)row) m |= 1u << r;
-        uint32_t tot;
-        uint32_t ex = block_exclusive_scan<uint32_t, kBlock>((uint32_t)__popc(m), scan_smem, &tot);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if ((m >> r) & 1u) cb.plist[base + filled + ex++] = p + (uint32_t)r;
-        filled += tot;
-      }
-      __syncthreads();
-      sp = cb.plist + base;
-    }
-    // pieces of kColdPiece entries, lane group by lane group; the sums wait in gsum[base + first
-    // entry] (rows of gsum the hot rows' pool cannot reach: cold entries + hot partials <= n)
-    const uint32_t np = (c + (uint32_t)kColdPiece - 1u) / (uint32_t)kColdPiece;
-    for (uint32_t k = (uint32_t)g; k < np; k += (uint32_t)GPB) {
-      const uint32_t q0 = k * (uint32_t)kColdPiece;
-      const uint32_t cntp = c - q0 < (uint32_t)kColdPiece ? c - q0 : (uint32_t)kColdPiece;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int qb = 0; qb < kColdPiece; qb += QB) {
-        if ((uint32_t)qb >= cntp) break;
-        Raw v[QB];
-        uint32_t bb[QB];
-#pragma unroll
-        for (int t = 0; t < QB; t++) {
-          const uint32_t q = (uint32_t)(qb + t) < cntp ? (uint32_t)(qb + t) : cntp - 1u;
-          bb[t] = grad_row(sp[q0 + q]);
-        }
-#pragma unroll
-        for (int t = 0; t < QB; t++) v[t] = Load4<GradT>::ld_raw(grad + (size_t)bb[t] * D + l * 4);
-#pragma unroll
-        for (int t = 0; t < QB; t++)
-          if ((uint32_t)(qb + t) < cntp) add(acc, cvt(v[t], bb[t]));
-      }
-      *reinterpret_cast<float4*>(gsum + (size_t)(base + q0) * D + l * 4) = acc;
-    }
-    __syncthreads();
-    if (g == 0) {
-      float4 tot = *reinterpret_cast<const float4*>(gsum + (size_t)base * D + l * 4);
-      constexpr int CU = 8;
-      for (uint32_t k = 1u; k < np; k += (uint32_t)CU) {
-        float4 h[CU];
-#pragma unroll
-        for (int t = 0; t < CU; t++) {
-          const uint32_t kk = k + (uint32_t)t < np ? k + (uint32_t)t : k;
-          h[t] = *reinterpret_cast<const float4*>(
-              gsum + (size_t)(base + kk * (uint32_t)kColdPiece) * D + l * 4);
-        }
-#pragma unroll
-        for (int t = 0; t < CU; t++)
-          if (k + (uint32_t)t < np) add(tot, h[t]);
-      }
-      apply_row_vec4<LPR>(o, (uint64_t)row, l, tot, table, state0, state1, prev_time);
-      if (l == 0) cb.cnt[row] = 0u;
-    }
+}
+
+// HCTR_SORT=rocprim selects the library's one-sweep sort (A/B measurements); default: radix_sort.hip
+inline bool use_library_sort() {
+  static const bool v = [] {
+    const char* e = getenv("HCTR_SORT");
+    return e != nullptr && e[0] == 'r';
+  }();
+  return v;
+}
+
+// What the hot / cold kernels of one batch share: geometry, buffers, counter sets.  Built once per
+// batch -- by SparseUpdater::prework() right after the index stage (the grouping work needs the
+// rows only, not the gradients: hot_sort_kernel and the cold rows' count / base / scatter then run
+// on side streams under the dense tower) or by the update itself.
+struct PrePlan {
+  bool valid = false;  // the grouping kernels of (vi, n, buckets) are enqueued; the reduces are not
+  const uint64_t* vi = nullptr;
+  size_t n = 0, buckets = 0;
+  size_t n_chunks = 0;
+  int lpr = 0;
+  HotGeom hg;
+  HotBufs hb;
+  ColdGeom cg;
+  ColdBufs cb;
+  hipEvent_t ev_hot = nullptr, ev_cold = nullptr;
+};
+
+__global__ void __launch_bounds__(kBlock) cold_clear_kernel(ColdBufs cb) {
+  const uint32_t nd = cb.counts[kCcRows];
+  for (uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x; i < nd;
+       i += gridDim.x * (uint32_t)kBlock)
+    cb.cnt[cb.dlist[i].x] = 0u;
+}
+
+// everything the path asks of a batch except what only the update knows (gradient alignment,
+// store-only mode)
+inline bool plan_possible(const SparseUpdater& u, size_t buckets, size_t nnz) {
+  const int D = u.D, lpr = D / 4;
+  const bool lpr_ok = D % 4 == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+  const uint32_t G = u.hot_streams;
+  if (!(u.hot_rows > 0 && u.one_hot_flag != nullptr && G > 0 && G <= kHotMaxStreams &&
+        nnz == buckets && nnz >= u.hot_min_n && nnz < 0x7FFFFFF0ull && lpr_ok &&
+        u.scale_row_offset == nullptr))
+    return false;
+  const size_t per_g = ceil_div<size_t>(nnz, (size_t)G);
+  const size_t n_chunks = (size_t)G * ceil_div<size_t>(per_g, (size_t)kHotChunk);
+  const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
+  return n_chunks <= (size_t)u.hot_chunks_max && n_chunks <= (size_t)kHotApplyChunks &&
+         !use_library_sort() && !(ip_env && ip_env[0] == '0');
+}
+
+inline int cold_short_max(int lpr) {
+  switch (lpr) {
+    case 1: return ColdShape<1>::kShortMax;
+    case 2: return ColdShape<2>::kShortMax;
+    case 4: return ColdShape<4>::kShortMax;
+    case 8: return ColdShape<8>::kShortMax;
+    case 16: return ColdShape<16>::kShortMax;
+    case 32: return ColdShape<32>::kShortMax;
+    default: return ColdShape<64>::kShortMax;
   }
+}
+
+inline void plan_build(SparseUpdater& u, PrePlan& pp, size_t buckets, size_t nnz, int combiner,
+                       bool off_is_u32, const uint64_t* vi) {
+  const uint32_t G = u.hot_streams;
+  const size_t per_g = ceil_div<size_t>(nnz, (size_t)G);
+  const size_t cpg = ceil_div<size_t>(per_g, (size_t)kHotChunk);
+  pp.vi = vi;
+  pp.n = nnz;
+  pp.buckets = buckets;
+  pp.n_chunks = (size_t)G * cpg;
+  pp.lpr = u.D / 4;
+  pp.hg.n = (uint32_t)nnz;
+  pp.hg.G = G;
+  pp.hg.cpg = (uint32_t)cpg;
+  pp.hg.rows = u.hot_rows;
+  pp.hg.map_inner = u.map_inner;
+  pp.hg.map_outer = u.map_outer;
+  pp.hg.loc_stride = u.hot_chunks_max;
+  pp.hb.S = u.hot_S;
+  pp.hb.meta = u.hot_meta;
+  pp.hb.tpref = u.hot_tpref;
+  pp.hb.items = u.hot_items;
+  pp.hb.loc_blk = u.hot_loc_blk;
+  pp.hb.joins = u.hot_joins;
+  // counter sets alternate: [0..3] / [4..7]; [8] = pairs the sort kept
+  pp.hb.counts = u.hot_counts + 4 * (u.hot_parity & 1u);
+  pp.hb.counts_next = u.hot_counts + 4 * ((u.hot_parity + 1u) & 1u);
+  pp.hb.loc = u.hot_loc;
+  pp.hb.head = u.hot_head;
+  pp.hb.tail = u.hot_tail;
+  pp.cg.n = (uint32_t)nnz;
+  pp.cg.hot_rows = u.hot_rows;
+  pp.cg.max_vocab = (uint32_t)u.max_vocab;
+  pp.cg.map_inner = u.map_inner;
+  pp.cg.map_outer = u.map_outer;
+  pp.cg.short_max = (uint32_t)cold_short_max(pp.lpr);
+  pp.cg.off_is_u32 = off_is_u32 ? 1 : 0;
+  pp.cg.combiner = combiner;
+  pp.cg.buckets = buckets;
+  pp.cb.cnt = u.cold_cnt;
+  pp.cb.rank = u.cold_rank;
+  pp.cb.plist = u.cold_plist;
+  pp.cb.bkt = u.cold_bkt;
+  pp.cb.dlist = (uint2*)u.cold_dlist;
+  pp.cb.singles = (uint2*)u.cold_singles;
+  pp.cb.segs = (uint4*)u.cold_segs;
+  pp.cb.longs = (uint4*)u.cold_longs;
+  pp.cb.counts = u.cold_counts + kCcWords * (u.hot_parity & 1u);
+  pp.cb.counts_next = u.cold_counts + kCcWords * ((u.hot_parity + 1u) & 1u);
+  u.hot_parity++;
+}
+
+// the grouping kernels of a planned batch: the hot rows' chunk sort on hs, the cold rows' count /
+// base / scatter on cs
+inline int plan_launch_grouping(SparseUpdater& u, PrePlan& pp, const void* ro, hipStream_t hs,
+                                hipStream_t cs) {
+  hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)pp.n_chunks), dim3(kHotBlock), 0, hs, pp.hg,
+                     u.one_hot_flag, pp.vi, pp.hb);
+  HCTR_LAUNCH_CHECK();
+  const unsigned pgrid = (unsigned)ceil_div<size_t>(pp.n, (size_t)(kColdBlock * kColdPer));
+  const unsigned bgrid = (unsigned)grid_for(pp.n, kColdBlock * kColdBasePer, 256);
+  hipLaunchKernelGGL(cold_count_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, pp.cg,
+                     u.one_hot_flag, ro, pp.vi, pp.cb);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cold_base_kernel, dim3(bgrid), dim3(kColdBlock), 0, cs, pp.cg, pp.cb);
+  HCTR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cold_scatter_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, pp.cg,
+                     u.one_hot_flag, pp.vi, pp.cb);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+// a batch whose grouping kernels ran ahead but whose update takes another path (or never comes):
+// the per-row words go back to zero
+inline int plan_discard(SparseUpdater& u, PrePlan& pp, hipStream_t s) {
+  if (!pp.valid) return HCTR_OK;
+  HCTR_HIP(hipStreamWaitEvent(s, pp.ev_hot, 0));
+  HCTR_HIP(hipStreamWaitEvent(s, pp.ev_cold, 0));
+  hipLaunchKernelGGL(cold_clear_kernel, dim3(grid_for(pp.n, kBlock, 1024)), dim3(kBlock), 0, s,
+                     pp.cb);
+  HCTR_LAUNCH_CHECK();
+  pp.valid = false;
+  return HCTR_OK;
 }
 
 // any D: one wavefront per run, lanes stride over the vector
@@ -2125,14 +2285,6 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-// HCTR_SORT=rocprim selects the library's one-sweep sort (A/B measurements); default: radix_sort.hip
-inline bool use_library_sort() {
-  static const bool v = [] {
-    const char* e = getenv("HCTR_SORT");
-    return e != nullptr && e[0] == 'r';
-  }();
-  return v;
-}
 
 template <typename SortK>
 int sort_pairs(void* temp, size_t& temp_bytes, const SortK* kin, SortK* kout, const uint32_t* vin,
@@ -2292,78 +2444,44 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
     int seg_grid_cap = 1 << 20;
     {
       const int lpr = D / 4;
-      const bool lpr_ok = a16 && D % 4 == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
-      const uint32_t G = u.hot_streams;
-      const size_t per_g = G > 0 ? ceil_div<size_t>(nnz, (size_t)G) : 0;
-      const size_t cpg = ceil_div<size_t>(per_g, (size_t)kHotChunk);
-      const size_t n_chunks = (size_t)G * cpg;
-      const char* ip_env = getenv("HCTR_SORT_IN_PLACE");
-      const bool hot = need_sort && u.hot_rows > 0 && u.one_hot_flag != nullptr && G > 0 &&
-                       G <= kHotMaxStreams &&
-                       nnz == buckets && nnz >= u.hot_min_n && nnz < 0xFFFFFFF0ull && lpr_ok &&
-                       u.scale_row_offset == nullptr && direct == nullptr &&
-                       n_chunks <= (size_t)u.hot_chunks_max && n_chunks <= (size_t)kHotApplyChunks &&
-                       !use_library_sort() &&
-                       !(ip_env && ip_env[0] == '0');
+      PrePlan* pp = (PrePlan*)u.pre_plan;
+      const bool hot = need_sort && a16 && direct == nullptr && plan_possible(u, buckets, nnz);
+      // (prework() only ever runs for an updater whose cold rows are counted)
+      const bool pre = hot && pp != nullptr && pp->valid && pp->vi == vi && pp->n == nnz &&
+                       pp->buckets == buckets;
+      if (pp != nullptr && pp->valid && !pre) HCTR_TRY(plan_discard(u, *pp, s));
       if (hot) HCTR_TRY(u.hot_buffers(s));
       if (hot) {
-        HotGeom hg;
-        hg.n = (uint32_t)nnz;
-        hg.G = G;
-        hg.cpg = (uint32_t)cpg;
-        hg.rows = u.hot_rows;
-        hg.map_inner = u.map_inner;
-        hg.map_outer = u.map_outer;
-        hg.loc_stride = u.hot_chunks_max;
-        HotBufs hb;
-        hb.S = u.hot_S;
-        hb.meta = u.hot_meta;
-        hb.tpref = u.hot_tpref;
-        hb.items = u.hot_items;
-        hb.loc_blk = u.hot_loc_blk;
-        hb.joins = u.hot_joins;
-        // counter sets alternate: [0..3] / [4..7]; [8] = pairs the sort kept
-        hb.counts = u.hot_counts + 4 * (u.hot_parity & 1u);
-        hb.counts_next = u.hot_counts + 4 * ((u.hot_parity + 1u) & 1u);
-        u.hot_parity++;
-        hb.loc = u.hot_loc;
-        hb.head = u.hot_head;
-        hb.tail = u.hot_tail;
-        // Two chains side by side: the cold pairs (filtering sort, then the segmented reduce over
-        // what it kept) on the side stream, the hot rows on the caller's; they touch disjoint
-        // rows.  Stage 2 of the profiler = fork .. join, all of the update.
+        pp = (PrePlan*)u.pre_plan;
+        const bool cold = u.cold_count && u.cold_cnt != nullptr;
+        if (!pre) plan_build(u, *pp, buckets, nnz, combiner, sizeof(OffT) == 4, vi);
+        const HotGeom& hg = pp->hg;
+        const HotBufs& hb = pp->hb;
+        const size_t n_chunks = pp->n_chunks;
+        // Two chains side by side: the cold rows (count / base / scatter / reduce -- or, with
+        // HCTR_COLD_COUNT=0, the filtering sort and the segmented reduce over what it kept) on the
+        // side stream, the hot rows on the caller's; they touch disjoint rows.  Stage 2 of the
+        // profiler = fork .. join, all of the update.
         hipStream_t cs = u.hot_serial ? s : u.hot_side;  // the cold chain's stream
         if (u.prof) u.prof->begin(2, s);
         if (cs != s) {
           HCTR_HIP(hipEventRecord(u.ev_fork, s));
           HCTR_HIP(hipStreamWaitEvent(cs, u.ev_fork, 0));
         }
-        const bool cold = u.cold_count && u.cold_cnt != nullptr && nnz < 0x7FFFFFF0ull;
+        if (pre) {  // grouped ahead (prework): the reduces wait for their chain's kernels only
+          HCTR_HIP(hipStreamWaitEvent(s, pp->ev_hot, 0));
+          HCTR_HIP(hipStreamWaitEvent(cs, pp->ev_cold, 0));
+          pp->valid = false;
+        } else if (cold) {
+          HCTR_TRY(plan_launch_grouping(u, *pp, (const void*)ro, s, cs));
+        } else {
+          hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)n_chunks), dim3(kHotBlock), 0, s, hg,
+                             u.one_hot_flag, vi, hb);
+          HCTR_LAUNCH_CHECK();
+        }
         if (cold) {
-          // the cold rows' chain: count, bases, scatter, reduce (no sort)
-          ColdGeom cg;
-          cg.n = (uint32_t)nnz;
-          cg.hot_rows = u.hot_rows;
-          cg.max_vocab = (uint32_t)u.max_vocab;
-          cg.map_inner = u.map_inner;
-          cg.map_outer = u.map_outer;
-          cg.off_is_u32 = sizeof(OffT) == 4 ? 1 : 0;
-          cg.combiner = combiner;
-          cg.buckets = buckets;
-          ColdBufs cb;
-          cb.cnt = u.cold_cnt;
-          cb.rank = u.cold_rank;
-          cb.plist = u.cold_plist;
-          cb.bkt = u.cold_bkt;
-          cb.dlist = (uint2*)u.cold_dlist;
-          cb.singles = (uint2*)u.cold_singles;
-          cb.segs = (uint4*)u.cold_segs;
-          cb.longs = (uint4*)u.cold_longs;
-          cb.counts = u.cold_counts + kCcWords * ((u.hot_parity + 1u) & 1u);  // (hot_parity is already
-          cb.counts_next = u.cold_counts + kCcWords * (u.hot_parity & 1u);    //  this update's + 1)
-          const unsigned pgrid = (unsigned)ceil_div<size_t>(nnz, (size_t)(kColdBlock * kColdPer));
-          const unsigned bgrid =
-              (unsigned)grid_for(nnz, kColdBlock * kColdBasePer, 256);
+          const ColdGeom& cg = pp->cg;
+          const ColdBufs& cb = pp->cb;
           // HCTR_COLD_SPLIT=1 (measurements): the three parts of the reduce as three launches
           const char* sp_env = getenv("HCTR_COLD_SPLIT");
           const bool split = sp_env != nullptr && sp_env[0] == '1';
@@ -2372,15 +2490,6 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
           const bool sgd = o.optimizer == HCTR_OPT_SGD;
 #define HCTR_COLD_CASE(LPR_)                                                                      \
   {                                                                                               \
-    cg.short_max = (uint32_t)ColdShape<LPR_>::kShortMax;                                          \
-    hipLaunchKernelGGL(cold_count_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, cg,               \
-                       u.one_hot_flag, (const void*)ro, vi, cb);                                  \
-    HCTR_LAUNCH_CHECK();                                                                          \
-    hipLaunchKernelGGL(cold_base_kernel, dim3(bgrid), dim3(kColdBlock), 0, cs, cg, cb);           \
-    HCTR_LAUNCH_CHECK();                                                                          \
-    hipLaunchKernelGGL(cold_scatter_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, cg,             \
-                       u.one_hot_flag, vi, cb);                                                   \
-    HCTR_LAUNCH_CHECK();                                                                          \
     for (uint32_t part = split ? 1u : 7u; part <= 7u; part = split && part < 4u ? part << 1 : 8u) { \
       if (sgd)                                                                                    \
         hipLaunchKernelGGL((cold_reduce_kernel<LPR_, GradT, true>), dim3(cold_grid), dim3(kBlock), \
@@ -2413,17 +2522,12 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
         const size_t items_max = nnz / kHotTile + n_chunks;
         // the hot rows' reduce is a grid-stride loop over a bounded number of workgroups: a kernel
         // that queues one workgroup per tile fills every wave slot of the device and the other
-        // chain's sort only trickles in (measured: its scatter 21 -> 96 us; 768 workgroups: 60 us).
-        // The cold chain's reduce keeps one workgroup per 8 tiles: with uniform keys it IS the
-        // update (2 GB), and a bounded grid sharing the chip with the dense tower's GEMMs was
-        // measured at + 1.6 ms per step (HCTR_SEG_GRID bounds it for measurements)
+        // chain only trickles in (measured, round 4: its scatter 21 -> 96 us; 768 workgroups: 60).
+        // HCTR_SEG_GRID bounds the sorting path's segmented reduce for measurements.
         const char* hg_env = getenv("HCTR_HOT_GRID");
         const char* sg_env = getenv("HCTR_SEG_GRID");
         const int hot_grid = hg_env ? atoi(hg_env) : 768;
         if (sg_env) seg_grid_cap = atoi(sg_env);
-        hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)n_chunks), dim3(kHotBlock), 0, s, hg,
-                           u.one_hot_flag, vi, hb);
-        HCTR_LAUNCH_CHECK();
 #define HCTR_HOT_CASE(LPR_)                                                                       \
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
@@ -2734,6 +2838,12 @@ int SparseUpdater::hot_buffers(hipStream_t s) {
     HCTR_HIP(hipMalloc(&cold_counts, 2 * kCcWords * sizeof(uint32_t)));
     HCTR_HIP(hipMemsetAsync(cold_counts, 0, 2 * kCcWords * sizeof(uint32_t), s));
   }
+  {
+    PrePlan* pp = new PrePlan();
+    HCTR_HIP(hipEventCreateWithFlags(&pp->ev_hot, hipEventDisableTiming));
+    HCTR_HIP(hipEventCreateWithFlags(&pp->ev_cold, hipEventDisableTiming));
+    pre_plan = pp;
+  }
   // (last: its presence is what marks the set complete)
   const size_t loc_bytes = (size_t)hot_rows * hot_chunks_max * sizeof(uint16_t);
   HCTR_HIP(hipMalloc(&hot_loc, loc_bytes));
@@ -2752,6 +2862,13 @@ int SparseUpdater::destroy() {
                   cold_dlist,   cold_singles,  cold_segs,    cold_longs,    cold_counts};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (pre_plan) {
+    PrePlan* pp = (PrePlan*)pre_plan;
+    if (pp->ev_hot) (void)hipEventDestroy(pp->ev_hot);
+    if (pp->ev_cold) (void)hipEventDestroy(pp->ev_cold);
+    delete pp;
+    pre_plan = nullptr;
+  }
   if (hot_side) {
     (void)hipStreamSynchronize(hot_side);
     (void)hipStreamDestroy(hot_side);
@@ -2798,6 +2915,27 @@ int SparseUpdater::presort(size_t buckets, size_t n, const void* row_offset, int
   early_n = n;
   early_vi = value_index;
   early_buckets = buckets;
+  return HCTR_OK;
+}
+
+int SparseUpdater::prework(size_t buckets, size_t nnz, int combiner, const void* row_offset,
+                            int key_type, const uint64_t* value_index, hipStream_t s) {
+  PrePlan* pp = (PrePlan*)pre_plan;
+  if (pp == nullptr || !cold_count || cold_cnt == nullptr || hot_loc == nullptr || !side ||
+      !hot_side || hot_serial)
+    return HCTR_OK;
+  if (pp->valid) HCTR_TRY(plan_discard(*this, *pp, s));  // (a batch that was never updated)
+  if (buckets == 0 || nnz == 0 || nnz > max_nnz || !plan_possible(*this, buckets, nnz))
+    return HCTR_OK;
+  plan_build(*this, *pp, buckets, nnz, combiner, key_type == HCTR_KEY_U32, value_index);
+  // both chains behind what s has enqueued so far (the index stage), next to what follows on it
+  HCTR_HIP(hipEventRecord(ev_fork, s));
+  HCTR_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+  HCTR_HIP(hipStreamWaitEvent(hot_side, ev_fork, 0));
+  HCTR_TRY(plan_launch_grouping(*this, *pp, row_offset, side, hot_side));
+  HCTR_HIP(hipEventRecord(pp->ev_hot, side));
+  HCTR_HIP(hipEventRecord(pp->ev_cold, hot_side));
+  pp->valid = true;
   return HCTR_OK;
 }
 
