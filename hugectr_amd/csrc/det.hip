@@ -369,6 +369,7 @@ struct hctr_det {
   std::vector<unsigned char> up_desc;
   std::vector<uint32_t> up_seg_class;
   std::vector<uint64_t> up_seg_off;
+  hipStream_t up_stream = nullptr;  // the stream those copies were queued on
 };
 
 namespace {
@@ -699,6 +700,14 @@ static int det_upload_spaces(hctr_det* h, const std::vector<Range>& rs,
   auto same = [](const auto& a, const auto& b) {
     return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
   };
+  // (the shadows say what the device holds in the order of ONE stream: a call on another stream
+  //  could run ahead of the copies still queued on the first -- it uploads again)
+  if (h->up_stream != s) {
+    h->up_desc.clear();
+    h->up_seg_class.clear();
+    h->up_seg_off.clear();
+    h->up_stream = s;
+  }
   std::vector<unsigned char> dbytes(ncls * sizeof(DetClassDesc));
   memcpy(dbytes.data(), desc.data(), dbytes.size());  // (padding bytes of the struct: value-initialised above)
   // (pageable sources: the runtime has consumed them when these calls return)

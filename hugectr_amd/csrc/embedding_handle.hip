@@ -288,6 +288,11 @@ struct hctr_embedding {
   // the index stage, on the updater's side streams, under the gather and the dense tower
   // (HCTR_PREWORK=0: inside the update)
   bool prework_enabled = false;
+  // Ahead only pays while most keys of a batch are known (measured, MI355X: Criteo-1TB shape with
+  // 4 % new keys a batch: step - 16 us; uniform keys over 416 M rows, every key new: the count's
+  // 1.7 M device atomics next to the gather cost the step + 78 us): decided per batch from the
+  // row counter the index stage posts -- rows handed out between the last two posts seen
+  uint64_t post_seq = 0, post_rows = 0, post_new = ~0ull;  // post_new: new rows of the last posted batch
   size_t cur_buckets = 0;
   size_t cur_nnz_bound = 0;
   size_t eval_nnz = 0;  // keys of the last evaluation batch (host count)
@@ -302,6 +307,8 @@ struct hctr_embedding {
     return p.embedding_type == HCTR_EMB_DISTRIBUTED_SLOT_HASH && p.world > 1 && p.combiner == 1;
   }
 };
+
+static int report_ht_flags(uint32_t f);
 
 namespace {
 
@@ -377,6 +384,12 @@ void refresh_row_bound(hctr_embedding* e) {
     e->upd.row_bound = rows + (e->cum_total - e->cum_keys[q % hctr_embedding::kSeqRing]);
   else
     e->upd.row_bound = 0;  // unknown: the sort takes the full key width
+  if (q > e->post_seq) {  // a newer post: new rows per batch since the last one seen
+    if (e->post_seq >= e->min_valid_seq && rows >= e->post_rows)
+      e->post_new = (rows - e->post_rows) / (q - e->post_seq);
+    e->post_seq = q;
+    e->post_rows = rows;
+  }
 }
 
 // returns (via *ro_out / *keys_out) the CSR this rank resolves
@@ -451,6 +464,11 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   // offsets (world == 1), its finish kernel presets the next batch's one-hot flag and posts the
   // row counter + error flags to pinned host words
   const bool fused_train = is_train != 0 && nnz > 0;
+  // A finish kernel that timed out at its grid barrier (error bit 4) left this table's
+  // first-occurrence masks and region counts half written: a later inserting batch would rank its
+  // keys against them.  Sticky: no further training batch until the caller has cleared the table
+  // (hctr_emb_init_params / load), which also clears the flag.
+  if (is_train && (*(volatile uint32_t*)e->h_err & 4u) != 0u) return report_ht_flags(4u);
   uint32_t* one_hot = bb.one_hot;
   uint32_t* one_hot_next = nullptr;
   if (fused_train) {
@@ -521,7 +539,8 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     e->prof.end(1, s);
     // (the switch is read per call: bench.py times the update with and without the work ahead)
     const char* pw_env = getenv("HCTR_PREWORK");
-    if (is_train && !ahead && e->p.world == 1 && (pw_env ? pw_env[0] != '0' : e->prework_enabled) &&
+    const bool pw_auto = e->prework_enabled && e->post_new != ~0ull && e->post_new * 4 < nnz;
+    if (is_train && !ahead && e->p.world == 1 && (pw_env ? pw_env[0] != '0' : pw_auto) &&
         !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
       e->upd.one_hot_flag = batch_one_hot;
       e->upd.scale_row_offset = nullptr;

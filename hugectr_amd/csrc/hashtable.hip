@@ -23,6 +23,9 @@
 //                    the caller's one-hot flag of the next batch (no copy / memset launches).
 #include "hashtable.h"
 
+#include <map>
+#include <mutex>
+
 #include <cstdlib>
 
 #include "block_prims.h"
@@ -859,18 +862,32 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   // few positions: fewer workgroups (every one of them takes part in the barrier), and never more
   // than the device can hold at once (a CPX partition or a CU-masked device has far fewer than
   // 256 CUs: a grid that is not resident as a whole could only time out at its barrier)
-  static const size_t resident = [] {
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_finish_kernel<0>, kFinBlock, 0) !=
-            hipSuccess ||
-        hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        per_cu < 1 || cus < 1) {
+  // (per device: a process may drive partitions / CU masks of different sizes)
+  size_t resident = (size_t)kHtFinishBlocks;
+  {
+    static std::mutex mu;
+    static std::map<int, size_t> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = per_device.find(dev);
+      if (it == per_device.end()) {
+        int per_cu = 0, cus = 0;
+        size_t r = (size_t)kHtFinishBlocks;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ht_finish_kernel<0>, kFinBlock,
+                                                         0) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            per_cu >= 1 && cus >= 1)
+          r = (size_t)per_cu * (size_t)cus;
+        else
+          (void)hipGetLastError();
+        it = per_device.emplace(dev, r).first;
+      }
+      resident = it->second;
+    } else {
       (void)hipGetLastError();
-      return (size_t)kHtFinishBlocks;
     }
-    return (size_t)per_cu * (size_t)cus;
-  }();
+  }
   // (HCTR_HT_FINISH_BLOCKS: the cap, for measurements; at most kHtFinishBlocksMax)
   static const size_t cap = [] {
     const char* e = getenv("HCTR_HT_FINISH_BLOCKS");

@@ -1351,13 +1351,17 @@ class Model:
                     got["g"] = g  # (alive until the join: the allocator cannot hand it out before)
 
                 def finish():
+                    ran = "g" in got
                     if tail and name in self._idx_ahead:
                         got["keep"] = got.pop("g", None)  # (until the next step has joined)
                         self._upd_keep = got
                     else:
                         got.clear()
                         torch.cuda.current_stream().wait_stream(side)
-                    self._upd_timing.append((True, ev))
+                    # (events of a step whose gradient hook never fired -- the embedding's output
+                    #  does not reach the loss -- were never recorded: not a timing sample)
+                    if ran:
+                        self._upd_timing.append((True, ev))
                 tensors[name] = _GatherEmb(h, train, on_grad,
                                            None if tail else launch_ahead)
                 after.append(finish)
