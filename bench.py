@@ -426,17 +426,18 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     prof_ahead = None
     if world == 1 and inline > 0:
         os.environ["HCTR_UPDATE_OVERLAP"] = "0"
-        # (a) as the product runs it: the update's grouping kernels (hot rows' chunk sort, cold
-        # rows' count / base / scatter) right behind the index stage on side streams, the update
-        # stage itself = the two reduces + join / apply
+        # (a) HCTR_PREWORK=1: the update's grouping kernels (hot rows' chunk sort, cold rows'
+        # count / base / scatter) right behind the index stage on side streams, the update stage
+        # itself = the two reduces + join / apply
+        pw_prev = os.environ.get("HCTR_PREWORK")
+        os.environ["HCTR_PREWORK"] = "1"
         emb.profiling(True)
         for _ in range(inline // 2):
             m.train()
         sync()
         prof_ahead = emb.profile()
-        # (b) everything of the update inside the update stage (HCTR_PREWORK=0): the stage time
-        # `roofline_update` is computed from
-        pw_prev = os.environ.get("HCTR_PREWORK")
+        # (b) everything of the update inside the update stage (HCTR_PREWORK=0, the default): the
+        # stage time `roofline_update` is computed from
         os.environ["HCTR_PREWORK"] = "0"
         emb.profiling(True)
         for _ in range(inline - inline // 2):
@@ -635,8 +636,9 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
                             "count / base / scatter, then singles + sorted short runs + long runs "
                             "with the optimizer folded in); `us` = fork .. join of the two chains "
                             "with ALL of it inside the update stage (HCTR_PREWORK=0); "
-                            "`us_grouping_ahead` = the same stage as the product runs it, the "
-                            "grouping kernels started behind the index stage on side streams",
+                            "`us_grouping_ahead` = the same stage under HCTR_PREWORK=1, the "
+                            "grouping kernels started behind the index stage on side streams "
+                            "(step time within noise of the default, so off by default)",
                             "us_grouping_ahead": (upd_ahead_s * 1e6) if upd_ahead_s else None,
                             "frac_grouping_ahead": (upd_bytes / upd_ahead_s / 1e9 / HBM_PEAK_GBPS)
                             if upd_ahead_s else None,

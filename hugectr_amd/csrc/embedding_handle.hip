@@ -539,8 +539,12 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     e->prof.end(1, s);
     // (the switch is read per call: bench.py times the update with and without the work ahead)
     const char* pw_env = getenv("HCTR_PREWORK");
-    const bool pw_auto = e->prework_enabled && e->post_new != ~0ull && e->post_new * 4 < nnz;
-    if (is_train && !ahead && e->p.world == 1 && (pw_env ? pw_env[0] != '0' : pw_auto) &&
+    const bool pw_on = pw_env ? pw_env[0] != '0' : e->prework_enabled;
+    // (a batch of mostly unseen keys keeps the work inside the update: its count is one device
+    //  atomic per position, next to the gather that is the slower place -- "2": regardless)
+    const bool pw_few_new = (pw_env && pw_env[0] == '2') ||
+                            (e->post_new != ~0ull && e->post_new * 4 < nnz);
+    if (is_train && !ahead && e->p.world == 1 && pw_on && pw_few_new &&
         !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
       e->upd.one_hot_flag = batch_one_hot;
       e->upd.scale_row_offset = nullptr;
@@ -724,7 +728,10 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   e->upd.hot_streams = (uint32_t)e->buckets_per_sample();
   e->presort_enabled = p.world > 1;
   if (const char* ps = getenv("HCTR_PRESORT")) e->presort_enabled = ps[0] != '0';
-  e->prework_enabled = p.world == 1;
+  // measured (MI355X, Criteo-1TB shape, nine runs on one box): the step with the grouping ahead is
+  // within the run-to-run noise of the step without (2.265 / 2.286 vs 2.233 ms) -- off unless asked
+  // for (HCTR_PREWORK=1, then still decided per batch from the posted row counter)
+  e->prework_enabled = false;
   e->upd.prof = &e->prof;
   e->opt.optimizer = p.optimizer;
   e->opt.update_type = p.update_type;
