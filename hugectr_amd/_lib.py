@@ -198,7 +198,9 @@ _SIGNATURES = {
     "hctr_sgd_shadow": (c_int, [c_size_t, c_float, c_float, _P, _P, _P, c_int, _P]),
     "hctr_bce_loss_workspace_bytes": (c_size_t, []),
     "hctr_bce_loss": (c_int, [c_size_t, _P, _P, c_float, _P, _P, _P, c_int, _P]),
-    "hctr_cross_v2_epilogue": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "hctr_convert_transpose16": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, c_int, _P]),
+    "hctr_gemm_nt16": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P, _P,
+                               _P, _P, c_int, _P]),
     "hctr_cross_v2_bwd_step_workspace_bytes": (c_size_t, [c_size_t, c_int]),
     "hctr_cross_v2_bwd_step": (c_int, [c_size_t, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
 }

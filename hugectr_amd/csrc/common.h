@@ -51,6 +51,27 @@ constexpr uint64_t kInvalidIndex = ~0ull;  // std::numeric_limits<size_t>::max()
 #define HCTR_DYN_LDS16(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #endif
 
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4: no VGPR round
+// trip); lane l's bytes land at lds_wave_base + 16 l, lds_wave_base must be wave-uniform.  A macro
+// for the same reason as HCTR_DYN_LDS: the host interpreter of tests/emu supplies its own.
+#ifndef HCTR_GLOBAL_LOAD_LDS16
+#define HCTR_GLOBAL_LOAD_LDS16(gptr, lds_wave_base)                                       \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                   (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+#endif
+
+// counted wait on this wave's vector-memory queue + a barrier that does not drain it (a plain
+// __syncthreads() waits for every outstanding LDS DMA: a ring of more than two staging buffers
+// would never have a tile in flight across it).  Macros: the host interpreter has no queues.
+#ifndef HCTR_WAIT_VMCNT
+#define HCTR_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define HCTR_RAW_BARRIER()                                  \
+  do {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+  } while (0)
+#endif
+
 template <typename T>
 static inline T ceil_div(T a, T b) {
   return (a + b - 1) / b;

@@ -966,19 +966,6 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-__global__ void __launch_bounds__(kBlock)
-    cross_v2_epilogue_kernel(size_t n, int w, const float* __restrict__ x0,
-                             const float* __restrict__ xl, const float* __restrict__ hmat,
-                             const float* __restrict__ bias, float* __restrict__ hidden_out,
-                             float* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-       i += (size_t)gridDim.x * kBlock) {
-    const float hv = hmat[i] + bias[i % w];
-    if (hidden_out) hidden_out[i] = hv;
-    out[i] = hv * x0[i] + xl[i];
-  }
-}
-
 // ================================================================================================
 // Fused ReLU backward + bias gradient for the MLP layers around the path:
 //   dz[b][n] = dy[b][n] * (y[b][n] > 0),   db[n] = sum_b dz[b][n]
@@ -2371,19 +2358,6 @@ int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* d
   HCTR_LAUNCH_CHECK();
   hipLaunchKernelGGL(skinny_fc_finish_kernel, dim3(ceil_div<int>(n * (kSkinnyK + 1), 64)),
                      dim3(1024), 0, s, blocks, k, n, workspace, dw, db);
-  HCTR_LAUNCH_CHECK();
-  return HCTR_OK;
-}
-
-int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,
-                           const float* h, const float* bias, float* hidden_out, float* out,
-                           hctr_stream_t stream) {
-  HCTR_REQUIRE(width >= 1, "shape");
-  if (batch == 0) return HCTR_OK;
-  HCTR_REQUIRE(x0 && xl && h && bias && out, "null pointer");
-  const size_t n = batch * (size_t)width;
-  hipLaunchKernelGGL(cross_v2_epilogue_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0,
-                     as_stream(stream), n, width, x0, xl, h, bias, hidden_out, out);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }

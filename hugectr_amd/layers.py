@@ -5,6 +5,8 @@ MultiCrossLayer:  R/HugeCTR/include/layers/multi_cross_layer.hpp:104-177
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -182,6 +184,28 @@ def _mm_f32(a, b):
     return torch.mm(a, b)
 
 
+def _own_gemm_ok(x, n, k):
+    """the shapes hctr_gemm_nt16 takes (cross_gemm.hip): 16-bit operands on the device, N a
+    multiple of 128, K of 64; HCTR_CROSS_GEMM=0 keeps the library GEMMs (measurements)"""
+    return (x.is_cuda and x.dtype in _DT16 and n % 128 == 0 and k % 64 == 0 and
+            os.environ.get("HCTR_CROSS_GEMM", "1") != "0")
+
+
+def gemm_nt16(a, bt, epilogue=0, bias=None, x0=None, xl=None):
+    """a [M, K] @ bt [N, K]^T on the library's own matrix-core kernel (hctr_gemm_nt16); epilogue 1
+    returns (x0 * (a @ bt^T + bias) + xl, a @ bt^T + bias), epilogue 2 returns a @ bt^T + xl"""
+    M, K = a.shape
+    N = bt.shape[0]
+    c = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    h = torch.empty_like(c) if epilogue == 1 else None
+    check(lib.hctr_gemm_nt16(M, N, K, ptr(a), a.stride(0), ptr(bt), bt.stride(0), ptr(c), N, epilogue,
+                             ptr(bias) if bias is not None else None,
+                             ptr(x0) if x0 is not None else None,
+                             ptr(xl) if xl is not None else None,
+                             ptr(h) if h is not None else None, _DT16[a.dtype], stream_ptr()))
+    return (c, h) if epilogue == 1 else c
+
+
 class _CrossV2Fn(torch.autograd.Function):
     """DCN-v2 cross layers, x_{l+1} = x0 * (x_l U_l V_l + b_l) + x_l, in the activations' own type
     T (fp16 / bf16 under use_mixed_precision: the GEMMs run on the matrix cores; fp32 otherwise)
@@ -196,13 +220,33 @@ class _CrossV2Fn(torch.autograd.Function):
     def forward(ctx, x0, U, V, b):
         T = x0.dtype
         L = U.shape[0]
-        Ut, Vt, bt = U.to(T), V.to(T), b.to(T)
         xs, ps, hs = [x0], [], []
         xl = x0
+        w, p = U.shape[1], U.shape[2]
+        own = _own_gemm_ok(x0, p, w) and _own_gemm_ok(x0, w, p)
+        bt = b.to(T)
+        if own:
+            # the 16-bit copies of the master weights as they lie (backward) and transposed (the
+            # forward's operands are read K-contiguous), one pass per tensor
+            Ut, UtT = torch.empty_like(U, dtype=T), torch.empty((L, p, w), dtype=T, device=U.device)
+            Vt, VtT = torch.empty_like(V, dtype=T), torch.empty((L, w, p), dtype=T, device=V.device)
+            Uc, Vc = U.contiguous(), V.contiguous()
+            check(lib.hctr_convert_transpose16(L, w, p, ptr(Uc), ptr(Ut), ptr(UtT), _DT16[T],
+                                               stream_ptr()))
+            check(lib.hctr_convert_transpose16(L, p, w, ptr(Vc), ptr(Vt), ptr(VtT), _DT16[T],
+                                               stream_ptr()))
+        else:
+            Ut, Vt = U.to(T), V.to(T)
         for l in range(L):
-            pl = xl @ Ut[l]
-            h = torch.addmm(bt[l], pl, Vt[l])
-            xl = torch.addcmul(xl, x0, h)
+            if own:
+                # two launches per layer: P = X_l U; then bias + X_0 .* H + X_l in the second
+                # GEMM's epilogue (the reference's fused epilogues, multi_cross_layer.cu:640-700)
+                pl = gemm_nt16(xl, UtT[l])
+                xl, h = gemm_nt16(pl, VtT[l], 1, bt[l], x0, xl)
+            else:
+                pl = xl @ Ut[l]
+                h = torch.addmm(bt[l], pl, Vt[l])
+                xl = torch.addcmul(xl, x0, h)
             ps.append(pl)
             hs.append(h)
             xs.append(xl)
@@ -241,7 +285,8 @@ class _CrossV2Fn(torch.autograd.Function):
             else:
                 s0 = dy * x0
                 acc.addcmul_(dy, hs[l])
-            s1 = s0 @ Vt[l].t()
+            own1 = _own_gemm_ok(s0, Vt.shape[1], Vt.shape[2])
+            s1 = gemm_nt16(s0, Vt[l]) if own1 else s0 @ Vt[l].t()
             # weight gradients reduce over K = batch into a small tile set (512 x 3456: 27 tiles of
             # 256 x 256 on 256 CUs): split-K through batched GEMMs, as the MLP's are (dense.py)
             if x0.is_cuda and x0.dtype in (torch.float16, torch.bfloat16):
@@ -252,7 +297,10 @@ class _CrossV2Fn(torch.autograd.Function):
                 dU[l] = _mm_f32(xs[l].t(), s1)
             if not fused:
                 db[l] = s0.sum(0, dtype=wdt)
-            dy = torch.addmm(dy, s1, Ut[l].t())
+            if _own_gemm_ok(s1, Ut.shape[1], Ut.shape[2]):
+                dy = gemm_nt16(s1, Ut[l], 2, xl=dy)  # (the residual in the GEMM's epilogue)
+            else:
+                dy = torch.addmm(dy, s1, Ut[l].t())
         return acc + dy, dU, dV, db
 
 

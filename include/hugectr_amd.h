@@ -634,11 +634,30 @@ size_t hctr_skinny_fc_bwd_workspace_bytes(int n);
 int hctr_skinny_fc_bwd(size_t batch, int k, int n, const float* x, const void* dy, const void* y,
                        float* dw, float* db, float* workspace, int dtype, hctr_stream_t stream);
 
-/* DCN v2 fused epilogue: out = x0 * (h + b) + x_l  (fused_matrix_elementwise_dot_add,
- * multi_cross_layer.cu:426-463); the two GEMMs stay in the caller's BLAS. */
-int hctr_cross_v2_epilogue(size_t batch, int width, const float* x0, const float* xl,
-                           const float* h, const float* bias, float* hidden_out, float* out,
-                           hctr_stream_t stream);
+/* The GEMMs of MultiCrossLayer v2 with the elementwise work the reference fuses into its GEMM
+ * epilogues (MultiCrossForwardFunctorv2 / MultiCrossBackwardFunctorv2,
+ * R/HugeCTR/src/layers/multi_cross_layer.cu:582-700, 732-812; fused_mul_fma3 :391-424), as this
+ * library's own matrix-core kernel (hugectr_amd/csrc/cross_gemm.hip):
+ *   c[m][n] = epilogue( sum_k a[m][k] * bt[n][k] ),  a [m][lda], bt [n][ldb] (both K-contiguous),
+ *   c [m][ldc]; 16-bit operands of `dtype` (hctr_emb_dtype_t F16 or BF16), fp32 accumulation.
+ * epilogue 0: c = (T)acc;
+ *          1: h_out = (T)(acc + bias[n]); c = (T)(xl + x0 * h_out)   -- the forward's second GEMM:
+ *             bias + X_0 .* H + X_l in one pass, H kept for the backward (bias 16-bit [n]; x0, xl,
+ *             h_out [m][ldc]);
+ *          2: c = (T)(acc + xl)                                       -- the backward's residual
+ *             (dY_{l-1} = S1 U^T + dY_l).
+ * n % 128 == 0, k % 64 == 0, leading dimensions multiples of 8 elements, 16-byte aligned buffers;
+ * any m. */
+int hctr_gemm_nt16(size_t m, int n, int k, const void* a, int lda, const void* bt, int ldb, void* c,
+                   int ldc, int epilogue, const void* bias, const void* x0, const void* xl,
+                   void* h_out, int dtype, hctr_stream_t stream);
+/* fp32 master weights [batch][rows][cols] -> their 16-bit copy dst [batch][rows][cols] and its
+ * transpose dst_t [batch][cols][rows] in one pass (either may be NULL): the operands of
+ * hctr_gemm_nt16 for MultiCrossLayer v2 (the reference converts its master weights per step too,
+ * R/HugeCTR/src/layers/multi_cross_layer.cu:582-600; the transpose exists only because both GEMM
+ * operands are read K-contiguous here). */
+int hctr_convert_transpose16(size_t batch, int rows, int cols, const float* src, void* dst,
+                             void* dst_t, int dtype, hctr_stream_t stream);
 /* One layer's elementwise step of MultiCrossBackwardFunctorv2 in the activations' 16-bit type
  * (fused_mul_fma3, R/HugeCTR/src/layers/multi_cross_layer.cu:391-424 / 127-165, + the bias gradient
  * the reference takes in the dV GEMM's epilogue, :770-776): s0 = dy .* x0, acc = (first ? 0 : acc)

@@ -148,6 +148,11 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F,
   *n = 2;
   return hipSuccess;
 }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F>
+static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) {
+  return hipSuccess;
+}
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
 static inline hipError_t hipGetDevice(int* d) {
   *d = 0;
@@ -336,6 +341,15 @@ static inline long long min(long long a, long long b) { return a < b ? a : b; }
 static inline long long max(long long a, long long b) { return a > b ? a : b; }
 static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
+
+// global_load_lds_dwordx4 (common.h: HCTR_GLOBAL_LOAD_LDS16): lane l's 16 bytes land at base + 16 l
+// (synchronously here; on the device the bytes are only there after the wave's vmcnt has drained
+// and a barrier was passed -- the interpreter cannot see a missing one)
+#define HCTR_GLOBAL_LOAD_LDS16(gptr, lds_wave_base)                                             \
+  memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63), (gptr), 16)
+
+#define HCTR_WAIT_VMCNT(n) ((void)0)
+#define HCTR_RAW_BARRIER() __syncthreads()
 
 // dynamically sized LDS (hugectr_amd/csrc/common.h spells it through these macros)
 #define HCTR_DYN_LDS(T, name) T* name = reinterpret_cast<T*>(hipemu::dyn_shared())

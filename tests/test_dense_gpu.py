@@ -111,6 +111,165 @@ def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
     assert_close(layer.biases.grad.cpu().numpy(), db, rt, 8 * at, "cross v2 db")
 
 
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("M,N,K,bm", [(200, 128, 64, 0), (1000, 256, 192, 128), (130, 384, 128, 64),
+                                      (64, 128, 512, 0)])
+def test_own_gemm_nt16_and_its_epilogues(monkeypatch, dtype_name, M, N, K, bm):
+    """hctr_gemm_nt16 (cross_gemm.hip: MFMA 32x32x16, LDS-DMA staging, swizzled tile image) against
+    fp64 products of the same 16-bit operands: plain, the forward's fused epilogue
+    (H = acc + b; C = X_l + X_0 * H, each rounded once) and the backward's residual; both tile
+    heights; M that is no multiple of the tile (rows past the end are read clamped, never stored);
+    the operand B asymmetric (a swapped fragment layout cannot pass)."""
+    import torch
+    from hugectr_amd.layers import gemm_nt16
+    dt = getattr(torch, dtype_name)
+    if bm:
+        monkeypatch.setenv("HCTR_GEMM_BM", str(bm))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(M + N + K)
+    a = (torch.randn((M, K), device="cuda", generator=g) * 0.5).to(dt)
+    bt = (torch.randn((N, K), device="cuda", generator=g) * 0.5).to(dt)
+    bt[:, 0] += torch.arange(N, device="cuda").to(dt) * 0.01  # (asymmetric in n)
+    bias = torch.randn((N,), device="cuda", generator=g).to(dt)
+    x0 = torch.randn((M, N), device="cuda", generator=g).to(dt)
+    xl = torch.randn((M, N), device="cuda", generator=g).to(dt)
+    ref = a.double() @ bt.double().t()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    scale = float(ref.abs().max())
+
+    def close(got, want, what, ulps=1.0):
+        err = float((got.double() - want).abs().max())
+        bound = ulps * eps * max(float(want.abs().max()), 1e-3) + 1e-5 * scale
+        assert err <= bound, (what, err, bound)
+
+    c = gemm_nt16(a, bt)
+    torch.cuda.synchronize()
+    close(c, ref, "plain")
+    out, h = gemm_nt16(a, bt, 1, bias, x0, xl)
+    torch.cuda.synchronize()
+    hw = ref + bias.double()
+    close(h, hw, "cross: h")
+    # C is computed from the ROUNDED h, as the unfused passes do
+    close(out, xl.double() + x0.double() * h.double(), "cross: out")
+    r = gemm_nt16(a, bt, 2, xl=xl)
+    torch.cuda.synchronize()
+    close(r, ref + xl.double(), "residual")
+    # untouched neighbours: a C with a wider leading dimension keeps its other columns
+    if N == 128:
+        from hugectr_amd import _lib
+        from hugectr_amd._lib import check, lib, ptr
+        wide = torch.full((M, 2 * N), 7.0, device="cuda").to(dt)
+        check(lib.hctr_gemm_nt16(M, N, K, ptr(a), K, ptr(bt), K, ptr(wide), 2 * N, 0, None, None, None,
+                                 None, _lib.F16 if dt == torch.float16 else _lib.BF16, None))
+        torch.cuda.synchronize()
+        assert torch.equal(wide[:, :N], c) and bool((wide[:, N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
+@pytest.mark.parametrize("L,R,C", [(3, 3456, 512), (2, 70, 33), (1, 1, 5)])
+def test_convert_transpose16(dtype_name, L, R, C):
+    """hctr_convert_transpose16: the 16-bit copy of fp32 weights and its transpose, the same bits as
+    torch's conversion"""
+    import torch
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr
+    dt = getattr(torch, dtype_name)
+    src = torch.randn((L, R, C), device="cuda")
+    a = torch.zeros((L, R, C), device="cuda", dtype=dt)
+    b = torch.zeros((L, C, R), device="cuda", dtype=dt)
+    code = _lib.F16 if dt == torch.float16 else _lib.BF16
+    check(lib.hctr_convert_transpose16(L, R, C, ptr(src), ptr(a), ptr(b), code, None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, src.to(dt)) and torch.equal(b, src.to(dt).transpose(1, 2))
+    b.zero_()
+    check(lib.hctr_convert_transpose16(L, R, C, ptr(src), None, ptr(b), code, None))
+    torch.cuda.synchronize()
+    assert torch.equal(b, src.to(dt).transpose(1, 2))
+
+
+@pytest.mark.parametrize("dtype_name,rt,at", [("float16", 2e-2, 2e-2), ("bfloat16", 6e-2, 6e-2)])
+@pytest.mark.parametrize("B,w,p,L", [(200, 256, 128, 2), (1024, 3456, 512, 3)])
+def test_cross_v2_on_the_own_gemm_matches_oracle(oracle, monkeypatch, dtype_name, rt, at, B, w, p, L):
+    """MultiCross v2 with its four activation GEMMs per layer on hctr_gemm_nt16 (forward: P = X U,
+    then bias + X_0 .* H + X_l in the second GEMM's epilogue; backward: S1 = S0 V^T and the residual
+    GEMM) against the fp32 oracle at a small shape and at `extra.cross`'s X1 shape (B = 8192,
+    w = 3456, p = 512, 3 layers), and against the library-GEMM form of the same layer
+    (HCTR_CROSS_GEMM=0)."""
+    import os
+    import torch
+    import hugectr_amd as ha
+    if B > 1000 and os.environ.get("HCTR_EMU") == "1":
+        pytest.skip("22 GFLOP: not under the host interpreter")
+    dt = getattr(torch, dtype_name)
+    rng = np.random.default_rng(5)
+    x0 = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
+    layer = ha.MultiCrossLayer(w, L, p).cuda()
+    with torch.no_grad():
+        layer.biases.normal_(0, 0.1)
+    U = layer.U.detach().cpu().numpy(); V = layer.V.detach().cpu().numpy()
+    b = layer.biases.detach().cpu().numpy()
+    og = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
+    res = {}
+    for own in ("1", "0"):
+        monkeypatch.setenv("HCTR_CROSS_GEMM", own)
+        layer.zero_grad()
+        xt = torch.from_numpy(x0).cuda().to(dt).requires_grad_(True)
+        out = layer(xt)
+        out.backward(torch.from_numpy(og).cuda().to(dt))
+        torch.cuda.synchronize()
+        res[own] = (out.detach().float().cpu().numpy(), xt.grad.float().cpu().numpy(),
+                    layer.U.grad.cpu().numpy().copy(), layer.V.grad.cpu().numpy().copy(),
+                    layer.biases.grad.cpu().numpy().copy())
+    x0r = torch.from_numpy(x0).to(dt).float().numpy()
+    ogr = torch.from_numpy(og).to(dt).float().numpy()
+    outs, hid, xus = oracle.cross_v2_fwd(x0r, U, V, b)
+    ig, dU, dV, db = oracle.cross_v2_bwd(x0r, U, V, outs, hid, xus, ogr)
+    # tolerances: relative to the tensor's own scale (sums over w = 3456 terms of 16-bit products)
+    def near(got, want, what, k=1.0):
+        err = np.abs(got.astype(np.float64) - want).max()
+        assert err <= k * (rt * np.abs(want).max() + at * 1e-2), (what, err, np.abs(want).max())
+    for own in ("1", "0"):
+        o, dx, gU, gV, gb = res[own]
+        near(o, outs[-1], f"fwd own={own}")
+        near(dx, ig, f"dx own={own}", 2)
+        near(gU, dU, f"dU own={own}", 2)
+        near(gV, dV, f"dV own={own}", 2)
+        near(gb, db, f"db own={own}", 2)
+    near(res["1"][0], res["0"][0].astype(np.float64), "own vs library fwd")
+
+
+def test_cross_v2_own_gemm_at_the_x1_shape_equals_the_library_form(monkeypatch):
+    """`extra.cross`'s X1 shape (B = 8192, w = 3456, p = 512, 3 layers, fp16) forward + backward on
+    hctr_gemm_nt16 against the same layer on the library GEMMs (both sides on the device: the
+    oracle at this size takes minutes of host time): outputs and gradients agree to the 16-bit
+    rounding of the [B, w] intermediates."""
+    import os
+    import torch
+    import hugectr_amd as ha
+    if os.environ.get("HCTR_EMU") == "1":
+        pytest.skip("174 GFLOP: not under the host interpreter")
+    B, w, p, L = 8192, 3456, 512, 3
+    torch.manual_seed(3)
+    layer = ha.MultiCrossLayer(w, L, p).cuda()
+    with torch.no_grad():
+        layer.biases.normal_(0, 0.1)
+    x = (torch.randn(B, w, device="cuda") * 0.5).half()
+    g = (torch.randn(B, w, device="cuda") * 0.5).half()
+    res = {}
+    for own in ("1", "0"):
+        monkeypatch.setenv("HCTR_CROSS_GEMM", own)
+        layer.zero_grad()
+        xt = x.clone().requires_grad_(True)
+        out = layer(xt)
+        out.backward(g)
+        torch.cuda.synchronize()
+        res[own] = [t.detach().double() for t in (out, xt.grad, layer.U.grad, layer.V.grad,
+                                                  layer.biases.grad)]
+    for a, b, what in zip(res["1"], res["0"], ("out", "dx", "dU", "dV", "db")):
+        err = float((a - b).abs().max())
+        assert err <= 4e-3 * float(b.abs().max()) + 1e-4, (what, err, float(b.abs().max()))
+
+
 @pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
 @pytest.mark.parametrize("B,w", [(300, 3456), (129, 24), (7, 2056)])
 def test_cross_v2_backward_step_equals_the_three_torch_passes(dtype_name, B, w):

@@ -5,7 +5,7 @@ oracle/_ref/libref_cross_kernels.so and executed by the host interpreter of test
 
   * oracle/pyoracle.py cross_v1_fwd / cross_v1_bwd (so far pinned to the CPU code inside the
     reference's gtest file only, tests/test_ref_layers_cpu.py), and
-  * this repo's kernel source: hctr_cross_v1_fwd / hctr_cross_v1_bwd / hctr_cross_v2_epilogue of
+  * this repo's kernel source: hctr_cross_v1_fwd / hctr_cross_v1_bwd of
     hugectr_amd/csrc/dense_ops.hip, stepped through by the same interpreter.
 
 v1: the dot product x_l . w_l is a cuBLAS GEMV in the reference (order unspecified) and a wavefront
@@ -116,20 +116,10 @@ def test_v1_forward_backward_next_to_the_reference_device_code(ref, elib, B, w, 
 def test_v2_fp32_elementwise_kernels(ref, elib, B, w):
     rng = np.random.default_rng(B * 100 + w)
     x0, xl, h, dy = (rng.standard_normal((B, w)).astype(f32) for _ in range(4))
-    # forward: x0 .* h + x_l (vector_fma4); the HIP epilogue adds the bias to the GEMM's output first
+    # forward: x0 .* h + x_l (vector_fma4).  (The HIP side of this step is the epilogue of the
+    # library's own GEMM, hctr_gemm_nt16 epilogue 1: tests/test_dense_gpu.py, against fp64.)
     r = np.full((B, w), np.nan, f32)
     ref.refcross_v2_dot_add(B, w, 0, _p(r), _p(h), _p(x0), _p(xl))
-    bias = (rng.standard_normal(w) * 0.1).astype(f32)
-    hb = np.full((B, w), np.nan, f32)
-    got = np.full((B, w), np.nan, f32)
-    emu.check(elib, elib.hctr_cross_v2_epilogue(B, w, _p(x0), _p(xl), _p(h), _p(bias), _p(hb), _p(got), None))
-    np.testing.assert_array_equal(hb, h + bias[None, :])  # (the GEMM epilogue's bias add)
-    r2 = np.full((B, w), np.nan, f32)
-    ref.refcross_v2_dot_add(B, w, 0, _p(r2), _p(hb), _p(x0), _p(xl))
-    # one multiply-add: a fused instruction on the device (both compilers contract a * b + c), two
-    # roundings in this host build -- at most one ulp of the larger operand apart
-    tol = np.maximum(np.abs(hb * x0), np.abs(xl)) * 2.0 ** -23
-    assert np.all(np.abs(got - r2) <= tol)
     np.testing.assert_array_equal(r, (h * x0).astype(f32) + xl)
     # backward: S0 = dY .* X0, dX += dY .* H (vector_mul_fma3_align)
     s0 = np.full((B, w), np.nan, f32)
