@@ -1150,8 +1150,17 @@ class Model:
         if not self._dense_params:
             return None
         if t == Optimizer_t.Adam:
-            return torch.optim.Adam(self._dense_params, lr=lr, betas=(o.beta1, o.beta2), eps=o.epsilon,
-                                    capturable=bool(getattr(self, "_graph_ok", False)))
+            kw = dict(lr=lr, betas=(o.beta1, o.beta2), eps=o.epsilon,
+                      capturable=bool(getattr(self, "_graph_ok", False)))
+            # one multi-tensor launch for the whole step instead of ~ 25 (a small-batch step is a
+            # chain of 5 us launches: BASELINE configs[0] spends 150 of its 510 us in them);
+            # HCTR_FUSED_ADAM=0 keeps the per-operation form
+            if os.environ.get("HCTR_FUSED_ADAM", "1") != "0":
+                try:
+                    return torch.optim.Adam(self._dense_params, fused=True, **kw)
+                except (RuntimeError, TypeError, ValueError):
+                    pass
+            return torch.optim.Adam(self._dense_params, **kw)
         if t == Optimizer_t.AdaGrad:
             return torch.optim.Adagrad(self._dense_params, lr=lr,
                                        initial_accumulator_value=o.initial_accu_value, eps=o.epsilon)
