@@ -278,6 +278,44 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
     assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
 
 
+@pytest.mark.parametrize("dtype,npd", [(1, np.float16)])
+@pytest.mark.parametrize("M,N,K,bm", [(70, 128, 128, 64), (200, 256, 64, 128)])
+def test_own_gemm_and_its_epilogues(elib, monkeypatch, dtype, npd, M, N, K, bm):
+    """hctr_gemm_nt16 (cross_gemm.hip) stepped through on the host: MFMA fragment layout, the
+    swizzled tile image the LDS DMA fills through permuted source addresses, the staging ring
+    (2 and 3 buffers), both tile heights, rows past the end, the three epilogues -- against fp64
+    products of the same fp16 operands (tests/test_dense_gpu.py runs the same on the device, where
+    the DMA is asynchronous)."""
+    rng = np.random.default_rng(M + K)
+    a = (rng.standard_normal((M, K)) * 0.5).astype(npd)
+    bt = (rng.standard_normal((N, K)) * 0.5).astype(npd)
+    bt[:, 0] += (np.arange(N) * 0.01).astype(npd)  # (asymmetric in n)
+    bias = rng.standard_normal(N).astype(npd)
+    x0 = rng.standard_normal((M, N)).astype(npd)
+    xl = rng.standard_normal((M, N)).astype(npd)
+    ref = a.astype(np.float64) @ bt.astype(np.float64).T
+    monkeypatch.setenv("HCTR_GEMM_BM", str(bm))
+    for stages in ("2", "3"):
+        monkeypatch.setenv("HCTR_GEMM_STAGES", stages)
+        c = np.full((M, N), np.nan, npd)
+        emu.check(elib, elib.hctr_gemm_nt16(M, N, K, emu.ptr(a), K, emu.ptr(bt), K, emu.ptr(c), N, 0,
+                                            None, None, None, None, dtype, None))
+        tol = 2.0 ** -10 * np.maximum(np.abs(ref), 1.0)
+        assert (np.abs(c.astype(np.float64) - ref) <= tol).all(), ("plain", stages)
+        h = np.full((M, N), np.nan, npd)
+        emu.check(elib, elib.hctr_gemm_nt16(M, N, K, emu.ptr(a), K, emu.ptr(bt), K, emu.ptr(c), N, 1,
+                                            emu.ptr(bias), emu.ptr(x0), emu.ptr(xl), emu.ptr(h), dtype,
+                                            None))
+        hw = ref + bias.astype(np.float64)
+        assert (np.abs(h.astype(np.float64) - hw) <= 2.0 ** -10 * np.maximum(np.abs(hw), 1.0)).all()
+        want = xl.astype(np.float64) + x0.astype(np.float64) * h.astype(np.float64)
+        assert (np.abs(c.astype(np.float64) - want) <= 2.0 ** -10 * np.maximum(np.abs(want), 1.0)).all()
+        emu.check(elib, elib.hctr_gemm_nt16(M, N, K, emu.ptr(a), K, emu.ptr(bt), K, emu.ptr(c), N, 2,
+                                            None, None, emu.ptr(xl), None, dtype, None))
+        want = ref + xl.astype(np.float64)
+        assert (np.abs(c.astype(np.float64) - want) <= 2.0 ** -10 * np.maximum(np.abs(want), 1.0)).all()
+
+
 def test_hash_rows_of_batches_full_of_unseen_keys(oracle, elib):
     """a first epoch: nearly every key of a batch is unseen, the finish kernel's list is DENSE (two
     or more entries per thread: the wave-aggregated form of its mask / region atomics) -- 30 000 and
