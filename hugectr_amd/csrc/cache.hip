@@ -96,12 +96,15 @@ __global__ void __launch_bounds__(kBlock)
     cache_emit_missing_kernel(const K* __restrict__ keys, size_t len,
                               const uint32_t* __restrict__ miss_flag,
                               const uint32_t* __restrict__ before, uint64_t* __restrict__ missing_index,
-                              K* __restrict__ missing_keys, size_t* __restrict__ d_missing_len) {
+                              K* __restrict__ missing_keys, size_t* __restrict__ d_missing_len,
+                              size_t pos_base) {
+  // (pos_base: the arrays are a piece of a longer key list -- the indices written are positions of
+  //  the whole list; hctr_tiered_lookup queries in pieces)
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len;
        i += (size_t)gridDim.x * kBlock) {
     if (miss_flag[i]) {
       const uint32_t j = before[i];
-      if (missing_index) missing_index[j] = i;
+      if (missing_index) missing_index[j] = pos_base + i;
       if (missing_keys) missing_keys[j] = keys[i];
     }
     if (i == len - 1) *d_missing_len = (size_t)before[i] + miss_flag[i];
@@ -270,6 +273,26 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// the pieces' miss lists (piece p: entries [p * piece, p * piece + cnt[p]) of the segmented arrays)
+// put end to end, in piece order = position order; *d_total = the whole count
+__global__ void __launch_bounds__(kBlock)
+    tier_concat_kernel(int pieces, size_t piece, const size_t* __restrict__ cnt,
+                       const long long* __restrict__ seg_keys, const uint64_t* __restrict__ seg_index,
+                       long long* __restrict__ keys, uint64_t* __restrict__ index,
+                       size_t* __restrict__ d_total) {
+  size_t base = 0;
+  for (int p = 0; p < pieces; p++) {
+    const size_t n = cnt[p];
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * kBlock) {
+      keys[base + i] = seg_keys[(size_t)p * piece + i];
+      index[base + i] = seg_index[(size_t)p * piece + i];
+    }
+    base += n;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = base;
+}
+
 // write-through update of unique rows: new = (add ? old : 0) + alpha * value, stored in the host
 // table and, when the row is cached, in the cache (whose copy is the newer one to read)
 template <bool V4>
@@ -374,7 +397,7 @@ bool vec4_ok(int D, const void* a, const void* b) {
 template <typename K>
 int cache_query_typed(hctr_cache* c, const K* keys, size_t len, float* values,
                       uint64_t* missing_index, K* missing_keys, size_t* d_missing_len,
-                      hipStream_t s) {
+                      hipStream_t s, size_t pos_base = 0) {
   const int grid = grid_for(len * 64, kBlock, 1 << 16);
   if (vec4_ok(c->D, values, c->vals))
     hipLaunchKernelGGL((cache_query_kernel<K, true>), dim3(grid), dim3(kBlock), 0, s, keys, len,
@@ -389,7 +412,7 @@ int cache_query_typed(hctr_cache* c, const K* keys, size_t len, float* values,
                                                s));
   hipLaunchKernelGGL(cache_emit_missing_kernel<K>, dim3(grid_for(len, kBlock, 4096)), dim3(kBlock),
                      0, s, keys, len, c->flags, c->before, missing_index, missing_keys,
-                     d_missing_len);
+                     d_missing_len, pos_base);
   HCTR_LAUNCH_CHECK();
   return HCTR_OK;
 }
@@ -564,18 +587,29 @@ struct hctr_tiered {
   long long* miss_keys = nullptr;
   uint64_t* miss_index = nullptr;
   size_t* d_missing_len = nullptr;
+  // lookup in pieces (hctr_tiered_lookup): the pieces' own miss lists and counts, the stream the
+  // host link's copies run on next to the cache queries of the following pieces
+  static constexpr int kPieces = 4;
+  long long* seg_keys = nullptr;
+  uint64_t* seg_index = nullptr;
+  size_t* d_piece_cnt = nullptr;  // [kPieces]
+  hipStream_t fill_stream = nullptr;
+  hipEvent_t ev_piece[kPieces] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_filled = nullptr;
 
   int reserve(size_t n, hipStream_t s) {
     if (n <= cap) return HCTR_OK;
     if (cap) HCTR_HIP(hipStreamSynchronize(s));
-    if (miss_keys) (void)hipFree(miss_keys);
-    if (miss_index) (void)hipFree(miss_index);
-    miss_keys = nullptr;
-    miss_index = nullptr;
+    for (void* q : {(void*)miss_keys, (void*)miss_index, (void*)seg_keys, (void*)seg_index})
+      if (q) (void)hipFree(q);
+    miss_keys = seg_keys = nullptr;
+    miss_index = seg_index = nullptr;
     size_t c = 1024;
     while (c < n) c *= 2;
     HCTR_HIP(hipMalloc(&miss_keys, c * 8));
     HCTR_HIP(hipMalloc(&miss_index, c * 8));
+    HCTR_HIP(hipMalloc(&seg_keys, c * 8));
+    HCTR_HIP(hipMalloc(&seg_index, c * 8));
     cap = c;
     return HCTR_OK;
   }
@@ -599,6 +633,11 @@ int hctr_tiered_create(size_t host_rows, int vec_size, size_t cache_capacity_in_
             hipSuccess;
   if (ok) ok = hipHostGetDevicePointer((void**)&t->host_dev, t->host, 0) == hipSuccess;
   if (ok) ok = hipMalloc(&t->d_missing_len, sizeof(size_t)) == hipSuccess;
+  if (ok) ok = hipMalloc(&t->d_piece_cnt, hctr_tiered::kPieces * sizeof(size_t)) == hipSuccess;
+  if (ok) ok = hipStreamCreateWithFlags(&t->fill_stream, hipStreamNonBlocking) == hipSuccess;
+  for (int p = 0; ok && p < hctr_tiered::kPieces; p++)
+    ok = hipEventCreateWithFlags(&t->ev_piece[p], hipEventDisableTiming) == hipSuccess;
+  if (ok) ok = hipEventCreateWithFlags(&t->ev_filled, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     set_error("hctr_tiered_create: host / device allocation failed");
     if (t->host) (void)hipHostFree(t->host);
@@ -615,9 +654,13 @@ int hctr_tiered_destroy(hctr_tiered* t) {
   if (!t) return HCTR_OK;
   (void)hipDeviceSynchronize();
   hctr_cache_destroy(t->cache);
-  if (t->miss_keys) (void)hipFree(t->miss_keys);
-  if (t->miss_index) (void)hipFree(t->miss_index);
-  if (t->d_missing_len) (void)hipFree(t->d_missing_len);
+  for (void* q : {(void*)t->miss_keys, (void*)t->miss_index, (void*)t->seg_keys,
+                  (void*)t->seg_index, (void*)t->d_missing_len, (void*)t->d_piece_cnt})
+    if (q) (void)hipFree(q);
+  if (t->fill_stream) (void)hipStreamDestroy(t->fill_stream);
+  for (hipEvent_t e : t->ev_piece)
+    if (e) (void)hipEventDestroy(e);
+  if (t->ev_filled) (void)hipEventDestroy(t->ev_filled);
   if (t->host) (void)hipHostFree(t->host);
   delete t;
   return HCTR_OK;
@@ -634,20 +677,74 @@ int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* o
   hipStream_t s = as_stream(stream);
   HCTR_TRY(t->reserve(len, s));
   size_t* dml = d_missing_len ? d_missing_len : t->d_missing_len;
-  // 1. hits are copied out of the cache, misses are listed (no host round trip)
-  HCTR_TRY(hctr_cache_query(t->cache, keys, len, out, t->miss_index, t->miss_keys, dml, stream));
-  // 2. missing rows: host table -> output, over the host link, by the GPU itself
-  const int grid = grid_for(len * 64, kBlock, 1 << 14);
-  if (vec4_ok(t->D, out, t->host_dev))
-    hipLaunchKernelGGL(tier_fill_kernel<true>, dim3(grid), dim3(kBlock), 0, s, t->miss_keys,
-                       t->miss_index, dml, t->rows, t->D, t->host_dev, out);
-  else
-    hipLaunchKernelGGL(tier_fill_kernel<false>, dim3(grid), dim3(kBlock), 0, s, t->miss_keys,
-                       t->miss_index, dml, t->rows, t->D, t->host_dev, out);
+  hctr_cache* c = t->cache;
+  // The three steps -- (1) hits copied out of the cache, misses listed; (2) missing rows host
+  // table -> output over the host link, by the GPU itself; (3) those rows into the cache -- as a
+  // pipeline over pieces of the key list (UvmTable::query's double-buffered H2D,
+  // R/gpu_cache/include/uvm_table.hpp:128-174): piece p's copy over the link runs on a private
+  // stream next to piece p + 1's cache query (an HBM-bound kernel), so the link's time hides behind
+  // the queries instead of following them (round 4: query 315 us + fill 225 us + replace 130 us one
+  // after the other).  ONE tick of the cache's clock for the whole call and one Replace over the
+  // pieces' miss lists put end to end in position order: the cache ends in exactly the state of
+  // the unpieced call (hits only refresh their slot's stamp with the call's clock value).
+  // HCTR_TIER_PIECES=1: the unpieced form.
+  int pieces = hctr_tiered::kPieces;
+  if (const char* e = getenv("HCTR_TIER_PIECES")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= hctr_tiered::kPieces) pieces = v;
+  }
+  // (short lists stay whole: four query launches of a few microseconds each would only add gaps;
+  //  HCTR_TIER_PIECE_MIN lowers the bound for tests)
+  size_t piece_min = 65536;
+  if (const char* e = getenv("HCTR_TIER_PIECE_MIN")) piece_min = (size_t)atoll(e);
+  if (len < piece_min) pieces = 1;
+  hipLaunchKernelGGL(cache_tick_kernel, dim3(1), dim3(64), 0, s, c->global_counter, dml);
   HCTR_LAUNCH_CHECK();
-  // 3. ... and into the cache (values are read back from the output rows just written)
-  return cache_modify_typed<long long>(t->cache, true, t->miss_keys, len, dml, out, t->miss_index,
-                                       s);
+  HCTR_TRY(c->reserve(len, s));
+  const size_t piece = ceil_div<size_t>(len, (size_t)pieces);
+  const bool v4 = vec4_ok(t->D, out, t->host_dev);
+  for (int p = 0; p < pieces; p++) {
+    const size_t b = (size_t)p * piece;
+    const size_t n = b >= len ? 0 : (len - b < piece ? len - b : piece);
+    if (n == 0) {
+      HCTR_HIP(hipMemsetAsync(t->d_piece_cnt + p, 0, sizeof(size_t), s));
+      continue;
+    }
+    long long* mk = pieces == 1 ? t->miss_keys : t->seg_keys + b;
+    uint64_t* mi = pieces == 1 ? t->miss_index : t->seg_index + b;
+    size_t* cnt = pieces == 1 ? dml : t->d_piece_cnt + p;
+    HCTR_TRY(cache_query_typed<long long>(c, (const long long*)keys + b, n, out + b * (size_t)t->D,
+                                          mi, mk, cnt, s, b));
+    hipStream_t fs = pieces == 1 ? s : t->fill_stream;
+    if (fs != s) {
+      HCTR_HIP(hipEventRecord(t->ev_piece[p], s));
+      HCTR_HIP(hipStreamWaitEvent(fs, t->ev_piece[p], 0));
+    }
+    // in pieces the copy shares the chip with the next piece's query: a few hundred wavefronts keep
+    // the host link full (64 GB/s x a few us of latency = a few hundred rows in flight); the 16 k
+    // workgroups of the whole-list form, parked on link latency, were measured to hold the query's
+    // wave slots (query 84 -> 300 us; lookup 1034 / 957 / 808 us at 1024 / 256 / 64 workgroups).
+    // The last piece's copy has nobody beside it and takes the full grid.
+    const char* fg_env = getenv("HCTR_TIER_FILL_GRID");
+    const int fcap = (pieces == 1 || p == pieces - 1) ? (1 << 14) : (fg_env ? atoi(fg_env) : 64);
+    const int grid = grid_for(n * 64, kBlock, fcap);
+    if (v4)
+      hipLaunchKernelGGL(tier_fill_kernel<true>, dim3(grid), dim3(kBlock), 0, fs, mk, mi, cnt,
+                         t->rows, t->D, t->host_dev, out);
+    else
+      hipLaunchKernelGGL(tier_fill_kernel<false>, dim3(grid), dim3(kBlock), 0, fs, mk, mi, cnt,
+                         t->rows, t->D, t->host_dev, out);
+    HCTR_LAUNCH_CHECK();
+  }
+  if (pieces > 1) {
+    hipLaunchKernelGGL(tier_concat_kernel, dim3(64), dim3(kBlock), 0, s, pieces, piece,
+                       t->d_piece_cnt, t->seg_keys, t->seg_index, t->miss_keys, t->miss_index, dml);
+    HCTR_LAUNCH_CHECK();
+    HCTR_HIP(hipEventRecord(t->ev_filled, t->fill_stream));
+    HCTR_HIP(hipStreamWaitEvent(s, t->ev_filled, 0));
+  }
+  // (3) the missing rows into the cache (values are read back from the output rows just written)
+  return cache_modify_typed<long long>(c, true, t->miss_keys, len, dml, out, t->miss_index, s);
 }
 
 int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,

@@ -85,11 +85,19 @@ def test_cache_large_batch_and_duplicates():
     assert (got.cpu().numpy() == want).all()
 
 
+@pytest.mark.parametrize("pieces", [4, 1, 3], ids=["four_pieces", "whole", "three_pieces"])
 @pytest.mark.parametrize("D", [32, 6])
-def test_tiered_table_matches_oracle(D):
+def test_tiered_table_matches_oracle(monkeypatch, D, pieces):
+    """lookup (hits from the cache, misses over the host link, Replace) + write-through scatter
+    against the oracle: values, miss counts, the host table and the cache's key sets after every
+    call -- with the lookup as one pass and as a pipeline of pieces whose host-link copies run on
+    a private stream next to the following pieces' cache queries (the same cache state by
+    construction: one tick of the clock, one Replace over the pieces' misses in position order)"""
     import torch
     from hugectr_amd.cache import TieredTable
     from oracle.cache_oracle import TieredOracle
+    monkeypatch.setenv("HCTR_TIER_PIECES", str(pieces))
+    monkeypatch.setenv("HCTR_TIER_PIECE_MIN", "0")
     rng = np.random.default_rng(D)
     rows, num_sets = 5000, 8                         # cache holds 512 of 5000 rows
     t = TieredTable(rows, D, num_sets)
