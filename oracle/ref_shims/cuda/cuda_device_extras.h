@@ -123,6 +123,32 @@ struct DeviceRadixSort {
     return cudaSuccess;
   }
 };
+// cub::DeviceSegmentedRadixSort::SortPairs by its documented contract: every segment
+// [begin_offsets[s], end_offsets[s]) sorted on its own, stably, on key bits [begin_bit, end_bit);
+// items outside every segment are not touched
+struct DeviceSegmentedRadixSort {
+  template <typename K, typename V, typename N, typename O>
+  static cudaError_t SortPairs(void* temp, size_t& temp_bytes, const K* kin, K* kout, const V* vin,
+                               V* vout, N n, int num_segments, const O* begin_offsets,
+                               const O* end_offsets, int begin_bit = 0,
+                               int end_bit = sizeof(K) * 8, cudaStream_t = nullptr) {
+    if (temp == nullptr) {
+      temp_bytes = 16;
+      return cudaSuccess;
+    }
+    (void)n;
+    for (int s = 0; s < num_segments; s++) {
+      const size_t b = (size_t)begin_offsets[s], e = (size_t)end_offsets[s];
+      if (e > b) {
+        size_t tb = 16;
+        char tmp[16];
+        DeviceRadixSort::SortPairs(tmp, tb, kin + b, kout + b, vin + b, vout + b, e - b, begin_bit,
+                                   end_bit);
+      }
+    }
+    return cudaSuccess;
+  }
+};
 // cub::DeviceSelect::Flagged / If: the flagged (or accepted) items in their input order, their count
 struct DeviceSelect {
   template <typename T, typename F, typename C, typename N>
