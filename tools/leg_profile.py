@@ -1,5 +1,5 @@
 """one extra leg of bench.py alone (argv[1]: dynamic | tiered | c1 | multi_hot), for a rocprofv3
-kernel trace of it: python tools/r4_next_profile.py LEG"""
+kernel trace of it: python tools/leg_profile.py LEG"""
 import json
 import os
 import sys

@@ -1,12 +1,12 @@
 #!/bin/bash
-# (on the GPU box) kernel traces of the legs VERDICT items 6 / 8 name: bash tools/r4_next_profile.sh TAG LEG...
+# (on the GPU box) kernel traces of the legs VERDICT items 6 / 8 name: bash tools/leg_profile.sh TAG LEG...
 TAG=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for LEG in "$@"; do
   OUT=gpurun_out/r4_next_${LEG}_$TAG.txt; : > $OUT
   rm -rf /tmp/np_$LEG
-  ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np_$LEG -o k -- python /root/repo/tools/r4_next_profile.py $LEG > /tmp/np_$LEG.out 2>&1 )
+  ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np_$LEG -o k -- python /root/repo/tools/leg_profile.py $LEG > /tmp/np_$LEG.out 2>&1 )
   grep "^{" /tmp/np_$LEG.out | tail -1 >> $OUT
   tail -3 /tmp/np_$LEG.out | cut -c1-300 >> $OUT
   echo "---- kernel stats" >> $OUT
