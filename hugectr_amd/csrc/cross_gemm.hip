@@ -105,13 +105,13 @@ struct GemmArgs {
 };
 
 // rows [row0, row0 + ROWS) x K step k0 of a row-major matrix into an LDS tile image (see the
-// header): ROWS / 8 DMA instructions of 8 rows each, spread over the 4 wavefronts
-template <int ROWS>
+// header): ROWS / 8 DMA instructions of 8 rows each, spread over the NW wavefronts
+template <int ROWS, int NW = 4>
 __device__ __forceinline__ void cg_stage(const unsigned short* __restrict__ src, int ld, int row0,
                                          int rows_total, int k0, unsigned short* tile, int wave,
                                          int lane) {
-  constexpr int PER_WAVE = ROWS / 8 / 4;  // DMA instructions per wavefront
-  static_assert(ROWS % 32 == 0, "tile rows");
+  constexpr int PER_WAVE = ROWS / 8 / NW;  // DMA instructions per wavefront
+  static_assert(ROWS % (8 * NW) == 0, "tile rows");
 #pragma unroll
   for (int j = 0; j < PER_WAVE; j++) {
     const int r8 = (wave * PER_WAVE + j) * 8;  // first row of this instruction's 8 (tile-local)
@@ -289,6 +289,132 @@ __global__ void __launch_bounds__(kGemmThreads)
   }
 }
 
+// The same product on 256 x 256 tiles (plain epilogue): 512 threads = 8 wavefronts as 2 x 4, a
+// wavefront owns 128 x 64 of C (4 x 2 MFMA tiles: 6 fragment reads per 8 MFMAs instead of 4 per 4),
+// two staging buffers of 64 KB.  What it is for: the K = 3456 -> N = 512 products at batch 65536
+// are bound by what the L2 can feed the LDS, not by the matrix pipe -- 2048 tiles of 128 x 128 move
+// 2048 x 54 x 32 KB = 3.6 GB through the L2 (12 TB/s at the measured 302 us); tiles of 256 x 256
+// move half of that.  One workgroup per CU (128 KB of LDS), so it is taken only while there are at
+// least as many tiles as CUs.  The accumulators leave through LDS in two passes of 128 rows.
+constexpr int kBigBM = 256, kBigBN = 256, kBigThreads = 512;
+
+template <bool BF>
+__global__ void __launch_bounds__(kBigThreads)
+    cross_gemm_nt16_big_kernel(GemmArgs g) {
+  using H16 = Cg16<BF>;
+  constexpr int MI = 4, NJ = 2;
+  constexpr int A_TILE = kBigBM * kGemmBK, B_TILE = kBigBN * kGemmBK, STAGE = A_TILE + B_TILE;
+  HCTR_DYN_LDS16(unsigned char, lds_raw);
+  unsigned short* lds = reinterpret_cast<unsigned short*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  int tile_m, tile_n;
+  {
+    const int b = blockIdx.x;
+    if ((g.tiles_m & 7) == 0) {
+      const int xcd = b & 7, slot = b >> 3;
+      tile_m = (slot / g.tiles_n) * 8 + xcd;
+      tile_n = slot % g.tiles_n;
+    } else {
+      tile_m = b / g.tiles_n;
+      tile_n = b % g.tiles_n;
+    }
+  }
+  const int m0 = tile_m * kBigBM, n0 = tile_n * kBigBN;
+  const int KT = g.K / kGemmBK;
+  cg_f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, fk = lane >> 5;
+  auto stage_tile = [&](int kt) {
+    unsigned short* buf = lds + (kt & 1) * STAGE;
+    cg_stage<kBigBM, 8>(g.A, g.lda, m0, g.M, kt * kGemmBK, buf, wave, lane);
+    cg_stage<kBigBN, 8>(g.Bt, g.ldb, n0, g.N, kt * kGemmBK, buf + A_TILE, wave, lane);
+  };
+  stage_tile(0);
+  for (int kt = 0; kt < KT; kt++) {
+    HCTR_WAIT_VMCNT(0);
+    HCTR_RAW_BARRIER();
+    if (kt + 1 < KT) stage_tile(kt + 1);
+    const unsigned short* at = lds + (kt & 1) * STAGE;
+    const unsigned short* bt = at + A_TILE;
+#pragma unroll
+    for (int s = 0; s < kGemmBK / 16; s++) {
+      cg_u32x4 af[MI], bf[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        const int r = wm * 128 + i * 32 + fr;
+        const int c = (2 * s + fk) ^ ((r >> 1) & 7);
+        af[i] = *reinterpret_cast<const cg_u32x4*>(at + r * kGemmBK + c * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int r = wn * 64 + j * 32 + fr;
+        const int c = (2 * s + fk) ^ ((r >> 1) & 7);
+        bf[j] = *reinterpret_cast<const cg_u32x4*>(bt + r * kGemmBK + c * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = H16::mfma(af[i], bf[j], acc[i][j]);
+    }
+  }
+  // epilogue: rows [128 p, 128 p + 128) of the tile through LDS as [128][256] fp32, p = 0, 1 (the
+  // wavefronts with wm == p hold them), then row-contiguous 16-byte stores by all 512 threads
+  float* ct = reinterpret_cast<float*>(lds_raw);
+  constexpr int NCH = 128 * kBigBN / 8 / kBigThreads;  // 8 chunks of 8 columns per thread and pass
+  const int cc = tid & 31;
+#pragma unroll 1
+  for (int p = 0; p < 2; p++) {
+    HCTR_RAW_BARRIER();  // (the K loop's / the previous pass's reads of the buffer are done)
+    if (wm == p) {
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            const int col = wn * 64 + j * 32 + fr;
+            ct[row * kBigBN + col] = acc[i][j][r];
+          }
+    }
+    HCTR_RAW_BARRIER();
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      const int row = (i * kBigThreads + tid) >> 5;
+      const int gm = m0 + p * 128 + row, gn = n0 + cc * 8;
+      const cg_f32x4 v0 = *reinterpret_cast<const cg_f32x4*>(ct + row * kBigBN + cc * 8);
+      const cg_f32x4 v1 = *reinterpret_cast<const cg_f32x4*>(ct + row * kBigBN + cc * 8 + 4);
+      const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      cg_u32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        ov[e] = (uint32_t)H16::from_f32(v[2 * e]) | ((uint32_t)H16::from_f32(v[2 * e + 1]) << 16);
+      if (gm < g.M) *reinterpret_cast<cg_u32x4*>(g.C + (size_t)gm * g.ldc + gn) = ov;
+    }
+  }
+}
+
+template <bool BF>
+int launch_big(const GemmArgs& g, hipStream_t s) {
+  constexpr int lds = 2 * (kBigBM + kBigBN) * kGemmBK * 2;  // 128 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    HCTR_HIP(hipFuncSetAttribute((const void*)cross_gemm_nt16_big_kernel<BF>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((cross_gemm_nt16_big_kernel<BF>), dim3((unsigned)(g.tiles_m * g.tiles_n)),
+                     dim3(kBigThreads), lds, s, g);
+  HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
 // fp32 master weights [batch][rows][cols] -> the 16-bit copy as it lies AND its transpose
 // [batch][cols][rows] in one pass (the forward wants both operands K-contiguous, the backward takes
 // the weights as they lie; torch's generic transpose was 28 us per tensor at the MLPerf size)
@@ -402,6 +528,18 @@ int hctr_gemm_nt16(size_t m, int n, int k, const void* a, int lda, const void* b
   const bool bm64 = bm_env ? atoi(bm_env) == 64 : tiles128 < 512;
   hipStream_t s = as_stream(stream);
   const bool bf = dtype == HCTR_EMB_BF16;
+  // plain products with at least a tile of 256 x 256 per CU: half the L2 -> LDS traffic per flop
+  // (HCTR_GEMM_BM=256 forces, any other value keeps the 128-wide tiles)
+  {
+    const size_t tiles256 = ceil_div<size_t>(m, 256) * (size_t)(n / 256);
+    const bool big = epilogue == kEpiPlain && n % 256 == 0 &&
+                     (bm_env ? atoi(bm_env) == 256 : tiles256 >= 256);
+    if (big) {
+      g.tiles_n = n / 256;
+      g.tiles_m = (int)ceil_div<size_t>(m, 256);
+      return bf ? launch_big<true>(g, s) : launch_big<false>(g, s);
+    }
+  }
   // depth of the staging ring (HCTR_GEMM_STAGES: 2 / 3 / 4, measurements)
   const char* st_env = getenv("HCTR_GEMM_STAGES");
   int stages = st_env ? atoi(st_env) : 2;

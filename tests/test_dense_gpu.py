@@ -113,12 +113,12 @@ def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
 @pytest.mark.parametrize("M,N,K,bm", [(200, 128, 64, 0), (1000, 256, 192, 128), (130, 384, 128, 64),
-                                      (64, 128, 512, 0)])
+                                      (64, 128, 512, 0), (700, 512, 192, 256), (256, 256, 64, 256)])
 def test_own_gemm_nt16_and_its_epilogues(monkeypatch, dtype_name, M, N, K, bm):
     """hctr_gemm_nt16 (cross_gemm.hip: MFMA 32x32x16, LDS-DMA staging, swizzled tile image) against
     fp64 products of the same 16-bit operands: plain, the forward's fused epilogue
-    (H = acc + b; C = X_l + X_0 * H, each rounded once) and the backward's residual; both tile
-    heights; M that is no multiple of the tile (rows past the end are read clamped, never stored);
+    (H = acc + b; C = X_l + X_0 * H, each rounded once) and the backward's residual; the tile
+    heights 64 / 128 and the 256 x 256 tiles of the plain product (8 wavefronts, two epilogue passes); M that is no multiple of the tile (rows past the end are read clamped, never stored);
     the operand B asymmetric (a swapped fragment layout cannot pass)."""
     import torch
     from hugectr_amd.layers import gemm_nt16

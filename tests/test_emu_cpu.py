@@ -279,7 +279,7 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
 
 
 @pytest.mark.parametrize("dtype,npd", [(1, np.float16)])
-@pytest.mark.parametrize("M,N,K,bm", [(70, 128, 128, 64), (200, 256, 64, 128)])
+@pytest.mark.parametrize("M,N,K,bm", [(70, 128, 128, 64), (200, 256, 64, 128), (300, 512, 128, 256)])
 def test_own_gemm_and_its_epilogues(elib, monkeypatch, dtype, npd, M, N, K, bm):
     """hctr_gemm_nt16 (cross_gemm.hip) stepped through on the host: MFMA fragment layout, the
     swizzled tile image the LDS DMA fills through permuted source addresses, the staging ring
