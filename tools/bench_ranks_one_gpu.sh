@@ -10,9 +10,12 @@ N=${1:-2}
 run() {
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 \
     --master-port $((29610 + RANDOM % 200)) bench.py --gpus $N --steps 4 --warmup 2 --batch 8192 \
-    --table-scale 0.02 --tunable off "$@" 2>&1 | grep '^{' | python -c "
+    --table-scale 0.02 --tunable off --extra-file /tmp/bench_ranks_extra.json "$@" 2>&1 | grep '^{' | python -c "
 import sys, json
-j = json.loads(sys.stdin.read())
+line = sys.stdin.read().strip()
+assert len(line.encode()) < 4096, len(line)
+json.loads(line)
+j = json.load(open('/tmp/bench_ranks_extra.json'))
 for name, l in (('weak', j), ('strong', j.get('strong'))):
     if isinstance(l, dict) and 'ms_per_step' in l:
         c = l['config']
