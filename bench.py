@@ -1142,7 +1142,37 @@ MLPERF_TABLES = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 4000000
 MLPERF_HOTNESS = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 
 
-def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
+def dynamic_optimizer_leg(steps, warmup, dev, alpha):
+    """stateful optimizers on dynamic tables (embedding::DynamicEmbeddingTable::update,
+    R/HugeCTR/embedding_storage/dynamic_embedding.cu:227-317): the step on the flat row store with
+    the state at the weights' row numbers (one probe per key, the forward's) beside the
+    reference's flow (HCTR_DYNAMIC_FLAT=0: unique keys -> wgrad -> probe of the weights + inserting
+    probe of a state table -> optimizer kernel), same collection and batches as
+    ebc_dynamic_multi_hot"""
+    import gc
+    r = {}
+    prev = os.environ.get("HCTR_DYNAMIC_FLAT")
+    try:
+        for opt in ("adagrad", "adam"):
+            for flat in ("1", "0"):
+                os.environ["HCTR_DYNAMIC_FLAT"] = flat
+                gc.collect()
+                torch.cuda.empty_cache()
+                leg = ebc_leg("multi_hot", steps, warmup, dev, alpha, dynamic=True, optimizer=opt)
+                r[f"{opt}_{'flat_row_store' if flat == '1' else 'unique_key_flow'}"] = {
+                    k: leg[k] for k in ("forward_us", "backward_update_us",
+                                        "forward_backward_update_us", "value", "unit")}
+    finally:
+        if prev is None:
+            os.environ.pop("HCTR_DYNAMIC_FLAT", None)
+        else:
+            os.environ["HCTR_DYNAMIC_FLAT"] = prev
+    r["workload"] = ("embedding_collection, MLPerf DLRM-DCNv2 tables and hotness on DYNAMIC hash "
+                     "tables, B=65536, D=128, fp16 output; AdaGrad and Adam")
+    return r
+
+
+def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False, optimizer="sgd"):
     """embedding_collection on one GPU (the reference's current-generation path):
     forward and backward + update of the collection alone, through EmbeddingCollection.forward /
     backward_and_update.  kind = "one_hot": Criteo-1TB tables, one key per table (the shape of the
@@ -1162,7 +1192,9 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
         # (EmbeddingTableConfig(max_vocabulary_size=-1), R/HugeCTR/embedding_storage/
         # dynamic_embedding.cu:130-330): keys are inserted on first sight, rows found by probing
         kw = dict(storage="dynamic", init_capacity=1 << 22)
-    ebc = EmbeddingCollection(cfg, B, lr=0.01, optimizer=_lib.OPT_SGD, scaler=1024.0,
+    opt_code = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "adam": _lib.OPT_ADAM,
+                "momentum": _lib.OPT_MOMENTUM_SGD}[optimizer]
+    ebc = EmbeddingCollection(cfg, B, lr=0.01, optimizer=opt_code, scaler=1024.0,
                               out_dtype=torch.float16, batch_major=True, max_hotness=max(hot),
                               hotness=hot, **kw)
     g = torch.Generator(device=dev)
@@ -1238,7 +1270,7 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False):
                      "sample), R/samples/dlrm/train.py:29-83") +
                     (" on DYNAMIC hash tables (BASELINE configs[4], embedding half)" if dynamic
                      else "") +
-                    f", B={B}, D={D}, fp16 output [B][26][D], SGD, power-law alpha={alpha}; the "
+                    f", B={B}, D={D}, fp16 output [B][26][D], {optimizer}, power-law alpha={alpha}; the "
                     "collection alone (no dense tower)",
         "direct_one_gpu_path": bool(ebc._direct), "keys_per_batch": nnz,
         "table_rows_total": int(sum(sizes)),
@@ -1364,7 +1396,7 @@ def main():
                          "the reference), fp32 = the reference's default (everything fp32).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in both.")
     ap.add_argument("--extra", default="auto",
-                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2"],
+                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2", "dynopt"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other precision on the same workload, `uniform_big_tables` (no key "
                          "repeats: the discriminating roofline), BASELINE configs[0] / [1] (DCN "
@@ -1489,6 +1521,8 @@ def main():
         run("ebc_dynamic_multi_hot", ("auto", "all", "ebc", "next"),
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha, dynamic=True))
         run("tiered", ("auto", "all", "next"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
+        run("ebc_dynamic_optimizers", ("all", "dynopt"),
+            lambda: dynamic_optimizer_leg(a.extra_steps, 3, dev, a.alpha))
         out["extra"] = extra
         # the discriminating figures as top-level keys (a driver that keeps the head of the line
         # sees them): the gather on uniform keys over big tables -- nothing cache-resident, no

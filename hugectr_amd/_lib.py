@@ -133,6 +133,7 @@ _SIGNATURES = {
     "hctr_det_lookup_index": (c_int, [_P, c_size_t, _P, c_size_t, c_int, _P, _P]),
     "hctr_det_rows": (c_int, [_P, c_size_t, POINTER(_P), _SZP]),
     "hctr_det_row_store": (c_int, [_P, POINTER(_P), POINTER(ctypes.c_uint64)]),
+    "hctr_det_state_store": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), _P]),
     "hctr_det_lookup_rows": (c_int, [_P, _P, c_size_t, _SZP, _SZP, c_size_t, c_int, _P, _P,
                                      POINTER(c_uint64), _P]),
     "hctr_radix_sort_temp_bytes": (c_size_t, [c_size_t]),

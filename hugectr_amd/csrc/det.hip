@@ -353,6 +353,12 @@ struct hctr_det {
   // (hctr_det_row_store).  A class that grows re-lays the arena out (doubling: amortised).
   float* arena = nullptr;
   size_t arena_rows = 0;
+  // optimizer state of the flat row store's users (hctr_det_state_store): n_state arrays
+  // [arena_rows][dim] fp32, zero for a row nobody updated yet -- what the reference's state table
+  // ("zeros" initializer, one entry per updated key, dynamic_embedding.cu:227-317) holds for a key,
+  // at the key's weight row: the state needs no probe of its own.  They travel with the arena.
+  float* state_arena[2] = {nullptr, nullptr};
+  int n_state = 0;
   uint64_t* idx = nullptr;  // scratch row indices
   uint64_t* idx2 = nullptr;
   size_t idx_cap = 0;
@@ -418,16 +424,30 @@ int arena_layout(hctr_det* h, const std::vector<size_t>& cap, const std::vector<
   for (size_t v : cap) total += v;
   float* na = nullptr;
   HCTR_HIP(hipMalloc(&na, total * dim * sizeof(float)));
+  float* ns[2] = {nullptr, nullptr};
+  for (int k = 0; k < h->n_state; k++) {
+    HCTR_HIP(hipMalloc(&ns[k], total * dim * sizeof(float)));
+    HCTR_HIP(hipMemsetAsync(ns[k], 0, total * dim * sizeof(float), s));
+  }
   size_t base = 0;
   for (size_t ci = 0; ci < h->cls.size(); ci++) {
     DetClass& c = h->cls[ci];
-    if (c.rows != nullptr && keep[ci] > 0)
+    if (c.rows != nullptr && keep[ci] > 0) {
       HCTR_HIP(hipMemcpyAsync(na + base * dim, c.rows, keep[ci] * dim * sizeof(float),
                               hipMemcpyDeviceToDevice, s));
+      const size_t old = (size_t)(c.rows - h->arena);  // (elements: the class's place in the old arena)
+      for (int k = 0; k < h->n_state; k++)
+        HCTR_HIP(hipMemcpyAsync(ns[k] + base * dim, h->state_arena[k] + old,
+                                keep[ci] * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     base += cap[ci];
   }
   HCTR_HIP(hipStreamSynchronize(s));
   if (h->arena) (void)hipFree(h->arena);
+  for (int k = 0; k < h->n_state; k++) {
+    if (h->state_arena[k]) (void)hipFree(h->state_arena[k]);
+    h->state_arena[k] = ns[k];
+  }
   h->arena = na;
   h->arena_rows = total;
   base = 0;
@@ -597,6 +617,8 @@ int hctr_det_destroy(hctr_det* h) {
   (void)hipDeviceSynchronize();
   for (auto& c : h->cls) class_destroy(c);
   if (h->arena) (void)hipFree(h->arena);
+  for (float* p : h->state_arena)
+    if (p) (void)hipFree(p);
   if (h->idx) (void)hipFree(h->idx);
   if (h->idx2) (void)hipFree(h->idx2);
   if (h->ptr_w) (void)hipFree(h->ptr_w);
@@ -937,9 +959,31 @@ int hctr_det_row_store(hctr_det* h, float** rows, uint64_t* total_rows) {
   return HCTR_OK;
 }
 
+int hctr_det_state_store(hctr_det* h, int num_state, float** state0, float** state1,
+                         hctr_stream_t stream) {
+  HCTR_REQUIRE(h && state0, "null pointer");
+  HCTR_REQUIRE(num_state >= 1 && num_state <= 2, "num_state");
+  HCTR_REQUIRE(h->arena != nullptr, "the table keeps no flat row store (classes of several dimensions)");
+  hipStream_t s = as_stream(stream);
+  const size_t bytes = h->arena_rows * (size_t)h->cls[0].dim * sizeof(float);
+  while (h->n_state < num_state) {
+    float* p = nullptr;
+    HCTR_HIP(hipMalloc(&p, bytes));
+    HCTR_HIP(hipMemsetAsync(p, 0, bytes, s));
+    h->state_arena[h->n_state++] = p;
+  }
+  *state0 = h->state_arena[0];
+  if (state1) *state1 = h->state_arena[1];
+  return HCTR_OK;
+}
+
 int hctr_det_clear(hctr_det* h, hctr_stream_t stream) {
   HCTR_REQUIRE(h, "null handle");
   hipStream_t s = as_stream(stream);
+  // (rows are handed out from 0 again: their state starts from zero again)
+  for (int k = 0; k < h->n_state; k++)
+    HCTR_HIP(hipMemsetAsync(h->state_arena[k], 0,
+                            h->arena_rows * (size_t)h->cls[0].dim * sizeof(float), s));
   for (auto& c : h->cls) {
     HCTR_TRY(c.ht.clear(s));
     HCTR_HIP(hipMemsetAsync(c.d_erased, 0, sizeof(unsigned long long), s));

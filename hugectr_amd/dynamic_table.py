@@ -94,6 +94,14 @@ class DynamicEmbeddingTable:
         check(lib.hctr_det_row_store(self._h, ctypes.byref(p), ctypes.byref(n)))
         return (p.value, int(n.value)) if p.value else (None, 0)
 
+    def state_store(self, num_state: int):
+        """(state0, state1 | None): addresses of the optimizer state arrays that share the row
+        numbers of row_store() (zeros for a row that was never updated).  Same validity."""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        check(lib.hctr_det_state_store(self._h, int(num_state), ctypes.byref(a), ctypes.byref(b),
+                                       stream_ptr()))
+        return a.value, b.value
+
     def scatter_add(self, keys, elements, id_spaces=None, id_space_offsets=None):
         sp, so, ns = self._ranges(keys.numel(), id_spaces, id_space_offsets)
         elements = elements.contiguous().float()

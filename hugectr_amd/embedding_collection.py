@@ -42,6 +42,9 @@ from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 
 _DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+# optimizers whose step on a dynamic table runs in the static tables' sparse update, on the flat
+# row store (EmbeddingCollection._dynamic_apply)
+_FLAT_STEP = (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_ADAM, _lib.OPT_MOMENTUM_SGD)
 
 
 @dataclass
@@ -205,6 +208,7 @@ class EmbeddingCollection:
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.B, self.bpg = global_batch, global_batch // self.world
         self.lr, self.optimizer, self.scaler, self.epsilon = lr, optimizer, scaler, epsilon
+        self.beta1, self.beta2, self.momentum_factor = beta1, beta2, momentum_factor
         self.out_dtype, self.batch_major, self.key_dtype = out_dtype, batch_major, key_dtype
         if not self.dynamic and optimizer not in (_lib.OPT_SGD, _lib.OPT_ADAGRAD, _lib.OPT_FTRL):
             # static EBC tables: SGD / AdaGrad / Ftrl only
@@ -335,11 +339,12 @@ class EmbeddingCollection:
         check(lib.hctr_updater_create(self.max_nnz, 0xFFFFFFEF if self.dynamic else self.local_rows,
                                       self.ev, ctypes.byref(self._upd)))
         # HCTR_DYNAMIC_FLAT=0: the pointer-per-key lookup and the unique-key optimizer step for
-        # every optimizer (what optimizers with a state table take in any case)
+        # every optimizer (what Nesterov / RMSProp / Ftrl take in any case)
         self._dyn_flat = self.dynamic and os.environ.get("HCTR_DYNAMIC_FLAT", "1") != "0"
         if optimizer == _lib.OPT_FTRL and not self.dynamic:
             check(lib.hctr_updater_set_ftrl(self._upd, *self.ftrl))
         self._times = 0
+        self._dyn_times = 0
         self._nnz_host = 0
         # One GPU, no Average lookup (static or dynamic tables): the send layout [peer][lookup][b][ev] IS the
         # feature-major output and there is nothing to exchange, so the two reorder passes around
@@ -610,18 +615,30 @@ class EmbeddingCollection:
         nnz = self._nnz_host
         if nnz == 0:
             return
-        if self._dyn_flat and self.optimizer == _lib.OPT_SGD:
-            # SGD keeps no state table: sort by row, sum per row in bucket order and apply --
-            # sgd_update_grad_kernel + scatter_add (dynamic_embedding.cu:300-330, optimizers.cuh:
-            # 29-45) in the segmented reduce of the static tables' update, on the flat row store:
-            # no unique-key list, no wgrad buffer, no second probe of the keys
+        if self._dyn_flat and self.optimizer in _FLAT_STEP:
+            # sort by row, sum per row in bucket order and apply -- *_update_grad_kernel +
+            # scatter_add (dynamic_embedding.cu:227-330, optimizers.cuh:29-140) in the segmented
+            # reduce of the static tables' update, on the flat row store: no unique-key list, no
+            # wgrad buffer, no second probe of the keys -- and, AdaGrad / Adam / MomentumSGD, no
+            # third one either: the state lies at the weights' row numbers (hctr_det_state_store;
+            # the reference probes a second table keyed like the first).  Same bits as the
+            # unique-key flow below: the same sums in the same order through the same formulas.
+            # (Nesterov / Ftrl are written differently there -- delta first, then w += delta -- and
+            # RMSProp is not a static optimizer at all: they keep the unique-key flow)
             store, total = self.det.row_store()
+            s0 = s1 = None
+            if self.optimizer != _lib.OPT_SGD:
+                s0, s1 = self.det.state_store(2 if self.optimizer == _lib.OPT_ADAM else 1)
+            # (Adam's step count: updates that met keys -- `++adam.times` sits inside the
+            #  reference's `if (num_unique_keys_cpu > 0)`, dynamic_embedding.cu:187, 239)
+            self._dyn_times += 1
             check(lib.hctr_updater_set_row_bound(self._upd, total))
             check(lib.hctr_updater_update(self._upd, self.nb, nnz, ptr(self.out_range),
                                           ptr(self._dyn_rows), ptr(top_grad), _DT[self.out_dtype],
-                                          _lib.OPT_SGD, _lib.UPDATE_LOCAL, self.lr, 0.9, 0.999,
-                                          self.epsilon, 0.0, self.scaler, self._times, store,
-                                          None, None, stream_ptr()))
+                                          self.optimizer, _lib.UPDATE_LOCAL, self.lr, self.beta1,
+                                          self.beta2, self.epsilon, self.momentum_factor,
+                                          self.scaler, self._dyn_times, store, s0, s1,
+                                          stream_ptr()))
             return
         urow = torch.empty(nnz, dtype=torch.int64, device=self.dev)
         ukey = torch.empty(nnz, dtype=torch.int64, device=self.dev)

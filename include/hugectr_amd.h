@@ -545,6 +545,18 @@ int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacit
  * pointer (and every class's hctr_det_rows pointer) changes when ANY class grows, i.e. only
  * inside a call that inserts. */
 int hctr_det_row_store(hctr_det* h, float** rows, uint64_t* total_rows);
+/* Optimizer state of the flat row store: num_state (1 or 2) arrays [total_rows][dim] fp32 that
+ * share the row numbers of hctr_det_row_store, allocated (zero-filled, on `stream`) by the first
+ * call that asks for them and moved with the rows when a class grows.  A row nobody updated yet
+ * holds zeros -- what the reference's state table (a second DynamicEmbeddingTable with the "zeros"
+ * initializer, keyed like the weights: embedding::DynamicEmbeddingTable::update,
+ * R/HugeCTR/embedding_storage/dynamic_embedding.cu:227-317) hands out for a key it meets first.
+ * With them hctr_updater_update runs AdaGrad / Adam / MomentumSGD on a dynamic table as on a
+ * static one: one probe per key (the forward's) instead of three.  state1 may be NULL when
+ * num_state == 1.  hctr_det_clear zeroes the state; a key that is removed and met again starts
+ * from zero state (its row number is a new one). */
+int hctr_det_state_store(hctr_det* h, int num_state, float** state0, float** state1,
+                         hctr_stream_t stream);
 /* embedding::DynamicEmbeddingTable::lookup (R/HugeCTR/embedding_storage/dynamic_embedding.cu:
  * 130-160): keys grouped by id space (HOST id_spaces / id_space_offsets as in hctr_det_lookup) ->
  * per key the address of its vector (elements, may be NULL) and / or a row number that is unique

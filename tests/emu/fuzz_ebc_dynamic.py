@@ -47,7 +47,7 @@ def one_case(seed):
     combiners = [str(rng.choice(["sum", "sum", "mean"])) for _ in range(L)]
     batch_major = bool(rng.integers(0, 2))
     dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.integers(0, 3))]
-    opt_name = str(rng.choice(["sgd", "sgd", "adagrad", "adam"]))
+    opt_name = str(rng.choice(["sgd", "adagrad", "adam", "momentum"]))
     max_hot = int(rng.choice([1, 2, 5, 9]))
     empty = float(rng.choice([0.0, 0.2, 0.7]))
     direct = str(rng.choice(["0", "1"]))
@@ -59,7 +59,8 @@ def one_case(seed):
     cfg = ha.EmbeddingCollectionConfig()
     for l in range(L):
         cfg.embedding_lookup(tcfg[lookup_table[l]], f"in{l}", f"out{l}", combiners[l])
-    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "adam": _lib.OPT_ADAM}[opt_name]
+    opt = {"sgd": _lib.OPT_SGD, "adagrad": _lib.OPT_ADAGRAD, "adam": _lib.OPT_ADAM,
+           "momentum": _lib.OPT_MOMENTUM_SGD}[opt_name]
     kw = dict(lr=0.05, optimizer=opt, scaler=float(rng.choice([1.0, 8.0])), epsilon=1e-6,
               batch_major=batch_major, max_hotness=max_hot, out_dtype=dtype, seed=seed % 97,
               storage="dynamic", initializer="", init_capacity=cap0)

@@ -100,6 +100,20 @@ def test_local_reduce(D, hot):
     lib.hctr_updater_destroy(upd)
 
 
+def _rows_at(torch, addr, rows, ev):
+    """fp32 rows `rows` of the flat [.][ev] array at device address addr (the library's own gather
+    with one key per bucket)"""
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    n = rows.numel()
+    out = torch.empty((n, ev), dtype=torch.float32, device="cuda")
+    rng = torch.arange(n + 1, dtype=torch.int64, device="cuda")
+    check(lib.hctr_forward_pool(n, ev, 0, ptr(rng), _lib.KEY_I64, ptr(rows), addr, ptr(out),
+                                _lib.F32, stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
 @pytest.mark.parametrize("world,shard", [(1, "table"), (2, "table"), (4, "row"), (2, "mixed")])
 @pytest.mark.parametrize("opt_name", ["sgd", "adagrad", "ftrl"])
 @pytest.mark.parametrize("preload", [True, False])
@@ -368,3 +382,76 @@ def test_flat_row_store_gives_the_bits_of_the_pointer_and_unique_key_path(monkey
     br = torch.arange(L * B + 1, dtype=torch.int64).cuda()
     a, b = ptrs.forward(keys, br), flat.forward(keys, br)
     assert torch.equal(a, b) and float(b.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", ["0", "1"])
+@pytest.mark.parametrize("opt_name,dtype", [("adagrad", "float32"), ("adam", "float32"),
+                                            ("momentum", "float32"), ("adagrad", "float16"),
+                                            ("adam", "bfloat16")])
+def test_flat_row_store_stateful_optimizers_give_the_bits_of_the_unique_key_path(
+        monkeypatch, direct, opt_name, dtype):
+    """AdaGrad / Adam / MomentumSGD on the flat row store: the optimizer state lies at the weights'
+    row numbers (hctr_det_state_store) and the static tables' sparse update applies the step in
+    place -- one probe per key (the forward's).  Same pooled vectors and the same table, bit for
+    bit, as the reference's flow that HCTR_DYNAMIC_FLAT=0 keeps: unique keys -> wgrad -> probe of
+    the weights + inserting probe of a state table keyed like them -> *_update_grad_kernel ->
+    scatter_add (dynamic_embedding.cu:227-330); the classes grow (rows AND state move) several
+    times on the way, and keys come back after steps in which they were absent (their state must
+    have travelled)."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(78)
+    B, ev = 96, 32
+    vocabs = [3000, 9, 400, 50000]
+    lookup_table = [0, 1, 2, 2, 3, 0]
+    tcfg = [ha.EmbeddingTableConfig(f"t{i}", -1, ev) for i in range(len(vocabs))]
+    cfg = ha.EmbeddingCollectionConfig()
+    for l, t in enumerate(lookup_table):
+        cfg.embedding_lookup(tcfg[t], f"in{l}", f"out{l}", "sum" if l % 2 == 0 else "mean")
+    opt = {"adagrad": _lib.OPT_ADAGRAD, "adam": _lib.OPT_ADAM, "momentum": _lib.OPT_MOMENTUM_SGD}[opt_name]
+    kw = dict(lr=0.05, optimizer=opt, scaler=8.0, epsilon=1e-6, batch_major=True, max_hotness=6,
+              out_dtype=getattr(torch, dtype), seed=5, storage="dynamic", initializer="",
+              init_capacity=16, beta1=0.8, beta2=0.95, momentum_factor=0.7)
+    monkeypatch.setenv("HCTR_EBC_DIRECT", direct)
+    monkeypatch.setenv("HCTR_DYNAMIC_FLAT", "0")
+    ptrs = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    monkeypatch.setenv("HCTR_DYNAMIC_FLAT", "1")
+    flat = ha.EmbeddingCollection.for_rank(0, 1, cfg, B, **kw)
+    assert flat._dyn_flat and not ptrs._dyn_flat
+    L = len(lookup_table)
+    caps = [flat.det.capacity_per_class()]
+    for step in range(7):
+        lens = rng.integers(0, 7, size=L * B).astype(np.int64)
+        if step == 3:  # a batch without keys: no step is counted (Adam's bias correction)
+            lens[:] = 0
+        br = np.zeros(L * B + 1, np.int64)
+        np.cumsum(lens, out=br[1:])
+        keys = np.concatenate([rng.integers(0, vocabs[lookup_table[l]], size=int(lens[l * B:(l + 1) * B].sum()))
+                               for l in range(L)]).astype(np.int64)
+        kt, brt = torch.from_numpy(keys).cuda(), torch.from_numpy(br).cuda()
+        a, b = ptrs.forward(kt, brt), flat.forward(kt, brt)
+        assert torch.equal(a, b), step
+        g = torch.randn(a.shape, device="cuda").to(a.dtype)
+        ptrs.backward_and_update(g)
+        flat.backward_and_update(g)
+        caps.append(flat.det.capacity_per_class())
+    assert caps[-1] != caps[0], "the test is meant to cross several growth steps"
+    assert ptrs.det.size() == flat.det.size() > 0
+    nst = 2 if opt_name == "adam" else 1
+    s0, s1 = flat.det.state_store(nst)
+    store, total = flat.det.row_store()
+    assert s0 and (s1 if nst == 2 else True) and total == sum(caps[-1])
+    for c in range(len(flat.det.dims)):
+        (ka, va), (kb, vb) = ptrs.det.export(c), flat.det.export(c)
+        oa, ob = torch.argsort(ka), torch.argsort(kb)
+        assert torch.equal(ka[oa], kb[ob]) and torch.equal(va[oa], vb[ob]), c
+        # the state itself: the state table's vectors of the unique-key flow, keyed like the
+        # weights ([m | v] per key for Adam), against the arrays at the weights' rows
+        sk, sv = ptrs.det_opt.states.export(c)
+        if sk.numel() == 0:
+            continue
+        _, rows, _ = flat.det.lookup_rows(sk, [c], [0, sk.numel()], insert=False, want_ptrs=False)
+        for j, addr in enumerate((s0, s1)[:nst]):
+            assert torch.equal(_rows_at(torch, addr, rows, ev), sv.view(-1, nst, ev)[:, j]), (c, j)
