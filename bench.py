@@ -1158,10 +1158,17 @@ def dynamic_optimizer_leg(steps, warmup, dev, alpha):
                 os.environ["HCTR_DYNAMIC_FLAT"] = flat
                 gc.collect()
                 torch.cuda.empty_cache()
-                leg = ebc_leg("multi_hot", steps, warmup, dev, alpha, dynamic=True, optimizer=opt)
-                r[f"{opt}_{'flat_row_store' if flat == '1' else 'unique_key_flow'}"] = {
-                    k: leg[k] for k in ("forward_us", "backward_update_us",
-                                        "forward_backward_update_us", "value", "unit")}
+                name = f"{opt}_{'flat_row_store' if flat == '1' else 'unique_key_flow'}"
+                free0 = torch.cuda.mem_get_info()[0]
+                try:
+                    leg = ebc_leg("multi_hot", steps, warmup, dev, alpha, dynamic=True,
+                                  optimizer=opt)
+                    r[name] = {k: leg[k] for k in ("forward_us", "backward_update_us",
+                                                   "forward_backward_update_us", "value", "unit")}
+                    del leg
+                except Exception as e:
+                    r[name] = {"error": repr(e)}
+                r[name]["hbm_free_gb_before"] = free0 / 1e9
     finally:
         if prev is None:
             os.environ.pop("HCTR_DYNAMIC_FLAT", None)

@@ -156,13 +156,16 @@ class DynamicTableOptimizer:
     def __init__(self, table: DynamicEmbeddingTable, optimizer: int, lr: float, beta1=0.9,
                  beta2=0.999, epsilon=1e-7, momentum_factor=0.9, rmsprop_beta=0.9,
                  ftrl_lambda1=0.0, ftrl_lambda2=0.0, ftrl_beta=0.0, scaler=1.0,
-                 initial_capacity: int = 1048576):
+                 initial_capacity: int = 1048576, with_states: bool = True):
+        # with_states=False: the owner keeps the optimizer state elsewhere (the flat row store's
+        # state arrays, DynamicEmbeddingTable.state_store) and never calls update() with an
+        # optimizer that needs it -- no second table is allocated
         self.table = table
         self.p = _lib.DetOptParams(optimizer, lr, beta1, beta2, epsilon, momentum_factor,
                                    rmsprop_beta, ftrl_lambda1, ftrl_lambda2, ftrl_beta, scaler)
         ns = _num_state(optimizer)
         self.states: Optional[DynamicEmbeddingTable] = None
-        if ns:
+        if ns and with_states:
             self.states = DynamicEmbeddingTable([d * ns for d in table.dims], "zeros",
                                                 initial_capacity, table.key_dtype)
 

@@ -259,9 +259,12 @@ class EmbeddingCollection:
             ncls = max(len(self.local_tables), 1)
             self.det = DynamicEmbeddingTable([self.ev] * ncls, initializer, init_capacity,
                                              torch.int64, seed=seed * 1000003 + self.rank)
+            # (a step that runs on the flat row store keeps its state there: no state table)
+            flat_step = (os.environ.get("HCTR_DYNAMIC_FLAT", "1") != "0" and optimizer in _FLAT_STEP)
             self.det_opt = DynamicTableOptimizer(
                 self.det, optimizer, lr, beta1, beta2, epsilon, momentum_factor, rmsprop_beta,
-                self.ftrl[0], self.ftrl[1], self.ftrl[2], scaler, init_capacity)
+                self.ftrl[0], self.ftrl[1], self.ftrl[2], scaler, init_capacity,
+                with_states=not flat_step)
             self.local_rows = 1
         else:
             self.table = torch.empty((self.local_rows, self.ev), dtype=torch.float32,
