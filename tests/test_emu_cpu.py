@@ -376,4 +376,6 @@ def test_no_collective_met_an_idle_lane(elib):
     """(runs last in this file) no shuffle of the kernels exercised above read a lane that was not
     taking part in it -- on the hardware such a read returns a stale register"""
     s = emu.stats(elib)
-    assert s["launches"] > 100 and s["shfl_from_inactive"] == 0, s
+    assert s["shfl_from_inactive"] == 0, s
+    if not os.environ.get("PYTEST_XDIST_WORKER"):  # (a worker of `-n N` ran only its share of the file)
+        assert s["launches"] > 100, s
