@@ -15,7 +15,8 @@ import emu  # noqa: E402
 pytestmark = pytest.mark.skipif(not emu.available(), reason="no host clang++ / make")
 
 
-@pytest.mark.parametrize("script,seed,cases", [("fuzz_ebc_dynamic.py", 0, 10), ("fuzz_det.py", 0, 10)])
+@pytest.mark.parametrize("script,seed,cases", [("fuzz_ebc_dynamic.py", 0, 10), ("fuzz_ebc_dynamic.py", 30, 10),
+                                               ("fuzz_det.py", 0, 10)])
 def test_fuzzer_seeds_agree(script, seed, cases):
     emu.build()  # (the child would build it as well; here a failure reads better)
     env = dict(os.environ)

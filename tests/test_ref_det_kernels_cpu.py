@@ -156,3 +156,121 @@ def test_reference_device_optimizer_kernels_next_to_oracle_and_hip_source(elib, 
     finally:
         lib.hctr_det_destroy(hw)
         lib.hctr_det_destroy(hs)
+
+
+FLAT_CASES = [("adagrad", do.ADAGRAD, {}), ("adam", do.ADAM, {}),
+              ("momentum", do.MOMENTUM, dict(momentum=0.3)), ("sgd", do.SGD, {})]
+
+
+@pytest.mark.parametrize("name,opt,kw", FLAT_CASES, ids=[c[0] for c in FLAT_CASES])
+@pytest.mark.parametrize("D,scaler", [(32, 1.0), (128, 64.0), (8, 1.0)])
+def test_reference_device_optimizer_kernels_next_to_the_flat_row_store_step(elib, name, opt, kw, D, scaler):
+    """The step the embedding_collection takes on dynamic tables of one vector size for SGD /
+    AdaGrad / Adam / MomentumSGD: row numbers from hctr_det_lookup_rows, weights in the flat row
+    store, state at the same row numbers (hctr_det_state_store), the static tables' sparse update
+    (hctr_updater_update) on the buckets' gradients -- no unique-key list, no wgrad buffer, no state
+    table.  Next to the reference's device kernels (optimizers.cuh) fed with the per-key gradient
+    sums in ascending bucket order (what LocalReduce hands them) and their scatter_add:
+    weights AND states bit for bit, keys met 0 ... 3 times per step, the classes growing on the way."""
+    from hugectr_amd import _lib
+    L = _ref()
+    lib = elib
+    emu.bind(lib)
+    rng = np.random.default_rng(opt * 13 + D)
+    lr, b1, b2, eps = 0.05, 0.9, 0.999, 1e-7
+    mom = kw.get("momentum", 0.9)
+    nt = 3
+    n_state = {do.ADAM: 2, do.SGD: 0}.get(opt, 1)
+    code = {do.ADAM: _lib.OPT_ADAM, do.ADAGRAD: _lib.OPT_ADAGRAD, do.MOMENTUM: _lib.OPT_MOMENTUM_SGD,
+            do.SGD: _lib.OPT_SGD}[opt]
+    pool = [rng.choice(10 ** 6, KEYS, replace=False).astype(np.int64) + t * 10 ** 7 for t in range(nt)]
+    dims = (ctypes.c_size_t * nt)(*([D] * nt))
+    hw, upd = ctypes.c_void_p(), ctypes.c_void_p()
+    emu.check(lib, lib.hctr_det_create(nt, dims, b"", 8, _lib.KEY_I64, 7, ctypes.byref(hw)))
+    emu.check(lib, lib.hctr_updater_create(4 * nt * KEYS, 0xFFFFFFEF, D, ctypes.byref(upd)))
+    ids = (ctypes.c_size_t * nt)(*range(nt))
+    w_ref, s_ref = {}, {}
+    times = 0
+    try:
+        for step in range(1, 6):
+            # the batch: per class a multiset of keys (0 ... 3 copies each), one key per bucket
+            per = []
+            for t in range(nt):
+                m = rng.integers(0, 4, size=KEYS) if step != 3 else np.zeros(KEYS, np.int64)
+                ks = np.repeat(pool[t], m)
+                per.append(ks[rng.permutation(ks.size)])
+            keys = np.concatenate(per).astype(np.int64)
+            n = keys.size
+            ofs = (ctypes.c_size_t * (nt + 1))(*np.concatenate([[0], np.cumsum([p.size for p in per])]).tolist())
+            rows = np.zeros(max(n, 1), np.uint64)
+            base = (ctypes.c_uint64 * (nt + 1))()
+            emu.check(lib, lib.hctr_det_lookup_rows(hw, _p(keys), n, ids, ofs, nt, 1, None, _p(rows),
+                                                    base, None))
+            store, total = ctypes.c_void_p(), ctypes.c_uint64()
+            emu.check(lib, lib.hctr_det_row_store(hw, ctypes.byref(store), ctypes.byref(total)))
+            table = np.ctypeslib.as_array(ctypes.cast(store, ctypes.POINTER(ctypes.c_float)),
+                                          shape=(total.value, D))
+            for k, r in zip(keys, rows[:n]):  # rows created by this lookup: the reference's side starts from them
+                if int(k) not in w_ref:
+                    w_ref[int(k)] = table[int(r)].copy()
+                    s_ref[int(k)] = np.zeros(D * max(n_state, 1), dtype=f32)
+            if n == 0:
+                continue  # (no keys: no step, `times` stays -- dynamic_embedding.cu:187)
+            times += 1
+            g = (rng.standard_normal((n, D)) * scaler).astype(f32)
+            # (1) reference: unique keys, their gradient sums in ascending bucket order
+            uk, first = np.unique(keys, return_index=True)
+            wg = np.zeros((uk.size, D), f32)
+            slot = {int(k): j for j, k in enumerate(uk)}
+            seen = set()
+            for i, k in enumerate(keys):
+                j = slot[int(k)]
+                wg[j] = g[i] if int(k) not in seen else (wg[j] + g[i]).astype(f32)
+                seen.add(int(k))
+            ev_start = (np.arange(uk.size + 1) * D).astype(np.uint32)
+            g_ref = wg.reshape(-1).copy()
+            sp = (ctypes.c_void_p * uk.size)(*[s_ref[int(k)].ctypes.data for k in uk])
+            wp = (ctypes.c_void_p * uk.size)(*[w_ref[int(k)].ctypes.data for k in uk])
+            bias = f32(np.sqrt(1.0 - float(f32(b2)) ** times) / (1.0 - float(f32(b1)) ** times))
+            args = {do.ADAM: (f32(lr) * bias, b1, b2, eps), do.ADAGRAD: (lr, eps, 0.0, 0.0)}.get(
+                opt, (lr, mom, 0.0, 0.0))
+            assert L.refdetk_update(opt, uk.size, _p(ev_start), sp, wp, *[float(a) for a in args],
+                                    scaler, _p(g_ref)) == 0
+            for j, k in enumerate(uk):
+                w_ref[int(k)] = (w_ref[int(k)] + g_ref[j * D:(j + 1) * D]).astype(f32)
+            # (2) the flat row store's step
+            s0, s1 = ctypes.c_void_p(), ctypes.c_void_p()
+            if n_state:
+                emu.check(lib, lib.hctr_det_state_store(hw, n_state, ctypes.byref(s0), ctypes.byref(s1), None))
+            br = np.arange(n + 1, dtype=np.int64)
+            emu.check(lib, lib.hctr_updater_set_row_bound(upd, total.value))
+            emu.check(lib, lib.hctr_updater_update(upd, n, n, _p(br), _p(rows), _p(g), _lib.F32, code,
+                                                   _lib.UPDATE_LOCAL, lr, b1, b2, eps, mom, scaler,
+                                                   times, store, s0, s1, None))
+            # ---- compare: every key ever met (absent ones must not have moved) ---------------------
+            allk = np.array(sorted(w_ref), np.int64)
+            cls = (allk // 10 ** 7).astype(np.int64)
+            order = np.argsort(cls, kind="stable")
+            allk, cls = allk[order], cls[order]
+            aofs = (ctypes.c_size_t * (nt + 1))(*np.concatenate([[0], np.cumsum(np.bincount(cls, minlength=nt))]).tolist())
+            arow = np.zeros(allk.size, np.uint64)
+            emu.check(lib, lib.hctr_det_lookup_rows(hw, _p(allk), allk.size, ids, aofs, nt, 0, None,
+                                                    _p(arow), base, None))
+            emu.check(lib, lib.hctr_det_row_store(hw, ctypes.byref(store), ctypes.byref(total)))
+            table = np.ctypeslib.as_array(ctypes.cast(store, ctypes.POINTER(ctypes.c_float)),
+                                          shape=(total.value, D))
+            np.testing.assert_array_equal(table[arow.astype(np.int64)],
+                                          np.stack([w_ref[int(k)] for k in allk]),
+                                          err_msg=f"{name} step {step}: weights")
+            for j, sp_ in enumerate((s0, s1)[:n_state]):
+                st = np.ctypeslib.as_array(ctypes.cast(sp_, ctypes.POINTER(ctypes.c_float)),
+                                           shape=(total.value, D))
+                np.testing.assert_array_equal(st[arow.astype(np.int64)],
+                                              np.stack([s_ref[int(k)][j * D:(j + 1) * D] for k in allk]),
+                                              err_msg=f"{name} step {step}: state {j}")
+        caps = (ctypes.c_size_t * nt)()
+        emu.check(lib, lib.hctr_det_capacity_per_class(hw, caps))
+        assert min(caps) > 8, "the classes were meant to grow"
+    finally:
+        lib.hctr_updater_destroy(upd)
+        lib.hctr_det_destroy(hw)
