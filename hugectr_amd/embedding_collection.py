@@ -265,6 +265,10 @@ class EmbeddingCollection:
                 self.det, optimizer, lr, beta1, beta2, epsilon, momentum_factor, rmsprop_beta,
                 self.ftrl[0], self.ftrl[1], self.ftrl[2], scaler, init_capacity,
                 with_states=not flat_step)
+            if flat_step and optimizer != _lib.OPT_SGD:
+                # (allocated now, not inside the first step: set-up inside a step was not free
+                #  with hundreds of GB resident)
+                self.det.state_store(2 if optimizer == _lib.OPT_ADAM else 1)
             self.local_rows = 1
         else:
             self.table = torch.empty((self.local_rows, self.ev), dtype=torch.float32,
