@@ -137,3 +137,77 @@ def test_det_update_matches_oracle(name):
             gs = opt.states.lookup(_dev(torch, keys), sp, so).cpu().numpy()
             assert_close(gs, os_.lookup(keys, sp, so), 1e-5, 1e-7, f"{name} state step {step}")
     assert t.size_per_class() == ow.size_per_class()
+
+
+def _rows_of(torch, addr, rows, ev):
+    """fp32 rows `rows` of the flat [.][ev] array at device address addr (the library's own gather)"""
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    n = rows.numel()
+    out = torch.empty((n, ev), dtype=torch.float32, device="cuda")
+    rng = torch.arange(n + 1, dtype=torch.int64, device="cuda")
+    check(lib.hctr_forward_pool(n, ev, 0, ptr(rng), _lib.KEY_I64, ptr(rows), addr, ptr(out),
+                                _lib.F32, stream_ptr()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_state_store_shares_the_row_numbers_travels_with_growth_and_clears():
+    """hctr_det_state_store: zero for rows never updated, one array more when a later caller asks for
+    two, moved with the rows when a class grows (the rows of the OTHER classes move as well), zeroed
+    by clear(); refused for classes of several dimensions (no flat row store)."""
+    import ctypes
+    import torch
+    from hugectr_amd import _lib
+    from hugectr_amd._lib import check, lib, ptr, stream_ptr
+    from hugectr_amd.dynamic_table import DynamicEmbeddingTable
+    ev = 8
+    t = DynamicEmbeddingTable([ev, ev, ev], "0.5", initial_capacity=16)
+    k0 = torch.arange(100, 110, dtype=torch.int64).cuda()
+    k2 = torch.arange(500, 506, dtype=torch.int64).cuda()
+    keys = torch.cat([k0, k2])
+    _, rows, base = t.lookup_rows(keys, [0, 2], [0, 10, 16], want_ptrs=False)
+    assert base == [0, 16, 32, 48]
+    s0, s1 = t.state_store(1)
+    assert s0 and not s1
+    assert float(_rows_of(torch, s0, rows, ev).abs().max()) == 0.0
+    # one AdaGrad step of the static tables' update on those rows: state = (g / scaler)^2
+    upd = ctypes.c_void_p()
+    check(lib.hctr_updater_create(64, 0xFFFFFFEF, ev, ctypes.byref(upd)))
+    try:
+        g = torch.arange(1, 16 * ev + 1, dtype=torch.float32).cuda().view(16, ev) / 64
+        br = torch.arange(17, dtype=torch.int64).cuda()
+        store, total = t.row_store()
+        check(lib.hctr_updater_set_row_bound(upd, total))
+        check(lib.hctr_updater_update(upd, 16, 16, ptr(br), ptr(rows), ptr(g), _lib.F32,
+                                      _lib.OPT_ADAGRAD, _lib.UPDATE_LOCAL, 0.1, 0.9, 0.999, 1e-6,
+                                      0.0, 2.0, 1, store, s0, None, stream_ptr()))
+        want = (g / 2.0) ** 2
+        assert torch.equal(_rows_of(torch, s0, rows, ev), want)
+        # a second array for a later caller: the first keeps its place and content
+        a0, a1 = t.state_store(2)
+        assert a0 == s0 and a1
+        assert torch.equal(_rows_of(torch, a0, rows, ev), want)
+        assert float(_rows_of(torch, a1, rows, ev).abs().max()) == 0.0
+        # class 1 grows (16 -> 64): every class's rows move, the state with them
+        k1 = torch.arange(1000, 1040, dtype=torch.int64).cuda()
+        t.lookup_rows(k1, [1], [0, 40], want_ptrs=False)
+        assert t.capacity_per_class() == [16, 64, 16]
+        _, rows2, base2 = t.lookup_rows(keys, [0, 2], [0, 10, 16], insert=False, want_ptrs=False)
+        assert base2 == [0, 16, 80, 96] and not torch.equal(rows2, rows)
+        b0, b1 = t.state_store(2)
+        assert torch.equal(_rows_of(torch, b0, rows2, ev), want)
+        assert float(_rows_of(torch, b1, rows2, ev).abs().max()) == 0.0
+        _, r1, _ = t.lookup_rows(k1, [1], [0, 40], insert=False, want_ptrs=False)
+        assert float(_rows_of(torch, b0, r1, ev).abs().max()) == 0.0  # new rows: zero state
+        # clear(): rows are handed out from 0 again and start from zero state
+        t.clear()
+        _, rows3, _ = t.lookup_rows(keys, [0, 2], [0, 10, 16], want_ptrs=False)
+        c0, _ = t.state_store(2)
+        assert float(_rows_of(torch, c0, rows3, ev).abs().max()) == 0.0
+    finally:
+        lib.hctr_updater_destroy(upd)
+    mixed = DynamicEmbeddingTable([8, 16], "0.5", initial_capacity=16)
+    assert mixed.row_store() == (None, 0)
+    with pytest.raises(_lib.HugeCTRAmdError, match="flat row store"):
+        mixed.state_store(1)
