@@ -41,6 +41,32 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def _node_seed(nodeid):
+    """32-bit seed of a test: a hash of its node id, mixed with HCTR_TEST_SEED (default 0) so the
+    whole suite can be replayed under other seeds (`HCTR_TEST_SEED=3 pytest -m gpu`)."""
+    import zlib
+    base = int(os.environ.get("HCTR_TEST_SEED", "0"))
+    return (zlib.crc32(nodeid.encode()) ^ (base * 0x9E3779B1)) & 0x7FFFFFFF
+
+
+@pytest.fixture(autouse=True)
+def _seed_every_test(request):
+    """No test may depend on the process's RNG state: python / numpy / torch (CPU and every GPU)
+    global generators are seeded per test from the test's node id, so a test draws the same
+    numbers whether it runs alone, after 29 others, or on a box it has never seen."""
+    import random
+    import numpy as np
+    seed = _node_seed(request.node.nodeid)
+    random.seed(seed)
+    np.random.seed(seed)
+    try:
+        import torch
+        torch.manual_seed(seed)  # (also seeds every CUDA device's default generator)
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pyoracle

@@ -75,17 +75,23 @@ def test_cross_v1_fwd_bwd(oracle, B, w, L):
     assert_close(layer.biases.grad.cpu().numpy(), bg, 2e-4, 1e-4, "cross db")
 
 
-@pytest.mark.parametrize("dtype_name,rt,at", [("float32", 1e-3, 1e-4), ("float16", 2e-2, 2e-3),
-                                              ("bfloat16", 8e-2, 1e-2)])
-def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
+@pytest.mark.parametrize("dtype_name", ["float32", "float16", "bfloat16"])
+def test_cross_v2_matches_oracle(oracle, dtype_name):
     """MultiCross v2 forward AND backward in the activations' type (fp32; fp16 / bf16 = the
     reference's mixed-precision MultiCrossLayer<__half>: GEMMs in the 16-bit type, fp32 master
     weights and weight gradients) against the fp32 oracle (CPU restatement of
-    multi_cross_layer_test.cpp's reference); 16-bit tolerances follow the type's rounding of the
-    [B, w] intermediates"""
+    multi_cross_layer_test.cpp's reference).
+
+    The bound is magnitude-aware: every [B, w] intermediate (P = X_l U, H = P V + b, X_0 .* H,
+    X_{l+1}) is rounded to the activation type, so an element of the result carries a few roundings
+    of numbers as large as the LARGEST intermediate that fed it -- not of its own (possibly tiny)
+    value.  err <= k * eps_T * (|want| + scale), scale = the largest magnitude among the oracle's
+    own intermediates of that tensor's chain.  (The reference's own test accepts rel 0.1 - 0.4 for
+    half, R/test/utest/core23_layer_test/multi_cross_layer_test.cpp:152-432.)"""
     import torch
     import hugectr_amd as ha
     dt = getattr(torch, dtype_name)
+    eps = {"float32": 2.0 ** -24, "float16": 2.0 ** -11, "bfloat16": 2.0 ** -8}[dtype_name]
     rng = np.random.default_rng(11)
     B, w, p, L = 64, 96, 16, 3
     x0 = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
@@ -99,16 +105,34 @@ def test_cross_v2_matches_oracle(oracle, dtype_name, rt, at):
     out = layer(xt)
     assert out.dtype == dt
     outs, hid, xus = oracle.cross_v2_fwd(x0r, U, V, b)
-    assert_close(out.detach().float().cpu().numpy(), outs[-1], rt, at, "cross v2 fwd")
+
+    def amax(*xs):
+        return max(float(np.abs(np.asarray(x)).max()) for x in xs)
+
+    def near(got, want, scale, k, what):
+        err = np.abs(np.asarray(got, np.float64) - want)
+        tol = k * eps * (np.abs(want) + scale)
+        bad = err > tol
+        assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} beyond {k} eps x (|want| + {scale:.3g}); "
+                               f"max err {err.max():.3e}")
+
+    fscale = amax(*outs, *hid, *xus, *[x0r * h for h in hid])
+    # k: measured worst case over 40 parameter draws is 1.1 (fwd) / 1.9 (bwd) eps for the 16-bit types
+    # and 3.1 / 5.4 eps for fp32 (summation order of the w = 96 dot products); 6x headroom
+    kf, kb = (32, 64) if dtype_name == "float32" else (8, 16)
+    near(out.detach().float().cpu().numpy(), outs[-1], fscale, kf, "cross v2 fwd")
     og = (rng.standard_normal((B, w)) * 0.5).astype(np.float32)
     ogt = torch.from_numpy(og).cuda().to(dt)
     out.backward(ogt)
-    ig, dU, dV, db = oracle.cross_v2_bwd(x0r, U, V, outs, hid, xus, ogt.float().cpu().numpy())
+    ogr = ogt.float().cpu().numpy()
+    ig, dU, dV, db = oracle.cross_v2_bwd(x0r, U, V, outs, hid, xus, ogr)
     assert layer.U.grad.dtype == torch.float32 and layer.biases.grad.dtype == torch.float32
-    assert_close(xt.grad.float().cpu().numpy(), ig, rt, 4 * at, "cross v2 dx")
-    assert_close(layer.U.grad.cpu().numpy(), dU, rt, 8 * at, "cross v2 dU")
-    assert_close(layer.V.grad.cpu().numpy(), dV, rt, 8 * at, "cross v2 dV")
-    assert_close(layer.biases.grad.cpu().numpy(), db, rt, 8 * at, "cross v2 db")
+    # backward: the gradient chain's intermediates scale with |dy| x the forward's magnitudes, and
+    # dU / dV / db are sums over the B rows of rounded [B, w] / [B, p] products
+    near(xt.grad.float().cpu().numpy(), ig, amax(ig, ogr) * max(1.0, fscale), kb, "cross v2 dx")
+    near(layer.U.grad.cpu().numpy(), dU, amax(dU), kb, "cross v2 dU")
+    near(layer.V.grad.cpu().numpy(), dV, amax(dV), kb, "cross v2 dV")
+    near(layer.biases.grad.cpu().numpy(), db, amax(db), kb, "cross v2 db")
 
 
 @pytest.mark.parametrize("dtype_name", ["float16", "bfloat16"])
