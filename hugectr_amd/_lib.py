@@ -73,6 +73,8 @@ _SIGNATURES = {
     "hctr_ht_set_value_head": (c_int, [_P, c_size_t, _P]),
     "hctr_ht_table_size": (c_size_t, [_P]),
     "hctr_ht_dump": (c_int, [_P, _P, _P, POINTER(c_size_t), _P]),
+    "hctr_ht_error_flags": (c_int, [_P, _P, POINTER(ctypes.c_uint32)]),
+    "hctr_ht_recover": (c_int, [_P, _P, c_size_t, _P]),
     "hctr_forward_pool": (c_int, [c_size_t, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
     "hctr_forward_pool_weighted": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "hctr_expand_key_grads": (c_int, [c_size_t, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -149,6 +151,7 @@ _SIGNATURES = {
     "hctr_det_clear": (c_int, [_P, _P]),
     "hctr_det_size_per_class": (c_int, [_P, _SZP, _P]),
     "hctr_det_capacity_per_class": (c_int, [_P, _SZP]),
+    "hctr_det_repair_count": (c_int, [_P, POINTER(ctypes.c_uint64)]),
     "hctr_det_update": (c_int, [_P, _P, POINTER(DetOptParams), _P, c_size_t, _SZP, _SZP, c_size_t,
                                 _P, _P, _P]),
     "hctr_cache_create": (c_int, [c_size_t, c_int, c_int, POINTER(_P)]),

@@ -376,6 +376,10 @@ struct hctr_det {
   std::vector<uint32_t> up_seg_class;
   std::vector<uint64_t> up_seg_off;
   hipStream_t up_stream = nullptr;  // the stream those copies were queued on
+  // pinned host word per class: the error flags of the class's hash index as its last inserting
+  // lookup left them (posted by the finish kernel, IndexExtras::host_error)
+  uint32_t* h_err = nullptr;
+  uint64_t repairs = 0;  // inserting lookups that were repaired and issued again
 };
 
 namespace {
@@ -538,16 +542,78 @@ inline const void* key_at(const hctr_det* h, const void* keys, size_t off) {
   return (const char*)keys + off * (h->key_type == HCTR_KEY_U32 ? 4 : 8);
 }
 
-// lookup with insertion of unseen keys; leaves row indices in h->idx[0..n)
+// an inserting lookup that was queued and is not verified yet (det_verify_inserts)
+struct Inserted {
+  size_t cls;
+  const void* keys;
+  size_t n;
+  uint64_t* idx;
+};
+
+// lookup with insertion of unseen keys; leaves row indices in idx[0..n).  `log`: the call is noted
+// for det_verify_inserts, which every caller runs before it reads idx.
 int class_lookup_insert(hctr_det* h, DetClass& c, size_t cls_index, const void* keys, size_t n,
-                        uint64_t* idx, hipStream_t s) {
+                        uint64_t* idx, hipStream_t s, std::vector<Inserted>* log,
+                        bool two_launches = false) {
   HCTR_TRY(class_reserve(h, c, n, h->key_type, s));
-  HCTR_TRY(c.ht.get_insert(keys, n, nullptr, idx, s));
+  IndexExtras ex;
+  ex.host_error = h->h_err + cls_index;
+  ex.two_launches = two_launches;
+  HCTR_TRY(c.ht.get_insert(keys, n, nullptr, idx, s, nullptr, &ex));
+  if (log != nullptr) log->push_back({cls_index, keys, n, idx});
   c.head_bound += n;
   hipLaunchKernelGGL(det_init_rows_kernel, dim3(grid_for(n * (size_t)c.dim, kBlock, 2048)),
                      dim3(kBlock), 0, s, c.ht.new_positions, c.ht.d_new_count, idx, c.rows, c.dim,
                      h->init_mode, h->init_val, h->seed + 0x9E3779B97F4A7C15ull * (cls_index + 1));
   HCTR_LAUNCH_CHECK();
+  return HCTR_OK;
+}
+
+// The hash index reports through its error word, never through the row it hands out: a finish
+// kernel whose grid barrier did not open leaves "no row" at every unseen key of its batch (they
+// would pool as zeros and be skipped by the update, silently).  Every inserting lookup is
+// therefore verified before its rows are used: one wait for the stream, the pinned error words of
+// the classes that inserted.  A barrier that gave up (bit 4: all-or-nothing, hashtable.hip) is
+// repaired and the class's lookups are queued again in their order with the two-launch finish
+// (no barrier) -- the rows are the ones an undisturbed run hands out (the row counter had not
+// moved).  Anything else (a full index: a bug in class_reserve's accounting) is an error.
+int det_verify_inserts(hctr_det* h, std::vector<Inserted>& ins, hipStream_t s) {
+  if (ins.empty()) return HCTR_OK;
+  HCTR_HIP(hipStreamSynchronize(s));
+  const volatile uint32_t* err = h->h_err;
+  std::vector<char> redo(h->cls.size(), 0);
+  bool any = false;
+  for (const Inserted& it : ins) {
+    const uint32_t e = err[it.cls];
+    if (e & ~4u) {
+      set_error("dynamic table: hash index of class " + std::to_string(it.cls) +
+                " reports error flags " + std::to_string(e));
+      return HCTR_ERR_HIP;
+    }
+    if (e & 4u) redo[it.cls] = 1, any = true;
+  }
+  if (!any) {
+    ins.clear();
+    return HCTR_OK;
+  }
+  for (const Inserted& it : ins)
+    if (redo[it.cls]) HCTR_TRY(h->cls[it.cls].ht.recover(it.keys, it.n, s));
+  for (const Inserted& it : ins)
+    if (redo[it.cls]) {
+      DetClass& c = h->cls[it.cls];
+      c.head_bound -= it.n < c.head_bound ? it.n : c.head_bound;  // (counted again below)
+      h->repairs++;
+      HCTR_TRY(class_lookup_insert(h, c, it.cls, it.keys, it.n, it.idx, s, nullptr, true));
+    }
+  HCTR_HIP(hipStreamSynchronize(s));
+  for (size_t ci = 0; ci < redo.size(); ci++)
+    if (redo[ci] && err[ci] != 0u) {
+      set_error("dynamic table: hash index of class " + std::to_string(ci) +
+                " could not be repaired after a grid barrier that did not open (error flags " +
+                std::to_string(err[ci]) + ")");
+      return HCTR_ERR_HIP;
+    }
+  ins.clear();
   return HCTR_OK;
 }
 
@@ -581,6 +647,13 @@ int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const
     }
   }
   const size_t cap = initial_capacity_per_class ? initial_capacity_per_class : 1048576;
+  if (hipHostMalloc(&h->h_err, num_classes * sizeof(uint32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    delete h;
+    set_error("hipHostMalloc (error words)");
+    return HCTR_ERR_HIP;
+  }
+  memset(h->h_err, 0, num_classes * sizeof(uint32_t));
   h->cls.resize(num_classes);
   bool flat = true;  // one dimension: one row store (hctr_det::arena)
   for (size_t i = 1; i < num_classes; i++) flat = flat && dimension_per_class[i] == dimension_per_class[0];
@@ -627,6 +700,7 @@ int hctr_det_destroy(hctr_det* h) {
   if (h->d_seg_class) (void)hipFree(h->d_seg_class);
   if (h->d_seg_off) (void)hipFree(h->d_seg_off);
   if (h->d_miss) (void)hipFree(h->d_miss);
+  if (h->h_err) (void)hipHostFree(h->h_err);
   delete h;
   return HCTR_OK;
 }
@@ -641,12 +715,18 @@ int hctr_det_lookup(hctr_det* h, const void* keys, float* elements, size_t num_k
   std::vector<Range> rs;
   HCTR_TRY(ranges_of(h, num_keys, id_spaces, id_space_offsets, num_id_spaces, &rs));
   HCTR_TRY(det_scratch(h, num_keys));
+  // every insertion (and the check that it handed out rows) before a row is read
+  std::vector<Inserted> ins;
+  for (const Range& r : rs)
+    if (r.n)
+      HCTR_TRY(class_lookup_insert(h, h->cls[r.cls], r.cls, key_at(h, keys, r.off), r.n,
+                                   h->idx + r.off, s, &ins));
+  HCTR_TRY(det_verify_inserts(h, ins, s));
   size_t out_off = 0;
   for (const Range& r : rs) {
     DetClass& c = h->cls[r.cls];
     if (r.n == 0) continue;
-    HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
-    launch_det_gather(h->idx, r.n, c.rows, c.dim, elements + out_off, s);
+    launch_det_gather(h->idx + r.off, r.n, c.rows, c.dim, elements + out_off, s);
     HCTR_LAUNCH_CHECK();
     out_off += r.n * (size_t)c.dim;
   }
@@ -669,12 +749,17 @@ int hctr_det_lookup_unsafe(hctr_det* h, const void* keys, float** elements, size
   for (const Range& r : rs) need[r.cls] += r.n;
   for (size_t ci = 0; ci < need.size(); ci++)
     if (need[ci]) HCTR_TRY(class_reserve(h, h->cls[ci], need[ci], h->key_type, s));
+  std::vector<Inserted> ins;
+  for (const Range& r : rs)
+    if (r.n)
+      HCTR_TRY(class_lookup_insert(h, h->cls[r.cls], r.cls, key_at(h, keys, r.off), r.n,
+                                   h->idx + r.off, s, &ins));
+  HCTR_TRY(det_verify_inserts(h, ins, s));
   for (const Range& r : rs) {
     DetClass& c = h->cls[r.cls];
     if (r.n == 0) continue;
-    HCTR_TRY(class_lookup_insert(h, c, r.cls, key_at(h, keys, r.off), r.n, h->idx, s));
     hipLaunchKernelGGL(det_ptr_kernel, dim3(grid_for(r.n, kBlock, 1024)), dim3(kBlock), 0, s,
-                       h->idx, r.n, c.rows, c.dim, elements + r.off);
+                       h->idx + r.off, r.n, c.rows, c.dim, elements + r.off);
     HCTR_LAUNCH_CHECK();
   }
   return HCTR_OK;
@@ -812,10 +897,12 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
       if (any) {
         for (size_t ci = 0; ci < ncls; ci++)
           if (need[ci]) HCTR_TRY(class_reserve(h, h->cls[ci], need[ci], h->key_type, s));
+        std::vector<Inserted> ins;
         for (const Range& r : rs)
           if (miss[r.cls])
             HCTR_TRY(class_lookup_insert(h, h->cls[r.cls], r.cls, key_at(h, keys, r.off), r.n,
-                                         h->idx + r.off, s));
+                                         h->idx + r.off, s, &ins));
+        HCTR_TRY(det_verify_inserts(h, ins, s));
         rebase();
         HCTR_TRY(det_upload_spaces(h, rs, base, s));
         rows_done = false;
@@ -941,7 +1028,11 @@ int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, siz
   if (num_keys == 0) return HCTR_OK;
   HCTR_REQUIRE(keys && row_index, "null pointer");
   DetClass& c = h->cls[class_index];
-  if (insert) return class_lookup_insert(h, c, class_index, keys, num_keys, row_index, as_stream(stream));
+  if (insert) {
+    std::vector<Inserted> ins;
+    HCTR_TRY(class_lookup_insert(h, c, class_index, keys, num_keys, row_index, as_stream(stream), &ins));
+    return det_verify_inserts(h, ins, as_stream(stream));
+  }
   return c.ht.get_mark(keys, num_keys, nullptr, row_index, as_stream(stream));
 }
 
@@ -1003,6 +1094,12 @@ int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream) {
     h->cls[i].head_bound = head;
     sizes[i] = head - (size_t)er;
   }
+  return HCTR_OK;
+}
+
+int hctr_det_repair_count(const hctr_det* h, uint64_t* out) {
+  HCTR_REQUIRE(h && out, "null pointer");
+  *out = h->repairs;
   return HCTR_OK;
 }
 
@@ -1098,12 +1195,16 @@ int hctr_det_update(hctr_det* weights, hctr_det* states, const hctr_det_opt_para
       HCTR_REQUIRE(r.cls < states->cls.size() && states->cls[r.cls].dim == cw.dim * smul,
                    "state table: dimension must be ev_size * num_parameters_per_weight");
       DetClass& cs = states->cls[r.cls];
-      HCTR_TRY(class_lookup_insert(states, cs, r.cls, kp, r.n, h->idx2, s));
+      std::vector<Inserted> ins;
+      HCTR_TRY(class_lookup_insert(states, cs, r.cls, kp, r.n, h->idx2, s, &ins));
+      HCTR_TRY(det_verify_inserts(states, ins, s));
       rows_s = cs.rows;
     }
-    if (opt == HCTR_OPT_FTRL)  // the reference looks the weights up (inserting) for Ftrl
-      HCTR_TRY(class_lookup_insert(h, cw, r.cls, kp, r.n, h->idx, s));
-    else
+    if (opt == HCTR_OPT_FTRL) {  // the reference looks the weights up (inserting) for Ftrl
+      std::vector<Inserted> ins;
+      HCTR_TRY(class_lookup_insert(h, cw, r.cls, kp, r.n, h->idx, s, &ins));
+      HCTR_TRY(det_verify_inserts(h, ins, s));
+    } else
       HCTR_TRY(cw.ht.get_mark(kp, r.n, nullptr, h->idx, s));
     hipLaunchKernelGGL(det_update_kernel, dim3(grid_for(r.n * (size_t)cw.dim, kBlock, 4096)),
                        dim3(kBlock), 0, s, o, r.n, cw.dim, h->idx, needs_state ? h->idx2 : nullptr,

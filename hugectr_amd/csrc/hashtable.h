@@ -61,6 +61,7 @@ struct HashTable {
   uint32_t* d_pending = nullptr;    // positions of the current batch that hold an unseen key
   uint32_t* d_latched = nullptr;    // d_pending as seen by the scan step of this get_insert
   uint32_t* d_error = nullptr;      // bit0: probe overflow (table full) bit1: counter > capacity
+                                    // bit2: the finish kernel's grid barrier did not open (recover)
   uint64_t* d_new_count = nullptr;  // number of keys inserted by the last get_insert
   // scratch sized for max_n positions
   size_t max_n = 0;
@@ -90,6 +91,11 @@ struct HashTable {
   int set_value_head(size_t v, hipStream_t s);
   int dump(int64_t* d_keys, uint64_t* d_vals, size_t* count, hipStream_t s);
   int error_flags(hipStream_t s, uint32_t* out);
+  // after error bit 4 (the finish kernel's grid barrier did not open: NO position of that batch got
+  // a row): puts back the slots the batch's keys left pending and the insert protocol's scalars /
+  // masks, clears bit 4.  The batch can then be resolved again (IndexExtras::two_launches needs no
+  // barrier).  `keys` = the n keys of the failed get_insert.
+  int recover(const void* keys, size_t n, hipStream_t s);
 };
 
 }  // namespace hctr

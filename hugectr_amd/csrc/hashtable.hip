@@ -253,6 +253,10 @@ constexpr int kFinRegions = 2048;  // (their bases live in LDS: 8 KB)
 constexpr int kProbeMaxBlocks = 4096;  // workgroups of the probe kernel (their list segments'
                                        // first entries live in the finish kernel's LDS: 16 KB)
 constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises error bit 2^2)
+// generation word of the grid barrier: bit 31 = a workgroup gave up waiting.  Giving up and opening
+// are both compare-and-swaps on this ONE word, so a batch's barrier either opens for every
+// workgroup or fails for every workgroup -- never rows for some positions and "no row" for others
+constexpr uint32_t kBarAbort = 1u << 31;
 
 struct FinishCtl {
   uint32_t *pending, *latched, *error, *barrier;
@@ -273,6 +277,7 @@ struct FinishCtl {
   uint64_t *host_rows, *host_seq;
   uint64_t seq;
   uint32_t* host_error;
+  uint32_t spin_limit;  // polls of the grid barrier before a workgroup gives up (HCTR_HT_SPIN_LIMIT)
 };
 
 __device__ __forceinline__ void post_to_host(const FinishCtl& c, uint64_t rows) {
@@ -302,7 +307,7 @@ __device__ __forceinline__ void st_agent(T* p, T v) {
 // all workgroups of the grid are resident (grid <= kHtFinishBlocks, far below what 256 CUs hold):
 // sense-reversing barrier on {arrived, generation}.  __syncthreads: every wave has waited for
 // its (write-through) stores before thread 0 arrives.
-__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
+__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks, uint32_t spin_limit) {
   // every thread waits for ITS OWN outstanding memory operations first (the no-return atomics on
   // masks / region counts of phase A included): the workgroup barrier alone orders the waves, not
   // the arrival of their atomics at the memory side -- a per-wave wait, no cache write-back
@@ -313,18 +318,40 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks) {
     ok = 1u;
     const uint32_t gen = ld_agent(bar + 1);
     __builtin_amdgcn_s_waitcnt(0);  // (the generation is read before this workgroup arrives)
-    const uint32_t old =
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nblocks - 1u) {
-      st_agent(bar, 0u);
-      __builtin_amdgcn_s_waitcnt(0);  // (the count is back at zero before anybody is released)
-      __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gen & kBarAbort) {
+      ok = 0u;  // given up before this workgroup arrived (or never cleared by the host)
     } else {
-      uint32_t spins = 0;
-      while (ld_agent(bar + 1) == gen) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kSpinLimit) {
+      const uint32_t old =
+          __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == nblocks - 1u) {
+        st_agent(bar, 0u);
+        __builtin_amdgcn_s_waitcnt(0);  // (the count is back at zero before anybody is released)
+        // opens the barrier -- unless a waiter has given up in the meantime
+        uint32_t expect = gen;
+        if (!__hip_atomic_compare_exchange_strong(bar + 1, &expect, (gen + 1u) & ~kBarAbort,
+                                                  __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT))
           ok = 0u;
+      } else {
+        uint32_t spins = 0;
+        for (;;) {
+          uint32_t cur = ld_agent(bar + 1);
+          if (cur == gen) {
+            if (spins++ < spin_limit) {
+              __builtin_amdgcn_s_sleep(1);
+              continue;
+            }
+            // gives up: poisons the generation, or learns that the barrier has just opened
+            uint32_t expect = gen;
+            if (__hip_atomic_compare_exchange_strong(bar + 1, &expect, gen | kBarAbort,
+                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+              ok = 0u;
+              break;
+            }
+            cur = expect;
+          }
+          ok = (cur & kBarAbort) ? 0u : 1u;
           break;
         }
       }
@@ -492,17 +519,19 @@ __global__ void __launch_bounds__(kFinBlock)
   }
   if constexpr (PHASE == 1) return;  // (the launch boundary is the barrier)
   if constexpr (PHASE == 0) {
-    if (!grid_barrier(c.barrier, G)) {
-      // the barrier never opened (the grid was not resident as a whole: a partitioned or masked
-      // device): no row can be handed out.  The pending positions of this workgroup's share get
-      // "no row" (they pool as zeros and the update skips them) instead of keeping PENDING | slot,
-      // the barrier words are put back so that the next batch starts clean, error bit 4 tells the
-      // host
+    if (!grid_barrier(c.barrier, G, c.spin_limit)) {
+      // the barrier did not open (the grid was not resident as a whole: a partitioned or masked
+      // device, or other work holding the CUs): no row is handed out to ANY position of the batch
+      // (grid_barrier: all workgroups fail together).  The pending positions of this workgroup's
+      // share get "no row" instead of keeping PENDING | slot, error bit 4 tells the host, and the
+      // generation word stays poisoned: every later batch fails the same way until the host has
+      // put the table right (HashTable::recover, or clear) -- the slots this batch claimed still
+      // hold PENDING | position, which a later batch must not mistake for its own
       for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) out[entry(k)] = kInvalidIndex;
       if (threadIdx.x == 0) {
-        atomicOr(c.error, 4u);
-        st_agent(c.barrier, 0u);
-        if (c.host_error != nullptr) *c.host_error = *c.error;
+        const uint32_t e = atomicOr(c.error, 4u) | 4u;
+        if (c.host_error != nullptr) *c.host_error = e;
+        if (b == 0) *c.new_count = 0;  // (nobody may initialise "the rows this batch created")
       }
       return;
     }
@@ -659,6 +688,33 @@ __global__ void __launch_bounds__(kBlock)
     if (ok) tab[slot].val = vals[i];
     else atomicOr(d_error, 1u);
   }
+}
+
+// after a finish kernel that gave up (error bit 4): the slots of the batch's keys that still hold
+// PENDING | position go back to "no row" (what an erased key holds: the next get_insert of the key
+// hands it a row), so that the batch can be resolved again
+template <typename K>
+__global__ void __launch_bounds__(kBlock)
+    ht_unpend_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys, size_t n,
+                     uint32_t* d_error) {
+  const long long empty = KeyTraits<K>::empty;
+  for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * kBlock) {
+    const K key = keys[i];
+    const long long k64 = widen<K>(key);
+    uint64_t slot = (uint64_t)murmur3_key(key) % size;
+    for (uint64_t probes = 0; probes < size; ++probes) {
+      const long long cur = tab[slot].key;
+      if (cur == k64) {
+        const unsigned long long v = tab[slot].val;
+        if (v >= kPendingBit && v != kInvalidIndex) tab[slot].val = kInvalidIndex;  // (same value from every duplicate)
+        break;
+      }
+      if (cur == empty) break;
+      slot = (slot + 1 == size) ? 0 : slot + 1;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAnd(d_error, ~4u);
 }
 
 // occupied-slot compaction (size_kernel / dump_kernel, nv_hashtable.cu:116-163), physical order
@@ -859,6 +915,10 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   c.host_seq = x.host_seq;
   c.seq = x.seq;
   c.host_error = x.host_error;
+  {  // (read per call: a test narrows it to force the give-up path)
+    const char* e = getenv("HCTR_HT_SPIN_LIMIT");
+    c.spin_limit = e ? (uint32_t)strtoul(e, nullptr, 10) : kSpinLimit;
+  }
   // few positions: fewer workgroups (every one of them takes part in the barrier), and never more
   // than the device can hold at once (a CPX partition or a CU-masked device has far fewer than
   // 256 CUs: a grid that is not resident as a whole could only time out at its barrier)
@@ -993,6 +1053,28 @@ int HashTable::dump(int64_t* d_keys, uint64_t* d_vals, size_t* cnt, hipStream_t 
   return HCTR_OK;
 }
 
+int HashTable::recover(const void* keys, size_t n, hipStream_t s) {
+  if (n > 0) {
+    const int grid = grid_for(n, kBlock);
+    if (key_type == HCTR_KEY_U32)
+      hipLaunchKernelGGL(ht_unpend_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries, size,
+                         (const uint32_t*)keys, n, d_error);
+    else
+      hipLaunchKernelGGL(ht_unpend_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries, size,
+                         (const long long*)keys, n, d_error);
+    HCTR_LAUNCH_CHECK();
+  }
+  // the scalars of the insert protocol (not the row counter, not the error word): pending,
+  // latched, barrier {arrived, generation}, mask parity -- and both mask buffers / region counts
+  HCTR_HIP(hipMemsetAsync(d_pending, 0, sizeof(uint32_t), s));
+  HCTR_HIP(hipMemsetAsync(d_latched, 0, sizeof(uint32_t), s));
+  HCTR_HIP(hipMemsetAsync(d_barrier, 0, 2 * sizeof(uint32_t), s));
+  HCTR_HIP(hipMemsetAsync(d_parity, 0, sizeof(uint32_t), s));
+  if (fin_masks)
+    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4, s));
+  return HCTR_OK;
+}
+
 int HashTable::error_flags(hipStream_t s, uint32_t* out) {
   HCTR_HIP(hipMemcpyAsync(out, d_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HCTR_HIP(hipStreamSynchronize(s));
@@ -1089,6 +1171,16 @@ int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* 
                  hctr_stream_t stream) {
   HCTR_REQUIRE(ht && d_keys && d_vals && count, "null pointer");
   return ht->impl.dump(d_keys, d_vals, count, as_stream(stream));
+}
+
+int hctr_ht_error_flags(hctr_hashtable* ht, hctr_stream_t stream, uint32_t* out) {
+  HCTR_REQUIRE(ht && out, "null pointer");
+  return ht->impl.error_flags(as_stream(stream), out);
+}
+
+int hctr_ht_recover(hctr_hashtable* ht, const void* keys, size_t n, hctr_stream_t stream) {
+  HCTR_REQUIRE(ht && (n == 0 || keys), "null pointer");
+  return ht->impl.recover(keys, n, as_stream(stream));
 }
 
 }  // extern "C"

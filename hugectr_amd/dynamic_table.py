@@ -142,6 +142,13 @@ class DynamicEmbeddingTable:
         check(lib.hctr_det_capacity_per_class(self._h, out))
         return list(out)
 
+    def repair_count(self) -> int:
+        """inserting lookups whose hash index gave up at its grid barrier and were repaired and
+        issued again inside the call (hctr_det_repair_count)"""
+        out = ctypes.c_uint64()
+        check(lib.hctr_det_repair_count(self._h, ctypes.byref(out)))
+        return int(out.value)
+
     def size(self) -> int:
         return sum(self.size_per_class())
 

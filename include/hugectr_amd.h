@@ -77,6 +77,18 @@ size_t hctr_ht_table_size(const hctr_hashtable* ht);
 /* dump occupied (key,val) pairs; d_keys device int64 [>=size], d_vals device uint64; host-syncs */
 int hctr_ht_dump(hctr_hashtable* ht, int64_t* d_keys, uint64_t* d_vals, size_t* count,
                  hctr_stream_t stream);
+/* Error word of the map (host-syncs): bit 0 = a probe met a full table (the reference: `end()`,
+ * only a debug assert, nv_hashtable.cu:61-72), bit 1 = more new keys than free rows (what
+ * check_overflow() reports, localized_slot_sparse_embedding_hash.hpp:552-569), bit 2 (value 4) =
+ * the cooperative second launch of a get_insert could not get all its workgroups onto the device
+ * and gave up: then NO unseen key of that call received a row (all-or-nothing; they read SIZE_MAX)
+ * and every later get_insert gives up the same way until hctr_ht_recover or hctr_ht_clear.
+ * The reference has no counterpart (its insert is one kernel with a racing atomicAdd). */
+int hctr_ht_error_flags(hctr_hashtable* ht, hctr_stream_t stream, uint32_t* out);
+/* After error bit 2: `keys` = the keys of every get_insert since the one that gave up.  Puts the
+ * map back as it was before those calls (their claimed slots read as erased keys) and clears the
+ * bit; the calls can then be issued again and hand out the rows an undisturbed run would have. */
+int hctr_ht_recover(hctr_hashtable* ht, const void* keys, size_t n, hctr_stream_t stream);
 
 /* forward_sum / forward_mean: R/HugeCTR/src/embeddings/forward_per_gpu_functor.cu:28-241.
  * out[u,:] = sum_j table[value_index[row_offset[u]+j],:]  (SIZE_MAX index adds 0; combiner 1
@@ -575,6 +587,11 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
 int hctr_det_clear(hctr_det* h, hctr_stream_t stream);
 int hctr_det_size_per_class(hctr_det* h, size_t* sizes, hctr_stream_t stream); /* host sync */
 int hctr_det_capacity_per_class(const hctr_det* h, size_t* capacities);
+/* Inserting lookups whose hash index gave up (hctr_ht_error_flags bit 2) and were repaired and
+ * issued again inside the call, since create.  Every inserting hctr_det_* call verifies its index
+ * before it uses a row (one wait for the stream); an error it cannot repair is HCTR_ERR_HIP, never
+ * a silently missing row. */
+int hctr_det_repair_count(const hctr_det* h, uint64_t* out);
 
 /* embedding::DynamicEmbeddingTable::update (R/HugeCTR/embedding_storage/dynamic_embedding.cu:176-330,
  * optimizers.cuh:29-233): optimizer step on the unique keys of a batch.  wgrad holds the summed

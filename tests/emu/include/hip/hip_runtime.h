@@ -327,6 +327,8 @@ static inline void hipemu_atomic_store(T* p, V v) {
 #define __hip_atomic_fetch_or(p, v, order, scope) __atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_and(p, v, order, scope) __atomic_fetch_and((p), (v), __ATOMIC_SEQ_CST)
 #define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), __ATOMIC_SEQ_CST)
+#define __hip_atomic_compare_exchange_strong(p, expected, desired, so, fo, scope) \
+  __atomic_compare_exchange_n((p), (expected), (desired), false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_min(p, v, order, scope) hipemu_fetch_min((p), (v))
 #define __hip_atomic_fetch_max(p, v, order, scope) hipemu_fetch_max((p), (v))
 

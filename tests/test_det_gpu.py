@@ -211,3 +211,46 @@ def test_state_store_shares_the_row_numbers_travels_with_growth_and_clears():
     assert mixed.row_store() == (None, 0)
     with pytest.raises(_lib.HugeCTRAmdError, match="flat row store"):
         mixed.state_store(1)
+
+
+def test_an_index_that_gives_up_is_repaired_inside_the_call_never_a_silent_zero(monkeypatch):
+    """a finish kernel whose grid barrier does not open used to leave "no row"
+    at the batch's unseen keys -- pooled as zeros, skipped by the update, reported by nobody.
+    HCTR_HT_SPIN_LIMIT=0 forces that path on every inserting lookup with more than one finish
+    workgroup: the calls must still return what an undisturbed table returns (same row numbers,
+    same vectors, same sizes), and the table must say that it repaired them."""
+    import torch
+    from hugectr_amd.dynamic_table import DynamicEmbeddingTable
+    rng = np.random.default_rng(3)
+    dims = [16, 16, 16]
+
+    def run(disturbed):
+        t = DynamicEmbeddingTable(dims, "", initial_capacity=4096, seed=11)
+        outs = []
+        r = np.random.default_rng(5)
+        for it in range(3):
+            ns = [int(r.integers(9000, 30000)) for _ in dims]
+            keys = np.concatenate([r.integers(0, 60000 * (it + 1), size=n) for n in ns]).astype(np.int64)
+            so = np.concatenate([[0], np.cumsum(ns)]).tolist()
+            if disturbed:
+                monkeypatch.setenv("HCTR_HT_SPIN_LIMIT", "0")
+            kt = _dev(torch, keys)
+            if it == 1:  # the plain lookup (vectors packed back to back)
+                outs.append(t.lookup(kt, [0, 1, 2], so).cpu().numpy())
+            else:        # the embedding_collection's call: table-wide row numbers
+                _, rows, base = t.lookup_rows(kt, [0, 1, 2], so, insert=True, want_ptrs=False)
+                outs.append(rows.cpu().numpy())
+                outs.append(np.asarray(base))
+            monkeypatch.delenv("HCTR_HT_SPIN_LIMIT", raising=False)
+            outs.append(np.asarray(t.size_per_class()))
+        # every key of the last batch is in the table (a find-only pass meets no "no row")
+        _, rows, _ = t.lookup_rows(kt, [0, 1, 2], so, insert=False, want_ptrs=False)
+        assert int((rows < 0).sum()) == 0
+        return outs, t.repair_count()
+
+    clean, n_clean = run(False)
+    forced, n_forced = run(True)
+    assert n_clean == 0 and n_forced >= 3, (n_clean, n_forced)
+    assert len(clean) == len(forced)
+    for a, b in zip(clean, forced):
+        assert np.array_equal(a, b)

@@ -279,3 +279,48 @@ def test_get_insert_many_batches_of_every_shape(oracle, key_bytes):
     assert (res[:live].view(np.uint64) == ref.get_insert(keys[:live])).all()
     assert (res[live:] == -7).all()
     assert g.size() == ref.size()
+
+
+def test_a_grid_barrier_that_gives_up_is_all_or_nothing_sticky_and_recoverable(oracle, monkeypatch):
+    """HCTR_HT_SPIN_LIMIT=0: a workgroup of the cooperative finish kernel that has to wait at the
+    grid barrier gives up at its first poll.  Then (1) NO unseen key of the batch has a row (the
+    known keys keep theirs), error bit 2 (value 4) is set; (2) the next inserting batch fails the
+    same way instead of reading the slots the first one left pending as its own; (3) after
+    hctr_ht_recover over the keys of both batches the same two batches resolve to exactly the rows
+    of the sequential oracle (the row counter never moved)."""
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(7)
+    cap = 1 << 17
+    g, ref = GpuHT(cap, _lib.KEY_I64), oracle.HashTable(cap, 8)
+    warm = rng.integers(0, 1 << 40, size=3000).astype(np.int64)
+    assert (g.get_insert(_mk(torch, warm, torch.int64)) == ref.get_insert(warm)).all()
+    # > 4096 positions per finish workgroup: 40 000 keys -> 10 workgroups at the barrier
+    b1 = np.concatenate([rng.integers(0, 1 << 40, size=37000), warm[:3000]]).astype(np.int64)
+    rng.shuffle(b1)
+    b2 = np.concatenate([rng.integers(0, 1 << 40, size=9000), b1[:1000]]).astype(np.int64)
+
+    def flags():
+        e = ctypes.c_uint32()
+        _lib.check(_lib.lib.hctr_ht_error_flags(g.h, _lib.stream_ptr(), ctypes.byref(e)))
+        return e.value
+
+    head0 = g.value_head()
+    monkeypatch.setenv("HCTR_HT_SPIN_LIMIT", "0")
+    r1 = g.get_insert(_mk(torch, b1, torch.int64))
+    assert flags() == 4
+    known = np.isin(b1, warm)
+    want_known = ref.get_mark(b1)  # (find only: the oracle's table is not touched)
+    assert (r1[known] == want_known[known]).all()
+    assert (r1[~known] == np.uint64(0xFFFFFFFFFFFFFFFF)).all(), "a position got a row from a barrier that gave up"
+    r2 = g.get_insert(_mk(torch, b2, torch.int64))
+    assert flags() == 4 and g.value_head() == head0
+    k2 = np.isin(b2, warm)
+    assert (r2[~k2] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+    monkeypatch.delenv("HCTR_HT_SPIN_LIMIT")
+    both = _mk(torch, np.concatenate([b1, b2]), torch.int64)
+    _lib.check(_lib.lib.hctr_ht_recover(g.h, _lib.ptr(both), both.numel(), _lib.stream_ptr()))
+    assert flags() == 0 and g.size() == ref.size()
+    assert (g.get_insert(_mk(torch, b1, torch.int64)) == ref.get_insert(b1)).all()
+    assert (g.get_insert(_mk(torch, b2, torch.int64)) == ref.get_insert(b2)).all()
+    assert flags() == 0 and g.size() == ref.size() and g.value_head() == ref.value_head()
