@@ -13,7 +13,10 @@
 // on std::random_device as in the reference), and growth is a doubling re-allocation + re-index.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -324,11 +327,124 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// HCTR_DET_TRACE=1: wall time of the pieces of a growth step, to stderr
+struct GrowTrace {
+  bool on;
+  double t0;
+  const char* what;
+  static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  explicit GrowTrace(const char* w) : what(w) {
+    static const bool e = [] { const char* v = getenv("HCTR_DET_TRACE"); return v && v[0] == '1'; }();
+    on = e;
+    t0 = on ? now() : 0.0;
+  }
+  void lap(const char* piece) {
+    if (!on) return;
+    const double t = now();
+    fprintf(stderr, "[det] %s: %s %.3f ms\n", what, piece, (t - t0) * 1e3);
+    t0 = t;
+  }
+};
+
+// ---- growing arrays --------------------------------------------------------------------------
+// A table's rows (and, for the flat row store's users, its optimizer state) live in ONE reserved
+// address range per array, class c in the region [c * stride_rows rows, (c + 1) * stride_rows rows);
+// physical memory is mapped behind the rows a class holds in pieces of one size as the class
+// grows (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess).  A row never moves:
+// growth copies nothing, frees nothing, allocates the increment only.  Why not hipMalloc + copy +
+// hipFree (rounds 3-5): a single hipMalloc of 8-20 GB on a device that has seen some traffic was
+// measured at 1.6 - 3.3 s every few calls (profiles/r6_vmm_probe.txt, r6_dyn_growth_trace.txt),
+// next to 3 us + 20 us - 3 ms for creating and mapping a piece.  Measured rules of this runtime
+// (ROCm 7.2, tools/vmm_probe.hip): the pieces of a range must all have ONE size (hipMemSetAccess
+// fails with "invalid argument" at the first piece larger than its predecessors), so the piece
+// size is a process-wide constant; reserving, freeing and reserving again is fine.
+inline size_t vm_piece_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("HCTR_DET_PIECE_MB");  // (a power of two; experiments only)
+    size_t mb = e ? (size_t)atol(e) : 64;
+    if (mb < 2) mb = 2;
+    size_t p = 2;
+    while (p < mb) p *= 2;
+    return p << 20;
+  }();
+  return v;
+}
+
+struct VmArray {
+  char* base = nullptr;
+  size_t va_bytes = 0;
+  struct Piece {
+    size_t off;
+    hipMemGenericAllocationHandle_t h;
+  };
+  std::vector<Piece> pieces;
+};
+
+int vm_reserve(VmArray& a, size_t bytes) {
+  hipDeviceptr_t p = nullptr;
+  if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess || p == nullptr) {
+    (void)hipGetLastError();
+    set_error("dynamic table: hipMemAddressReserve of " + std::to_string(bytes >> 30) + " GiB failed");
+    return HCTR_ERR_HIP;
+  }
+  a.base = (char*)p;
+  a.va_bytes = bytes;
+  return HCTR_OK;
+}
+
+// physical pieces behind [off, off + bytes) (both multiples of the piece size, nothing mapped there yet)
+int vm_map(VmArray& a, size_t off, size_t bytes, bool zero, hipStream_t s) {
+  const size_t piece = vm_piece_bytes();
+  int dev = 0;
+  HCTR_HIP(hipGetDevice(&dev));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  hipMemAccessDesc acc = {};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (size_t o = off; o < off + bytes; o += piece) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("dynamic table: out of device memory (hipMemCreate of a " +
+                std::to_string(piece >> 20) + " MiB piece)");
+      return HCTR_ERR_HIP;
+    }
+    if (hipMemMap(a.base + o, piece, 0, h, 0) != hipSuccess ||
+        hipMemSetAccess(a.base + o, piece, &acc, 1) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipMemRelease(h);
+      set_error("dynamic table: hipMemMap / hipMemSetAccess failed");
+      return HCTR_ERR_HIP;
+    }
+    a.pieces.push_back({o, h});
+  }
+  if (zero && bytes) HCTR_HIP(hipMemsetAsync(a.base + off, 0, bytes, s));
+  return HCTR_OK;
+}
+
+void vm_release(VmArray& a) {
+  const size_t piece = vm_piece_bytes();
+  for (const VmArray::Piece& p : a.pieces) {
+    (void)hipMemUnmap(a.base + p.off, piece);
+    (void)hipMemRelease(p.h);
+  }
+  a.pieces.clear();
+  if (a.base) (void)hipMemAddressFree(a.base, a.va_bytes);
+  a.base = nullptr;
+  a.va_bytes = 0;
+}
+
 struct DetClass {
   HashTable ht;
-  float* rows = nullptr;  // (inside hctr_det::arena when the table keeps one row store)
-  bool owns_rows = true;
-  size_t cap = 0;         // rows allocated == ht.capacity
+  float* rows = nullptr;  // the class's region of hctr_det::rows_va (fixed for the table's life)
+  size_t mapped = 0;      // bytes of the region that have memory behind them (a multiple of the piece)
+  size_t cap = 0;         // rows the class may hand out == ht.capacity; cap * row bytes <= mapped
   int dim = 0;
   size_t head_bound = 0;  // host upper bound of the row counter (value head)
   unsigned long long* d_erased = nullptr;
@@ -346,17 +462,21 @@ struct hctr_det {
   float init_val = 0.f;
   uint64_t seed = 0;
   uint64_t adam_times = 0;
-  // Classes of ONE dimension (an embedding_collection group always: one ev_size) keep their rows in
-  // one allocation, class c at row sum(cap of the classes before it): the table-wide row numbers
-  // that hctr_det_lookup_rows hands out are then rows of one flat [arena_rows][dim] table, and the
-  // static tables' gather and sparse-update kernels run on a dynamic table as they are
-  // (hctr_det_row_store).  A class that grows re-lays the arena out (doubling: amortised).
-  float* arena = nullptr;
+  // Row store: class c owns rows [c * stride_rows, c * stride_rows + cap_c) of rows_va (VmArray
+  // above).  Classes of ONE dimension (an embedding_collection group always: one ev_size): the
+  // table-wide row numbers that hctr_det_lookup_rows hands out are then rows of one flat
+  // [arena_rows = classes * stride_rows][dim] table (sparsely backed), and the static tables'
+  // gather and sparse-update kernels run on a dynamic table as they are (hctr_det_row_store).
+  VmArray rows_va;
+  size_t stride_rows = 0;             // a power of two; classes * stride_rows < 2^32 - 16
+  std::vector<size_t> region_off;     // byte offset of every class's region in rows_va (+ total)
+  float* arena = nullptr;             // rows_va.base when the classes share a dimension, else null
   size_t arena_rows = 0;
-  // optimizer state of the flat row store's users (hctr_det_state_store): n_state arrays
-  // [arena_rows][dim] fp32, zero for a row nobody updated yet -- what the reference's state table
+  // optimizer state of the flat row store's users (hctr_det_state_store): n_state arrays laid out
+  // and backed like the rows, zero for a row nobody updated yet -- what the reference's state table
   // ("zeros" initializer, one entry per updated key, dynamic_embedding.cu:227-317) holds for a key,
-  // at the key's weight row: the state needs no probe of its own.  They travel with the arena.
+  // at the key's weight row: the state needs no probe of its own.
+  VmArray state_va[2];
   float* state_arena[2] = {nullptr, nullptr};
   int n_state = 0;
   uint64_t* idx = nullptr;  // scratch row indices
@@ -397,12 +517,10 @@ int det_scratch(hctr_det* h, size_t n) {
   return HCTR_OK;
 }
 
-int class_create(DetClass& c, size_t cap, int dim, int key_type, bool owns_rows) {
+int class_create(DetClass& c, size_t cap, int dim, int key_type) {
   c.dim = dim;
   c.cap = cap;
-  c.owns_rows = owns_rows;
   HCTR_TRY(c.ht.create(cap, key_type));
-  if (owns_rows) HCTR_HIP(hipMalloc(&c.rows, cap * (size_t)dim * sizeof(float)));
   HCTR_HIP(hipMalloc(&c.d_erased, sizeof(unsigned long long)));
   HCTR_HIP(hipMemset(c.d_erased, 0, sizeof(unsigned long long)));
   c.head_bound = 0;
@@ -411,66 +529,46 @@ int class_create(DetClass& c, size_t cap, int dim, int key_type, bool owns_rows)
 
 void class_destroy(DetClass& c) {
   c.ht.destroy();
-  if (c.rows && c.owns_rows) (void)hipFree(c.rows);
   if (c.d_erased) (void)hipFree(c.d_erased);
   c.rows = nullptr;
   c.d_erased = nullptr;
 }
 
-// make room for n more rows (cuco::dynamic_map::reserve): doubling re-allocation of the row store
-// and a re-index of the live keys into a table of the new capacity (tombstones are dropped)
-// one allocation for the row stores of all classes, class ci at row sum(cap[0..ci)); rows
-// [0, keep[ci]) of every class travel to their new place
-int arena_layout(hctr_det* h, const std::vector<size_t>& cap, const std::vector<size_t>& keep,
-                 hipStream_t s) {
-  const size_t dim = (size_t)h->cls[0].dim;
-  size_t total = 0;
-  for (size_t v : cap) total += v;
-  float* na = nullptr;
-  HCTR_HIP(hipMalloc(&na, total * dim * sizeof(float)));
-  float* ns[2] = {nullptr, nullptr};
-  for (int k = 0; k < h->n_state; k++) {
-    HCTR_HIP(hipMalloc(&ns[k], total * dim * sizeof(float)));
-    HCTR_HIP(hipMemsetAsync(ns[k], 0, total * dim * sizeof(float), s));
+// memory behind rows [0, rows) of class ci, in every array the table keeps (state: zero-filled)
+int class_map(hctr_det* h, size_t ci, size_t rows, hipStream_t s) {
+  DetClass& c = h->cls[ci];
+  if (rows > h->stride_rows) {
+    set_error("dynamic table: class " + std::to_string(ci) + " needs " + std::to_string(rows) +
+              " rows, its address range holds " + std::to_string(h->stride_rows) +
+              " (2^32 row numbers shared by " + std::to_string(h->cls.size()) + " classes)");
+    return HCTR_ERR_INVALID_ARG;
   }
-  size_t base = 0;
-  for (size_t ci = 0; ci < h->cls.size(); ci++) {
-    DetClass& c = h->cls[ci];
-    if (c.rows != nullptr && keep[ci] > 0) {
-      HCTR_HIP(hipMemcpyAsync(na + base * dim, c.rows, keep[ci] * dim * sizeof(float),
-                              hipMemcpyDeviceToDevice, s));
-      const size_t old = (size_t)(c.rows - h->arena);  // (elements: the class's place in the old arena)
-      for (int k = 0; k < h->n_state; k++)
-        HCTR_HIP(hipMemcpyAsync(ns[k] + base * dim, h->state_arena[k] + old,
-                                keep[ci] * dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-    base += cap[ci];
-  }
-  HCTR_HIP(hipStreamSynchronize(s));
-  if (h->arena) (void)hipFree(h->arena);
-  for (int k = 0; k < h->n_state; k++) {
-    if (h->state_arena[k]) (void)hipFree(h->state_arena[k]);
-    h->state_arena[k] = ns[k];
-  }
-  h->arena = na;
-  h->arena_rows = total;
-  base = 0;
-  for (size_t ci = 0; ci < h->cls.size(); ci++) {
-    h->cls[ci].rows = na + base * dim;
-    h->cls[ci].cap = cap[ci];
-    base += cap[ci];
-  }
+  const size_t piece = vm_piece_bytes();
+  const size_t need = ceil_div<size_t>(rows * (size_t)c.dim * sizeof(float), piece) * piece;
+  if (need <= c.mapped) return HCTR_OK;
+  HCTR_TRY(vm_map(h->rows_va, h->region_off[ci] + c.mapped, need - c.mapped, false, s));
+  for (int k = 0; k < h->n_state; k++)
+    HCTR_TRY(vm_map(h->state_va[k], h->region_off[ci] + c.mapped, need - c.mapped, true, s));
+  c.mapped = need;
   return HCTR_OK;
 }
 
+// make room for n more rows (cuco::dynamic_map::reserve): the index is re-built at twice the
+// capacity (tombstones are dropped); the rows stay where they are and get more memory behind them
 int class_reserve(hctr_det* h, DetClass& c, size_t n, int key_type, hipStream_t s) {
   if (c.head_bound + n <= c.cap) return HCTR_OK;
   size_t head = 0;
+  GrowTrace tr("class_reserve");
   HCTR_TRY(c.ht.value_head(s, &head));  // synchronises: the exact row counter
   c.head_bound = head;
+  tr.lap("value_head (stream drained)");
   if (head + n <= c.cap) return HCTR_OK;
   size_t ncap = c.cap * 2;
   while (ncap < head + n) ncap *= 2;
+  if (ncap > h->stride_rows && head + n <= h->stride_rows) ncap = h->stride_rows;
+  const size_t ci = (size_t)(&c - h->cls.data());
+  HCTR_TRY(class_map(h, ci, ncap, s));
+  tr.lap("pieces mapped");
   // live (key, row) pairs of the old index
   int64_t* d_keys = nullptr;
   uint64_t* d_vals = nullptr;
@@ -493,30 +591,13 @@ int class_reserve(hctr_det* h, DetClass& c, size_t n, int key_type, hipStream_t 
     HCTR_TRY(nht.insert(d_keys, d_vals, live, s));
   }
   HCTR_TRY(nht.set_value_head(head, s));
-  if (h->arena != nullptr) {
-    // (head_bound: the host's upper bound of a class's row counter -- what lies above it was
-    //  never handed out)
-    std::vector<size_t> cap(h->cls.size()), keep(h->cls.size());
-    for (size_t ci = 0; ci < h->cls.size(); ci++) {
-      const DetClass& o = h->cls[ci];
-      cap[ci] = &o == &c ? ncap : o.cap;
-      keep[ci] = &o == &c ? head : (o.head_bound < o.cap ? o.head_bound : o.cap);
-    }
-    HCTR_TRY(arena_layout(h, cap, keep, s));
-  } else {
-    float* nrows = nullptr;
-    HCTR_HIP(hipMalloc(&nrows, ncap * (size_t)c.dim * sizeof(float)));
-    HCTR_HIP(hipMemcpyAsync(nrows, c.rows, head * (size_t)c.dim * sizeof(float),
-                            hipMemcpyDeviceToDevice, s));
-    HCTR_HIP(hipStreamSynchronize(s));
-    (void)hipFree(c.rows);
-    c.rows = nrows;
-    c.cap = ncap;
-  }
+  tr.lap("re-index");
   (void)hipFree(d_keys);
   (void)hipFree(d_vals);
   c.ht.destroy();
   c.ht = nht;
+  c.cap = ncap;
+  tr.lap("old index freed");
   // rows of erased keys stay allocated (indices are never reused); only the index forgets them
   return HCTR_OK;
 }
@@ -655,30 +736,67 @@ int hctr_det_create(size_t num_classes, const size_t* dimension_per_class, const
   }
   memset(h->h_err, 0, num_classes * sizeof(uint32_t));
   h->cls.resize(num_classes);
-  bool flat = true;  // one dimension: one row store (hctr_det::arena)
+  bool flat = true;  // one dimension: the row numbers index one flat table (hctr_det::arena)
   for (size_t i = 1; i < num_classes; i++) flat = flat && dimension_per_class[i] == dimension_per_class[0];
-  for (size_t i = 0; i < num_classes; i++) {
-    if (dimension_per_class[i] == 0 || dimension_per_class[i] > (1u << 20)) {
-      set_error("dimension_per_class out of range");
-      for (size_t j = 0; j < i; j++) class_destroy(h->cls[j]);
-      delete h;
-      return HCTR_ERR_INVALID_ARG;
-    }
-    const int rc = class_create(h->cls[i], cap, (int)dimension_per_class[i], key_type, !flat);
-    if (rc != HCTR_OK) {
-      for (size_t j = 0; j <= i; j++) class_destroy(h->cls[j]);
-      delete h;
-      return rc;
+  auto fail = [&](int rc) {
+    for (auto& c : h->cls) class_destroy(c);
+    vm_release(h->rows_va);
+    (void)hipHostFree(h->h_err);
+    delete h;
+    return rc;
+  };
+  {
+    int vmm = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess ||
+        vmm == 0) {
+      (void)hipGetLastError();
+      set_error("dynamic table: the device does not support virtual memory management");
+      return fail(HCTR_ERR_HIP);
     }
   }
-  if (flat) {
-    const std::vector<size_t> caps(num_classes, cap), none(num_classes, 0);
-    const int rc = arena_layout(h, caps, none, nullptr);
-    if (rc != HCTR_OK) {
-      for (auto& c : h->cls) class_destroy(c);
-      delete h;
-      return rc;
+  size_t max_row_bytes = 0;
+  for (size_t i = 0; i < num_classes; i++) {
+    if (dimension_per_class[i] == 0 || dimension_per_class[i] > (1u << 14)) {
+      set_error("dimension_per_class out of range (1 .. 16384)");
+      return fail(HCTR_ERR_INVALID_ARG);
     }
+    max_row_bytes = std::max(max_row_bytes, dimension_per_class[i] * sizeof(float));
+  }
+  // row numbers are 32-bit for the sparse update's sort: classes * stride_rows < 2^32 - 16; a
+  // region of at most 1 TiB, all regions of an array at most 16 TiB of addresses; a region is a
+  // whole number of pieces (stride_rows >= 2^24 rows of >= 4 bytes)
+  size_t stride = (size_t)1 << 28;
+  while (stride * num_classes > 0xFFF00000ull) stride >>= 1;
+  while (stride * max_row_bytes > ((size_t)1 << 40)) stride >>= 1;
+  while (stride > ((size_t)1 << 24) && stride * max_row_bytes * num_classes > ((size_t)16 << 40)) stride >>= 1;
+  if (stride < ((size_t)1 << 24) || stride * max_row_bytes * num_classes > ((size_t)16 << 40) ||
+      (stride * sizeof(float)) % vm_piece_bytes() != 0) {
+    set_error("dynamic table: too many classes for one table (at most 255, fewer for very long vectors)");
+    return fail(HCTR_ERR_INVALID_ARG);
+  }
+  if (cap > stride) {
+    set_error("dynamic table: initial capacity above the " + std::to_string(stride) +
+              " rows a class of this table can hold");
+    return fail(HCTR_ERR_INVALID_ARG);
+  }
+  h->stride_rows = stride;
+  h->region_off.assign(num_classes + 1, 0);
+  for (size_t i = 0; i < num_classes; i++)
+    h->region_off[i + 1] = h->region_off[i] + stride * dimension_per_class[i] * sizeof(float);
+  {
+    const int rc = vm_reserve(h->rows_va, h->region_off[num_classes]);
+    if (rc != HCTR_OK) return fail(rc);
+  }
+  for (size_t i = 0; i < num_classes; i++) {
+    int rc = class_create(h->cls[i], cap, (int)dimension_per_class[i], key_type);
+    h->cls[i].rows = reinterpret_cast<float*>(h->rows_va.base + h->region_off[i]);
+    if (rc == HCTR_OK) rc = class_map(h, i, cap, nullptr);
+    if (rc != HCTR_OK) return fail(rc);
+  }
+  if (flat) {
+    h->arena = reinterpret_cast<float*>(h->rows_va.base);
+    h->arena_rows = stride * num_classes;
   }
   (void)hipDeviceSynchronize();
   *out = h;
@@ -689,9 +807,8 @@ int hctr_det_destroy(hctr_det* h) {
   if (!h) return HCTR_OK;
   (void)hipDeviceSynchronize();
   for (auto& c : h->cls) class_destroy(c);
-  if (h->arena) (void)hipFree(h->arena);
-  for (float* p : h->state_arena)
-    if (p) (void)hipFree(p);
+  vm_release(h->rows_va);
+  for (VmArray& a : h->state_va) vm_release(a);
   if (h->idx) (void)hipFree(h->idx);
   if (h->idx2) (void)hipFree(h->idx2);
   if (h->ptr_w) (void)hipFree(h->ptr_w);
@@ -857,8 +974,8 @@ int hctr_det_lookup_rows(hctr_det* h, const void* keys, size_t num_keys, const s
   }
   const size_t ncls = h->cls.size();
   std::vector<uint64_t> base(ncls + 1, 0);
-  auto rebase = [&] {
-    for (size_t ci = 0; ci < ncls; ci++) base[ci + 1] = base[ci] + h->cls[ci].cap;
+  auto rebase = [&] {  // (fixed for the table's life: a class's region never moves)
+    for (size_t ci = 0; ci < ncls; ci++) base[ci + 1] = base[ci] + h->stride_rows;
   };
   rebase();
   if (num_keys) {
@@ -1056,12 +1173,12 @@ int hctr_det_state_store(hctr_det* h, int num_state, float** state0, float** sta
   HCTR_REQUIRE(num_state >= 1 && num_state <= 2, "num_state");
   HCTR_REQUIRE(h->arena != nullptr, "the table keeps no flat row store (classes of several dimensions)");
   hipStream_t s = as_stream(stream);
-  const size_t bytes = h->arena_rows * (size_t)h->cls[0].dim * sizeof(float);
   while (h->n_state < num_state) {
-    float* p = nullptr;
-    HCTR_HIP(hipMalloc(&p, bytes));
-    HCTR_HIP(hipMemsetAsync(p, 0, bytes, s));
-    h->state_arena[h->n_state++] = p;
+    VmArray& a = h->state_va[h->n_state];
+    HCTR_TRY(vm_reserve(a, h->rows_va.va_bytes));
+    for (size_t ci = 0; ci < h->cls.size(); ci++)  // behind what the rows have mapped so far
+      HCTR_TRY(vm_map(a, h->region_off[ci], h->cls[ci].mapped, true, s));
+    h->state_arena[h->n_state++] = reinterpret_cast<float*>(a.base);
   }
   *state0 = h->state_arena[0];
   if (state1) *state1 = h->state_arena[1];
@@ -1073,8 +1190,8 @@ int hctr_det_clear(hctr_det* h, hctr_stream_t stream) {
   hipStream_t s = as_stream(stream);
   // (rows are handed out from 0 again: their state starts from zero again)
   for (int k = 0; k < h->n_state; k++)
-    HCTR_HIP(hipMemsetAsync(h->state_arena[k], 0,
-                            h->arena_rows * (size_t)h->cls[0].dim * sizeof(float), s));
+    for (size_t ci = 0; ci < h->cls.size(); ci++)
+      HCTR_HIP(hipMemsetAsync(h->state_va[k].base + h->region_off[ci], 0, h->cls[ci].mapped, s));
   for (auto& c : h->cls) {
     HCTR_TRY(c.ht.clear(s));
     HCTR_HIP(hipMemsetAsync(c.d_erased, 0, sizeof(unsigned long long), s));

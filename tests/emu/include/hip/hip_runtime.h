@@ -4,6 +4,7 @@
 // host pointers; every call is synchronous, streams and events are ignored).
 #pragma once
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <atomic>
 #include <cmath>
@@ -153,17 +154,69 @@ template <typename F>
 static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) {
   return hipSuccess;
 }
-enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+enum hipDeviceAttribute_t {
+  hipDeviceAttributeMultiprocessorCount = 16,
+  hipDeviceAttributeVirtualMemoryManagementSupported = 10000
+};
 static inline hipError_t hipGetDevice(int* d) {
   *d = 0;
   return hipSuccess;
 }
-static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
-  *v = 256;
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+  *v = a == hipDeviceAttributeVirtualMemoryManagementSupported ? 1 : 256;
   return hipSuccess;
 }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) {
   return hipSuccess;
+}
+
+// ---- virtual memory management: a reserved range is an inaccessible anonymous mapping, a mapped
+//      piece is the same addresses made readable / writable (the host pages in what is touched) ----
+typedef void* hipDeviceptr_t;
+typedef size_t hipMemGenericAllocationHandle_t;  // (the piece's size)
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation {
+  hipMemLocationType type;
+  int id;
+};
+struct hipMemAllocationProp {
+  hipMemAllocationType type;
+  hipMemLocation location;
+};
+struct hipMemAccessDesc {
+  hipMemLocation location;
+  hipMemAccessFlags flags;
+};
+static inline hipError_t hipMemAddressReserve(hipDeviceptr_t* p, size_t bytes, size_t, void*,
+                                              unsigned long long) {
+  void* q = mmap(nullptr, bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (q == MAP_FAILED) return hipErrorOutOfMemory;
+  *p = q;
+  return hipSuccess;
+}
+static inline hipError_t hipMemAddressFree(hipDeviceptr_t p, size_t bytes) {
+  return munmap(p, bytes) == 0 ? hipSuccess : hipErrorInvalidValue;
+}
+static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t bytes,
+                                      const hipMemAllocationProp*, unsigned long long) {
+  *h = bytes;
+  return hipSuccess;
+}
+static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipSuccess; }
+static inline hipError_t hipMemMap(void* p, size_t bytes, size_t, hipMemGenericAllocationHandle_t h,
+                                   unsigned long long) {
+  return h == bytes && (reinterpret_cast<uintptr_t>(p) & 4095) == 0 ? hipSuccess : hipErrorInvalidValue;
+}
+static inline hipError_t hipMemSetAccess(void* p, size_t bytes, const hipMemAccessDesc*, size_t) {
+  if (mprotect(p, bytes, PROT_READ | PROT_WRITE) != 0) return hipErrorInvalidValue;
+  memset(p, 0xA5, bytes < (1u << 20) ? bytes : (1u << 20));  // fresh device memory holds garbage
+  return hipSuccess;
+}
+static inline hipError_t hipMemUnmap(void* p, size_t bytes) {
+  (void)madvise(p, bytes, MADV_DONTNEED);
+  return mprotect(p, bytes, PROT_NONE) == 0 ? hipSuccess : hipErrorInvalidValue;
 }
 static inline hipError_t hipEventCreate(hipEvent_t* e) {
   *e = nullptr;

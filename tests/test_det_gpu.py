@@ -152,10 +152,11 @@ def _rows_of(torch, addr, rows, ev):
     return out
 
 
-def test_state_store_shares_the_row_numbers_travels_with_growth_and_clears():
+def test_state_store_shares_the_row_numbers_stays_put_through_growth_and_clears():
     """hctr_det_state_store: zero for rows never updated, one array more when a later caller asks for
-    two, moved with the rows when a class grows (the rows of the OTHER classes move as well), zeroed
-    by clear(); refused for classes of several dimensions (no flat row store)."""
+    two; when a class grows NOTHING moves -- the row store's address, every class's row numbers and
+    the state behind them stay (memory is mapped behind the grown class, zero-filled for the
+    state); zeroed by clear(); refused for classes of several dimensions (no flat row store)."""
     import ctypes
     import torch
     from hugectr_amd import _lib
@@ -167,7 +168,12 @@ def test_state_store_shares_the_row_numbers_travels_with_growth_and_clears():
     k2 = torch.arange(500, 506, dtype=torch.int64).cuda()
     keys = torch.cat([k0, k2])
     _, rows, base = t.lookup_rows(keys, [0, 2], [0, 10, 16], want_ptrs=False)
-    assert base == [0, 16, 32, 48]
+    stride = base[1]  # rows of address range per class: a power of two, classes * stride < 2^32
+    assert base == [0, stride, 2 * stride, 3 * stride] and stride & (stride - 1) == 0
+    assert 3 * stride < 2**32 - 16 and stride >= 2**24
+    assert int(rows[:10].min()) == 0 and int(rows[10:].min()) == 2 * stride
+    store0, total0 = t.row_store()
+    assert total0 == 3 * stride
     s0, s1 = t.state_store(1)
     assert s0 and not s1
     assert float(_rows_of(torch, s0, rows, ev).abs().max()) == 0.0
@@ -189,13 +195,15 @@ def test_state_store_shares_the_row_numbers_travels_with_growth_and_clears():
         assert a0 == s0 and a1
         assert torch.equal(_rows_of(torch, a0, rows, ev), want)
         assert float(_rows_of(torch, a1, rows, ev).abs().max()) == 0.0
-        # class 1 grows (16 -> 64): every class's rows move, the state with them
+        # class 1 grows (16 -> 64): nobody's rows move, neither does the state
         k1 = torch.arange(1000, 1040, dtype=torch.int64).cuda()
         t.lookup_rows(k1, [1], [0, 40], want_ptrs=False)
         assert t.capacity_per_class() == [16, 64, 16]
         _, rows2, base2 = t.lookup_rows(keys, [0, 2], [0, 10, 16], insert=False, want_ptrs=False)
-        assert base2 == [0, 16, 80, 96] and not torch.equal(rows2, rows)
+        assert base2 == base and torch.equal(rows2, rows)
+        assert t.row_store() == (store0, total0)
         b0, b1 = t.state_store(2)
+        assert (b0, b1) == (a0, a1)
         assert torch.equal(_rows_of(torch, b0, rows2, ev), want)
         assert float(_rows_of(torch, b1, rows2, ev).abs().max()) == 0.0
         _, r1, _ = t.lookup_rows(k1, [1], [0, 40], insert=False, want_ptrs=False)

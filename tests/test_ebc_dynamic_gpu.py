@@ -396,9 +396,9 @@ def test_flat_row_store_stateful_optimizers_give_the_bits_of_the_unique_key_path
     place -- one probe per key (the forward's).  Same pooled vectors and the same table, bit for
     bit, as the reference's flow that HCTR_DYNAMIC_FLAT=0 keeps: unique keys -> wgrad -> probe of
     the weights + inserting probe of a state table keyed like them -> *_update_grad_kernel ->
-    scatter_add (dynamic_embedding.cu:227-330); the classes grow (rows AND state move) several
-    times on the way, and keys come back after steps in which they were absent (their state must
-    have travelled)."""
+    scatter_add (dynamic_embedding.cu:227-330); the classes grow several times on the way (memory
+    is mapped behind rows AND state, zero state for the new rows), and keys come back after steps in
+    which they were absent (their state must still be there)."""
     import torch
     import hugectr_amd as ha
     from hugectr_amd import _lib
@@ -442,7 +442,9 @@ def test_flat_row_store_stateful_optimizers_give_the_bits_of_the_unique_key_path
     nst = 2 if opt_name == "adam" else 1
     s0, s1 = flat.det.state_store(nst)
     store, total = flat.det.row_store()
-    assert s0 and (s1 if nst == 2 else True) and total == sum(caps[-1])
+    assert s0 and (s1 if nst == 2 else True)
+    # (row numbers: one power-of-two range of addresses per class, backed as far as the class grew)
+    assert total % len(caps[-1]) == 0 and total // len(caps[-1]) >= max(caps[-1]) and total < 2**32 - 16
     for c in range(len(flat.det.dims)):
         (ka, va), (kb, vb) = ptrs.det.export(c), flat.det.export(c)
         oa, ob = torch.argsort(ka), torch.argsort(kb)

@@ -45,11 +45,15 @@ for it in range(8):
     caps0 = sum(ebc.det.capacity_per_class())
     t0 = time.perf_counter()
     out = ebc.forward(keys, br)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
     if grad is None:
         grad = (torch.randn(out.shape, device=dev) * 1e-3).to(out.dtype)
     ebc.backward_and_update(grad)
     torch.cuda.synchronize()
-    steps.append({"ms": round((time.perf_counter() - t0) * 1e3, 2), "rows_before": caps0,
-                  "rows_after": sum(ebc.det.capacity_per_class())})
+    steps.append({"ms": round((time.perf_counter() - t0) * 1e3, 2),
+                  "forward_ms": round((t1 - t0) * 1e3, 2), "rows_before": caps0,
+                  "rows_after": sum(ebc.det.capacity_per_class()),
+                  "repairs": ebc.det.repair_count()})
 print(json.dumps({"optimizer": opt, "flat": os.environ.get("HCTR_DYNAMIC_FLAT", "1"),
                   "initial_capacity_per_class": cap, "steps": steps}))
