@@ -403,12 +403,9 @@ __global__ void __launch_bounds__(kBigThreads)
 template <bool BF>
 int launch_big(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = 2 * (kBigBM + kBigBN) * kGemmBK * 2;  // 128 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    HCTR_HIP(hipFuncSetAttribute((const void*)cross_gemm_nt16_big_kernel<BF>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  // (per device and cheap: asked on every launch rather than remembered per process)
+  HCTR_HIP(hipFuncSetAttribute((const void*)cross_gemm_nt16_big_kernel<BF>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((cross_gemm_nt16_big_kernel<BF>), dim3((unsigned)(g.tiles_m * g.tiles_n)),
                      dim3(kBigThreads), lds, s, g);
   HCTR_LAUNCH_CHECK();
@@ -454,12 +451,9 @@ constexpr int gemm_lds_bytes() {
 template <int BM, bool BF, int EPI, int STAGES>
 int launch_one(const GemmArgs& g, hipStream_t s) {
   constexpr int lds = gemm_lds_bytes<BM, STAGES>();
-  static bool attr_set = false;  // (above 64 KB the kernel has to be told)
-  if (lds > 65536 && !attr_set) {
+  if (lds > 65536)  // (above 64 KB the kernel has to be told -- per device, so on every launch)
     HCTR_HIP(hipFuncSetAttribute((const void*)cross_gemm_nt16_kernel<BM, BF, EPI, STAGES>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
   hipLaunchKernelGGL((cross_gemm_nt16_kernel<BM, BF, EPI, STAGES>),
                      dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(kGemmThreads), lds, s, g);
   HCTR_LAUNCH_CHECK();

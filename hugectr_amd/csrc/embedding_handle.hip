@@ -466,8 +466,9 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
   const bool fused_train = is_train != 0 && nnz > 0;
   // A finish kernel that timed out at its grid barrier (error bit 4) left this table's
   // first-occurrence masks and region counts half written: a later inserting batch would rank its
-  // keys against them.  Sticky: no further training batch until the caller has cleared the table
-  // (hctr_emb_init_params / load), which also clears the flag.
+  // keys against them, and the slots the batch claimed still hold PENDING | position.  Sticky: no
+  // further training batch until the caller has cleared the table with hctr_emb_reset (the one
+  // call that empties the hash index and zeroes this flag; init_params / load do neither).
   if (is_train && (*(volatile uint32_t*)e->h_err & 4u) != 0u) return report_ht_flags(4u);
   uint32_t* one_hot = bb.one_hot;
   uint32_t* one_hot_next = nullptr;
@@ -995,7 +996,8 @@ size_t hctr_emb_slots_on_rank(const hctr_embedding* e) { return e ? e->buckets_p
 static int report_ht_flags(uint32_t f) {
   if ((f & 4u) != 0u) {
     set_error("index stage: the cooperative finish kernel timed out at its grid barrier (device "
-              "partitioned or CU-masked below the kernel's grid?); the batch's unseen keys got no row");
+              "partitioned or CU-masked below the kernel's grid?); none of the batch's unseen keys got a row, "
+              "and no further training batch is taken until hctr_emb_reset has cleared the table");
     return HCTR_ERR_HIP;
   }
   if (f != 0u) {

@@ -2038,6 +2038,10 @@ inline bool plan_possible(const SparseUpdater& u, size_t buckets, size_t nnz) {
         nnz == buckets && nnz >= u.hot_min_n && nnz < 0x7FFFFFF0ull && lpr_ok &&
         u.scale_row_offset == nullptr))
     return false;
+  // (a gradient map -- the embedding_collection's transposed read -- is applied by the cold chain
+  //  for one-hot batches only, cold_reduce_kernel's grad_row(); a ragged batch with nnz == buckets
+  //  would read unmapped rows there: the sorting path, which maps in every case, takes those)
+  if (u.map_inner != 0u) return false;
   const size_t per_g = ceil_div<size_t>(nnz, (size_t)G);
   const size_t n_chunks = (size_t)G * ceil_div<size_t>(per_g, (size_t)kHotChunk);
   const char* ip_env = getenv("HCTR_SORT_IN_PLACE");

@@ -89,14 +89,15 @@ class DynamicEmbeddingTable:
 
     def row_store(self):
         """(address, rows) of the one flat fp32 table that the row numbers of lookup_rows index when
-        all classes share a dimension, else (None, 0).  Valid until the next inserting call."""
+        all classes share a dimension, else (None, 0).  Fixed for the table's life (memory is mapped
+        behind a class as it grows; rows never move)."""
         p, n = ctypes.c_void_p(), ctypes.c_uint64()
         check(lib.hctr_det_row_store(self._h, ctypes.byref(p), ctypes.byref(n)))
         return (p.value, int(n.value)) if p.value else (None, 0)
 
     def state_store(self, num_state: int):
         """(state0, state1 | None): addresses of the optimizer state arrays that share the row
-        numbers of row_store() (zeros for a row that was never updated).  Same validity."""
+        numbers of row_store() (zeros for a row that was never updated).  Fixed as well."""
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
         check(lib.hctr_det_state_store(self._h, int(num_state), ctypes.byref(a), ctypes.byref(b),
                                        stream_ptr()))

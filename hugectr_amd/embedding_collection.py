@@ -600,7 +600,7 @@ class EmbeddingCollection:
         self._dyn_rows, self._dyn_base = rows, base
         bm = direct and self.batch_major  # one GPU: pooled straight into the batch-major output
         if flat:
-            store, _ = self.det.row_store()  # (after the inserts: growing moves it)
+            store, _ = self.det.row_store()
             if direct:
                 check(lib.hctr_forward_pool_mapped(self.nb, self.ev, 0, ptr(self.out_range),
                                                    _lib.KEY_I64, ptr(rows), store, ptr(send),

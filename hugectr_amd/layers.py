@@ -196,6 +196,16 @@ def gemm_nt16(a, bt, epilogue=0, bias=None, x0=None, xl=None):
     returns (x0 * (a @ bt^T + bias) + xl, a @ bt^T + bias), epilogue 2 returns a @ bt^T + xl"""
     M, K = a.shape
     N = bt.shape[0]
+    # rows may be strided (a leading dimension), elements of a row may not; the epilogue operands
+    # are read as [M, N] with leading dimension N
+    if a.stride(1) != 1:
+        a = a.contiguous()
+    if bt.stride(1) != 1:
+        bt = bt.contiguous()
+    assert bt.shape[1] == K and a.dtype == bt.dtype
+    bias, x0, xl = (t if t is None or t.is_contiguous() else t.contiguous() for t in (bias, x0, xl))
+    assert x0 is None or x0.shape == (M, N)
+    assert xl is None or xl.shape == (M, N)
     c = torch.empty((M, N), dtype=a.dtype, device=a.device)
     h = torch.empty_like(c) if epilogue == 1 else None
     check(lib.hctr_gemm_nt16(M, N, K, ptr(a), a.stride(0), ptr(bt), bt.stride(0), ptr(c), N, epilogue,
@@ -223,7 +233,10 @@ class _CrossV2Fn(torch.autograd.Function):
         xs, ps, hs = [x0], [], []
         xl = x0
         w, p = U.shape[1], U.shape[2]
-        own = _own_gemm_ok(x0, p, w) and _own_gemm_ok(x0, w, p)
+        # (hctr_convert_transpose16 reads U / V as fp32: 16-bit parameters -- module.half() -- take
+        #  the library GEMMs; the epilogue operands are read with leading dimension N)
+        own = (_own_gemm_ok(x0, p, w) and _own_gemm_ok(x0, w, p) and
+               U.dtype == torch.float32 and V.dtype == torch.float32 and x0.is_contiguous())
         bt = b.to(T)
         if own:
             # the 16-bit copies of the master weights as they lie (backward) and transposed (the

@@ -542,24 +542,34 @@ int hctr_det_remove(hctr_det* h, const void* keys, size_t num_keys, const size_t
 int hctr_det_export(hctr_det* h, size_t class_index, void* keys, float* values, size_t num_keys,
                     size_t* exported, hctr_stream_t stream);
 /* row indices of keys in one class's row store (insert != 0: unseen keys are inserted and
- * initialised; else unseen -> SIZE_MAX) and the store itself ([capacity][dim] fp32; the pointer
- * changes when the table grows): lets the path's gather / update kernels run on dynamic tables */
+ * initialised; else unseen -> SIZE_MAX) and the store itself ([capacity][dim] fp32; the pointer is
+ * fixed for the table's life -- growth maps memory behind it): lets the path's gather / update
+ * kernels run on dynamic tables */
 int hctr_det_lookup_index(hctr_det* h, size_t class_index, const void* keys, size_t num_keys,
                           int insert, uint64_t* row_index, hctr_stream_t stream);
 int hctr_det_rows(hctr_det* h, size_t class_index, float** rows, size_t* capacity);
-/* A table whose classes share ONE dimension (an embedding_collection group: one ev_size) keeps all
- * rows in one allocation, class c from row class_row_base[c] on, so the table-wide row numbers of
- * hctr_det_lookup_rows index one flat [total_rows][dim] fp32 table: the static tables' gather
+/* Storage: every class owns a fixed region of ONE reserved address range per table, stride_rows
+ * (a power of two >= 2^24, classes * stride_rows < 2^32 - 16) rows long, and physical memory is
+ * mapped behind the rows it holds as it grows (hipMemAddressReserve / hipMemMap) -- where the
+ * reference's cuCollections map adds sub-maps
+ * (R/third_party/dynamic_embedding_table/dynamic_embedding_table.cu), here a row never moves, a
+ * growth step copies nothing and allocates its increment only.  Limits that follow: at most 255
+ * classes per table, vectors of at most 16384 floats, stride_rows rows per class.
+ * A table whose classes share ONE dimension (an embedding_collection group: one ev_size): class c
+ * owns rows [class_row_base[c], class_row_base[c] + capacity_c), class_row_base[c] = c *
+ * stride_rows, so the table-wide row numbers of
+ * hctr_det_lookup_rows index one flat (sparsely backed) [total_rows][dim] fp32 table: the static tables' gather
  * (hctr_forward_pool*) and sparse update (hctr_updater_update) then run on a dynamic table as they
  * are -- embedding::DynamicEmbeddingTable::lookup + update
  * (R/HugeCTR/embedding_storage/dynamic_embedding.cu:130-330) without the pointer list, the unique
  * list and the wgrad buffer in between.  *rows = NULL when the classes differ in dimension.  The
- * pointer (and every class's hctr_det_rows pointer) changes when ANY class grows, i.e. only
- * inside a call that inserts. */
+ * pointer, every class's hctr_det_rows pointer, class_row_base and every row number handed out
+ * stay valid for the table's life; only rows below a class's capacity have memory behind them. */
 int hctr_det_row_store(hctr_det* h, float** rows, uint64_t* total_rows);
 /* Optimizer state of the flat row store: num_state (1 or 2) arrays [total_rows][dim] fp32 that
- * share the row numbers of hctr_det_row_store, allocated (zero-filled, on `stream`) by the first
- * call that asks for them and moved with the rows when a class grows.  A row nobody updated yet
+ * share the row numbers (and the backing, piece for piece) of hctr_det_row_store, created
+ * (zero-filled, on `stream`) by the first call that asks for them; memory mapped behind a class that
+ * grows is zero-filled as well, the addresses never change.  A row nobody updated yet
  * holds zeros -- what the reference's state table (a second DynamicEmbeddingTable with the "zeros"
  * initializer, keyed like the weights: embedding::DynamicEmbeddingTable::update,
  * R/HugeCTR/embedding_storage/dynamic_embedding.cu:227-317) hands out for a key it meets first.
