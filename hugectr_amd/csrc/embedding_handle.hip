@@ -546,7 +546,7 @@ int forward_typed(hctr_embedding* e, int is_train, const K* ro_in, const K* keys
     const bool pw_few_new = (pw_env && pw_env[0] == '2') ||
                             (e->post_new != ~0ull && e->post_new * 4 < nnz);
     if (is_train && !ahead && e->p.world == 1 && pw_on && pw_few_new &&
-        !(e->opt.optimizer == HCTR_OPT_SGD && (e->opt.atomic_update || e->opt.order_free))) {
+        !(e->opt.optimizer == HCTR_OPT_SGD && e->opt.atomic_update)) {
       e->upd.one_hot_flag = batch_one_hot;
       e->upd.scale_row_offset = nullptr;
       const int prc = e->upd.prework(buckets, nnz, e->p.combiner, ro, e->p.key_type,
@@ -742,10 +742,7 @@ int hctr_emb_create(const hctr_embedding_params* params, hctr_embedding** out) {
   e->opt.epsilon = p.epsilon;
   e->opt.momentum_factor = p.momentum_factor;
   e->opt.scaler = p.scaler;
-  // atomic_update: 1 = the reference's literal kernel (fp32 atomicAdd per element), 2 = its
-  // PERMISSION only (the order of a row's additions is free where that is faster), 0 = ordered
-  e->opt.atomic_update = p.atomic_update == 1 ? 1 : 0;
-  e->opt.order_free = p.atomic_update == 2 ? 1 : 0;
+  e->opt.atomic_update = p.atomic_update;
   // OptimizerTensor<TypeEmbeddingComp>: fp16 embeddings keep their optimizer state in fp16
   e->opt.state_half = p.out_dtype == HCTR_EMB_F16 ? 1 : 0;
   if (hipMemset(e->slot_id, 0, V * sizeof(uint64_t)) != hipSuccess ||

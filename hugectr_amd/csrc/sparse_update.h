@@ -12,11 +12,6 @@ struct OptState {
   float momentum_factor = 0.f;
   float scaler = 1.f;
   int atomic_update = 0;
-  // plain SGD only: the order in which the gradients of a row are added is the caller's to give up
-  // (the reference's default atomic_update = true does: an fp32 atomicAdd per element in arrival
-  // order, sparse_optimizer.cu:564-582).  Then the hot rows of a one-hot batch are summed inside
-  // LDS in arrival order (hot_accum_kernel); everything else keeps its fixed association.
-  int order_free = 0;
   float ftrl_lambda1 = 0.f, ftrl_lambda2 = 0.f, ftrl_beta = 0.f;  // EBC static tables only
   uint64_t times = 0;  // Adam step counter (incremented before each update)
   int state_half = 0;  // optimizer state holds fp16 values (fp16 embeddings)

@@ -1362,201 +1362,6 @@ __global__ void __launch_bounds__(kBlock, 5)  // (<= 102 VGPRs: leaves room for 
   }
 }
 
-// ---- hot rows, order-free form (round 6) -------------------------------------------------------
-// hot_sort -> hot_reduce -> hot_join are three dependent launches whose only purpose is a FIXED
-// order of the additions inside a chunk: an LDS sort (a latency chain at 416 workgroups), a gather
-// of the gradient rows in sorted order through HBM lists, partial sums of tile-crossing runs that
-// travel through HBM once more.  Where the caller has said that the order of the additions is free
-// -- plain SGD under the reference's own default atomic_update = true, whose kernel is an fp32
-// atomicAdd per element in arrival order (R/HugeCTR/src/optimizers/sparse_optimizer.cu:564-582,
-// 652-660) -- one launch does the chunk's work: the workgroup of a chunk marks the hot
-// rows the chunk meets in an LDS bitmap (their rank among the marked rows = the row's accumulator
-// and the number of its partial), streams the chunk's hot gradient rows ONCE, in whatever order its
-// lane groups get to them, and adds them into fp32 accumulators in LDS (ds_add_f32); the
-// accumulators leave as the chunk's partial sums and hot_apply_kernel adds the partials of a row
-// in chunk order as before.  What is order-free is the sum INSIDE one chunk of <= 4096 positions;
-// across chunks the association is still fixed.  Bound (fp32, any order of n additions):
-// |err| <= (n - 1) * eps * sum |g_i| per element -- the same bound the ordered form is held to
-// (INTEGRATION.md section 3), with n <= 4096 per partial.
-// LDS: vectors of more than 256 bytes are taken in two column halves one after the other, and a
-// chunk that meets more hot rows than fit (kAccLdsBytes of accumulators) takes them in windows of
-// cap_rows; every gradient element is read exactly once in any case.
-constexpr int kAccBlock = 512;
-constexpr int kAccWaves = kAccBlock / 64;
-constexpr int kAccRounds = kHotChunk / kAccBlock;  // positions per thread
-constexpr int kAccWords = kHotMaxRows / 32;        // bitmap words (512)
-constexpr int kAccMaxWin = 64;
-constexpr int kAccLdsBytes = 56 * 1024;            // accumulators (two workgroups per CU)
-constexpr int kAccFixedWords = 2 * kAccWords + kHotChunk + 2 * kAccMaxWin + 2;
-static_assert(kAccWords == kAccBlock, "one thread per bitmap word");
-
-template <int LPR, typename GradT>
-__global__ void __launch_bounds__(kAccBlock, 2)
-    hot_accum_kernel(HotGeom hg, const uint32_t* __restrict__ one_hot,
-                     const uint64_t* __restrict__ value_index, const GradT* __restrict__ grad,
-                     float* __restrict__ pool_end, HotBufs hb, uint32_t cap_rows) {
-  typedef typename Load4<GradT>::raw Raw;
-  constexpr int D = LPR * 4;
-  constexpr int NH = D > 64 ? 2 : 1;  // column halves, one after the other
-  constexpr int DW = D / NH;          // columns per pass
-  constexpr int LG = DW / 4;          // lanes per position
-  constexpr int NG = kAccBlock / LG;  // lane groups
-  constexpr int QB = 8;               // gradient pieces in flight per lane
-  if (blockIdx.x == 0 && threadIdx.x == 0)
-    hb.counts_next[0] = hb.counts_next[1] = hb.counts_next[2] = 0u;
-  if (*one_hot == 0u) return;
-  HCTR_DYN_LDS16(uint32_t, lds);
-  uint32_t* const bitmap = lds;                 // [kAccWords] rows the chunk meets
-  uint32_t* const wpre = bitmap + kAccWords;    // [kAccWords] marked rows in front of a word
-  uint32_t* const list = wpre + kAccWords;      // [kHotChunk] accumulator << 12 | position, by window
-  uint32_t* const wcnt = list + kHotChunk;      // [kAccMaxWin] entries per window
-  uint32_t* const wcur = wcnt + kAccMaxWin;     // [kAccMaxWin] first entry / cursor of a window
-  uint32_t* const sh = wcur + kAccMaxWin;       // [2] pool base
-  float* const acc = reinterpret_cast<float*>(lds + ((kAccFixedWords + 3) & ~3));
-  __shared__ uint32_t scan_smem[kAccWaves + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t chunk = blockIdx.x;
-  const uint32_t g = chunk / hg.cpg, c = chunk % hg.cpg;
-  const uint32_t len_g = hg.n > g ? (hg.n - g + hg.G - 1u) / hg.G : 0u;  // positions of my stream
-  const uint32_t c0 = c * (uint32_t)kHotChunk;
-  bitmap[threadIdx.x] = 0u;
-  if (threadIdx.x < 2 * kAccMaxWin) wcnt[threadIdx.x] = 0u;
-  __syncthreads();
-  // ---- the rows the chunk meets ------------------------------------------------------------------
-  uint32_t e[kAccRounds], vmask = 0u;
-#pragma unroll
-  for (int r = 0; r < kAccRounds; r++) {
-    const uint32_t i = (uint32_t)(wave * (64 * kAccRounds) + r * 64 + lane);
-    e[r] = 0u;
-    if (c0 + i < len_g) {
-      const uint64_t row = value_index[(size_t)(c0 + i) * hg.G + g];
-      if (row < (uint64_t)hg.rows) {
-        e[r] = ((uint32_t)row << kHotPosBits) | i;
-        vmask |= 1u << r;
-        atomicOr(&bitmap[(uint32_t)row >> 5], 1u << ((uint32_t)row & 31u));
-      }
-    }
-  }
-  __syncthreads();
-  const uint32_t myword = bitmap[threadIdx.x];
-  uint32_t n_rows;
-  const uint32_t ex = block_exclusive_scan<uint32_t, kAccBlock>((uint32_t)__popc(myword), scan_smem, &n_rows);
-  wpre[threadIdx.x] = ex;
-  if (threadIdx.x == 0) hb.meta[2 * chunk] = n_rows;
-  if (n_rows == 0u) return;  // (uniform: every thread holds the block total)
-  if (threadIdx.x == 0) {
-    // a block of pool slots for the chunk's partials (which block does not matter); the low word of
-    // the 64-bit counter hot_sort_kernel shares with its work items
-    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(hb.counts),
-                                             (unsigned long long)n_rows);
-    hb.meta[2 * chunk + 1] = (uint32_t)old;
-    sh[0] = (uint32_t)old;
-  }
-  {  // where hot_apply_kernel finds the chunk's partial of a row
-    uint32_t w = myword, k = 0u;
-    while (w != 0u) {
-      const uint32_t b = (uint32_t)__ffs((int)w) - 1u;
-      w &= w - 1u;
-      const uint32_t row = threadIdx.x * 32u + b;
-      hb.loc[(size_t)row * hg.loc_stride + chunk] = (uint16_t)(ex + k);
-      atomicOr(hb.loc_blk + row, 1u << (chunk >> 5));
-      k++;
-    }
-  }
-  __syncthreads();
-  // ---- the chunk's hot positions, grouped by the window their accumulator falls into --------------
-  const uint32_t n_win = (n_rows + cap_rows - 1u) / cap_rows;
-  uint32_t slot_of[kAccRounds];
-#pragma unroll
-  for (int r = 0; r < kAccRounds; r++) {
-    const uint32_t row = e[r] >> kHotPosBits;
-    slot_of[r] = wpre[row >> 5] + (uint32_t)__popc(bitmap[row >> 5] & ((1u << (row & 31u)) - 1u));
-  }
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  // (two sweeps over the registers: entries per window, then their places -- one LDS atomic per
-  //  wavefront, round and window met)
-#pragma unroll
-  for (int sweep = 0; sweep < 2; sweep++) {
-#pragma unroll
-    for (int r = 0; r < kAccRounds; r++) {
-      const bool valid = ((vmask >> r) & 1u) != 0u;
-      const uint32_t win = slot_of[r] / cap_rows;
-      unsigned long long todo = __ballot(valid);
-      while (todo != 0ull) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t w0 = (uint32_t)__shfl((int)win, leader, 64);
-        const unsigned long long same = __ballot(valid && win == w0);
-        if (sweep == 0) {
-          if (lane == leader) atomicAdd(&wcnt[w0], (uint32_t)__popcll(same));
-        } else {
-          uint32_t base = 0u;
-          if (lane == leader) base = atomicAdd(&wcur[w0], (uint32_t)__popcll(same));
-          base = (uint32_t)__shfl((int)base, leader, 64);
-          if (valid && win == w0)
-            list[base + (uint32_t)__popcll(same & lt)] =
-                ((slot_of[r] - w0 * cap_rows) << kHotPosBits) | (e[r] & (uint32_t)(kHotChunk - 1));
-        }
-        todo &= ~same;
-      }
-    }
-    __syncthreads();
-    if (sweep == 0) {
-      if (threadIdx.x == 0) {
-        uint32_t run = 0u;
-        for (uint32_t w = 0; w < n_win; w++) {
-          wcur[w] = run;
-          run += wcnt[w];
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // (wcur[w] now = the END of window w's entries; its start = the end of the window before)
-  const uint32_t pbase = sh[0];
-  const int gq = threadIdx.x / LG, l = threadIdx.x % LG;
-  for (uint32_t w = 0; w < n_win; w++) {
-    const uint32_t ws = w == 0u ? 0u : wcur[w - 1u], we = wcur[w];
-    const uint32_t rows_w = n_rows - w * cap_rows < cap_rows ? n_rows - w * cap_rows : cap_rows;
-#pragma unroll 1
-    for (int half = 0; half < NH; half++) {
-      for (uint32_t i = threadIdx.x; i < rows_w * (uint32_t)(DW / 4); i += kAccBlock)
-        reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      __syncthreads();
-      for (uint32_t k0 = ws + (uint32_t)gq; k0 < we; k0 += (uint32_t)(NG * QB)) {
-        Raw v[QB];
-        uint32_t en[QB];
-#pragma unroll
-        for (int q = 0; q < QB; q++) {
-          const uint32_t k = k0 + (uint32_t)(q * NG);
-          en[q] = list[k < we ? k : k0];
-          const uint32_t u = (c0 + (en[q] & (uint32_t)(kHotChunk - 1))) * hg.G + g;
-          const uint32_t b = hg.map_inner ? (u % hg.map_inner) * hg.map_outer + u / hg.map_inner : u;
-          v[q] = Load4<GradT>::ld_raw(grad + (size_t)b * D + half * DW + l * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < QB; q++) {
-          if (k0 + (uint32_t)(q * NG) < we) {
-            const float4 f = Load4<GradT>::cvt(v[q]);
-            float* a = acc + (size_t)(en[q] >> kHotPosBits) * DW + l * 4;
-            atomicAdd(a + 0, f.x);
-            atomicAdd(a + 1, f.y);
-            atomicAdd(a + 2, f.z);
-            atomicAdd(a + 3, f.w);
-          }
-        }
-      }
-      __syncthreads();
-      // the accumulators leave as the chunk's partial sums (pool slot = first slot + row's rank)
-      for (uint32_t i = threadIdx.x; i < rows_w * (uint32_t)(DW / 4); i += kAccBlock) {
-        const uint32_t rl = i / (uint32_t)(DW / 4), c4 = i % (uint32_t)(DW / 4);
-        *reinterpret_cast<float4*>(pool_end - ((size_t)(pbase + w * cap_rows + rl) + 1u) * D +
-                                   half * DW + c4 * 4) = reinterpret_cast<const float4*>(acc)[i];
-      }
-      __syncthreads();
-    }
-  }
-}
-
 // runs that cross tile borders inside a chunk: tail of the tile they start in + the heads after it
 template <int LPR>
 __global__ void __launch_bounds__(kBlock)
@@ -2310,12 +2115,10 @@ inline void plan_build(SparseUpdater& u, PrePlan& pp, size_t buckets, size_t nnz
 // the grouping kernels of a planned batch: the hot rows' chunk sort on hs, the cold rows' count /
 // base / scatter on cs
 inline int plan_launch_grouping(SparseUpdater& u, PrePlan& pp, const void* ro, hipStream_t hs,
-                                hipStream_t cs, bool hot_sort = true) {
-  if (hot_sort) {  // (the order-free form of the hot rows needs no grouping: hot_accum_kernel)
-    hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)pp.n_chunks), dim3(kHotBlock), 0, hs, pp.hg,
-                       u.one_hot_flag, pp.vi, pp.hb);
-    HCTR_LAUNCH_CHECK();
-  }
+                                hipStream_t cs) {
+  hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)pp.n_chunks), dim3(kHotBlock), 0, hs, pp.hg,
+                     u.one_hot_flag, pp.vi, pp.hb);
+  HCTR_LAUNCH_CHECK();
   const unsigned pgrid = (unsigned)ceil_div<size_t>(pp.n, (size_t)(kColdBlock * kColdPer));
   const unsigned bgrid = (unsigned)grid_for(pp.n, kColdBlock * kColdBasePer, 256);
   hipLaunchKernelGGL(cold_count_kernel, dim3(pgrid), dim3(kColdBlock), 0, cs, pp.cg,
@@ -2650,12 +2453,6 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
       // (prework() only ever runs for an updater whose cold rows are counted)
       const bool pre = hot && pp != nullptr && pp->valid && pp->vi == vi && pp->n == nnz &&
                        pp->buckets == buckets;
-      // plain SGD whose caller left the order of the additions free (OptState::order_free): the
-      // hot rows' three grouping / reducing launches become one (hot_accum_kernel); a batch
-      // grouped ahead (prework) keeps the ordered kernels its lists were built for
-      const char* of_env = getenv("HCTR_HOT_ORDER_FREE");  // "0": the ordered form (measurements)
-      const bool order_free = hot && !pre && opt.order_free != 0 && opt.optimizer == HCTR_OPT_SGD &&
-                              !(of_env && of_env[0] == '0');
       if (pp != nullptr && pp->valid && !pre) HCTR_TRY(plan_discard(u, *pp, s));
       if (hot) HCTR_TRY(u.hot_buffers(s));
       if (hot) {
@@ -2680,8 +2477,8 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
           HCTR_HIP(hipStreamWaitEvent(cs, pp->ev_cold, 0));
           pp->valid = false;
         } else if (cold) {
-          HCTR_TRY(plan_launch_grouping(u, *pp, (const void*)ro, s, cs, !order_free));
-        } else if (!order_free) {
+          HCTR_TRY(plan_launch_grouping(u, *pp, (const void*)ro, s, cs));
+        } else {
           hipLaunchKernelGGL(hot_sort_kernel, dim3((unsigned)n_chunks), dim3(kHotBlock), 0, s, hg,
                              u.one_hot_flag, vi, hb);
           HCTR_LAUNCH_CHECK();
@@ -2734,36 +2531,16 @@ int update_typed(SparseUpdater& u, size_t buckets, size_t nnz, int combiner, con
         const char* hg_env = getenv("HCTR_HOT_GRID");
         const char* sg_env = getenv("HCTR_SEG_GRID");
         const int hot_grid = hg_env ? atoi(hg_env) : 768;
-        const char* acc_rows_env = getenv("HCTR_HOT_ACC_ROWS");
-        (void)acc_rows_env;
         if (sg_env) seg_grid_cap = atoi(sg_env);
 #define HCTR_HOT_CASE(LPR_)                                                                       \
   {                                                                                               \
     constexpr int GPB = kBlock / LPR_;                                                            \
-    if (order_free) {                                                                             \
-      constexpr int DW_ = (LPR_ * 4 > 64 ? LPR_ * 2 : LPR_ * 4);                                  \
-      uint32_t cap_rows = (uint32_t)(kAccLdsBytes / (DW_ * 4));                                   \
-      if (cap_rows > (uint32_t)kHotChunk) cap_rows = kHotChunk;                                   \
-      if (acc_rows_env && atoi(acc_rows_env) > 0 && (uint32_t)atoi(acc_rows_env) < cap_rows)      \
-        cap_rows = (uint32_t)atoi(acc_rows_env);  /* (tests: several windows at a small size) */  \
-      if (cap_rows * (uint32_t)kAccMaxWin < (uint32_t)kHotChunk)                                  \
-        cap_rows = (uint32_t)kHotChunk / kAccMaxWin;                                              \
-      const size_t lds = (size_t)((kAccFixedWords + 3) & ~3) * 4 + (size_t)cap_rows * DW_ * 4;    \
-      HCTR_HIP(hipFuncSetAttribute((const void*)hot_accum_kernel<LPR_, GradT>,                    \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-      hipLaunchKernelGGL((hot_accum_kernel<LPR_, GradT>), dim3((unsigned)n_chunks),               \
-                         dim3(kAccBlock), lds, s, hg, u.one_hot_flag, vi, grad, pool_end, hb,     \
-                         cap_rows);                                                               \
-      HCTR_LAUNCH_CHECK();                                                                        \
-    } else {                                                                                      \
-      hipLaunchKernelGGL((hot_reduce_kernel<LPR_, GradT>),                                        \
-                         dim3(grid_for(items_max, GPB, hot_grid)), dim3(kBlock), 0, s, hg,        \
-                         u.one_hot_flag, grad, pool_end, hb);                                     \
-      HCTR_LAUNCH_CHECK();                                                                        \
-      hipLaunchKernelGGL((hot_join_kernel<LPR_>), dim3(grid_for(items_max / 8 + 1, GPB, 2048)),   \
-                         dim3(kBlock), 0, s, hg, u.one_hot_flag, pool_end, hb);                   \
-      HCTR_LAUNCH_CHECK();                                                                        \
-    }                                                                                             \
+    hipLaunchKernelGGL((hot_reduce_kernel<LPR_, GradT>), dim3(grid_for(items_max, GPB, hot_grid)), \
+                       dim3(kBlock), 0, s, hg, u.one_hot_flag, grad, pool_end, hb);               \
+    HCTR_LAUNCH_CHECK();                                                                          \
+    hipLaunchKernelGGL((hot_join_kernel<LPR_>), dim3(grid_for(items_max / 8 + 1, GPB, 2048)),     \
+                       dim3(kBlock), 0, s, hg, u.one_hot_flag, pool_end, hb);                     \
+    HCTR_LAUNCH_CHECK();                                                                          \
     hipLaunchKernelGGL((hot_apply_kernel<LPR_>), dim3(grid_for(u.hot_rows, GPB)), dim3(kBlock),   \
                        0, s, hg, (uint32_t)n_chunks, u.one_hot_flag, o, table, state0, state1,    \
                        (unsigned long long*)prev_time, (const float*)pool_end, hb);               \

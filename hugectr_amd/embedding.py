@@ -86,9 +86,7 @@ class SparseEmbeddingHash:
         p.beta1, p.beta2, p.epsilon = opt.beta1, opt.beta2, opt.epsilon
         p.initial_accu_value = opt.initial_accu_value
         p.momentum_factor = opt.momentum_factor
-        # (True / 1: the reference's literal fp32-atomicAdd kernel; 2: its permission only -- the
-        #  order of a row's additions is free where that is faster; False / 0: ordered)
-        p.atomic_update = int(opt.atomic_update)
+        p.atomic_update = 1 if opt.atomic_update else 0
         p.scaler = opt.scaler
         p.rank, p.world, p.seed = rank, world, seed
         self._h = ctypes.c_void_p()

@@ -592,15 +592,11 @@ class Model:
                          momentum_factor=o.momentum_factor,
                          # CreateOptimizer's default atomic_update=True (optimizer_wrapper.hpp:40)
                          # is read as PERMISSION for an order-nondeterministic update, not as a
-                         # demand for fp32 atomics (2): everything is sorted / counted and summed in
-                         # a fixed order (5x faster than atomics under power-law duplicates) except
-                         # the hot rows of a one-hot batch, whose sums inside a chunk of 4096
-                         # samples are formed in LDS in arrival order (hctr_amd.h, hctr_opt_params).
-                         # HCTR_SGD_ATOMIC=1 selects the reference's literal opt_sgd_atomic_kernel
-                         # form, HCTR_SGD_ORDERED=1 (or atomic_update=False) the fully ordered one.
-                         atomic_update=(1 if os.environ.get("HCTR_SGD_ATOMIC") == "1" else
-                                        0 if os.environ.get("HCTR_SGD_ORDERED") == "1" else 2)
-                         if o.atomic_update else 0,
+                         # demand for fp32 atomics: the sorted, segmented update is 5x faster under
+                         # power-law duplicates and deterministic.  HCTR_SGD_ATOMIC=1
+                         # selects the reference's literal opt_sgd_atomic_kernel form.
+                         atomic_update=bool(o.atomic_update) and
+                         os.environ.get("HCTR_SGD_ATOMIC") == "1",
                          scaler=self.solver.scaler)
 
     def compile(self, loss_names=None, loss_weights=None):

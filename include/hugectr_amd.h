@@ -167,15 +167,7 @@ typedef struct {
   float beta1, beta2, epsilon;     /* Adam (epsilon also AdaGrad) */
   float initial_accu_value;        /* AdaGrad */
   float momentum_factor;           /* MomentumSGD factor / Nesterov mu */
-  int atomic_update;               /* SGD: 0 = every row's gradients are added in ascending bucket
-                                    * order (deterministic); 1 = the reference's default kernel,
-                                    * an fp32 atomicAdd per element in arrival order
-                                    * (optimizer_wrapper.hpp:40, sparse_optimizer.cu:564-582);
-                                    * 2 = that default read as a PERMISSION: ordered as 0, except
-                                    * that the sums of the hot rows (the first 8192 rows handed
-                                    * out) of a one-key-per-bucket batch are formed in arrival
-                                    * order inside chunks of 4096 samples (fp32, in LDS): results
-                                    * differ from 0 by at most (n-1) eps sum|g| per element */
+  int atomic_update;               /* SGD: 1 = fp32 atomicAdd path (optimizer_wrapper.hpp:40) */
   float scaler;                    /* loss scaler the gradients are divided by */
   /* placement: this process is GPU `rank` of `world` (global ids, resource_manager semantics) */
   int rank;

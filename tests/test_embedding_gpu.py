@@ -687,29 +687,21 @@ def test_row_with_a_quarter_million_gradients(D):
 
 
 @pytest.mark.parametrize("opt_kw", [dict(optimizer=6, atomic_update=False), dict(optimizer=3),
-                                    dict(optimizer=1, update_type=0),
-                                    dict(optimizer=6, atomic_update=2), dict(optimizer=6, atomic_update=2)],
-                         ids=["sgd", "adagrad", "adam", "sgd_order_free", "sgd_order_free_windows"])
+                                    dict(optimizer=1, update_type=0)],
+                         ids=["sgd", "adagrad", "adam"])
 @pytest.mark.parametrize("B,D,dt,hot_rows", [(16384, 128, "f16", 8192), (12000, 16, "f32", 500),
                                              (4100, 64, "bf16", 16384)])
-def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, request, opt_kw, B, D, dt, hot_rows):
+def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, opt_kw, B, D, dt, hot_rows):
     """the hot-row path of the sparse update (hot_chunk_kernel + hot_apply_kernel, the cold pairs
     sorted on the side stream by a first pass that leaves the hot rows out) at sizes where it is on
     by default in the bench: Criteo-like skew (tables of 3 / 4 / 10 rows whose rows fill whole
     streams and cross chunk borders, power-law tables, a nearly unique one), rows on both sides of
     the bound, a ragged batch in between (both kernels exit on the device flag).  Table and state
     against the oracle within the re-association of long sums; the same bits on a second handle;
-    next to the plain path (HCTR_HOT_ROWS=0).  atomic_update = 2 (the reference's default read as
-    a permission): the hot rows' sums inside a chunk are formed in LDS in arrival order
-    (hot_accum_kernel; "windows": 48 accumulators at a time, so a chunk takes its rows in several
-    windows) -- held to the same written-down re-association bound, not to equal bits."""
+    next to the plain path (HCTR_HOT_ROWS=0)."""
     import torch
     import hugectr_amd as ha
     from hugectr_amd import _lib
-    if "order_free_windows" in request.node.name:
-        monkeypatch.setenv("HCTR_HOT_ACC_ROWS", "48")
-    else:
-        monkeypatch.delenv("HCTR_HOT_ACC_ROWS", raising=False)
     sizes = [3, 4, 10, 36, 1000, 50000, 200000, 97]
     S = len(sizes)
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
@@ -780,10 +772,7 @@ def test_update_hot_rows_of_one_hot_batches(oracle, monkeypatch, request, opt_kw
 
     a = run(hot_rows)
     b = run(hot_rows)
-    if opt_kw.get("atomic_update") != 2:
-        assert torch.equal(a, b), "the hot path is not deterministic"
-    else:  # (the order inside a chunk is given up by definition)
-        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-3, 1e-4, "order-free twice")
+    assert torch.equal(a, b), "the hot path is not deterministic"
     c = run(0)
     assert_close(a.cpu().numpy(), c.cpu().numpy(), 1e-3, 1e-4, "hot path vs plain path")
 

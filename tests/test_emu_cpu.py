@@ -210,10 +210,7 @@ def test_gather_fused_into_interaction_equals_pool_then_interaction(oracle, elib
 
 
 HOT_OPTS = [("sgd", dict(optimizer=6, atomic_update=0)), ("adagrad", dict(optimizer=3)),
-            ("adam", dict(optimizer=1, update_type=0)),
-            # atomic_update = 2: the hot rows' sums inside a chunk in arrival order (hot_accum_kernel)
-            ("sgd_order_free", dict(optimizer=6, atomic_update=2)),
-            ("sgd_order_free_windows", dict(optimizer=6, atomic_update=2))]
+            ("adam", dict(optimizer=1, update_type=0))]
 
 
 @pytest.mark.parametrize("name,kw", HOT_OPTS, ids=[o[0] for o in HOT_OPTS])
@@ -235,10 +232,6 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
     def run(rows_env):
         monkeypatch.setenv("HCTR_HOT_MIN", "0")
         monkeypatch.setenv("HCTR_HOT_ROWS", str(rows_env))
-        if name.endswith("windows"):  # 64 accumulators per window: a chunk takes its rows in several
-            monkeypatch.setenv("HCTR_HOT_ACC_ROWS", "64")
-        else:
-            monkeypatch.delenv("HCTR_HOT_ACC_ROWS", raising=False)
         rng = np.random.default_rng(B + D)
         emb = emu.Embedding(elib, _lib.EMB_LOCALIZED, B, V, D, 2 * S, S, 0, opt, out_dtype=odt)
         table = emb.table().copy()
@@ -280,10 +273,7 @@ def test_hot_rows_of_one_hot_batches(oracle, elib, monkeypatch, name, kw, B, S, 
 
     a = run(hot_rows)
     b = run(hot_rows)
-    if kw.get("atomic_update") != 2:  # (the order-free form gives the order up by definition)
-        assert (a.view(np.uint32) == b.view(np.uint32)).all(), "the hot path is not deterministic"
-    else:
-        assert_close(a, b, 3e-4, 3e-5, "order-free twice")
+    assert (a.view(np.uint32) == b.view(np.uint32)).all(), "the hot path is not deterministic"
     c = run(0)
     assert_close(a, c, 3e-4, 3e-5, "hot path vs plain path")
 

@@ -21,15 +21,13 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--atomic", type=int, default=0, help="hctr_opt_params.atomic_update: 0 ordered, 2 order-free hot rows")
     a = ap.parse_args()
     sizes = [max(1, int(v * a.scale)) for v in CRITEO_1TB]
     V, B, S, D = sum(sizes), a.batch, len(sizes), a.dim
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16}.get(a.dtype, torch.float32)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     rng = np.random.default_rng(1234)
     emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S, S, 0,
-                                 ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=a.atomic,
-                                              scaler=1024.0 if a.dtype == "f16" else 1.0),
+                                 ha.OptParams(optimizer=_lib.OPT_SGD, lr=0.01, atomic_update=False),
                                  slot_size_array=sizes, out_dtype=dt)
     emb.init_params()
     ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
