@@ -564,7 +564,8 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     idx_s = stage_us.get("hash_index", 0.0) * 1e-6
     per_rank = None
     if world > 1:
-        mine = {"rank": rank, "slots": spr, "table_rows": my_rows, "stage_us": stage_us,
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "backend": dist.get_backend(),
+                "slots": spr, "table_rows": my_rows, "stage_us": stage_us,
                 "exchange": xrep, "new_keys_per_step": new_keys}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
@@ -1448,6 +1449,13 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+            # a multi-GPU line is an RCCL line or no line at all: no silent fall to a host backend
+            if dist.get_backend() != "nccl":
+                sys.exit(f"bench.py --gpus {a.gpus}: the process group is on '{dist.get_backend()}', "
+                         "not on nccl (= RCCL); refusing to time it")
+            if torch.cuda.device_count() < world and os.environ.get("HCTR_RANKS_ON_ONE_GPU") != "1":
+                sys.exit(f"bench.py --gpus {a.gpus}: {torch.cuda.device_count()} device(s) visible for "
+                         f"{world} ranks")
 
     if a.config != "c3":
         out = small_config_leg(a.config, a.steps, a.warmup, dev)

@@ -61,6 +61,7 @@ class EmbeddingCollectionConfig:
         self.lookups = []  # (table_config, bottom_name, top_name, combiner)
         self.shard_matrix = None
         self.shard_strategy = "mp"
+        self.compression = {}  # table name -> "reduction" | "unique" (shard(compression_strategy=))
         self.top_name: Optional[str] = None  # one name for the concatenated output (train.py:398)
 
     def embedding_lookup(self, table_config, bottom_name, top_name, combiner):
@@ -80,7 +81,36 @@ class EmbeddingCollectionConfig:
         NAMES it holds, with shard_strategy = [("mp", names), ("dp", names)]."""
         self.shard_matrix = [list(r) for r in shard_matrix]
         self.shard_strategy = shard_strategy
+        self.compression = self._check_compression(compression_strategy)
         return self
+
+    def _check_compression(self, compression_strategy):
+        """compression_strategy: [(CompressionStrategy.Reduction | Unique, [table names]), ...] -- how
+        the model-parallel lookups of a table travel (EmbeddingCollectionParam's constructor,
+        R/HugeCTR/embedding/common.cpp:280-307, 323-340): a table may appear under one strategy only,
+        and when the list is given it must name exactly the model-parallel tables.  Not given: the
+        reference's default, Reduction for pooled lookups.  -> {table name: "reduction" | "unique"}"""
+        if not compression_strategy:
+            return {}
+        out = {}
+        for kind, names in compression_strategy:
+            k = str(getattr(kind, "name", kind)).lower()
+            if k not in ("reduction", "unique"):
+                raise RuntimeError(f"shard: unknown CompressionStrategy {kind!r}")
+            for n in names:
+                if str(n) in out:
+                    raise RuntimeError("Duplicate table id in different CompressionStrategy")
+                out[str(n)] = k
+        mp = None
+        if isinstance(self.shard_strategy, (list, tuple)):
+            mp = {str(n) for kind, names in self.shard_strategy if str(kind).lower() == "mp"
+                  for n in names}
+        elif str(self.shard_strategy).lower() == "mp":
+            mp = {t.name for t, _, _, _ in self.lookups}
+        if mp is not None and set(out) != mp:
+            raise RuntimeError("Table ids in CompressionStrategy does not match with table ids in "
+                               "TablePlacementStrategy")
+        return out
 
     def ownership(self, tables, world) -> List[List[int]]:
         """-> [gpu][table] in {0, 1}.  A table listed on several GPUs is row-sharded over them; a
@@ -197,6 +227,18 @@ class EmbeddingCollection:
         # optimizer state this one uses -- the evaluation runtime of a model owns per-batch
         # scratch only (a second copy of 100+ GB tables would not even fit for a moment)
         assert global_batch % self.world == 0
+        # CompressionStrategy.Unique selects the reference's unique-compressed model-parallel
+        # operator (distinct rows travel, the receiver pools;
+        # R/HugeCTR/embedding/dense_model_parallel_embedding.cpp:1-279).  This runtime has ONE
+        # model-parallel operator, Reduction (the owner pools, pooled vectors travel).  On one GPU
+        # nothing travels and the two give the same output, so the request is honoured as is; on
+        # several GPUs it is refused rather than silently run as Reduction.
+        uniq = sorted(n for n, k in getattr(config, "compression", {}).items() if k == "unique")
+        if uniq and self.world > 1:
+            raise _lib.HugeCTRAmdError(
+                "EmbeddingCollectionConfig.shard: CompressionStrategy.Unique for tables "
+                f"{uniq} on {self.world} GPUs is not available (model-parallel lookups run with "
+                "CompressionStrategy.Reduction only)")
         config = self._expand_concat_lookups(config, hotness, batch_major)
         if storage is None:  # max_vocabulary_size < 0 means dynamic (embedding_storage/common.hpp:78,
             # embedding_table.cpp:27-34: one dynamic table makes the whole group dynamic)

@@ -407,6 +407,11 @@ class CommunicationStrategy(enum.Enum):  # R/HugeCTR/include/embedding/common.hp
     Hierarchical = 1
 
 
+class CompressionStrategy(enum.Enum):  # embedding_collection_wrapper.hpp:40-43
+    Reduction = 0  # pool on the owner, ship pooled vectors (SparseModelParallel)
+    Unique = 1     # ship each distinct row once, pool on the receiver (DenseModelParallel*)
+
+
 @dataclass
 class DenseLayerComputeConfig:  # scheduling hints of the reference's MLP layer; accepted, unused
     async_wgrad: bool = False

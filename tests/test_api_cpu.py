@@ -322,3 +322,38 @@ def test_scale_layer_follows_the_reference_upscale_and_first_copy_downscale():
         gn = g.numpy()
         first = gn[:, ::factor] if axis == 0 else gn[:, :3]
         assert (x.grad.numpy() == first).all()
+
+
+def test_shard_compression_strategy_is_checked_like_the_reference():
+    """EmbeddingCollectionConfig.shard(..., compression_strategy): the sanity checks of
+    EmbeddingCollectionParam's constructor (R/HugeCTR/embedding/common.cpp:280-307) -- a table under
+    one strategy only, the strategies name exactly the model-parallel tables -- and the request is
+    kept (not dropped): `Unique` is refused by the runtime on more than one GPU, where it would
+    select an operator this library does not have, instead of silently running as `Reduction`."""
+    import hugectr_amd.hugectr as hugectr
+    from hugectr_amd.embedding_collection import EmbeddingCollectionConfig, EmbeddingTableConfig
+    assert hugectr.CompressionStrategy.Reduction.name == "Reduction"
+    assert hugectr.CompressionStrategy.Unique.name == "Unique"
+    tabs = [EmbeddingTableConfig(f"t{i}", 100, 8) for i in range(3)]
+
+    def cfg():
+        c = EmbeddingCollectionConfig()
+        c.embedding_lookup(tabs, ["a", "b", "c"], "emb", ["sum"] * 3)
+        return c
+    names = [["t0", "t1", "t2"]]
+    c = cfg().shard(names, [("mp", ["t0", "t1"]), ("dp", ["t2"])],
+                    [(hugectr.CompressionStrategy.Reduction, ["t0"]),
+                     (hugectr.CompressionStrategy.Unique, ["t1"])])
+    assert c.compression == {"t0": "reduction", "t1": "unique"}
+    assert cfg().shard(names, [("mp", ["t0", "t1", "t2"])]).compression == {}
+    with pytest.raises(RuntimeError, match="Duplicate table id"):
+        cfg().shard(names, [("mp", ["t0", "t1", "t2"])],
+                    [(hugectr.CompressionStrategy.Reduction, ["t0", "t1", "t2"]),
+                     (hugectr.CompressionStrategy.Unique, ["t1"])])
+    with pytest.raises(RuntimeError, match="does not match"):
+        cfg().shard(names, [("mp", ["t0", "t1"]), ("dp", ["t2"])],
+                    [(hugectr.CompressionStrategy.Reduction, ["t0"])])
+    from hugectr_amd import _lib
+    from hugectr_amd.embedding_collection import EmbeddingCollection
+    with pytest.raises(_lib.HugeCTRAmdError, match="CompressionStrategy.Unique"):
+        EmbeddingCollection.for_rank(0, 2, c, 64)
