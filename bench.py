@@ -20,6 +20,15 @@ import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _counter_file(name):
+    """the newest round's counter file under profiles/ (tools/measure_round.sh writes rN_<name>)"""
+    for r in (6, 5):
+        p = os.path.join(ROOT, "profiles", f"r{r}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r6_{name}")
 sys.path.insert(0, ROOT)
 
 # R/test/embedding_collection_test/dgx_a100_one_hot.py:24-51 -- Criteo-1TB slot_size_array
@@ -500,7 +509,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
     tag = label or ("fp32" if esz == 4 else "fp16")
     here = _csrc_hash()
     if world == 1 and D == 128 and a.batch == 65536 and a.table_scale == 1.0:
-        pmc_path = os.path.join(ROOT, "profiles", f"r5_pmc_hbm_traffic_{tag}.json")
+        pmc_path = _counter_file(f"pmc_hbm_traffic_{tag}.json")
         if not os.path.exists(pmc_path):
             pmc_path = os.path.join(ROOT, "profiles", f"r4_pmc_hbm_traffic_{tag}.json")
         try:
@@ -540,7 +549,7 @@ def dlrm_leg(a, precision, steps, warmup, world, rank, dev, scaling="weak", alph
             pmc = None
         # matrix-pipe utilisation of the interaction kernels (SQ pass of tools/measure_round.sh)
         try:
-            sq_path = os.path.join(ROOT, "profiles", "r5_pmc_sq_counters.json")
+            sq_path = _counter_file("pmc_sq_counters.json")
             if not os.path.exists(sq_path):
                 sq_path = os.path.join(ROOT, "profiles", "r4_pmc_sq_counters.json")
             j = json.load(open(sq_path))
@@ -1244,7 +1253,7 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False, 
     both_us = timed(train)
     nnz = B * sum(hot)
     pmc, pmc_src, pmc_stale = None, None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r5_pmc_hbm_traffic_ebc.json")
+    pmc_path = _counter_file("pmc_hbm_traffic_ebc.json")
     if not os.path.exists(pmc_path):
         pmc_path = os.path.join(ROOT, "profiles", "r4_pmc_hbm_traffic_ebc.json")
     if os.path.exists(pmc_path) and B == 65536 and D == 128 and abs(alpha - 1.1) < 1e-9:
