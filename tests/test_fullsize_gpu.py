@@ -134,6 +134,82 @@ def test_fullsize_multihot_pooling_is_linear_in_the_rows(criteo):
         assert float(out[lens == 0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("opt_name", ["sgd", "adagrad"])
+def test_fullsize_fp16_gradients_with_the_loss_scaler_match_fp64(opt_name):
+    """The update the bench times -- fp16 top gradients, loss scaler 1024, the hot-row / cold-count
+    split of a one-key-per-bucket batch -- at BASELINE configs[2]'s full size, against an fp64
+    index_add_ over the batch's distinct rows (only fp32 SGD was checked at this
+    size).  SGD: w - lr * sum(g) / scaler.  AdaGrad (a stateful optimizer through the same split;
+    fp16 embeddings keep fp16 state): from zero state one step is the closed form
+    w - lr * gi / (|gi| + eps), state = fp16(gi^2) (sparse_optimizer.cu:413-439).  Every distinct
+    row of the batch is compared (227 k), the hottest of which add ~ 20 k gradients; untouched rows
+    keep their bits."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    free, _ = torch.cuda.mem_get_info()
+    need = (100 if opt_name == "sgd" else 150) * 2**30
+    if free < need:
+        pytest.skip(f"needs ~{need >> 30} GiB of free HBM")
+    B, S, D = 65536, len(CRITEO_1TB), 128
+    lr, scaler, eps = 0.5, 1024.0, 1e-6
+    opt = ha.OptParams(optimizer=_lib.OPT_SGD if opt_name == "sgd" else _lib.OPT_ADAGRAD, lr=lr,
+                       atomic_update=False, scaler=scaler, epsilon=eps, initial_accu_value=0.0)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, sum(CRITEO_1TB), D, S, S, 0, opt,
+                                 slot_size_array=CRITEO_1TB, out_dtype=torch.float16)
+    try:
+        emb.init_params()
+        rng = np.random.default_rng(78)
+        ro = torch.arange(0, B * S + 1, dtype=torch.int64, device="cuda")
+        kb = torch.from_numpy(_batch(rng, B)).cuda()
+        emb.forward(True, ro, kb)
+        vi = emb.value_index(B * S).clone()
+        urows, inv = torch.unique(vi, return_inverse=True)
+        before = emb.table()[urows].clone()
+        gen = torch.Generator(device="cuda").manual_seed(79)
+        # (scaled as a loss-scaled gradient of a 65536-sample mean is: small numbers times 1024)
+        g = (torch.randn((B, S, D), device="cuda", generator=gen) * 0.02 * scaler / 64).half()
+        # an untouched neighbour of every touched row (when it is not touched itself)
+        other = (urows + 1).clamp_max(emb.get_vocabulary_size() - 1)
+        other = other[~torch.isin(other, urows)]
+        other_before = emb.table()[other].clone()
+        emb.forward(True, ro, kb)
+        emb.backward(g)
+        emb.update_params()
+        torch.cuda.synchronize()
+        gi = torch.zeros((urows.numel(), D), dtype=torch.float64, device="cuda")
+        gi.index_add_(0, inv, g.view(B * S, D).double())
+        gi /= scaler
+        got = emb.table()[urows].double()
+        n_r = torch.bincount(inv, minlength=urows.numel()).double().unsqueeze(1)
+        # fp32 sums of n fp16 addends, any fixed association: |err| <= n eps32 sum|g| / scaler per
+        # element; the bound below uses the row's own n and its gradients' size
+        gabs = torch.zeros_like(gi)
+        gabs.index_add_(0, inv, g.view(B * S, D).double().abs())
+        sum_err = n_r * 2.0 ** -24 * gabs / scaler
+        if opt_name == "sgd":
+            want = before.double() - lr * gi
+            bound = lr * sum_err + 2 * torch.abs(want) * 2.0 ** -24 + 1e-12
+        else:
+            want = before.double() - lr * gi / (gi.abs() + eps)
+            # d/dgi of gi / (|gi| + eps) = eps / (|gi| + eps)^2 <= 1 / (|gi| + eps)
+            bound = lr * sum_err / (gi.abs() + eps) + 4 * torch.abs(want) * 2.0 ** -24 + 1e-7
+            st = emb.opt_state(0)[urows]
+            assert st.dtype == torch.float16
+            want_st = (gi * gi)
+            st_err = (st.double() - want_st).abs()
+            assert bool((st_err <= want_st * 2.0 ** -10 + 2 * gi.abs() * sum_err + 1e-7).all()), \
+                float(st_err.max())
+        err = (got - want).abs()
+        bad = err > bound
+        assert not bool(bad.any()), (int(bad.sum()), float((err / bound).max()), float(err.max()))
+        assert float((got - before.double()).abs().max()) > 1e-4, "the table did not move"
+        assert torch.equal(emb.table()[other], other_before), "an untouched row changed"
+    finally:
+        del emb
+        torch.cuda.empty_cache()
+
+
 def test_fullsize_interaction_matches_fp32_bmm():
     import torch
     import hugectr_amd as ha
