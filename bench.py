@@ -1312,25 +1312,35 @@ def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False, 
     }
 
 
-def tiered_leg(steps, warmup, dev, alpha=1.1, rows=20_000_000, D=128, n=1 << 20):
-    """BASELINE configs[3] at the size one box's host memory takes: a [rows, D] fp32 table in
-    pinned host memory behind the HBM embedding cache (R/gpu_cache/include/nv_gpu_cache.hpp,
-    uvm_table.hpp:133-174), one-hot power-law keys, a NEW batch every call.  lookup = cache Query +
-    miss fill straight out of host memory + Replace; update = per-row gradient sums + write-through
-    SGD.  Bound by the host link (PCIe 5 x16: 64 GB/s per direction), not by HBM."""
-    from hugectr_amd.cache import TieredEmbedding
-    sets = 1 << 16  # 4.2 M cached rows = 2.1 GB of HBM for a 10 GB table
-    te = TieredEmbedding(rows, D, sets, n, lr=0.01)
+def tiered_leg(steps, warmup, dev, alpha=1.1, rows=20_000_000, D=128, n=1 << 20, tables=4):
+    """BASELINE configs[3] (4 tables with a 10 B-row KEY SPACE each, host-HBM tiered, power-law
+    keys) at the size one box's host memory takes: arbitrary int64 keys -- table * 10^10 + a key
+    scattered over [0, 10^10) -- resolve through the device index of hctr_uvm_* to rows of a
+    [rows, D] fp32 store in pinned host memory, handed out on first touch; the hot rows sit in the
+    HBM cache (R/gpu_cache/include/nv_gpu_cache.hpp, uvm_table.hpp:127-174).  A NEW batch every
+    call.  lookup = index probe + cache Query + miss fill straight out of host memory + Replace
+    (write-back: a dirty victim goes home first); update = per-row gradient sums + SGD on the
+    distinct rows, in the cache for the rows that are cached.  Bound by the host link (PCIe 5 x16:
+    64 GB/s per direction), not by HBM."""
+    from hugectr_amd.cache import UvmEmbedding
+    cached = 1 << 22  # 4.2 M cached rows = 2.1 GB of HBM for a 10 GB store
+    te = UvmEmbedding(cached, rows, D, n, lr=0.01)
     te.table.host[:] = 0.01
     g = torch.Generator(device=dev)
     g.manual_seed(5)
+    per_table = rows // tables  # distinct keys a table can come to hold
+    SPACE = 10**10
 
     def draw():
-        u = torch.rand(n, device=dev, generator=g, dtype=torch.float32).double()
-        e = 1.0 - alpha
-        y = ((float(rows) ** e - 1.0) * u + 1.0) ** (1.0 / e) if alpha > 0 else u * rows + 1
-        k = (torch.round(y) - 1).clamp_(0, rows - 1).to(torch.int64)
-        return (k * 7919) % rows  # hot rows scattered over the table
+        ks = []
+        for t in range(tables):
+            u = torch.rand(n // tables, device=dev, generator=g, dtype=torch.float32).double()
+            e = 1.0 - alpha
+            y = ((float(per_table) ** e - 1.0) * u + 1.0) ** (1.0 / e) if alpha > 0 else u * per_table + 1
+            rank = (torch.round(y) - 1).clamp_(0, per_table - 1).to(torch.int64)
+            # the rank-th most frequent key of table t lies anywhere in the table's 10^10 keys
+            ks.append(t * SPACE + (rank * 2654435761 + 12345) % SPACE)
+        return torch.stack(ks, 1).reshape(-1).contiguous()
     nb = warmup + steps
     batches = [draw() for _ in range(2 * nb + 8)]
     grad = torch.randn((n, D), device=dev) * 1e-3
@@ -1358,22 +1368,30 @@ def tiered_leg(steps, warmup, dev, alpha=1.1, rows=20_000_000, D=128, n=1 << 20)
         te.forward(k)
         te.backward_update(grad)
     both_us = timed(train, 8 + nb)
+    miss_train = float(torch.stack(miss).double().mean()) / n
+    te.table.check_overflow()
+    keys_held = te.table.size()
+    t0 = time.perf_counter()
+    te.table.flush()
+    flush_ms = (time.perf_counter() - t0) * 1e3
     link_bytes = miss_rate * n * D * 4
     LINK = 64.0
     return {
-        "workload": f"tiered table (BASELINE configs[3] in miniature): {rows} x {D} fp32 rows "
-                    f"({rows * D * 4 / 2**30:.1f} GiB) in pinned host memory, {sets * 64} cached "
-                    f"rows in HBM, {n} one-hot power-law (alpha={alpha}) keys per call, a new "
-                    "batch every call",
+        "workload": f"tiered table of arbitrary keys (BASELINE configs[3] in miniature): {tables} "
+                    f"tables x 10^10 key space, {rows} x {D} fp32 rows ({rows * D * 4 / 2**30:.1f} GiB) "
+                    f"of pinned host memory handed out on first touch, {cached} cached rows in HBM, "
+                    f"{n} one-hot power-law (alpha={alpha}) keys per call, a new batch every call",
         "lookup_us": look_us, "lookup_update_us": both_us, "update_us": both_us - look_us,
-        "miss_rate": miss_rate, "value": n / (both_us * 1e-6),
-        "unit": "keys/s (lookup + write-through SGD)",
+        "miss_rate": miss_rate, "miss_rate_while_training": miss_train, "keys_held": keys_held,
+        "flush_ms_at_the_end": flush_ms, "value": n / (both_us * 1e-6),
+        "unit": "keys/s (lookup + write-back SGD)",
         "roofline": {"bound": "host link (PCIe 5 x16, per direction)", "peak": LINK,
                      "unit": "GB/s", "achieved": link_bytes / (look_us * 1e-6) / 1e9,
                      "frac": link_bytes / (look_us * 1e-6) / 1e9 / LINK,
                      "algorithmic_bytes_per_launch": link_bytes, "traffic": None,
-                     "note": "bytes = missed rows x D x 4 crossing the link during the lookup; "
-                             "the cache hits (HBM) ride along in the same time"},
+                     "note": "bytes = missed rows x D x 4 crossing the link during the lookup (as "
+                             "many dirty victims travel the other way while training); the cache "
+                             "hits (HBM) ride along in the same time"},
     }
 
 

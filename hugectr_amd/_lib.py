@@ -167,6 +167,17 @@ _SIGNATURES = {
     "hctr_tiered_cache": (_P, [_P]),
     "hctr_tiered_lookup": (c_int, [_P, _P, c_size_t, _P, _P, _P]),
     "hctr_tiered_scatter": (c_int, [_P, _P, c_size_t, _P, c_int, c_float, _P]),
+    "hctr_tiered_flush": (c_int, [_P, _P]),
+    "hctr_uvm_create": (c_int, [c_size_t, c_size_t, c_size_t, c_int, c_float, c_int, POINTER(_P)]),
+    "hctr_uvm_destroy": (c_int, [_P]),
+    "hctr_uvm_tier": (_P, [_P]),
+    "hctr_uvm_add": (c_int, [_P, _P, _P, c_size_t]),
+    "hctr_uvm_query": (c_int, [_P, _P, c_size_t, _P, _P]),
+    "hctr_uvm_clear": (c_int, [_P, _P]),
+    "hctr_uvm_lookup": (c_int, [_P, _P, c_size_t, _P, _P, _P, _P]),
+    "hctr_uvm_scatter_rows": (c_int, [_P, _P, c_size_t, _P, c_int, c_float, _P]),
+    "hctr_uvm_check_overflow": (c_int, [_P, _P]),
+    "hctr_uvm_size": (c_int, [_P, _P, POINTER(c_size_t)]),
     "hctr_uniq_create": (c_int, [c_size_t, POINTER(_P)]),
     "hctr_uniq_destroy": (c_int, [_P]),
     "hctr_uniq_plan": (c_int, [_P, c_size_t, c_size_t, c_int, c_int, c_int, c_int, c_int, _P,

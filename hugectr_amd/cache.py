@@ -88,6 +88,11 @@ class TieredTable:
     def last_missing(self) -> int:
         return int(self._miss.item())
 
+    def flush(self):
+        """cached rows that are newer than the host table go home (write-back cache): call before
+        reading `.host`"""
+        check(lib.hctr_tiered_flush(self._h, stream_ptr()))
+
     def scatter_add(self, unique_keys: torch.Tensor, values: torch.Tensor, alpha: float = 1.0):
         check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
                                       ptr(values.contiguous()), 1, alpha, stream_ptr()))
@@ -95,6 +100,80 @@ class TieredTable:
     def scatter_update(self, unique_keys: torch.Tensor, values: torch.Tensor):
         check(lib.hctr_tiered_scatter(self._h, ptr(unique_keys), unique_keys.numel(),
                                       ptr(values.contiguous()), 0, 1.0, stream_ptr()))
+
+
+class UvmTable:
+    """gpu_cache::UvmTable(device_table_capacity, host_table_capacity, max_batch_size, vec_size,
+    default_value) (R/gpu_cache/include/uvm_table.hpp:127-174): arbitrary keys -> fp32 vectors that
+    live in host memory, the hot ones in HBM.  add(h_keys, h_vectors) / query(d_keys) -> d_vectors /
+    clear() as in the reference; lookup / scatter_rows serve the training path (hugectr_amd.h)."""
+
+    def __init__(self, device_table_capacity: int, host_table_capacity: int, max_batch_size: int,
+                 vec_size: int, default_value: float = 0.0, key_dtype=torch.int64):
+        self.D, self.capacity, self.max_batch = vec_size, host_table_capacity, max_batch_size
+        self.key_dtype = key_dtype
+        self._h = ctypes.c_void_p()
+        kt = _lib.KEY_I64 if key_dtype == torch.int64 else _lib.KEY_U32
+        check(lib.hctr_uvm_create(device_table_capacity, host_table_capacity, max_batch_size,
+                                  vec_size, float(default_value), kt, ctypes.byref(self._h)))
+        tier = lib.hctr_uvm_tier(self._h)
+        addr = lib.hctr_tiered_host_rows(tier)
+        buf = (ctypes.c_float * (host_table_capacity * vec_size)).from_address(addr)
+        self.host = np.ctypeslib.as_array(buf).reshape(host_table_capacity, vec_size)
+        self.cache = GpuCache(-(-device_table_capacity // 64), vec_size,
+                              _handle=lib.hctr_tiered_cache(tier))
+        self._miss = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.host = None
+            lib.hctr_uvm_destroy(self._h)
+            self._h = None
+
+    def add(self, h_keys: np.ndarray, h_vectors: np.ndarray):
+        kd = np.int64 if self.key_dtype == torch.int64 else np.uint32
+        k = np.ascontiguousarray(h_keys, dtype=kd)
+        v = np.ascontiguousarray(h_vectors, dtype=np.float32).reshape(k.size, self.D)
+        check(lib.hctr_uvm_add(self._h, k.ctypes.data_as(ctypes.c_void_p),
+                               v.ctypes.data_as(ctypes.c_void_p), k.size))
+
+    def query(self, d_keys: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((d_keys.numel(), self.D), dtype=torch.float32, device=d_keys.device)
+        check(lib.hctr_uvm_query(self._h, ptr(d_keys), d_keys.numel(), ptr(out), stream_ptr()))
+        return out
+
+    def clear(self):
+        check(lib.hctr_uvm_clear(self._h, stream_ptr()))
+
+    def flush(self):
+        """cached rows newer than the host store go home: call before reading `.host`"""
+        check(lib.hctr_tiered_flush(lib.hctr_uvm_tier(self._h), stream_ptr()))
+
+    def lookup(self, d_keys: torch.Tensor, want_rows: bool = True):
+        """training: unseen keys take the next host row; -> (vectors, rows | None)"""
+        n = d_keys.numel()
+        out = torch.empty((n, self.D), dtype=torch.float32, device=d_keys.device)
+        rows = torch.empty(n, dtype=torch.int64, device=d_keys.device) if want_rows else None
+        check(lib.hctr_uvm_lookup(self._h, ptr(d_keys), n, ptr(out), ptr(rows), ptr(self._miss),
+                                  stream_ptr()))
+        return out, rows
+
+    def scatter_rows(self, unique_rows: torch.Tensor, values: torch.Tensor, add: bool = True,
+                     alpha: float = 1.0):
+        values = values.contiguous()
+        check(lib.hctr_uvm_scatter_rows(self._h, ptr(unique_rows), unique_rows.numel(), ptr(values),
+                                        1 if add else 0, alpha, stream_ptr()))
+
+    def check_overflow(self):
+        check(lib.hctr_uvm_check_overflow(self._h, stream_ptr()))
+
+    def size(self) -> int:
+        n = ctypes.c_size_t()
+        check(lib.hctr_uvm_size(self._h, stream_ptr(), ctypes.byref(n)))
+        return n.value
+
+    def last_missing(self) -> int:
+        return int(self._miss.item())
 
 
 class TieredEmbedding:
@@ -138,3 +217,49 @@ class TieredEmbedding:
                                         ctypes.byref(nu), ptr(self._urow), None, ptr(self._wgrad),
                                         stream_ptr()))
         self.table.scatter_add(self._urow[:nu.value], self._wgrad[:nu.value], alpha=-self.lr)
+
+
+class UvmEmbedding:
+    """One-hot embedding over tables whose KEY SPACE does not fit anywhere (BASELINE configs[3]:
+    4 x 10 B rows): arbitrary int64 keys -> UvmTable rows (host store, hot rows in HBM, first touch
+    takes the next row).  forward = hctr_uvm_lookup; backward_update = per-row gradient sums
+    (hctr_ebc_local_reduce on the rows, ascending position order) and the write-back SGD step on
+    the distinct rows.  Several tables share the store through disjoint key ranges."""
+
+    def __init__(self, device_table_capacity: int, host_table_capacity: int, embedding_vec_size: int,
+                 max_keys_per_batch: int, lr: float = 0.01):
+        self.table = UvmTable(device_table_capacity, host_table_capacity, max_keys_per_batch,
+                              embedding_vec_size)
+        self.D, self.lr, self.max_keys = embedding_vec_size, lr, max_keys_per_batch
+        self._upd = ctypes.c_void_p()
+        check(lib.hctr_updater_create(max_keys_per_batch, max_keys_per_batch, embedding_vec_size,
+                                      ctypes.byref(self._upd)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self._ro = torch.arange(max_keys_per_batch + 1, dtype=torch.int64, device=dev)
+        self._urow = torch.empty(max_keys_per_batch, dtype=torch.int64, device=dev)
+        self._wgrad = torch.empty((max_keys_per_batch, embedding_vec_size), dtype=torch.float32,
+                                  device=dev)
+        self._rows = None
+
+    def __del__(self):
+        if getattr(self, "_upd", None):
+            lib.hctr_updater_destroy(self._upd)
+            self._upd = None
+
+    def forward(self, keys: torch.Tensor) -> torch.Tensor:
+        assert keys.numel() <= self.max_keys and keys.dtype == torch.int64
+        out, self._rows = self.table.lookup(keys.contiguous())
+        return out
+
+    def backward_update(self, grad: torch.Tensor):
+        """grad [n, vec] of the vectors the last forward returned"""
+        n = self._rows.numel()
+        nu = ctypes.c_size_t()
+        dt = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}[grad.dtype]
+        grad = grad.contiguous()
+        check(lib.hctr_ebc_local_reduce(self._upd, n, n, ptr(self._ro), ptr(self._rows),
+                                        self.table.capacity, None, ptr(grad), dt,
+                                        ctypes.byref(nu), ptr(self._urow), None, ptr(self._wgrad),
+                                        stream_ptr()))
+        self.table.scatter_rows(self._urow[:nu.value], self._wgrad[:nu.value], add=True,
+                                alpha=-self.lr)

@@ -741,9 +741,12 @@ int hctr_cache_dump(hctr_cache* c, void* keys, size_t* d_dump_counter, size_t st
  * above holds the hot rows.  lookup = Query + the GPU reading the missing rows straight out of
  * host memory into `out` + Replace -- three launches, no host synchronisation (rows outside
  * [0, host_rows) read as zeros).  d_missing_len (device, may be NULL) receives the miss count.
- * scatter: write-through update of UNIQUE rows, new = (add ? old : 0) + alpha * values[i], stored
- * in the host table and in the cached copy when there is one (alpha = -lr and the per-row gradient
- * sums of hctr_ebc_local_reduce make it the SGD step of a tiered embedding). */
+ * scatter: update of UNIQUE rows, new = (add ? old : 0) + alpha * values[i] (alpha = -lr and the
+ * per-row gradient sums of hctr_ebc_local_reduce make it the SGD step of a tiered embedding).  The
+ * cache is WRITE-BACK: a cached row is updated in HBM only and goes home to the host table when
+ * its slot is taken over by another row or at hctr_tiered_flush; a row that is not cached is
+ * updated in the host table.  Every lookup reads current values either way; the HOST pointer of
+ * hctr_tiered_host_rows shows them after hctr_tiered_flush (host sync). */
 typedef struct hctr_tiered hctr_tiered;
 int hctr_tiered_create(size_t host_rows, int vec_size, size_t cache_capacity_in_set,
                        hctr_tiered** out);
@@ -754,6 +757,44 @@ int hctr_tiered_lookup(hctr_tiered* t, const int64_t* keys, size_t len, float* o
                        size_t* d_missing_len, hctr_stream_t stream);
 int hctr_tiered_scatter(hctr_tiered* t, const int64_t* unique_keys, size_t len, const float* values,
                         int add, float alpha, hctr_stream_t stream);
+int hctr_tiered_flush(hctr_tiered* t, hctr_stream_t stream);
+
+/* gpu_cache::UvmTable<key_type, index_type, vec_type> as a whole
+ * (R/gpu_cache/include/uvm_table.hpp:127-174; src/uvm_table.cu:283-510): a key -> vector map whose
+ * vectors live in host memory with the hot ones in HBM -- BASELINE configs[3]'s 10 B-row key spaces
+ * need an index in front of the store, not a store as large as the key space.  The constructor's
+ * arguments are the reference's (device_table_capacity / host_table_capacity in vectors,
+ * max_batch_size, vec_size, default_value) + the key type.  One device index (the path's own hash
+ * map, 16 bytes of HBM per slot, capacity / 0.75 slots) maps a key to a row of the pinned host
+ * store, handed out on first touch in order of first occurrence; the set-associative cache of
+ * hctr_cache_* keeps the hot rows (device_table_capacity rounded up to whole sets of 64).
+ *   add   (:137, uvm_table.cu:318-418): HOST keys / vectors, synchronous; a key met again gets the
+ *         new vector (its last one when a call lists it twice); HCTR_ERR_OVERFLOW when the host
+ *         store is full (the reference spills into an unordered_map on the host).
+ *   query (:136, :421-497): DEVICE keys -> DEVICE vectors; a key that was never added reads
+ *         default_value in every element.  Asynchronous on `stream`.
+ *   clear (:138): forgets every key (index and cache).
+ * For the training path (not in the reference's class, which serves inference):
+ *   lookup: as query, but a key met for the first time takes the next row of the host store -- whose
+ *         content is whatever hctr_tiered_host_rows(hctr_uvm_tier(u)) holds there (the caller's
+ *         initialisation) -- and row_index (may be NULL; len <= max_batch_size) receives every
+ *         key's row for the update; hctr_uvm_check_overflow reports a full store (host sync).
+ *   scatter_rows: hctr_tiered_scatter on rows handed back by lookup (unique within the call). */
+typedef struct hctr_uvm hctr_uvm;
+int hctr_uvm_create(size_t device_table_capacity, size_t host_table_capacity, size_t max_batch_size,
+                    int vec_size, float default_value, int key_type, hctr_uvm** out);
+int hctr_uvm_destroy(hctr_uvm* u);
+hctr_tiered* hctr_uvm_tier(hctr_uvm* u);
+int hctr_uvm_add(hctr_uvm* u, const void* h_keys, const float* h_vectors, size_t len);
+int hctr_uvm_query(hctr_uvm* u, const void* d_keys, size_t len, float* d_vectors,
+                   hctr_stream_t stream);
+int hctr_uvm_clear(hctr_uvm* u, hctr_stream_t stream);
+int hctr_uvm_lookup(hctr_uvm* u, const void* d_keys, size_t len, float* d_vectors,
+                    uint64_t* d_row_index, size_t* d_missing_len, hctr_stream_t stream);
+int hctr_uvm_scatter_rows(hctr_uvm* u, const uint64_t* d_unique_rows, size_t len,
+                          const float* values, int add, float alpha, hctr_stream_t stream);
+int hctr_uvm_check_overflow(hctr_uvm* u, hctr_stream_t stream);
+int hctr_uvm_size(hctr_uvm* u, hctr_stream_t stream, size_t* out); /* keys held; host sync */
 
 #ifdef __cplusplus
 }

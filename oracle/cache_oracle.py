@@ -137,3 +137,48 @@ class TieredOracle:
             self.host[k] = new
             if cached:
                 self.cache.vals[s, slot] = new
+
+
+class UvmOracle:
+    """gpu_cache::UvmTable restated (R/gpu_cache/include/uvm_table.hpp:127-174): key -> vector, unknown
+    keys read the default value; rows of the host store are handed out in order of first occurrence
+    (add and the training lookup alike), the cache above is TieredOracle's, keyed by row."""
+
+    def __init__(self, device_table_capacity, host_table_capacity, vec_size, default_value=0.0,
+                 max_batch_size=1 << 30):
+        self.max_batch = max_batch_size  # longer key lists run as that many separate lookups
+        self.tier = TieredOracle(host_table_capacity, vec_size, -(-device_table_capacity // 64))
+        self.row = {}
+        self.default = np.float32(default_value)
+        self.capacity = host_table_capacity
+
+    def _rows(self, keys, insert):
+        out = np.empty(len(keys), np.int64)
+        for i, k in enumerate(keys):
+            k = int(k)
+            if k not in self.row and insert and len(self.row) < self.capacity:
+                self.row[k] = len(self.row)
+            out[i] = self.row.get(k, -1)
+        return out
+
+    def add(self, keys, vectors):
+        last = {int(k): i for i, k in enumerate(keys)}
+        pick = [i for i, k in enumerate(keys) if last[int(k)] == i]
+        rows = self._rows([keys[i] for i in pick], True)
+        self.tier.scatter(rows, np.asarray(vectors, np.float32)[pick], add=False)
+
+    def _lookup(self, keys, insert):
+        outs, rws, nmiss = [], [], 0
+        for b in range(0, len(keys), self.max_batch):
+            rows = self._rows(keys[b:b + self.max_batch], insert)
+            out, nmiss = self.tier.lookup(rows)  # (the count of the last piece, as the device reports)
+            out[rows < 0] = self.default
+            outs.append(out)
+            rws.append(rows)
+        return np.concatenate(outs), np.concatenate(rws), nmiss
+
+    def query(self, keys):
+        return self._lookup(keys, False)[0]
+
+    def lookup(self, keys):
+        return self._lookup(keys, True)
