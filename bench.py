@@ -1431,7 +1431,7 @@ def main():
                          "the reference), fp32 = the reference's default (everything fp32).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in both.")
     ap.add_argument("--extra", default="auto",
-                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2", "dynopt"],
+                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2", "dynopt", "tiered"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other precision on the same workload, `uniform_big_tables` (no key "
                          "repeats: the discriminating roofline), BASELINE configs[0] / [1] (DCN "
@@ -1562,7 +1562,7 @@ def main():
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha))
         run("ebc_dynamic_multi_hot", ("auto", "all", "ebc", "next"),
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha, dynamic=True))
-        run("tiered", ("auto", "all", "next"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
+        run("tiered", ("auto", "all", "next", "tiered"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
         run("ebc_dynamic_optimizers", ("all", "dynopt"),
             lambda: dynamic_optimizer_leg(a.extra_steps, 3, dev, a.alpha))
         out["extra"] = extra
