@@ -1189,6 +1189,116 @@ def dynamic_optimizer_leg(steps, warmup, dev, alpha):
     return r
 
 
+def c5_model_leg(steps, warmup, dev, B=16384):
+    """BASELINE configs[4]: Wide & Deep + MMoE, multi-hot, embedding_collection API on DYNAMIC hash
+    tables (max_vocabulary_size = -1), fp16 dense tower -- through hugectr.Model.train().  The graph
+    is the reference's MMoE sample (R/samples/mmoe/mmoe_parquet.py: 3 experts 256-128, two softmax
+    gates, two towers, two BinaryCrossEntropyLoss weighted 0.5 / 0.5) fed by an
+    EmbeddingCollectionConfig as R/samples/wdl and R/samples/ftrl/dlrm_train_ftrl.py:222-245 write
+    it -- deep tables ev = 16 (hotness 1..5) into the experts and gates, wide tables ev = 1 whose sum
+    joins tower A's logit (R/samples/wdl/wdl_1gpu.py's wide branch) -- AdaGrad, Parquet input.
+    One step = Model.train()."""
+    import shutil
+    import tempfile
+    import hugectr_amd.hugectr as hugectr
+    nb = 6
+    sizes = [73622, 91, 17, 1425, 3, 24, 15, 5, 10, 2, 3, 6, 8, 133, 114, 1675, 6, 6, 51, 38, 8, 47, 10,
+             9, 10, 3, 4, 7, 5, 2, 52, 9]  # the census tables of the MMoE sample
+    hot = [5, 3, 1, 2] + [1] * 28
+    wide, deep = [0, 3, 15], list(range(32))
+    tmp = tempfile.mkdtemp(prefix="hctr_bench_c5_")
+    try:
+        hugectr.tools.DataGenerator(hugectr.tools.DataGeneratorParams(
+            format=hugectr.DataReaderType_t.Parquet, label_dim=2, dense_dim=0, num_slot=32,
+            i64_input_key=True, source=os.path.join(tmp, "train", "_file_list.txt"),
+            eval_source="", slot_size_array=sizes, nnz_array=hot,
+            dist_type=hugectr.Distribution_t.PowerLaw, power_law_type=hugectr.PowerLaw_t.Short,
+            num_files=1, eval_num_files=0, num_samples_per_file=B * nb, num_samples=B * nb,
+            eval_num_samples=0)).generate()
+        solver = hugectr.CreateSolver(max_eval_batches=1, batchsize_eval=B, batchsize=B, lr=0.01,
+                                      vvgpu=[[0]], repeat_dataset=True, i64_input_key=True,
+                                      use_mixed_precision=True, scaler=1024.0,
+                                      use_embedding_collection=True)
+        reader = hugectr.DataReaderParams(
+            data_reader_type=hugectr.DataReaderType_t.Parquet,
+            source=[os.path.join(tmp, "train", "_file_list.txt")], eval_source="",
+            slot_size_array=sizes, check_type=hugectr.Check_t.Non)
+        optimizer = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.AdaGrad,
+                                            update_type=hugectr.Update_t.Global)
+        m = hugectr.Model(solver, reader, optimizer)
+        L, T = hugectr.DenseLayer, hugectr.Layer_t
+        m.add(hugectr.Input(label_dims=[1, 1], label_names=["labelA", "labelB"], dense_dim=0,
+                            dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                                for i in range(32)]))
+        ebc = hugectr.EmbeddingCollectionConfig()
+        for i in wide:
+            ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"w{i}", -1, 1),
+                                 bottom_name=f"data{i}", top_name=f"wide{i}", combiner="sum")
+        for i in deep:
+            ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"d{i}", -1, 16),
+                                 bottom_name=f"data{i}", top_name=f"deep{i}", combiner="sum")
+        names = [f"w{i}" for i in wide] + [f"d{i}" for i in deep]
+        ebc.shard(shard_matrix=[names], shard_strategy=[("mp", names)])
+        m.add(ebc)
+        m.add(L(layer_type=T.Concat, bottom_names=[f"deep{i}" for i in deep], top_names=["emb"]))
+        m.add(L(layer_type=T.Slice, bottom_names=["emb"],
+                top_names=["e0_in", "e1_in", "e2_in", "gateA_in", "gateB_in"],
+                ranges=[(0, 512)] * 5))
+        for e in range(3):
+            m.add(L(layer_type=T.MLP, bottom_names=[f"e{e}_in"], top_names=[f"e{e}_out"],
+                    num_outputs=[256, 128], act_type=hugectr.Activation_t.Relu))
+            m.add(L(layer_type=T.Slice, bottom_names=[f"e{e}_out"],
+                    top_names=[f"e{e}_out_A", f"e{e}_out_B"], ranges=[(0, 128), (0, 128)]))
+        for t in "AB":
+            m.add(L(layer_type=T.InnerProduct, bottom_names=[f"gate{t}_in"], top_names=[f"g{t}_dense"],
+                    num_output=3))
+            m.add(L(layer_type=T.Softmax, bottom_names=[f"g{t}_dense"], top_names=[f"g{t}_softmax"]))
+            m.add(L(layer_type=T.Slice, bottom_names=[f"g{t}_softmax"],
+                    top_names=[f"g{t}_e0", f"g{t}_e1", f"g{t}_e2"], ranges=[(0, 1), (1, 2), (2, 3)]))
+            for e in range(3):
+                m.add(L(layer_type=T.Scale, bottom_names=[f"g{t}_e{e}"],
+                        top_names=[f"g{t}_e{e}_scaled"], axis=0, factor=128))
+                m.add(L(layer_type=T.ElementwiseMultiply,
+                        bottom_names=[f"e{e}_out_{t}", f"g{t}_e{e}_scaled"],
+                        top_names=[f"e{e}_{t}_gated"]))
+            m.add(L(layer_type=T.Add, bottom_names=[f"e{e}_{t}_gated" for e in range(3)],
+                    top_names=[f"tower_{t}_input"]))
+            m.add(L(layer_type=T.MLP, bottom_names=[f"tower_{t}_input"], top_names=[f"{t}_fc2"],
+                    num_outputs=[64, 1],
+                    activations=[hugectr.Activation_t.Relu, hugectr.Activation_t.Non]))
+        m.add(L(layer_type=T.Concat, bottom_names=[f"wide{i}" for i in wide], top_names=["wide"]))
+        m.add(L(layer_type=T.ReduceSum, bottom_names=["wide"], top_names=["wide_sum"], axis=1))
+        m.add(L(layer_type=T.Add, bottom_names=["A_fc2", "wide_sum"], top_names=["A_logit"]))
+        m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["A_logit", "labelA"],
+                top_names=["lossA"]))
+        m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["B_fc2", "labelB"],
+                top_names=["lossB"]))
+        m.compile(loss_names=["labelA", "labelB"], loss_weights=[0.5, 0.5])
+        for _ in range(warmup):
+            m.train()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.train()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        nnz = B * sum(hot[i] for i in deep) + B * sum(hot[i] for i in wide)
+        held = sum(rt["train"].det.size() for rt in m._ebc)
+        return {
+            "workload": "BASELINE configs[4]: Wide & Deep + MMoE (3 experts, 2 gates, 2 tasks), "
+                        f"embedding_collection over {len(deep)} deep (ev 16) + {len(wide)} wide (ev 1) "
+                        f"DYNAMIC hash tables, multi-hot ({nnz // B} keys per sample), mixed "
+                        f"precision (fp16 tower), AdaGrad, bs {B}, Model.train()",
+            "ms_per_step": el / steps * 1e3, "value": B * steps / el, "unit": "samples/s",
+            "keys_per_step": nnz, "keys_held_by_the_dynamic_tables": held,
+            "loss": m.get_current_loss(),
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def ebc_leg(kind, steps, warmup, dev, alpha=1.1, B=65536, D=128, dynamic=False, optimizer="sgd"):
     """embedding_collection on one GPU (the reference's current-generation path):
     forward and backward + update of the collection alone, through EmbeddingCollection.forward /
@@ -1431,7 +1541,7 @@ def main():
                          "the reference), fp32 = the reference's default (everything fp32).  "
                          "Tables, pooling accumulation and the sparse optimizer are fp32 in both.")
     ap.add_argument("--extra", default="auto",
-                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2", "dynopt", "tiered"],
+                    choices=["auto", "none", "all", "ebc", "model", "uniform", "next", "dense", "dcnv2", "dynopt", "tiered", "c5"],
                     help="extra legs appended to the JSON line under `extra` (1 GPU only): the "
                          "other precision on the same workload, `uniform_big_tables` (no key "
                          "repeats: the discriminating roofline), BASELINE configs[0] / [1] (DCN "
@@ -1562,6 +1672,8 @@ def main():
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha))
         run("ebc_dynamic_multi_hot", ("auto", "all", "ebc", "next"),
             lambda: ebc_leg("multi_hot", a.extra_steps, 3, dev, a.alpha, dynamic=True))
+        run("c5_wdl_mmoe_dynamic", ("auto", "all", "next", "model", "c5"),
+            lambda: c5_model_leg(a.extra_steps * 3, 8, dev))
         run("tiered", ("auto", "all", "next", "tiered"), lambda: tiered_leg(a.extra_steps, 3, dev, a.alpha))
         run("ebc_dynamic_optimizers", ("all", "dynopt"),
             lambda: dynamic_optimizer_leg(a.extra_steps, 3, dev, a.alpha))
