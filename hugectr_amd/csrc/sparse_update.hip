@@ -2166,20 +2166,51 @@ __global__ void __launch_bounds__(kBlock)
     const uint32_t cnt = run_start[r + 1] - off;
     const uint64_t row = (uint64_t)sorted_rows[off];
     if (row == kNoRow) continue;
+    auto grad_of = [&](uint32_t k, int v) -> float {
+      const uint32_t b = sorted_buckets[off + k];
+      float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
+      if (combiner == 1) {
+        long long n = (long long)scale_ro[b + 1] - (long long)scale_ro[b];
+        if (n > 1) {
+          const float sc = 1.0f / (float)n;  // even sizes: align2 rule (16-bit scaler)
+          gv = Load4<GradT>::rnd(gv * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc));
+        }
+      }
+      return gv;
+    };
+    // A LONG run of a short vector (the wide tables of Wide & Deep: D = 1, a hot row met tens of
+    // thousands of times): with one lane per element the wavefront would walk the run with 1 .. 32
+    // lanes, two dependent loads per entry (measured: 1.75 ms per step for three D = 1 tables at
+    // batch 16384).  Instead 64 / L lane groups (L = D rounded up to a power of two) take every
+    // (64 / L)-th entry each, in ascending order, and their partial sums are combined by a fixed
+    // butterfly -- an association that depends on the run's length only.  Runs of up to 64 entries
+    // keep the plain ascending sum.
+    if (D <= 32 && cnt > 64u) {
+      int L = 1;
+      while (L < D) L <<= 1;
+      const int G = 64 / L, g = lane / L, v = lane % L;
+      float part = 0.0f;
+      if (v < D)
+        for (uint32_t k = (uint32_t)g; k < cnt; k += (uint32_t)G) part += grad_of(k, v);
+      for (int ofs = 32; ofs >= L; ofs >>= 1) part += __shfl_xor(part, ofs, 64);
+      if (g == 0 && v < D) {
+        const float gi = part / o.scaler;
+        const size_t f = row * (uint64_t)D + v;
+        float w = table[f];
+        float s0 = needs_s0(o) ? ld_state1(state0, f, o.state_half) : 0.f;
+        float s1 = needs_s1(o) ? ld_state1(state1, f, o.state_half) : 0.f;
+        unsigned long long pt = needs_pt(o) ? prev_time[f] : 1ull;
+        apply_opt(o, gi, w, &s0, &s1, &pt);
+        table[f] = w;
+        if (needs_s0(o)) st_state1(state0, f, o.state_half, s0);
+        if (needs_s1(o)) st_state1(state1, f, o.state_half, s1);
+        if (needs_pt(o)) prev_time[f] = pt;
+      }
+      continue;
+    }
     for (int v = lane; v < D; v += 64) {
       float gi = 0.0f;
-      for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t b = sorted_buckets[off + k];
-        float gv = Load4<GradT>::ld1(grad + (size_t)b * D + v);
-        if (combiner == 1) {
-          long long n = (long long)scale_ro[b + 1] - (long long)scale_ro[b];
-          if (n > 1) {
-            const float sc = 1.0f / (float)n;  // even sizes: align2 rule (16-bit scaler)
-            gv = Load4<GradT>::rnd(gv * (D % 2 == 0 ? Load4<GradT>::rnd(sc) : sc));
-          }
-        }
-        gi += gv;
-      }
+      for (uint32_t k = 0; k < cnt; k++) gi += grad_of(k, v);
       gi /= o.scaler;
       const size_t f = row * (uint64_t)D + v;
       float w = table[f];

@@ -918,3 +918,55 @@ def test_index_stage_beside_a_device_full_of_gemms(oracle, ahead):
             emb.index_adopt()
         emb.check_overflow()  # (a barrier that never opened raises here: error bit 4)
         assert (emb.value_index(k.size).cpu().numpy().view(np.uint64) == ht.get_insert(k)).all()
+
+
+@pytest.mark.parametrize("name,kw", [OPTS[0], OPTS[1], OPTS[4]], ids=["sgd", "adam_local", "adagrad"])
+@pytest.mark.parametrize("D,dt,combiner", [(1, "f32", 0), (1, "f16", 0), (3, "f32", 1), (6, "f16", 0),
+                                           (20, "f32", 0)])
+def test_long_runs_of_short_vectors_match_oracle(oracle, name, kw, D, dt, combiner):
+    """Vectors whose length is no multiple of 4 take the generic update (one wavefront per distinct
+    row); a row met more than 64 times in the batch -- the wide tables of Wide & Deep, D = 1, whose
+    hot rows collect thousands of gradients -- is summed by 64 / L lane groups side by side and a
+    fixed butterfly instead of one lane walking the run.  Tables of 2 / 5 / 300 rows: runs of ~ 1000,
+    ~ 400 and of a handful (the plain ascending sum), multi-hot and mean; the oracle adds in
+    ascending bucket order, so the bound is the re-association's: n eps per element."""
+    import torch
+    import hugectr_amd as ha
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(D)
+    tdt = torch.float16 if dt == "f16" else torch.float32
+    B, sizes, hot = 2048, [2, 5, 300], 2
+    S = len(sizes)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    V = int(sum(sizes))
+    opt = ha.OptParams(lr=0.05, scaler=4.0, **kw)
+    emb = ha.SparseEmbeddingHash(_lib.EMB_LOCALIZED, B, 0, V, D, S * hot, S, combiner, opt,
+                                 out_dtype=tdt)
+    emb.init_params()
+    torch.cuda.synchronize()
+    table = emb.table().cpu().numpy().copy()
+    ns = {1: 2, 3: 1, 6: 0}[opt.optimizer]
+    s0 = np.zeros_like(table) if ns >= 1 else None
+    s1 = np.zeros_like(table) if ns >= 2 else None
+    ht = oracle.HashTable(V, 8)
+    for it in range(3):
+        lens = rng.integers(1, hot + 1, size=B * S)
+        ro = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        slot_of = np.repeat(np.tile(np.arange(S), B), lens)
+        keys = (rng.integers(0, 1 << 30, size=slot_of.size) % np.array(sizes)[slot_of] + offs[slot_of]).astype(np.int64)
+        emb.forward(True, _t(torch, ro), _t(torch, keys))
+        vi = ht.get_insert(keys)
+        g = (rng.standard_normal((B * S, D)) * 0.1).astype(np.float32)
+        gt = _t(torch, g).to(tdt).view(B, S, D).contiguous()
+        emb.backward(gt)
+        emb.update_params()
+        torch.cuda.synchronize()
+        wg = oracle.backward(ro, gt.float().cpu().numpy().reshape(-1, D), D, combiner)
+        oo = _oracle_opt(oracle, opt, it + 1)
+        oo.state_half = 1 if dt == "f16" else 0
+        oracle.update_params(ro, vi, wg, oo, table, s0, s1, None)
+        # ~ 1000 addends of size 0.1: 1000 eps32 x 0.1 x sqrt-ish growth, / scaler, through lr (SGD) or the
+        # optimizer's normalisation (Adam / AdaGrad move by ~ lr whatever the gradient's size)
+        assert_close(emb.table().cpu().numpy(), table, 2e-4, 2e-5, f"{name} table it{it}")
+        if s0 is not None:
+            assert_close(emb.opt_state(0).float().cpu().numpy(), s0, 2e-3, 1e-5, f"{name} state0 it{it}")
