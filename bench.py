@@ -1196,8 +1196,8 @@ def c5_model_leg(steps, warmup, dev, B=16384):
     gates, two towers, two BinaryCrossEntropyLoss weighted 0.5 / 0.5) fed by an
     EmbeddingCollectionConfig as R/samples/wdl and R/samples/ftrl/dlrm_train_ftrl.py:222-245 write
     it -- deep tables ev = 16 (hotness 1..5) into the experts and gates, wide tables ev = 1 whose sum
-    joins tower A's logit (R/samples/wdl/wdl_1gpu.py's wide branch) -- AdaGrad, Parquet input.
-    One step = Model.train()."""
+    joins tower A's logit (R/samples/wdl/wdl_1gpu.py's wide branch) -- AdaGrad, Parquet input read
+    once and served from HBM.  One step = Model.train()."""
     import shutil
     import tempfile
     import hugectr_amd.hugectr as hugectr
@@ -1276,6 +1276,9 @@ def c5_model_leg(steps, warmup, dev, B=16384):
         m.add(L(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["B_fc2", "labelB"],
                 top_names=["lossB"]))
         m.compile(loss_names=["labelA", "labelB"], loss_weights=[0.5, 0.5])
+        # (as the other legs: read once through the Parquet reader, then served from HBM)
+        batches = [m.reader.next_batch(True) for _ in range(nb)]
+        m.reader = _CycleReader(batches)
         for _ in range(warmup):
             m.train()
         torch.cuda.synchronize()

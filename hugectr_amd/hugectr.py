@@ -685,14 +685,20 @@ class Model:
         self._mods.to(self.device)
         self._dense_params = [p for p in self._mods.parameters()]
         # solver.use_cuda_graph (graph_wrapper.cpp:30-41, default on): small batches are bound by
-        # launch latency, not by kernels -- the dense tower's forward, loss, backward and optimizer
-        # step are captured once into a HIP graph and replayed (one GPU, legacy embeddings, one loss,
-        # at most 8192 samples per step -- measured: 1.13 -> 0.51 ms at 1024, no gain at 16384;
-        # HCTR_HIP_GRAPH=0 keeps eager launches, =1 captures whatever the batch size)
+        # launch latency, not by kernels -- the dense tower's forward, loss(es), backward and
+        # optimizer step are captured once into a HIP graph and replayed (one GPU; legacy
+        # embeddings: at most 8192 samples per step -- measured: 1.13 -> 0.51 ms at 1024, no gain
+        # at 16384 on DeepFM; models on an embedding_collection: whatever the batch, their towers
+        # -- Wide & Deep, MMoE: tens of slices, gates and small MLPs per step -- are launch-bound
+        # far beyond that; HCTR_HIP_GRAPH=0 keeps eager launches, =1 captures whatever the model)
         env = os.environ.get("HCTR_HIP_GRAPH", "auto")
+        ebc_graph = bool(self.ebc_configs) and not self._emb and all(
+            isinstance(rt["train"], EmbeddingCollection) for rt in self._ebc)
         self._graph_ok = (bool(s.use_cuda_graph) and env != "0" and self.world == 1 and
-                          not self.ebc_configs and len(self._loss_layers) == 1 and
-                          (self.bpg <= 8192 or env == "1"))
+                          len(self._loss_layers) >= 1 and
+                          ((not self.ebc_configs and len(self._loss_layers) == 1 and
+                            (self.bpg <= 8192 or env == "1")) or
+                           (ebc_graph and (self.bpg <= 32768 or env == "1"))))
         self._graph, self._graph_wait = None, 0
         self._dense_opt = self._make_dense_opt()
         # Model.reader_override: anything with next_batch(train) / has_eval() handing out batches
@@ -1485,6 +1491,50 @@ class Model:
         tensors[name] = _Pending(resolve)
         after.append(finish)
 
+    def _ebc_tensors(self, tensors, rt, get_E):
+        """names the dense layers read -> (lazily resolved) pieces of one collection's output
+        [batch, lookups, ev], handed out by get_E()"""
+        cfg = rt["parent"]
+        span = getattr(rt["train"], "virt_span", None)
+
+        def piece(v0, reps, as_float=False):
+            def resolve():
+                E = get_E()
+                x = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
+                return x.float() if as_float else x
+            return _Pending(resolve)
+        if rt["whole"]:
+            if cfg.top_name:
+                tensors[cfg.top_name] = _Pending(get_E)
+            else:
+                for l, (_, _, top, _) in enumerate(cfg.lookups):
+                    v0, reps = span[l] if span else (l, 1)
+                    tensors[top] = piece(v0, reps)
+        else:  # one of several collections of a mixed-size config
+            for j, l in enumerate(rt["ids"]):
+                v0, reps = span[j] if span else (j, 1)
+                if cfg.top_name:
+                    tensors[(id(cfg), l)] = piece(v0, reps, as_float=True)
+                else:
+                    tensors[cfg.lookups[l][2]] = piece(v0, reps)
+
+    def _ebc_concat_tops(self, tensors):
+        for cfg in self.ebc_configs:
+            if cfg.top_name and dict.__contains__(tensors, (id(cfg), 0)):
+                n = len(cfg.lookups)
+                tensors[cfg.top_name] = _Pending(
+                    lambda cfg=cfg, n=n: torch.cat([tensors[(id(cfg), l)] for l in range(n)], dim=1))
+
+    def _multi_task_loss(self, tensors):
+        """weighted sum of the tasks' losses + every task's scores side by side"""
+        total, probs = None, []
+        for L, lg, lab in tensors["__logits__"]:
+            w = self._loss_weights.get(L.bottom_names[1], 1.0)
+            li = torch.nn.functional.binary_cross_entropy_with_logits(lg.float(), lab.float())
+            total = li * w if total is None else total + li * w
+            probs.append(torch.sigmoid(lg.float()))
+        return total, probs
+
     def _run_batch(self, batch, train: bool, nxt=None):
         tensors = _Tensors({self.input.dense_name: batch["dense"]})
         off = 0
@@ -1496,35 +1546,8 @@ class Model:
         for name in self._emb:
             self._emb_forward(name, batch, nxt, train, tensors, leaves, after)
         for i, rt in enumerate(self._ebc):
-            get_E = self._ebc_begin(rt, batch, train, after)
-            cfg = rt["parent"]
-            span = getattr(rt["train"], "virt_span", None)
-
-            def piece(v0, reps, get_E=get_E, as_float=False):
-                def resolve():
-                    E = get_E()
-                    x = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
-                    return x.float() if as_float else x
-                return _Pending(resolve)
-            if rt["whole"]:
-                if cfg.top_name:
-                    tensors[cfg.top_name] = _Pending(get_E)
-                else:
-                    for l, (_, _, top, _) in enumerate(cfg.lookups):
-                        v0, reps = span[l] if span else (l, 1)
-                        tensors[top] = piece(v0, reps)
-            else:  # one of several collections of a mixed-size config
-                for j, l in enumerate(rt["ids"]):
-                    v0, reps = span[j] if span else (j, 1)
-                    if cfg.top_name:
-                        tensors[(id(cfg), l)] = piece(v0, reps, as_float=True)
-                    else:
-                        tensors[cfg.lookups[l][2]] = piece(v0, reps)
-        for cfg in self.ebc_configs:
-            if cfg.top_name and dict.__contains__(tensors, (id(cfg), 0)):
-                n = len(cfg.lookups)
-                tensors[cfg.top_name] = _Pending(
-                    lambda cfg=cfg, n=n: torch.cat([tensors[(id(cfg), l)] for l in range(n)], dim=1))
+            self._ebc_tensors(tensors, rt, self._ebc_begin(rt, batch, train, after))
+        self._ebc_concat_tops(tensors)
         label = batch["label"].float()
         # the logit gradient is (sigmoid - y) * scaler / batch_per_gpu / total_gpu_count
         # (BinaryCrossEntropy_Kernel, R/HugeCTR/src/loss.cu:242-249): every gradient below --
@@ -1539,12 +1562,7 @@ class Model:
         logit, loss = self._forward_dense(tensors, train, head)
         if multi:
             # weighted sum of the tasks' losses; evaluation scores = every task's, side by side
-            total, probs = None, []
-            for L, lg, lab in tensors["__logits__"]:
-                w = self._loss_weights.get(L.bottom_names[1], 1.0)
-                li = torch.nn.functional.binary_cross_entropy_with_logits(lg.float(), lab.float())
-                total = li * w if total is None else total + li * w
-                probs.append(torch.sigmoid(lg.float()))
+            total, probs = self._multi_task_loss(tensors)
             if not train:
                 return total, torch.cat(probs, dim=1)
             (total * (self.solver.scaler / self.world)).backward()
@@ -1574,17 +1592,28 @@ class Model:
     def _graph_dense(self, G, skip_step: bool):
         """forward of the dense layers on the graph's static inputs, loss, backward, optimizer step"""
         tensors = _Tensors({self.input.dense_name: G["dense"]})
-        tensors[self.input.label_names[0]] = G["label"]
+        off = 0
+        for n, d in zip(self.input.label_names, self.input.label_dims):
+            tensors[n] = G["label"] if len(self.input.label_names) == 1 else \
+                G["label"][:, off:off + d]
+            off += d
         for name, (se, p, h, ex, localized) in self._emb.items():
             if self._xstate[name]["fused_gather"]:
                 tensors[name] = _GatherEmb(h, True, lambda g, n=name: G["grads"].__setitem__(n, g))
             else:
                 tensors[name] = G["leaf"][name]
+        for i, rt in enumerate(self._ebc):
+            self._ebc_tensors(tensors, rt, lambda i=i: G["ebc_leaf"][i])
+        self._ebc_concat_tops(tensors)
         gscale = self.solver.scaler / max(self.bpg, 1)
-        head = (G["label"], gscale) if (self._head_layer is not None and
+        multi = len(self._loss_layers) > 1
+        head = (G["label"], gscale) if (self._head_layer is not None and not multi and
                                         G["label"].shape[1] == 1) else None
         logit, loss = self._forward_dense(tensors, True, head)
-        if loss is not None:
+        if multi:
+            loss, _ = self._multi_task_loss(tensors)
+            (loss * self.solver.scaler).backward()
+        elif loss is not None:
             loss.backward()
         else:
             lg = tensors[self._loss_layer.bottom_names[0]]
@@ -1592,16 +1621,21 @@ class Model:
             lg.backward(dlogit)
         for name, leaf in G["leaf"].items():
             G["grads"][name] = leaf.grad
+        for i, leaf in enumerate(G["ebc_leaf"]):
+            G["ebc_grads"][i] = leaf.grad
         self._dense_step(skip=skip_step)
         return loss.detach().reshape(())
 
     def _graph_capture(self, batch):
         B = self.bpg
-        G = {"lr": self._lr, "leaf": {}, "pooled": {}, "grads": {},
+        G = {"lr": self._lr, "leaf": {}, "pooled": {}, "grads": {}, "ebc_leaf": [], "ebc_grads": {},
              "dense": torch.empty_like(batch["dense"]),
              "label": torch.empty_like(batch["label"].float())}
         G["dense"].copy_(batch["dense"])
         G["label"].copy_(batch["label"].float())
+        for rt in self._ebc:  # the collections' outputs: static leaves the replay reads
+            E = self._ebc_forward(rt, batch, True)
+            G["ebc_leaf"].append(E.detach().clone().requires_grad_(True))
         for name, (se, p, h, ex, localized) in self._emb.items():
             ro, keys = batch["sparse"][se.bottom_name]
             if self._xstate[name]["fused_gather"]:
@@ -1621,7 +1655,7 @@ class Model:
             for _ in range(2):
                 self._graph_dense(G, skip_step=True)
         torch.cuda.current_stream().wait_stream(side)
-        for leaf in G["leaf"].values():
+        for leaf in list(G["leaf"].values()) + G["ebc_leaf"]:
             leaf.grad = None
         for q in self._dense_params:
             q.grad = None
@@ -1645,9 +1679,17 @@ class Model:
                     h.index(True, ro, keys)
                 else:
                     h.forward(True, ro, keys, out=G["pooled"][name])
+            for i, rt in enumerate(self._ebc):
+                with torch.no_grad():
+                    G["ebc_leaf"][i].copy_(self._ebc_forward(rt, batch, True))
             G["dense"].copy_(batch["dense"])
             G["label"].copy_(batch["label"])
         G["graph"].replay()
+        for i, rt in enumerate(self._ebc):
+            g = G["ebc_grads"].get(i)
+            if g is not None:  # (None: the losses do not depend on this collection's output)
+                rt["train"].lr = self._lr
+                rt["train"].backward_and_update(g.contiguous())
         for name, (se, p, h, ex, localized) in self._emb.items():
             g = G["grads"][name]
             if not self._xstate[name]["fused_gather"]:

@@ -149,6 +149,53 @@ def test_get_insert_empty_and_single(oracle):
     assert ht.value_head() == 1
 
 
+@pytest.mark.parametrize("n,distinct_new", [(100_000, 40), (100_000, 5_000), (3_000, 700)])
+def test_unseen_and_erased_keys_repeated_many_times_inside_one_batch(n, distinct_new):
+    """The unseen keys' protocol under contention: a batch in which FEW unseen keys fill most
+    positions (the thread that claims a key's slot and the many other occurrences of the key meet
+    within nanoseconds: claim, store, atomic min and the mins deferred to the finish kernel all
+    occur), next to erased keys -- entries whose key is in the table with "no row" as a dynamic
+    table's remove() leaves them, which nobody claims -- and known keys.  Rows must be what a
+    sequential insert in position order hands out (first occurrence of an unseen OR erased key takes
+    the next row)."""
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(int(os.environ.get("HCTR_TEST_SEED", "0")) + 11)
+    cap = 60_000
+    ht = GpuHT(cap, _lib.KEY_I64)
+    known = (rng.permutation(40_000)[:8_000].astype(np.int64) * 7919 + 3)
+    r0 = ht.get_insert(_mk(torch, known, torch.int64))
+    assert (r0 == np.arange(known.size, dtype=np.uint64)).all()
+    erased = np.arange(1, 301, dtype=np.int64) * 1_000_003 + 10**12
+    ev = torch.full((erased.size,), -1, dtype=torch.int64, device="cuda")  # SIZE_MAX: "no row"
+    et = _mk(torch, erased, torch.int64)
+    _lib.check(_lib.lib.hctr_ht_insert(ht.h, _lib.ptr(et), _lib.ptr(ev), erased.size, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    state = {int(k): i for i, k in enumerate(known.tolist())}
+    head = known.size
+    for batch in range(3):
+        fresh = rng.integers(1, 2**40, size=distinct_new).astype(np.int64) + 10**13 * (batch + 1)
+        # most positions: the few fresh keys; the rest: erased and known keys
+        pick = rng.random(n)
+        keys = np.where(pick < 0.7, fresh[rng.integers(0, fresh.size, n)],
+                        np.where(pick < 0.85, erased[rng.integers(0, erased.size, n)],
+                                 known[rng.integers(0, known.size, n)]))
+        want = np.empty(n, dtype=np.uint64)
+        for i, k in enumerate(keys.tolist()):
+            r = state.get(k)
+            if r is None:
+                r = state[k] = head
+                head += 1
+            want[i] = r
+        got = ht.get_insert(_mk(torch, keys, torch.int64))
+        assert (got == want).all(), f"batch {batch}: {int((got != want).sum())} positions differ"
+        assert ht.value_head() == head
+    # everything is a plain hit now
+    allk = np.array(list(state.keys()), dtype=np.int64)
+    assert (ht.get_mark(_mk(torch, allk, torch.int64)) ==
+            np.array(list(state.values()), dtype=np.uint64)).all()
+
+
 def test_overflow_is_flagged():
     """more distinct keys than max_vocabulary_size_per_gpu -> check_overflow raises
     (R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:552-569)"""

@@ -999,3 +999,87 @@ def test_hip_graph_replay_trains_like_eager_launches(tmp_path, monkeypatch, mixe
     assert_allclose(b[2][ob], a[2][oa], **tol)
     assert_allclose(b[3], a[3], **tol)
     assert abs(a[4] - b[4]) < 1e-2
+
+
+def _wdl_two_task_model(hugectr, tmp_path, p, hot, two_tasks):
+    solver = hugectr.CreateSolver(batchsize=512, batchsize_eval=512, lr=0.05, vvgpu=[[0]],
+                                  i64_input_key=True, max_eval_batches=1, seed=11,
+                                  use_mixed_precision=True, scaler=1024.0,
+                                  use_embedding_collection=True)
+    reader = hugectr.DataReaderParams(data_reader_type=hugectr.DataReaderType_t.Parquet,
+                                      source=[p.source], eval_source=p.eval_source,
+                                      slot_size_array=SIZES, check_type=hugectr.Check_t.Non)
+    opt = hugectr.CreateOptimizer(optimizer_type=hugectr.Optimizer_t.AdaGrad,
+                                  update_type=hugectr.Update_t.Global)
+    model = hugectr.Model(solver, reader, opt)
+    model.add(hugectr.Input(label_dim=1, label_name="label", dense_dim=13, dense_name="dense",
+                            data_reader_sparse_param_array=[
+                                hugectr.DataReaderSparseParam(f"data{i}", hot[i], True, 1)
+                                for i in range(26)]))
+    wide, deep = [0, 1], list(range(2, 10))
+    ebc = hugectr.EmbeddingCollectionConfig()
+    for i in wide:
+        ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"w{i}", -1, 1),
+                             bottom_name=f"data{i}", top_name=f"wide{i}", combiner="sum")
+    for i in deep:
+        ebc.embedding_lookup(table_config=hugectr.EmbeddingTableConfig(f"d{i}", -1, 16),
+                             bottom_name=f"data{i}", top_name=f"deep{i}", combiner="sum")
+    names = [f"w{i}" for i in wide] + [f"d{i}" for i in deep]
+    ebc.shard(shard_matrix=[names], shard_strategy=[("mp", names)])
+    model.add(ebc)
+    D, T, A = hugectr.DenseLayer, hugectr.Layer_t, hugectr.Activation_t
+    model.add(D(layer_type=T.Concat, bottom_names=[f"deep{i}" for i in deep], top_names=["emb"]))
+    model.add(D(layer_type=T.Slice, bottom_names=["emb"], top_names=["inA", "inB"],
+                ranges=[(0, 128), (0, 128)]))
+    model.add(D(layer_type=T.MLP, bottom_names=["inA"], top_names=["mlpA"], num_outputs=[64, 1],
+                activations=[A.Relu, A.Non]))
+    model.add(D(layer_type=T.Concat, bottom_names=[f"wide{i}" for i in wide], top_names=["wide"]))
+    model.add(D(layer_type=T.ReduceSum, bottom_names=["wide"], top_names=["wide_sum"], axis=1))
+    model.add(D(layer_type=T.Add, bottom_names=["mlpA", "wide_sum"], top_names=["logitA"]))
+    model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["logitA", "label"],
+                top_names=["lossA"]))
+    if two_tasks:  # a second tower on the same label: two BinaryCrossEntropyLoss layers
+        model.add(D(layer_type=T.MLP, bottom_names=["inB"], top_names=["logitB"],
+                    num_outputs=[32, 1], activations=[A.Relu, A.Non]))
+        model.add(D(layer_type=T.BinaryCrossEntropyLoss, bottom_names=["logitB", "label"],
+                    top_names=["lossB"]))
+    model.compile()
+    return model
+
+
+@pytest.mark.parametrize("two_tasks", [False, True])
+def test_hip_graph_replay_of_an_embedding_collection_model(tmp_path, monkeypatch, two_tasks):
+    """use_cuda_graph on a model written with EmbeddingCollectionConfig (Wide & Deep on dynamic
+    tables, mixed vector sizes, fp16 tower, one or two losses -- BASELINE configs[4]'s family):
+    the collections' lookups and their backward + update stay eager launches around the replayed
+    dense tower.  The same steps with and without the graph give the same losses and tables."""
+    import hugectr_amd.hugectr as hugectr
+    from numpy.testing import assert_allclose
+    hot = [1, 2] + [1] * 24
+    p = _gen(tmp_path, hugectr, n_train=4096, n_eval=512, nnz=hot)
+    res = {}
+    for mode in ("0", "auto"):
+        monkeypatch.setenv("HCTR_HIP_GRAPH", mode)
+        torch.manual_seed(5)
+        m = _wdl_two_task_model(hugectr, tmp_path, p, hot, two_tasks)
+        losses = []
+        for _ in range(10):
+            assert m.train()
+            losses.append(m.get_current_loss())
+        if os.environ.get("HCTR_EMU") != "1":  # (the host interpreter has no graphs: eager both times)
+            assert (m._graph is not None) == (mode == "auto")
+        tabs = {}
+        for rt in m._ebc:
+            e = rt["train"]
+            for t in range(len(e.class_of_table)):
+                k, v = e.det.export(e.class_of_table[t])
+                o = torch.argsort(k)
+                tabs[(e.ev, t)] = (k[o].cpu().numpy(), v[o].float().cpu().numpy())
+        res[mode] = (np.array(losses), tabs)
+    a, b = res["0"], res["auto"]
+    assert np.isfinite(b[0]).all() and b[0][-1] < b[0][0]
+    assert_allclose(b[0], a[0], rtol=2e-3)
+    assert a[1].keys() == b[1].keys()
+    for key in a[1]:
+        assert (a[1][key][0] == b[1][key][0]).all()
+        assert_allclose(b[1][key][1], a[1][key][1], rtol=5e-3, atol=5e-4)
