@@ -76,6 +76,8 @@ struct HashTable {
   uint32_t* block_cnt = nullptr;    // entries of every segment (behind the list)
   uint32_t* d_parity = nullptr;     // which mask buffer the next inserting batch takes
   uint32_t* d_snap = nullptr;       // two-launch finish: what its first half saw (FinishCtl::snap)
+  uint32_t* d_barrier_odd = nullptr;  // arrivals of the odd generations (d_barrier[0]: the even ones)
+  uint32_t* d_defer = nullptr;      // the probe kernel left some atomic mins to the finish kernel
   uint64_t* d_scratch64 = nullptr;  // 1 element
 
   int create(size_t capacity, int key_type);

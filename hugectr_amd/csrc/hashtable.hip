@@ -9,11 +9,22 @@
 // keys of the batch), i.e. exactly what a sequential insert in array order produces.
 //
 // get_insert is 2 launches (round 3; five before):
-//   1 probe_insert : find/claim slot (CAS on key); known key -> index; unseen -> atomicMin of
-//                    (PENDING | position) into the slot value, out = PENDING | slot.  Its threads
-//                    also make the caller's private copy of the row offsets (world == 1).
+//   1 probe_insert : find/claim slot (CAS on key); known key -> index; unseen -> out = PENDING |
+//                    slot and the slot value becomes PENDING | (smallest position of the key).
+//                    Two forms, chosen per batch from the number of keys the PREVIOUS batch
+//                    inserted (a device word: no host decision).  Few unseen keys (steady state):
+//                    every occurrence lowers the value with an atomic min.  Many (a first epoch):
+//                    the thread that CLAIMED the slot stores PENDING | its position (an atomic
+//                    store, no read-modify-write: one memory-side atomic per unseen key instead of
+//                    two), a later occurrence that SEES a pending value lowers it with an atomic
+//                    min (the store it saw precedes its min in the word's modification order), and
+//                    one that sees "no row yet" (the claimer's store still on its way, or an erased
+//                    key, which nobody claims) defers its min to the finish kernel (list flag; the
+//                    finish kernel then runs those first and takes a second grid barrier).  Its
+//                    threads also make the caller's private copy of the row offsets (world == 1).
 //   2 finish       : exits on one scalar load when the batch held no unseen key.  Otherwise, in
-//                    kHtFinishBlocks co-resident workgroups with ONE grid barrier between them:
+//                    kHtFinishBlocks co-resident workgroups with ONE grid barrier between them (two
+//                    when the batch deferred any min: (0) those run first, then a barrier):
 //                    (A) per 64 positions a mask of the FIRST occurrences of unseen keys + counts
 //                    per workgroup; barrier; (S) every workgroup scans the counts, workgroup 0
 //                    bumps the row counter; (D) every pending position computes its key's row =
@@ -65,16 +76,30 @@ __global__ void ht_init_kernel(HtEntry* e, uint64_t size, long long empty) {
 // one key, the full protocol: probe (linear), claim an empty slot for an unseen key, hand back the
 // row or the pending marker (see the header of this file).  Returns true when the position is left
 // pending (the caller appends it to the batch's list: the finish kernel works on that list only).
+// list entry of a pending position: bit 31 = its atomic min on the slot value is still to be done
+constexpr uint32_t kListDefer = 0x80000000u;
+
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Returns 0: resolved (out[i] written), 1: left pending, 2: left pending and its min deferred.
 template <typename K>
-__device__ __forceinline__ bool ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
-                                                    K key, size_t i, uint64_t* __restrict__ out,
-                                                    uint32_t* d_error) {
+__device__ __forceinline__ int ht_probe_insert_one(HtEntry* __restrict__ tab, uint64_t size,
+                                                   K key, size_t i, uint64_t* __restrict__ out,
+                                                   uint32_t* d_error, uint64_t slot, long long cur,
+                                                   bool store_form) {
+  // `cur` = the key of the home entry as the caller has just read it: an unseen key whose home slot
+  // is empty goes straight to its claim.
   const long long empty = KeyTraits<K>::empty;
   const long long k64 = widen<K>(key);
-  uint64_t slot = (uint64_t)murmur3_key(key) % size;
   bool ok = false, claimed = false;
   for (uint64_t probes = 0; probes < size; ++probes) {
-    long long cur = tab[slot].key;
     if (cur == k64) {
       ok = true;
       break;
@@ -89,24 +114,39 @@ __device__ __forceinline__ bool ht_probe_insert_one(HtEntry* __restrict__ tab, u
       }
     }
     slot = (slot + 1 == size) ? 0 : slot + 1;
+    cur = tab[slot].key;
   }
   if (!ok) {
     atomicOr(d_error, 1u);
     out[i] = kInvalidIndex;
-    return false;
+    return 0;
   }
-  if (!claimed) {  // (a slot this thread has just claimed holds no row yet: no read needed)
+  out[i] = kPendingBit | slot;  // (overwritten below when the key turns out to own a row)
+  if (store_form) {
+    if (claimed) {
+      // the ONE claimer of the slot: nobody lowers the value before seeing this store (below)
+      st_agent(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i));
+      return 1;
+    }
+    // (an atomic load: what it returns is ordered against this thread's atomic min on the word)
+    const unsigned long long v = ld_agent(&tab[slot].val);
+    if (v < kPendingBit) {
+      out[i] = row_of(v);
+      return 0;
+    }
+    if (v == kInvalidIndex) return 2;  // no pending value to lower yet: the finish kernel's phase 0
+  } else if (!claimed) {
+    // (a slot this thread has just claimed holds no row yet: no read needed)
     const unsigned long long v = tab[slot].val;
     if (v < kPendingBit) {
       out[i] = row_of(v);
-      return false;
+      return 0;
     }
   }
   // no-return atomic: nothing waits for it
   (void)__hip_atomic_fetch_min(&tab[slot].val, (unsigned long long)(kPendingBit | (uint64_t)i),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  out[i] = kPendingBit | slot;
-  return true;
+  return 1;
 }
 
 // Steady state = every key is in the table and sits in its home slot or close to it, so the
@@ -115,12 +155,15 @@ __device__ __forceinline__ bool ht_probe_insert_one(HtEntry* __restrict__ tab, u
 // entry is not its own (collision, or unseen) walks the full protocol above.
 constexpr int kHtUnroll = 4;
 
+// (8 waves per SIMD = at most 64 VGPRs: the grid of a 1.7 M-key batch is 6.5 waves per SIMD and must
+//  be resident at once -- at 74 VGPRs / 6 waves the steady probe was measured 27.6 -> 33.1 us)
 template <typename K>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 8)
     ht_probe_insert_kernel(HtEntry* __restrict__ tab, uint64_t size, const K* __restrict__ keys,
                            size_t n, const uint64_t* d_n, uint64_t* __restrict__ out,
                            uint32_t* d_pending, uint32_t* __restrict__ d_list,
                            uint32_t* __restrict__ block_cnt, uint32_t seg_cap, uint32_t* d_error,
+                           uint32_t* d_defer, const uint64_t* __restrict__ d_prev_new,
                            const K* __restrict__ ro_src, K* __restrict__ ro_dst, size_t n_offsets,
                            uint32_t* __restrict__ one_hot) {
   // Positions left pending go to THIS workgroup's segment of the batch's list, d_list[blockIdx *
@@ -131,6 +174,8 @@ __global__ void __launch_bounds__(kBlock)
   if (threadIdx.x == 0) s_cnt = 0u;
   __syncthreads();
   const size_t nl = live_count(d_n, n);
+  // more than an eighth of the previous batch's keys were unseen: the claimers store (header)
+  const bool store_form = *d_prev_new * 8ull > (uint64_t)nl;
   const size_t nthreads = (size_t)gridDim.x * kBlock;
   const size_t gtid = blockIdx.x * (size_t)kBlock + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -162,14 +207,17 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int u = 0; u < kHtUnroll; u++) {
       const size_t i = i0 + (size_t)u * nthreads;
-      bool pend = false;
+      int pst = 0;
       if (i < nl) {
         if ((long long)ent[u].x == widen<K>(key[u]) && ent[u].y < kPendingBit)
           out[i] = row_of(ent[u].y);
         else  // (issuing the four keys' claims together was measured: no gain with 4 % unseen
               //  keys, and the steady state lost 5 us to the extra registers)
-          pend = ht_probe_insert_one<K>(tab, size, key[u], i, out, d_error);
+          pst = ht_probe_insert_one<K>(tab, size, key[u], i, out, d_error, slot[u],
+                                        (long long)ent[u].x, store_form);
       }
+      const bool pend = pst != 0;
+      if (pst == 2) *d_defer = 1u;  // (benign race: every writer stores 1)
       const unsigned long long m = __ballot(pend);
       if (m != 0ull) {  // one LDS atomic per wavefront and unroll step that has any
         const int leader = __ffsll((long long)m) - 1;
@@ -178,7 +226,8 @@ __global__ void __launch_bounds__(kBlock)
         base = (uint32_t)__shfl((int)base, leader, 64);
         if (pend) {
           const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          if (k < seg_cap) my_list[k] = (uint32_t)i;  // (seg_cap = every key of this workgroup)
+          // (seg_cap = every key of this workgroup)
+          if (k < seg_cap) my_list[k] = (uint32_t)i | (pst == 2 ? kListDefer : 0u);
         }
       }
     }
@@ -249,7 +298,8 @@ __device__ __forceinline__ void record_slot_id(const SlotIdSink& k, uint64_t pos
 
 // ---- get_insert, launch 2 ------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
-constexpr int kFinRegions = 2048;  // (their bases live in LDS: 8 KB)
+constexpr int kFinRegions = 4096;  // (their bases live in LDS: 16 KB; 1.7 M positions: regions of
+                                    //  448 = 7 mask words, which phase D loads in one batch)
 constexpr int kProbeMaxBlocks = 4096;  // workgroups of the probe kernel (their list segments'
                                        // first entries live in the finish kernel's LDS: 16 KB)
 constexpr uint32_t kSpinLimit = 1u << 24;  // (a barrier that never opens raises error bit 2^2)
@@ -260,6 +310,8 @@ constexpr uint32_t kBarAbort = 1u << 31;
 
 struct FinishCtl {
   uint32_t *pending, *latched, *error, *barrier;
+  uint32_t* barrier_odd;  // arrivals of the barriers with an odd generation (grid_barrier)
+  uint32_t* defer;  // set by the probe kernel when some position left its atomic min to phase 0
   uint32_t* snap;  // two-launch form: {unseen keys?, mask parity, row counter lo, hi} of the first half
   uint64_t *counter, *base, *new_count;
   // positions whose key was not in the table: segment b of the list = [b * seg_cap, ... +
@@ -295,19 +347,18 @@ __device__ __forceinline__ void post_to_host(const FinishCtl& c, uint64_t rows) 
 // barrier itself needs no cache write-back / invalidate (an agent-scope release fence writes the
 // XCD's whole L2 back -- measured ~20 us per barrier with the probe kernel's 14 MB of fresh
 // stores sitting there).
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ void st_agent(T* p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // all workgroups of the grid are resident (grid <= kHtFinishBlocks, far below what 256 CUs hold):
 // sense-reversing barrier on {arrived, generation}.  __syncthreads: every wave has waited for
-// its (write-through) stores before thread 0 arrives.
-__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks, uint32_t spin_limit) {
+// its (write-through) stores before thread 0 arrives.  `gen` = the generation word as thread 0 read
+// it when the kernel began (it cannot move before this workgroup has arrived; a second barrier of
+// the same launch passes gen + 1): no read of it sits between the phase in front and the arrival.
+// Arrivals are counted on one of TWO words, picked by the generation's parity: the workgroup that
+// arrives last puts its word back to zero WITHOUT waiting for that store before it opens the
+// barrier -- the next barrier counts on the other word, and the one after that cannot open before
+// this workgroup has arrived at it, which it does with every memory operation of its own drained.
+__device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t* cnt_odd, uint32_t nblocks,
+                                             uint32_t spin_limit, uint32_t gen) {
   // every thread waits for ITS OWN outstanding memory operations first (the no-return atomics on
   // masks / region counts of phase A included): the workgroup barrier alone orders the waves, not
   // the arrival of their atomics at the memory side -- a per-wave wait, no cache write-back
@@ -316,16 +367,14 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks, ui
   __shared__ uint32_t ok;
   if (threadIdx.x == 0) {
     ok = 1u;
-    const uint32_t gen = ld_agent(bar + 1);
-    __builtin_amdgcn_s_waitcnt(0);  // (the generation is read before this workgroup arrives)
     if (gen & kBarAbort) {
       ok = 0u;  // given up before this workgroup arrived (or never cleared by the host)
     } else {
+      uint32_t* const cnt = (gen & 1u) ? cnt_odd : bar;
       const uint32_t old =
-          __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old == nblocks - 1u) {
-        st_agent(bar, 0u);
-        __builtin_amdgcn_s_waitcnt(0);  // (the count is back at zero before anybody is released)
+        st_agent(cnt, 0u);
         // opens the barrier -- unless a waiter has given up in the meantime
         uint32_t expect = gen;
         if (!__hip_atomic_compare_exchange_strong(bar + 1, &expect, (gen + 1u) & ~kBarAbort,
@@ -361,6 +410,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* bar, uint32_t nblocks, ui
   return ok != 0u;
 }
 
+// PHASE 3: phase 0 alone (the deferred atomic mins), in front of PHASE 1 in the two-launch form.
 // PHASE 0: the whole kernel, one grid barrier between its halves (every workgroup resident: the
 // in-line index stage).  PHASE 1 / 2: the same two halves as two launches, no barrier -- for an
 // index stage that runs beside other work (hctr_emb_index_ahead under the dense tower's GEMMs: a
@@ -374,6 +424,8 @@ __global__ void __launch_bounds__(kFinBlock)
                      SlotIdSink sink, uint64_t capacity) {
   if constexpr (PHASE == 2) {
     if (c.snap[0] == 0u) return;
+  } else if constexpr (PHASE == 3) {
+    if (*c.pending == 0u || *c.defer == 0u) return;
   } else {
     if (*c.pending == 0u) {  // steady state: no unseen key in this batch
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -386,6 +438,11 @@ __global__ void __launch_bounds__(kFinBlock)
       }
       return;
     }
+  }
+  // (thread 0: the barrier's generation, read here so that its latency hides behind phase A)
+  uint32_t bar_gen = 0u;
+  if constexpr (PHASE == 0) {
+    if (threadIdx.x == 0) bar_gen = ld_agent(c.barrier + 1);
   }
   __shared__ uint32_t smem[kFinBlock / 64 + 1];
   // v2: a finish workgroup takes the list segments of ITS share of the probe workgroups (a few
@@ -419,8 +476,46 @@ __global__ void __launch_bounds__(kFinBlock)
       if (seg_first[mid] <= (uint32_t)k) lo = mid;
       else hi = mid;
     }
-    return (uint64_t)c.list[(size_t)(q0 + lo) * c.seg_cap + ((uint32_t)k - seg_first[lo])];
+    return c.list[(size_t)(q0 + lo) * c.seg_cap + ((uint32_t)k - seg_first[lo])];
   };
+  // ---- 0: the atomic mins the probe kernel deferred (a position that met its key's slot before
+  //         the claimer's store had arrived, or an erased key: nobody claims those).  The probe
+  //         kernel is over, so every claimer's store is in place; a barrier, then phase A reads
+  //         the smallest position of every key ------------------------------------------------------
+  auto give_up = [&]() {
+    for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock)
+      out[entry(k) & ~kListDefer] = kInvalidIndex;
+    if (threadIdx.x == 0) {
+      const uint32_t e = atomicOr(c.error, 4u) | 4u;
+      if (c.host_error != nullptr) *c.host_error = e;
+      if (b == 0) *c.new_count = 0;  // (nobody may initialise "the rows this batch created")
+    }
+  };
+  if constexpr (PHASE == 0 || PHASE == 3) {
+    const bool deferred = PHASE == 3 || *c.defer != 0u;  // (uniform over the grid)
+    if (deferred) {
+      for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) {
+        const uint32_t raw = entry(k);
+        if ((raw & kListDefer) != 0u) {
+          const uint64_t i = (uint64_t)(raw & ~kListDefer);
+          const uint64_t slot = out[i] & ~kPendingBit;
+          (void)__hip_atomic_fetch_min(&tab[slot].val, (unsigned long long)(kPendingBit | i),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if constexpr (PHASE == 3) return;  // (the launch boundary is the barrier)
+      if (!grid_barrier(c.barrier, c.barrier_odd, G, c.spin_limit, bar_gen)) {
+        give_up();
+        return;
+      }
+      bar_gen = (bar_gen + 1u) & ~kBarAbort;
+      if (b == 0 && threadIdx.x == 0) *c.defer = 0u;  // (every workgroup has read it)
+    }
+  }
+  if constexpr (PHASE == 3) return;
+  if constexpr (PHASE == 1) {
+    if (b == 0 && threadIdx.x == 0) *c.defer = 0u;  // (read by the launch in front of this one)
+  }
   // (workgroup 0 moves the counter and flips the parity only behind the barrier / in the second
   //  launch, which reads the first launch's snapshot)
   const uint64_t c0 = PHASE == 2 ? ((uint64_t)c.snap[3] << 32 | c.snap[2]) : *c.counter;
@@ -450,8 +545,13 @@ __global__ void __launch_bounds__(kFinBlock)
   // ---- A: the pending positions that hold the FIRST occurrence of their key set their bit and
   //         count themselves into their region --------------------------------------------------
   // (the first kKeep entries of a thread stay in registers for phase D: two dependent loads less)
-  constexpr int kKeep = PHASE == 0 ? 4 : 0;  // (two launches: nothing survives in registers)
-  uint64_t keep_i[kKeep > 0 ? kKeep : 1], keep_slot[kKeep > 0 ? kKeep : 1];
+  // kept per entry: position, slot and the slot's value as phase A read it -- PENDING | first
+  // position of the key.  Nobody publishes a row in front of the barrier, so phase D ranks from
+  // the kept value and never reads the table again (one random read per unseen key less; a dense
+  // list of 6656 entries per workgroup fits the eight kept rounds whole).
+  constexpr int kKeep = PHASE == 0 ? 8 : 0;  // (two launches: nothing survives in registers)
+  uint32_t keep_i[kKeep > 0 ? kKeep : 1];
+  uint64_t keep_slot[kKeep > 0 ? kKeep : 1], keep_v[kKeep > 0 ? kKeep : 1];
   if constexpr (PHASE != 2) {
     // A DENSE list (most keys of the batch unseen: a first epoch): the 64 entries of a wavefront
     // are consecutive positions of one probe workgroup, i.e. one or two mask words, and 64 atomics
@@ -493,33 +593,36 @@ __global__ void __launch_bounds__(kFinBlock)
 #pragma unroll
     for (int j = 0; j < kKeep; j++) {
       const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
-      keep_i[j] = 0;
+      keep_i[j] = 0u;
       keep_slot[j] = 0;
+      keep_v[j] = 0;
       bool first = false;
       if (k < P) {
-        const uint64_t i = entry(k);
+        const uint64_t i = (uint64_t)(entry(k) & ~kListDefer);
         const uint64_t slot = out[i] & ~kPendingBit;
-        keep_i[j] = i;
+        keep_i[j] = (uint32_t)i;
         keep_slot[j] = slot;
-        first = tab[slot].val == (kPendingBit | i);
+        // (memory-side atomics of this launch may have written the word: past the caches)
+        keep_v[j] = ld_agent(&tab[slot].val);
+        first = keep_v[j] == (kPendingBit | i);
       }
-      mark(first, keep_i[j]);
+      mark(first, (uint64_t)keep_i[j]);
     }
     for (size_t k0 = (size_t)kKeep * kFinBlock; k0 < P; k0 += kFinBlock) {  // (uniform trips)
       const size_t k = k0 + threadIdx.x;
       bool first = false;
       uint64_t i = 0;
       if (k < P) {
-        i = entry(k);
+        i = (uint64_t)(entry(k) & ~kListDefer);
         const uint64_t slot = out[i] & ~kPendingBit;
-        first = tab[slot].val == (kPendingBit | i);
+        first = ld_agent(&tab[slot].val) == (kPendingBit | i);
       }
       mark(first, i);
     }
   }
   if constexpr (PHASE == 1) return;  // (the launch boundary is the barrier)
   if constexpr (PHASE == 0) {
-    if (!grid_barrier(c.barrier, G, c.spin_limit)) {
+    if (!grid_barrier(c.barrier, c.barrier_odd, G, c.spin_limit, bar_gen)) {
       // the barrier did not open (the grid was not resident as a whole: a partitioned or masked
       // device, or other work holding the CUs): no row is handed out to ANY position of the batch
       // (grid_barrier: all workgroups fail together).  The pending positions of this workgroup's
@@ -527,12 +630,7 @@ __global__ void __launch_bounds__(kFinBlock)
       // generation word stays poisoned: every later batch fails the same way until the host has
       // put the table right (HashTable::recover, or clear) -- the slots this batch claimed still
       // hold PENDING | position, which a later batch must not mistake for its own
-      for (size_t k = (size_t)threadIdx.x; k < P; k += kFinBlock) out[entry(k)] = kInvalidIndex;
-      if (threadIdx.x == 0) {
-        const uint32_t e = atomicOr(c.error, 4u) | 4u;
-        if (c.host_error != nullptr) *c.host_error = e;
-        if (b == 0) *c.new_count = 0;  // (nobody may initialise "the rows this batch created")
-      }
+      give_up();
       return;
     }
   }
@@ -540,14 +638,20 @@ __global__ void __launch_bounds__(kFinBlock)
   //         range ------------------------------------------------------------------------------------
   __shared__ uint32_t region_base[kFinRegions];
   {
-    uint32_t run = 0u;
-    for (uint32_t r0 = 0; r0 < R; r0 += kFinBlock) {
-      const uint32_t r = r0 + threadIdx.x;
-      const uint32_t v = r < R ? ld_agent(&region_cnt[r]) : 0u;
-      uint32_t tot;
-      const uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v, smem, &tot);
-      if (r < R) region_base[r] = run + ex;
-      run += tot;
+    // thread t: regions [4 t, 4 t + 4) -- four independent loads, one scan of the workgroup
+    static_assert(kFinRegions == 4 * kFinBlock, "one scan covers every region");
+    uint32_t v4[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t r = 4u * threadIdx.x + (uint32_t)q;
+      v4[q] = r < R ? ld_agent(&region_cnt[r]) : 0u;
+    }
+    uint32_t run;
+    uint32_t ex = block_exclusive_scan<uint32_t, kFinBlock>(v4[0] + v4[1] + v4[2] + v4[3], smem, &run);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      region_base[4u * threadIdx.x + (uint32_t)q] = ex;
+      ex += v4[q];
     }
     const uint32_t total = run;
     __syncthreads();
@@ -572,8 +676,7 @@ __global__ void __launch_bounds__(kFinBlock)
   }
   // ---- D: rows.  rank of a first position fp = firsts in the regions before its own + firsts of
   //         its own region in front of it (mask words, a few tens at most) -------------------------
-  auto resolve = [&](uint64_t i, uint64_t slot) {
-    const uint64_t v = tab[slot].val;
+  auto resolve = [&](uint64_t i, uint64_t slot, uint64_t v) {
     if (v < kPendingBit) {  // the key's first occurrence has already published the row
       out[i] = row_of(v);
       return;
@@ -583,14 +686,13 @@ __global__ void __launch_bounds__(kFinBlock)
     const size_t w0 = ((size_t)r * per) >> 6, wf = fp >> 6;
     uint32_t rank = region_base[r] +
                     (uint32_t)__popcll(ld_agent(&masks[wf]) & ((1ull << (fp & 63)) - 1ull));
-    for (size_t w = w0; w < wf; w += 4) {  // (independent loads, clamped: four in flight)
-      const unsigned long long m0 = ld_agent(&masks[w]);
-      const unsigned long long m1 = ld_agent(&masks[w + 1 < wf ? w + 1 : w]);
-      const unsigned long long m2 = ld_agent(&masks[w + 2 < wf ? w + 2 : w]);
-      const unsigned long long m3 = ld_agent(&masks[w + 3 < wf ? w + 3 : w]);
-      rank += (uint32_t)__popcll(m0) + (w + 1 < wf ? (uint32_t)__popcll(m1) : 0u) +
-              (w + 2 < wf ? (uint32_t)__popcll(m2) : 0u) +
-              (w + 3 < wf ? (uint32_t)__popcll(m3) : 0u);
+    for (size_t w = w0; w < wf; w += 8) {  // (independent loads, clamped: eight in flight --
+                                           //  a region of the Criteo-1TB batch in one trip)
+      unsigned long long m[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) m[q] = ld_agent(&masks[w + q < wf ? w + q : w]);
+#pragma unroll
+      for (int q = 0; q < 8; q++) rank += w + q < wf ? (uint32_t)__popcll(m[q]) : 0u;
     }
     uint64_t fin = c0 + rank;
     if (fin >= capacity) fin = kInvalidIndex;  // table full: the key gets no row
@@ -604,11 +706,12 @@ __global__ void __launch_bounds__(kFinBlock)
 #pragma unroll
   for (int j = 0; j < kKeep; j++) {
     const size_t k = (size_t)threadIdx.x + (size_t)j * kFinBlock;
-    if (k < P) resolve(keep_i[j], keep_slot[j]);
+    if (k < P) resolve((uint64_t)keep_i[j], keep_slot[j], keep_v[j]);
   }
   for (size_t k = (size_t)threadIdx.x + (size_t)kKeep * kFinBlock; k < P; k += kFinBlock) {
-    const uint64_t i = entry(k);
-    resolve(i, out[i] & ~kPendingBit);
+    const uint64_t i = (uint64_t)(entry(k) & ~kListDefer);
+    const uint64_t slot = out[i] & ~kPendingBit;
+    resolve(i, slot, tab[slot].val);
   }
 }
 
@@ -793,6 +896,8 @@ int HashTable::create(size_t cap, int kt) {
   d_barrier = reinterpret_cast<uint32_t*>(scal + 6);
   d_parity = reinterpret_cast<uint32_t*>(scal + 7);
   d_snap = reinterpret_cast<uint32_t*>(scal + 8);
+  d_defer = reinterpret_cast<uint32_t*>(scal + 10);
+  d_barrier_odd = reinterpret_cast<uint32_t*>(scal + 11);
   HCTR_HIP(hipMemset(scal, 0, 96));
   return clear(nullptr);
 }
@@ -820,8 +925,9 @@ int HashTable::clear(hipStream_t s) {
                      size, empty);
   HCTR_LAUNCH_CHECK();
   HCTR_HIP(hipMemsetAsync(d_counter, 0, 64, s));
+  HCTR_HIP(hipMemsetAsync(d_defer, 0, 16, s));  // (and the odd generations' arrival word behind it)
   if (fin_masks)
-    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4, s));
+    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * kFinRegions * 4, s));
   return HCTR_OK;
 }
 
@@ -837,8 +943,8 @@ int HashTable::reserve(size_t n) {
   HCTR_HIP(hipMalloc(&tile_sums, (need_tiles + 2 * kHtFinishBlocksMax) * sizeof(uint32_t)));
   HCTR_HIP(hipMalloc(&new_positions, (n > 0 ? n : 1) * sizeof(uint64_t)));
   mask_words = n / 64 + 2;
-  HCTR_HIP(hipMalloc(&fin_masks, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
-  HCTR_HIP(hipMemset(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4));
+  HCTR_HIP(hipMalloc(&fin_masks, mask_words * 2 * sizeof(unsigned long long) + 2 * kFinRegions * 4));
+  HCTR_HIP(hipMemset(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * kFinRegions * 4));
   region_cnt = reinterpret_cast<uint32_t*>(fin_masks + 2 * mask_words);
   HCTR_HIP(hipMemset(d_parity, 0, sizeof(uint32_t)));
   {  // list segments: every probe workgroup's share of n, rounded up to whole passes
@@ -876,7 +982,8 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   }
   IndexExtras none;
   const IndexExtras& x = ex ? *ex : none;
-  HCTR_REQUIRE(n < 0xFFFFFFFFull, "get_insert: more than 2^32 - 1 keys in one call");
+  // (bit 31 of a list entry is the "min deferred" flag)
+  HCTR_REQUIRE(n < 0x80000000ull, "get_insert: more than 2^31 - 1 keys in one call");
   const size_t work = n > x.n_offsets ? n : x.n_offsets;
   const int grid = grid_for(ceil_div<size_t>(work, kHtUnroll), kBlock, kProbeMaxBlocks);
   // every key a workgroup may leave pending has a place in its segment of the list
@@ -885,12 +992,12 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   if (key_type == HCTR_KEY_U32) {
     hipLaunchKernelGGL(ht_probe_insert_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, s, entries,
                        size, (const uint32_t*)keys, n, d_n, out, d_pending, pend_list, block_cnt,
-                       seg_cap, d_error, (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst,
+                       seg_cap, d_error, d_defer, d_new_count, (const uint32_t*)x.ro_src, (uint32_t*)x.ro_dst,
                        x.n_offsets, x.one_hot);
   } else {
     hipLaunchKernelGGL(ht_probe_insert_kernel<long long>, dim3(grid), dim3(kBlock), 0, s, entries,
                        size, (const long long*)keys, n, d_n, out, d_pending, pend_list, block_cnt,
-                       seg_cap, d_error, (const long long*)x.ro_src, (long long*)x.ro_dst,
+                       seg_cap, d_error, d_defer, d_new_count, (const long long*)x.ro_src, (long long*)x.ro_dst,
                        x.n_offsets, x.one_hot);
   }
   HCTR_LAUNCH_CHECK();
@@ -903,6 +1010,8 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   c.latched = d_latched;
   c.error = d_error;
   c.barrier = d_barrier;
+  c.defer = d_defer;
+  c.barrier_odd = d_barrier_odd;
   c.counter = d_counter;
   c.base = d_base;
   c.new_count = d_new_count;
@@ -962,6 +1071,9 @@ int HashTable::get_insert(const void* keys, size_t n, const uint64_t* d_n, uint6
   if (fg < 1) fg = 1;
   c.snap = d_snap;
   if (x.two_launches) {
+    hipLaunchKernelGGL(ht_finish_kernel<3>, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n,
+                       d_n, c, new_positions, sink, capacity);
+    HCTR_LAUNCH_CHECK();
     hipLaunchKernelGGL(ht_finish_kernel<1>, dim3((int)fg), dim3(kFinBlock), 0, s, entries, out, n,
                        d_n, c, new_positions, sink, capacity);
     HCTR_LAUNCH_CHECK();
@@ -1069,9 +1181,11 @@ int HashTable::recover(const void* keys, size_t n, hipStream_t s) {
   HCTR_HIP(hipMemsetAsync(d_pending, 0, sizeof(uint32_t), s));
   HCTR_HIP(hipMemsetAsync(d_latched, 0, sizeof(uint32_t), s));
   HCTR_HIP(hipMemsetAsync(d_barrier, 0, 2 * sizeof(uint32_t), s));
+  HCTR_HIP(hipMemsetAsync(d_barrier_odd, 0, sizeof(uint32_t), s));
   HCTR_HIP(hipMemsetAsync(d_parity, 0, sizeof(uint32_t), s));
+  HCTR_HIP(hipMemsetAsync(d_defer, 0, sizeof(uint32_t), s));
   if (fin_masks)
-    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * 2048 * 4, s));
+    HCTR_HIP(hipMemsetAsync(fin_masks, 0, mask_words * 2 * sizeof(unsigned long long) + 2 * kFinRegions * 4, s));
   return HCTR_OK;
 }
 

@@ -1497,10 +1497,18 @@ class Model:
         cfg = rt["parent"]
         span = getattr(rt["train"], "virt_span", None)
 
+        parts = {}  # E.unbind(1), taken once: ONE backward node (a stack) for all one-vector
+                    # lookups instead of a zero-fill + add of the whole output per lookup
+
         def piece(v0, reps, as_float=False):
             def resolve():
                 E = get_E()
-                x = E[:, v0, :] if reps == 1 else E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
+                if reps == 1:
+                    if "u" not in parts:
+                        parts["u"] = E.unbind(1)
+                    x = parts["u"][v0]
+                else:
+                    x = E[:, v0:v0 + reps, :].reshape(E.shape[0], -1)
                 return x.float() if as_float else x
             return _Pending(resolve)
         if rt["whole"]:
