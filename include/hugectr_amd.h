@@ -56,7 +56,9 @@ int hctr_hash_keys(const void* keys, int key_type, size_t n, uint32_t* out, hctr
  * (R/HugeCTR/include/hashtable/nv_hashtable.hpp:31-189, src/hashtable/nv_hashtable.cu:169-303).
  * Physical slot count = (size_t)(capacity / 0.75f); slot = murmur(key) % slots; linear probing;
  * new keys receive consecutive indices in order of FIRST OCCURRENCE in `keys` (deterministic,
- * where the reference's atomicAdd order is racy -- see DESIGN.md q1). */
+ * where the reference's atomicAdd order is racy -- see DESIGN.md section 4, q1).  One get_insert call
+ * takes at most 2^31 - 1 keys.  A key whose entry holds "no row" (SIZE_MAX, as hctr_ht_insert can
+ * write it and a dynamic table's remove() leaves it) is handed a row like an unseen key. */
 typedef struct hctr_hashtable hctr_hashtable;
 int hctr_ht_create(size_t capacity, int key_type, hctr_hashtable** out);
 int hctr_ht_destroy(hctr_hashtable* ht);
