@@ -209,42 +209,13 @@ template <int LPR, int NB, int JU, typename OffT, typename OutT>
 __global__ void __launch_bounds__(kBlock)
     pool_flat_kernel(size_t buckets, int combiner, const OffT* __restrict__ row_offset,
                      const uint64_t* __restrict__ value_index, const float* __restrict__ table,
-                     OutT* __restrict__ out, OutMap om, int xcds) {
+                     OutT* __restrict__ out, OutMap om) {
   constexpr int D = LPR * 4;
   constexpr int GPB = kBlock / LPR;
   const int g = threadIdx.x / LPR;
   const int l = threadIdx.x % LPR;
-  // Workgroups go round the XCDs in the order of their ids, and every XCD has its own L2: with a
-  // plain grid-stride loop each XCD walks a thin slice of EVERY table and fetches every hot row
-  // for itself (embedding_collection, MLPerf DCNv2 hotness: 3.09 GB crossed the fabric for 1.67 GB
-  // of distinct rows).  With xcds > 1 the buckets -- feature-major: a table's buckets lie side by
-  // side -- are cut into `xcds` consecutive ranges of EQUAL KEY COUNT (two binary searches of the
-  // offsets per workgroup), range x belongs to the workgroups with id % xcds == x, and a table's
-  // hot rows are fetched into one L2 (two at a cut).  Which workgroup pools a bucket changes; what
-  // it computes does not.
-  size_t u_lo = 0, u_hi = buckets, first = (size_t)blockIdx.x, nblk = (size_t)gridDim.x;
-  if (xcds > 1) {
-    const size_t x = blockIdx.x % (unsigned)xcds;
-    first = blockIdx.x / (unsigned)xcds;
-    nblk = gridDim.x / (unsigned)xcds;
-    const unsigned long long total = (unsigned long long)row_offset[buckets];
-    auto cut = [&](size_t part) -> size_t {  // first bucket (a multiple of NB) of part `part`
-      if (part == 0) return 0;
-      if (part >= (size_t)xcds) return buckets;
-      const unsigned long long k = total / (unsigned)xcds * part;
-      size_t lo = 0, hi = buckets;  // first u with row_offset[u] >= k
-      while (lo < hi) {
-        const size_t mid = (lo + hi) >> 1;
-        if ((unsigned long long)row_offset[mid] < k) lo = mid + 1;
-        else hi = mid;
-      }
-      return lo / NB * NB;
-    };
-    u_lo = cut(x);
-    u_hi = cut(x + 1);
-  }
-  const size_t stride = nblk * GPB * NB;
-  for (size_t u0 = u_lo + (first * GPB + g) * NB; u0 < u_hi; u0 += stride) {
+  const size_t stride = (size_t)gridDim.x * GPB * NB;
+  for (size_t u0 = ((size_t)blockIdx.x * GPB + g) * NB; u0 < buckets; u0 += stride) {
     const int nb = (int)((buckets - u0) < (size_t)NB ? (buckets - u0) : (size_t)NB);
     const long long kbeg = (long long)row_offset[u0];
     int e[NB];  // bucket ends relative to kbeg (group-uniform)
@@ -595,11 +566,9 @@ int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint6
   {                                                                                            \
     constexpr int GPB = kBlock / LPR_;                                                         \
     if (multi_hot) {                                                                           \
-      int grid = grid_for(ceil_div<size_t>(buckets, (size_t)8), GPB, 256 * 8);                \
-      const int xcds = (pool_xcds > 1 && grid >= pool_xcds) ? pool_xcds : 1;                   \
-      grid = grid / xcds * xcds;                                                               \
+      const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)8), GPB, 256 * 8);          \
       hipLaunchKernelGGL((pool_flat_kernel<LPR_, 8, 8, OffT, OutT>), dim3(grid), dim3(kBlock), \
-                         0, s, buckets, combiner, ro, vi, table, out, om, xcds);               \
+                         0, s, buckets, combiner, ro, vi, table, out, om);                     \
     } else {                                                                                   \
       const int grid = grid_for(ceil_div<size_t>(buckets, (size_t)BU_), GPB, 256 * 8);        \
       hipLaunchKernelGGL((pool_vec4_kernel<LPR_, BU_, OffT, OutT>), dim3(grid), dim3(kBlock), \
@@ -608,10 +577,6 @@ int launch_pool(size_t buckets, int D, int combiner, const OffT* ro, const uint6
   }
   const bool aligned = (reinterpret_cast<uintptr_t>(table) % 16 == 0) &&
                        (reinterpret_cast<uintptr_t>(out) % 16 == 0);
-  // (HCTR_POOL_XCDS: 8 = the XCDs of an MI355X; 1 = the plain grid-stride loop, for measurements)
-  const char* px_env = getenv("HCTR_POOL_XCDS");
-  const int pool_xcds = px_env ? atoi(px_env) : 8;
-  (void)pool_xcds;
   if (aligned && D % 4 == 0) {
     switch (D / 4) {
       case 1: HCTR_POOL_CASE(1, 4) break;
