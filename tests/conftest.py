@@ -65,6 +65,20 @@ def _seed_every_test(request):
     except Exception:
         pass
     yield
+    # ... and no test may leave its handles to be destroyed at a random point of a LATER test: what a
+    # test created (tables, hash indices, caches: their __del__ frees device memory and unmaps
+    # address ranges) goes when the test ends.  One `-m gpu -x` run in sixty died of a segmentation
+    # fault inside a dynamic table's destroy that the garbage collector had started from the call of
+    # the NEXT test (profiles/r6_det_destroy_segfault.txt; not reproduced in 44 looped runs).
+    import gc
+    gc.collect()
+    if "gpu" in request.node.keywords:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")
