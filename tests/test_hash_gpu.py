@@ -196,6 +196,27 @@ def test_unseen_and_erased_keys_repeated_many_times_inside_one_batch(n, distinct
             np.array(list(state.values()), dtype=np.uint64)).all()
 
 
+def test_get_insert_mostly_unseen_batches_at_the_bench_batch_size(oracle):
+    """A first epoch at the bench's batch size: 1.7 M keys per call, most of them unseen, a fifth
+    of the positions repeating a key of the same call -- from the second call on the probe kernel
+    takes its store form (the previous call inserted more than an eighth of a batch: claimers store,
+    later occurrences lower with an atomic min or defer it to the finish kernel, two grid barriers).
+    Rows must be the sequential oracle's, bit for bit, in every call."""
+    import torch
+    from hugectr_amd import _lib
+    rng = np.random.default_rng(int(os.environ.get("HCTR_TEST_SEED", "0")) + 5)
+    cap, n = 6_000_000, 1_703_936
+    ht_o = oracle.HashTable(cap, 8)
+    ht_g = GpuHT(cap, _lib.KEY_I64)
+    for batch in range(3):
+        keys = (rng.integers(0, 3_000_000, size=n).astype(np.int64) * 2_654_435_761) % (1 << 45)
+        got = ht_g.get_insert(_mk(torch, keys, torch.int64))
+        want = ht_o.get_insert(keys)
+        assert (got == want).all(), f"call {batch}: {int((got != want).sum())} rows differ"
+        assert ht_g.value_head() == ht_o.value_head()
+    assert ht_g.size() == ht_o.size()
+
+
 def test_overflow_is_flagged():
     """more distinct keys than max_vocabulary_size_per_gpu -> check_overflow raises
     (R/HugeCTR/include/embeddings/localized_slot_sparse_embedding_hash.hpp:552-569)"""
